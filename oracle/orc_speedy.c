@@ -1,0 +1,590 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY (see orc_speedy.h).
+ *
+ * CPU restatement of the reference's per-frame analysis:  reference speedy.c.
+ * Every function cites the reference lines it follows.  Floating-point promotion points are kept
+ * exactly as the reference's C expressions evaluate under FLT_EVAL_METHOD == 0 (x86-64 SSE2), with
+ * no fused multiply-add (build with -ffp-contract=off): the reference is built with plain
+ * `gcc -g` (reference Makefile:13).
+ *
+ * Two deliberate, documented departures (both far inside the 1e-4 float tolerance of north_star):
+ *   1. the FFT: the reference links FFTW3 (double) or kissfft (float) (speedy.c:39-43,438-473),
+ *      neither of which exists in this image.  The transform here is the repo's own "DFT spec"
+ *      (DESIGN.md): a W-point double-precision mixed-radix Stockham transform of the packed real
+ *      frame followed by the real-input untangle, magnitude = (float)sqrt(re*re + im*im).
+ *   2. log(): the reference calls libm's log (speedy.c:716).  orc_log below is a fixed operation
+ *      sequence (the classic fdlibm polynomial) so that the HIP kernel can reproduce it bit for bit;
+ *      it agrees with glibc's log to <= 1 ulp (tests/test_oracle_dft_log.py).
+ */
+#include "orc_speedy.h"
+
+#include <assert.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+#define kFrameRateHz 100.0 /* speedy.c:90 */
+#define kMinimumSpeed 0.01 /* speedy.c:92 */
+#define ORC_MAX_HYST (12 + 12 + 1)
+
+/* ------------------------------------------------------------------------------------------ */
+/* First-order filter, speedy.c:50-88                                                          */
+void orc_fof_design(orc_fof* f, float tc) {
+  f->state = 0.0;
+  if (tc > 0) {
+    f->alpha = exp(-1.0 / tc); /* speedy.c:67: double exp, rounded to float on store */
+  } else {
+    f->alpha = 0.0;
+  }
+}
+float orc_fof_iterate(orc_fof* f, float input) {
+  /* speedy.c:74 — all-float expression: (1-alpha) float, two float products, float sum */
+  f->state = (1 - f->alpha) * input + f->alpha * f->state;
+  return f->state;
+}
+void orc_fof_reset(orc_fof* f) { f->state = 0; }
+void orc_fof_set_state(orc_fof* f, float s) { f->state = s; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* log spec: fdlibm's e_log.c algorithm, fixed operation order, no FMA.                        */
+double orc_log(double x) {
+  static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                      two54 = 1.80143985094819840000e+16, Lg1 = 6.666666666666735130e-01,
+                      Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                      Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01,
+                      Lg6 = 1.531383769920937332e-01, Lg7 = 1.479819860511658591e-01;
+  double hfsq, f, s, z, R, w, t1, t2, dk;
+  int32_t k, hx, i, j;
+  uint32_t lx;
+  uint64_t bits;
+  memcpy(&bits, &x, 8);
+  hx = (int32_t)(bits >> 32);
+  lx = (uint32_t)bits;
+  k = 0;
+  if (hx < 0x00100000) { /* x < 2**-1022 */
+    if (((hx & 0x7fffffff) | lx) == 0) return -HUGE_VAL;
+    if (hx < 0) return NAN;
+    k -= 54;
+    x *= two54;
+    memcpy(&bits, &x, 8);
+    hx = (int32_t)(bits >> 32);
+  }
+  if (hx >= 0x7ff00000) return x + x;
+  k += (hx >> 20) - 1023;
+  hx &= 0x000fffff;
+  i = (hx + 0x95f64) & 0x100000;
+  memcpy(&bits, &x, 8);
+  bits = (bits & 0xffffffffull) | ((uint64_t)(uint32_t)(hx | (i ^ 0x3ff00000)) << 32);
+  memcpy(&x, &bits, 8);
+  k += (i >> 20);
+  f = x - 1.0;
+  if ((0x000fffff & (2 + hx)) < 3) { /* |f| < 2**-20 */
+    if (f == 0.0) {
+      if (k == 0) return 0.0;
+      dk = (double)k;
+      return dk * ln2_hi + dk * ln2_lo;
+    }
+    R = f * f * (0.5 - 0.33333333333333333 * f);
+    if (k == 0) return f - R;
+    dk = (double)k;
+    return dk * ln2_hi - ((R - dk * ln2_lo) - f);
+  }
+  s = f / (2.0 + f);
+  dk = (double)k;
+  z = s * s;
+  i = hx - 0x6147a;
+  w = z * z;
+  j = 0x6b851 - hx;
+  t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  i |= j;
+  R = t2 + t1;
+  if (i > 0) {
+    hfsq = 0.5 * f * f;
+    if (k == 0) return f - (hfsq - s * (hfsq + R));
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+  }
+  if (k == 0) return f - s * (f - R);
+  return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* DFT spec.  Stockham autosort, decimation in frequency, mixed radix.             */
+/* Radix order: all 4s, then a 2, then 3s, then 5s, then remaining primes ascending.           */
+#define ORC_MAX_STAGES 32
+typedef struct {
+  int n;
+  int nstages;
+  int radix[ORC_MAX_STAGES];
+  double* tw;   /* tw[2t], tw[2t+1] = cos(2 pi t/n), -sin(2 pi t/n) */
+  double* work; /* 2 * 2n doubles ping-pong */
+} orc_plan;
+
+static int orc_factor(int n, int* radix) {
+  int ns = 0;
+  while (n % 4 == 0) { radix[ns++] = 4; n /= 4; }
+  while (n % 2 == 0) { radix[ns++] = 2; n /= 2; }
+  while (n % 3 == 0) { radix[ns++] = 3; n /= 3; }
+  while (n % 5 == 0) { radix[ns++] = 5; n /= 5; }
+  for (int p = 7; n > 1; p += 2) {
+    while (n % p == 0) { radix[ns++] = p; n /= p; }
+  }
+  return ns;
+}
+
+static orc_plan* orc_plan_create(int n) {
+  orc_plan* p = (orc_plan*)calloc(1, sizeof(orc_plan));
+  p->n = n;
+  p->nstages = (n > 1) ? orc_factor(n, p->radix) : 0;
+  p->tw = (double*)malloc(sizeof(double) * 2 * n);
+  p->work = (double*)malloc(sizeof(double) * 4 * n);
+  for (int t = 0; t < n; t++) {
+    p->tw[2 * t] = cos(2.0 * M_PI * t / n);
+    p->tw[2 * t + 1] = -sin(2.0 * M_PI * t / n);
+  }
+  return p;
+}
+static void orc_plan_destroy(orc_plan* p) {
+  if (!p) return;
+  free(p->tw);
+  free(p->work);
+  free(p);
+}
+
+#define C5_1 0.30901699437494742
+#define C5_2 (-0.80901699437494742)
+#define S5_1 0.95105651629515357
+#define S5_2 0.58778525229247313
+#define S3_1 0.86602540378443865
+
+/* One radix-r butterfly: a[i] (re,im) for i<r -> b[j].  Fixed operation order. */
+static void orc_butterfly(const orc_plan* P, int r, const double* ar, const double* ai, double* br,
+                          double* bi) {
+  if (r == 2) {
+    br[0] = ar[0] + ar[1]; bi[0] = ai[0] + ai[1];
+    br[1] = ar[0] - ar[1]; bi[1] = ai[0] - ai[1];
+  } else if (r == 4) {
+    double t0r = ar[0] + ar[2], t0i = ai[0] + ai[2];
+    double t1r = ar[0] - ar[2], t1i = ai[0] - ai[2];
+    double t2r = ar[1] + ar[3], t2i = ai[1] + ai[3];
+    double t3r = ar[1] - ar[3], t3i = ai[1] - ai[3];
+    br[0] = t0r + t2r; bi[0] = t0i + t2i;
+    br[2] = t0r - t2r; bi[2] = t0i - t2i;
+    br[1] = t1r + t3i; bi[1] = t1i - t3r; /* t1 - i t3 */
+    br[3] = t1r - t3i; bi[3] = t1i + t3r; /* t1 + i t3 */
+  } else if (r == 3) {
+    double t1r = ar[1] + ar[2], t1i = ai[1] + ai[2];
+    double t2r = ar[0] - 0.5 * t1r, t2i = ai[0] - 0.5 * t1i;
+    double t3r = S3_1 * (ar[1] - ar[2]), t3i = S3_1 * (ai[1] - ai[2]);
+    br[0] = ar[0] + t1r; bi[0] = ai[0] + t1i;
+    br[1] = t2r + t3i; bi[1] = t2i - t3r;
+    br[2] = t2r - t3i; bi[2] = t2i + t3r;
+  } else if (r == 5) {
+    double t1r = ar[1] + ar[4], t1i = ai[1] + ai[4];
+    double t2r = ar[2] + ar[3], t2i = ai[2] + ai[3];
+    double t3r = ar[1] - ar[4], t3i = ai[1] - ai[4];
+    double t4r = ar[2] - ar[3], t4i = ai[2] - ai[3];
+    br[0] = (ar[0] + t1r) + t2r; bi[0] = (ai[0] + t1i) + t2i;
+    double m1r = (ar[0] + C5_1 * t1r) + C5_2 * t2r, m1i = (ai[0] + C5_1 * t1i) + C5_2 * t2i;
+    double m2r = (ar[0] + C5_2 * t1r) + C5_1 * t2r, m2i = (ai[0] + C5_2 * t1i) + C5_1 * t2i;
+    double n1r = S5_1 * t3r + S5_2 * t4r, n1i = S5_1 * t3i + S5_2 * t4i;
+    double n2r = S5_2 * t3r - S5_1 * t4r, n2i = S5_2 * t3i - S5_1 * t4i;
+    br[1] = m1r + n1i; bi[1] = m1i - n1r; /* m1 - i n1 */
+    br[4] = m1r - n1i; bi[4] = m1i + n1r;
+    br[2] = m2r + n2i; bi[2] = m2i - n2r;
+    br[3] = m2r - n2i; bi[3] = m2i + n2r;
+  } else {
+    /* generic prime radix: b[j] = a[0] + sum_{i>=1} a[i] * w_r^{(i j) mod r}, i ascending */
+    int step = P->n / r;
+    for (int j = 0; j < r; j++) {
+      double accr = ar[0], acci = ai[0];
+      for (int i = 1; i < r; i++) {
+        int t = ((i * j) % r) * step;
+        double wr = P->tw[2 * t], wi = P->tw[2 * t + 1];
+        accr = accr + (ar[i] * wr - ai[i] * wi);
+        acci = acci + (ar[i] * wi + ai[i] * wr);
+      }
+      br[j] = accr; bi[j] = acci;
+    }
+  }
+}
+
+static void orc_plan_execute(orc_plan* P, const double* in, double* out) {
+  int n = P->n;
+  if (n == 1) { out[0] = in[0]; out[1] = in[1]; return; }
+  double* x = P->work;
+  double* y = P->work + 2 * n;
+  memcpy(x, in, sizeof(double) * 2 * n);
+  int s = 1;   /* product of the radices of the stages already done */
+  int cur = n; /* length of the sub-transforms still to do */
+  double* ar = (double*)malloc(sizeof(double) * 4 * n);
+  double* ai = ar + n; double* br = ai + n; double* bi = br + n;
+  for (int st = 0; st < P->nstages; st++) {
+    int r = P->radix[st];
+    int m = cur / r;
+    for (int p = 0; p < m; p++) {
+      for (int q = 0; q < s; q++) {
+        for (int i = 0; i < r; i++) {
+          int idx = q + s * (p + i * m);
+          ar[i] = x[2 * idx]; ai[i] = x[2 * idx + 1];
+        }
+        orc_butterfly(P, r, ar, ai, br, bi);
+        for (int j = 0; j < r; j++) {
+          int t = (int)(((long)s * p * j) % n);
+          double wr = P->tw[2 * t], wi = P->tw[2 * t + 1];
+          int o = q + s * (r * p + j);
+          y[2 * o] = br[j] * wr - bi[j] * wi;
+          y[2 * o + 1] = br[j] * wi + bi[j] * wr;
+        }
+      }
+    }
+    double* tmp = x; x = y; y = tmp;
+    s *= r;
+    cur = m;
+  }
+  free(ar);
+  memcpy(out, x, sizeof(double) * 2 * n);
+}
+
+void orc_dft_forward(int n, const double* in, double* out) {
+  orc_plan* P = orc_plan_create(n);
+  orc_plan_execute(P, in, out);
+  orc_plan_destroy(P);
+}
+
+void orc_dft_naive(int n, const double* in, double* out) {
+  for (int k = 0; k < n; k++) {
+    long double sr = 0, si = 0;
+    for (int t = 0; t < n; t++) {
+      long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)(((long)k * t) % n) / n;
+      long double c = cosl(ang), s = sinl(ang);
+      sr += in[2 * t] * c - in[2 * t + 1] * s;
+      si += in[2 * t] * s + in[2 * t + 1] * c;
+    }
+    out[2 * k] = (double)sr; out[2 * k + 1] = (double)si;
+  }
+}
+
+/* Spectrum of a real, zero-padded frame: x[W] floats -> |X[k]|, k < 2W (DESIGN.md "DFT spec"). */
+typedef struct {
+  int W;
+  orc_plan* plan;  /* W-point */
+  double* tw2;     /* e^{-2 pi i k / (2W)}, k < W */
+  double* z;       /* 2W doubles */
+  double* Z;       /* 2W doubles */
+} orc_specplan;
+
+static orc_specplan* orc_specplan_create(int W) {
+  orc_specplan* sp = (orc_specplan*)calloc(1, sizeof(orc_specplan));
+  sp->W = W;
+  sp->plan = orc_plan_create(W);
+  sp->tw2 = (double*)malloc(sizeof(double) * 2 * W);
+  sp->z = (double*)malloc(sizeof(double) * 2 * W);
+  sp->Z = (double*)malloc(sizeof(double) * 2 * W);
+  for (int k = 0; k < W; k++) {
+    sp->tw2[2 * k] = cos(2.0 * M_PI * k / (2.0 * W));
+    sp->tw2[2 * k + 1] = -sin(2.0 * M_PI * k / (2.0 * W));
+  }
+  return sp;
+}
+static void orc_specplan_destroy(orc_specplan* sp) {
+  if (!sp) return;
+  orc_plan_destroy(sp->plan);
+  free(sp->tw2); free(sp->z); free(sp->Z); free(sp);
+}
+static void orc_specplan_run(orc_specplan* sp, const float* x, float* mags) {
+  int W = sp->W, N = 2 * W;
+  for (int n = 0; n < W; n++) {
+    sp->z[2 * n] = (2 * n < W) ? (double)x[2 * n] : 0.0;
+    sp->z[2 * n + 1] = (2 * n + 1 < W) ? (double)x[2 * n + 1] : 0.0;
+  }
+  orc_plan_execute(sp->plan, sp->z, sp->Z);
+  const double* Z = sp->Z;
+  for (int k = 0; k < W; k++) {
+    int k2 = (W - k) % W;
+    double a_r = Z[2 * k], a_i = Z[2 * k + 1];
+    double b_r = Z[2 * k2], b_i = -Z[2 * k2 + 1];
+    double er = 0.5 * (a_r + b_r), ei = 0.5 * (a_i + b_i);
+    double dr = a_r - b_r, di = a_i - b_i;
+    double o_r = 0.5 * di, o_i = -0.5 * dr;
+    double c = sp->tw2[2 * k], s = sp->tw2[2 * k + 1];
+    double xr = er + (c * o_r - s * o_i);
+    double xi = ei + (c * o_i + s * o_r);
+    mags[k] = (float)sqrt(xr * xr + xi * xi);
+  }
+  mags[W] = (float)fabs(Z[0] - Z[1]);
+  for (int k = W + 1; k < N; k++) mags[k] = mags[N - k];
+}
+void orc_spectrum_magnitudes(int W, const float* x, float* mags) {
+  orc_specplan* sp = orc_specplan_create(W);
+  orc_specplan_run(sp, x, mags);
+  orc_specplan_destroy(sp);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* speedyStreamStruct, speedy.c:130-176                                                        */
+struct orc_speedy {
+  int sample_rate, window_size, fft_size;
+  int future, past;        /* speedy.h:136-146 made run-time */
+  int hyst_size;           /* speedy.c:95: 2*(F+P+1) */
+  int spec_hist;           /* speedy.c:97: F+P+1 */
+  float* window;
+  float* input;
+  int64_t current_time;
+  float* spectrogram;
+  float** spectrogram_history;
+  float* normalized_spectrogram;
+  float* normalized_last_spectrogram;
+  orc_specplan* plan;
+  float* windowed;
+  float* hysteresis_buffer;
+  float preemph_state;
+  float mean_spectrogram_energy, mean_emphasis_weighted_local_difference;
+  float mean_emphasis_weighted_lpf, mean_relative_spectral_difference, max_energy_hysteresis;
+  int skip_frame_count;
+  orc_fof energy_filter, difference_filter;
+  float current_duration, desired_duration;
+  float features[ORC_FEATURE_COUNT];
+};
+/* feature slots, speedy.c:106-123 */
+#define s_energy_lp (s->features[1])
+#define s_energy_local (s->features[2])
+#define s_energy_compressed (s->features[3])
+#define s_time_energy (s->features[12])
+#define s_energy_hysteresis (s->features[4])
+#define s_spectrogram_energy (s->features[0])
+#define s_low_energy_threshold (s->features[14])
+#define s_low_energy_frame (s->features[5])
+#define s_local_spectral_difference (s->features[6])
+#define s_emphasis_weighted_local_difference (s->features[7])
+#define s_emphasis_weighted_lpf (s->features[8])
+#define s_relative_spectral_difference (s->features[9])
+#define s_speech_changes (s->features[10])
+#define s_time_spectral (s->features[13])
+#define s_audio_tension (s->features[11])
+
+static int orc_modulo(int64_t x, int N) { return (int)((x % N + N) % N); } /* speedy.c:198-200 */
+
+orc_speedyStream orc_speedyCreateStream(int sample_rate, int match_matlab) { /* speedy.c:206-299 */
+  orc_speedyStream s = (orc_speedyStream)calloc(1, sizeof(struct orc_speedy));
+  if (!s) return NULL;
+  s->future = match_matlab ? 8 : 12;
+  s->past = match_matlab ? 12 : 8;
+  s->hyst_size = 2 * (s->future + s->past + 1);
+  s->spec_hist = s->future + s->past + 1;
+  s->window_size = (int)(1.5 * sample_rate / (float)kFrameRateHz); /* speedy.c:213 */
+  s->fft_size = 2 * s->window_size;
+  s->sample_rate = sample_rate;
+  s->input = (float*)malloc(sizeof(float) * s->window_size);
+  s->windowed = (float*)malloc(sizeof(float) * s->window_size);
+  s->hysteresis_buffer = (float*)calloc(s->hyst_size, sizeof(float));
+  s->normalized_spectrogram = (float*)calloc(s->fft_size, sizeof(float));
+  s->normalized_last_spectrogram = (float*)calloc(s->fft_size, sizeof(float));
+  s->spectrogram = (float*)calloc(s->fft_size, sizeof(float));
+  s->window = (float*)malloc(sizeof(float) * s->window_size);
+  s->spectrogram_history = (float**)calloc(s->spec_hist, sizeof(float*));
+  for (int i = 0; i < s->spec_hist; i++)
+    s->spectrogram_history[i] = (float*)calloc(s->fft_size, sizeof(float));
+  for (int i = 0; i < s->window_size; i++) /* speedy.c:256-258: double expression -> float */
+    s->window[i] = 0.54 - 0.46 * cos(2 * M_PI * i / (s->window_size - 1.0));
+  s->mean_spectrogram_energy = 2.14204; /* speedy.c:263-267 */
+  s->mean_emphasis_weighted_local_difference = 123.837;
+  s->mean_emphasis_weighted_lpf = 123.979;
+  s->mean_relative_spectral_difference = 0.971975;
+  s->max_energy_hysteresis = 1.41421;
+  s->plan = orc_specplan_create(s->window_size);
+  orc_fof_design(&s->energy_filter, kFrameRateHz); /* speedy.c:287-292 */
+  orc_fof_set_state(&s->energy_filter, s->mean_spectrogram_energy);
+  orc_fof_design(&s->difference_filter, kFrameRateHz);
+  orc_fof_set_state(&s->difference_filter, s->mean_emphasis_weighted_local_difference);
+  s->skip_frame_count = 1; /* speedy.c:293 */
+  return s;
+}
+
+void orc_speedyDestroyStream(orc_speedyStream s) {
+  if (!s) return;
+  free(s->input); free(s->windowed); free(s->hysteresis_buffer);
+  free(s->normalized_spectrogram); free(s->normalized_last_spectrogram);
+  free(s->spectrogram); free(s->window);
+  for (int i = 0; i < s->spec_hist; i++) free(s->spectrogram_history[i]);
+  free(s->spectrogram_history);
+  orc_specplan_destroy(s->plan);
+  free(s);
+}
+
+int orc_speedyInputFrameSize(orc_speedyStream s) { return s->window_size; }
+int orc_speedyInputFrameStep(orc_speedyStream s) { return s->sample_rate / kFrameRateHz; } /* :335-338 */
+int orc_speedyFFTSize(orc_speedyStream s) { return s->fft_size; }
+int orc_speedyHysteresisFuture(orc_speedyStream s) { return s->future; }
+int orc_speedyHysteresisPast(orc_speedyStream s) { return s->past; }
+float orc_speedyBinToFreq(orc_speedyStream s, int bin) { /* speedy.c:345-348 */
+  return bin * (s->sample_rate / (float)s->fft_size);
+}
+int orc_speedyFreqToBin(orc_speedyStream s, float freq) { /* speedy.c:350-353 */
+  return round(freq * s->fft_size / s->sample_rate);
+}
+float* orc_speedyGetSpectrogram(orc_speedyStream s) { return s->spectrogram; }
+float* orc_speedyGetNormalizedSpectrogram(orc_speedyStream s) { return s->normalized_spectrogram; }
+float* orc_speedyGetInternalState(orc_speedyStream s) { return s->features; }
+float orc_speedyGetEnergyCompressed(orc_speedyStream s) { return s_energy_compressed; }
+float orc_speedyGetSpeechChanges(orc_speedyStream s) { return s_speech_changes; }
+int64_t orc_speedyGetCurrentTime(orc_speedyStream s) { return s->current_time; }
+
+void orc_speedyPreemphasisFilter(orc_speedyStream s, float* input, int length) { /* speedy.c:416-425 */
+  for (int i = 0; i < length; i++) {
+    float last_sample = input[i];
+    input[i] = 1.0 * input[i] - 0.97 * s->preemph_state; /* double expression, float store */
+    s->preemph_state = last_sample;
+  }
+}
+
+float* orc_speedySpectrogram(orc_speedyStream s, float* input) { /* speedy.c:438-473 */
+  for (int i = 0; i < s->window_size; i++) s->windowed[i] = input[i] * s->window[i]; /* float product */
+  orc_specplan_run(s->plan, s->windowed, s->spectrogram);
+  return s->spectrogram;
+}
+
+void orc_speedySaveSpectrogramData(orc_speedyStream s, float* spectrogram, int64_t at_time) { /* :476-483 */
+  memcpy(s->spectrogram_history[orc_modulo(at_time, s->spec_hist)], spectrogram,
+         sizeof(float) * s->fft_size);
+}
+float* orc_speedyGetSpectrogramAtTime(orc_speedyStream s, int64_t at_time) { /* :485-487 */
+  return s->spectrogram_history[orc_modulo(at_time, s->spec_hist)];
+}
+
+void orc_speedyAddToHysteresisBuffer(orc_speedyStream s, float value, int64_t at_time) { /* :615-619 */
+  s->hysteresis_buffer[orc_modulo(at_time, s->hyst_size)] = value;
+}
+
+void orc_speedyComputeLocalEnergy(orc_speedyStream s, float* spectrogram, int64_t at_time) { /* :510-523 */
+  (void)spectrogram; /* the reference reads stream->spectrogram, not the argument (speedy.c:515) */
+  float my_spectrogram_energy = 0.0;
+  for (int i = 1; i < s->fft_size / 2; i++)
+    my_spectrogram_energy += s->spectrogram[i] * s->spectrogram[i];
+  s_energy_lp = orc_fof_iterate(&s->energy_filter, my_spectrogram_energy);
+  s_energy_local = my_spectrogram_energy / s_energy_lp;
+  s_energy_compressed = sqrt(s_energy_local > 2 ? 2.0 : s_energy_local); /* double sqrt -> float */
+  orc_speedyAddToHysteresisBuffer(s, s_energy_compressed, at_time);
+  s_time_energy = at_time;
+}
+
+void orc_speedyAddData(orc_speedyStream s, const float* input, int64_t at_time) { /* :540-551 */
+  for (int i = 0; i < s->window_size; i++) s->input[i] = input[i];
+  orc_speedyPreemphasisFilter(s, s->input, s->window_size);
+  float* spectrogram = orc_speedySpectrogram(s, s->input);
+  orc_speedySaveSpectrogramData(s, spectrogram, at_time);
+  orc_speedyComputeLocalEnergy(s, spectrogram, at_time);
+  s->current_time = at_time;
+}
+void orc_speedyAddDataShort(orc_speedyStream s, const int16_t* input, int64_t at_time) { /* :553-565 */
+  for (int i = 0; i < s->window_size; i++) s->input[i] = input[i] / 32768.0;
+  orc_speedyPreemphasisFilter(s, s->input, s->window_size);
+  float* spectrogram = orc_speedySpectrogram(s, s->input);
+  orc_speedySaveSpectrogramData(s, spectrogram, at_time);
+  orc_speedyComputeLocalEnergy(s, spectrogram, at_time);
+  s->current_time = at_time;
+}
+
+float orc_speedyEvaluateHysteresis(orc_speedyStream s, int64_t at_time) { /* speedy.c:590-610 */
+  float past_max = 0.0, future_max = 0.0;
+  const int F = s->future, P = s->past;
+  for (int i = 0; i <= F; i++) {
+    float value = s->hysteresis_buffer[orc_modulo(at_time + i, s->hyst_size)];
+    value *= (F - i) / (float)F;
+    if (value > future_max) future_max = value;
+  }
+  for (int i = 0; i <= P; i++) {
+    float value = s->hysteresis_buffer[orc_modulo(at_time - i, s->hyst_size)];
+    value *= (P - i) / (float)P;
+    if (value > past_max) past_max = value;
+  }
+  return (past_max + future_max) / 2.0;
+}
+
+float orc_speedyNormalizeByEnergy(const float* spectrogram, float* normalized, int length) { /* :628-647 */
+  float signal_energy = 0.0;
+  float max_value = 0;
+  for (int i = 1; i < length; i++) {
+    signal_energy += spectrogram[i] * spectrogram[i];
+    if (spectrogram[i] > max_value) max_value = spectrogram[i];
+  }
+  const float eps = 2.2204e-16;
+  float inverse_norm = 1.0 / (sqrt(signal_energy) + eps);
+  for (int i = 0; i < length; i++) normalized[i] = spectrogram[i] * inverse_norm;
+  return signal_energy;
+}
+
+void orc_speedyComputeSpectralDifference(orc_speedyStream s, const float* spectrogram,
+                                         const float* last_spectrogram, int64_t at_time) { /* :664-729 */
+  s_energy_hysteresis = orc_speedyEvaluateHysteresis(s, at_time);
+  s_spectrogram_energy = orc_speedyNormalizeByEnergy(spectrogram, s->normalized_spectrogram, s->fft_size / 2);
+  orc_speedyNormalizeByEnergy(last_spectrogram, s->normalized_last_spectrogram, s->fft_size / 2);
+  s_low_energy_threshold = 0.04 * s->max_energy_hysteresis;
+  s_low_energy_frame = s_spectrogram_energy <= s_low_energy_threshold;
+  s_time_spectral = at_time;
+  if (s_low_energy_frame) s->skip_frame_count = 1;
+  if (s->skip_frame_count-- > 0) {
+    s_low_energy_frame = 1;
+    s_local_spectral_difference = 0;
+    s_emphasis_weighted_local_difference = 0;
+    s_relative_spectral_difference = 0;
+    s_speech_changes = 0;
+    s_emphasis_weighted_lpf = orc_fof_iterate(&s->difference_filter, 0.0);
+    return;
+  } else {
+    s->skip_frame_count = 0;
+  }
+  float bin_threshold = 0;
+  for (int i = 1; i < s->fft_size / 2; i++) bin_threshold = fmax(bin_threshold, spectrogram[i]);
+  bin_threshold /= 100.0; /* double division, float store */
+
+  s_local_spectral_difference = 0.0;
+  const float eps = 2.2204e-16;
+  for (int i = 1; i < s->fft_size / 2; i++) {
+    if (spectrogram[i] > bin_threshold && last_spectrogram[i] > bin_threshold) {
+      /* float sum, float sum, float quotient; log and fabs in double; float accumulator */
+      s_local_spectral_difference +=
+          fabs(orc_log((s->normalized_spectrogram[i] + eps) / (s->normalized_last_spectrogram[i] + eps)));
+    }
+  }
+  s_emphasis_weighted_local_difference = s_local_spectral_difference * s_energy_hysteresis;
+  s_emphasis_weighted_lpf = orc_fof_iterate(&s->difference_filter, s_emphasis_weighted_local_difference);
+  s_relative_spectral_difference =
+      s_emphasis_weighted_local_difference / (s_emphasis_weighted_lpf + 0.01 * s->mean_emphasis_weighted_lpf);
+  s_speech_changes = fmin(s_relative_spectral_difference, 4 * s->mean_relative_spectral_difference);
+}
+
+int orc_speedyComputeTension(orc_speedyStream s, int64_t at_time, float* tension) { /* speedy.c:752-766 */
+  float a = 1 / 2.0, b = 1 / 4.0, M_E_ = 0.7, M_S = 1.0;
+  if (at_time + s->future <= s->current_time) {
+    float* current_spectrogram = orc_speedyGetSpectrogramAtTime(s, at_time);
+    float* previous_spectrogram = orc_speedyGetSpectrogramAtTime(s, at_time - 1);
+    s_energy_hysteresis = orc_speedyEvaluateHysteresis(s, at_time);
+    orc_speedyComputeSpectralDifference(s, current_spectrogram, previous_spectrogram, at_time);
+    s_audio_tension = a * (s_energy_hysteresis - M_E_) + b * (s_speech_changes - M_S);
+    *tension = s_audio_tension;
+    return 1;
+  }
+  return 0;
+}
+
+float orc_speedyComputeSpeedFromTension(float tension, float R_g, float duration_feedback_strength,
+                                        orc_speedyStream s) { /* speedy.c:768-788 */
+  float requested_speed;
+  if (R_g > 1.0) {
+    requested_speed = fmax(1, R_g + (1 - R_g) * tension);
+  } else {
+    requested_speed = fmax(kMinimumSpeed, fmin(1, R_g - (1 - R_g) * tension));
+  }
+  if (duration_feedback_strength > 0) {
+    float excess_duration = s->current_duration - s->desired_duration;
+    requested_speed += fmax(kMinimumSpeed, duration_feedback_strength * excess_duration);
+  }
+  float frame_duration = 1.0 / kFrameRateHz;
+  s->current_duration += frame_duration / requested_speed;
+  s->desired_duration += frame_duration / R_g;
+  return requested_speed;
+}

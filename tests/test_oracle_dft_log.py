@@ -1,0 +1,58 @@
+"""The oracle's own building blocks: the mixed-radix DFT against the O(n^2) definition (the role of the
+reference's kiss_fft_test.cc:50-85) and orc_log against libm."""
+import math
+
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8, 11, 15, 16, 120, 165, 240, 330, 360, 480, 661, 720])
+def test_dft_matches_definition(orc, n):
+    L = orc.lib()
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(2 * n)
+    a = np.zeros(2 * n)
+    b = np.zeros(2 * n)
+    L.orc_dft_forward(n, orc.dptr(x), orc.dptr(a))
+    L.orc_dft_naive(n, orc.dptr(x), orc.dptr(b))
+    scale = np.abs(b).max() + 1.0
+    assert np.abs(a - b).max() / scale < 2e-14 * max(1, math.log2(n + 1))
+
+
+def test_kiss_fft_cosine_8pt(orc):
+    """kiss_fft_test.cc:50-85: 8-point cosine -> bins 1 and 7 hold N/2, the rest 0."""
+    L = orc.lib()
+    n = 8
+    x = np.zeros(2 * n)
+    x[0::2] = np.cos(2 * np.pi * np.arange(n) / n)
+    y = np.zeros(2 * n)
+    L.orc_dft_forward(n, orc.dptr(x), orc.dptr(y))
+    mag = np.hypot(y[0::2], y[1::2])
+    assert abs(mag[1] - 4) < 1e-12 and abs(mag[7] - 4) < 1e-12
+    assert np.abs(np.delete(mag, [1, 7])).max() < 1e-12
+
+
+@pytest.mark.parametrize("W", [120, 165, 240, 330, 360, 661])
+def test_packed_real_spectrum(orc, W):
+    """|DFT_2W| of the zero-padded real frame via the packed W-point transform == numpy's rfft (double)."""
+    L = orc.lib()
+    rng = np.random.default_rng(W)
+    x = rng.standard_normal(W).astype(np.float32)
+    mags = np.zeros(2 * W, np.float32)
+    L.orc_spectrum_magnitudes(W, orc.fptr(x), orc.fptr(mags))
+    ref = np.abs(np.fft.fft(np.concatenate([x.astype(np.float64), np.zeros(W)])))
+    assert np.abs(mags - ref).max() <= 2e-7 * ref.max() + 1e-7
+    assert np.array_equal(mags[W + 1:], mags[1:W][::-1])
+
+
+def test_log_within_one_ulp_of_libm(orc):
+    L = orc.lib()
+    rng = np.random.default_rng(7)
+    xs = np.concatenate([np.exp(rng.uniform(-40, 40, 20000)), 1 + rng.uniform(-1e-6, 1e-6, 2000),
+                         rng.uniform(0.5, 2.0, 20000), [1.0, 2.0, 0.5, 1e-300, 1e300]])
+    worst = 0.0
+    for v in xs:
+        a, b = L.orc_log(float(v)), math.log(float(v))
+        ulp = math.ulp(b) if b != 0 else 5e-324
+        worst = max(worst, abs(a - b) / ulp)
+    assert worst <= 1.0, worst
