@@ -1,0 +1,112 @@
+/* speedy_hip.h — the thin C-ABI between host code and the hand-written HIP (gfx950) kernels of the
+ * Speedy hot path:   analysis -> tension -> speed -> pitch-synchronous overlap-add.
+ *
+ * Plain C: pointers and sizes only, no HIP/torch types.  `hip_stream` arguments are a hipStream_t cast
+ * to void* (NULL = the default stream).  Every pointer marked DEVICE must be HBM-resident on the
+ * current device; HOST pointers are ordinary host memory.
+ *
+ * What each entry point replaces in the reference (google/speedy):
+ *   spx_plan_create        speedyCreateStream's tables (speedy.c:206-299: window :256-258, FFT plan
+ *                          :269-277, filter alphas :287-292) + libsonic's period limits
+ *   spx_batch_analyze      speedyAddDataShort ... speedyComputeLocalEnergy for every frame of every
+ *                          stream (speedy.c:553-565,416-425,438-473,510-523), the mono mix of
+ *                          sonicSendDataToSpeedy (soniclib.c:262-287) and the per-frame part of
+ *                          speedyComputeSpectralDifference (speedy.c:628-647,705-719)
+ *   spx_batch_walk         the frame-sequential rest: filters, hysteresis, tension, speed
+ *                          (speedy.c:73-76,590-610,682-728,752-788; soniclib.c:339-345) and the TSM stage the
+ *                          reference reaches through sonicIntSetSpeed / sonicIntWriteShortToStream /
+ *                          sonicIntFlushStream (soniclib.c:354,369,538-551)
+ *   spx_batch_run          = analyze + walk: one whole sonicWriteShortToStream ... sonicFlushStream
+ *                          life cycle (speedy_wave.cc:154-242) for N independent streams at once
+ * The reference-compatible streaming API on top of this is include/sonic2.h.
+ */
+#ifndef SPEEDY_HIP_H_
+#define SPEEDY_HIP_H_
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef SPX_FEATURE_COUNT
+#define SPX_FEATURE_COUNT 15 /* speedy.h:115 */
+#endif
+
+typedef struct spx_plan* spx_plan_t;
+
+/* Per-stream job description (HOST array).  Offsets are in int16 elements from the batch base pointers. */
+typedef struct {
+  int64_t in_off;   /* first input sample of this stream, in shorts, inside `in`                      */
+  int64_t n_in;     /* input length in multi-channel sample frames (sonic2.h:56-59 units)             */
+  int64_t out_off;  /* first output sample, in shorts, inside `out`                                   */
+  int64_t out_cap;  /* output capacity in multi-channel sample frames                                 */
+  int32_t channels; /* interleaved channel count                                                      */
+  float speed;      /* sonicSetSpeed                (soniclib.c:177)                                  */
+  float nonlinear;  /* sonicEnableNonlinearSpeedup  (soniclib.c:555); 0 = linear: TSM stage only      */
+  float feedback;   /* sonicSetDurationFeedbackStrength (soniclib.c:565)                              */
+} spx_stream_job;
+
+/* Optional debug taps (DEVICE, any may be NULL): the reference's five callbacks (sonic2.h:104-125).
+ * Row r of stream s lives at index tap_off[s] + r, with tap_off[s] = sum over earlier streams of their
+ * analysis-frame counts (spx_plan_frames).  Taps are excluded from the roofline byte count. */
+typedef struct {
+  float* tension;     /* [frames]        tension of read-buffer k  (soniclib.c:320-324)                */
+  float* speed;       /* [frames]        speed handed to the TSM stage (soniclib.c:349-354)            */
+  float* features;    /* [frames][15]    speedyGetInternalState at tension time (soniclib.c:325-329)   */
+  float* spectrogram; /* [frames][N]     |DFT| of analysis frame j (soniclib.c:297-302)                */
+  float* normalized;  /* [frames][N/2]   normalised spectrum used for tension k (speedy.c:673-675)     */
+} spx_taps;
+
+/* ---- errors: 0 = ok; otherwise a negative code, text via spx_last_error() (thread-local) ---- */
+const char* spx_last_error(void);
+int spx_abi_version(void);
+
+/* ---- plan: tables for one (sample rate, hysteresis mode) pair ---- */
+spx_plan_t spx_plan_create(int sample_rate, int match_matlab);
+void spx_plan_destroy(spx_plan_t plan);
+int spx_plan_frame_step(spx_plan_t plan);   /* speedyInputFrameStep, speedy.c:335-338 */
+int spx_plan_window_size(spx_plan_t plan);  /* speedyInputFrameSize, speedy.c:330-333 */
+int spx_plan_fft_size(spx_plan_t plan);     /* speedyFFTSize,        speedy.c:340-343 */
+int spx_plan_future(spx_plan_t plan);       /* kTemporalHysteresisFuture, speedy.h:136-146 */
+int spx_plan_max_required(spx_plan_t plan); /* libsonic maxRequired = 2*(rate/65) */
+/* Number of analysis frames the shim schedules for n_in input frames (soniclib.c:440-444). */
+int64_t spx_plan_frames(spx_plan_t plan, int64_t n_in);
+/* Safe output capacity (frames) for n_in input frames at `speed`. */
+int64_t spx_plan_out_capacity(spx_plan_t plan, int64_t n_in, float speed);
+
+/* ---- batch execution ---- */
+/* Bytes of DEVICE scratch needed for a batch (depends only on the jobs' lengths). */
+size_t spx_batch_workspace_bytes(spx_plan_t plan, const spx_stream_job* jobs, int n_streams);
+
+/* Whole life cycle for n_streams independent streams, asynchronous on hip_stream:
+ *   in   DEVICE  int16 input samples (read once)
+ *   out  DEVICE  int16 output samples (written once)
+ *   n_out DEVICE int64[n_streams]: produced frames per stream (negative = out_cap overflow)
+ * Returns 0 when the launches were enqueued. */
+int spx_batch_run(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, const int16_t* in,
+                  int16_t* out, int64_t* n_out, void* workspace, size_t workspace_bytes,
+                  const spx_taps* taps, void* hip_stream);
+
+/* The two stages separately (same arguments); spx_batch_run = analyze then walk. */
+int spx_batch_analyze(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, const int16_t* in,
+                      void* workspace, size_t workspace_bytes, const spx_taps* taps, void* hip_stream);
+int spx_batch_walk(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, const int16_t* in,
+                   int16_t* out, int64_t* n_out, void* workspace, size_t workspace_bytes,
+                   const spx_taps* taps, void* hip_stream);
+
+/* Timing hooks for bench.py: HIP events recorded on hip_stream around each kernel of the LAST
+ * spx_batch_run/analyze/walk call with timing enabled.  ms_* receive milliseconds (after a stream sync). */
+void spx_set_timing(int enabled);
+int spx_last_kernel_ms(float* ms_analyze, float* ms_walk);
+
+/* ---- plain device-memory helpers (so that C/C++ hosts need no HIP headers) ---- */
+void* spx_device_alloc(size_t bytes);
+void spx_device_free(void* p);
+int spx_copy_to_device(void* dst, const void* src, size_t bytes, void* hip_stream);
+int spx_copy_to_host(void* dst, const void* src, size_t bytes, void* hip_stream);
+int spx_stream_synchronize(void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPEEDY_HIP_H_ */

@@ -1,0 +1,108 @@
+"""Loader for libspeedy_hip.so.  Fails loudly: the product has no CPU path."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspeedy_hip.so")
+_LIB = None
+
+c_short_p = C.POINTER(C.c_short)
+c_float_p = C.POINTER(C.c_float)
+c_int64_p = C.POINTER(C.c_int64)
+
+
+class StreamJob(C.Structure):  # spx_stream_job, include/speedy_hip.h
+    _fields_ = [("in_off", C.c_int64), ("n_in", C.c_int64), ("out_off", C.c_int64), ("out_cap", C.c_int64),
+                ("channels", C.c_int32), ("speed", C.c_float), ("nonlinear", C.c_float), ("feedback", C.c_float)]
+
+
+class Taps(C.Structure):  # spx_taps
+    _fields_ = [("tension", C.c_void_p), ("speed", C.c_void_p), ("features", C.c_void_p),
+                ("spectrogram", C.c_void_p), ("normalized", C.c_void_p)]
+
+
+TENSION_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_float)
+FEATURES_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, c_float_p)
+
+# name -> (restype, argtypes); every symbol declared in include/speedy_hip.h and include/sonic2.h
+SYMBOLS = {
+    "spx_last_error": (C.c_char_p, []),
+    "spx_abi_version": (C.c_int, []),
+    "spx_plan_create": (C.c_void_p, [C.c_int, C.c_int]),
+    "spx_plan_destroy": (None, [C.c_void_p]),
+    "spx_plan_frame_step": (C.c_int, [C.c_void_p]),
+    "spx_plan_window_size": (C.c_int, [C.c_void_p]),
+    "spx_plan_fft_size": (C.c_int, [C.c_void_p]),
+    "spx_plan_future": (C.c_int, [C.c_void_p]),
+    "spx_plan_max_required": (C.c_int, [C.c_void_p]),
+    "spx_plan_frames": (C.c_int64, [C.c_void_p, C.c_int64]),
+    "spx_plan_out_capacity": (C.c_int64, [C.c_void_p, C.c_int64, C.c_float]),
+    "spx_batch_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(StreamJob), C.c_int]),
+    "spx_batch_run": (C.c_int, [C.c_void_p, C.POINTER(StreamJob), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_size_t, C.POINTER(Taps), C.c_void_p]),
+    "spx_batch_analyze": (C.c_int, [C.c_void_p, C.POINTER(StreamJob), C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_size_t, C.POINTER(Taps), C.c_void_p]),
+    "spx_batch_walk": (C.c_int, [C.c_void_p, C.POINTER(StreamJob), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_size_t, C.POINTER(Taps), C.c_void_p]),
+    "spx_set_timing": (None, [C.c_int]),
+    "spx_last_kernel_ms": (C.c_int, [c_float_p, c_float_p]),
+    "spx_device_alloc": (C.c_void_p, [C.c_size_t]),
+    "spx_device_free": (None, [C.c_void_p]),
+    "spx_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "spx_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "spx_stream_synchronize": (C.c_int, [C.c_void_p]),
+    # include/sonic2.h
+    "sonicCreateStream": (C.c_void_p, [C.c_int, C.c_int]),
+    "sonicDestroyStream": (None, [C.c_void_p]),
+    "sonicWriteShortToStream": (C.c_int, [C.c_void_p, c_short_p, C.c_int]),
+    "sonicReadShortFromStream": (C.c_int, [C.c_void_p, c_short_p, C.c_int]),
+    "sonicWriteFloatToStream": (C.c_int, [C.c_void_p, c_float_p, C.c_int]),
+    "sonicReadFloatFromStream": (C.c_int, [C.c_void_p, c_float_p, C.c_int]),
+    "sonicSetRate": (None, [C.c_void_p, C.c_float]),
+    "sonicSetSpeed": (None, [C.c_void_p, C.c_float]),
+    "sonicFlushStream": (C.c_int, [C.c_void_p]),
+    "sonicEnableNonlinearSpeedup": (None, [C.c_void_p, C.c_float]),
+    "sonicSetDurationFeedbackStrength": (None, [C.c_void_p, C.c_float]),
+    "getSonicBufferSize": (C.c_int, [C.c_void_p]),
+    "sonicSpectrogramSize": (C.c_int, [C.c_void_p]),
+    "sonicTensionCallback": (None, [C.c_void_p, TENSION_FN]),
+    "getSonicTensionCallback": (C.c_void_p, [C.c_void_p]),
+    "sonicSpeedCallback": (None, [C.c_void_p, TENSION_FN]),
+    "getSonicSpeedCallback": (C.c_void_p, [C.c_void_p]),
+    "sonicFeaturesCallback": (None, [C.c_void_p, FEATURES_FN]),
+    "getSonicFeaturesCallback": (C.c_void_p, [C.c_void_p]),
+    "sonicSpectrogramCallback": (None, [C.c_void_p, FEATURES_FN]),
+    "getSonicSpectrogramCallback": (C.c_void_p, [C.c_void_p]),
+    "sonicNormalizedSpectrogramCallback": (None, [C.c_void_p, FEATURES_FN]),
+    "getSonicNormalizedSpectrogramCallback": (C.c_void_p, [C.c_void_p]),
+    "sonicIntGetNumChannels": (C.c_int, [C.c_void_p]),
+    "sonicIntGetSampleRate": (C.c_int, [C.c_void_p]),
+    "sonicIntGetSpeed": (C.c_float, [C.c_void_p]),
+    "speedyHipSetMatchMatlab": (None, [C.c_int]),
+    "sonicSamplesAvailable": (C.c_int, [C.c_void_p]),
+    "speedyHipLastError": (C.c_char_p, []),
+}
+
+
+def build():
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+
+
+def lib():
+    """The loaded library.  torch is imported first so that one HIP runtime (torch's) serves both."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the product has no CPU fallback)")
+    import torch  # noqa: F401  (loads libamdhip64 with the soname the library links against)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)  # AttributeError = the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L

@@ -1,0 +1,148 @@
+"""Batch engine: N independent streams, device-resident, one spx_batch_run call (include/speedy_hip.h).
+
+Host-side mirror of what the reference's caller loop does per stream (speedy_wave.cc:154-242): create,
+setSpeed, enableNonlinear, setFeedback, write everything, flush, drain."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import StreamJob, Taps, lib
+
+
+class Plan:
+    def __init__(self, sample_rate, match_matlab=False):
+        self.L = lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("speedy_amd needs a HIP device; there is no CPU path")
+        self.h = self.L.spx_plan_create(int(sample_rate), int(bool(match_matlab)))
+        if not self.h:
+            raise RuntimeError("spx_plan_create: " + self.L.spx_last_error().decode())
+        self.sample_rate = sample_rate
+        self.B = self.L.spx_plan_frame_step(self.h)
+        self.W = self.L.spx_plan_window_size(self.h)
+        self.N = self.L.spx_plan_fft_size(self.h)
+        self.F = self.L.spx_plan_future(self.h)
+        self.max_required = self.L.spx_plan_max_required(self.h)
+
+    def frames(self, n_in):
+        return self.L.spx_plan_frames(self.h, int(n_in))
+
+    def out_capacity(self, n_in, speed):
+        return self.L.spx_plan_out_capacity(self.h, int(n_in), float(speed))
+
+    def close(self):
+        if self.h:
+            self.L.spx_plan_destroy(self.h)
+            self.h = None
+
+
+class Batch:
+    """A prepared batch: inputs packed into one HBM buffer, outputs and workspace allocated once."""
+
+    def __init__(self, plan, lengths, channels, speed, nonlinear=1.0, feedback=0.0, device="cuda", taps=False,
+                 spectrogram_taps=False):
+        self.plan = plan
+        n = len(lengths)
+        self.n = n
+        ch = np.broadcast_to(np.asarray(channels, np.int32), (n,)).copy()
+        sp = np.broadcast_to(np.asarray(speed, np.float32), (n,)).copy()
+        nlv = np.broadcast_to(np.asarray(nonlinear, np.float32), (n,)).copy()
+        fb = np.broadcast_to(np.asarray(feedback, np.float32), (n,)).copy()
+        self.lengths = np.asarray(lengths, np.int64)
+        self.channels = ch
+        self.jobs = (StreamJob * n)()
+        in_off = out_off = 0
+        self.in_offs, self.out_offs, self.out_caps, self.frame_offs, self.frames = [], [], [], [], []
+        fo = 0
+        for i in range(n):
+            cap = plan.out_capacity(int(self.lengths[i]), float(sp[i]))
+            j = self.jobs[i]
+            j.in_off, j.n_in, j.out_off, j.out_cap = in_off, int(self.lengths[i]), out_off, cap
+            j.channels, j.speed, j.nonlinear, j.feedback = int(ch[i]), float(sp[i]), float(nlv[i]), float(fb[i])
+            self.in_offs.append(in_off)
+            self.out_offs.append(out_off)
+            self.out_caps.append(cap)
+            T = plan.frames(int(self.lengths[i])) if nlv[i] != 0 else 0
+            self.frame_offs.append(fo)
+            self.frames.append(T)
+            fo += T
+            in_off += int(self.lengths[i]) * int(ch[i])
+            out_off += cap * int(ch[i])
+        self.total_in, self.total_out, self.total_frames = in_off, out_off, fo
+        dev = torch.device(device)
+        self.device = dev
+        self.d_in = torch.zeros(max(1, in_off) + 64, dtype=torch.int16, device=dev)
+        self.d_out = torch.zeros(max(1, out_off), dtype=torch.int16, device=dev)
+        self.d_nout = torch.zeros(n, dtype=torch.int64, device=dev)
+        wsb = plan.L.spx_batch_workspace_bytes(plan.h, self.jobs, n)
+        self.d_ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
+        self.taps = None
+        if taps:
+            T1 = max(1, fo)
+            self.t_tension = torch.zeros(T1, dtype=torch.float32, device=dev)
+            self.t_speed = torch.zeros(T1, dtype=torch.float32, device=dev)
+            self.t_features = torch.zeros(T1 * 15, dtype=torch.float32, device=dev)
+            self.taps = Taps(self.t_tension.data_ptr(), self.t_speed.data_ptr(), self.t_features.data_ptr(), None,
+                             None)
+            if spectrogram_taps:
+                self.t_spec = torch.zeros(T1 * plan.N, dtype=torch.float32, device=dev)
+                self.t_norm = torch.zeros(T1 * plan.W, dtype=torch.float32, device=dev)
+                self.taps.spectrogram = self.t_spec.data_ptr()
+                self.taps.normalized = self.t_norm.data_ptr()
+
+    def upload(self, streams):
+        """streams: list of int16 numpy arrays (interleaved).  Packs and copies them to HBM."""
+        host = np.zeros(self.d_in.numel(), np.int16)
+        for i, x in enumerate(streams):
+            x = np.ascontiguousarray(x, np.int16).ravel()
+            assert x.size == int(self.lengths[i]) * int(self.channels[i])
+            host[self.in_offs[i]:self.in_offs[i] + x.size] = x
+        self.d_in.copy_(torch.from_numpy(host))
+
+    def run(self, stream=None):
+        """Enqueue the whole hot path (analysis + walk) for the batch on `stream` (torch stream or None)."""
+        hs = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        rc = self.plan.L.spx_batch_run(self.plan.h, self.jobs, self.n, self.d_in.data_ptr(), self.d_out.data_ptr(),
+                                       self.d_nout.data_ptr(), self.d_ws.data_ptr(), self.d_ws.numel(),
+                                       C.byref(self.taps) if self.taps is not None else None, hs)
+        if rc != 0:
+            raise RuntimeError("spx_batch_run: " + self.plan.L.spx_last_error().decode())
+
+    def results(self):
+        """Synchronise and return per-stream int16 outputs (host numpy)."""
+        torch.cuda.synchronize(self.device)
+        nout = self.d_nout.cpu().numpy()
+        if (nout < 0).any():
+            raise RuntimeError("output capacity exceeded for streams %s" % np.nonzero(nout < 0)[0][:8])
+        out = self.d_out.cpu().numpy()
+        res = []
+        for i in range(self.n):
+            c = int(self.channels[i])
+            res.append(out[self.out_offs[i]:self.out_offs[i] + int(nout[i]) * c].copy())
+        return res
+
+    def tap_arrays(self, i):
+        """tension/speed/features rows of stream i (host numpy)."""
+        torch.cuda.synchronize(self.device)
+        fo, T = self.frame_offs[i], self.frames[i]
+        K = max(0, T - self.plan.F + 1)
+        r = dict(tension=self.t_tension[fo:fo + K].cpu().numpy(), speed=self.t_speed[fo:fo + K].cpu().numpy(),
+                 features=self.t_features[fo * 15:(fo + K) * 15].cpu().numpy().reshape(K, 15))
+        if getattr(self, "t_spec", None) is not None:
+            N, W = self.plan.N, self.plan.W
+            r["spectrogram"] = self.t_spec[fo * N:(fo + T) * N].cpu().numpy().reshape(T, N)
+            r["normalized"] = self.t_norm[fo * W:(fo + K) * W].cpu().numpy().reshape(K, W)
+        return r
+
+
+def compress_batch(streams, sample_rate, channels, speed, nonlinear=1.0, feedback=0.0, match_matlab=False,
+                   taps=False, spectrogram_taps=False):
+    """One-call convenience: returns (list of outputs, Batch)."""
+    plan = Plan(sample_rate, match_matlab)
+    ch = np.broadcast_to(np.asarray(channels, np.int32), (len(streams),))
+    lengths = [np.asarray(x).size // int(c) for x, c in zip(streams, ch)]
+    b = Batch(plan, lengths, channels, speed, nonlinear, feedback, taps=taps, spectrogram_taps=spectrogram_taps)
+    b.upload(streams)
+    b.run()
+    return b.results(), b

@@ -1,0 +1,375 @@
+// Analysis kernel for gfx950: everything of the Speedy analysis that is local to a 10 ms frame (or to a
+// frame and its predecessor).  One 256-thread workgroup owns a tile of SPX_TF consecutive frames of one
+// stream plus one halo frame.
+//
+//   a2  mono mix            soniclib.c:262-287   (integer mean over channels, truncating)
+//   a3  /32768, pre-emph    speedy.c:553-565,416-425  (carry = last sample of the previous window, which is
+//                                                  sample W-B-1 of the current one)
+//   a4  Hamming + |DFT_N|   speedy.c:256-258,438-473  (DESIGN.md "DFT spec": packed W-point fp64 Stockham
+//                                                  transform in LDS + real-input untangle)
+//   a6  frame energy        speedy.c:513-516 (== :633-640), float accumulation in index order
+//   a8  normalise, 40 dB gate, sum |log ratio|   speedy.c:628-647,705-719
+//
+// Order-sensitive float reductions (energy, spectral difference) run one lane per frame in the
+// reference's index order so that results are bit-identical to the CPU oracle; the DFT, the logs and the
+// gates run one lane per bin.  Built with -ffp-contract=off.
+#include "spx_internal.h"
+
+#define SPX_TF 16  // frames per tile (plus one halo slot)
+
+int spx_analysis_tile_frames() { return SPX_TF; }
+
+static __host__ __device__ inline size_t work_bytes(int W) {
+  size_t a = (size_t)4 * 2 * 2 * W * sizeof(double);         // 4 waves x ping-pong x W complex
+  size_t b = (size_t)SPX_TF * (W + 1) * sizeof(double);      // aliased: log terms
+  return (a > b ? a : b);
+}
+size_t spx_analysis_lds_bytes(const SpxPlanDev& P) {
+  size_t mags = (size_t)(SPX_TF + 1) * (P.W + 1) * sizeof(float);
+  size_t small = (size_t)3 * (SPX_TF + 1) * sizeof(float);
+  return work_bytes(P.W) + ((mags + 15) & ~(size_t)15) + ((small + 15) & ~(size_t)15);
+}
+
+__device__ __forceinline__ void wave_sync() {
+  // LDS traffic of one wave is serviced in issue order; only the compiler must not reorder across this.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Natural log: the fdlibm operation sequence of DESIGN.md "log spec" (same as oracle/orc_speedy.c orc_log).
+__device__ inline double spx_log(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+               two54 = 1.80143985094819840000e+16, Lg1 = 6.666666666666735130e-01,
+               Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01,
+               Lg6 = 1.531383769920937332e-01, Lg7 = 1.479819860511658591e-01;
+  double hfsq, f, s, z, R, w, t1, t2, dk;
+  int k, hx, i, j;
+  unsigned lx;
+  long long bits = __double_as_longlong(x);
+  hx = (int)(bits >> 32);
+  lx = (unsigned)bits;
+  k = 0;
+  if (hx < 0x00100000) {
+    if (((hx & 0x7fffffff) | lx) == 0) return -__builtin_huge_val();
+    if (hx < 0) return __builtin_nan("");
+    k -= 54;
+    x *= two54;
+    bits = __double_as_longlong(x);
+    hx = (int)(bits >> 32);
+  }
+  if (hx >= 0x7ff00000) return x + x;
+  k += (hx >> 20) - 1023;
+  hx &= 0x000fffff;
+  i = (hx + 0x95f64) & 0x100000;
+  bits = __double_as_longlong(x);
+  bits = (bits & 0xffffffffLL) | ((long long)(unsigned)(hx | (i ^ 0x3ff00000)) << 32);
+  x = __longlong_as_double(bits);
+  k += (i >> 20);
+  f = x - 1.0;
+  if ((0x000fffff & (2 + hx)) < 3) {
+    if (f == 0.0) {
+      if (k == 0) return 0.0;
+      dk = (double)k;
+      return dk * ln2_hi + dk * ln2_lo;
+    }
+    R = f * f * (0.5 - 0.33333333333333333 * f);
+    if (k == 0) return f - R;
+    dk = (double)k;
+    return dk * ln2_hi - ((R - dk * ln2_lo) - f);
+  }
+  s = f / (2.0 + f);
+  dk = (double)k;
+  z = s * s;
+  i = hx - 0x6147a;
+  w = z * z;
+  j = 0x6b851 - hx;
+  t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  i |= j;
+  R = t2 + t1;
+  if (i > 0) {
+    hfsq = 0.5 * f * f;
+    if (k == 0) return f - (hfsq - s * (hfsq + R));
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+  }
+  if (k == 0) return f - s * (f - R);
+  return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+#define C5_1 0.30901699437494742
+#define C5_2 (-0.80901699437494742)
+#define S5_1 0.95105651629515357
+#define S5_2 0.58778525229247313
+#define S3_1 0.86602540378443865
+
+struct cplx {
+  double r, i;
+};
+
+__device__ __forceinline__ cplx ld(const double* buf, int idx) {
+  const double2 v = *reinterpret_cast<const double2*>(buf + 2 * idx);
+  return {v.x, v.y};
+}
+__device__ __forceinline__ void st_tw(double* buf, int idx, cplx b, const double* __restrict__ tw, int t) {
+  const double2 w = *reinterpret_cast<const double2*>(tw + 2 * t);
+  double2 o;
+  o.x = b.r * w.x - b.i * w.y;
+  o.y = b.r * w.y + b.i * w.x;
+  *reinterpret_cast<double2*>(buf + 2 * idx) = o;
+}
+
+// One Stockham stage of radix r over the W-point transform held in x (-> y).  s = product of earlier radices.
+__device__ void dft_stage(const SpxPlanDev& P, int r, int s, int cur, const double* x, double* y, int lane) {
+  const int W = P.W;
+  const int m = cur / r;
+  const int span = W / r;
+  const double* __restrict__ tw = P.tw;
+  if (r == 4) {
+    for (int b = lane; b < span; b += SPX_WAVE) {
+      const int p = b / s, q = b - p * s;
+      cplx a0 = ld(x, b), a1 = ld(x, b + span), a2 = ld(x, b + 2 * span), a3 = ld(x, b + 3 * span);
+      cplx t0 = {a0.r + a2.r, a0.i + a2.i}, t1 = {a0.r - a2.r, a0.i - a2.i};
+      cplx t2 = {a1.r + a3.r, a1.i + a3.i}, t3 = {a1.r - a3.r, a1.i - a3.i};
+      cplx b0 = {t0.r + t2.r, t0.i + t2.i}, b2 = {t0.r - t2.r, t0.i - t2.i};
+      cplx b1 = {t1.r + t3.i, t1.i - t3.r}, b3 = {t1.r - t3.i, t1.i + t3.r};
+      const int o = q + s * 4 * p;
+      const int tp = s * p;  // < W
+      st_tw(y, o, b0, tw, 0);
+      st_tw(y, o + s, b1, tw, tp % W);
+      st_tw(y, o + 2 * s, b2, tw, (2 * tp) % W);
+      st_tw(y, o + 3 * s, b3, tw, (3 * tp) % W);
+    }
+  } else if (r == 2) {
+    for (int b = lane; b < span; b += SPX_WAVE) {
+      const int p = b / s, q = b - p * s;
+      cplx a0 = ld(x, b), a1 = ld(x, b + span);
+      cplx b0 = {a0.r + a1.r, a0.i + a1.i}, b1 = {a0.r - a1.r, a0.i - a1.i};
+      const int o = q + s * 2 * p;
+      st_tw(y, o, b0, tw, 0);
+      st_tw(y, o + s, b1, tw, (s * p) % W);
+    }
+  } else if (r == 3) {
+    for (int b = lane; b < span; b += SPX_WAVE) {
+      const int p = b / s, q = b - p * s;
+      cplx a0 = ld(x, b), a1 = ld(x, b + span), a2 = ld(x, b + 2 * span);
+      cplx t1 = {a1.r + a2.r, a1.i + a2.i};
+      cplx t2 = {a0.r - 0.5 * t1.r, a0.i - 0.5 * t1.i};
+      cplx t3 = {S3_1 * (a1.r - a2.r), S3_1 * (a1.i - a2.i)};
+      cplx b0 = {a0.r + t1.r, a0.i + t1.i};
+      cplx b1 = {t2.r + t3.i, t2.i - t3.r}, b2 = {t2.r - t3.i, t2.i + t3.r};
+      const int o = q + s * 3 * p;
+      const int tp = s * p;
+      st_tw(y, o, b0, tw, 0);
+      st_tw(y, o + s, b1, tw, tp % W);
+      st_tw(y, o + 2 * s, b2, tw, (2 * tp) % W);
+    }
+  } else if (r == 5) {
+    for (int b = lane; b < span; b += SPX_WAVE) {
+      const int p = b / s, q = b - p * s;
+      cplx a0 = ld(x, b), a1 = ld(x, b + span), a2 = ld(x, b + 2 * span), a3 = ld(x, b + 3 * span),
+           a4 = ld(x, b + 4 * span);
+      cplx t1 = {a1.r + a4.r, a1.i + a4.i}, t2 = {a2.r + a3.r, a2.i + a3.i};
+      cplx t3 = {a1.r - a4.r, a1.i - a4.i}, t4 = {a2.r - a3.r, a2.i - a3.i};
+      cplx b0 = {(a0.r + t1.r) + t2.r, (a0.i + t1.i) + t2.i};
+      cplx m1 = {(a0.r + C5_1 * t1.r) + C5_2 * t2.r, (a0.i + C5_1 * t1.i) + C5_2 * t2.i};
+      cplx m2 = {(a0.r + C5_2 * t1.r) + C5_1 * t2.r, (a0.i + C5_2 * t1.i) + C5_1 * t2.i};
+      cplx n1 = {S5_1 * t3.r + S5_2 * t4.r, S5_1 * t3.i + S5_2 * t4.i};
+      cplx n2 = {S5_2 * t3.r - S5_1 * t4.r, S5_2 * t3.i - S5_1 * t4.i};
+      cplx b1 = {m1.r + n1.i, m1.i - n1.r}, b4 = {m1.r - n1.i, m1.i + n1.r};
+      cplx b2 = {m2.r + n2.i, m2.i - n2.r}, b3 = {m2.r - n2.i, m2.i + n2.r};
+      const int o = q + s * 5 * p;
+      const int tp = s * p;
+      st_tw(y, o, b0, tw, 0);
+      st_tw(y, o + s, b1, tw, tp % W);
+      st_tw(y, o + 2 * s, b2, tw, (2 * tp) % W);
+      st_tw(y, o + 3 * s, b3, tw, (3 * tp) % W);
+      st_tw(y, o + 4 * s, b4, tw, (4 * tp) % W);
+    }
+  } else {
+    // generic prime radix: one lane per (butterfly, output) pair, inputs accumulated in ascending order
+    const int step = W / r;
+    for (int item = lane; item < W; item += SPX_WAVE) {
+      const int b = item / r, j = item - b * r;
+      const int p = b / s, q = b - p * s;
+      cplx acc = ld(x, b);
+      for (int i = 1; i < r; i++) {
+        cplx a = ld(x, b + i * span);
+        const double2 w = *reinterpret_cast<const double2*>(tw + 2 * (((i * j) % r) * step));
+        acc.r = acc.r + (a.r * w.x - a.i * w.y);
+        acc.i = acc.i + (a.r * w.y + a.i * w.x);
+      }
+      st_tw(y, q + s * (r * p + j), acc, tw, (int)(((long long)s * p * j) % W));
+    }
+  }
+  (void)m;
+}
+
+__device__ __forceinline__ int mono_sample(const int16_t* __restrict__ in, int64_t a, int C) {
+  if (C == 1) return in[a];
+  int sum = 0;
+  const int16_t* p = in + a * C;
+  for (int c = 0; c < C; c++) sum += p[c];
+  return sum / C;
+}
+
+__global__ void __launch_bounds__(SPX_BLOCK)
+spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int n_streams,
+                    const int16_t* __restrict__ in_base, SpxFrameRec* __restrict__ rec, SpxTapsDev taps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int W = P.W, B = P.B, N = P.N;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // tile -> (stream, first frame): binary search over streams[].first_tile
+  const int tile = blockIdx.x;
+  int lo = 0, hi = n_streams - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (streams[mid].first_tile <= tile) lo = mid; else hi = mid - 1;
+  }
+  const SpxStreamDev S = streams[lo];
+  const int T = S.n_frames;
+  const int j0 = S.frame_begin + (tile - S.first_tile) * SPX_TF;
+  const int j1 = min(j0 + SPX_TF, T);
+  const int C = S.channels;
+  const int16_t* __restrict__ in = in_base + S.in_off;
+
+  double* work = reinterpret_cast<double*>(lds);
+  const size_t wb = work_bytes(W);
+  float* mags = reinterpret_cast<float*>(lds + wb);
+  const size_t mags_b = (((size_t)(SPX_TF + 1) * (W + 1) * sizeof(float)) + 15) & ~(size_t)15;
+  float* fE = reinterpret_cast<float*>(lds + wb + mags_b);
+  float* fThr = fE + (SPX_TF + 1);
+  float* fInv = fThr + (SPX_TF + 1);
+  const int MS = W + 1;  // mags row stride (floats)
+
+  double* bufA = work + (size_t)wave * 4 * W;
+  double* bufB = bufA + 2 * W;
+
+  // ---------------- phase 1: spectra of slots 0..TF (slot s = frame j0-1+s), one wave per slot ----------
+  for (int s = wave; s <= SPX_TF; s += 4) {
+    const int j = j0 - 1 + s;
+    float* mrow = mags + (size_t)s * MS;
+    if (j < 0 || j >= j1) {  // outside the stream (or the tile's tail): zero spectrum
+      for (int k = lane; k < W; k += SPX_WAVE) mrow[k] = 0.0f;
+      continue;
+    }
+    const int64_t a0 = (int64_t)j * B;
+    for (int i = lane; i < 2 * W; i += SPX_WAVE) {
+      double v = 0.0;
+      if (i < W) {
+        const int m = mono_sample(in, a0 + i, C);
+        int mp;
+        if (i > 0) mp = mono_sample(in, a0 + i - 1, C);
+        else mp = (j > 0) ? mono_sample(in, a0 + (W - B) - 1, C) : 0;
+        const float x = (float)(m / 32768.0);
+        const float xp = (float)(mp / 32768.0);
+        const float y = (float)(1.0 * (double)x - 0.97 * (double)xp);  // speedy.c:422
+        v = (double)(y * P.window[i]);                                  // speedy.c:442 / :462
+      }
+      bufA[i] = v;
+    }
+    wave_sync();
+    double* x = bufA;
+    double* y = bufB;
+    int sprod = 1, cur = W;
+    for (int stg = 0; stg < P.nstages; stg++) {
+      const int r = P.radix[stg];
+      dft_stage(P, r, sprod, cur, x, y, lane);
+      wave_sync();
+      double* t = x; x = y; y = t;
+      sprod *= r;
+      cur /= r;
+    }
+    // untangle the packed transform:  X[k] = E[k] + e^{-2 pi i k/N} O[k]
+    float* spec_out = taps.spectrogram ? taps.spectrogram + (size_t)(S.frame_off + j) * N : nullptr;
+    for (int k = lane; k < W; k += SPX_WAVE) {
+      const int k2 = (k == 0) ? 0 : W - k;
+      cplx a = ld(x, k), bb = ld(x, k2);
+      const double b_r = bb.r, b_i = -bb.i;
+      const double er = 0.5 * (a.r + b_r), ei = 0.5 * (a.i + b_i);
+      const double dr = a.r - b_r, di = a.i - b_i;
+      const double o_r = 0.5 * di, o_i = -0.5 * dr;
+      const double2 w = *reinterpret_cast<const double2*>(P.tw2 + 2 * k);
+      const double xr = er + (w.x * o_r - w.y * o_i);
+      const double xi = ei + (w.x * o_i + w.y * o_r);
+      const float mag = (float)__builtin_sqrt(xr * xr + xi * xi);
+      mrow[k] = mag;
+      if (spec_out) {
+        spec_out[k] = mag;
+        if (k > 0) spec_out[N - k] = mag;
+        else spec_out[W] = (float)__builtin_fabs(a.r - a.i);
+      }
+    }
+    wave_sync();
+  }
+  __syncthreads();
+
+  // ---------------- phase 2: per-slot energy (float, index order), max, inverse norm ----------------
+  if (tid <= SPX_TF) {
+    const float* mrow = mags + (size_t)tid * MS;
+    float e = 0.0f, mx = 0.0f;
+    for (int i = 1; i < W; i++) {
+      const float v = mrow[i];
+      e += v * v;
+      mx = fmaxf(mx, v);
+    }
+    const float eps = 2.2204e-16f;
+    fE[tid] = e;
+    fThr[tid] = (float)((double)mx / 100.0);                                   // speedy.c:709
+    fInv[tid] = (float)(1.0 / (__builtin_sqrt((double)e) + (double)eps));      // speedy.c:642
+  }
+  __syncthreads();
+
+  // ---------------- phase 3: gated |log ratio| terms, one lane per (slot, bin) ----------------
+  double* terms = work;  // aliases the DFT buffers, [SPX_TF][W+1]
+  const int nfr = j1 - j0;
+  for (int idx = tid; idx < nfr * (W - 1); idx += SPX_BLOCK) {
+    const int f = idx / (W - 1);
+    const int i = 1 + (idx - f * (W - 1));
+    const int s = f + 1;
+    const float cur = mags[(size_t)s * MS + i], last = mags[(size_t)(s - 1) * MS + i];
+    const float thr = fThr[s];
+    double term = 0.0;
+    if (cur > thr && last > thr) {
+      const float eps = 2.2204e-16f;
+      const float nc = cur * fInv[s], nl = last * fInv[s - 1];
+      const float ratio = (nc + eps) / (nl + eps);
+      term = __builtin_fabs(spx_log((double)ratio));                           // speedy.c:715-717
+    }
+    terms[(size_t)f * (W + 1) + i] = term;
+  }
+  if (taps.normalized) {
+    // normalised spectrum of frame j is the one used for tension k = j+1 (speedy.c:673-675)
+    for (int idx = tid; idx < nfr * W; idx += SPX_BLOCK) {
+      const int f = idx / W, i = idx - f * W;
+      const int j = j0 + f;
+      if (j + 1 < T) taps.normalized[(size_t)(S.frame_off + j + 1) * W + i] = mags[(size_t)(f + 1) * MS + i] * fInv[f + 1];
+    }
+    if (j0 == 0)
+      for (int i = tid; i < W; i += SPX_BLOCK) taps.normalized[(size_t)S.frame_off * W + i] = 0.0f;
+  }
+  __syncthreads();
+
+  // ---------------- phase 4: float accumulation of the terms in bin order, one lane per frame --------
+  if (tid < nfr) {
+    const double* trow = terms + (size_t)tid * (W + 1);
+    float lsd = 0.0f;
+    for (int i = 1; i < W; i++) lsd = (float)((double)lsd + trow[i]);          // speedy.c:715 (float +=)
+    const float lowthr = (float)(0.04 * (double)1.41421f);                     // speedy.c:682
+    const float e = fE[tid + 1];
+    SpxFrameRec r;
+    r.energy = e;
+    r.lsd = (e <= lowthr) ? 0.0f : lsd;
+    rec[S.frame_off + j0 + tid] = r;
+  }
+}
+
+void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int n_tiles,
+                         const int16_t* in, SpxFrameRec* rec, SpxTapsDev taps, hipStream_t st) {
+  if (n_tiles <= 0) return;
+  const size_t lds = spx_analysis_lds_bytes(P);
+  hipLaunchKernelGGL(spx_analysis_kernel, dim3(n_tiles), dim3(SPX_BLOCK), lds, st, P, streams, n_streams, in,
+                     rec, taps);
+}

@@ -1,0 +1,297 @@
+// C-ABI of the batch engine (include/speedy_hip.h): plan tables, workspace layout, kernel launches.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/speedy_hip.h"
+#include "spx_internal.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail(-2, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct spx_plan {
+  SpxPlanDev dev;
+  void* tables = nullptr;  // one device allocation behind dev.tw/tw2/window/taper*
+};
+
+static bool g_timing = false;
+static hipEvent_t g_ev[4];
+static bool g_ev_init = false;
+static bool g_ev_valid = false;
+
+extern "C" {
+
+const char* spx_last_error(void) { return g_err.c_str(); }
+int spx_abi_version(void) { return 1; }
+
+static int factor_radices(int n, int* radix) {  // DESIGN.md "DFT spec": 4s, then 2, 3s, 5s, other primes ascending
+  int ns = 0;
+  while (n % 4 == 0) { radix[ns++] = 4; n /= 4; }
+  while (n % 2 == 0) { radix[ns++] = 2; n /= 2; }
+  while (n % 3 == 0) { radix[ns++] = 3; n /= 3; }
+  while (n % 5 == 0) { radix[ns++] = 5; n /= 5; }
+  for (int p = 7; n > 1; p += 2)
+    while (n % p == 0) { radix[ns++] = p; n /= p; }
+  return ns;
+}
+
+spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
+  if (sample_rate < 1000 || sample_rate > 400000) {
+    fail(-1, "spx_plan_create: unsupported sample rate");
+    return nullptr;
+  }
+  spx_plan* p = new spx_plan();
+  SpxPlanDev& d = p->dev;
+  memset(&d, 0, sizeof(d));
+  d.rate = sample_rate;
+  d.B = (int)(sample_rate / 100.0);                    // speedy.c:335-338
+  d.W = (int)(1.5 * sample_rate / (float)100.0);       // speedy.c:213
+  d.N = 2 * d.W;
+  d.F = match_matlab ? 8 : 12;                         // speedy.h:136-146
+  d.Pp = match_matlab ? 12 : 8;
+  d.nstages = (d.W > 1) ? factor_radices(d.W, d.radix) : 0;
+  if (d.nstages > SPX_MAX_STAGES) {
+    delete p;
+    fail(-1, "spx_plan_create: too many DFT stages");
+    return nullptr;
+  }
+  d.minPeriod = sample_rate / 400;
+  d.maxPeriod = sample_rate / 65;
+  d.maxRequired = 2 * d.maxPeriod;
+  d.skip = sample_rate > 4000 ? sample_rate / 4000 : 1;
+  d.alpha = (float)exp(-1.0 / (float)100.0);          // speedy.c:67 with time constant kFrameRateHz
+  d.one_minus_alpha = 1 - d.alpha;                     // float, speedy.c:74
+
+  const int W = d.W;
+  const size_t n_tw = 2 * (size_t)W, n_win = (size_t)W, n_tf = d.F + 1, n_tp = d.Pp + 1;
+  const size_t bytes = sizeof(double) * 2 * n_tw + sizeof(float) * (n_win + n_tf + n_tp + 8);
+  std::vector<unsigned char> host(bytes, 0);
+  double* tw = reinterpret_cast<double*>(host.data());
+  double* tw2 = tw + n_tw;
+  float* win = reinterpret_cast<float*>(tw2 + n_tw);
+  float* tf = win + n_win;
+  float* tp = tf + n_tf;
+  for (int t = 0; t < W; t++) {
+    tw[2 * t] = cos(2.0 * M_PI * t / W);
+    tw[2 * t + 1] = -sin(2.0 * M_PI * t / W);
+    tw2[2 * t] = cos(2.0 * M_PI * t / (2.0 * W));
+    tw2[2 * t + 1] = -sin(2.0 * M_PI * t / (2.0 * W));
+    win[t] = 0.54 - 0.46 * cos(2 * M_PI * t / (W - 1.0));  // speedy.c:256-258
+  }
+  for (int i = 0; i <= d.F; i++) tf[i] = (d.F - i) / (float)d.F;    // speedy.c:597
+  for (int i = 0; i <= d.Pp; i++) tp[i] = (d.Pp - i) / (float)d.Pp;  // speedy.c:604
+  if (hipMalloc(&p->tables, bytes) != hipSuccess ||
+      hipMemcpy(p->tables, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    fail(-2, "spx_plan_create: device allocation/copy failed (is a GPU visible?)");
+    if (p->tables) (void)hipFree(p->tables);
+    delete p;
+    return nullptr;
+  }
+  unsigned char* base = static_cast<unsigned char*>(p->tables);
+  d.tw = reinterpret_cast<const double*>(base);
+  d.tw2 = d.tw + n_tw;
+  d.window = reinterpret_cast<const float*>(d.tw2 + n_tw);
+  d.taperF = d.window + n_win;
+  d.taperP = d.taperF + n_tf;
+  return p;
+}
+
+void spx_plan_destroy(spx_plan_t plan) {
+  if (!plan) return;
+  if (plan->tables) (void)hipFree(plan->tables);
+  delete plan;
+}
+int spx_plan_frame_step(spx_plan_t p) { return p->dev.B; }
+int spx_plan_window_size(spx_plan_t p) { return p->dev.W; }
+int spx_plan_fft_size(spx_plan_t p) { return p->dev.N; }
+int spx_plan_future(spx_plan_t p) { return p->dev.F; }
+int spx_plan_max_required(spx_plan_t p) { return p->dev.maxRequired; }
+
+static int64_t frames_for(const SpxPlanDev& d, int64_t n_in) {
+  // frame j is sent to the analysis once sample j*B + W has been written (soniclib.c:440-444)
+  if (n_in < d.W + 1) return 0;
+  return (n_in - d.W - 1) / d.B + 1;
+}
+int64_t spx_plan_frames(spx_plan_t p, int64_t n_in) { return frames_for(p->dev, n_in); }
+
+int64_t spx_plan_out_capacity(spx_plan_t p, int64_t n_in, float speed) {
+  double s = speed < 0.01 ? 0.01 : speed;
+  double lo = s < 1.0 ? s : 1.0;  // nonlinear speed never drops below min(1, speed) (speedy.c:774-776)
+  return (int64_t)(n_in / lo) + 4 * (int64_t)p->dev.maxRequired + 1024;
+}
+
+}  // extern "C"
+#include <map>
+#include <mutex>
+const SpxPlanDev* spx_internal_shared_plan(int sample_rate, int match_matlab) {
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, spx_plan*> cache;
+  std::lock_guard<std::mutex> g(mu);
+  auto key = std::make_pair(sample_rate, match_matlab ? 1 : 0);
+  auto it = cache.find(key);
+  if (it != cache.end()) return &it->second->dev;
+  spx_plan* p = spx_plan_create(sample_rate, match_matlab);
+  if (!p) return nullptr;
+  cache[key] = p;
+  return &p->dev;
+}
+int64_t spx_internal_frames_for(const SpxPlanDev& d, int64_t n_in) { return frames_for(d, n_in); }
+extern "C" {
+
+struct Layout {
+  size_t off_streams, off_states, off_rec, off_scratch, total;
+  int64_t total_frames;
+};
+static Layout layout_for(const SpxPlanDev& d, const spx_stream_job* jobs, int n) {
+  Layout L;
+  int64_t tf = 0;
+  for (int i = 0; i < n; i++) tf += (jobs[i].nonlinear != 0.0f) ? frames_for(d, jobs[i].n_in) : 0;
+  L.total_frames = tf;
+  size_t o = 0;
+  L.off_streams = o; o += ((sizeof(SpxStreamDev) * (size_t)n + 255) & ~(size_t)255);
+  L.off_states = o;  o += ((sizeof(SpxStreamState) * (size_t)n + 255) & ~(size_t)255);
+  L.off_rec = o;     o += ((sizeof(SpxFrameRec) * (size_t)(tf + 1) + 255) & ~(size_t)255);
+  L.off_scratch = o; o += ((sizeof(float) * 4 * (size_t)(tf + 1) + 255) & ~(size_t)255);
+  L.total = o;
+  return L;
+}
+
+size_t spx_batch_workspace_bytes(spx_plan_t plan, const spx_stream_job* jobs, int n_streams) {
+  return layout_for(plan->dev, jobs, n_streams).total;
+}
+
+static int build_streams(const SpxPlanDev& d, const spx_stream_job* jobs, int n, std::vector<SpxStreamDev>& v,
+                         int* n_tiles) {
+  v.resize(n);
+  int64_t fo = 0;
+  int tiles = 0;
+  const int TF = spx_analysis_tile_frames();
+  for (int i = 0; i < n; i++) {
+    const spx_stream_job& j = jobs[i];
+    if (j.channels < 1 || j.n_in < 0) return fail(-1, "spx_batch: bad job");
+    SpxStreamDev& s = v[i];
+    s.in_off = j.in_off; s.n_in = j.n_in; s.out_off = j.out_off; s.out_cap = j.out_cap;
+    s.channels = j.channels; s.speed = j.speed; s.nonlinear = j.nonlinear; s.feedback = j.feedback;
+    const int64_t T = (j.nonlinear != 0.0f) ? frames_for(d, j.n_in) : 0;
+    if (T > 0x7fffff00) return fail(-1, "spx_batch: stream too long");
+    s.n_frames = (int32_t)T;
+    s.frame_begin = 0;
+    s.flags = SPX_F_INIT | SPX_F_FLUSH;
+    s.frame_off = fo;
+    s.first_tile = tiles;
+    fo += T;
+    tiles += (int)((T + TF - 1) / TF);
+  }
+  *n_tiles = tiles;
+  return 0;
+}
+
+static SpxTapsDev taps_of(const spx_taps* t) {
+  SpxTapsDev d = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (t) { d.tension = t->tension; d.speed = t->speed; d.features = t->features;
+           d.spectrogram = t->spectrogram; d.normalized = t->normalized; }
+  return d;
+}
+
+static void ensure_events() {
+  if (!g_ev_init) {
+    for (auto& e : g_ev) (void)hipEventCreate(&e);
+    g_ev_init = true;
+  }
+}
+
+static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
+                    int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs, bool do_a,
+                    bool do_w) {
+  if (!plan || !jobs || n <= 0) return fail(-1, "spx_batch: bad arguments");
+  const SpxPlanDev& d = plan->dev;
+  Layout L = layout_for(d, jobs, n);
+  if (ws_bytes < L.total || !ws) return fail(-1, "spx_batch: workspace too small");
+  std::vector<SpxStreamDev> sv;
+  int n_tiles = 0;
+  int rc = build_streams(d, jobs, n, sv, &n_tiles);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(hs);
+  unsigned char* w = static_cast<unsigned char*>(ws);
+  SpxStreamDev* dstreams = reinterpret_cast<SpxStreamDev*>(w + L.off_streams);
+  SpxStreamState* states = reinterpret_cast<SpxStreamState*>(w + L.off_states);
+  SpxFrameRec* rec = reinterpret_cast<SpxFrameRec*>(w + L.off_rec);
+  float* scratch = reinterpret_cast<float*>(w + L.off_scratch);
+  HIPCHK(hipMemcpyAsync(dstreams, sv.data(), sizeof(SpxStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
+  SpxTapsDev td = taps_of(taps);
+  if (g_timing) ensure_events();
+  if (do_a) {
+    if (g_timing) (void)hipEventRecord(g_ev[0], st);
+    spx_launch_analysis(d, dstreams, n, n_tiles, in, rec, td, st);
+    if (g_timing) (void)hipEventRecord(g_ev[1], st);
+  }
+  if (do_w) {
+    if (g_timing) (void)hipEventRecord(g_ev[2], st);
+    spx_launch_walk(d, dstreams, n, in, out, n_out, states, rec, scratch, td, st);
+    if (g_timing) (void)hipEventRecord(g_ev[3], st);
+  }
+  if (g_timing) g_ev_valid = do_a && do_w;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int spx_batch_run(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
+                  int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs) {
+  return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true);
+}
+int spx_batch_analyze(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, void* ws,
+                      size_t ws_bytes, const spx_taps* taps, void* hs) {
+  return run_impl(plan, jobs, n, in, nullptr, nullptr, ws, ws_bytes, taps, hs, true, false);
+}
+int spx_batch_walk(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
+                   int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs) {
+  return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, false, true);
+}
+
+void spx_set_timing(int enabled) { g_timing = enabled != 0; }
+int spx_last_kernel_ms(float* ms_analyze, float* ms_walk) {
+  if (!g_ev_valid) return fail(-1, "spx_last_kernel_ms: no timed run");
+  HIPCHK(hipEventSynchronize(g_ev[3]));
+  float a = 0, w = 0;
+  HIPCHK(hipEventElapsedTime(&a, g_ev[0], g_ev[1]));
+  HIPCHK(hipEventElapsedTime(&w, g_ev[2], g_ev[3]));
+  if (ms_analyze) *ms_analyze = a;
+  if (ms_walk) *ms_walk = w;
+  return 0;
+}
+
+void* spx_device_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { fail(-2, "spx_device_alloc failed"); return nullptr; }
+  return p;
+}
+void spx_device_free(void* p) { if (p) (void)hipFree(p); }
+int spx_copy_to_device(void* dst, const void* src, size_t bytes, void* hs) {
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(hs)));
+  return 0;
+}
+int spx_copy_to_host(void* dst, const void* src, size_t bytes, void* hs) {
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(hs)));
+  return 0;
+}
+int spx_stream_synchronize(void* hs) {
+  HIPCHK(hipStreamSynchronize(static_cast<hipStream_t>(hs)));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+// Internal definitions shared by the HIP kernels and the C-ABI host code.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SPX_MAX_STAGES 16
+#define SPX_WAVE 64
+#define SPX_BLOCK 256
+#define SPX_FEATURE_COUNT 15  // speedy.h:115
+
+// Constant tables and sizes of one plan; passed BY VALUE to every kernel.
+struct SpxPlanDev {
+  int rate;
+  int B;  // frame step   = rate/100              (speedy.c:335-338)
+  int W;  // window size  = (int)(1.5*rate/100)   (speedy.c:213)
+  int N;  // fft size     = 2*W                   (speedy.c:214)
+  int F;  // kTemporalHysteresisFuture            (speedy.h:136-146)
+  int Pp; // kTemporalHysteresisPast
+  int nstages;
+  int radix[SPX_MAX_STAGES];
+  int minPeriod, maxPeriod, maxRequired, skip;  // libsonic limits
+  float alpha;            // (float)exp(-1.0/100)             (speedy.c:67,287)
+  float one_minus_alpha;  // (1 - alpha) evaluated in float   (speedy.c:74)
+  const double* tw;    // [W]  (cos, -sin)(2 pi t / W)
+  const double* tw2;   // [W]  (cos, -sin)(2 pi k / 2W)
+  const float* window; // [W]  Hamming                         (speedy.c:256-258)
+  const float* taperF; // [F+1]  (F-i)/(float)F               (speedy.c:597)
+  const float* taperP; // [P+1]  (P-i)/(float)P               (speedy.c:604)
+};
+
+// Per-stream job in device memory.  A job covers "everything new since the last call": batch jobs start
+// from scratch (SPX_F_INIT) and end the stream (SPX_F_FLUSH) in one go; the streaming API issues a job
+// per sonicWrite*/sonicFlush call with the state record carried in device memory between calls.
+#define SPX_F_INIT 1   // ignore the stored state, start a fresh stream
+#define SPX_F_FLUSH 2  // after the new input: sonicFlushStream (soniclib.c:529-552)
+struct SpxStreamDev {
+  int64_t in_off, n_in, out_off, out_cap;  // n_in = input frames present so far (from the stream start)
+  int64_t frame_off;    // index of this stream's analysis frame 0 in the per-frame arrays
+  int32_t n_frames;     // analysis frames available with n_in samples
+  int32_t frame_begin;  // analysis frames already done by earlier jobs
+  int32_t channels;
+  int32_t flags;
+  float speed, nonlinear, feedback;
+  int32_t first_tile;   // index of this job's first analysis tile
+};
+
+// TSM-stage state (libsonic's stream struct) in absolute stream coordinates.
+struct SpxWalkState {
+  int64_t base;    // absolute index of the first sample still buffered in the TSM stage
+  int64_t out_n;   // frames produced since the stream start
+  int64_t avail;   // frames handed to the TSM stage so far
+  int remaining;   // remainingInputToCopy
+  int prevPeriod, prevMinDiff;
+  int overflow;
+};
+// Everything a stream carries from one job to the next.
+struct SpxStreamState {
+  SpxWalkState w;
+  float lp;        // energy low-pass state          (speedy.c:166,288)
+  float lpf;       // difference low-pass state      (speedy.c:167,291)
+  float cur_dur;   // speedy.c:170
+  float des_dur;   // speedy.c:171
+  float curSpeed;  // speed currently set in the TSM stage
+  int handed;      // ring buffers handed to the TSM stage so far (readBufferFrameIndex, soniclib.c:73)
+  int pad[2];
+};
+
+// Per-analysis-frame record written by the analysis kernel and consumed by the walk kernel.
+struct SpxFrameRec {
+  float energy;  // sum_{i=1}^{N/2-1} s[i]^2, float, index order  (speedy.c:513-516 == :633-640)
+  float lsd;     // local spectral difference with cur = this frame, last = previous (speedy.c:711-719)
+};
+
+// Scratch per analysis frame used by the walk kernel's frame-rate passes.
+struct SpxTapsDev {
+  float* tension;
+  float* speed;
+  float* features;
+  float* spectrogram;
+  float* normalized;
+};
+
+void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int n_tiles,
+                         const int16_t* in, SpxFrameRec* rec, SpxTapsDev taps, hipStream_t st);
+void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, const int16_t* in,
+                     int16_t* out, int64_t* n_out, SpxStreamState* states, const SpxFrameRec* rec, float* scratch,
+                     SpxTapsDev taps, hipStream_t st);
+size_t spx_analysis_lds_bytes(const SpxPlanDev& P);
+int spx_analysis_tile_frames();
+
+// Shared, cached plan per (sample rate, hysteresis mode); owned by the library for the process lifetime.
+struct spx_plan;
+const SpxPlanDev* spx_internal_shared_plan(int sample_rate, int match_matlab);
+int64_t spx_internal_frames_for(const SpxPlanDev& d, int64_t n_in);
