@@ -94,10 +94,11 @@ int spx_batch_walk(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, c
                    int16_t* out, int64_t* n_out, void* workspace, size_t workspace_bytes,
                    const spx_taps* taps, void* hip_stream);
 
-/* Timing hooks for bench.py: HIP events recorded on hip_stream around each kernel of the LAST
- * spx_batch_run/analyze/walk call with timing enabled.  ms_* receive milliseconds (after a stream sync). */
+/* Timing hooks for bench.py: while enabled, every spx_batch_run records HIP events on hip_stream around
+ * each of its two kernels (no host synchronisation is added to the call).  spx_timing_collect waits for the
+ * recorded events, returns the summed kernel milliseconds and the number of calls since the last collect. */
 void spx_set_timing(int enabled);
-int spx_last_kernel_ms(float* ms_analyze, float* ms_walk);
+int spx_timing_collect(double* sum_ms_analyze, double* sum_ms_walk, int* n_calls);
 
 /* ---- plain device-memory helpers (so that C/C++ hosts need no HIP headers) ---- */
 void* spx_device_alloc(size_t bytes);

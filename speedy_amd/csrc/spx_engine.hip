@@ -29,10 +29,12 @@ struct spx_plan {
   void* tables = nullptr;  // one device allocation behind dev.tw/tw2/window/taper*
 };
 
+// Timing: one set of four HIP events per timed call, recorded on the launch stream and resolved lazily by
+// spx_timing_collect (so that the timed region itself carries no host synchronisation).
 static bool g_timing = false;
-static hipEvent_t g_ev[4];
-static bool g_ev_init = false;
-static bool g_ev_valid = false;
+struct EvSet { hipEvent_t e[4]; };
+static std::vector<EvSet> g_ev_pending;
+static std::vector<EvSet> g_ev_free;
 
 extern "C" {
 
@@ -130,9 +132,11 @@ static int64_t frames_for(const SpxPlanDev& d, int64_t n_in) {
 int64_t spx_plan_frames(spx_plan_t p, int64_t n_in) { return frames_for(p->dev, n_in); }
 
 int64_t spx_plan_out_capacity(spx_plan_t p, int64_t n_in, float speed) {
-  double s = speed < 0.01 ? 0.01 : speed;
-  double lo = s < 1.0 ? s : 1.0;  // nonlinear speed never drops below min(1, speed) (speedy.c:774-776)
-  return (int64_t)(n_in / lo) + 4 * (int64_t)p->dev.maxRequired + 1024;
+  // speed >= 1: the stage never emits more than it consumes.  speed < 1: the nonlinear speed can fall to the
+  // kMinimumSpeed clamp, 0.01 (speedy.c:92,776), i.e. up to 100 output frames per input frame.
+  const int64_t slack = 4 * (int64_t)p->dev.maxRequired + 1024;
+  if (speed >= 1.0f) return n_in + slack;
+  return n_in * 100 + slack;
 }
 
 }  // extern "C"
@@ -208,11 +212,11 @@ static SpxTapsDev taps_of(const spx_taps* t) {
   return d;
 }
 
-static void ensure_events() {
-  if (!g_ev_init) {
-    for (auto& e : g_ev) (void)hipEventCreate(&e);
-    g_ev_init = true;
-  }
+static EvSet take_events() {
+  EvSet s;
+  if (!g_ev_free.empty()) { s = g_ev_free.back(); g_ev_free.pop_back(); return s; }
+  for (auto& e : s.e) (void)hipEventCreate(&e);
+  return s;
 }
 
 static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
@@ -234,18 +238,20 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   float* scratch = reinterpret_cast<float*>(w + L.off_scratch);
   HIPCHK(hipMemcpyAsync(dstreams, sv.data(), sizeof(SpxStreamDev) * (size_t)n, hipMemcpyHostToDevice, st));
   SpxTapsDev td = taps_of(taps);
-  if (g_timing) ensure_events();
+  const bool timed = g_timing && do_a && do_w;
+  EvSet ev;
+  if (timed) ev = take_events();
   if (do_a) {
-    if (g_timing) (void)hipEventRecord(g_ev[0], st);
+    if (timed) (void)hipEventRecord(ev.e[0], st);
     spx_launch_analysis(d, dstreams, n, n_tiles, in, rec, td, st);
-    if (g_timing) (void)hipEventRecord(g_ev[1], st);
+    if (timed) (void)hipEventRecord(ev.e[1], st);
   }
   if (do_w) {
-    if (g_timing) (void)hipEventRecord(g_ev[2], st);
+    if (timed) (void)hipEventRecord(ev.e[2], st);
     spx_launch_walk(d, dstreams, n, in, out, n_out, states, rec, scratch, td, st);
-    if (g_timing) (void)hipEventRecord(g_ev[3], st);
+    if (timed) (void)hipEventRecord(ev.e[3], st);
   }
-  if (g_timing) g_ev_valid = do_a && do_w;
+  if (timed) g_ev_pending.push_back(ev);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -264,14 +270,21 @@ int spx_batch_walk(spx_plan_t plan, const spx_stream_job* jobs, int n, const int
 }
 
 void spx_set_timing(int enabled) { g_timing = enabled != 0; }
-int spx_last_kernel_ms(float* ms_analyze, float* ms_walk) {
-  if (!g_ev_valid) return fail(-1, "spx_last_kernel_ms: no timed run");
-  HIPCHK(hipEventSynchronize(g_ev[3]));
-  float a = 0, w = 0;
-  HIPCHK(hipEventElapsedTime(&a, g_ev[0], g_ev[1]));
-  HIPCHK(hipEventElapsedTime(&w, g_ev[2], g_ev[3]));
-  if (ms_analyze) *ms_analyze = a;
-  if (ms_walk) *ms_walk = w;
+int spx_timing_collect(double* sum_ms_analyze, double* sum_ms_walk, int* n_calls) {
+  double a = 0, w = 0;
+  int n = 0;
+  for (auto& ev : g_ev_pending) {
+    HIPCHK(hipEventSynchronize(ev.e[3]));
+    float fa = 0, fw = 0;
+    HIPCHK(hipEventElapsedTime(&fa, ev.e[0], ev.e[1]));
+    HIPCHK(hipEventElapsedTime(&fw, ev.e[2], ev.e[3]));
+    a += fa; w += fw; n++;
+    g_ev_free.push_back(ev);
+  }
+  g_ev_pending.clear();
+  if (sum_ms_analyze) *sum_ms_analyze = a;
+  if (sum_ms_walk) *sum_ms_walk = w;
+  if (n_calls) *n_calls = n;
   return 0;
 }
 

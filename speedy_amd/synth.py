@@ -5,6 +5,8 @@ import numpy as np
 
 
 def speech_like(n, sample_rate, seed, channels=1):
+    if n <= 0:
+        return np.zeros(0, np.int16)
     rng = np.random.default_rng(1234 + seed)
     t = np.arange(n) / float(sample_rate)
     # f0 random walk 90..250 Hz, updated every 20 ms
