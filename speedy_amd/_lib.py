@@ -4,7 +4,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspeedy_hip.so")
+LIB_PATH = os.environ.get("SPEEDY_HIP_LIB") or os.path.join(_HERE, "lib", "libspeedy_hip.so")
 _LIB = None
 
 c_short_p = C.POINTER(C.c_short)

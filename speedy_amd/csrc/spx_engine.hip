@@ -53,7 +53,7 @@ static int factor_radices(int n, int* radix) {  // DESIGN.md "DFT spec": 4s, the
 }
 
 spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
-  if (sample_rate < 1000 || sample_rate > 400000) {
+  if (sample_rate < 1000 || sample_rate > 127999) {  // the walk kernel holds <= 256 lags per search
     fail(-1, "spx_plan_create: unsupported sample rate");
     return nullptr;
   }
@@ -248,7 +248,9 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   }
   if (do_w) {
     if (timed) (void)hipEventRecord(ev.e[2], st);
-    spx_launch_walk(d, dstreams, n, in, out, n_out, states, rec, scratch, td, st);
+    int maxC = 1;
+    for (int i = 0; i < n; i++) if (jobs[i].channels > maxC) maxC = jobs[i].channels;
+    spx_launch_walk(d, dstreams, n, maxC, in, out, n_out, states, rec, scratch, td, st);
     if (timed) (void)hipEventRecord(ev.e[3], st);
   }
   if (timed) g_ev_pending.push_back(ev);

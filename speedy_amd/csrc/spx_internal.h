@@ -82,7 +82,8 @@ struct SpxTapsDev {
 
 void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int n_tiles,
                          const int16_t* in, SpxFrameRec* rec, SpxTapsDev taps, hipStream_t st);
-void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, const int16_t* in,
+void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int max_channels,
+                     const int16_t* in,
                      int16_t* out, int64_t* n_out, SpxStreamState* states, const SpxFrameRec* rec, float* scratch,
                      SpxTapsDev taps, hipStream_t st);
 size_t spx_analysis_lds_bytes(const SpxPlanDev& P);

@@ -1,4 +1,4 @@
-// Walk kernel for gfx950: one 256-thread workgroup per stream.
+// Walk kernel for gfx950: one workgroup of NW wavefronts (NW = 1 or 4) per stream.
 //
 // Prologue (frame rate, O(1) work per 10 ms frame; order-sensitive recurrences run on one lane in the
 // reference's order, everything else one lane per frame):
@@ -14,144 +14,334 @@
 //       driven exactly as the shim drives it: one (setSpeed, write frameStep samples) pair per tension
 //       frame (soniclib.c:354,369), the un-analysed tail at the last speed (soniclib.c:538-550), then
 //       sonicIntFlushStream (soniclib.c:551).
+//
+// How a pitch step maps to the hardware:
+//   * the input lives in an LDS sliding window (int16, refilled with coalesced loads every ~25 steps), so a
+//     step touches HBM only to store its 2n output bytes; the stores are never waited for (the workgroup
+//     barrier used here drains lgkmcnt only);
+//   * the search signals are kept in LDS as u16 biased by 32768, twice (once shifted by a sample), so that
+//     any lag reads two aligned sample PAIRS per ds_read_b32 and one v_sad_u16 adds two |a-b| terms;
+//   * the lags x sample-pairs space is spread over all lanes; partial sums meet in LDS with ds_add_u32;
+//   * arg-min / arg-max of diff/lag: float ratios, DPP wave reduction, then an exact integer resolve of
+//     the few lanes within 2^-16 of the extremum on the scalar unit (ties -> smallest lag, as a sequential
+//     scan would);  every wave does this redundantly, so no broadcast barrier is needed.
 // All sample arithmetic is integer; results are bit-exact against oracle/orc_sonic.c.
+#include <stdlib.h>
+
 #include "spx_internal.h"
 
 #define SPX_CH 1024  // frames per prologue chunk held in LDS
 
 typedef SpxWalkState WalkState;
 
-struct Cand {  // AMDF candidate: diff over `p` terms
-  unsigned diff;
-  int p;  // 0 = empty
-};
+// Diagnostic build only (-DSPX_STAMPS): per-phase shader-cycle sums of workgroup 0, lane 0.  Never in the product.
+#ifdef SPX_STAMPS
+__device__ unsigned long long g_spx_stamps[32];
+#define STAMP_DECL                                         \
+  for (int i_ = 0; i_ < 16; i_++) X.stamp_acc[i_] = 0;     \
+  X.stamp_last = __builtin_readcyclecounter();
+#define STAMP(i)                                                          \
+  do {                                                                    \
+    const unsigned long long t_ = __builtin_readcyclecounter();           \
+    X.stamp_acc[i] += t_ - X.stamp_last;                                  \
+    X.stamp_last = t_;                                                    \
+  } while (0)
+#define STAMP_FLUSH                                                                              \
+  if (threadIdx.x == 0 && blockIdx.x == 0)                                                       \
+    for (int i_ = 0; i_ < 16; i_++) g_spx_stamps[i_] += X.stamp_acc[i_];
+extern "C" void spx_debug_stamps(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spx_stamps), sizeof(unsigned long long) * 32);
+  if (reset) {
+    unsigned long long z[32] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spx_stamps), z, sizeof(z));
+  }
+}
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
 
-__device__ __forceinline__ Cand cand_min(Cand a, Cand b) {
-  if (b.p == 0) return a;
-  if (a.p == 0) return b;
-  const unsigned long long l = (unsigned long long)a.diff * (unsigned)b.p;
-  const unsigned long long r = (unsigned long long)b.diff * (unsigned)a.p;
-  if (l < r) return a;
-  if (r < l) return b;
-  return a.p < b.p ? a : b;
+template <int NW>
+__device__ __forceinline__ void lds_sync() {
+  if (NW > 1) {
+    // LDS-only workgroup barrier: outstanding global stores stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
 }
-__device__ __forceinline__ Cand cand_max(Cand a, Cand b) {
-  if (b.p == 0) return a;
-  if (a.p == 0) return b;
-  const unsigned long long l = (unsigned long long)a.diff * (unsigned)b.p;
-  const unsigned long long r = (unsigned long long)b.diff * (unsigned)a.p;
-  if (l > r) return a;
-  if (r > l) return b;
-  return a.p < b.p ? a : b;
+
+// ---- wave-level float min / max over 64 lanes (DPP inside rows of 16, readlane across rows) ----
+#define SPX_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+__device__ __forceinline__ float wave_min_f(float v) {
+  v = fminf(v, SPX_DPP(v, 0xB1));   // quad_perm [1,0,3,2]
+  v = fminf(v, SPX_DPP(v, 0x4E));   // quad_perm [2,3,0,1]
+  v = fminf(v, SPX_DPP(v, 0x141));  // row_half_mirror
+  v = fminf(v, SPX_DPP(v, 0x140));  // row_mirror
+  const int iv = __builtin_bit_cast(int, v);
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+  return fminf(fminf(a, b), fminf(c, d));
 }
-__device__ __forceinline__ Cand cand_shfl_xor(Cand c, int m) {
-  Cand o;
-  o.diff = (unsigned)__shfl_xor((int)c.diff, m);
-  o.p = __shfl_xor(c.p, m);
-  return o;
+__device__ __forceinline__ float wave_max_f(float v) {
+  v = fmaxf(v, SPX_DPP(v, 0xB1));
+  v = fmaxf(v, SPX_DPP(v, 0x4E));
+  v = fmaxf(v, SPX_DPP(v, 0x141));
+  v = fmaxf(v, SPX_DPP(v, 0x140));
+  const int iv = __builtin_bit_cast(int, v);
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
 
 struct WalkCtx {
   const int16_t* in;  // stream input (interleaved)
   int16_t* out;       // stream output
   int64_t out_cap;
-  int64_t zero_from;  // absolute frame index from which reads return 0 (flush padding)
+  int64_t limit;      // absolute frame index from which reads return 0 (end of input / flush padding)
   int C;
-  short* sMono;       // [maxRequired] mono mix of the current window
-  short* sDown;       // [maxRequired/skip] decimated window
-  Cand* sCand;        // [8] per-wave partial results
+  // LDS sliding window over frames [wbase, wbase + wcap)
+  unsigned short* monoH;   // mono mix biased by 32768: monoH[k] = mono(wbase + k) + 32768
+  unsigned short* monoHB;  // the same shifted by one frame: monoHB[k] = monoH[k + 1]
+  short* raw;              // interleaved raw samples, only kept when C > 1 (the cross-fade is per channel)
+  int64_t wbase;           // -1 = window invalid
+  int wcap;
+  unsigned short* dnH;     // biased decimated signal of the current step (and its shifted copy)
+  unsigned short* dnHB;
+  unsigned* diffC;    // per-lag AMDF sums, coarse search
+  unsigned* diffR;    // per-lag AMDF sums, refine search
+#ifdef SPX_STAMPS
+  unsigned long long stamp_last;
+  unsigned long long stamp_acc[16];
+#endif
 };
 
-__device__ __forceinline__ int raw_sample(const WalkCtx& X, int64_t a, int c) {
-  return (a < X.zero_from) ? (int)X.in[a * X.C + c] : 0;
+__device__ __forceinline__ int global_sample(const WalkCtx& X, int64_t a, int c) {
+  return (a < X.limit) ? (int)X.in[a * X.C + c] : 0;
+}
+// sample through the LDS window when it covers frame a, else from HBM
+__device__ __forceinline__ int any_sample(const WalkCtx& X, int64_t a, int c) {
+  const int64_t o = a - X.wbase;
+  if (X.wbase >= 0 && o >= 0 && o < X.wcap) {
+    if (X.C == 1) return (int)X.monoH[o] - 32768;
+    return (int)X.raw[o * X.C + c];
+  }
+  return global_sample(X, a, c);
 }
 
-// AMDF over lags [minP, maxP] on x (LDS).  Returns best/worst exactly as a sequential scan that keeps the
-// FIRST lag with the smallest (largest) diff/lag would.  4 lanes per lag, 64 lags per pass.
-__device__ __forceinline__ void amdf_search(const WalkCtx& X, const short* x, int minP, int maxP, int* retBest, int* retMin,
-                            int* retMax) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = tid & 3;
-  Cand bmin = {0u, 0}, bmax = {0u, 0};
-  for (int l0 = 0; minP + l0 <= maxP; l0 += 64) {
-    const int p = minP + l0 + (tid >> 2);
-    unsigned acc = 0;
-    if (p <= maxP) {
-      for (int i = q; i < p; i += 4) {
-        const int d = (int)x[i] - (int)x[i + p];
-        acc += (unsigned)(d < 0 ? -d : d);
+// Make the window cover [pos, pos + need).  Uniform across the workgroup.  The biased mono signal and its
+// shifted copy are built here, once per refill, so a pitch step never touches HBM for its input.
+template <int NW>
+__device__ __forceinline__ void ensure_window(WalkCtx& X, int64_t pos, int need) {
+  constexpr int NT = 64 * NW;
+  if (X.wbase >= 0 && pos >= X.wbase && pos + need <= X.wbase + X.wcap) return;
+  lds_sync<NW>();  // everyone is done reading the old window
+  const int64_t nb = pos & ~(int64_t)7;
+  const int C = X.C;
+  if (C == 1) {
+    const int16_t* __restrict__ src = X.in + nb;
+    const int64_t room = X.limit - nb;  // frames of real input from nb on
+    for (int k0 = threadIdx.x; k0 < X.wcap + 1; k0 += 8 * NT) {
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {  // eight coalesced loads in flight before the first LDS write
+        const int k = k0 + u * NT;
+        v[u] = (k < X.wcap + 1 && k < room) ? (int)src[k] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int k = k0 + u * NT;
+        const unsigned short w = (unsigned short)(v[u] + 32768);
+        if (k < X.wcap) X.monoH[k] = w;
+        if (k > 0 && k < X.wcap + 1) X.monoHB[k - 1] = w;
       }
     }
-    acc += (unsigned)__shfl_xor((int)acc, 1);
-    acc += (unsigned)__shfl_xor((int)acc, 2);
-    Cand c = {acc, (p <= maxP && q == 0) ? p : 0};
-    Cand cmn = c, cmx = c;
-    for (int m = 4; m < 64; m <<= 1) {
-      cmn = cand_min(cmn, cand_shfl_xor(cmn, m));
-      cmx = cand_max(cmx, cand_shfl_xor(cmx, m));
-    }
-    __syncthreads();  // previous users of sCand are done
-    if (lane == 0) {
-      X.sCand[wave] = cmn;
-      X.sCand[4 + wave] = cmx;
-    }
-    __syncthreads();
-    for (int w = 0; w < 4; w++) {
-      bmin = cand_min(bmin, X.sCand[w]);
-      bmax = cand_max(bmax, X.sCand[4 + w]);
+  } else {
+    for (int k = threadIdx.x; k < X.wcap + 1; k += NT) {
+      const int64_t g = nb + k;
+      int sum = 0;
+      for (int c = 0; c < C; c++) {
+        const int v = (g < X.limit) ? (int)X.in[g * C + c] : 0;
+        if (k < X.wcap) X.raw[(size_t)k * C + c] = (short)v;
+        sum += v;
+      }
+      const unsigned short u = (unsigned short)(sum / C + 32768);
+      if (k < X.wcap) X.monoH[k] = u;
+      if (k > 0) X.monoHB[k - 1] = u;
     }
   }
-  // sequential-scan initial state for the maximum is (maxDiff = 0, worstPeriod = 255): it is only replaced
-  // by a lag with diff > 0.
-  int worst = 255;
-  unsigned maxDiff = 0;
-  if (bmax.p != 0 && bmax.diff > 0) {
-    worst = bmax.p;
-    maxDiff = bmax.diff;
+  X.wbase = nb;
+  lds_sync<NW>();
+}
+
+// AMDF partial sums for lags minP .. minP+nl-1 over a biased u16 signal that starts `o` samples into the
+// arrays (A0 = dword view of the signal array, A1 = dword view of its copy shifted by one sample), added into
+// diff[l].  Terms are taken in pairs (i = 2j, 2j+1): a = s[2j..2j+1], b = s[2j+p..2j+p+1]; whichever of the two
+// views makes the pair dword-aligned is used.  For odd p the last pair holds one valid term and is masked.
+// Each (lag, part) item owns a contiguous run of pairs and keeps four LDS reads in flight.
+template <int NW>
+__device__ __forceinline__ void amdf_accumulate(const unsigned* A0, const unsigned* A1, int o, int minP, int nl,
+                                                unsigned* diff) {
+  constexpr int NT = 64 * NW;
+  int parts = NT / nl;
+  if (parts < 1) parts = 1;
+  if (parts > 16) parts = 16;
+  const int items = nl * parts;
+  const float inv_nl = 1.0f / (float)nl;
+  const float inv_parts = 1.0f / (float)parts;
+  const unsigned* ap = (o & 1) ? A1 + ((o - 1) >> 1) : A0 + (o >> 1);
+  for (int item = threadIdx.x; item < items; item += NT) {
+    const int q = (int)(((float)item + 0.5f) * inv_nl);
+    const int l = item - q * nl;
+    const int p = minP + l;
+    const int ob = o + p;
+    const unsigned* bp = (ob & 1) ? A1 + ((ob - 1) >> 1) : A0 + (ob >> 1);
+    const int nfull = p >> 1;
+    const int chunk = (int)(((float)(nfull + parts - 1) + 0.5f) * inv_parts);
+    int j = q * chunk;
+    int j1 = j + chunk;
+    if (j1 > nfull) j1 = nfull;
+    unsigned acc = 0;
+    for (; j < j1; j += 8) {  // eight pairs per trip, all sixteen LDS reads in flight; lanes past j1 add |a-a| = 0
+      unsigned a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const bool ok = j + u < j1;
+        const int k = ok ? j + u : j;
+        a[u] = ap[k];
+        b[u] = (ok ? bp : ap)[k];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_sad_u16(a[u], b[u], acc);
+    }
+    if ((p & 1) && q == parts - 1)  // the lone term i = p-1
+      acc = __builtin_amdgcn_sad_u16(ap[nfull] & 0xffffu, bp[nfull] & 0xffffu, acc);
+    atomicAdd(&diff[l], acc);
   }
-  *retBest = bmin.p;
-  *retMin = (int)(bmin.diff / (unsigned)bmin.p);
-  *retMax = (int)(maxDiff / (unsigned)worst);
+}
+
+// Arg-min and arg-max of diff[l]/(minP+l), l < nl, exactly as the dependency's sequential scan decides them:
+// the FIRST lag with the smallest ratio; the first lag with the largest ratio, starting from (0, 255).
+// Every lane returns the same values.
+__device__ __forceinline__ void amdf_select(const unsigned* diff, int minP, int nl, int* retBest, int* retMin,
+                                            int* retMax) {
+  const int lane = threadIdx.x & 63;
+  unsigned bestD = 0, worstD = 0;
+  int bestP = 0, worstP = 0;
+  for (int base = 0; base < nl; base += 64) {
+    const int l = base + lane;
+    const bool valid = l < nl;
+    const unsigned d = valid ? diff[l] : 0u;
+    const int p = minP + l;
+    const float r = (float)d * __builtin_amdgcn_rcpf((float)p);  // within 2^-21 of d/p; resolved exactly below
+    const float rmin = wave_min_f(valid ? r : __builtin_huge_valf());
+    const float rmax = wave_max_f(valid ? r : -1.0f);
+    unsigned long long mmin = __ballot(valid && r <= rmin * 1.0000153f);  // 1 + 2^-16
+    unsigned long long mmax = __ballot(valid && r >= rmax * 0.9999847f);
+    while (mmin) {  // exact integer resolve, ascending lag order, strict '<' keeps the first
+      const int i = __builtin_ctzll(mmin);
+      mmin &= mmin - 1;
+      const unsigned di = (unsigned)__builtin_amdgcn_readlane((int)d, i);
+      const int pi = minP + base + i;
+      if (bestP == 0 || (unsigned long long)di * (unsigned)bestP < (unsigned long long)bestD * (unsigned)pi) {
+        bestD = di;
+        bestP = pi;
+      }
+    }
+    while (mmax) {
+      const int i = __builtin_ctzll(mmax);
+      mmax &= mmax - 1;
+      const unsigned di = (unsigned)__builtin_amdgcn_readlane((int)d, i);
+      const int pi = minP + base + i;
+      if (worstP == 0 || (unsigned long long)di * (unsigned)worstP > (unsigned long long)worstD * (unsigned)pi) {
+        worstD = di;
+        worstP = pi;
+      }
+    }
+  }
+  if (worstD == 0) worstP = 255;  // the scan's initial (maxDiff = 0, worstPeriod = 255) survives
+  *retBest = bestP;
+  *retMin = (int)(bestD / (unsigned)bestP);
+  *retMax = (int)(worstD / (unsigned)worstP);
 }
 
 // findPitchPeriod at absolute position pos (all threads return the same value).
-__device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, const WalkCtx& X, WalkState& st, int64_t pos) {
+template <int NW>
+__device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X, WalkState& st, int64_t pos) {
+  constexpr int NT = 64 * NW;
   const int tid = threadIdx.x;
   const int C = X.C, skip = P.skip, maxRequired = P.maxRequired;
-  __syncthreads();  // earlier readers of sMono/sDown are done
-  for (int t = tid; t < maxRequired; t += SPX_BLOCK) {
-    int v;
-    if (C == 1) {
-      v = raw_sample(X, pos + t, 0);
-    } else {
+  STAMP(1);
+  ensure_window<NW>(X, pos, maxRequired + 2 * skip + 2);
+  STAMP(2);
+  const int o = (int)(pos - X.wbase);
+  const bool direct = (C == 1 && skip == 1);
+  // ---- phase B: the decimated, biased search signal of this step (earlier readers are past a barrier) ----
+  const int cnt = maxRequired / skip;
+  if (!direct) {
+    const int div = skip * C;
+    const double inv = 1.0 / (double)div;
+    for (int t = tid; t < cnt + 2; t += NT) {
       int sum = 0;
-      for (int c = 0; c < C; c++) sum += raw_sample(X, pos + t, c);
-      v = sum / C;
+      if (C == 1) {
+        const unsigned short* w = X.monoH + o + t * skip;
+        for (int j = 0; j < skip; j++) sum += (int)w[j];
+        sum -= 32768 * skip;
+      } else {
+        const short* w = X.raw + (size_t)(o + t * skip) * C;
+        for (int j = 0; j < div; j++) sum += w[j];
+      }
+      // truncating sum / div via the exact double-reciprocal form (see emit_overlap_add)
+      const int mag = sum < 0 ? -sum : sum;
+      const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
+      const unsigned short u = (unsigned short)((sum < 0 ? -qm : qm) + 32768);
+      X.dnH[t] = u;
+      if (t > 0) X.dnHB[t - 1] = u;
     }
-    X.sMono[t] = (short)v;
   }
-  if (skip > 1 || C > 1) {
-    const int cnt = maxRequired / skip;
-    for (int t = tid; t < cnt; t += SPX_BLOCK) {
-      int sum = 0;
-      for (int j = 0; j < skip; j++)
-        for (int c = 0; c < C; c++) sum += raw_sample(X, pos + (int64_t)t * skip + j, c);
-      X.sDown[t] = (short)(sum / (skip * C));
-    }
-  }
-  __syncthreads();
+  STAMP(3);
+  lds_sync<NW>();
+  STAMP(4);
+  // ---- phase D: first search; the refine accumulators are cleared here (their readers are all done) ----
+  for (int t = tid; t < 256; t += NT) X.diffR[t] = 0;
   int period, minDiff, maxDiff;
-  if (C == 1 && skip == 1) {
-    amdf_search(X, X.sMono, P.minPeriod, P.maxPeriod, &period, &minDiff, &maxDiff);
+  const int minC = direct ? P.minPeriod : P.minPeriod / skip;
+  const int maxC = direct ? P.maxPeriod : P.maxPeriod / skip;
+  const unsigned* M0 = reinterpret_cast<const unsigned*>(X.monoH);
+  const unsigned* M1 = reinterpret_cast<const unsigned*>(X.monoHB);
+  if (direct)
+    amdf_accumulate<NW>(M0, M1, o, minC, maxC - minC + 1, X.diffC);
+  else
+    amdf_accumulate<NW>(reinterpret_cast<const unsigned*>(X.dnH), reinterpret_cast<const unsigned*>(X.dnHB), 0, minC,
+                        maxC - minC + 1, X.diffC);
+  STAMP(5);
+  lds_sync<NW>();
+  STAMP(6);
+  amdf_select(X.diffC, minC, maxC - minC + 1, &period, &minDiff, &maxDiff);
+  STAMP(7);
+  if (!direct && skip != 1) {
+    period *= skip;
+    int lo = period - (skip << 2), hi = period + (skip << 2);
+    if (lo < P.minPeriod) lo = P.minPeriod;
+    if (hi > P.maxPeriod) hi = P.maxPeriod;
+    // ---- phase G: refine at full rate ----
+    amdf_accumulate<NW>(M0, M1, o, lo, hi - lo + 1, X.diffR);
+    STAMP(8);
+    lds_sync<NW>();
+    STAMP(9);
+    for (int t = tid; t < 256; t += NT) X.diffC[t] = 0;
+    amdf_select(X.diffR, lo, hi - lo + 1, &period, &minDiff, &maxDiff);
+    STAMP(10);
   } else {
-    amdf_search(X, X.sDown, P.minPeriod / skip, P.maxPeriod / skip, &period, &minDiff, &maxDiff);
-    if (skip != 1) {
-      period *= skip;
-      int lo = period - (skip << 2), hi = period + (skip << 2);
-      if (lo < P.minPeriod) lo = P.minPeriod;
-      if (hi > P.maxPeriod) hi = P.maxPeriod;
-      amdf_search(X, X.sMono, lo, hi, &period, &minDiff, &maxDiff);
-    }
+    lds_sync<NW>();
+    for (int t = tid; t < 256; t += NT) X.diffC[t] = 0;
   }
   int ret = period;
   if (!(minDiff == 0 || st.prevPeriod == 0) && !(maxDiff > minDiff * 3) && !(minDiff * 2 <= st.prevMinDiff * 3))
@@ -162,32 +352,71 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, const Walk
 }
 
 // Append n frames copied from absolute input position a.
+template <int NW>
 __device__ __forceinline__ void emit_copy(const WalkCtx& X, WalkState& st, int64_t a, int64_t n) {
+  constexpr int NT = 64 * NW;
   const int C = X.C;
   if (st.out_n + n > X.out_cap) st.overflow = 1;
-  const int64_t total = n * C;
-  for (int64_t e = threadIdx.x; e < total; e += SPX_BLOCK) {
-    const int64_t f = e / C;
-    const int c = (int)(e - f * C);
-    if (st.out_n + f < X.out_cap) X.out[(st.out_n + f) * C + c] = (int16_t)raw_sample(X, a + f, c);
+  int64_t nv = X.out_cap - st.out_n;  // frames that still fit
+  if (nv > n) nv = n;
+  const int64_t o = a - X.wbase;
+  int16_t* __restrict__ dst = X.out + st.out_n * C;
+  if (C == 1 && X.wbase >= 0 && o >= 0 && o + n <= X.wcap) {  // whole run inside the LDS window
+    const unsigned short* w = X.monoH + o;
+    for (int t = threadIdx.x; t < (int)nv; t += NT) dst[t] = (int16_t)((int)w[t] - 32768);
+  } else {
+    const int64_t total = nv * C;
+    for (int64_t e = threadIdx.x; e < total; e += NT) {
+      int64_t f = e;
+      int c = 0;
+      if (C != 1) { f = e / C; c = (int)(e - f * C); }
+      dst[e] = (int16_t)any_sample(X, a + f, c);
+    }
   }
   st.out_n += n;
 }
 
-// Append n frames of cross-fade: out[t] = (down[t]*(n-t) + up[t]*t)/n, integer, truncating.
-__device__ __forceinline__ void emit_overlap_add(const WalkCtx& X, WalkState& st, int64_t a_down, int64_t a_up, int n,
-                                 int64_t out_at) {
+// Append n frames of cross-fade: out[t] = (down[t]*(n-t) + up[t]*t)/n, integer, truncating toward zero.
+// |numerator| <= 32768*n < 2^31; the quotient is taken as trunc(|num| * (1/n) + 2^-20) in double, which is exact:
+// non-integer quotients are at least 1/n >= 2^-11 below the next integer, integer ones land 2^-20 above.
+template <int NW>
+__device__ __forceinline__ void emit_overlap_add(const WalkCtx& X, int64_t a_down, int64_t a_up, int n,
+                                                 int64_t out_at) {
+  constexpr int NT = 64 * NW;
   const int C = X.C;
-  const int total = n * C;
-  for (int e = threadIdx.x; e < total; e += SPX_BLOCK) {
-    const int t = e / C, c = e - t * C;
-    const int d = raw_sample(X, a_down + t, c), u = raw_sample(X, a_up + t, c);
-    if (out_at + t < X.out_cap) X.out[(out_at + t) * C + c] = (int16_t)((d * (n - t) + u * t) / n);
+  const double inv = 1.0 / (double)n;
+  int64_t nv64 = X.out_cap - out_at;
+  const int nv = nv64 > n ? n : (nv64 < 0 ? 0 : (int)nv64);
+  int16_t* __restrict__ dst = X.out + out_at * C;
+  const int64_t od = a_down - X.wbase, ou = a_up - X.wbase;
+  const bool inwin = X.wbase >= 0 && od >= 0 && ou >= 0 && od + n <= X.wcap && ou + n <= X.wcap;
+  if (C == 1 && inwin) {
+    const unsigned short* wd = X.monoH + od;
+    const unsigned short* wu = X.monoH + ou;
+    for (int t = threadIdx.x; t < nv; t += NT) {
+      const int d = (int)wd[t] - 32768, u = (int)wu[t] - 32768;
+      const int num = d * (n - t) + u * t;
+      const int mag = num < 0 ? -num : num;
+      const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
+      dst[t] = (int16_t)(num < 0 ? -qm : qm);
+    }
+  } else {
+    const int total = nv * C;
+    for (int e = threadIdx.x; e < total; e += NT) {
+      int t = e, c = 0;
+      if (C != 1) { t = e / C; c = e - t * C; }
+      const int d = any_sample(X, a_down + t, c), u = any_sample(X, a_up + t, c);
+      const int num = d * (n - t) + u * t;
+      const int mag = num < 0 ? -num : num;
+      const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
+      dst[e] = (int16_t)(num < 0 ? -qm : qm);
+    }
   }
 }
 
 // processStreamInput with `avail` frames handed over so far (absolute count).
-__device__ __forceinline__ void tsm_process(const SpxPlanDev& P, const WalkCtx& X, WalkState& st, float speed, int64_t avail) {
+template <int NW>
+__device__ __forceinline__ void tsm_process(const SpxPlanDev& P, WalkCtx& X, WalkState& st, float speed, int64_t avail) {
   const int maxRequired = P.maxRequired;
   if ((double)speed > 1.00001 || (double)speed < 0.99999) {
     const int64_t numSamples = avail - st.base;
@@ -197,64 +426,98 @@ __device__ __forceinline__ void tsm_process(const SpxPlanDev& P, const WalkCtx& 
       if (st.remaining > 0) {
         int n = st.remaining;
         if (n > maxRequired) n = maxRequired;
-        emit_copy(X, st, st.base + position, n);
+        emit_copy<NW>(X, st, st.base + position, n);
         st.remaining -= n;
         position += n;
       } else {
         const int64_t pos = st.base + position;
-        const int period = find_pitch_period(P, X, st, pos);
+        const int period = find_pitch_period<NW>(P, X, st, pos);
         if ((double)speed > 1.0) {
-          long n;
+          int n;  // the dependency converts to long; every value here fits an int
           if (speed >= 2.0f) {
-            n = (long)((float)period / (speed - 1.0f));
+            n = (int)((float)period / (speed - 1.0f));
           } else {
             n = period;
             st.remaining = (int)((float)period * (2.0f - speed) / (speed - 1.0f));
           }
           if (st.out_n + n > X.out_cap) st.overflow = 1;
-          emit_overlap_add(X, st, pos, pos + period, (int)n, st.out_n);
-          st.out_n += n;
           if (n == 0) return;  // the dependency treats this as failure and leaves the input untouched
+          STAMP(11);
+          emit_overlap_add<NW>(X, pos, pos + period, n, st.out_n);
+          STAMP(13);
+          st.out_n += n;
           position += period + n;
         } else {
-          long n;
+          int n;
           if (speed < 0.5f) {
-            n = (long)((float)period * speed / (1.0f - speed));
+            n = (int)((float)period * speed / (1.0f - speed));
           } else {
             n = period;
             st.remaining = (int)((float)period * (2.0f * speed - 1.0f) / (1.0f - speed));
           }
-          emit_copy(X, st, pos, period);
+          emit_copy<NW>(X, st, pos, period);
           if (st.out_n + n > X.out_cap) st.overflow = 1;
-          emit_overlap_add(X, st, pos + period, pos, (int)n, st.out_n);
-          st.out_n += n;
           if (n == 0) return;
+          emit_overlap_add<NW>(X, pos + period, pos, n, st.out_n);
+          st.out_n += n;
           position += n;
         }
       }
     } while (position + maxRequired <= numSamples);
     st.base += position;
   } else {
-    emit_copy(X, st, st.base, avail - st.base);
+    emit_copy<NW>(X, st, st.base, avail - st.base);
     st.base = avail;
   }
 }
 
-__global__ void __launch_bounds__(SPX_BLOCK)
+// LDS layout (bytes), shared by host and device
+struct WalkLds {
+  int off_sA, off_sB, off_mono, off_monoB, off_raw, off_dn, off_dnB, off_diffC, off_diffR, total, wcap;
+};
+static __host__ __device__ inline WalkLds walk_lds_layout(const SpxPlanDev& P, int maxC) {
+  WalkLds L;
+  const int need = P.maxRequired + 2 * P.skip + 2;
+  int wcap = 4096;
+  if (wcap < 4 * need) wcap = 4 * need;
+  while ((size_t)wcap * (maxC > 1 ? maxC + 2 : 2) * 2 > 48 * 1024 && wcap > need + 64) wcap /= 2;
+  wcap = (wcap + 7) & ~7;
+  L.wcap = wcap;
+  int o = 0;
+  L.off_sA = o; o += SPX_CH * 4;
+  L.off_sB = o;    // the prologue's second array aliases the (not yet used) window
+  L.off_mono = o;
+  const int mb = ((wcap + 8) * 2 + 15) & ~15;
+  o += mb;
+  L.off_monoB = o; o += mb;
+  L.off_raw = o;
+  if (maxC > 1) o += ((wcap + 1) * maxC * 2 + 15) & ~15;
+  if (o - L.off_sB < SPX_CH * 4) o = L.off_sB + SPX_CH * 4;
+  const int dnb = ((P.maxRequired / P.skip + 8) * 2 + 15) & ~15;
+  L.off_dn = o; o += dnb;
+  L.off_dnB = o; o += dnb;
+  L.off_diffC = o; o += 256 * 4;
+  L.off_diffR = o; o += 256 * 4;
+  L.total = o;
+  return L;
+}
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
 spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const int16_t* __restrict__ in_base,
                 int16_t* __restrict__ out_base, int64_t* __restrict__ n_out, SpxStreamState* __restrict__ states,
-                const SpxFrameRec* __restrict__ rec_base, float* __restrict__ scratch_base, SpxTapsDev taps) {
+                const SpxFrameRec* __restrict__ rec_base, float* __restrict__ scratch_base, SpxTapsDev taps,
+                int maxC) {
+  constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
   const SpxStreamDev S = streams[blockIdx.x];
   const int T = S.n_frames, F = P.F, Pp = P.Pp, B = P.B;
   const float Rg = S.speed, nl = S.nonlinear, fb = S.feedback;
 
-  float* sA = reinterpret_cast<float*>(lds);  // [SPX_CH]
-  float* sB = sA + SPX_CH;                    // [SPX_CH]
-  short* sMono = reinterpret_cast<short*>(sB + SPX_CH);
-  short* sDown = sMono + ((P.maxRequired + 7) & ~7);
-  Cand* sCand = reinterpret_cast<Cand*>(sDown + ((P.maxRequired + 7) & ~7));
+  const WalkLds LY = walk_lds_layout(P, maxC);
+  float* sA = reinterpret_cast<float*>(lds + LY.off_sA);  // [SPX_CH]
+  float* sB = reinterpret_cast<float*>(lds + LY.off_sB);  // [SPX_CH], aliases the window
 
   // ---- state carried between jobs of one stream ----
   SpxStreamState Z;
@@ -286,7 +549,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
     float lp = Z.lp;
     for (int c0 = fa; c0 < T; c0 += SPX_CH) {
       const int n = min(SPX_CH, T - c0);
-      for (int i = tid; i < n; i += SPX_BLOCK) sA[i] = rec[c0 + i].energy;
+      for (int i = tid; i < n; i += NT) sA[i] = rec[c0 + i].energy;
       __syncthreads();
       if (tid == 0) {
         for (int i = 0; i < n; i++) {
@@ -295,7 +558,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
         }
       }
       __syncthreads();
-      for (int i = tid; i < n; i += SPX_BLOCK) {
+      for (int i = tid; i < n; i += NT) {
         const float e = sA[i], l = sB[i];
         const float local = e / l;                                               // speedy.c:519
         const float comp = (float)__builtin_sqrt(local > 2 ? 2.0 : (double)local);  // speedy.c:520
@@ -312,7 +575,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
     }
     Z.lp = lp;
     // ---- pass 2: hysteresis and emphasis-weighted difference, one lane per tension frame ----
-    for (int k = K0 + tid; k < K; k += SPX_BLOCK) {
+    for (int k = K0 + tid; k < K; k += NT) {
       float future_max = 0.0f, past_max = 0.0f;
       for (int i = 0; i <= F; i++) {
         const int tau = k + i;  // hysteresis slot `tau` holds frame tau-1; slots <= 0 are the zero init
@@ -344,7 +607,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
     float lpf = Z.lpf;
     for (int c0 = K0; c0 < K; c0 += SPX_CH) {
       const int n = min(SPX_CH, K - c0);
-      for (int i = tid; i < n; i += SPX_BLOCK) sA[i] = scr[4 * (c0 + i) + 2];
+      for (int i = tid; i < n; i += NT) sA[i] = scr[4 * (c0 + i) + 2];
       __syncthreads();
       if (tid == 0) {
         for (int i = 0; i < n; i++) {
@@ -353,7 +616,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
         }
       }
       __syncthreads();
-      for (int i = tid; i < n; i += SPX_BLOCK) {
+      for (int i = tid; i < n; i += NT) {
         const int k = c0 + i;
         const float ewld = sA[i], l = sB[i];
         const float hyst = scr[4 * k + 1];
@@ -389,7 +652,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
     const float fd = (float)(1.0 / 100.0);  // speedy.c:783
     for (int c0 = K0; c0 < K; c0 += SPX_CH) {
       const int n = min(SPX_CH, K - c0);
-      for (int i = tid; i < n; i += SPX_BLOCK) sA[i] = scr[4 * (c0 + i) + 3];
+      for (int i = tid; i < n; i += NT) sA[i] = scr[4 * (c0 + i) + 3];
       __syncthreads();
       if (tid == 0) {
         for (int i = 0; i < n; i++) {
@@ -408,7 +671,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
       __syncthreads();
       cur_dur = sA[0];
       des_dur = sA[1];
-      for (int i = tid; i < n; i += SPX_BLOCK) {
+      for (int i = tid; i < n; i += NT) {
         scr[4 * (c0 + i) + 3] = sB[i];
         if (taps.speed) taps.speed[S.frame_off + c0 + i] = sB[i];
       }
@@ -419,16 +682,27 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   }
   __syncthreads();
 
+  __syncthreads();
+
   // ---------------------------------- the TSM walk ----------------------------------
   WalkCtx X;
   X.in = in_base + S.in_off;
   X.out = out_base + S.out_off;
   X.out_cap = S.out_cap;
-  X.zero_from = INT64_MAX;
+  X.limit = S.n_in;
   X.C = S.channels;
-  X.sMono = sMono;
-  X.sDown = sDown;
-  X.sCand = sCand;
+  X.monoH = reinterpret_cast<unsigned short*>(lds + LY.off_mono);
+  X.monoHB = reinterpret_cast<unsigned short*>(lds + LY.off_monoB);
+  X.raw = reinterpret_cast<short*>(lds + LY.off_raw);
+  X.wbase = -1;
+  X.wcap = LY.wcap;
+  X.dnH = reinterpret_cast<unsigned short*>(lds + LY.off_dn);
+  X.dnHB = reinterpret_cast<unsigned short*>(lds + LY.off_dnB);
+  X.diffC = reinterpret_cast<unsigned*>(lds + LY.off_diffC);
+  X.diffR = reinterpret_cast<unsigned*>(lds + LY.off_diffR);
+  for (int t = tid; t < 256; t += NT) { X.diffC[t] = 0; X.diffR[t] = 0; }
+  __syncthreads();
+  STAMP_DECL
   WalkState st = Z.w;
   float curSpeed = Z.curSpeed;
   int64_t avail = st.avail;
@@ -453,7 +727,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
           if (i == 0) {  // stage the next chunk of speeds in LDS
             __syncthreads();
             const int n = (int)min((int64_t)SPX_CH, (int64_t)K - ev);
-            for (int t = tid; t < n; t += SPX_BLOCK) sA[t] = scr[4 * (ev + t) + 3];
+            for (int t = tid; t < n; t += NT) sA[t] = scr[4 * (ev + t) + 3];
             __syncthreads();
           }
           curSpeed = sA[i];
@@ -465,16 +739,21 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
     } else {
       const int64_t remainingS = avail - st.base;
       expected = st.out_n + (int)(((float)remainingS / curSpeed + 0) / 1.0f + 0.5f);
-      X.zero_from = avail;
+      X.limit = avail;  // everything from here on reads as the flush's zero padding
+      lds_sync<NW>();
+      X.wbase = -1;     // the window may hold samples past the new limit
       avail += 2 * P.maxRequired;
     }
-    tsm_process(P, X, st, curSpeed, avail);
+    STAMP(0);
+    tsm_process<NW>(P, X, st, curSpeed, avail);
+    STAMP(12);
     if (ev >= ev1) {
       if (st.out_n > expected) st.out_n = expected;
       st.base = avail;  // the dependency empties its input after a flush
       st.remaining = 0;
     }
   }
+  STAMP_FLUSH
   if (tid == 0) {
     st.avail = avail;
     Z.w = st;
@@ -485,15 +764,25 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   }
 }
 
-static size_t walk_lds_bytes(const SpxPlanDev& P) {
-  size_t mr = (size_t)((P.maxRequired + 7) & ~7);
-  return 2 * SPX_CH * sizeof(float) + 2 * mr * sizeof(short) + 8 * sizeof(Cand) + 16;
-}
-
-void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, const int16_t* in,
+void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int maxC, const int16_t* in,
                      int16_t* out, int64_t* n_out, SpxStreamState* states, const SpxFrameRec* rec,
                      float* scratch, SpxTapsDev taps, hipStream_t st) {
   if (n_streams <= 0) return;
-  hipLaunchKernelGGL(spx_walk_kernel, dim3(n_streams), dim3(SPX_BLOCK), walk_lds_bytes(P), st, P, streams,
-                     in, out, n_out, states, rec, scratch, taps);
+  if (maxC < 1) maxC = 1;
+  const WalkLds LY = walk_lds_layout(P, maxC);
+  // Waves per stream: few streams -> several waves per stream use the otherwise idle SIMDs; many streams -> one
+  // wave each and more streams per CU.  SPX_WALK_NW overrides (tuning only).
+  int nw = (n_streams <= 1024) ? 4 : 1;
+  if (const char* e = getenv("SPX_WALK_NW")) nw = atoi(e);
+#define SPX_LAUNCH_WALK(NWV)                                                                                     \
+  hipLaunchKernelGGL(spx_walk_kernel<NWV>, dim3(n_streams), dim3(64 * NWV), LY.total, st, P, streams, in, out,    \
+                     n_out, states, rec, scratch, taps, maxC)
+  switch (nw) {
+    case 1: SPX_LAUNCH_WALK(1); break;
+    case 2: SPX_LAUNCH_WALK(2); break;
+    case 8: SPX_LAUNCH_WALK(8); break;
+    case 16: SPX_LAUNCH_WALK(16); break;
+    default: SPX_LAUNCH_WALK(4); break;
+  }
+#undef SPX_LAUNCH_WALK
 }
