@@ -1,0 +1,76 @@
+"""CPU-only: the C-ABI library builds for gfx950, loads, and exports every function include/*.h declares.
+No compute call is made (there is no GPU here); the product has no CPU path and must say so."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    txt = re.sub(r"typedef[^;]*\(\s*\*\s*\w+\s*\)\s*\([^;]*\)\s*;", "", txt)  # function-pointer typedefs
+    names = re.findall(r"\b([A-Za-z_]\w*)\s*\([^;{]*\)\s*;", txt)
+    return sorted(set(n for n in names if n not in ("defined",)))
+
+
+@pytest.fixture(scope="module")
+def hiplib():
+    import speedy_amd
+    speedy_amd.build()
+    return speedy_amd.lib()
+
+
+@pytest.mark.parametrize("header", ["speedy_hip.h", "sonic2.h"])
+def test_every_declared_symbol_is_exported(hiplib, header):
+    names = declared_functions(header)
+    assert len(names) >= 15
+    raw = ctypes.CDLL(os.path.join(ROOT, "speedy_amd", "lib", "libspeedy_hip.so"))
+    missing = [n for n in names if not hasattr(raw, n)]
+    assert not missing, missing
+
+
+def test_python_binding_covers_the_headers():
+    from speedy_amd._lib import SYMBOLS
+    declared = set(declared_functions("speedy_hip.h")) | set(declared_functions("sonic2.h"))
+    assert declared <= set(SYMBOLS), sorted(declared - set(SYMBOLS))
+
+
+def test_reference_api_surface_present():
+    """Every function of the reference's public header (sonic2.h:54-125) exists with the same name."""
+    ref = ["sonicCreateStream", "sonicDestroyStream", "sonicWriteShortToStream", "sonicReadShortFromStream",
+           "sonicWriteFloatToStream", "sonicReadFloatFromStream", "sonicSetRate", "sonicSetSpeed", "sonicFlushStream",
+           "sonicEnableNonlinearSpeedup", "sonicSetDurationFeedbackStrength", "getSonicBufferSize",
+           "sonicTensionCallback", "getSonicTensionCallback", "sonicSpeedCallback", "getSonicSpeedCallback",
+           "sonicFeaturesCallback", "getSonicFeaturesCallback", "sonicSpectrogramCallback",
+           "getSonicSpectrogramCallback", "sonicNormalizedSpectrogramCallback",
+           "getSonicNormalizedSpectrogramCallback", "sonicSpectrogramSize"]
+    assert set(ref) <= set(declared_functions("sonic2.h"))
+
+
+def test_no_cpu_fallback(hiplib):
+    """Without a GPU the product refuses to run instead of silently computing on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from speedy_amd.batch import Plan
+    with pytest.raises(RuntimeError):
+        Plan(16000)
+    assert not hiplib.sonicCreateStream(16000, 1)
+    assert b"no HIP device" in hiplib.speedyHipLastError() or b"plan" in hiplib.speedyHipLastError()
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under speedy_amd/ may reference it."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "speedy_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                t = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle|#include\s+\"[^\"]*orc_|liborc", t, flags=re.M):
+                    bad.append(f)
+    assert not bad, bad

@@ -1,0 +1,216 @@
+"""GPU: the reference-compatible streaming API (include/sonic2.h) of the HIP library, driven exactly like the
+reference's own tests drive soniclib.c, compared with the oracle's restatement of that shim call for call."""
+import numpy as np
+import pytest
+
+import sonic_props as sp
+from util import read_wav
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_compress(x, rate, ch, speed, nonlinear, chunk=1024, mm=True, feedback=0.0):
+    from speedy_amd.sonic2 import time_compress
+    return time_compress(x, rate, ch, speed, nonlinear, feedback=feedback, chunk=chunk, match_matlab=mm)
+
+
+def _oracle_stream(orc, x, rate, ch, speed, nl, fb, mm, chunk):
+    """Write/read/flush/drain through the oracle shim, recording the read count after every write."""
+    L = orc.lib()
+    h = L.orc_sonicCreateStream(rate, ch, int(mm))
+    L.orc_sonicSetSpeed(h, speed)
+    L.orc_sonicEnableNonlinearSpeedup(h, nl)
+    L.orc_sonicSetDurationFeedbackStrength(h, fb)
+    outs, counts = [], []
+    buf = np.zeros(chunk * ch, np.int16)
+    n = x.size // ch
+    for pos in range(0, n, chunk):
+        seg = np.ascontiguousarray(x[pos * ch:(pos + chunk) * ch])
+        L.orc_sonicWriteShortToStream(h, orc.sptr(seg), seg.size // ch)
+        got = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), chunk)
+        counts.append(got)
+        outs.append(buf[: got * ch].copy())
+    L.orc_sonicFlushStream(h)
+    while True:
+        got = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), chunk)
+        if got == 0:
+            break
+        outs.append(buf[: got * ch].copy())
+    L.orc_sonicDestroyStream(h)
+    return np.concatenate(outs), counts
+
+
+@pytest.mark.parametrize("name,ch,speed,nl,fb,mm,chunk", [
+    ("tapestry.wav", 1, 3.5, 1.0, 0.0, False, 1000),   # compress_sound, speedy_wave.cc:199-231
+    ("tapestry.wav", 1, 3.0, 1.0, 0.1, True, 128),     # MeasureExcessDuration, speedy_test.cc:663-684
+    ("tapestry.wav", 1, 2.0, 0.0, 0.0, False, 1024),   # CompressSound, sonic_classic_test.cc:463-498
+    ("tapestry22050.wav", 1, 1.5, 1.0, 0.0, True, 333),
+    ("tapestry.wav", 2, 3.0, 1.0, 0.0, True, 128),     # duplicated stereo
+])
+def test_stream_equals_oracle_call_for_call(orc, name, ch, speed, nl, fb, mm, chunk):
+    """Same bytes AND the same number of frames readable after every single write."""
+    from speedy_amd.sonic2 import SonicStream
+    x, rate, _ = read_wav(name)
+    if ch == 2:
+        x = np.repeat(x, 2)
+    ref, ref_counts = _oracle_stream(orc, x, rate, ch, speed, nl, fb, mm, chunk)
+    s = SonicStream(rate, ch, mm)
+    s.set_speed(speed)
+    s.enable_nonlinear(nl)
+    s.set_feedback(fb)
+    assert s.buffer_size() == 0  # sonic_test.cc:496
+    outs, counts = [], []
+    n = x.size // ch
+    for pos in range(0, n, chunk):
+        assert s.write_short(x[pos * ch:(pos + chunk) * ch]) == 1
+        got = s.read_short(chunk)
+        counts.append(got.size // ch)
+        outs.append(got)
+    if nl != 0:
+        assert s.buffer_size() == rate // 100  # sonic_test.cc:500
+    assert s.flush() == 1
+    while True:
+        got = s.read_short(chunk)
+        if got.size == 0:
+            break
+        outs.append(got)
+    s.close()
+    assert counts == ref_counts
+    assert np.array_equal(np.concatenate(outs), ref)
+
+
+def test_callbacks_match_oracle(orc):
+    """The five monitoring callbacks (sonic2.h:104-125), in value and in call order."""
+    from speedy_amd.sonic2 import SonicStream
+    x, rate, ch = read_wav("tapestry.wav")
+    L = orc.lib()
+    ref = {"tension": [], "speed": [], "features": [], "spec": []}
+    h = L.orc_sonicCreateStream(rate, ch, 0)
+    n = L.orc_sonicSpectrogramSize(h)
+    cbs = [orc.TENSION_FN(lambda s, t, v: ref["tension"].append((t, v))),
+           orc.TENSION_FN(lambda s, t, v: ref["speed"].append((t, v))),
+           orc.FEATURES_FN(lambda s, t, p: ref["features"].append((t, np.ctypeslib.as_array(p, shape=(15,)).copy()))),
+           orc.FEATURES_FN(lambda s, t, p: ref["spec"].append((t, np.ctypeslib.as_array(p, shape=(n,)).copy())))]
+    L.orc_sonicTensionCallback(h, cbs[0])
+    L.orc_sonicSpeedCallback(h, cbs[1])
+    L.orc_sonicFeaturesCallback(h, cbs[2])
+    L.orc_sonicSpectrogramCallback(h, cbs[3])
+    L.orc_sonicSetSpeed(h, 3.5)
+    L.orc_sonicEnableNonlinearSpeedup(h, 1.0)
+    L.orc_sonicSetDurationFeedbackStrength(h, 0.0)
+    for pos in range(0, x.size, 1000):
+        seg = np.ascontiguousarray(x[pos:pos + 1000])
+        L.orc_sonicWriteShortToStream(h, orc.sptr(seg), seg.size)
+    L.orc_sonicDestroyStream(h)
+
+    got = {"tension": [], "speed": [], "features": [], "spec": [], "norm": []}
+    s = SonicStream(rate, ch, False)
+    s.set_speed(3.5)
+    s.enable_nonlinear(1.0)
+    s.set_feedback(0.0)
+    s.on_tension(lambda t, v: got["tension"].append((t, v)))
+    s.on_speed(lambda t, v: got["speed"].append((t, v)))
+    s.on_features(lambda t, f: got["features"].append((t, f)))
+    s.on_spectrogram(lambda t, f: got["spec"].append((t, f)))
+    s.on_normalized(lambda t, f: got["norm"].append((t, f)))
+    assert s.spectrogram_size() == n == 480
+    for pos in range(0, x.size, 1000):
+        s.write_short(x[pos:pos + 1000])
+    s.close()
+    assert len(got["tension"]) == len(ref["tension"]) == 303  # 314 analysis calls - F + 1
+    assert len(got["spec"]) == len(ref["spec"]) == 314
+    for key in ("tension", "speed"):
+        assert [t for t, _ in got[key]] == [t for t, _ in ref[key]]
+        assert np.array_equal(np.float32([v for _, v in got[key]]), np.float32([v for _, v in ref[key]]))
+    for key in ("features", "spec"):
+        assert [t for t, _ in got[key]] == [t for t, _ in ref[key]]
+        assert np.array_equal(np.array([v for _, v in got[key]]), np.array([v for _, v in ref[key]]))
+    assert [t for t, _ in got["tension"]][:3] == [0, 1, 2] and [t for t, _ in got["spec"]][:3] == [1, 2, 3]
+    assert len(got["norm"]) == 314
+
+
+def test_float_api(orc):
+    """sonicWriteFloatToStream / sonicReadFloatFromStream, nonlinear and linear scaling (soniclib.c:496)."""
+    from speedy_amd.sonic2 import SonicStream
+    x, rate, ch = read_wav("tapestry.wav")
+    xf = (x.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    L = orc.lib()
+    for nl in (1.0, 0.0):
+        h = L.orc_sonicCreateStream(rate, ch, 0)
+        L.orc_sonicSetSpeed(h, 2.5)
+        L.orc_sonicEnableNonlinearSpeedup(h, nl)
+        L.orc_sonicWriteFloatToStream(h, orc.fptr(xf), xf.size)
+        L.orc_sonicFlushStream(h)
+        buf = np.zeros(xf.size, np.float32)
+        nref = L.orc_sonicReadFloatFromStream(h, orc.fptr(buf), xf.size)
+        L.orc_sonicDestroyStream(h)
+        s = SonicStream(rate, ch, False)
+        s.set_speed(2.5)
+        s.enable_nonlinear(nl)
+        assert s.write_float(xf) == 1
+        s.flush()
+        out = s.read_float(xf.size)
+        s.close()
+        assert out.size == nref and np.array_equal(out, buf[:nref])
+
+
+def test_reference_property_tests_through_the_hip_api():
+    """sonic_classic_test.cc / sonic_test.cc properties on the product itself."""
+    comp = lambda x, rate, ch, speed, nl: _gpu_compress(x, rate, ch, speed, nl)  # noqa: E731
+    sp.check_sine_speed(comp, 3.0)
+    sp.check_sine_speed(comp, 0.5)
+    sp.check_mono_stereo_identity(comp, sp.sine_440(), 16000)
+    x, rate, _ = read_wav("tapestry.wav")
+    sp.check_mono_stereo_identity(comp, x, rate)
+    sp.check_nonlinear_sine(comp, 3.0)
+
+
+def test_negative_speed_input_does_not_crash():
+    """speedy_test.cc:1059-1076: 24 kHz file, speed 0.25, nonlinear, one big write."""
+    from speedy_amd.sonic2 import SonicStream
+    x, rate, ch = read_wav("negative_speed.wav")
+    s = SonicStream(rate, ch, True)
+    s.set_speed(0.25)
+    s.enable_nonlinear(1.0)
+    assert s.write_short(x) == 1
+    s.close()
+
+
+def test_feedback_reduces_excess_duration(orc):
+    """speedy_test.cc:653-711: 100 concatenations of tapestry at 3x; a stronger duration feedback leaves less
+    excess duration.  (2048-frame writes instead of 128 keep the call count reasonable; the stream is the same.)"""
+    from speedy_amd.sonic2 import SonicStream
+    x, rate, ch = read_wav("tapestry.wav")
+    long_x = np.tile(x, 100)
+
+    def excess(fb):
+        s = SonicStream(rate, ch, True)
+        s.set_speed(3.0)
+        s.enable_nonlinear(1.0)
+        s.set_feedback(fb)
+        got = 0
+        for pos in range(0, long_x.size, 2048):
+            s.write_short(long_x[pos:pos + 2048])
+            got += s.read_short(4096).size
+        s.close()
+        return got
+
+    def oracle_excess(fb):
+        L = orc.lib()
+        h = L.orc_sonicCreateStream(rate, ch, 1)
+        L.orc_sonicSetSpeed(h, 3.0)
+        L.orc_sonicEnableNonlinearSpeedup(h, 1.0)
+        L.orc_sonicSetDurationFeedbackStrength(h, fb)
+        buf = np.zeros(4096, np.int16)
+        got = 0
+        for pos in range(0, long_x.size, 2048):
+            seg = np.ascontiguousarray(long_x[pos:pos + 2048])
+            L.orc_sonicWriteShortToStream(h, orc.sptr(seg), seg.size)
+            got += L.orc_sonicReadShortFromStream(h, orc.sptr(buf), 4096)
+        L.orc_sonicDestroyStream(h)
+        return got
+
+    gots = [excess(fb) for fb in (0.0, 0.1, 0.2, 0.4)]
+    assert gots == [oracle_excess(fb) for fb in (0.0, 0.1, 0.2, 0.4)]
+    e = [abs(long_x.size / 3.0 - g) / rate for g in gots]
+    assert e[1] < e[0] and e[2] < e[1] and e[3] < e[2]

@@ -1,0 +1,71 @@
+"""Anchors the (parity-unpinned) TSM restatement oracle/orc_sonic.c on the properties the reference's own tests
+require of libsonic: sonic_classic_test.cc (un-shimmed library) and the shim-level checks of sonic_test.cc."""
+import numpy as np
+import pytest
+
+import sonic_props as sp
+from util import read_wav
+
+
+@pytest.fixture(scope="module")
+def compress(orc):
+    def f(x, rate, ch, speed, nonlinear):
+        return orc.compress_sound(x, rate, ch, speed, nonlinear, 0.0, True, chunk=1024, taps=False)["out"]
+    return f
+
+
+def test_speedup_sine(compress):
+    sp.check_sine_speed(compress, 3.0)
+
+
+def test_slowdown_sine(compress):
+    sp.check_sine_speed(compress, 0.5)
+
+
+def test_full_speech_range(compress):
+    sp.check_speech_lengths(compress)
+
+
+def test_full_noise_range(compress):
+    sp.check_noise_lengths(compress)
+
+
+def test_sinusoid_stereo_match(compress):
+    sp.check_mono_stereo_identity(compress, sp.sine_440(), 16000)
+
+
+def test_tapestry_stereo_match(compress):
+    x, rate, _ = read_wav("tapestry.wav")
+    sp.check_mono_stereo_identity(compress, x, rate)
+
+
+def test_nonlinear_sine_speedup(compress):
+    sp.check_nonlinear_sine(compress, 3.0)
+
+
+def test_chunking_does_not_change_output(orc):
+    """Constant speed: the output does not depend on how the caller chunks its writes (walk events)."""
+    x, rate, ch = read_wav("tapestry.wav")
+    a = orc.compress_sound(x, rate, ch, 2.3, 0.0, 0.0, False, chunk=128, taps=False)["out"]
+    b = orc.compress_sound(x, rate, ch, 2.3, 0.0, 0.0, False, chunk=50381, taps=False)["out"]
+    c = orc.compress_sound(x, rate, ch, 3.5, 1.0, 0.1, False, chunk=77, taps=False)["out"]
+    d = orc.compress_sound(x, rate, ch, 3.5, 1.0, 0.1, False, chunk=1000, taps=False)["out"]
+    assert np.array_equal(a, b) and np.array_equal(c, d)
+
+
+def test_mono_vs_offset_stereo_tension(orc):
+    """sonic_test.cc:871-947: mono vs stereo with -+50 offsets: same tension (1e-5 rel), exactly 2x the values,
+    channel average within +-1 of the mono output."""
+    x, rate, _ = read_wav("tapestry.wav")
+    st = np.empty(2 * x.size, np.int16)
+    st[0::2] = x - 50
+    st[1::2] = x + 50
+    m = orc.compress_sound(x, rate, 1, 3.0, 1.0, 0.0, True)
+    s = orc.compress_sound(st, rate, 2, 3.0, 1.0, 0.0, True)
+    assert m["tension"].shape == s["tension"].shape
+    assert np.allclose(m["tension"], s["tension"], rtol=1e-5, atol=1e-6)
+    assert s["out"].size == 2 * m["out"].size
+    avg = (s["out"][0::2].astype(int) + s["out"][1::2].astype(int)) // 2  # C division of small sums
+    avg = np.trunc((s["out"][0::2].astype(int) + s["out"][1::2].astype(int)) / 2).astype(int)
+    assert np.abs(avg - m["out"]).max() <= 1
+    assert np.array_equal(m["tension"], m["features"][:, 11])  # sonic_test.cc:937
