@@ -52,6 +52,8 @@ struct SpxWalkState {
   int remaining;   // remainingInputToCopy
   int prevPeriod, prevMinDiff;
   int overflow;
+  int prevPeriod_toggle;  // which of the two LDS lag-sum buffers the next pitch step uses (walk kernel internal)
+  int pad_;
 };
 // Everything a stream carries from one job to the next.
 struct SpxStreamState {

@@ -181,95 +181,102 @@ __device__ __forceinline__ void ensure_window(WalkCtx& X, int64_t pos, int need)
   lds_sync<NW>();
 }
 
-// AMDF partial sums for lags minP .. minP+nl-1 over a biased u16 signal that starts `o` samples into the
-// arrays (A0 = dword view of the signal array, A1 = dword view of its copy shifted by one sample), added into
-// diff[l].  Terms are taken in pairs (i = 2j, 2j+1): a = s[2j..2j+1], b = s[2j+p..2j+p+1]; whichever of the two
-// views makes the pair dword-aligned is used.  For odd p the last pair holds one valid term and is masked.
-// Each (lag, part) item owns a contiguous run of pairs and keeps four LDS reads in flight.
-template <int NW>
-__device__ __forceinline__ void amdf_accumulate(const unsigned* A0, const unsigned* A1, int o, int minP, int nl,
-                                                unsigned* diff) {
-  constexpr int NT = 64 * NW;
-  int parts = NT / nl;
-  if (parts < 1) parts = 1;
-  if (parts > 16) parts = 16;
-  const int items = nl * parts;
-  const float inv_nl = 1.0f / (float)nl;
-  const float inv_parts = 1.0f / (float)parts;
-  const unsigned* ap = (o & 1) ? A1 + ((o - 1) >> 1) : A0 + (o >> 1);
-  for (int item = threadIdx.x; item < items; item += NT) {
-    const int q = (int)(((float)item + 0.5f) * inv_nl);
-    const int l = item - q * nl;
-    const int p = minP + l;
-    const int ob = o + p;
-    const unsigned* bp = (ob & 1) ? A1 + ((ob - 1) >> 1) : A0 + (ob >> 1);
-    const int nfull = p >> 1;
-    const int chunk = (int)(((float)(nfull + parts - 1) + 0.5f) * inv_parts);
-    int j = q * chunk;
-    int j1 = j + chunk;
-    if (j1 > nfull) j1 = nfull;
-    unsigned acc = 0;
-    for (; j < j1; j += 8) {  // eight pairs per trip, all sixteen LDS reads in flight; lanes past j1 add |a-a| = 0
-      unsigned a[8], b[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const bool ok = j + u < j1;
-        const int k = ok ? j + u : j;
-        a[u] = ap[k];
-        b[u] = (ok ? bp : ap)[k];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_sad_u16(a[u], b[u], acc);
-    }
-    if ((p & 1) && q == parts - 1)  // the lone term i = p-1
-      acc = __builtin_amdgcn_sad_u16(ap[nfull] & 0xffffu, bp[nfull] & 0xffffu, acc);
-    atomicAdd(&diff[l], acc);
+// Sum over pairs j in [j0, j1) of |s[2j] - s[2j+p]| + |s[2j+1] - s[2j+p+1]| on biased u16 data: ap is the
+// (wave-uniform) dword view of the signal at the search position, bp the lane's own dword view at lag p.
+// j1 differs per lane: the EXEC mask does the predication, no per-term compare/select instructions.
+__device__ __forceinline__ unsigned sad_run(const unsigned* ap, const unsigned* bp, int j0, int j1) {
+  unsigned acc = 0;
+  int j = j0;
+  for (; j + 4 <= j1; j += 4) {
+    const unsigned a0 = ap[j], a1 = ap[j + 1], a2 = ap[j + 2], a3 = ap[j + 3];
+    const unsigned b0 = bp[j], b1 = bp[j + 1], b2 = bp[j + 2], b3 = bp[j + 3];
+    acc = __builtin_amdgcn_sad_u16(a0, b0, acc);
+    acc = __builtin_amdgcn_sad_u16(a1, b1, acc);
+    acc = __builtin_amdgcn_sad_u16(a2, b2, acc);
+    acc = __builtin_amdgcn_sad_u16(a3, b3, acc);
   }
+  for (; j < j1; j++) acc = __builtin_amdgcn_sad_u16(ap[j], bp[j], acc);
+  return acc;
 }
 
-// Arg-min and arg-max of diff[l]/(minP+l), l < nl, exactly as the dependency's sequential scan decides them:
-// the FIRST lag with the smallest ratio; the first lag with the largest ratio, starting from (0, 255).
-// Every lane returns the same values.
-__device__ __forceinline__ void amdf_select(const unsigned* diff, int minP, int nl, int* retBest, int* retMin,
-                                            int* retMax) {
+// Exact division of small unsigned numbers (x < 2^31, 1 <= d < 2^12) without the 30-instruction integer
+// division expansion: float estimate, then at most one correction each way.
+__device__ __forceinline__ unsigned udiv_small(unsigned x, unsigned d) {
+  unsigned q = (unsigned)((float)x * __builtin_amdgcn_rcpf((float)d));
+  long long r = (long long)x - (long long)q * d;
+  while (r < 0) { q--; r += d; }
+  while (r >= (long long)d) { q++; r -= d; }
+  return q;
+}
+
+// Running result of the dependency's sequential arg-min / arg-max scan over lags.
+struct Sel {
+  unsigned bestD, worstD;
+  int bestP, worstP;
+};
+
+// Fold the 64 lanes' (d, p) candidates (lane order = ascending lag) into the running result, exactly as a
+// sequential scan would: float ratios, DPP wave min/max, then an exact integer resolve on the scalar unit of the
+// lanes within 2^-16 of the extremum (strict compare, so the FIRST lag wins ties).  Wave-uniform result.
+template <bool WANT_MAX>
+__device__ __forceinline__ void select_fold(Sel& S, unsigned d, int p0, bool valid) {
   const int lane = threadIdx.x & 63;
-  unsigned bestD = 0, worstD = 0;
-  int bestP = 0, worstP = 0;
-  for (int base = 0; base < nl; base += 64) {
-    const int l = base + lane;
-    const bool valid = l < nl;
-    const unsigned d = valid ? diff[l] : 0u;
-    const int p = minP + l;
-    const float r = (float)d * __builtin_amdgcn_rcpf((float)p);  // within 2^-21 of d/p; resolved exactly below
-    const float rmin = wave_min_f(valid ? r : __builtin_huge_valf());
-    const float rmax = wave_max_f(valid ? r : -1.0f);
-    unsigned long long mmin = __ballot(valid && r <= rmin * 1.0000153f);  // 1 + 2^-16
-    unsigned long long mmax = __ballot(valid && r >= rmax * 0.9999847f);
-    while (mmin) {  // exact integer resolve, ascending lag order, strict '<' keeps the first
-      const int i = __builtin_ctzll(mmin);
-      mmin &= mmin - 1;
-      const unsigned di = (unsigned)__builtin_amdgcn_readlane((int)d, i);
-      const int pi = minP + base + i;
-      if (bestP == 0 || (unsigned long long)di * (unsigned)bestP < (unsigned long long)bestD * (unsigned)pi) {
-        bestD = di;
-        bestP = pi;
-      }
+  const float r = (float)d * __builtin_amdgcn_rcpf((float)(p0 + lane));  // within 2^-21 of d/p
+  const float rmin = wave_min_f(valid ? r : __builtin_huge_valf());
+  unsigned long long mmin = __ballot(valid && r <= rmin * 1.0000153f);  // 1 + 2^-16
+  while (mmin) {
+    const int i = __builtin_ctzll(mmin);
+    mmin &= mmin - 1;
+    const unsigned di = (unsigned)__builtin_amdgcn_readlane((int)d, i);
+    const int pi = p0 + i;
+    if (S.bestP == 0 || (unsigned long long)di * (unsigned)S.bestP < (unsigned long long)S.bestD * (unsigned)pi) {
+      S.bestD = di;
+      S.bestP = pi;
     }
+  }
+  if (WANT_MAX) {
+    const float rmax = wave_max_f(valid ? r : -1.0f);
+    unsigned long long mmax = __ballot(valid && r >= rmax * 0.9999847f);
     while (mmax) {
       const int i = __builtin_ctzll(mmax);
       mmax &= mmax - 1;
       const unsigned di = (unsigned)__builtin_amdgcn_readlane((int)d, i);
-      const int pi = minP + base + i;
-      if (worstP == 0 || (unsigned long long)di * (unsigned)worstP > (unsigned long long)worstD * (unsigned)pi) {
-        worstD = di;
-        worstP = pi;
+      const int pi = p0 + i;
+      if (S.worstP == 0 ||
+          (unsigned long long)di * (unsigned)S.worstP > (unsigned long long)S.worstD * (unsigned)pi) {
+        S.worstD = di;
+        S.worstP = pi;
       }
     }
   }
-  if (worstD == 0) worstP = 255;  // the scan's initial (maxDiff = 0, worstPeriod = 255) survives
-  *retBest = bestP;
-  *retMin = (int)(bestD / (unsigned)bestP);
-  *retMax = (int)(worstD / (unsigned)worstP);
+}
+__device__ __forceinline__ void select_finish(const Sel& S, int* retBest, int* retMin, int* retMax) {
+  // the scan's initial (maxDiff = 0, worstPeriod = 255) survives unless some lag has diff > 0
+  const unsigned worstD = S.worstD;
+  const int worstP = (worstD == 0) ? 255 : S.worstP;
+  *retBest = S.bestP;
+  *retMin = (int)udiv_small(S.bestD, (unsigned)S.bestP);
+  *retMax = (int)udiv_small(worstD, (unsigned)worstP);
+}
+
+// One lane per lag, the whole sum in the lane (no cross-lane traffic): used for the coarse search, which every
+// wave runs redundantly.  A0/A1: dword views of the signal array and of its copy shifted by one sample; o = offset
+// of the search position inside them.
+template <bool WANT_MAX>
+__device__ __forceinline__ void search_lane_per_lag(const unsigned* A0, const unsigned* A1, int o, int minP, int nl,
+                                                    Sel& S) {
+  const int lane = threadIdx.x & 63;
+  const unsigned* ap = (o & 1) ? A1 + ((o - 1) >> 1) : A0 + (o >> 1);
+  for (int base = 0; base < nl; base += 64) {
+    const bool valid = base + lane < nl;
+    const int p = minP + base + lane;
+    const int ob = o + p;
+    const unsigned* bp = (ob & 1) ? A1 + ((ob - 1) >> 1) : A0 + (ob >> 1);
+    const int nfull = valid ? (p >> 1) : 0;
+    unsigned d = sad_run(ap, bp, 0, nfull);
+    if (valid && (p & 1)) d = __builtin_amdgcn_sad_u16(ap[nfull] & 0xffffu, bp[nfull] & 0xffffu, d);  // term i = p-1
+    select_fold<WANT_MAX>(S, d, minP + base, valid);
+  }
 }
 
 // findPitchPeriod at absolute position pos (all threads return the same value).
@@ -307,41 +314,67 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
     }
   }
   STAMP(3);
-  lds_sync<NW>();
+  if (!direct) lds_sync<NW>();
   STAMP(4);
-  // ---- phase D: first search; the refine accumulators are cleared here (their readers are all done) ----
-  for (int t = tid; t < 256; t += NT) X.diffR[t] = 0;
+  // ---- first search: every wave on its own, in registers (no atomics, no barrier) ----
+  const unsigned* M0 = reinterpret_cast<const unsigned*>(X.monoH);
+  const unsigned* M1 = reinterpret_cast<const unsigned*>(X.monoHB);
   int period, minDiff, maxDiff;
   const int minC = direct ? P.minPeriod : P.minPeriod / skip;
   const int maxC = direct ? P.maxPeriod : P.maxPeriod / skip;
-  const unsigned* M0 = reinterpret_cast<const unsigned*>(X.monoH);
-  const unsigned* M1 = reinterpret_cast<const unsigned*>(X.monoHB);
-  if (direct)
-    amdf_accumulate<NW>(M0, M1, o, minC, maxC - minC + 1, X.diffC);
-  else
-    amdf_accumulate<NW>(reinterpret_cast<const unsigned*>(X.dnH), reinterpret_cast<const unsigned*>(X.dnHB), 0, minC,
-                        maxC - minC + 1, X.diffC);
-  STAMP(5);
-  lds_sync<NW>();
-  STAMP(6);
-  amdf_select(X.diffC, minC, maxC - minC + 1, &period, &minDiff, &maxDiff);
-  STAMP(7);
-  if (!direct && skip != 1) {
-    period *= skip;
+  Sel S1 = {0u, 0u, 0, 0};
+  if (direct || skip == 1) {  // this search is the final one: it also needs the worst lag
+    if (direct) search_lane_per_lag<true>(M0, M1, o, minC, maxC - minC + 1, S1);
+    else search_lane_per_lag<true>(reinterpret_cast<const unsigned*>(X.dnH), reinterpret_cast<const unsigned*>(X.dnHB),
+                                   0, minC, maxC - minC + 1, S1);
+    select_finish(S1, &period, &minDiff, &maxDiff);
+    if (!direct) lds_sync<NW>();  // the next step rewrites the decimated signal
+    STAMP(7);
+  } else {
+    search_lane_per_lag<false>(reinterpret_cast<const unsigned*>(X.dnH), reinterpret_cast<const unsigned*>(X.dnHB), 0,
+                               minC, maxC - minC + 1, S1);
+    STAMP(7);
+    period = S1.bestP * skip;
     int lo = period - (skip << 2), hi = period + (skip << 2);
     if (lo < P.minPeriod) lo = P.minPeriod;
     if (hi > P.maxPeriod) hi = P.maxPeriod;
-    // ---- phase G: refine at full rate ----
-    amdf_accumulate<NW>(M0, M1, o, lo, hi - lo + 1, X.diffR);
+    const int nlR = hi - lo + 1;
+    // ---- refine at full rate: wave w takes pairs [w*CH, (w+1)*CH) of every lag; sums meet in LDS ----
+    unsigned* diff = X.diffR + ((st.prevPeriod_toggle & 1) ? 256 : 0);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int CH = (((hi >> 1) + NW) / NW + 3) & ~3;
+    const unsigned* ap = (o & 1) ? M1 + ((o - 1) >> 1) : M0 + (o >> 1);
+    for (int base = 0; base < nlR; base += 64) {
+      const bool valid = base + lane < nlR;
+      const int p = lo + base + lane;
+      const int ob = o + p;
+      const unsigned* bp = (ob & 1) ? M1 + ((ob - 1) >> 1) : M0 + (ob >> 1);
+      const int nfull = valid ? (p >> 1) : 0;
+      int j1 = (wave + 1) * CH;
+      if (j1 > nfull) j1 = nfull;
+      unsigned d = sad_run(ap, bp, wave * CH, j1);
+      if (wave == NW - 1 && valid && (p & 1))
+        d = __builtin_amdgcn_sad_u16(ap[nfull] & 0xffffu, bp[nfull] & 0xffffu, d);
+      if (valid) {
+        if (NW > 1) atomicAdd(&diff[base + lane], d);
+        else diff[base + lane] = d;
+      }
+    }
     STAMP(8);
     lds_sync<NW>();
     STAMP(9);
-    for (int t = tid; t < 256; t += NT) X.diffC[t] = 0;
-    amdf_select(X.diffR, lo, hi - lo + 1, &period, &minDiff, &maxDiff);
+    // the other buffer was last read before this step's barriers: clear it for the next step
+    unsigned* other = X.diffR + ((st.prevPeriod_toggle & 1) ? 0 : 256);
+    if (NW > 1) for (int t = tid; t < 256; t += NT) other[t] = 0;
+    Sel S2 = {0u, 0u, 0, 0};
+    for (int base = 0; base < nlR; base += 64) {
+      const bool valid = base + lane < nlR;
+      const unsigned d = valid ? diff[base + lane] : 0u;
+      select_fold<true>(S2, d, lo + base, valid);
+    }
+    select_finish(S2, &period, &minDiff, &maxDiff);
+    st.prevPeriod_toggle ^= 1;
     STAMP(10);
-  } else {
-    lds_sync<NW>();
-    for (int t = tid; t < 256; t += NT) X.diffC[t] = 0;
   }
   int ret = period;
   if (!(minDiff == 0 || st.prevPeriod == 0) && !(maxDiff > minDiff * 3) && !(minDiff * 2 <= st.prevMinDiff * 3))
@@ -496,8 +529,8 @@ static __host__ __device__ inline WalkLds walk_lds_layout(const SpxPlanDev& P, i
   const int dnb = ((P.maxRequired / P.skip + 8) * 2 + 15) & ~15;
   L.off_dn = o; o += dnb;
   L.off_dnB = o; o += dnb;
-  L.off_diffC = o; o += 256 * 4;
-  L.off_diffR = o; o += 256 * 4;
+  L.off_diffC = o; o += 16;
+  L.off_diffR = o; o += 2 * 256 * 4;  // double-buffered per-lag sums of the refine search
   L.total = o;
   return L;
 }
@@ -523,7 +556,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   SpxStreamState Z;
   if (S.flags & SPX_F_INIT) {
     Z.w.base = 0; Z.w.out_n = 0; Z.w.avail = 0; Z.w.remaining = 0; Z.w.prevPeriod = 0; Z.w.prevMinDiff = 0;
-    Z.w.overflow = 0;
+    Z.w.overflow = 0; Z.w.prevPeriod_toggle = 0; Z.w.pad_ = 0;
     Z.lp = 2.14204f;    // speedy.c:263,288
     Z.lpf = 123.837f;   // speedy.c:264,291
     Z.cur_dur = 0.0f; Z.des_dur = 0.0f;
@@ -700,7 +733,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   X.dnHB = reinterpret_cast<unsigned short*>(lds + LY.off_dnB);
   X.diffC = reinterpret_cast<unsigned*>(lds + LY.off_diffC);
   X.diffR = reinterpret_cast<unsigned*>(lds + LY.off_diffR);
-  for (int t = tid; t < 256; t += NT) { X.diffC[t] = 0; X.diffR[t] = 0; }
+  for (int t = tid; t < 512; t += NT) X.diffR[t] = 0;
   __syncthreads();
   STAMP_DECL
   WalkState st = Z.w;
