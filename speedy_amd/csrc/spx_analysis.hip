@@ -17,6 +17,21 @@
 
 #define SPX_TF 16  // frames per tile (plus one halo slot)
 
+#ifdef SPX_STAMPS
+__device__ unsigned long long g_spx_astamps[16];
+#define ASTAMP_DECL unsigned long long as_last = __builtin_readcyclecounter(), as_acc[10] = {0,0,0,0,0,0,0,0,0,0};
+#define ASTAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); as_acc[i] += t_ - as_last; as_last = t_; } while (0)
+#define ASTAMP_FLUSH if (threadIdx.x == 0 && blockIdx.x == 7) for (int i_ = 0; i_ < 10; i_++) g_spx_astamps[i_] += as_acc[i_];
+extern "C" void spx_debug_astamps(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spx_astamps), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spx_astamps), z, sizeof(z)); }
+}
+#else
+#define ASTAMP_DECL
+#define ASTAMP(i)
+#define ASTAMP_FLUSH
+#endif
+
 int spx_analysis_tile_frames() { return SPX_TF; }
 
 static __host__ __device__ inline size_t work_bytes(int W) {
@@ -247,6 +262,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   double* bufA = work + (size_t)wave * 4 * W;
   double* bufB = bufA + 2 * W;
 
+  ASTAMP_DECL
   // ---------------- phase 1: spectra of slots 0..TF (slot s = frame j0-1+s), one wave per slot ----------
   for (int s = wave; s <= SPX_TF; s += 4) {
     const int j = j0 - 1 + s;
@@ -271,6 +287,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       bufA[i] = v;
     }
     wave_sync();
+    ASTAMP(0);
     double* x = bufA;
     double* y = bufB;
     int sprod = 1, cur = W;
@@ -282,6 +299,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       sprod *= r;
       cur /= r;
     }
+    ASTAMP(1);
     // untangle the packed transform:  X[k] = E[k] + e^{-2 pi i k/N} O[k]
     float* spec_out = taps.spectrogram ? taps.spectrogram + (size_t)(S.frame_off + j) * N : nullptr;
     for (int k = lane; k < W; k += SPX_WAVE) {
@@ -303,8 +321,11 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       }
     }
     wave_sync();
+    ASTAMP(2);
   }
+  ASTAMP(3);
   __syncthreads();
+  ASTAMP(4);
 
   // ---------------- phase 2: per-slot energy (float, index order), max, inverse norm ----------------
   if (tid <= SPX_TF) {
@@ -321,6 +342,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
     fInv[tid] = (float)(1.0 / (__builtin_sqrt((double)e) + (double)eps));      // speedy.c:642
   }
   __syncthreads();
+  ASTAMP(5);
 
   // ---------------- phase 3: gated |log ratio| terms, one lane per (slot, bin) ----------------
   double* terms = work;  // aliases the DFT buffers, [SPX_TF][W+1]
@@ -351,6 +373,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       for (int i = tid; i < W; i += SPX_BLOCK) taps.normalized[(size_t)S.frame_off * W + i] = 0.0f;
   }
   __syncthreads();
+  ASTAMP(6);
 
   // ---------------- phase 4: float accumulation of the terms in bin order, one lane per frame --------
   if (tid < nfr) {
@@ -364,6 +387,8 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
     r.lsd = (e <= lowthr) ? 0.0f : lsd;
     rec[S.frame_off + j0 + tid] = r;
   }
+  ASTAMP(7);
+  ASTAMP_FLUSH
 }
 
 void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int n_tiles,

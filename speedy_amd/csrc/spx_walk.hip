@@ -34,6 +34,18 @@
 
 typedef SpxWalkState WalkState;
 
+// Values that are the same in every lane but that the compiler cannot prove uniform (they come from LDS or from
+// lane-indexed loads): pin them to SGPRs so the bookkeeping around a pitch step runs on the scalar unit.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float unif(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ int64_t uni64(int64_t v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+  return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
 // Diagnostic build only (-DSPX_STAMPS): per-phase shader-cycle sums of workgroup 0, lane 0.  Never in the product.
 #ifdef SPX_STAMPS
 __device__ unsigned long long g_spx_stamps[32];
@@ -254,9 +266,9 @@ __device__ __forceinline__ void select_finish(const Sel& S, int* retBest, int* r
   // the scan's initial (maxDiff = 0, worstPeriod = 255) survives unless some lag has diff > 0
   const unsigned worstD = S.worstD;
   const int worstP = (worstD == 0) ? 255 : S.worstP;
-  *retBest = S.bestP;
-  *retMin = (int)udiv_small(S.bestD, (unsigned)S.bestP);
-  *retMax = (int)udiv_small(worstD, (unsigned)worstP);
+  *retBest = uni(S.bestP);
+  *retMin = uni((int)udiv_small(S.bestD, (unsigned)S.bestP));
+  *retMax = uni((int)udiv_small(worstD, (unsigned)worstP));
 }
 
 // One lane per lag, the whole sum in the lane (no cross-lane traffic): used for the coarse search, which every
@@ -275,6 +287,47 @@ __device__ __forceinline__ void search_lane_per_lag(const unsigned* A0, const un
     const int nfull = valid ? (p >> 1) : 0;
     unsigned d = sad_run(ap, bp, 0, nfull);
     if (valid && (p & 1)) d = __builtin_amdgcn_sad_u16(ap[nfull] & 0xffffu, bp[nfull] & 0xffffu, d);  // term i = p-1
+    select_fold<WANT_MAX>(S, d, minP + base, valid);
+  }
+}
+
+// The same search spread over the NW waves of the workgroup: wave w takes the pairs [w*CH, (w+1)*CH) of every lag
+// (one lane per lag), the partial sums meet in LDS (ds_add_u32 into `buf`, which is all zero on entry), one
+// LDS barrier, then every wave folds the totals itself.  `other` is the buffer the PREVIOUS step used; every wave
+// is past reading it once this step's barrier is crossed, so it is cleared here for the next step.
+template <int NW, bool WANT_MAX>
+__device__ __forceinline__ void search_split(const unsigned* A0, const unsigned* A1, int o, int minP, int nl,
+                                             unsigned* buf, unsigned* other, Sel& S, WalkCtx& X, int sb) {
+  (void)X; (void)sb;
+  if (NW == 1) {
+    search_lane_per_lag<WANT_MAX>(A0, A1, o, minP, nl, S);
+    return;
+  }
+  constexpr int NT = 64 * NW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int maxP = minP + nl - 1;
+  const int CH = (((maxP >> 1) + NW) / NW + 3) & ~3;
+  const unsigned* ap = (o & 1) ? A1 + ((o - 1) >> 1) : A0 + (o >> 1);
+  for (int base = 0; base < nl; base += 64) {
+    const bool valid = base + lane < nl;
+    const int p = minP + base + lane;
+    const int ob = o + p;
+    const unsigned* bp = (ob & 1) ? A1 + ((ob - 1) >> 1) : A0 + (ob >> 1);
+    const int nfull = valid ? (p >> 1) : 0;
+    int j1 = (wave + 1) * CH;
+    if (j1 > nfull) j1 = nfull;
+    unsigned d = sad_run(ap, bp, wave * CH, j1);
+    if (wave == NW - 1 && valid && (p & 1))
+      d = __builtin_amdgcn_sad_u16(ap[nfull] & 0xffffu, bp[nfull] & 0xffffu, d);  // the lone term i = p-1
+    if (valid) atomicAdd(&buf[base + lane], d);
+  }
+  STAMP(sb);
+  lds_sync<NW>();
+  STAMP(sb + 1);
+  for (int t = tid; t < 256; t += NT) other[t] = 0;
+  for (int base = 0; base < nl; base += 64) {
+    const bool valid = base + lane < nl;
+    const unsigned d = valid ? buf[base + lane] : 0u;
     select_fold<WANT_MAX>(S, d, minP + base, valid);
   }
 }
@@ -314,66 +367,35 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
     }
   }
   STAMP(3);
-  if (!direct) lds_sync<NW>();
+  lds_sync<NW>();  // decimated signal visible; last step's buffer clearing finished
   STAMP(4);
-  // ---- first search: every wave on its own, in registers (no atomics, no barrier) ----
+  // ---- first search ----
   const unsigned* M0 = reinterpret_cast<const unsigned*>(X.monoH);
   const unsigned* M1 = reinterpret_cast<const unsigned*>(X.monoHB);
+  const unsigned* D0 = reinterpret_cast<const unsigned*>(X.dnH);
+  const unsigned* D1 = reinterpret_cast<const unsigned*>(X.dnHB);
   int period, minDiff, maxDiff;
   const int minC = direct ? P.minPeriod : P.minPeriod / skip;
   const int maxC = direct ? P.maxPeriod : P.maxPeriod / skip;
+  const int tg = st.prevPeriod_toggle & 1;
+  st.prevPeriod_toggle ^= 1;
   Sel S1 = {0u, 0u, 0, 0};
   if (direct || skip == 1) {  // this search is the final one: it also needs the worst lag
-    if (direct) search_lane_per_lag<true>(M0, M1, o, minC, maxC - minC + 1, S1);
-    else search_lane_per_lag<true>(reinterpret_cast<const unsigned*>(X.dnH), reinterpret_cast<const unsigned*>(X.dnHB),
-                                   0, minC, maxC - minC + 1, S1);
+    search_split<NW, true>(direct ? M0 : D0, direct ? M1 : D1, direct ? o : 0, minC, maxC - minC + 1,
+                           X.diffC + 256 * tg, X.diffC + 256 * (1 - tg), S1, X, 5);
     select_finish(S1, &period, &minDiff, &maxDiff);
-    if (!direct) lds_sync<NW>();  // the next step rewrites the decimated signal
     STAMP(7);
   } else {
-    search_lane_per_lag<false>(reinterpret_cast<const unsigned*>(X.dnH), reinterpret_cast<const unsigned*>(X.dnHB), 0,
-                               minC, maxC - minC + 1, S1);
+    search_split<NW, false>(D0, D1, 0, minC, maxC - minC + 1, X.diffC + 256 * tg, X.diffC + 256 * (1 - tg), S1, X, 5);
     STAMP(7);
     period = S1.bestP * skip;
     int lo = period - (skip << 2), hi = period + (skip << 2);
     if (lo < P.minPeriod) lo = P.minPeriod;
     if (hi > P.maxPeriod) hi = P.maxPeriod;
-    const int nlR = hi - lo + 1;
-    // ---- refine at full rate: wave w takes pairs [w*CH, (w+1)*CH) of every lag; sums meet in LDS ----
-    unsigned* diff = X.diffR + ((st.prevPeriod_toggle & 1) ? 256 : 0);
-    const int lane = tid & 63, wave = tid >> 6;
-    const int CH = (((hi >> 1) + NW) / NW + 3) & ~3;
-    const unsigned* ap = (o & 1) ? M1 + ((o - 1) >> 1) : M0 + (o >> 1);
-    for (int base = 0; base < nlR; base += 64) {
-      const bool valid = base + lane < nlR;
-      const int p = lo + base + lane;
-      const int ob = o + p;
-      const unsigned* bp = (ob & 1) ? M1 + ((ob - 1) >> 1) : M0 + (ob >> 1);
-      const int nfull = valid ? (p >> 1) : 0;
-      int j1 = (wave + 1) * CH;
-      if (j1 > nfull) j1 = nfull;
-      unsigned d = sad_run(ap, bp, wave * CH, j1);
-      if (wave == NW - 1 && valid && (p & 1))
-        d = __builtin_amdgcn_sad_u16(ap[nfull] & 0xffffu, bp[nfull] & 0xffffu, d);
-      if (valid) {
-        if (NW > 1) atomicAdd(&diff[base + lane], d);
-        else diff[base + lane] = d;
-      }
-    }
-    STAMP(8);
-    lds_sync<NW>();
-    STAMP(9);
-    // the other buffer was last read before this step's barriers: clear it for the next step
-    unsigned* other = X.diffR + ((st.prevPeriod_toggle & 1) ? 0 : 256);
-    if (NW > 1) for (int t = tid; t < 256; t += NT) other[t] = 0;
+    // ---- refine at full rate ----
     Sel S2 = {0u, 0u, 0, 0};
-    for (int base = 0; base < nlR; base += 64) {
-      const bool valid = base + lane < nlR;
-      const unsigned d = valid ? diff[base + lane] : 0u;
-      select_fold<true>(S2, d, lo + base, valid);
-    }
+    search_split<NW, true>(M0, M1, o, lo, hi - lo + 1, X.diffR + 256 * tg, X.diffR + 256 * (1 - tg), S2, X, 8);
     select_finish(S2, &period, &minDiff, &maxDiff);
-    st.prevPeriod_toggle ^= 1;
     STAMP(10);
   }
   int ret = period;
@@ -468,10 +490,10 @@ __device__ __forceinline__ void tsm_process(const SpxPlanDev& P, WalkCtx& X, Wal
         if ((double)speed > 1.0) {
           int n;  // the dependency converts to long; every value here fits an int
           if (speed >= 2.0f) {
-            n = (int)((float)period / (speed - 1.0f));
+            n = uni((int)((float)period / (speed - 1.0f)));
           } else {
             n = period;
-            st.remaining = (int)((float)period * (2.0f - speed) / (speed - 1.0f));
+            st.remaining = uni((int)((float)period * (2.0f - speed) / (speed - 1.0f)));
           }
           if (st.out_n + n > X.out_cap) st.overflow = 1;
           if (n == 0) return;  // the dependency treats this as failure and leaves the input untouched
@@ -483,10 +505,10 @@ __device__ __forceinline__ void tsm_process(const SpxPlanDev& P, WalkCtx& X, Wal
         } else {
           int n;
           if (speed < 0.5f) {
-            n = (int)((float)period * speed / (1.0f - speed));
+            n = uni((int)((float)period * speed / (1.0f - speed)));
           } else {
             n = period;
-            st.remaining = (int)((float)period * (2.0f * speed - 1.0f) / (1.0f - speed));
+            st.remaining = uni((int)((float)period * (2.0f * speed - 1.0f) / (1.0f - speed)));
           }
           emit_copy<NW>(X, st, pos, period);
           if (st.out_n + n > X.out_cap) st.overflow = 1;
@@ -529,8 +551,8 @@ static __host__ __device__ inline WalkLds walk_lds_layout(const SpxPlanDev& P, i
   const int dnb = ((P.maxRequired / P.skip + 8) * 2 + 15) & ~15;
   L.off_dn = o; o += dnb;
   L.off_dnB = o; o += dnb;
-  L.off_diffC = o; o += 16;
-  L.off_diffR = o; o += 2 * 256 * 4;  // double-buffered per-lag sums of the refine search
+  L.off_diffC = o; o += 2 * 256 * 4;  // double-buffered per-lag sums, first search
+  L.off_diffR = o; o += 2 * 256 * 4;  // double-buffered per-lag sums, refine search
   L.total = o;
   return L;
 }
@@ -733,11 +755,14 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   X.dnHB = reinterpret_cast<unsigned short*>(lds + LY.off_dnB);
   X.diffC = reinterpret_cast<unsigned*>(lds + LY.off_diffC);
   X.diffR = reinterpret_cast<unsigned*>(lds + LY.off_diffR);
-  for (int t = tid; t < 512; t += NT) X.diffR[t] = 0;
+  for (int t = tid; t < 512; t += NT) { X.diffR[t] = 0; X.diffC[t] = 0; }
   __syncthreads();
   STAMP_DECL
   WalkState st = Z.w;
-  float curSpeed = Z.curSpeed;
+  st.base = uni64(st.base); st.out_n = uni64(st.out_n); st.avail = uni64(st.avail);
+  st.remaining = uni(st.remaining); st.prevPeriod = uni(st.prevPeriod); st.prevMinDiff = uni(st.prevMinDiff);
+  st.overflow = uni(st.overflow); st.prevPeriod_toggle = uni(st.prevPeriod_toggle);
+  float curSpeed = unif(Z.curSpeed);
   int64_t avail = st.avail;
   // Events, in the order the shim issues them:
   //   nonlinear: one (setSpeed, write B) per tension frame           soniclib.c:354,369
@@ -763,7 +788,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
             for (int t = tid; t < n; t += NT) sA[t] = scr[4 * (ev + t) + 3];
             __syncthreads();
           }
-          curSpeed = sA[i];
+          curSpeed = unif(sA[i]);
         }
         avail += B;
       } else {
@@ -771,7 +796,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
       }
     } else {
       const int64_t remainingS = avail - st.base;
-      expected = st.out_n + (int)(((float)remainingS / curSpeed + 0) / 1.0f + 0.5f);
+      expected = st.out_n + uni((int)(((float)remainingS / curSpeed + 0) / 1.0f + 0.5f));
       X.limit = avail;  // everything from here on reads as the flush's zero padding
       lds_sync<NW>();
       X.wbase = -1;     // the window may hold samples past the new limit
@@ -805,7 +830,7 @@ void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_str
   const WalkLds LY = walk_lds_layout(P, maxC);
   // Waves per stream: few streams -> several waves per stream use the otherwise idle SIMDs; many streams -> one
   // wave each and more streams per CU.  SPX_WALK_NW overrides (tuning only).
-  int nw = (n_streams <= 1024) ? 4 : 1;
+  int nw = (n_streams <= 256) ? 8 : (n_streams <= 1024) ? 4 : 1;  // measured on MI355X: 5.14 / 5.34 / 6.77 ms at 256 streams
   if (const char* e = getenv("SPX_WALK_NW")) nw = atoi(e);
 #define SPX_LAUNCH_WALK(NWV)                                                                                     \
   hipLaunchKernelGGL(spx_walk_kernel<NWV>, dim3(n_streams), dim3(64 * NWV), LY.total, st, P, streams, in, out,    \

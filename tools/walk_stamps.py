@@ -33,3 +33,20 @@ tot = sum(buf)
 print("stream 0: total stamped cycles %d" % tot)
 for i in range(14):
     print("  %2d %-40s %10d  %5.1f %%" % (i, NAMES.get(i, ""), buf[i], 100.0 * buf[i] / max(1, tot)))
+
+# analysis kernel, workgroup 7, lane 0
+try:
+    L.spx_debug_astamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    ab = (C.c_ulonglong * 16)()
+    L.spx_debug_astamps(ab, 1)
+    b.run()
+    torch.cuda.synchronize()
+    L.spx_debug_astamps(ab, 1)
+    an = ["frame load+window", "DFT stages", "untangle+mag", "loop exit", "sync", "phase2 energy (+sync)",
+          "phase3 log terms (+sync)", "phase4 accumulate"]
+    tot = sum(ab[:8])
+    print("analysis tile (wave 0 of workgroup 7): total %d cycles" % tot)
+    for i in range(8):
+        print("  %d %-28s %9d  %5.1f %%" % (i, an[i], ab[i], 100.0 * ab[i] / max(1, tot)))
+except AttributeError:
+    pass
