@@ -39,10 +39,14 @@ static __host__ __device__ inline size_t work_bytes(int W) {
   size_t b = (size_t)SPX_TF * (W + 1) * sizeof(double);      // aliased: log terms
   return (a > b ? a : b);
 }
+static __host__ __device__ inline size_t stage_samples(const SpxPlanDev& P) {
+  return (size_t)(SPX_TF + 1) * P.B + (P.W - P.B) + 8;  // mono samples of frames j0-1 .. j0+TF-1
+}
 size_t spx_analysis_lds_bytes(const SpxPlanDev& P) {
   size_t mags = (size_t)(SPX_TF + 1) * (P.W + 1) * sizeof(float);
   size_t small = (size_t)3 * (SPX_TF + 1) * sizeof(float);
-  return work_bytes(P.W) + ((mags + 15) & ~(size_t)15) + ((small + 15) & ~(size_t)15);
+  size_t stage = (stage_samples(P) * sizeof(short) + 15) & ~(size_t)15;
+  return work_bytes(P.W) + ((mags + 15) & ~(size_t)15) + ((small + 15) & ~(size_t)15) + stage;
 }
 
 __device__ __forceinline__ void wave_sync() {
@@ -127,7 +131,7 @@ __device__ __forceinline__ cplx ld(const double* buf, int idx) {
   const double2 v = *reinterpret_cast<const double2*>(buf + 2 * idx);
   return {v.x, v.y};
 }
-__device__ __forceinline__ void st_tw(double* buf, int idx, cplx b, const double* __restrict__ tw, int t) {
+__device__ __forceinline__ void st_tw(double* buf, int idx, cplx b, const double* tw, int t) {
   const double2 w = *reinterpret_cast<const double2*>(tw + 2 * t);
   double2 o;
   o.x = b.r * w.x - b.i * w.y;
@@ -136,14 +140,17 @@ __device__ __forceinline__ void st_tw(double* buf, int idx, cplx b, const double
 }
 
 // One Stockham stage of radix r over the W-point transform held in x (-> y).  s = product of earlier radices.
-__device__ void dft_stage(const SpxPlanDev& P, int r, int s, int cur, const double* x, double* y, int lane) {
+// b / s for b < 4096 by an exact multiply-shift (inv = ceil(2^20 / s), s | W).  The twiddle index j*s*p is
+// always below W (s*p < W/r), so no reduction modulo W is needed.
+__device__ void dft_stage(const SpxPlanDev& P, const double* tw, int r, int s, int cur, const double* x, double* y,
+                          int lane) {
   const int W = P.W;
   const int m = cur / r;
   const int span = W / r;
-  const double* __restrict__ tw = P.tw;
+  const unsigned inv_s = ((1u << 20) + (unsigned)s - 1u) / (unsigned)s;
   if (r == 4) {
     for (int b = lane; b < span; b += SPX_WAVE) {
-      const int p = b / s, q = b - p * s;
+      const int p = (int)(((unsigned)b * inv_s) >> 20), q = b - p * s;
       cplx a0 = ld(x, b), a1 = ld(x, b + span), a2 = ld(x, b + 2 * span), a3 = ld(x, b + 3 * span);
       cplx t0 = {a0.r + a2.r, a0.i + a2.i}, t1 = {a0.r - a2.r, a0.i - a2.i};
       cplx t2 = {a1.r + a3.r, a1.i + a3.i}, t3 = {a1.r - a3.r, a1.i - a3.i};
@@ -152,22 +159,22 @@ __device__ void dft_stage(const SpxPlanDev& P, int r, int s, int cur, const doub
       const int o = q + s * 4 * p;
       const int tp = s * p;  // < W
       st_tw(y, o, b0, tw, 0);
-      st_tw(y, o + s, b1, tw, tp % W);
-      st_tw(y, o + 2 * s, b2, tw, (2 * tp) % W);
-      st_tw(y, o + 3 * s, b3, tw, (3 * tp) % W);
+      st_tw(y, o + s, b1, tw, tp);
+      st_tw(y, o + 2 * s, b2, tw, 2 * tp);
+      st_tw(y, o + 3 * s, b3, tw, 3 * tp);
     }
   } else if (r == 2) {
     for (int b = lane; b < span; b += SPX_WAVE) {
-      const int p = b / s, q = b - p * s;
+      const int p = (int)(((unsigned)b * inv_s) >> 20), q = b - p * s;
       cplx a0 = ld(x, b), a1 = ld(x, b + span);
       cplx b0 = {a0.r + a1.r, a0.i + a1.i}, b1 = {a0.r - a1.r, a0.i - a1.i};
       const int o = q + s * 2 * p;
       st_tw(y, o, b0, tw, 0);
-      st_tw(y, o + s, b1, tw, (s * p) % W);
+      st_tw(y, o + s, b1, tw, s * p);
     }
   } else if (r == 3) {
     for (int b = lane; b < span; b += SPX_WAVE) {
-      const int p = b / s, q = b - p * s;
+      const int p = (int)(((unsigned)b * inv_s) >> 20), q = b - p * s;
       cplx a0 = ld(x, b), a1 = ld(x, b + span), a2 = ld(x, b + 2 * span);
       cplx t1 = {a1.r + a2.r, a1.i + a2.i};
       cplx t2 = {a0.r - 0.5 * t1.r, a0.i - 0.5 * t1.i};
@@ -177,12 +184,12 @@ __device__ void dft_stage(const SpxPlanDev& P, int r, int s, int cur, const doub
       const int o = q + s * 3 * p;
       const int tp = s * p;
       st_tw(y, o, b0, tw, 0);
-      st_tw(y, o + s, b1, tw, tp % W);
-      st_tw(y, o + 2 * s, b2, tw, (2 * tp) % W);
+      st_tw(y, o + s, b1, tw, tp);
+      st_tw(y, o + 2 * s, b2, tw, 2 * tp);
     }
   } else if (r == 5) {
     for (int b = lane; b < span; b += SPX_WAVE) {
-      const int p = b / s, q = b - p * s;
+      const int p = (int)(((unsigned)b * inv_s) >> 20), q = b - p * s;
       cplx a0 = ld(x, b), a1 = ld(x, b + span), a2 = ld(x, b + 2 * span), a3 = ld(x, b + 3 * span),
            a4 = ld(x, b + 4 * span);
       cplx t1 = {a1.r + a4.r, a1.i + a4.i}, t2 = {a2.r + a3.r, a2.i + a3.i};
@@ -197,17 +204,17 @@ __device__ void dft_stage(const SpxPlanDev& P, int r, int s, int cur, const doub
       const int o = q + s * 5 * p;
       const int tp = s * p;
       st_tw(y, o, b0, tw, 0);
-      st_tw(y, o + s, b1, tw, tp % W);
-      st_tw(y, o + 2 * s, b2, tw, (2 * tp) % W);
-      st_tw(y, o + 3 * s, b3, tw, (3 * tp) % W);
-      st_tw(y, o + 4 * s, b4, tw, (4 * tp) % W);
+      st_tw(y, o + s, b1, tw, tp);
+      st_tw(y, o + 2 * s, b2, tw, 2 * tp);
+      st_tw(y, o + 3 * s, b3, tw, 3 * tp);
+      st_tw(y, o + 4 * s, b4, tw, 4 * tp);
     }
   } else {
     // generic prime radix: one lane per (butterfly, output) pair, inputs accumulated in ascending order
     const int step = W / r;
     for (int item = lane; item < W; item += SPX_WAVE) {
       const int b = item / r, j = item - b * r;
-      const int p = b / s, q = b - p * s;
+      const int p = (int)(((unsigned)b * inv_s) >> 20), q = b - p * s;
       cplx acc = ld(x, b);
       for (int i = 1; i < r; i++) {
         cplx a = ld(x, b + i * span);
@@ -215,7 +222,7 @@ __device__ void dft_stage(const SpxPlanDev& P, int r, int s, int cur, const doub
         acc.r = acc.r + (a.r * w.x - a.i * w.y);
         acc.i = acc.i + (a.r * w.y + a.i * w.x);
       }
-      st_tw(y, q + s * (r * p + j), acc, tw, (int)(((long long)s * p * j) % W));
+      st_tw(y, q + s * (r * p + j), acc, tw, s * p * j);
     }
   }
   (void)m;
@@ -259,8 +266,31 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   float* fInv = fThr + (SPX_TF + 1);
   const int MS = W + 1;  // mags row stride (floats)
 
+  const size_t small_b = (((size_t)3 * (SPX_TF + 1) * sizeof(float)) + 15) & ~(size_t)15;
+  const double* ltw = P.tw;    // twiddles stay in global memory (L1-resident, 16 B per lane per use)
+  const double* ltw2 = P.tw2;
+  short* smono = reinterpret_cast<short*>(lds + wb + mags_b + small_b);    // mono mix of the tile's input span
+
   double* bufA = work + (size_t)wave * 4 * W;
   double* bufB = bufA + 2 * W;
+
+  // ---------------- phase 0: the tile's input span into LDS (all loads in flight) -------------
+  const int jfirst = (j0 > 0) ? j0 - 1 : 0;            // first frame whose samples are needed
+  const int64_t sbase = (int64_t)jfirst * B;           // absolute index of smono[0]
+  const int nstage = (j1 - jfirst) * B + (W - B);      // frames jfirst .. j1-1
+  if (C == 1) {
+    const int16_t* __restrict__ src = in + sbase;
+    for (int k0 = tid; k0 < nstage; k0 += 8 * SPX_BLOCK) {
+      short v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int k = k0 + u * SPX_BLOCK; v[u] = (k < nstage) ? src[k] : (short)0; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int k = k0 + u * SPX_BLOCK; if (k < nstage) smono[k] = v[u]; }
+    }
+  } else {
+    for (int k = tid; k < nstage; k += SPX_BLOCK) smono[k] = (short)mono_sample(in, sbase + k, C);
+  }
+  __syncthreads();
 
   ASTAMP_DECL
   // ---------------- phase 1: spectra of slots 0..TF (slot s = frame j0-1+s), one wave per slot ----------
@@ -271,14 +301,14 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       for (int k = lane; k < W; k += SPX_WAVE) mrow[k] = 0.0f;
       continue;
     }
-    const int64_t a0 = (int64_t)j * B;
+    const short* fr = smono + (size_t)(j - jfirst) * B;  // this frame's W mono samples
     for (int i = lane; i < 2 * W; i += SPX_WAVE) {
       double v = 0.0;
       if (i < W) {
-        const int m = mono_sample(in, a0 + i, C);
+        const int m = fr[i];
         int mp;
-        if (i > 0) mp = mono_sample(in, a0 + i - 1, C);
-        else mp = (j > 0) ? mono_sample(in, a0 + (W - B) - 1, C) : 0;
+        if (i > 0) mp = fr[i - 1];
+        else mp = (j > 0) ? (int)fr[(W - B) - 1] : 0;
         const float x = (float)(m / 32768.0);
         const float xp = (float)(mp / 32768.0);
         const float y = (float)(1.0 * (double)x - 0.97 * (double)xp);  // speedy.c:422
@@ -293,7 +323,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
     int sprod = 1, cur = W;
     for (int stg = 0; stg < P.nstages; stg++) {
       const int r = P.radix[stg];
-      dft_stage(P, r, sprod, cur, x, y, lane);
+      dft_stage(P, ltw, r, sprod, cur, x, y, lane);
       wave_sync();
       double* t = x; x = y; y = t;
       sprod *= r;
@@ -309,7 +339,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       const double er = 0.5 * (a.r + b_r), ei = 0.5 * (a.i + b_i);
       const double dr = a.r - b_r, di = a.i - b_i;
       const double o_r = 0.5 * di, o_i = -0.5 * dr;
-      const double2 w = *reinterpret_cast<const double2*>(P.tw2 + 2 * k);
+      const double2 w = *reinterpret_cast<const double2*>(ltw2 + 2 * k);
       const double xr = er + (w.x * o_r - w.y * o_i);
       const double xi = ei + (w.x * o_i + w.y * o_r);
       const float mag = (float)__builtin_sqrt(xr * xr + xi * xi);

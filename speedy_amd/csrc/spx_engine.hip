@@ -72,6 +72,11 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
     fail(-1, "spx_plan_create: too many DFT stages");
     return nullptr;
   }
+  if (spx_analysis_lds_bytes(d) > 160 * 1024) {  // one CU's LDS; reached above about 49 kHz
+    delete p;
+    fail(-1, "spx_plan_create: sample rate too high for the analysis tile (LDS)");
+    return nullptr;
+  }
   d.minPeriod = sample_rate / 400;
   d.maxPeriod = sample_rate / 65;
   d.maxRequired = 2 * d.maxPeriod;
