@@ -150,13 +150,13 @@ __device__ __forceinline__ int any_sample(const WalkCtx& X, int64_t a, int c) {
 
 // Make the window cover [pos, pos + need).  Uniform across the workgroup.  The biased mono signal and its
 // shifted copy are built here, once per refill, so a pitch step never touches HBM for its input.
-template <int NW>
+template <int NW, bool FAST>
 __device__ __forceinline__ void ensure_window(WalkCtx& X, int64_t pos, int need) {
   constexpr int NT = 64 * NW;
   if (X.wbase >= 0 && pos >= X.wbase && pos + need <= X.wbase + X.wcap) return;
   lds_sync<NW>();  // everyone is done reading the old window
   const int64_t nb = pos & ~(int64_t)7;
-  const int C = X.C;
+  const int C = FAST ? 1 : X.C;
   if (C == 1) {
     const int16_t* __restrict__ src = X.in + nb;
     const int64_t room = X.limit - nb;  // frames of real input from nb on
@@ -274,12 +274,12 @@ __device__ __forceinline__ void select_finish(const Sel& S, int* retBest, int* r
 // One lane per lag, the whole sum in the lane (no cross-lane traffic): used for the coarse search, which every
 // wave runs redundantly.  A0/A1: dword views of the signal array and of its copy shifted by one sample; o = offset
 // of the search position inside them.
-template <bool WANT_MAX>
+template <bool WANT_MAX, bool FAST>
 __device__ __forceinline__ void search_lane_per_lag(const unsigned* A0, const unsigned* A1, int o, int minP, int nl,
                                                     Sel& S) {
   const int lane = threadIdx.x & 63;
   const unsigned* ap = (o & 1) ? A1 + ((o - 1) >> 1) : A0 + (o >> 1);
-  for (int base = 0; base < nl; base += 64) {
+  for (int base = 0; base < (FAST ? 1 : nl); base += 64) {  // FAST: at most 64 lags per search
     const bool valid = base + lane < nl;
     const int p = minP + base + lane;
     const int ob = o + p;
@@ -295,12 +295,12 @@ __device__ __forceinline__ void search_lane_per_lag(const unsigned* A0, const un
 // (one lane per lag), the partial sums meet in LDS (ds_add_u32 into `buf`, which is all zero on entry), one
 // LDS barrier, then every wave folds the totals itself.  `other` is the buffer the PREVIOUS step used; every wave
 // is past reading it once this step's barrier is crossed, so it is cleared here for the next step.
-template <int NW, bool WANT_MAX>
+template <int NW, bool WANT_MAX, bool FAST>
 __device__ __forceinline__ void search_split(const unsigned* A0, const unsigned* A1, int o, int minP, int nl,
                                              unsigned* buf, unsigned* other, Sel& S, WalkCtx& X, int sb) {
   (void)X; (void)sb;
   if (NW == 1) {
-    search_lane_per_lag<WANT_MAX>(A0, A1, o, minP, nl, S);
+    search_lane_per_lag<WANT_MAX, FAST>(A0, A1, o, minP, nl, S);
     return;
   }
   constexpr int NT = 64 * NW;
@@ -308,7 +308,7 @@ __device__ __forceinline__ void search_split(const unsigned* A0, const unsigned*
   const int maxP = minP + nl - 1;
   const int CH = (((maxP >> 1) + NW) / NW + 3) & ~3;
   const unsigned* ap = (o & 1) ? A1 + ((o - 1) >> 1) : A0 + (o >> 1);
-  for (int base = 0; base < nl; base += 64) {
+  for (int base = 0; base < (FAST ? 1 : nl); base += 64) {  // FAST: at most 64 lags per search
     const bool valid = base + lane < nl;
     const int p = minP + base + lane;
     const int ob = o + p;
@@ -325,7 +325,7 @@ __device__ __forceinline__ void search_split(const unsigned* A0, const unsigned*
   lds_sync<NW>();
   STAMP(sb + 1);
   for (int t = tid; t < 256; t += NT) other[t] = 0;
-  for (int base = 0; base < nl; base += 64) {
+  for (int base = 0; base < (FAST ? 1 : nl); base += 64) {  // FAST: at most 64 lags per search
     const bool valid = base + lane < nl;
     const unsigned d = valid ? buf[base + lane] : 0u;
     select_fold<WANT_MAX>(S, d, minP + base, valid);
@@ -333,16 +333,16 @@ __device__ __forceinline__ void search_split(const unsigned* A0, const unsigned*
 }
 
 // findPitchPeriod at absolute position pos (all threads return the same value).
-template <int NW>
+template <int NW, bool FAST>
 __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X, WalkState& st, int64_t pos) {
   constexpr int NT = 64 * NW;
   const int tid = threadIdx.x;
-  const int C = X.C, skip = P.skip, maxRequired = P.maxRequired;
+  const int C = FAST ? 1 : X.C, skip = P.skip, maxRequired = P.maxRequired;
   STAMP(1);
-  ensure_window<NW>(X, pos, maxRequired + 2 * skip + 2);
+  ensure_window<NW, FAST>(X, pos, maxRequired + 2 * skip + 2);
   STAMP(2);
   const int o = (int)(pos - X.wbase);
-  const bool direct = (C == 1 && skip == 1);
+  const bool direct = FAST ? false : (C == 1 && skip == 1);
   // ---- phase B: the decimated, biased search signal of this step (earlier readers are past a barrier) ----
   const int cnt = maxRequired / skip;
   if (!direct) {
@@ -380,13 +380,13 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
   const int tg = st.prevPeriod_toggle & 1;
   st.prevPeriod_toggle ^= 1;
   Sel S1 = {0u, 0u, 0, 0};
-  if (direct || skip == 1) {  // this search is the final one: it also needs the worst lag
-    search_split<NW, true>(direct ? M0 : D0, direct ? M1 : D1, direct ? o : 0, minC, maxC - minC + 1,
+  if (!FAST && (direct || skip == 1)) {  // this search is the final one: it also needs the worst lag
+    search_split<NW, true, FAST>(direct ? M0 : D0, direct ? M1 : D1, direct ? o : 0, minC, maxC - minC + 1,
                            X.diffC + 256 * tg, X.diffC + 256 * (1 - tg), S1, X, 5);
     select_finish(S1, &period, &minDiff, &maxDiff);
     STAMP(7);
   } else {
-    search_split<NW, false>(D0, D1, 0, minC, maxC - minC + 1, X.diffC + 256 * tg, X.diffC + 256 * (1 - tg), S1, X, 5);
+    search_split<NW, false, FAST>(D0, D1, 0, minC, maxC - minC + 1, X.diffC + 256 * tg, X.diffC + 256 * (1 - tg), S1, X, 5);
     STAMP(7);
     period = S1.bestP * skip;
     int lo = period - (skip << 2), hi = period + (skip << 2);
@@ -394,7 +394,7 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
     if (hi > P.maxPeriod) hi = P.maxPeriod;
     // ---- refine at full rate ----
     Sel S2 = {0u, 0u, 0, 0};
-    search_split<NW, true>(M0, M1, o, lo, hi - lo + 1, X.diffR + 256 * tg, X.diffR + 256 * (1 - tg), S2, X, 8);
+    search_split<NW, true, FAST>(M0, M1, o, lo, hi - lo + 1, X.diffR + 256 * tg, X.diffR + 256 * (1 - tg), S2, X, 8);
     select_finish(S2, &period, &minDiff, &maxDiff);
     STAMP(10);
   }
@@ -407,10 +407,10 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
 }
 
 // Append n frames copied from absolute input position a.
-template <int NW>
+template <int NW, bool FAST>
 __device__ __forceinline__ void emit_copy(const WalkCtx& X, WalkState& st, int64_t a, int64_t n) {
   constexpr int NT = 64 * NW;
-  const int C = X.C;
+  const int C = FAST ? 1 : X.C;
   if (st.out_n + n > X.out_cap) st.overflow = 1;
   int64_t nv = X.out_cap - st.out_n;  // frames that still fit
   if (nv > n) nv = n;
@@ -434,11 +434,11 @@ __device__ __forceinline__ void emit_copy(const WalkCtx& X, WalkState& st, int64
 // Append n frames of cross-fade: out[t] = (down[t]*(n-t) + up[t]*t)/n, integer, truncating toward zero.
 // |numerator| <= 32768*n < 2^31; the quotient is taken as trunc(|num| * (1/n) + 2^-20) in double, which is exact:
 // non-integer quotients are at least 1/n >= 2^-11 below the next integer, integer ones land 2^-20 above.
-template <int NW>
+template <int NW, bool FAST>
 __device__ __forceinline__ void emit_overlap_add(const WalkCtx& X, int64_t a_down, int64_t a_up, int n,
                                                  int64_t out_at) {
   constexpr int NT = 64 * NW;
-  const int C = X.C;
+  const int C = FAST ? 1 : X.C;
   const double inv = 1.0 / (double)n;
   int64_t nv64 = X.out_cap - out_at;
   const int nv = nv64 > n ? n : (nv64 < 0 ? 0 : (int)nv64);
@@ -470,7 +470,7 @@ __device__ __forceinline__ void emit_overlap_add(const WalkCtx& X, int64_t a_dow
 }
 
 // processStreamInput with `avail` frames handed over so far (absolute count).
-template <int NW>
+template <int NW, bool FAST>
 __device__ __forceinline__ void tsm_process(const SpxPlanDev& P, WalkCtx& X, WalkState& st, float speed, int64_t avail) {
   const int maxRequired = P.maxRequired;
   if ((double)speed > 1.00001 || (double)speed < 0.99999) {
@@ -481,12 +481,12 @@ __device__ __forceinline__ void tsm_process(const SpxPlanDev& P, WalkCtx& X, Wal
       if (st.remaining > 0) {
         int n = st.remaining;
         if (n > maxRequired) n = maxRequired;
-        emit_copy<NW>(X, st, st.base + position, n);
+        emit_copy<NW, FAST>(X, st, st.base + position, n);
         st.remaining -= n;
         position += n;
       } else {
         const int64_t pos = st.base + position;
-        const int period = find_pitch_period<NW>(P, X, st, pos);
+        const int period = find_pitch_period<NW, FAST>(P, X, st, pos);
         if ((double)speed > 1.0) {
           int n;  // the dependency converts to long; every value here fits an int
           if (speed >= 2.0f) {
@@ -498,7 +498,7 @@ __device__ __forceinline__ void tsm_process(const SpxPlanDev& P, WalkCtx& X, Wal
           if (st.out_n + n > X.out_cap) st.overflow = 1;
           if (n == 0) return;  // the dependency treats this as failure and leaves the input untouched
           STAMP(11);
-          emit_overlap_add<NW>(X, pos, pos + period, n, st.out_n);
+          emit_overlap_add<NW, FAST>(X, pos, pos + period, n, st.out_n);
           STAMP(13);
           st.out_n += n;
           position += period + n;
@@ -510,10 +510,10 @@ __device__ __forceinline__ void tsm_process(const SpxPlanDev& P, WalkCtx& X, Wal
             n = period;
             st.remaining = uni((int)((float)period * (2.0f * speed - 1.0f) / (1.0f - speed)));
           }
-          emit_copy<NW>(X, st, pos, period);
+          emit_copy<NW, FAST>(X, st, pos, period);
           if (st.out_n + n > X.out_cap) st.overflow = 1;
           if (n == 0) return;
-          emit_overlap_add<NW>(X, pos + period, pos, n, st.out_n);
+          emit_overlap_add<NW, FAST>(X, pos + period, pos, n, st.out_n);
           st.out_n += n;
           position += n;
         }
@@ -521,7 +521,7 @@ __device__ __forceinline__ void tsm_process(const SpxPlanDev& P, WalkCtx& X, Wal
     } while (position + maxRequired <= numSamples);
     st.base += position;
   } else {
-    emit_copy<NW>(X, st, st.base, avail - st.base);
+    emit_copy<NW, FAST>(X, st, st.base, avail - st.base);
     st.base = avail;
   }
 }
@@ -557,7 +557,7 @@ static __host__ __device__ inline WalkLds walk_lds_layout(const SpxPlanDev& P, i
   return L;
 }
 
-template <int NW>
+template <int NW, bool FAST>
 __global__ void __launch_bounds__(64 * NW)
 spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const int16_t* __restrict__ in_base,
                 int16_t* __restrict__ out_base, int64_t* __restrict__ n_out, SpxStreamState* __restrict__ states,
@@ -803,7 +803,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
       avail += 2 * P.maxRequired;
     }
     STAMP(0);
-    tsm_process<NW>(P, X, st, curSpeed, avail);
+    tsm_process<NW, FAST>(P, X, st, curSpeed, avail);
     STAMP(12);
     if (ev >= ev1) {
       if (st.out_n > expected) st.out_n = expected;
@@ -833,8 +833,17 @@ void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_str
   int nw = (n_streams <= 256) ? 8 : (n_streams <= 1024) ? 4 : 1;  // measured on MI355X: 5.14 / 5.34 / 6.77 ms at 256 streams
   if (const char* e = getenv("SPX_WALK_NW")) nw = atoi(e);
 #define SPX_LAUNCH_WALK(NWV)                                                                                     \
-  hipLaunchKernelGGL(spx_walk_kernel<NWV>, dim3(n_streams), dim3(64 * NWV), LY.total, st, P, streams, in, out,    \
-                     n_out, states, rec, scratch, taps, maxC)
+  do {                                                                                                           \
+    if (fast)                                                                                                    \
+      hipLaunchKernelGGL((spx_walk_kernel<NWV, true>), dim3(n_streams), dim3(64 * NWV), LY.total, st, P, streams,  \
+                         in, out, n_out, states, rec, scratch, taps, maxC);                                      \
+    else                                                                                                         \
+      hipLaunchKernelGGL((spx_walk_kernel<NWV, false>), dim3(n_streams), dim3(64 * NWV), LY.total, st, P, streams, \
+                         in, out, n_out, states, rec, scratch, taps, maxC);                                      \
+  } while (0)
+  // FAST: every stream mono, decimated search, and at most 64 lags in either search (rates below 32 kHz)
+  const bool fast = maxC == 1 && P.skip >= 2 && (P.maxPeriod / P.skip - P.minPeriod / P.skip + 1) <= 64 &&
+                    (8 * P.skip + 1) <= 64 && !getenv("SPX_WALK_GENERIC");
   switch (nw) {
     case 1: SPX_LAUNCH_WALK(1); break;
     case 2: SPX_LAUNCH_WALK(2); break;
