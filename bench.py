@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for "
+                    "a functional check of the N > 1 path on a single GPU)")
     args = ap.parse_args()
 
     import torch
@@ -78,12 +80,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (the product has no CPU path)")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if local_rank < ndev else local_rank % max(1, ndev)
+    torch.cuda.set_device(dev_index)
     dist = None
+    red_dev = "cuda"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
+            red_dev = "cpu"
+        # work-partition handshake: every rank announces its shard (stream count, input frames)
+        from speedy_amd.dist import handshake
+        layout = handshake(dist, STREAMS_PER_GPU, STREAMS_PER_GPU * RATE * SECONDS, device=red_dev)
+        assert layout.shape == (world, 2)
 
     from speedy_amd.batch import Batch, Plan
     n = RATE * SECONDS
@@ -112,7 +125,7 @@ def main():
     sa, sw, nc = C.c_double(0), C.c_double(0), C.c_int(0)
     L.spx_timing_collect(C.byref(sa), C.byref(sw), C.byref(nc))
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     outs = b.results()
