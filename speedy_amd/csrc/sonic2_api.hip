@@ -291,6 +291,10 @@ static int write_shorts(sonicStream s, const short* in, int sampleCount) {
   }
   if (s->mode == 1 && s->bufferSize == 0) s->bufferSize = s->plan->B;  // sonicAllocateBuffers, soniclib.c:195
   if (!in || sampleCount <= 0) return 1;
+  if (s->nIn + sampleCount >= (1ll << 30)) {
+    g_api_err = "stream longer than 2^30 frames is not supported";
+    return 0;
+  }
   const size_t C = (size_t)s->channels;
   if (!s->dIn.reserve((size_t)(s->nIn + sampleCount) * C + 64, (size_t)s->nIn * C, s->hs)) return 0;
   if (hipMemcpyAsync(s->dIn.p + (size_t)s->nIn * C, in, sizeof(short) * (size_t)sampleCount * C,

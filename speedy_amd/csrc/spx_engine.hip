@@ -193,6 +193,7 @@ static int build_streams(const SpxPlanDev& d, const spx_stream_job* jobs, int n,
   for (int i = 0; i < n; i++) {
     const spx_stream_job& j = jobs[i];
     if (j.channels < 1 || j.n_in < 0) return fail(-1, "spx_batch: bad job");
+    if (j.n_in >= (1ll << 30)) return fail(-1, "spx_batch: stream of 2^30 frames or more (in-kernel positions are 32-bit)");
     SpxStreamDev& s = v[i];
     s.in_off = j.in_off; s.n_in = j.n_in; s.out_off = j.out_off; s.out_cap = j.out_cap;
     s.channels = j.channels; s.speed = j.speed; s.nonlinear = j.nonlinear; s.feedback = j.feedback;

@@ -32,7 +32,13 @@
 
 #define SPX_CH 1024  // frames per prologue chunk held in LDS
 
-typedef SpxWalkState WalkState;
+// In-kernel positions are 32-bit (the host rejects streams of 2^30 frames or more): half the SGPRs and none of the
+// 64-bit add/compare sequences in the per-step bookkeeping.  The carried state record stays 64-bit.
+typedef int pos_t;
+struct WalkState {
+  pos_t base, out_n, avail;
+  int remaining, prevPeriod, prevMinDiff, overflow, prevPeriod_toggle;
+};
 
 // Values that are the same in every lane but that the compiler cannot prove uniform (they come from LDS or from
 // lane-indexed loads): pin them to SGPRs so the bookkeeping around a pitch step runs on the scalar unit.
@@ -116,14 +122,14 @@ __device__ __forceinline__ float wave_max_f(float v) {
 struct WalkCtx {
   const int16_t* in;  // stream input (interleaved)
   int16_t* out;       // stream output
-  int64_t out_cap;
-  int64_t limit;      // absolute frame index from which reads return 0 (end of input / flush padding)
+  pos_t out_cap;
+  pos_t limit;      // absolute frame index from which reads return 0 (end of input / flush padding)
   int C;
   // LDS sliding window over frames [wbase, wbase + wcap)
   unsigned short* monoH;   // mono mix biased by 32768: monoH[k] = mono(wbase + k) + 32768
   unsigned short* monoHB;  // the same shifted by one frame: monoHB[k] = monoH[k + 1]
   short* raw;              // interleaved raw samples, only kept when C > 1 (the cross-fade is per channel)
-  int64_t wbase;           // -1 = window invalid
+  pos_t wbase;           // -1 = window invalid
   int wcap;
   unsigned short* dnH;     // biased decimated signal of the current step (and its shifted copy)
   unsigned short* dnHB;
@@ -135,12 +141,12 @@ struct WalkCtx {
 #endif
 };
 
-__device__ __forceinline__ int global_sample(const WalkCtx& X, int64_t a, int c) {
-  return (a < X.limit) ? (int)X.in[a * X.C + c] : 0;
+__device__ __forceinline__ int global_sample(const WalkCtx& X, pos_t a, int c) {
+  return (a < X.limit) ? (int)X.in[(size_t)a * X.C + c] : 0;
 }
 // sample through the LDS window when it covers frame a, else from HBM
-__device__ __forceinline__ int any_sample(const WalkCtx& X, int64_t a, int c) {
-  const int64_t o = a - X.wbase;
+__device__ __forceinline__ int any_sample(const WalkCtx& X, pos_t a, int c) {
+  const pos_t o = a - X.wbase;
   if (X.wbase >= 0 && o >= 0 && o < X.wcap) {
     if (X.C == 1) return (int)X.monoH[o] - 32768;
     return (int)X.raw[o * X.C + c];
@@ -151,15 +157,15 @@ __device__ __forceinline__ int any_sample(const WalkCtx& X, int64_t a, int c) {
 // Make the window cover [pos, pos + need).  Uniform across the workgroup.  The biased mono signal and its
 // shifted copy are built here, once per refill, so a pitch step never touches HBM for its input.
 template <int NW, bool FAST>
-__device__ __forceinline__ void ensure_window(WalkCtx& X, int64_t pos, int need) {
+__device__ __forceinline__ void ensure_window(WalkCtx& X, pos_t pos, int need) {
   constexpr int NT = 64 * NW;
   if (X.wbase >= 0 && pos >= X.wbase && pos + need <= X.wbase + X.wcap) return;
   lds_sync<NW>();  // everyone is done reading the old window
-  const int64_t nb = pos & ~(int64_t)7;
+  const pos_t nb = pos & ~7;
   const int C = FAST ? 1 : X.C;
   if (C == 1) {
     const int16_t* __restrict__ src = X.in + nb;
-    const int64_t room = X.limit - nb;  // frames of real input from nb on
+    const pos_t room = X.limit - nb;  // frames of real input from nb on
     for (int k0 = threadIdx.x; k0 < X.wcap + 1; k0 += 8 * NT) {
       int v[8];
 #pragma unroll
@@ -177,10 +183,10 @@ __device__ __forceinline__ void ensure_window(WalkCtx& X, int64_t pos, int need)
     }
   } else {
     for (int k = threadIdx.x; k < X.wcap + 1; k += NT) {
-      const int64_t g = nb + k;
+      const pos_t g = nb + k;
       int sum = 0;
       for (int c = 0; c < C; c++) {
-        const int v = (g < X.limit) ? (int)X.in[g * C + c] : 0;
+        const int v = (g < X.limit) ? (int)X.in[(size_t)g * C + c] : 0;
         if (k < X.wcap) X.raw[(size_t)k * C + c] = (short)v;
         sum += v;
       }
@@ -334,7 +340,7 @@ __device__ __forceinline__ void search_split(const unsigned* A0, const unsigned*
 
 // findPitchPeriod at absolute position pos (all threads return the same value).
 template <int NW, bool FAST>
-__device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X, WalkState& st, int64_t pos) {
+__device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X, WalkState& st, pos_t pos) {
   constexpr int NT = 64 * NW;
   const int tid = threadIdx.x;
   const int C = FAST ? 1 : X.C, skip = P.skip, maxRequired = P.maxRequired;
@@ -408,21 +414,21 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
 
 // Append n frames copied from absolute input position a.
 template <int NW, bool FAST>
-__device__ __forceinline__ void emit_copy(const WalkCtx& X, WalkState& st, int64_t a, int64_t n) {
+__device__ __forceinline__ void emit_copy(const WalkCtx& X, WalkState& st, pos_t a, pos_t n) {
   constexpr int NT = 64 * NW;
   const int C = FAST ? 1 : X.C;
   if (st.out_n + n > X.out_cap) st.overflow = 1;
-  int64_t nv = X.out_cap - st.out_n;  // frames that still fit
+  pos_t nv = X.out_cap - st.out_n;  // frames that still fit
   if (nv > n) nv = n;
-  const int64_t o = a - X.wbase;
-  int16_t* __restrict__ dst = X.out + st.out_n * C;
+  const pos_t o = a - X.wbase;
+  int16_t* __restrict__ dst = X.out + (size_t)st.out_n * C;
   if (C == 1 && X.wbase >= 0 && o >= 0 && o + n <= X.wcap) {  // whole run inside the LDS window
     const unsigned short* w = X.monoH + o;
     for (int t = threadIdx.x; t < (int)nv; t += NT) dst[t] = (int16_t)((int)w[t] - 32768);
   } else {
-    const int64_t total = nv * C;
-    for (int64_t e = threadIdx.x; e < total; e += NT) {
-      int64_t f = e;
+    const pos_t total = nv * C;
+    for (pos_t e = threadIdx.x; e < total; e += NT) {
+      pos_t f = e;
       int c = 0;
       if (C != 1) { f = e / C; c = (int)(e - f * C); }
       dst[e] = (int16_t)any_sample(X, a + f, c);
@@ -435,15 +441,15 @@ __device__ __forceinline__ void emit_copy(const WalkCtx& X, WalkState& st, int64
 // |numerator| <= 32768*n < 2^31; the quotient is taken as trunc(|num| * (1/n) + 2^-20) in double, which is exact:
 // non-integer quotients are at least 1/n >= 2^-11 below the next integer, integer ones land 2^-20 above.
 template <int NW, bool FAST>
-__device__ __forceinline__ void emit_overlap_add(const WalkCtx& X, int64_t a_down, int64_t a_up, int n,
-                                                 int64_t out_at) {
+__device__ __forceinline__ void emit_overlap_add(const WalkCtx& X, pos_t a_down, pos_t a_up, int n,
+                                                 pos_t out_at) {
   constexpr int NT = 64 * NW;
   const int C = FAST ? 1 : X.C;
   const double inv = 1.0 / (double)n;
-  int64_t nv64 = X.out_cap - out_at;
+  pos_t nv64 = X.out_cap - out_at;
   const int nv = nv64 > n ? n : (nv64 < 0 ? 0 : (int)nv64);
-  int16_t* __restrict__ dst = X.out + out_at * C;
-  const int64_t od = a_down - X.wbase, ou = a_up - X.wbase;
+  int16_t* __restrict__ dst = X.out + (size_t)out_at * C;
+  const pos_t od = a_down - X.wbase, ou = a_up - X.wbase;
   const bool inwin = X.wbase >= 0 && od >= 0 && ou >= 0 && od + n <= X.wcap && ou + n <= X.wcap;
   if (C == 1 && inwin) {
     const unsigned short* wd = X.monoH + od;
@@ -471,12 +477,12 @@ __device__ __forceinline__ void emit_overlap_add(const WalkCtx& X, int64_t a_dow
 
 // processStreamInput with `avail` frames handed over so far (absolute count).
 template <int NW, bool FAST>
-__device__ __forceinline__ void tsm_process(const SpxPlanDev& P, WalkCtx& X, WalkState& st, float speed, int64_t avail) {
+__device__ __forceinline__ void tsm_process(const SpxPlanDev& P, WalkCtx& X, WalkState& st, float speed, pos_t avail) {
   const int maxRequired = P.maxRequired;
   if ((double)speed > 1.00001 || (double)speed < 0.99999) {
-    const int64_t numSamples = avail - st.base;
+    const pos_t numSamples = avail - st.base;
     if (numSamples < maxRequired) return;
-    int64_t position = 0;
+    pos_t position = 0;
     do {
       if (st.remaining > 0) {
         int n = st.remaining;
@@ -485,7 +491,7 @@ __device__ __forceinline__ void tsm_process(const SpxPlanDev& P, WalkCtx& X, Wal
         st.remaining -= n;
         position += n;
       } else {
-        const int64_t pos = st.base + position;
+        const pos_t pos = st.base + position;
         const int period = find_pitch_period<NW, FAST>(P, X, st, pos);
         if ((double)speed > 1.0) {
           int n;  // the dependency converts to long; every value here fits an int
@@ -743,8 +749,8 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   WalkCtx X;
   X.in = in_base + S.in_off;
   X.out = out_base + S.out_off;
-  X.out_cap = S.out_cap;
-  X.limit = S.n_in;
+  X.out_cap = (pos_t)(S.out_cap > 0x7fffffff ? 0x7fffffff : S.out_cap);
+  X.limit = (pos_t)S.n_in;
   X.C = S.channels;
   X.monoH = reinterpret_cast<unsigned short*>(lds + LY.off_mono);
   X.monoHB = reinterpret_cast<unsigned short*>(lds + LY.off_monoB);
@@ -758,33 +764,33 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   for (int t = tid; t < 512; t += NT) { X.diffR[t] = 0; X.diffC[t] = 0; }
   __syncthreads();
   STAMP_DECL
-  WalkState st = Z.w;
-  st.base = uni64(st.base); st.out_n = uni64(st.out_n); st.avail = uni64(st.avail);
-  st.remaining = uni(st.remaining); st.prevPeriod = uni(st.prevPeriod); st.prevMinDiff = uni(st.prevMinDiff);
-  st.overflow = uni(st.overflow); st.prevPeriod_toggle = uni(st.prevPeriod_toggle);
+  WalkState st;
+  st.base = uni((pos_t)Z.w.base); st.out_n = uni((pos_t)Z.w.out_n); st.avail = uni((pos_t)Z.w.avail);
+  st.remaining = uni(Z.w.remaining); st.prevPeriod = uni(Z.w.prevPeriod); st.prevMinDiff = uni(Z.w.prevMinDiff);
+  st.overflow = uni(Z.w.overflow); st.prevPeriod_toggle = uni(Z.w.prevPeriod_toggle);
   float curSpeed = unif(Z.curSpeed);
-  int64_t avail = st.avail;
+  pos_t avail = st.avail;
   // Events, in the order the shim issues them:
   //   nonlinear: one (setSpeed, write B) per tension frame           soniclib.c:354,369
   //              at flush, the remaining complete ring buffers at the last speed   soniclib.c:538-550
   //   linear:    one write of everything new (soniclib.c:397-399; chunking is irrelevant at constant speed)
   //   at flush:  sonicIntFlushStream (soniclib.c:551): pad 2*maxRequired zeros, process, truncate
   const bool do_flush = (S.flags & SPX_F_FLUSH) != 0;
-  const int64_t ev0 = (nl != 0.0f) ? Z.handed : 0;
-  int64_t ev1;  // one past the last ordinary event
-  if (nl != 0.0f) ev1 = do_flush ? S.n_in / B : K;  // complete ring buffers written: soniclib.c:446-449
-  else ev1 = (S.n_in > avail) ? 1 : 0;
+  const pos_t ev0 = (nl != 0.0f) ? Z.handed : 0;
+  pos_t ev1;  // one past the last ordinary event
+  if (nl != 0.0f) ev1 = do_flush ? (pos_t)(S.n_in / B) : K;  // complete ring buffers written: soniclib.c:446-449
+  else ev1 = ((pos_t)S.n_in > avail) ? 1 : 0;
   if (ev1 < ev0) ev1 = ev0;
-  const int64_t ev_end = ev1 + (do_flush ? 1 : 0);
-  for (int64_t ev = ev0; ev < ev_end; ev++) {
-    int64_t expected = 0;
+  const pos_t ev_end = ev1 + (do_flush ? 1 : 0);
+  for (pos_t ev = ev0; ev < ev_end; ev++) {
+    pos_t expected = 0;
     if (ev < ev1) {
       if (nl != 0.0f) {
         if (ev < K) {
           const int i = (int)((ev - ev0) % SPX_CH);
           if (i == 0) {  // stage the next chunk of speeds in LDS
             __syncthreads();
-            const int n = (int)min((int64_t)SPX_CH, (int64_t)K - ev);
+            const int n = (int)min((pos_t)SPX_CH, (pos_t)K - ev);
             for (int t = tid; t < n; t += NT) sA[t] = scr[4 * (ev + t) + 3];
             __syncthreads();
           }
@@ -792,10 +798,10 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
         }
         avail += B;
       } else {
-        avail = S.n_in;
+        avail = (pos_t)S.n_in;
       }
     } else {
-      const int64_t remainingS = avail - st.base;
+      const pos_t remainingS = avail - st.base;
       expected = st.out_n + uni((int)(((float)remainingS / curSpeed + 0) / 1.0f + 0.5f));
       X.limit = avail;  // everything from here on reads as the flush's zero padding
       lds_sync<NW>();
@@ -813,12 +819,13 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   }
   STAMP_FLUSH
   if (tid == 0) {
-    st.avail = avail;
-    Z.w = st;
+    Z.w.base = st.base; Z.w.out_n = st.out_n; Z.w.avail = avail; Z.w.remaining = st.remaining;
+    Z.w.prevPeriod = st.prevPeriod; Z.w.prevMinDiff = st.prevMinDiff; Z.w.overflow = st.overflow;
+    Z.w.prevPeriod_toggle = st.prevPeriod_toggle; Z.w.pad_ = 0;
     Z.curSpeed = curSpeed;
     if (nl != 0.0f) Z.handed = (int)ev1;
     states[blockIdx.x] = Z;
-    if (n_out) n_out[blockIdx.x] = st.overflow ? -st.out_n : st.out_n;
+    if (n_out) n_out[blockIdx.x] = st.overflow ? -(int64_t)st.out_n : (int64_t)st.out_n;
   }
 }
 
