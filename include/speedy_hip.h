@@ -96,8 +96,13 @@ int spx_batch_walk(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, c
 
 /* Timing hooks for bench.py: while enabled, every spx_batch_run records HIP events on hip_stream around
  * each of its two kernels (no host synchronisation is added to the call).  spx_timing_collect waits for the
- * recorded events, returns the summed kernel milliseconds and the number of calls since the last collect. */
+ * recorded events, returns the summed kernel milliseconds (over all launches of each kernel) and the number of
+ * spx_batch_run calls since the last collect. */
 void spx_set_timing(int enabled);
+/* spx_batch_run splits every stream into `chunks` consecutive time ranges (default 1 = off; on MI355X the extra launch tails cost more than the overlap gains at 256 x 10 s) and overlaps the
+ * analysis of range c+1 (on an internal HIP stream) with the walk of range c (on hip_stream); results are
+ * identical for any value, the state record is carried exactly as in the streaming API. */
+void spx_set_pipeline_chunks(int chunks);
 int spx_timing_collect(double* sum_ms_analyze, double* sum_ms_walk, int* n_calls);
 
 /* ---- plain device-memory helpers (so that C/C++ hosts need no HIP headers) ---- */

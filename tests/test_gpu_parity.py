@@ -144,3 +144,23 @@ def test_full_size_round_trip_properties():
         assert np.array_equal(r1[i], r2[i])
         assert np.array_equal(r1[i], r1[i % 8])  # same input, any slot of the batch -> same bytes
         assert 2.5 < n / r1[i].size < 4.5
+
+
+@pytest.mark.parametrize("chunks", [2, 5])
+def test_time_chunk_pipelining_is_bit_exact(orc, chunks):
+    """spx_set_pipeline_chunks: the batch call split into time ranges (analysis of range c+1 overlapping the walk of
+    range c on a second HIP stream) must give the same bytes as the single-range call."""
+    from speedy_amd._lib import lib
+    from speedy_amd.synth import speech_like
+    rate = 16000
+    streams = [speech_like(30000 + 777 * i, rate, seed=40 + i, channels=1 + (i & 1)) for i in range(5)]
+    chs = [1 + (i & 1) for i in range(5)]
+    nls = [1.0, 1.0, 0.0, 1.0, 1.0]
+    try:
+        lib().spx_set_pipeline_chunks(chunks)
+        outs, b = _batch(streams, rate, chs, [3.5, 1.5, 2.0, 0.6, 3.5], nls, 0.1, False, taps=False)
+    finally:
+        lib().spx_set_pipeline_chunks(1)
+    for i, x in enumerate(streams):
+        ref = _oracle(orc, x, rate, chs[i], [3.5, 1.5, 2.0, 0.6, 3.5][i], nls[i], 0.1, False)
+        assert np.array_equal(outs[i], ref["out"]), i
