@@ -164,3 +164,66 @@ def test_time_chunk_pipelining_is_bit_exact(orc, chunks):
     for i, x in enumerate(streams):
         ref = _oracle(orc, x, rate, chs[i], [3.5, 1.5, 2.0, 0.6, 3.5][i], nls[i], 0.1, False)
         assert np.array_equal(outs[i], ref["out"]), i
+
+
+@pytest.mark.parametrize("speed,nl", [(2.0, 0.0), (3.5, 1.0)])
+def test_baseline_single_stream_60s(orc, speed, nl):
+    """BASELINE configs[1] (60 s, 2.0x linear: TSM only) and configs[2] (60 s, 3.5x nonlinear: full path), one stream."""
+    from speedy_amd.synth import speech_like
+    rate, n = 16000, 960000
+    x = speech_like(n, rate, seed=77)
+    outs, b = _batch([x], rate, 1, speed, nl, 0.0, False, taps=(nl != 0))
+    ref = _oracle(orc, x, rate, 1, speed, nl, 0.0, False)
+    if nl:
+        taps = b.tap_arrays(0)
+        assert taps["tension"].shape == ref["tension"].shape
+        assert np.array_equal(taps["tension"], ref["tension"])
+        assert np.array_equal(taps["speed"], ref["speed"])
+    assert np.array_equal(outs[0], ref["out"])
+    assert abs(n / outs[0].size - speed) < 0.15 * speed
+
+
+def test_baseline_mixed_batch_shape(orc):
+    """BASELINE configs[4] in miniature: stream i has rate 16000 if i even else 22050, channels 1 if (i/2) even
+    else 2, speed 1.5 if (i/4) even else 3.5, nonlinear 1.  One plan (one launch pair) per rate."""
+    from speedy_amd.synth import speech_like
+    n_streams = 16
+    cfg = [(16000 if i % 2 == 0 else 22050, 1 if (i // 2) % 2 == 0 else 2, 1.5 if (i // 4) % 2 == 0 else 3.5)
+           for i in range(n_streams)]
+    for rate in (16000, 22050):
+        idx = [i for i in range(n_streams) if cfg[i][0] == rate]
+        streams = [speech_like(3 * rate, rate, seed=200 + i, channels=cfg[i][1]) for i in idx]
+        outs, b = _batch(streams, rate, [cfg[i][1] for i in idx], [cfg[i][2] for i in idx], 1.0, 0.0, False, taps=False)
+        for k, i in enumerate(idx):
+            ref = _oracle(orc, streams[k], rate, cfg[i][1], cfg[i][2], 1.0, 0.0, False)
+            assert np.array_equal(outs[k], ref["out"]), (rate, i)
+
+
+def test_streaming_random_chunking(orc):
+    """Ragged write sizes (1 .. 4000 frames, some empty) through the streaming API: same bytes as one big write."""
+    from speedy_amd.sonic2 import SonicStream
+    from speedy_amd.synth import speech_like
+    rate = 16000
+    x = speech_like(60000, rate, seed=5, channels=2)
+    ref = _oracle(orc, x, rate, 2, 3.5, 1.0, 0.1, False)["out"]
+    rng = np.random.default_rng(3)
+    s = SonicStream(rate, 2, False)
+    s.set_speed(3.5)
+    s.enable_nonlinear(1.0)
+    s.set_feedback(0.1)
+    pos, n, outs = 0, x.size // 2, []
+    while pos < n:
+        k = int(rng.choice([0, 1, 7, 160, 161, 999, 4000]))
+        seg = x[pos * 2:(pos + k) * 2]
+        assert s.write_short(seg) == 1
+        pos += seg.size // 2
+        if rng.random() < 0.5:
+            outs.append(s.read_short(int(rng.integers(1, 3000))))
+    s.flush()
+    while True:
+        got = s.read_short(1000)
+        if got.size == 0:
+            break
+        outs.append(got)
+    s.close()
+    assert np.array_equal(np.concatenate(outs), ref)
