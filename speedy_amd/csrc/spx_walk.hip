@@ -282,7 +282,7 @@ __device__ __forceinline__ void select_finish(const Sel& S, int* retBest, int* r
 // of the search position inside them.
 template <bool WANT_MAX, bool FAST>
 __device__ __forceinline__ void search_lane_per_lag(const unsigned* A0, const unsigned* A1, int o, int minP, int nl,
-                                                    Sel& S) {
+                                                    Sel& S, unsigned* dlane = nullptr) {
   const int lane = threadIdx.x & 63;
   const unsigned* ap = (o & 1) ? A1 + ((o - 1) >> 1) : A0 + (o >> 1);
   for (int base = 0; base < (FAST ? 1 : nl); base += 64) {  // FAST: at most 64 lags per search
@@ -293,6 +293,7 @@ __device__ __forceinline__ void search_lane_per_lag(const unsigned* A0, const un
     const int nfull = valid ? (p >> 1) : 0;
     unsigned d = sad_run(ap, bp, 0, nfull);
     if (valid && (p & 1)) d = __builtin_amdgcn_sad_u16(ap[nfull] & 0xffffu, bp[nfull] & 0xffffu, d);  // term i = p-1
+    if (dlane && base == 0) *dlane = d;
     select_fold<WANT_MAX>(S, d, minP + base, valid);
   }
 }
@@ -303,10 +304,10 @@ __device__ __forceinline__ void search_lane_per_lag(const unsigned* A0, const un
 // is past reading it once this step's barrier is crossed, so it is cleared here for the next step.
 template <int NW, bool WANT_MAX, bool FAST>
 __device__ __forceinline__ void search_split(const unsigned* A0, const unsigned* A1, int o, int minP, int nl,
-                                             unsigned* buf, unsigned* other, Sel& S, WalkCtx& X, int sb) {
+                                             unsigned* buf, unsigned* other, Sel& S, WalkCtx& X, int sb, unsigned* dlane = nullptr) {
   (void)X; (void)sb;
   if (NW == 1) {
-    search_lane_per_lag<WANT_MAX, FAST>(A0, A1, o, minP, nl, S);
+    search_lane_per_lag<WANT_MAX, FAST>(A0, A1, o, minP, nl, S, dlane);
     return;
   }
   constexpr int NT = 64 * NW;
@@ -334,6 +335,7 @@ __device__ __forceinline__ void search_split(const unsigned* A0, const unsigned*
   for (int base = 0; base < (FAST ? 1 : nl); base += 64) {  // FAST: at most 64 lags per search
     const bool valid = base + lane < nl;
     const unsigned d = valid ? buf[base + lane] : 0u;
+    if (dlane && base == 0) *dlane = d;
     select_fold<WANT_MAX>(S, d, minP + base, valid);
   }
 }
@@ -400,8 +402,26 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
     if (hi > P.maxPeriod) hi = P.maxPeriod;
     // ---- refine at full rate ----
     Sel S2 = {0u, 0u, 0, 0};
-    search_split<NW, true, FAST>(M0, M1, o, lo, hi - lo + 1, X.diffR + 256 * tg, X.diffR + 256 * (1 - tg), S2, X, 8);
-    select_finish(S2, &period, &minDiff, &maxDiff);
+    if (FAST) {
+      // Only "maxDiff > 3*minDiff" is ever asked of the worst lag, and max_p floor(d_p/p) = floor(max_p d_p/p), so
+      // the test is "some lag has d_p >= (3*minDiff+1)*p": no arg-max, and only on the steps where the
+      // previous-period rule can fire at all.
+      unsigned dl = 0;
+      search_split<NW, false, FAST>(M0, M1, o, lo, hi - lo + 1, X.diffR + 256 * tg, X.diffR + 256 * (1 - tg), S2, X, 8,
+                                    &dl);
+      period = uni(S2.bestP);
+      minDiff = uni((int)udiv_small(S2.bestD, (unsigned)S2.bestP));
+      maxDiff = 0x7fffffff;  // "a clear match" unless shown otherwise
+      if (minDiff != 0 && st.prevPeriod != 0 && minDiff * 2 > st.prevMinDiff * 3) {
+        const int lane = tid & 63;
+        const bool valid = lane < hi - lo + 1;
+        const unsigned long long need = (unsigned long long)(3u * (unsigned)minDiff + 1u) * (unsigned)(lo + lane);
+        if (__ballot(valid && (unsigned long long)dl >= need) == 0) maxDiff = 0;  // no lag that bad: keep the old period
+      }
+    } else {
+      search_split<NW, true, FAST>(M0, M1, o, lo, hi - lo + 1, X.diffR + 256 * tg, X.diffR + 256 * (1 - tg), S2, X, 8);
+      select_finish(S2, &period, &minDiff, &maxDiff);
+    }
     STAMP(10);
   }
   int ret = period;
