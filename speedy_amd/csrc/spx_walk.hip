@@ -377,6 +377,9 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
   STAMP(3);
   lds_sync<NW>();  // decimated signal visible; last step's buffer clearing finished
   STAMP(4);
+#if defined(SPX_EXPERIMENT) && SPX_EXPERIMENT == 1
+  { st.prevPeriod = 100; st.prevMinDiff = 1; return 100 + (int)(pos & 15); }
+#endif
   // ---- first search ----
   const unsigned* M0 = reinterpret_cast<const unsigned*>(X.monoH);
   const unsigned* M1 = reinterpret_cast<const unsigned*>(X.monoHB);
@@ -400,6 +403,9 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
     int lo = period - (skip << 2), hi = period + (skip << 2);
     if (lo < P.minPeriod) lo = P.minPeriod;
     if (hi > P.maxPeriod) hi = P.maxPeriod;
+#if defined(SPX_EXPERIMENT) && SPX_EXPERIMENT == 2
+    { st.prevPeriod = period; st.prevMinDiff = 1; return period; }
+#endif
     // ---- refine at full rate ----
     Sel S2 = {0u, 0u, 0, 0};
     if (FAST) {
@@ -524,7 +530,9 @@ __device__ __forceinline__ void tsm_process(const SpxPlanDev& P, WalkCtx& X, Wal
           if (st.out_n + n > X.out_cap) st.overflow = 1;
           if (n == 0) return;  // the dependency treats this as failure and leaves the input untouched
           STAMP(11);
+#if !(defined(SPX_EXPERIMENT) && SPX_EXPERIMENT == 3)
           emit_overlap_add<NW, FAST>(X, pos, pos + period, n, st.out_n);
+#endif
           STAMP(13);
           st.out_n += n;
           position += period + n;
