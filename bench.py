@@ -131,8 +131,32 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    n_in_local = n * STREAMS_PER_GPU
     outs = b.results()
     n_out = int(sum(o.size for o in outs))
+
+    # PCIe-inclusive rate (reported beside, never as `value`): pinned host input -> HBM, the same step, produced
+    # output -> pinned host memory.
+    pcie = None
+    if rank == 0:
+        h_in = torch.empty(b.d_in.numel(), dtype=torch.int16).pin_memory()
+        h_in.copy_(b.d_in.cpu())
+        h_out = torch.empty(b.d_out.numel(), dtype=torch.int16).pin_memory()
+        reps = 5
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            b.d_in.copy_(h_in, non_blocking=True)
+            b.run()
+            counts = b.d_nout.cpu().numpy()  # synchronises
+            for i in range(b.n):
+                lo = b.out_offs[i]
+                h_out[lo:lo + int(counts[i])].copy_(b.d_out[lo:lo + int(counts[i])], non_blocking=True)
+            torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t1) / reps
+        pcie = {"value": n_in_local / dt1 / 1e6, "unit": "Msamples/s", "ms_per_step": dt1 * 1e3,
+                "note": "rank 0 only: H2D of the int16 input + the step + D2H of the produced int16 output, pinned host "
+                        "buffers; not the headline value"}
     n_in = n * STREAMS_PER_GPU
 
     if rank == 0:
@@ -173,6 +197,8 @@ def main():
                          "note": "latency-bound at this size: 256 sequential per-stream walks, one workgroup "
                                  "each (DESIGN.md)"},
         }
+        if pcie is not None:
+            line["pcie_inclusive"] = pcie
         if not args.no_cpu_baseline and world >= 1:
             line["cpu_baseline"] = cpu_baseline(streams)
         print(json.dumps(line))

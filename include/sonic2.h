@@ -59,10 +59,22 @@ spectrogramFunction getSonicSpectrogramCallback(sonicStream stream);
 void sonicNormalizedSpectrogramCallback(sonicStream stream, spectrogramFunction f);
 spectrogramFunction getSonicNormalizedSpectrogramCallback(sonicStream stream);
 
-/* The libsonic entry points the reference's tests call directly (sonic_test.cc:370,735-750). */
+/* The libsonic ("sonicInt*") entry points the reference reaches through sonic.h and its tests call directly
+ * (sonic_test.cc:370,735-750; soniclib.c:94-182).  They address the TSM stage alone = a stream in linear mode. */
 int sonicIntGetNumChannels(sonicStream stream);
 int sonicIntGetSampleRate(sonicStream stream);
 float sonicIntGetSpeed(sonicStream stream);
+sonicStream sonicIntCreateStream(int sampleRate, int numChannels);
+void sonicIntDestroyStream(sonicStream stream);
+void sonicIntSetSpeed(sonicStream stream, float speed);
+void sonicIntSetRate(sonicStream stream, float rate);
+int sonicIntWriteShortToStream(sonicStream stream, const short* samples, int numSamples);
+int sonicIntWriteFloatToStream(sonicStream stream, const float* samples, int numSamples);
+int sonicIntReadShortFromStream(sonicStream stream, short* samples, int maxSamples);
+int sonicIntReadFloatFromStream(sonicStream stream, float* samples, int maxSamples);
+int sonicIntFlushStream(sonicStream stream);
+void sonicIntSetUserData(sonicStream stream, void* userData);
+void* sonicIntGetUserData(sonicStream stream);
 
 /* ---- extensions (not in the reference) ---- */
 /* The reference selects the temporal-hysteresis shape at COMPILE time (-DMATCH_MATLAB, speedy.h:136-146);

@@ -80,6 +80,17 @@ SYMBOLS = {
     "sonicIntGetNumChannels": (C.c_int, [C.c_void_p]),
     "sonicIntGetSampleRate": (C.c_int, [C.c_void_p]),
     "sonicIntGetSpeed": (C.c_float, [C.c_void_p]),
+    "sonicIntCreateStream": (C.c_void_p, [C.c_int, C.c_int]),
+    "sonicIntDestroyStream": (None, [C.c_void_p]),
+    "sonicIntSetSpeed": (None, [C.c_void_p, C.c_float]),
+    "sonicIntSetRate": (None, [C.c_void_p, C.c_float]),
+    "sonicIntWriteShortToStream": (C.c_int, [C.c_void_p, c_short_p, C.c_int]),
+    "sonicIntWriteFloatToStream": (C.c_int, [C.c_void_p, c_float_p, C.c_int]),
+    "sonicIntReadShortFromStream": (C.c_int, [C.c_void_p, c_short_p, C.c_int]),
+    "sonicIntReadFloatFromStream": (C.c_int, [C.c_void_p, c_float_p, C.c_int]),
+    "sonicIntFlushStream": (C.c_int, [C.c_void_p]),
+    "sonicIntSetUserData": (None, [C.c_void_p, C.c_void_p]),
+    "sonicIntGetUserData": (C.c_void_p, [C.c_void_p]),
     "speedyHipSetMatchMatlab": (None, [C.c_int]),
     "sonicSamplesAvailable": (C.c_int, [C.c_void_p]),
     "speedyHipLastError": (C.c_char_p, []),

@@ -79,6 +79,7 @@ struct sonicStreamStruct {  // speedyConnectionStruct + the parts of libsonic's 
   bool started = false;     // a job has been launched (state record valid)
   bool failed = false;
   std::vector<float> hostRow;  // callback scratch
+  void* userData = nullptr;    // sonicIntSetUserData (soniclib.c:98,106)
 };
 
 static bool any_callback(sonicStream s) {
@@ -348,6 +349,31 @@ int sonicReadFloatFromStream(sonicStream s, float* out, int bufferSize) {
   return n;
 }
 
+// ---- the libsonic entry points the reference's tests call directly (sonic_test.cc:370,735-750).  They address
+// the TSM stage alone, which is what a stream in linear mode is here. ----
+static bool linear_only(sonicStream s, const char* who) {
+  if (s->mode == 1 || (s->mode < 0 && s->nonlinearFactor != 0.0f)) {
+    g_api_err = std::string(who) + ": direct TSM-stage calls on a stream in nonlinear mode are not supported";
+    return false;
+  }
+  return true;
+}
+sonicStream sonicIntCreateStream(int sampleRate, int numChannels) { return sonicCreateStream(sampleRate, numChannels); }
+void sonicIntDestroyStream(sonicStream s) { sonicDestroyStream(s); }
+void sonicIntSetSpeed(sonicStream s, float speed) { s->globalSpeed = speed; }
+void sonicIntSetRate(sonicStream s, float rate) { s->rate = rate; }
+int sonicIntWriteShortToStream(sonicStream s, const short* in, int n) {
+  return linear_only(s, "sonicIntWriteShortToStream") ? write_shorts(s, in, n) : 0;
+}
+int sonicIntWriteFloatToStream(sonicStream s, const float* in, int n) {
+  return linear_only(s, "sonicIntWriteFloatToStream") ? sonicWriteFloatToStream(s, in, n) : 0;
+}
+int sonicIntReadShortFromStream(sonicStream s, short* out, int n) { return sonicReadShortFromStream(s, out, n); }
+int sonicIntReadFloatFromStream(sonicStream s, float* out, int n) { return sonicReadFloatFromStream(s, out, n); }
+int sonicIntFlushStream(sonicStream s);
+void sonicIntSetUserData(sonicStream s, void* p) { s->userData = p; }
+void* sonicIntGetUserData(sonicStream s) { return s->userData; }
+
 int sonicFlushStream(sonicStream s) {
   if (s->failed) return 0;
   if (s->mode < 0) s->mode = (s->nonlinearFactor != 0.0f) ? 1 : 0;
@@ -356,5 +382,6 @@ int sonicFlushStream(sonicStream s) {
   s->flushed = true;
   return rc;
 }
+int sonicIntFlushStream(sonicStream s) { return linear_only(s, "sonicIntFlushStream") ? sonicFlushStream(s) : 0; }
 
 }  // extern "C"

@@ -214,3 +214,29 @@ def test_feedback_reduces_excess_duration(orc):
     assert gots == [oracle_excess(fb) for fb in (0.0, 0.1, 0.2, 0.4)]
     e = [abs(long_x.size / 3.0 - g) / rate for g in gots]
     assert e[1] < e[0] and e[2] < e[1] and e[3] < e[2]
+
+
+def test_stereo_original_sonic_entry_points():
+    """sonic_test.cc:728-754 (TestStereoOriginalSonic): the raw sonicInt* calls, stereo sine at 3x, repeated flushes;
+    length within 1 %."""
+    from speedy_amd._lib import c_short_p, lib
+    L = lib()
+    rate, ch, speed = 22050, 2, 3.0
+    n = rate
+    i = np.arange(n)
+    mono = (16000 * np.sin(2 * np.pi * 237.0 * i / np.float32(rate))).astype(np.int16)
+    x = np.repeat(mono, 2)
+    h = L.sonicIntCreateStream(rate, ch)
+    assert h and L.sonicIntGetNumChannels(h) == 2
+    L.sonicIntSetSpeed(h, speed)
+    assert L.sonicIntWriteShortToStream(h, x.ctypes.data_as(c_short_p), n) == 1
+    buf = np.zeros(1024 * ch, np.int16)
+    total = 0
+    while True:
+        got = L.sonicIntReadShortFromStream(h, buf.ctypes.data_as(c_short_p), 1024)
+        total += got * ch
+        L.sonicIntFlushStream(h)
+        if got <= 0:
+            break
+    L.sonicIntDestroyStream(h)
+    assert abs(total - x.size / speed) <= x.size / speed * 0.01
