@@ -103,6 +103,10 @@ void spx_set_timing(int enabled);
  * analysis of range c+1 (on an internal HIP stream) with the walk of range c (on hip_stream); results are
  * identical for any value, the state record is carried exactly as in the streaming API. */
 void spx_set_pipeline_chunks(int chunks);
+/* Concurrent mode of spx_batch_run (default on): the analysis kernel runs on an internal HIP stream and publishes one
+ * flag per tile; the walk kernel runs at the same time on hip_stream and takes each 128-frame chunk as soon as its
+ * tiles are ready.  Results are identical with it on or off. */
+void spx_set_concurrent(int on);
 int spx_timing_collect(double* sum_ms_analyze, double* sum_ms_walk, int* n_calls);
 
 /* ---- plain device-memory helpers (so that C/C++ hosts need no HIP headers) ---- */

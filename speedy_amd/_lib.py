@@ -47,6 +47,7 @@ SYMBOLS = {
                                  C.c_void_p, C.c_size_t, C.POINTER(Taps), C.c_void_p]),
     "spx_set_timing": (None, [C.c_int]),
     "spx_set_pipeline_chunks": (None, [C.c_int]),
+    "spx_set_concurrent": (None, [C.c_int]),
     "spx_timing_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "spx_device_alloc": (C.c_void_p, [C.c_size_t]),
     "spx_device_free": (None, [C.c_void_p]),

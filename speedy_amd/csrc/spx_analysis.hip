@@ -238,13 +238,16 @@ __device__ __forceinline__ int mono_sample(const int16_t* __restrict__ in, int64
 
 __global__ void __launch_bounds__(SPX_BLOCK)
 spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int n_streams,
-                    const int16_t* __restrict__ in_base, SpxFrameRec* __restrict__ rec, SpxTapsDev taps) {
+                    const int16_t* __restrict__ in_base, SpxFrameRec* __restrict__ rec, SpxTapsDev taps,
+                    const int* __restrict__ tile_order, int* tile_flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int W = P.W, B = P.B, N = P.N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   // tile -> (stream, first frame): binary search over streams[].first_tile
-  const int tile = blockIdx.x;
+  // tile_order (optional): launch order -> tile id, earliest frames of every stream first, so that a walk kernel
+  // running concurrently finds its next chunk ready
+  const int tile = tile_order ? tile_order[blockIdx.x] : (int)blockIdx.x;
   int lo = 0, hi = n_streams - 1;
   while (lo < hi) {
     int mid = (lo + hi + 1) >> 1;
@@ -417,14 +420,26 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
     r.lsd = (e <= lowthr) ? 0.0f : lsd;
     rec[S.frame_off + j0 + tid] = r;
   }
+  if (tile_flags) {
+    // publish the tile's records to the concurrently running walk kernel (cdna_hip_programming.md Guideline 16):
+    // every storing wave drains its stores, workgroup barrier, one agent-scope release, then the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&tile_flags[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   ASTAMP(7);
   ASTAMP_FLUSH
 }
 
 void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int n_tiles,
-                         const int16_t* in, SpxFrameRec* rec, SpxTapsDev taps, hipStream_t st) {
+                         const int16_t* in, SpxFrameRec* rec, SpxTapsDev taps, const int* tile_order, int* tile_flags,
+                         hipStream_t st) {
   if (n_tiles <= 0) return;
   const size_t lds = spx_analysis_lds_bytes(P);
   hipLaunchKernelGGL(spx_analysis_kernel, dim3(n_tiles), dim3(SPX_BLOCK), lds, st, P, streams, n_streams, in,
-                     rec, taps);
+                     rec, taps, tile_order, tile_flags);
 }

@@ -38,6 +38,7 @@ struct spx_plan {
 // Timing: one set of four HIP events per timed call, recorded on the launch stream and resolved lazily by
 // spx_timing_collect (so that the timed region itself carries no host synchronisation).
 static bool g_timing = false;
+static int g_concurrent = 1;  // spx_set_concurrent: analysis and walk kernels on two streams, tile-flag hand-off
 static int g_chunks = 1;  // spx_set_pipeline_chunks (measured on MI355X, 256 x 10 s: 1 -> 5.09 ms, 2 -> 5.25, 4 -> 5.54 per step)
 struct EvPair { hipEvent_t a, b; int kind; };  // kind 0 = analysis launch, 1 = walk launch
 static std::vector<EvPair> g_ev_pending;
@@ -89,6 +90,7 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
   d.maxPeriod = sample_rate / 65;
   d.maxRequired = 2 * d.maxPeriod;
   d.skip = sample_rate > 4000 ? sample_rate / 4000 : 1;
+  d.tile_frames = spx_analysis_tile_frames();
   d.alpha = (float)exp(-1.0 / (float)100.0);          // speedy.c:67 with time constant kFrameRateHz
   d.one_minus_alpha = 1 - d.alpha;                     // float, speedy.c:74
 
@@ -174,7 +176,8 @@ int64_t spx_internal_frames_for(const SpxPlanDev& d, int64_t n_in) { return fram
 extern "C" {
 
 struct Layout {
-  size_t off_streams, off_states, off_rec, off_scratch, total;
+  size_t off_streams, off_states, off_rec, off_scratch, off_order, off_flags, total;
+  int64_t max_tiles;
   int64_t total_frames;
 };
 static Layout layout_for(const SpxPlanDev& d, const spx_stream_job* jobs, int n) {
@@ -187,6 +190,10 @@ static Layout layout_for(const SpxPlanDev& d, const spx_stream_job* jobs, int n)
   L.off_states = o;  o += ((sizeof(SpxStreamState) * (size_t)n + 255) & ~(size_t)255);
   L.off_rec = o;     o += ((sizeof(SpxFrameRec) * (size_t)(tf + 1) + 255) & ~(size_t)255);
   L.off_scratch = o; o += ((sizeof(float) * 4 * (size_t)(tf + 1) + 255) & ~(size_t)255);
+  const int TFr = spx_analysis_tile_frames();
+  L.max_tiles = tf / TFr + n + 1;  // every stream may end with a partial tile
+  L.off_order = o;   o += ((sizeof(int) * (size_t)L.max_tiles + 255) & ~(size_t)255);
+  L.off_flags = o;   o += ((sizeof(int) * (size_t)L.max_tiles + 255) & ~(size_t)255);
   L.total = o;
   return L;
 }
@@ -271,16 +278,40 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   const bool timed = g_timing && do_a && do_w;
   int maxC = 1;
   for (int i = 0; i < n; i++) if (jobs[i].channels > maxC) maxC = jobs[i].channels;
+  // Concurrent mode: the analysis kernel goes to the plan's side stream in "earliest frames first" tile order and
+  // publishes a flag per tile; the walk kernel starts at once on the caller's stream and consumes chunks of frames
+  // as their tiles become ready.  Same arithmetic, same results; only the serialisation of the two kernels goes.
+  const bool concurrent = g_concurrent && do_a && do_w && nch == 1 && tiles[0] > 0;
+  int* d_order = reinterpret_cast<int*>(w + L.off_order);
+  int* d_flags = reinterpret_cast<int*>(w + L.off_flags);
   hipStream_t sa = st;  // stream the analysis launches go to
-  if (nch > 1) {
+  if (nch > 1 || concurrent) {
     if (!plan->side) {
       HIPCHK(hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&plan->ev_start, hipEventDisableTiming));
       for (auto& e : plan->ev_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     sa = plan->side;
-    // the side stream starts after everything already queued on the caller's stream (job tables, and the
-    // previous call's walk, which still reads the frame records this call's analysis will overwrite)
+  }
+  if (concurrent) {
+    // tile ids in launch order: tile t of every stream before tile t+1 of any
+    std::vector<int> order;
+    order.reserve((size_t)tiles[0]);
+    std::vector<int> cnt(n);
+    int maxT = 0;
+    for (int i = 0; i < n; i++) {
+      cnt[i] = (i + 1 < n ? sv[i + 1].first_tile : tiles[0]) - sv[i].first_tile;
+      if (cnt[i] > maxT) maxT = cnt[i];
+    }
+    for (int t = 0; t < maxT; t++)
+      for (int i = 0; i < n; i++)
+        if (t < cnt[i]) order.push_back(sv[i].first_tile + t);
+    HIPCHK(hipMemcpyAsync(d_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(d_flags, 0, sizeof(int) * (size_t)tiles[0], st));
+  }
+  if (sa != st) {
+    // the side stream starts after everything already queued on the caller's stream (job tables, cleared flags, and
+    // the previous call's walk, which still reads the frame records this call's analysis will overwrite)
     HIPCHK(hipEventRecord(plan->ev_start, st));
     HIPCHK(hipStreamWaitEvent(sa, plan->ev_start, 0));
   }
@@ -289,19 +320,20 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     if (do_a && tiles[c] > 0) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, sa); }
-      spx_launch_analysis(d, dj, n, tiles[c], in, rec, td, sa);
+      spx_launch_analysis(d, dj, n, tiles[c], in, rec, td, concurrent ? d_order : nullptr,
+                          concurrent ? d_flags : nullptr, sa);
       if (timed) { (void)hipEventRecord(e1, sa); g_ev_pending.push_back({e0, e1, 0}); }
     }
-    if (nch > 1) {
-      HIPCHK(hipEventRecord(plan->ev_chunk[c], sa));
-      HIPCHK(hipStreamWaitEvent(st, plan->ev_chunk[c], 0));
-    }
+    if (sa != st) HIPCHK(hipEventRecord(plan->ev_chunk[c], sa));
+    if (sa != st && !concurrent) HIPCHK(hipStreamWaitEvent(st, plan->ev_chunk[c], 0));
     if (do_w) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, st); }
-      spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, rec, scratch, td, st);
+      spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, rec, scratch, td, concurrent ? d_flags : nullptr, st);
       if (timed) { (void)hipEventRecord(e1, st); g_ev_pending.push_back({e0, e1, 1}); }
     }
+    // the caller's stream is "done" only when the analysis launch has retired too
+    if (concurrent) HIPCHK(hipStreamWaitEvent(st, plan->ev_chunk[c], 0));
   }
   if (timed) g_calls_pending++;
   HIPCHK(hipGetLastError());
@@ -322,6 +354,7 @@ int spx_batch_walk(spx_plan_t plan, const spx_stream_job* jobs, int n, const int
 }
 
 void spx_set_timing(int enabled) { g_timing = enabled != 0; }
+void spx_set_concurrent(int on) { g_concurrent = on != 0; }
 void spx_set_pipeline_chunks(int chunks) { g_chunks = chunks < 1 ? 1 : (chunks > SPX_MAX_CHUNKS ? SPX_MAX_CHUNKS : chunks); }
 int spx_timing_collect(double* sum_ms_analyze, double* sum_ms_walk, int* n_calls) {
   double a = 0, w = 0;

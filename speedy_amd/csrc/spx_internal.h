@@ -19,6 +19,7 @@ struct SpxPlanDev {
   int nstages;
   int radix[SPX_MAX_STAGES];
   int minPeriod, maxPeriod, maxRequired, skip;  // libsonic limits
+  int tile_frames;  // frames per analysis tile (spx_analysis_tile_frames)
   float alpha;            // (float)exp(-1.0/100)             (speedy.c:67,287)
   float one_minus_alpha;  // (1 - alpha) evaluated in float   (speedy.c:74)
   const double* tw;    // [W]  (cos, -sin)(2 pi t / W)
@@ -83,11 +84,12 @@ struct SpxTapsDev {
 };
 
 void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int n_tiles,
-                         const int16_t* in, SpxFrameRec* rec, SpxTapsDev taps, hipStream_t st);
+                         const int16_t* in, SpxFrameRec* rec, SpxTapsDev taps, const int* tile_order, int* tile_flags,
+                         hipStream_t st);
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int max_channels,
                      const int16_t* in,
                      int16_t* out, int64_t* n_out, SpxStreamState* states, const SpxFrameRec* rec, float* scratch,
-                     SpxTapsDev taps, hipStream_t st);
+                     SpxTapsDev taps, const int* tile_flags, hipStream_t st);
 size_t spx_analysis_lds_bytes(const SpxPlanDev& P);
 int spx_analysis_tile_frames();
 

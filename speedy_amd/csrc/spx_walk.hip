@@ -31,6 +31,7 @@
 #include "spx_internal.h"
 
 #define SPX_CH 1024  // frames per prologue chunk held in LDS
+#define SPX_WCH 64   // frames in the first walk chunk when the analysis kernel runs concurrently (multiple of the tile)
 
 // In-kernel positions are 32-bit (the host rejects streams of 2^30 frames or more): half the SGPRs and none of the
 // 64-bit add/compare sequences in the per-step bookkeeping.  The carried state record stays 64-bit.
@@ -562,7 +563,7 @@ __device__ __forceinline__ void tsm_process(const SpxPlanDev& P, WalkCtx& X, Wal
 
 // LDS layout (bytes), shared by host and device
 struct WalkLds {
-  int off_sA, off_sB, off_mono, off_monoB, off_raw, off_dn, off_dnB, off_diffC, off_diffR, total, wcap;
+  int off_sA, off_sB, off_mono, off_monoB, off_raw, off_dn, off_dnB, off_diffC, off_diffR, off_wait, total, wcap;
 };
 static __host__ __device__ inline WalkLds walk_lds_layout(const SpxPlanDev& P, int maxC) {
   WalkLds L;
@@ -574,14 +575,14 @@ static __host__ __device__ inline WalkLds walk_lds_layout(const SpxPlanDev& P, i
   L.wcap = wcap;
   int o = 0;
   L.off_sA = o; o += SPX_CH * 4;
-  L.off_sB = o;    // the prologue's second array aliases the (not yet used) window
+  L.off_sB = o; o += SPX_CH * 4;
+  L.off_wait = o; o += 16;
   L.off_mono = o;
   const int mb = ((wcap + 8) * 2 + 15) & ~15;
   o += mb;
   L.off_monoB = o; o += mb;
   L.off_raw = o;
   if (maxC > 1) o += ((wcap + 1) * maxC * 2 + 15) & ~15;
-  if (o - L.off_sB < SPX_CH * 4) o = L.off_sB + SPX_CH * 4;
   const int dnb = ((P.maxRequired / P.skip + 8) * 2 + 15) & ~15;
   L.off_dn = o; o += dnb;
   L.off_dnB = o; o += dnb;
@@ -595,18 +596,20 @@ template <int NW, bool FAST>
 __global__ void __launch_bounds__(64 * NW)
 spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const int16_t* __restrict__ in_base,
                 int16_t* __restrict__ out_base, int64_t* __restrict__ n_out, SpxStreamState* __restrict__ states,
-                const SpxFrameRec* __restrict__ rec_base, float* __restrict__ scratch_base, SpxTapsDev taps,
-                int maxC) {
+                const SpxFrameRec* rec_base, float* __restrict__ scratch_base, SpxTapsDev taps, int maxC,
+                const int* tile_flags) {
   constexpr int NT = 64 * NW;
+  // the walk is the latency-critical chain: where the analysis kernel shares a SIMD, these waves issue first
+  __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
   const SpxStreamDev S = streams[blockIdx.x];
-  const int T = S.n_frames, F = P.F, Pp = P.Pp, B = P.B;
+  const int Ttot = S.n_frames, F = P.F, Pp = P.Pp, B = P.B;
   const float Rg = S.speed, nl = S.nonlinear, fb = S.feedback;
 
   const WalkLds LY = walk_lds_layout(P, maxC);
   float* sA = reinterpret_cast<float*>(lds + LY.off_sA);  // [SPX_CH]
-  float* sB = reinterpret_cast<float*>(lds + LY.off_sB);  // [SPX_CH], aliases the window
+  float* sB = reinterpret_cast<float*>(lds + LY.off_sB);  // [SPX_CH]
 
   // ---- state carried between jobs of one stream ----
   SpxStreamState Z;
@@ -627,153 +630,10 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
 
   const SpxFrameRec* rec = rec_base + S.frame_off;
   float* scr = scratch_base + (size_t)S.frame_off * 4;  // per frame: comp, hyst, ewld->tension, speed
-  const int fa = S.frame_begin;                                   // frames already folded into the state
-  const int K0 = (nl != 0.0f && fa >= F) ? fa - F + 1 : 0;        // tension frames already done
-  const int K = (nl != 0.0f && T >= F) ? T - F + 1 : 0;           // tension frames available (soniclib.c:317)
   const float lowthr = (float)(0.04 * (double)1.41421f);          // speedy.c:682
   float* tfeat = taps.features ? taps.features + (size_t)S.frame_off * SPX_FEATURE_COUNT : nullptr;
-
-  if (nl != 0.0f && T > fa) {
-    // ---- pass 1: energy low-pass (sequential) -> local -> compressed ----
-    float lp = Z.lp;
-    for (int c0 = fa; c0 < T; c0 += SPX_CH) {
-      const int n = min(SPX_CH, T - c0);
-      for (int i = tid; i < n; i += NT) sA[i] = rec[c0 + i].energy;
-      __syncthreads();
-      if (tid == 0) {
-        for (int i = 0; i < n; i++) {
-          lp = P.one_minus_alpha * sA[i] + P.alpha * lp;  // speedy.c:74
-          sB[i] = lp;
-        }
-      }
-      __syncthreads();
-      for (int i = tid; i < n; i += NT) {
-        const float e = sA[i], l = sB[i];
-        const float local = e / l;                                               // speedy.c:519
-        const float comp = (float)__builtin_sqrt(local > 2 ? 2.0 : (double)local);  // speedy.c:520
-        const int j = c0 + i;
-        scr[4 * j + 0] = comp;
-        const int k = j - F + 1;  // the tension frame whose callback sees these AddData-time values
-        if (tfeat && k >= 0) {
-          float* f = tfeat + (size_t)k * SPX_FEATURE_COUNT;
-          f[1] = l; f[2] = local; f[3] = comp; f[12] = (float)(j + 1);
-        }
-      }
-      if (n > 0) lp = sB[n - 1];  // every lane keeps the carried state
-      __syncthreads();
-    }
-    Z.lp = lp;
-    // ---- pass 2: hysteresis and emphasis-weighted difference, one lane per tension frame ----
-    for (int k = K0 + tid; k < K; k += NT) {
-      float future_max = 0.0f, past_max = 0.0f;
-      for (int i = 0; i <= F; i++) {
-        const int tau = k + i;  // hysteresis slot `tau` holds frame tau-1; slots <= 0 are the zero init
-        float v = (tau >= 1) ? scr[4 * (tau - 1) + 0] : 0.0f;
-        v *= P.taperF[i];
-        if (v > future_max) future_max = v;
-      }
-      for (int i = 0; i <= Pp; i++) {
-        const int tau = k - i;
-        float v = (tau >= 1) ? scr[4 * (tau - 1) + 0] : 0.0f;
-        v *= P.taperP[i];
-        if (v > past_max) past_max = v;
-      }
-      const float hyst = (float)((double)(past_max + future_max) / 2.0);  // speedy.c:609
-      const float e_cur = (k == 0) ? 0.0f : rec[k - 1].energy;           // history slot k holds frame k-1
-      const bool low = e_cur <= lowthr;
-      const float lsd = (k == 0 || low) ? 0.0f : rec[k - 1].lsd;
-      const float ewld = low ? 0.0f : lsd * hyst;                          // speedy.c:720
-      scr[4 * k + 1] = hyst;
-      scr[4 * k + 2] = ewld;
-      if (tfeat) {
-        float* f = tfeat + (size_t)k * SPX_FEATURE_COUNT;
-        f[0] = e_cur; f[4] = hyst; f[5] = low ? 1.0f : 0.0f; f[6] = lsd; f[7] = ewld;
-        f[13] = (float)k; f[14] = lowthr;
-      }
-    }
-    __syncthreads();
-    // ---- pass 3: difference low-pass (sequential) -> relative difference -> tension -> raw speed ----
-    float lpf = Z.lpf;
-    for (int c0 = K0; c0 < K; c0 += SPX_CH) {
-      const int n = min(SPX_CH, K - c0);
-      for (int i = tid; i < n; i += NT) sA[i] = scr[4 * (c0 + i) + 2];
-      __syncthreads();
-      if (tid == 0) {
-        for (int i = 0; i < n; i++) {
-          lpf = P.one_minus_alpha * sA[i] + P.alpha * lpf;
-          sB[i] = lpf;
-        }
-      }
-      __syncthreads();
-      for (int i = tid; i < n; i += NT) {
-        const int k = c0 + i;
-        const float ewld = sA[i], l = sB[i];
-        const float hyst = scr[4 * k + 1];
-        const float e_cur = (k == 0) ? 0.0f : rec[k - 1].energy;
-        const bool low = e_cur <= lowthr;
-        float rel = 0.0f, sc = 0.0f;
-        if (!low) {
-          rel = (float)((double)ewld / ((double)l + 0.01 * (double)123.979f));       // speedy.c:725-726
-          sc = (float)fmin((double)rel, (double)(4 * 0.971975f));                    // speedy.c:727-728
-        }
-        const float a = 0.5f, b = 0.25f, M_E_ = 0.7f, M_S = 1.0f;
-        const float tension = a * (hyst - M_E_) + b * (sc - M_S);                    // speedy.c:761
-        float v;
-        if ((double)Rg > 1.0) {
-          v = (float)fmax(1.0, (double)(Rg + (1 - Rg) * tension));                   // speedy.c:774
-        } else {
-          v = (float)fmax(0.01, fmin(1.0, (double)(Rg - (1 - Rg) * tension)));       // speedy.c:776
-        }
-        scr[4 * k + 2] = tension;
-        scr[4 * k + 3] = v;
-        if (tfeat) {
-          float* f = tfeat + (size_t)k * SPX_FEATURE_COUNT;
-          f[8] = l; f[9] = rel; f[10] = sc; f[11] = tension;
-        }
-        if (taps.tension) taps.tension[S.frame_off + k] = tension;
-      }
-      if (n > 0) lpf = sB[n - 1];
-      __syncthreads();
-    }
-    Z.lpf = lpf;
-    // ---- pass 4: duration feedback (sequential) and blend with the global speed ----
-    float cur_dur = Z.cur_dur, des_dur = Z.des_dur;
-    const float fd = (float)(1.0 / 100.0);  // speedy.c:783
-    for (int c0 = K0; c0 < K; c0 += SPX_CH) {
-      const int n = min(SPX_CH, K - c0);
-      for (int i = tid; i < n; i += NT) sA[i] = scr[4 * (c0 + i) + 3];
-      __syncthreads();
-      if (tid == 0) {
-        for (int i = 0; i < n; i++) {
-          float req = sA[i];
-          if (fb > 0) {
-            const float excess = cur_dur - des_dur;
-            req = (float)((double)req + fmax(0.01, (double)(fb * excess)));          // speedy.c:780-781
-          }
-          cur_dur += fd / req;
-          des_dur += fd / Rg;
-          sB[i] = req * nl + Rg * (1 - nl);                                          // soniclib.c:344-345
-        }
-        sA[0] = cur_dur;  // broadcast the carried sums (sA is re-read only by the next chunk's load)
-        sA[1] = des_dur;
-      }
-      __syncthreads();
-      cur_dur = sA[0];
-      des_dur = sA[1];
-      for (int i = tid; i < n; i += NT) {
-        scr[4 * (c0 + i) + 3] = sB[i];
-        if (taps.speed) taps.speed[S.frame_off + c0 + i] = sB[i];
-      }
-      __syncthreads();
-    }
-    Z.cur_dur = cur_dur;
-    Z.des_dur = des_dur;
-  }
-  __syncthreads();
-
-  __syncthreads();
-
-  // ---------------------------------- the TSM walk ----------------------------------
+  int* sWait = reinterpret_cast<int*>(lds + LY.off_wait);
+  // ---------------------------------- TSM stage context ----------------------------------
   WalkCtx X;
   X.in = in_base + S.in_off;
   X.out = out_base + S.out_off;
@@ -798,52 +658,229 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   st.overflow = uni(Z.w.overflow); st.prevPeriod_toggle = uni(Z.w.prevPeriod_toggle);
   float curSpeed = unif(Z.curSpeed);
   pos_t avail = st.avail;
-  // Events, in the order the shim issues them:
-  //   nonlinear: one (setSpeed, write B) per tension frame           soniclib.c:354,369
-  //              at flush, the remaining complete ring buffers at the last speed   soniclib.c:538-550
-  //   linear:    one write of everything new (soniclib.c:397-399; chunking is irrelevant at constant speed)
-  //   at flush:  sonicIntFlushStream (soniclib.c:551): pad 2*maxRequired zeros, process, truncate
+  pos_t handed = (nl != 0.0f) ? Z.handed : 0;
   const bool do_flush = (S.flags & SPX_F_FLUSH) != 0;
-  const pos_t ev0 = (nl != 0.0f) ? Z.handed : 0;
-  pos_t ev1;  // one past the last ordinary event
-  if (nl != 0.0f) ev1 = do_flush ? (pos_t)(S.n_in / B) : K;  // complete ring buffers written: soniclib.c:446-449
-  else ev1 = ((pos_t)S.n_in > avail) ? 1 : 0;
-  if (ev1 < ev0) ev1 = ev0;
-  const pos_t ev_end = ev1 + (do_flush ? 1 : 0);
-  for (pos_t ev = ev0; ev < ev_end; ev++) {
-    pos_t expected = 0;
-    if (ev < ev1) {
-      if (nl != 0.0f) {
-        if (ev < K) {
-          const int i = (int)((ev - ev0) % SPX_CH);
-          if (i == 0) {  // stage the next chunk of speeds in LDS
-            __syncthreads();
-            const int n = (int)min((pos_t)SPX_CH, (pos_t)K - ev);
-            for (int t = tid; t < n; t += NT) sA[t] = scr[4 * (ev + t) + 3];
-            __syncthreads();
+  // The frames are taken in chunks.  Sequential launches (tile_flags == nullptr) use one chunk.  When the analysis
+  // kernel runs CONCURRENTLY on another HIP stream, a chunk is SPX_WCH frames and starts only once the analysis
+  // tiles that cover it have published their records (agent-scope release there, one relaxed poll + agent-scope
+  // acquire here: cdna_hip_programming.md Guideline 16).  The walk consumes 10 s of audio in milliseconds while the
+  // analysis delivers it in about one, so after the first chunk it never waits.
+  int fa_c = S.frame_begin;
+  int wch = SPX_WCH;  // grows: the analysis is soon far ahead, and every chunk costs a round of prologue passes
+  for (;;) {
+    int T_c = Ttot;
+    if (tile_flags != nullptr && nl != 0.0f && Ttot - fa_c > wch) T_c = fa_c + wch;
+    wch *= 2;
+    const bool last = T_c >= Ttot;
+    if (tile_flags != nullptr && nl != 0.0f && T_c > fa_c) {
+      const int TF = P.tile_frames;
+      const int i0 = (fa_c - S.frame_begin) / TF, i1 = (T_c - S.frame_begin + TF - 1) / TF;
+      if (tid == 0) {
+        int ok = 1;
+        for (int i = i0; i < i1 && ok; i++) {
+          unsigned spins = 0;
+          while (__hip_atomic_load(&tile_flags[S.first_tile + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > (1u << 22)) { ok = 0; break; }  // ~seconds: never hang the GPU on a lost producer
           }
-          curSpeed = unif(sA[i]);
         }
-        avail += B;
-      } else {
-        avail = (pos_t)S.n_in;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *sWait = ok;
       }
-    } else {
-      const pos_t remainingS = avail - st.base;
-      expected = st.out_n + uni((int)(((float)remainingS / curSpeed + 0) / 1.0f + 0.5f));
-      X.limit = avail;  // everything from here on reads as the flush's zero padding
-      lds_sync<NW>();
-      X.wbase = -1;     // the window may hold samples past the new limit
-      avail += 2 * P.maxRequired;
+      __syncthreads();
+      if (*sWait == 0) { st.overflow = 1; break; }
     }
-    STAMP(0);
-    tsm_process<NW, FAST>(P, X, st, curSpeed, avail);
-    STAMP(12);
-    if (ev >= ev1) {
-      if (st.out_n > expected) st.out_n = expected;
-      st.base = avail;  // the dependency empties its input after a flush
-      st.remaining = 0;
+    const int fa = fa_c, T = T_c;
+    const int K0 = (nl != 0.0f && fa >= F) ? fa - F + 1 : 0;        // tension frames already done
+    const int K = (nl != 0.0f && T >= F) ? T - F + 1 : 0;           // tension frames available (soniclib.c:317)
+    if (nl != 0.0f && T > fa) {
+      // ---- pass 1: energy low-pass (sequential) -> local -> compressed ----
+      float lp = Z.lp;
+      for (int c0 = fa; c0 < T; c0 += SPX_CH) {
+        const int n = min(SPX_CH, T - c0);
+        for (int i = tid; i < n; i += NT) sA[i] = rec[c0 + i].energy;
+        __syncthreads();
+        if (tid == 0) {
+          for (int i = 0; i < n; i++) {
+            lp = P.one_minus_alpha * sA[i] + P.alpha * lp;  // speedy.c:74
+            sB[i] = lp;
+          }
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) {
+          const float e = sA[i], l = sB[i];
+          const float local = e / l;                                               // speedy.c:519
+          const float comp = (float)__builtin_sqrt(local > 2 ? 2.0 : (double)local);  // speedy.c:520
+          const int j = c0 + i;
+          scr[4 * j + 0] = comp;
+          const int k = j - F + 1;  // the tension frame whose callback sees these AddData-time values
+          if (tfeat && k >= 0) {
+            float* f = tfeat + (size_t)k * SPX_FEATURE_COUNT;
+            f[1] = l; f[2] = local; f[3] = comp; f[12] = (float)(j + 1);
+          }
+        }
+        if (n > 0) lp = sB[n - 1];  // every lane keeps the carried state
+        __syncthreads();
+      }
+      Z.lp = lp;
+      // ---- pass 2: hysteresis and emphasis-weighted difference, one lane per tension frame ----
+      for (int k = K0 + tid; k < K; k += NT) {
+        float future_max = 0.0f, past_max = 0.0f;
+        for (int i = 0; i <= F; i++) {
+          const int tau = k + i;  // hysteresis slot `tau` holds frame tau-1; slots <= 0 are the zero init
+          float v = (tau >= 1) ? scr[4 * (tau - 1) + 0] : 0.0f;
+          v *= P.taperF[i];
+          if (v > future_max) future_max = v;
+        }
+        for (int i = 0; i <= Pp; i++) {
+          const int tau = k - i;
+          float v = (tau >= 1) ? scr[4 * (tau - 1) + 0] : 0.0f;
+          v *= P.taperP[i];
+          if (v > past_max) past_max = v;
+        }
+        const float hyst = (float)((double)(past_max + future_max) / 2.0);  // speedy.c:609
+        const float e_cur = (k == 0) ? 0.0f : rec[k - 1].energy;           // history slot k holds frame k-1
+        const bool low = e_cur <= lowthr;
+        const float lsd = (k == 0 || low) ? 0.0f : rec[k - 1].lsd;
+        const float ewld = low ? 0.0f : lsd * hyst;                          // speedy.c:720
+        scr[4 * k + 1] = hyst;
+        scr[4 * k + 2] = ewld;
+        if (tfeat) {
+          float* f = tfeat + (size_t)k * SPX_FEATURE_COUNT;
+          f[0] = e_cur; f[4] = hyst; f[5] = low ? 1.0f : 0.0f; f[6] = lsd; f[7] = ewld;
+          f[13] = (float)k; f[14] = lowthr;
+        }
+      }
+      __syncthreads();
+      // ---- pass 3: difference low-pass (sequential) -> relative difference -> tension -> raw speed ----
+      float lpf = Z.lpf;
+      for (int c0 = K0; c0 < K; c0 += SPX_CH) {
+        const int n = min(SPX_CH, K - c0);
+        for (int i = tid; i < n; i += NT) sA[i] = scr[4 * (c0 + i) + 2];
+        __syncthreads();
+        if (tid == 0) {
+          for (int i = 0; i < n; i++) {
+            lpf = P.one_minus_alpha * sA[i] + P.alpha * lpf;
+            sB[i] = lpf;
+          }
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) {
+          const int k = c0 + i;
+          const float ewld = sA[i], l = sB[i];
+          const float hyst = scr[4 * k + 1];
+          const float e_cur = (k == 0) ? 0.0f : rec[k - 1].energy;
+          const bool low = e_cur <= lowthr;
+          float rel = 0.0f, sc = 0.0f;
+          if (!low) {
+            rel = (float)((double)ewld / ((double)l + 0.01 * (double)123.979f));       // speedy.c:725-726
+            sc = (float)fmin((double)rel, (double)(4 * 0.971975f));                    // speedy.c:727-728
+          }
+          const float a = 0.5f, b = 0.25f, M_E_ = 0.7f, M_S = 1.0f;
+          const float tension = a * (hyst - M_E_) + b * (sc - M_S);                    // speedy.c:761
+          float v;
+          if ((double)Rg > 1.0) {
+            v = (float)fmax(1.0, (double)(Rg + (1 - Rg) * tension));                   // speedy.c:774
+          } else {
+            v = (float)fmax(0.01, fmin(1.0, (double)(Rg - (1 - Rg) * tension)));       // speedy.c:776
+          }
+          scr[4 * k + 2] = tension;
+          scr[4 * k + 3] = v;
+          if (tfeat) {
+            float* f = tfeat + (size_t)k * SPX_FEATURE_COUNT;
+            f[8] = l; f[9] = rel; f[10] = sc; f[11] = tension;
+          }
+          if (taps.tension) taps.tension[S.frame_off + k] = tension;
+        }
+        if (n > 0) lpf = sB[n - 1];
+        __syncthreads();
+      }
+      Z.lpf = lpf;
+      // ---- pass 4: duration feedback (sequential) and blend with the global speed ----
+      float cur_dur = Z.cur_dur, des_dur = Z.des_dur;
+      const float fd = (float)(1.0 / 100.0);  // speedy.c:783
+      for (int c0 = K0; c0 < K; c0 += SPX_CH) {
+        const int n = min(SPX_CH, K - c0);
+        for (int i = tid; i < n; i += NT) sA[i] = scr[4 * (c0 + i) + 3];
+        __syncthreads();
+        if (tid == 0) {
+          for (int i = 0; i < n; i++) {
+            float req = sA[i];
+            if (fb > 0) {
+              const float excess = cur_dur - des_dur;
+              req = (float)((double)req + fmax(0.01, (double)(fb * excess)));          // speedy.c:780-781
+            }
+            cur_dur += fd / req;
+            des_dur += fd / Rg;
+            sB[i] = req * nl + Rg * (1 - nl);                                          // soniclib.c:344-345
+          }
+          sA[0] = cur_dur;  // broadcast the carried sums (sA is re-read only by the next chunk's load)
+          sA[1] = des_dur;
+        }
+        __syncthreads();
+        cur_dur = sA[0];
+        des_dur = sA[1];
+        for (int i = tid; i < n; i += NT) {
+          scr[4 * (c0 + i) + 3] = sB[i];
+          if (taps.speed) taps.speed[S.frame_off + c0 + i] = sB[i];
+        }
+        __syncthreads();
+      }
+      Z.cur_dur = cur_dur;
+      Z.des_dur = des_dur;
     }
+    __syncthreads();
+    // Events, in the order the shim issues them:
+    //   nonlinear: one (setSpeed, write B) per tension frame           soniclib.c:354,369
+    //              at flush, the remaining complete ring buffers at the last speed   soniclib.c:538-550
+    //   linear:    one write of everything new (soniclib.c:397-399; chunking is irrelevant at constant speed)
+    //   at flush:  sonicIntFlushStream (soniclib.c:551): pad 2*maxRequired zeros, process, truncate
+    const bool fin = last && do_flush;
+    const pos_t ev0 = handed;
+    pos_t ev1;  // one past the last ordinary event of this chunk
+    if (nl != 0.0f) ev1 = fin ? (pos_t)(S.n_in / B) : K;  // complete ring buffers written: soniclib.c:446-449
+    else ev1 = (last && (pos_t)S.n_in > avail) ? 1 : 0;
+    if (ev1 < ev0) ev1 = ev0;
+    const pos_t ev_end = ev1 + (fin ? 1 : 0);
+    for (pos_t ev = ev0; ev < ev_end; ev++) {
+      pos_t expected = 0;
+      if (ev < ev1) {
+        if (nl != 0.0f) {
+          if (ev < K) {
+            const int i = (int)((ev - ev0) % SPX_CH);
+            if (i == 0) {  // stage the next chunk of speeds in LDS
+              __syncthreads();
+              const int n = (int)min((pos_t)SPX_CH, (pos_t)K - ev);
+              for (int t = tid; t < n; t += NT) sA[t] = scr[4 * (ev + t) + 3];
+              __syncthreads();
+            }
+            curSpeed = unif(sA[i]);
+          }
+          avail += B;
+        } else {
+          avail = (pos_t)S.n_in;
+        }
+      } else {
+        const pos_t remainingS = avail - st.base;
+        expected = st.out_n + uni((int)(((float)remainingS / curSpeed + 0) / 1.0f + 0.5f));
+        X.limit = avail;  // everything from here on reads as the flush's zero padding
+        lds_sync<NW>();
+        X.wbase = -1;     // the window may hold samples past the new limit
+        avail += 2 * P.maxRequired;
+      }
+      STAMP(0);
+      tsm_process<NW, FAST>(P, X, st, curSpeed, avail);
+      STAMP(12);
+      if (ev >= ev1) {
+        if (st.out_n > expected) st.out_n = expected;
+        st.base = avail;  // the dependency empties its input after a flush
+        st.remaining = 0;
+      }
+    }
+    if (nl != 0.0f) handed = ev1;
+    fa_c = T_c;
+    if (last) break;
   }
   STAMP_FLUSH
   if (tid == 0) {
@@ -851,7 +888,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
     Z.w.prevPeriod = st.prevPeriod; Z.w.prevMinDiff = st.prevMinDiff; Z.w.overflow = st.overflow;
     Z.w.prevPeriod_toggle = st.prevPeriod_toggle; Z.w.pad_ = 0;
     Z.curSpeed = curSpeed;
-    if (nl != 0.0f) Z.handed = (int)ev1;
+    if (nl != 0.0f) Z.handed = (int)handed;
     states[blockIdx.x] = Z;
     if (n_out) n_out[blockIdx.x] = st.overflow ? -(int64_t)st.out_n : (int64_t)st.out_n;
   }
@@ -859,7 +896,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
 
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int maxC, const int16_t* in,
                      int16_t* out, int64_t* n_out, SpxStreamState* states, const SpxFrameRec* rec,
-                     float* scratch, SpxTapsDev taps, hipStream_t st) {
+                     float* scratch, SpxTapsDev taps, const int* tile_flags, hipStream_t st) {
   if (n_streams <= 0) return;
   if (maxC < 1) maxC = 1;
   const WalkLds LY = walk_lds_layout(P, maxC);
@@ -871,10 +908,10 @@ void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_str
   do {                                                                                                           \
     if (fast)                                                                                                    \
       hipLaunchKernelGGL((spx_walk_kernel<NWV, true>), dim3(n_streams), dim3(64 * NWV), LY.total, st, P, streams,  \
-                         in, out, n_out, states, rec, scratch, taps, maxC);                                      \
+                         in, out, n_out, states, rec, scratch, taps, maxC, tile_flags);                                      \
     else                                                                                                         \
       hipLaunchKernelGGL((spx_walk_kernel<NWV, false>), dim3(n_streams), dim3(64 * NWV), LY.total, st, P, streams, \
-                         in, out, n_out, states, rec, scratch, taps, maxC);                                      \
+                         in, out, n_out, states, rec, scratch, taps, maxC, tile_flags);                                      \
   } while (0)
   // FAST: every stream mono, decimated search, and at most 64 lags in either search (rates below 32 kHz)
   const bool fast = maxC == 1 && P.skip >= 2 && (P.maxPeriod / P.skip - P.minPeriod / P.skip + 1) <= 64 &&

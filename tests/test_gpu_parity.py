@@ -227,3 +227,42 @@ def test_streaming_random_chunking(orc):
         outs.append(got)
     s.close()
     assert np.array_equal(np.concatenate(outs), ref)
+
+
+def test_concurrent_handoff_under_uneven_load():
+    """spx_set_concurrent: the analysis kernel publishes per-tile flags (agent-scope release) while the walk kernel
+    consumes them on another HIP stream (relaxed poll + agent-scope acquire).  Uneven load on purpose: 200 streams of
+    0.1 .. 6 s, repeated launches into the same buffers (consumer caches warm); every output sample and every
+    tension / speed value must equal the sequential two-launch mode."""
+    from speedy_amd._lib import lib
+    from speedy_amd.batch import Batch, Plan
+    from speedy_amd.synth import speech_like
+    rate = 16000
+    rng = np.random.default_rng(11)
+    lens = [int(v) for v in rng.integers(1600, 96000, 200)]
+    base = [speech_like(96000, rate, seed=300 + i) for i in range(10)]
+    streams = [base[i % 10][: lens[i]] for i in range(200)]
+    plan = Plan(rate, False)
+    L = lib()
+
+    def run(concurrent, reps):
+        L.spx_set_concurrent(int(concurrent))
+        try:
+            b = Batch(plan, lens, 1, 3.5, 1.0, 0.1, taps=True)
+            b.upload(streams)
+            outs = None
+            for _ in range(reps):
+                b.run()
+                outs = b.results()
+            taps = [b.tap_arrays(i) for i in range(0, 200, 7)]
+            return outs, taps
+        finally:
+            L.spx_set_concurrent(1)
+
+    ref_out, ref_taps = run(False, 1)
+    for reps in (1, 3):
+        out, taps = run(True, reps)
+        for i in range(200):
+            assert np.array_equal(out[i], ref_out[i]), (reps, i)
+        for a, r in zip(taps, ref_taps):
+            assert np.array_equal(a["tension"], r["tension"]) and np.array_equal(a["speed"], r["speed"])
