@@ -13,6 +13,8 @@
 // Order-sensitive float reductions (energy, spectral difference) run one lane per frame in the
 // reference's index order so that results are bit-identical to the CPU oracle; the DFT, the logs and the
 // gates run one lane per bin.  Built with -ffp-contract=off.
+#include <stdlib.h>
+
 #include "spx_internal.h"
 
 #define SPX_TF 16  // frames per tile (plus one halo slot)
@@ -439,7 +441,8 @@ void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n
                          const int16_t* in, SpxFrameRec* rec, SpxTapsDev taps, const int* tile_order, int* tile_flags,
                          hipStream_t st) {
   if (n_tiles <= 0) return;
-  const size_t lds = spx_analysis_lds_bytes(P);
+  size_t lds = spx_analysis_lds_bytes(P);
+  if (const char* e = getenv("SPX_ANALYSIS_LDS_PAD")) lds += (size_t)atoi(e);  // tuning: fewer workgroups per CU
   hipLaunchKernelGGL(spx_analysis_kernel, dim3(n_tiles), dim3(SPX_BLOCK), lds, st, P, streams, n_streams, in,
                      rec, taps, tile_order, tile_flags);
 }

@@ -670,7 +670,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   for (;;) {
     int T_c = Ttot;
     if (tile_flags != nullptr && nl != 0.0f && Ttot - fa_c > wch) T_c = fa_c + wch;
-    wch *= 2;
+    wch += SPX_WCH;  // 64, 128, 192, ...: each chunk needs its tiles ready when it starts, so grow gently
     const bool last = T_c >= Ttot;
     if (tile_flags != nullptr && nl != 0.0f && T_c > fa_c) {
       const int TF = P.tile_frames;
