@@ -404,8 +404,13 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       const int j = j0 + f;
       if (j + 1 < T) taps.normalized[(size_t)(S.frame_off + j + 1) * W + i] = mags[(size_t)(f + 1) * MS + i] * fInv[f + 1];
     }
-    if (j0 == 0)
+    if (j0 == 0) {
       for (int i = tid; i < W; i += SPX_BLOCK) taps.normalized[(size_t)S.frame_off * W + i] = 0.0f;
+    } else if (j0 == S.frame_begin) {
+      // a resumed stream: the launch that analysed frame j0-1 stopped before row j0; the halo slot holds it
+      for (int i = tid; i < W; i += SPX_BLOCK)
+        taps.normalized[(size_t)(S.frame_off + j0) * W + i] = mags[i] * fInv[0];
+    }
   }
   __syncthreads();
   ASTAMP(6);

@@ -83,7 +83,7 @@ class SonicStream:
         self.L.sonicSpectrogramCallback(self.h, cb)
 
     def on_normalized(self, fn):
-        n = self.spectrogram_size() // 2
+        n = self.spectrogram_size()   # fft_size floats like the reference's buffer; bins >= fft_size/2 are zero
         cb = FEATURES_FN(lambda s, t, p: fn(t, np.ctypeslib.as_array(p, shape=(n,)).copy()))
         self._keep.append(cb)
         self.L.sonicNormalizedSpectrogramCallback(self.h, cb)

@@ -46,3 +46,69 @@ def test_cli_matches_oracle(orc, tmp_path, args, nl, fb, mm):
         assert t.size == ref["tension"].size and s.size == ref["speed"].size
         assert np.allclose(t, ref["tension"], rtol=1e-5, atol=1e-6)  # %g keeps 6 significant digits
         assert np.allclose(s, ref["speed"], rtol=1e-5, atol=1e-6)
+
+
+def _run(args, timeout=180):
+    if not os.path.exists(CLI):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "speedy_amd", "csrc"), "cli"])
+    r = subprocess.run([CLI, "--input", os.path.join(GOLDEN, "tapestry.wav")] + args, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+def test_cli_match_nonlinear_two_pass(orc, tmp_path):
+    """speedy_wave.cc:424-427 with the flags of its header example (:62): probe pass nonlinear without output,
+    final pass linear at the achieved rate."""
+    out = str(tmp_path / "matched.wav")
+    _run(["--output", out, "--nonlinear", "0.0", "--speed", "3", "--match_nonlinear"])
+    x, rate, ch = read_wav("tapestry.wav")
+    probe = orc.compress_sound(x, rate, ch, 3.0, 1.0, 0.0, False, chunk=1000)
+    achieved = float(x.size // ch) / float(probe["out"].size // ch)
+    ref = orc.compress_sound(x, rate, ch, achieved, 0.0, 0.0, False, chunk=1000)
+    assert np.array_equal(_read_out(out), ref["out"])
+
+
+def test_cli_length_two_pass(orc, tmp_path):
+    """speedy_wave.cc:428-461: --length rescales the request by (wanted / achieved) of a probing pass."""
+    out = str(tmp_path / "len.wav")
+    _run(["--output", out, "--length", "1.5"])
+    x, rate, ch = read_wav("tapestry.wav")
+    total = x.size // ch
+    want = float(np.float32(total) / np.float32(rate)) / 1.5
+    probe = orc.compress_sound(x, rate, ch, want, 1.0, 0.0, False, chunk=1000)
+    got_speed = float(total) / float(probe["out"].size // ch)
+    ref = orc.compress_sound(x, rate, ch, want * (want / got_speed), 1.0, 0.0, False, chunk=1000)
+    got = _read_out(out)
+    assert np.array_equal(got, ref["out"])
+    assert abs(got.size / rate - 1.5) < 0.15    # what the flag is for
+
+
+def test_cli_feature_and_spectrogram_files(orc, tmp_path):
+    """--features_file / --spectrogram_file / --normalized_spectrogram_file (speedy_wave.cc:86-124): one text
+    row per callback, compared with the oracle shim's callbacks fed the same 1000-frame writes."""
+    out = str(tmp_path / "o.wav")
+    ff, gf, nf = (str(tmp_path / n) for n in ("f.txt", "g.txt", "n.txt"))
+    _run(["--output", out, "--features_file", ff, "--spectrogram_file", gf, "--normalized_spectrogram_file", nf])
+    x, rate, ch = read_wav("tapestry.wav")
+    L = orc.lib()
+    rows = {"f": [], "g": [], "n": []}
+    h = L.orc_sonicCreateStream(rate, ch, 0)
+    n = L.orc_sonicSpectrogramSize(h)
+    cbs = [orc.FEATURES_FN(lambda s, t, p: rows["f"].append(np.ctypeslib.as_array(p, shape=(15,)).copy())),
+           orc.FEATURES_FN(lambda s, t, p: rows["g"].append(np.ctypeslib.as_array(p, shape=(n,)).copy())),
+           orc.FEATURES_FN(lambda s, t, p: rows["n"].append(np.ctypeslib.as_array(p, shape=(n,)).copy()))]
+    L.orc_sonicFeaturesCallback(h, cbs[0])
+    L.orc_sonicSpectrogramCallback(h, cbs[1])
+    L.orc_sonicNormalizedSpectrogramCallback(h, cbs[2])
+    L.orc_sonicSetSpeed(h, 3.5)
+    L.orc_sonicEnableNonlinearSpeedup(h, 1.0)
+    for pos in range(0, x.size, 1000):
+        seg = np.ascontiguousarray(x[pos:pos + 1000])
+        L.orc_sonicWriteShortToStream(h, orc.sptr(seg), seg.size)
+    L.orc_sonicDestroyStream(h)
+    for path, key in ((ff, "f"), (gf, "g"), (nf, "n")):
+        got, ref = np.loadtxt(path), np.array(rows[key], dtype=np.float64)
+        assert got.shape == ref.shape, key
+        bad = ~np.isclose(got, ref, rtol=1e-5, atol=1e-6, equal_nan=True)   # %g keeps 6 significant digits
+        assert not bad.any(), (key, int(bad.sum()), got[bad][:4], ref[bad][:4])

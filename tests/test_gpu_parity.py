@@ -51,7 +51,9 @@ def test_spectrogram_tap_matches_oracle(orc):
     h = L.orc_sonicCreateStream(rate, ch, 1)
     n = L.orc_sonicSpectrogramSize(h)
     cb1 = orc.FEATURES_FN(lambda s, t, p: spec_rows.append(np.ctypeslib.as_array(p, shape=(n,)).copy()))
+    cb2 = orc.FEATURES_FN(lambda s, t, p: norm_rows.append(np.ctypeslib.as_array(p, shape=(n,)).copy()))
     L.orc_sonicSpectrogramCallback(h, cb1)
+    L.orc_sonicNormalizedSpectrogramCallback(h, cb2)
     L.orc_sonicSetSpeed(h, 3.0)
     L.orc_sonicEnableNonlinearSpeedup(h, 1.0)
     L.orc_sonicWriteShortToStream(h, orc.sptr(x), x.size)
@@ -62,6 +64,11 @@ def test_spectrogram_tap_matches_oracle(orc):
     assert taps["spectrogram"].shape == ref.shape
     assert np.abs(taps["spectrogram"] - ref).max() <= TOL
     assert np.array_equal(taps["spectrogram"], ref)
+    # the reference's callback at analysis call j hands out the buffer the tension computation k = j-F filled
+    # (soniclib.c:303-310); the batch tap is indexed by k and holds the W computed bins
+    F, W = b.plan.F, n // 2
+    nref = np.array(norm_rows)[F:, :W]
+    assert nref.shape[0] == len(norm_rows) - F and np.array_equal(taps["normalized"][:nref.shape[0]], nref)
     assert abs(float((taps["normalized"][150] ** 2).sum()) - 1.0) < 4e-3  # speedy_test.cc:975-978
 
 
