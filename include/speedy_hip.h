@@ -71,8 +71,11 @@ int spx_plan_future(spx_plan_t plan);       /* kTemporalHysteresisFuture, speedy
 int spx_plan_max_required(spx_plan_t plan); /* libsonic maxRequired = 2*(rate/65) */
 /* Number of analysis frames the shim schedules for n_in input frames (soniclib.c:440-444). */
 int64_t spx_plan_frames(spx_plan_t plan, int64_t n_in);
-/* Safe output capacity (frames) for n_in input frames at `speed`. */
+/* Safe output capacity (frames) for n_in input frames at `speed`: n_in + slack for speed >= 1; for a slow-down
+ * (n_in + flush padding) * 2/s + slack with s = speed for a linear job and s = 0.01 (the kMinimumSpeed clamp,
+ * speedy.c:92,776) when the nonlinear path may drive the speed.  The three-argument form assumes nonlinear. */
 int64_t spx_plan_out_capacity(spx_plan_t plan, int64_t n_in, float speed);
+int64_t spx_plan_out_capacity_for(spx_plan_t plan, int64_t n_in, float speed, float nonlinear);
 
 /* ---- batch execution ---- */
 /* Bytes of DEVICE scratch needed for a batch (depends only on the jobs' lengths). */

@@ -194,9 +194,11 @@ def compress_sound(x, sample_rate, channels, speed, nonlinear=1.0, feedback=0.0,
     L = lib()
     x = np.ascontiguousarray(x, dtype=np.int16)
     n_in = x.size // channels
-    cap = int(n_in / min(speed, 1.0) * 1.0) + 8 * sample_rate if speed < 1 else n_in + 8 * sample_rate
-    if speed < 1:
-        cap = int(n_in / max(speed, 0.01)) * 2 + 8 * sample_rate
+    cap = n_in + 8 * sample_rate
+    if speed < 1:   # a nonlinear slow-down may run at the speed floor 0.01 for whole passages (speedy.c:776), and
+        # one pitch step at speed s emits up to 2/s frames per frame consumed; the flush padding is stretched too
+        s_min = 0.01 if nonlinear > 0 else max(float(speed), 1e-4)
+        cap = int((n_in + 4 * (sample_rate // 65) + 64) * 2.0 / s_min) + 8 * sample_rate
     out = np.zeros(cap * channels, dtype=np.int16)
     ncap = n_in // max(1, sample_rate // 100) + 16
     ten = np.zeros(ncap, np.float32)

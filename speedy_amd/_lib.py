@@ -38,6 +38,7 @@ SYMBOLS = {
     "spx_plan_max_required": (C.c_int, [C.c_void_p]),
     "spx_plan_frames": (C.c_int64, [C.c_void_p, C.c_int64]),
     "spx_plan_out_capacity": (C.c_int64, [C.c_void_p, C.c_int64, C.c_float]),
+    "spx_plan_out_capacity_for": (C.c_int64, [C.c_void_p, C.c_int64, C.c_float, C.c_float]),
     "spx_batch_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(StreamJob), C.c_int]),
     "spx_batch_run": (C.c_int, [C.c_void_p, C.POINTER(StreamJob), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_size_t, C.POINTER(Taps), C.c_void_p]),

@@ -28,8 +28,8 @@ class Plan:
     def frames(self, n_in):
         return self.L.spx_plan_frames(self.h, int(n_in))
 
-    def out_capacity(self, n_in, speed):
-        return self.L.spx_plan_out_capacity(self.h, int(n_in), float(speed))
+    def out_capacity(self, n_in, speed, nonlinear=1.0):
+        return self.L.spx_plan_out_capacity_for(self.h, int(n_in), float(speed), float(nonlinear))
 
     def close(self):
         if self.h:
@@ -56,7 +56,7 @@ class Batch:
         self.in_offs, self.out_offs, self.out_caps, self.frame_offs, self.frames = [], [], [], [], []
         fo = 0
         for i in range(n):
-            cap = plan.out_capacity(int(self.lengths[i]), float(sp[i]))
+            cap = plan.out_capacity(int(self.lengths[i]), float(sp[i]), float(nlv[i]))
             j = self.jobs[i]
             j.in_off, j.n_in, j.out_off, j.out_cap = in_off, int(self.lengths[i]), out_off, cap
             j.channels, j.speed, j.nonlinear, j.feedback = int(ch[i]), float(sp[i]), float(nlv[i]), float(fb[i])

@@ -220,11 +220,8 @@ static int launch_job(sonicStream s, bool flush) {
   const int64_t fa = s->framesDone;
   const bool taps = nonlinear && any_callback(s);
 
-  // output capacity: everything new can at most be copied through or stretched by 1/min(speed)
-  double stretch = 1.0;
-  if (s->globalSpeed < 1.0f) stretch = nonlinear ? 100.0 : 1.0 / (s->globalSpeed < 0.01f ? 0.01 : s->globalSpeed) + 1.0;
-  const int64_t newIn = s->nIn + (flush ? 2 * P.maxRequired : 0);
-  const int64_t bound = (int64_t)((double)(newIn + 4 * P.maxRequired) * stretch) + 1024;
+  // output capacity: the bound of spx_internal_out_bound on the total produced since the stream start
+  const int64_t bound = spx_internal_out_bound(P, s->nIn + 2 * (int64_t)P.maxRequired, s->globalSpeed, nonlinear);
   // `bound` limits the TOTAL output since the stream start, so it is the capacity to provide
   if (s->outBound < s->outKnown) s->outBound = s->outKnown;
   const int64_t need = bound > s->outBound ? bound : s->outBound;

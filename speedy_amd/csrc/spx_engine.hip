@@ -45,6 +45,20 @@ static std::vector<EvPair> g_ev_pending;
 static std::vector<hipEvent_t> g_ev_free;
 static int g_calls_pending = 0;
 
+// Upper bound on the frames a stream can produce from n_in input frames (flush padding included here).
+// speed >= 1: the stage never emits more than it consumes (the nonlinear speed stays >= 1, speedy.c:772).
+// speed < 1: one pitch step at speed s emits at most 2/s frames per frame consumed -- for s < 0.5 it emits
+// period + n and consumes n = (int)(period*s/(1-s)) >= 1, and period/n <= 2(1-s)/s because floor(x) >= x/2 for
+// x >= 1; for 0.5 <= s < 1 the ratio is (2*period + r)/(period + r) <= 2.  The nonlinear speed can sit at the
+// kMinimumSpeed clamp 0.01 (speedy.c:92,776) whatever the requested speed.
+int64_t spx_internal_out_bound(const SpxPlanDev& P, int64_t n_in, float speed, bool nonlinear) {
+  const int64_t slack = 4 * (int64_t)P.maxRequired + 1024;
+  if (speed >= 1.0f) return n_in + slack;
+  double s = nonlinear ? 0.01 : (double)speed;
+  if (s < 1e-4) s = 1e-4;
+  return (int64_t)((double)(n_in + 2 * (int64_t)P.maxRequired) * (2.0 / s)) + slack;
+}
+
 extern "C" {
 
 const char* spx_last_error(void) { return g_err.c_str(); }
@@ -149,12 +163,11 @@ static int64_t frames_for(const SpxPlanDev& d, int64_t n_in) {
 }
 int64_t spx_plan_frames(spx_plan_t p, int64_t n_in) { return frames_for(p->dev, n_in); }
 
+int64_t spx_plan_out_capacity_for(spx_plan_t p, int64_t n_in, float speed, float nonlinear) {
+  return spx_internal_out_bound(p->dev, n_in, speed, nonlinear != 0.0f);
+}
 int64_t spx_plan_out_capacity(spx_plan_t p, int64_t n_in, float speed) {
-  // speed >= 1: the stage never emits more than it consumes.  speed < 1: the nonlinear speed can fall to the
-  // kMinimumSpeed clamp, 0.01 (speedy.c:92,776), i.e. up to 100 output frames per input frame.
-  const int64_t slack = 4 * (int64_t)p->dev.maxRequired + 1024;
-  if (speed >= 1.0f) return n_in + slack;
-  return n_in * 100 + slack;
+  return spx_internal_out_bound(p->dev, n_in, speed, true);
 }
 
 }  // extern "C"

@@ -95,5 +95,6 @@ int spx_analysis_tile_frames();
 
 // Shared, cached plan per (sample rate, hysteresis mode); owned by the library for the process lifetime.
 struct spx_plan;
+int64_t spx_internal_out_bound(const SpxPlanDev& P, int64_t n_in, float speed, bool nonlinear);
 const SpxPlanDev* spx_internal_shared_plan(int sample_rate, int match_matlab);
 int64_t spx_internal_frames_for(const SpxPlanDev& d, int64_t n_in);

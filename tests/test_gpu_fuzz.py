@@ -1,0 +1,118 @@
+"""GPU differential fuzz: seeded random configurations (rate, channels, speed, nonlinear factor, feedback,
+hysteresis shape) and adversarial signals through both entry points -- the batch C-ABI and the streaming sonic2 API
+with random write sizes -- against the oracle.  Everything must be bit-identical (int16 output, float taps).
+
+The signals are the ones a pitch search and an int16 cross-fade are most likely to get wrong: full-scale square
+waves (the AMDF sums at their maximum), int16 extremes, DC, silence with a click, pure tones at the edges of the
+65-400 Hz search range, white noise (no clear pitch: the previous-period rule fires), and speech-like synthetic.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SOAK = int(os.environ.get("SPX_FUZZ_SOAK", "0"))   # extra seeds for a one-off soak run
+RATES = [8000, 11025, 16000, 22050, 32000, 44100, 48000]
+
+
+def _signal(kind, n, rate, ch, rng):
+    t = np.arange(n)
+    if kind == "square":
+        per = int(rng.integers(rate // 400, rate // 65 + 1))
+        x = np.where((t // max(1, per // 2)) % 2 == 0, 32767, -32768)
+    elif kind == "extremes":
+        x = rng.choice(np.array([-32768, 32767, 0, -1, 1]), size=n)
+    elif kind == "dc":
+        x = np.full(n, int(rng.integers(-32768, 32768)))
+    elif kind == "click":
+        x = np.zeros(n, np.int64)
+        if n:
+            x[rng.integers(0, n, size=max(1, n // 4000))] = 30000
+    elif kind == "tone":
+        f = float(rng.choice([50.0, 65.0, 66.0, 120.0, 399.0, 400.0, 420.0, 1000.0]))
+        x = np.round(20000 * np.sin(2 * np.pi * f * t / rate))
+    elif kind == "noise":
+        x = rng.integers(-20000, 20000, size=n)
+    else:
+        from speedy_amd.synth import speech_like
+        return speech_like(n, rate, seed=int(rng.integers(1 << 30)), channels=ch)
+    x = np.asarray(x, np.int64)
+    if ch == 1:
+        return x.astype(np.int16)
+    cols = [np.roll(x, 3 * c) if c % 2 else x // (c + 1) for c in range(ch)]   # channels differ
+    return np.stack(cols, axis=1).reshape(-1).astype(np.int16)
+
+
+KINDS = ["square", "extremes", "dc", "click", "tone", "noise", "speech"]
+
+
+def _cases(seed, count):
+    rng = np.random.default_rng(seed)
+    for i in range(count):
+        rate = int(rng.choice(RATES))
+        ch = int(rng.choice([1, 1, 2, 3]))
+        kind = KINDS[i % len(KINDS)]
+        n = int(rng.integers(0, int(2.0 * rate)))
+        speed = float(np.round(rng.choice([rng.uniform(0.3, 0.95), rng.uniform(1.05, 6.0), 1.0, 2.0, 0.5]), 3))
+        nl = float(rng.choice([0.0, 1.0, 1.0, 0.5]))
+        fb = float(rng.choice([0.0, 0.1, 0.5]))
+        mm = bool(rng.integers(0, 2))
+        yield i, rate, ch, kind, n, speed, nl, fb, mm, rng
+
+
+@pytest.mark.parametrize("seed", list(range(1, 7)) + list(range(100, 100 + SOAK)))
+def test_batch_fuzz(orc, seed):
+    from speedy_amd.batch import compress_batch
+    for i, rate, ch, kind, n, speed, nl, fb, mm, rng in _cases(seed, 21):
+        x = _signal(kind, n, rate, ch, rng)
+        ref = orc.compress_sound(x, rate, ch, speed, nl, fb, mm, chunk=1000)
+        outs, b = compress_batch([x], rate, ch, speed, nl, fb, mm, taps=(nl != 0))
+        tag = (seed, i, rate, ch, kind, n, speed, nl, fb, mm)
+        assert np.array_equal(outs[0], ref["out"]), tag
+        if nl != 0:
+            taps = b.tap_arrays(0)
+            for key in ("tension", "speed", "features"):
+                assert np.array_equal(taps[key], ref[key]), tag + (key,)
+
+
+@pytest.mark.parametrize("seed", list(range(11, 15)) + list(range(1000, 1000 + SOAK)))
+def test_streaming_fuzz(orc, seed):
+    """Same idea through sonicWriteShortToStream / sonicReadShortFromStream with random write and read sizes: the
+    frames available after every call must equal the oracle shim's."""
+    from speedy_amd.sonic2 import SonicStream
+    L = orc.lib()
+    for i, rate, ch, kind, n, speed, nl, fb, mm, rng in _cases(seed, 14):
+        x = _signal(kind, n, rate, ch, rng)
+        tag = (seed, i, rate, ch, kind, n, speed, nl, fb, mm)
+        h = L.orc_sonicCreateStream(rate, ch, int(mm))
+        L.orc_sonicSetSpeed(h, speed)
+        L.orc_sonicEnableNonlinearSpeedup(h, nl)
+        L.orc_sonicSetDurationFeedbackStrength(h, fb)
+        s = SonicStream(rate, ch, mm)
+        s.set_speed(speed)
+        s.enable_nonlinear(nl)
+        s.set_feedback(fb)
+        pos = 0
+        buf = np.zeros(4096 * ch, np.int16)
+        while pos < n:
+            w = int(rng.integers(1, 3000))
+            seg = np.ascontiguousarray(x[pos * ch:(pos + w) * ch])
+            pos += w
+            assert L.orc_sonicWriteShortToStream(h, orc.sptr(seg), seg.size // ch) == 1
+            s.write_short(seg)
+            r = int(rng.integers(1, 4097))
+            k = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), r)
+            got = s.read_short(r)
+            assert got.size == k * ch and np.array_equal(got, buf[:k * ch]), tag + ("read", pos)
+        L.orc_sonicFlushStream(h)
+        s.flush()
+        while True:
+            k = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), 4096)
+            got = s.read_short(4096)
+            assert got.size == k * ch and np.array_equal(got, buf[:k * ch]), tag + ("drain",)
+            if k == 0:
+                break
+        L.orc_sonicDestroyStream(h)
+        s.close()
