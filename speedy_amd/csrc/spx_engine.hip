@@ -294,7 +294,8 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // Concurrent mode: the analysis kernel goes to the plan's side stream in "earliest frames first" tile order and
   // publishes a flag per tile; the walk kernel starts at once on the caller's stream and consumes chunks of frames
   // as their tiles become ready.  Same arithmetic, same results; only the serialisation of the two kernels goes.
-  const bool concurrent = g_concurrent && do_a && do_w && nch == 1 && tiles[0] > 0;
+  static const bool env_serial = getenv("SPX_SERIAL") != nullptr;  // tuning: kernels back to back on one stream
+  const bool concurrent = g_concurrent && !env_serial && do_a && do_w && nch == 1 && tiles[0] > 0;
   int* d_order = reinterpret_cast<int*>(w + L.off_order);
   int* d_flags = reinterpret_cast<int*>(w + L.off_flags);
   hipStream_t sa = st;  // stream the analysis launches go to

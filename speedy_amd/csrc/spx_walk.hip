@@ -56,18 +56,28 @@ __device__ __forceinline__ int64_t uni64(int64_t v) {
 // Diagnostic build only (-DSPX_STAMPS): per-phase shader-cycle sums of workgroup 0, lane 0.  Never in the product.
 #ifdef SPX_STAMPS
 __device__ unsigned long long g_spx_stamps[32];
+#ifndef SPX_STAMP_SEL
+#define SPX_STAMP_SEL 0
+#endif
+// One region per build (SPX_STAMP_SEL): a single accumulator keeps the register pressure of the measured kernel
+// close to the product's.  Slot 30 = whole kernel, slot 31 = pitch steps.
 #define STAMP_DECL                                         \
-  for (int i_ = 0; i_ < 16; i_++) X.stamp_acc[i_] = 0;     \
-  X.stamp_last = __builtin_readcyclecounter();
+  X.stamp_acc = 0; X.stamp_steps = 0;                      \
+  X.stamp_last = __builtin_readcyclecounter();             \
+  X.stamp_t0 = X.stamp_last;
 #define STAMP(i)                                                          \
   do {                                                                    \
     const unsigned long long t_ = __builtin_readcyclecounter();           \
-    X.stamp_acc[i] += t_ - X.stamp_last;                                  \
+    if ((i) == SPX_STAMP_SEL) X.stamp_acc += t_ - X.stamp_last;           \
+    if ((i) == 1) X.stamp_steps++;                                        \
     X.stamp_last = t_;                                                    \
   } while (0)
 #define STAMP_FLUSH                                                                              \
-  if (threadIdx.x == 0 && blockIdx.x == 0)                                                       \
-    for (int i_ = 0; i_ < 16; i_++) g_spx_stamps[i_] += X.stamp_acc[i_];
+  if (threadIdx.x == 0 && blockIdx.x == 0) {                                                     \
+    g_spx_stamps[SPX_STAMP_SEL] += X.stamp_acc;                                                  \
+    g_spx_stamps[30] += __builtin_readcyclecounter() - X.stamp_t0;                               \
+    g_spx_stamps[31] += X.stamp_steps;                                                           \
+  }
 extern "C" void spx_debug_stamps(unsigned long long* out, int reset) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spx_stamps), sizeof(unsigned long long) * 32);
   if (reset) {
@@ -137,8 +147,8 @@ struct WalkCtx {
   unsigned* diffC;    // per-lag AMDF sums, coarse search
   unsigned* diffR;    // per-lag AMDF sums, refine search
 #ifdef SPX_STAMPS
-  unsigned long long stamp_last;
-  unsigned long long stamp_acc[16];
+  unsigned long long stamp_last, stamp_acc, stamp_t0;
+  unsigned stamp_steps;
 #endif
 };
 
@@ -916,6 +926,11 @@ void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_str
   // FAST: every stream mono, decimated search, and at most 64 lags in either search (rates below 32 kHz)
   const bool fast = maxC == 1 && P.skip >= 2 && (P.maxPeriod / P.skip - P.minPeriod / P.skip + 1) <= 64 &&
                     (8 * P.skip + 1) <= 64 && !getenv("SPX_WALK_GENERIC");
+#ifdef SPX_STAMPS
+  (void)nw;
+  SPX_LAUNCH_WALK(8);  // the diagnostic build measures the 8-wave kernel only
+  return;
+#endif
   switch (nw) {
     case 1: SPX_LAUNCH_WALK(1); break;
     case 2: SPX_LAUNCH_WALK(2); break;

@@ -167,6 +167,17 @@ def test_reference_property_tests_through_the_hip_api():
     sp.check_nonlinear_sine(comp, 3.0)
 
 
+def test_chirp_and_dtw_properties_through_the_hip_api(orc):
+    """sonic_classic_test.cc:303-394 (speed changes between writes) and sonic_test.cc:639-724 (DTW slopes of the
+    linear and the nonlinear 3x tapestry) on the product; the oracle's speedySpectrogram is only the measuring
+    device the reference test uses too."""
+    from speedy_amd.sonic2 import SonicStream
+    from test_oracle_sonic_properties import _spectrogram
+    sp.check_chirp_speedup(lambda rate, ch: SonicStream(rate, ch, True))
+    comp = lambda x, rate, ch, speed, nl: _gpu_compress(x, rate, ch, speed, nl)  # noqa: E731
+    sp.check_speech_dtw(comp, _spectrogram(orc))
+
+
 def test_negative_speed_input_does_not_crash():
     """speedy_test.cc:1059-1076: 24 kHz file, speed 0.25, nonlinear, one big write."""
     from speedy_amd.sonic2 import SonicStream

@@ -69,3 +69,50 @@ def test_mono_vs_offset_stereo_tension(orc):
     avg = np.trunc((s["out"][0::2].astype(int) + s["out"][1::2].astype(int)) / 2).astype(int)
     assert np.abs(avg - m["out"]).max() <= 1
     assert np.array_equal(m["tension"], m["features"][:, 11])  # sonic_test.cc:937
+
+
+def _spectrogram(orc):
+    def f(x, rate):
+        """ComputeSpectrogram of sonic_test.cc:211-240 on the oracle's speedySpectrogram."""
+        s = orc.Speedy(rate, True)
+        w, h = s.frame_size, s.fft_size // 2
+        rows = []
+        for at in range(0, x.size - w, w):
+            full = s.spectrogram(x[at:at + w].astype(np.float32))
+            row = np.zeros(h, np.float32)
+            row[: h // 2] = full[: h // 2]
+            rows.append(row)
+        s.close()
+        return np.array(rows)
+    return f
+
+
+def test_speech_sample_dtw_slopes(orc, compress):
+    sp.check_speech_dtw(compress, _spectrogram(orc))
+
+
+class _OrcStream:
+    """The oracle shim behind the set_speed / write_short / read_short / flush shape the property checks use."""
+
+    def __init__(self, orc, rate, ch):
+        self.orc, self.L, self.ch = orc, orc.lib(), ch
+        self.h = self.L.orc_sonicCreateStream(rate, ch, 1)
+
+    def set_speed(self, v):
+        self.L.orc_sonicSetSpeed(self.h, v)
+
+    def write_short(self, x):
+        x = np.ascontiguousarray(x, np.int16)
+        return self.L.orc_sonicWriteShortToStream(self.h, self.orc.sptr(x), x.size // self.ch)
+
+    def read_short(self, n):
+        buf = np.zeros(n * self.ch, np.int16)
+        k = self.L.orc_sonicReadShortFromStream(self.h, self.orc.sptr(buf), n)
+        return buf[: k * self.ch]
+
+    def flush(self):
+        self.L.orc_sonicFlushStream(self.h)
+
+
+def test_chirp_speed_changes(orc):
+    sp.check_chirp_speedup(lambda rate, ch: _OrcStream(orc, rate, ch))

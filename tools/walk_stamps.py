@@ -1,52 +1,60 @@
-"""Diagnostic only: per-phase shader-cycle shares of the walk kernel (workgroup 0), from the -DSPX_STAMPS build.
-Usage on the GPU box:  SPEEDY_HIP_LIB=speedy_amd/lib/libspeedy_hip_stamps.so python tools/walk_stamps.py"""
+"""Diagnostic only: per-phase shader-cycle shares of the walk kernel (workgroup 0 = stream 0), from the
+`make -C speedy_amd/csrc stamps` builds -- one library per stamped region so that the single accumulator does not
+disturb the kernel's register allocation.  Usage on the GPU box:  python tools/walk_stamps.py   (SPX_SERIAL=1 is
+set for the children so that the walk kernel is measured alone)."""
 import ctypes as C
 import os
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-from speedy_amd.batch import Batch, Plan  # noqa: E402
-from speedy_amd.synth import speech_like  # noqa: E402
-
 NAMES = {0: "event loop (between process calls)", 1: "pre-step (copy steps, loop ctl)", 2: "ensure_window",
          3: "phase B build signals", 4: "sync c", 5: "coarse accumulate", 6: "sync e", 7: "coarse select",
          8: "refine accumulate", 9: "sync h", 10: "refine select", 11: "decision", 12: "after OLA -> end of process",
          13: "overlap-add"}
-rate, n, nstreams = 16000, 160000, int(os.environ.get("NSTREAMS", "256"))
-plan = Plan(rate, False)
-base = [speech_like(n, rate, seed=i) for i in range(8)]
-b = Batch(plan, [n] * nstreams, 1, 3.5, 1.0, 0.0)
-b.upload([base[i % 8] for i in range(nstreams)])
-b.run()
-torch.cuda.synchronize()
-L = plan.L
-L.spx_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-buf = (C.c_ulonglong * 32)()
-L.spx_debug_stamps(buf, 1)
-b.run()
-torch.cuda.synchronize()
-L.spx_debug_stamps(buf, 1)
-tot = sum(buf)
-print("stream 0: total stamped cycles %d" % tot)
-for i in range(14):
-    print("  %2d %-40s %10d  %5.1f %%" % (i, NAMES.get(i, ""), buf[i], 100.0 * buf[i] / max(1, tot)))
 
-# analysis kernel, workgroup 7, lane 0
-try:
-    L.spx_debug_astamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-    ab = (C.c_ulonglong * 16)()
-    L.spx_debug_astamps(ab, 1)
+
+def child(sel):
+    sys.path.insert(0, ROOT)
+    import torch
+    from speedy_amd.batch import Batch, Plan
+    from speedy_amd.synth import speech_like
+    rate, n, nstreams = 16000, 160000, int(os.environ.get("NSTREAMS", "256"))
+    plan = Plan(rate, False)
+    base = [speech_like(n, rate, seed=i) for i in range(8)]
+    b = Batch(plan, [n] * nstreams, 1, 3.5, 1.0, 0.0)
+    b.upload([base[i % 8] for i in range(nstreams)])
     b.run()
     torch.cuda.synchronize()
-    L.spx_debug_astamps(ab, 1)
-    an = ["frame load+window", "DFT stages", "untangle+mag", "loop exit", "sync", "phase2 energy (+sync)",
-          "phase3 log terms (+sync)", "phase4 accumulate"]
-    tot = sum(ab[:8])
-    print("analysis tile (wave 0 of workgroup 7): total %d cycles" % tot)
-    for i in range(8):
-        print("  %d %-28s %9d  %5.1f %%" % (i, an[i], ab[i], 100.0 * ab[i] / max(1, tot)))
-except AttributeError:
-    pass
+    L = plan.L
+    L.spx_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    buf = (C.c_ulonglong * 32)()
+    L.spx_debug_stamps(buf, 1)
+    b.run()
+    torch.cuda.synchronize()
+    L.spx_debug_stamps(buf, 1)
+    print("STAMP %d %d %d %d" % (sel, buf[sel], buf[30], buf[31]))
+
+
+if len(sys.argv) > 1:
+    child(int(sys.argv[1]))
+    sys.exit(0)
+
+rows = []
+for sel in range(14):
+    env = dict(os.environ, SPX_SERIAL="1",
+               SPEEDY_HIP_LIB=os.path.join(ROOT, "speedy_amd", "lib", "stamps", "libspeedy_hip_stamps_%d.so" % sel))
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), str(sel)], env=env, capture_output=True, text=True)
+    for line in out.stdout.splitlines():
+        if line.startswith("STAMP"):
+            rows.append([int(v) for v in line.split()[1:]])
+    if out.returncode:
+        print("region", sel, "failed:", out.stderr[-400:])
+if rows:
+    steps = rows[0][3]
+    total = sum(r[1] for r in rows)
+    print("stream 0: %d pitch steps, kernel %d cycles (%.0f per step); stamped regions sum to %d" %
+          (steps, rows[0][2], rows[0][2] / max(1, steps), total))
+    for sel, cyc, kern, _ in rows:
+        print("  %2d %-40s %10d  %5.1f %%  %7.0f cycles/step" % (sel, NAMES.get(sel, ""), cyc, 100.0 * cyc / max(1, total),
+                                                                  cyc / max(1, steps)))
