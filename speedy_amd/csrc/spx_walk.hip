@@ -103,31 +103,30 @@ __device__ __forceinline__ void lds_sync() {
   }
 }
 
-// ---- wave-level float min / max over 64 lanes (DPP inside rows of 16, readlane across rows) ----
-#define SPX_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
-__device__ __forceinline__ float wave_min_f(float v) {
-  v = fminf(v, SPX_DPP(v, 0xB1));   // quad_perm [1,0,3,2]
-  v = fminf(v, SPX_DPP(v, 0x4E));   // quad_perm [2,3,0,1]
-  v = fminf(v, SPX_DPP(v, 0x141));  // row_half_mirror
-  v = fminf(v, SPX_DPP(v, 0x140));  // row_mirror
-  const int iv = __builtin_bit_cast(int, v);
-  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
-  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
-  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
-  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
-  return fminf(fminf(a, b), fminf(c, d));
+// ---- wave-level min / max over 64 lanes of NON-NEGATIVE floats, done on their bit patterns (same order as
+// unsigned integers, and v_min_u32 / v_max_u32 take the DPP operand directly: one instruction per stage, no float
+// canonicalisation).  Rows of 16 by quad_perm / mirror, then row_bcast:15 and row_bcast:31 carry the row results
+// to lane 63.  Every lane gets the result (readlane 63 -> SGPR).
+// Written as inline assembly because the compiler keeps a v_mov_b32_dpp + v_min pair (and a copy) per stage; the
+// s_nop 1 in front of every stage is the VALU-write -> DPP-read hazard distance the assembler does not insert here.
+#define SPX_WAVE_REDUCE(OP, v)                                                            \
+  asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+               "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+               "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"     \
+               "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"          \
+               "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"        \
+               "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"        \
+               "s_nop 1"                                                                  \
+               : "+v"(v))
+__device__ __forceinline__ float wave_min_f(float f) {
+  unsigned v = __builtin_bit_cast(unsigned, f);
+  SPX_WAVE_REDUCE("v_min_u32_dpp", v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)v, 63));
 }
-__device__ __forceinline__ float wave_max_f(float v) {
-  v = fmaxf(v, SPX_DPP(v, 0xB1));
-  v = fmaxf(v, SPX_DPP(v, 0x4E));
-  v = fmaxf(v, SPX_DPP(v, 0x141));
-  v = fmaxf(v, SPX_DPP(v, 0x140));
-  const int iv = __builtin_bit_cast(int, v);
-  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
-  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
-  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
-  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
-  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+__device__ __forceinline__ float wave_max_f(float f) {
+  unsigned v = __builtin_bit_cast(unsigned, f);
+  SPX_WAVE_REDUCE("v_max_u32_dpp", v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)v, 63));
 }
 
 struct WalkCtx {
@@ -179,10 +178,21 @@ __device__ __forceinline__ void ensure_window(WalkCtx& X, pos_t pos, int need) {
     const pos_t room = X.limit - nb;  // frames of real input from nb on
     for (int k0 = threadIdx.x; k0 < X.wcap + 1; k0 += 8 * NT) {
       int v[8];
+      const int last = (int)(room < X.wcap + 1 ? room : X.wcap + 1) - 1;  // last index holding real input
+      if (last >= 0) {  // uniform
 #pragma unroll
-      for (int u = 0; u < 8; u++) {  // eight coalesced loads in flight before the first LDS write
-        const int k = k0 + u * NT;
-        v[u] = (k < X.wcap + 1 && k < room) ? (int)src[k] : 0;
+        for (int u = 0; u < 8; u++) {  // eight coalesced loads in flight before the first LDS write:
+          const int k = k0 + u * NT;   // clamped address, unconditional load, so nothing serialises them
+          v[u] = (int)src[k < last ? k : last];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int k = k0 + u * NT;
+          if (k > last) v[u] = 0;
+        }
+      } else {  // the whole window lies in the zero padding: no address there may be touched
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = 0;
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
@@ -231,10 +241,15 @@ __device__ __forceinline__ unsigned sad_run(const unsigned* ap, const unsigned* 
 // Exact division of small unsigned numbers (x < 2^31, 1 <= d < 2^12) without the 30-instruction integer
 // division expansion: float estimate, then at most one correction each way.
 __device__ __forceinline__ unsigned udiv_small(unsigned x, unsigned d) {
+  // x < 2^27 (an AMDF sum) and d >= 10 (a lag), q < 2^19, so the estimate is off by at most 2: two branch-free fix-ups each
+  // way in wrapping 32-bit arithmetic (the true remainder lies in (-2d, 3d), far from the wrap)
   unsigned q = (unsigned)((float)x * __builtin_amdgcn_rcpf((float)d));
-  long long r = (long long)x - (long long)q * d;
-  while (r < 0) { q--; r += d; }
-  while (r >= (long long)d) { q++; r -= d; }
+  int r = (int)(x - q * d);
+  const int di = (int)d;
+  q -= r < 0; r += r < 0 ? di : 0;
+  q -= r < 0; r += r < 0 ? di : 0;
+  q += r >= di; r -= r >= di ? di : 0;
+  q += r >= di; r -= r >= di ? di : 0;
   return q;
 }
 
@@ -247,12 +262,18 @@ struct Sel {
 // Fold the 64 lanes' (d, p) candidates (lane order = ascending lag) into the running result, exactly as a
 // sequential scan would: float ratios, DPP wave min/max, then an exact integer resolve on the scalar unit of the
 // lanes within 2^-16 of the extremum (strict compare, so the FIRST lag wins ties).  Wave-uniform result.
-template <bool WANT_MAX>
+template <bool WANT_MAX, bool FRESH = false>
 __device__ __forceinline__ void select_fold(Sel& S, unsigned d, int p0, bool valid) {
   const int lane = threadIdx.x & 63;
   const float r = (float)d * __builtin_amdgcn_rcpf((float)(p0 + lane));  // within 2^-21 of d/p
   const float rmin = wave_min_f(valid ? r : __builtin_huge_valf());
-  unsigned long long mmin = __ballot(valid && r <= rmin * 1.0000153f);  // 1 + 2^-16
+  unsigned long long mmin = __builtin_amdgcn_ballot_w64(valid && r <= rmin * 1.0000153f);  // 1 + 2^-16
+  if (FRESH) {  // S is empty and some lane is valid: the first candidate is taken without a comparison
+    const int i = __builtin_ctzll(mmin);
+    mmin &= mmin - 1;
+    S.bestD = (unsigned)__builtin_amdgcn_readlane((int)d, i);
+    S.bestP = p0 + i;
+  }
   while (mmin) {
     const int i = __builtin_ctzll(mmin);
     mmin &= mmin - 1;
@@ -264,8 +285,8 @@ __device__ __forceinline__ void select_fold(Sel& S, unsigned d, int p0, bool val
     }
   }
   if (WANT_MAX) {
-    const float rmax = wave_max_f(valid ? r : -1.0f);
-    unsigned long long mmax = __ballot(valid && r >= rmax * 0.9999847f);
+    const float rmax = wave_max_f(valid ? r : 0.0f);
+    unsigned long long mmax = __builtin_amdgcn_ballot_w64(valid && r >= rmax * 0.9999847f);
     while (mmax) {
       const int i = __builtin_ctzll(mmax);
       mmax &= mmax - 1;
@@ -305,7 +326,7 @@ __device__ __forceinline__ void search_lane_per_lag(const unsigned* A0, const un
     unsigned d = sad_run(ap, bp, 0, nfull);
     if (valid && (p & 1)) d = __builtin_amdgcn_sad_u16(ap[nfull] & 0xffffu, bp[nfull] & 0xffffu, d);  // term i = p-1
     if (dlane && base == 0) *dlane = d;
-    select_fold<WANT_MAX>(S, d, minP + base, valid);
+    select_fold<WANT_MAX, FAST>(S, d, minP + base, valid);
   }
 }
 
@@ -347,7 +368,7 @@ __device__ __forceinline__ void search_split(const unsigned* A0, const unsigned*
     const bool valid = base + lane < nl;
     const unsigned d = valid ? buf[base + lane] : 0u;
     if (dlane && base == 0) *dlane = d;
-    select_fold<WANT_MAX>(S, d, minP + base, valid);
+    select_fold<WANT_MAX, FAST>(S, d, minP + base, valid);
   }
 }
 
@@ -433,7 +454,7 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
         const int lane = tid & 63;
         const bool valid = lane < hi - lo + 1;
         const unsigned long long need = (unsigned long long)(3u * (unsigned)minDiff + 1u) * (unsigned)(lo + lane);
-        if (__ballot(valid && (unsigned long long)dl >= need) == 0) maxDiff = 0;  // no lag that bad: keep the old period
+        if (__builtin_amdgcn_ballot_w64(valid && (unsigned long long)dl >= need) == 0) maxDiff = 0;  // no lag that bad: keep the old period
       }
     } else {
       search_split<NW, true, FAST>(M0, M1, o, lo, hi - lo + 1, X.diffR + 256 * tg, X.diffR + 256 * (1 - tg), S2, X, 8);
