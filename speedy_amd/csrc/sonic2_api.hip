@@ -50,6 +50,7 @@ struct sonicStreamStruct {  // speedyConnectionStruct + the parts of libsonic's 
   const SpxPlanDev* plan = nullptr;
   int sampleRate = 0, channels = 0;
   float globalSpeed = 1.0f;         // soniclib.c:114
+  bool speedupOnly = true;          // every launch so far had speed > 1 and 0 <= nonlinear factor <= 1
   float nonlinearFactor = 0.0f;     // soniclib.c:117
   float feedbackStrength = 0.1f;    // soniclib.c:122
   float rate = 1.0f;
@@ -246,6 +247,8 @@ static int launch_job(sonicStream s, bool flush) {
   J.channels = s->channels;
   J.flags = (s->started ? 0 : SPX_F_INIT) | (flush ? SPX_F_FLUSH : 0);
   J.speed = s->globalSpeed; J.nonlinear = nonlinear ? s->nonlinearFactor : 0.0f; J.feedback = s->feedbackStrength;
+  // once a stream has run at a speed <= 1 its carried speed may be below 1: stay on the general kernel from then on
+  if (!(J.speed > 1.0f && J.nonlinear >= 0.0f && J.nonlinear <= 1.0f)) s->speedupOnly = false;
   J.first_tile = 0;
   if (hipMemcpyAsync(s->dJob, &J, sizeof(J), hipMemcpyHostToDevice, s->hs) != hipSuccess) return 0;
   SpxTapsDev td = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -258,7 +261,8 @@ static int launch_job(sonicStream s, bool flush) {
     const int tiles = (int)((T - fa + TF - 1) / TF);
     spx_launch_analysis(P, s->dJob, 1, tiles, s->dIn.p, s->dRec.p, td, nullptr, nullptr, s->hs);
   }
-  spx_launch_walk(P, s->dJob, 1, s->channels, s->dIn.p, s->dOut.p, s->dNOut, s->dState, s->dRec.p, s->dScr.p, td, nullptr, s->hs);
+  spx_launch_walk(P, s->dJob, 1, s->channels, s->dIn.p, s->dOut.p, s->dNOut, s->dState, s->dRec.p, s->dScr.p, td, nullptr,
+                  s->speedupOnly, s->hs);
   if (hipGetLastError() != hipSuccess) { g_api_err = "kernel launch failed"; s->failed = true; return 0; }
   s->started = true;
   s->dirty = true;

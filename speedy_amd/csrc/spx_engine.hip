@@ -290,7 +290,11 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   SpxTapsDev td = taps_of(taps);
   const bool timed = g_timing && do_a && do_w;
   int maxC = 1;
-  for (int i = 0; i < n; i++) if (jobs[i].channels > maxC) maxC = jobs[i].channels;
+  bool speedup_only = true;  // every job speeds up: the walk kernel specialised for speeds >= 1 applies
+  for (int i = 0; i < n; i++) {
+    if (jobs[i].channels > maxC) maxC = jobs[i].channels;
+    if (!(jobs[i].speed > 1.0f && jobs[i].nonlinear >= 0.0f && jobs[i].nonlinear <= 1.0f)) speedup_only = false;
+  }
   // Concurrent mode: the analysis kernel goes to the plan's side stream in "earliest frames first" tile order and
   // publishes a flag per tile; the walk kernel starts at once on the caller's stream and consumes chunks of frames
   // as their tiles become ready.  Same arithmetic, same results; only the serialisation of the two kernels goes.
@@ -343,7 +347,8 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     if (do_w) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, st); }
-      spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, rec, scratch, td, concurrent ? d_flags : nullptr, st);
+      spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, rec, scratch, td, concurrent ? d_flags : nullptr,
+                      speedup_only, st);
       if (timed) { (void)hipEventRecord(e1, st); g_ev_pending.push_back({e0, e1, 1}); }
     }
     // the caller's stream is "done" only when the analysis launch has retired too

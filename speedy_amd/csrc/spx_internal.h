@@ -89,7 +89,9 @@ void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int max_channels,
                      const int16_t* in,
                      int16_t* out, int64_t* n_out, SpxStreamState* states, const SpxFrameRec* rec, float* scratch,
-                     SpxTapsDev taps, const int* tile_flags, hipStream_t st);
+                     SpxTapsDev taps, const int* tile_flags, bool speedup_only, hipStream_t st);
+// speedup_only: every job has speed > 1 and 0 <= nonlinear <= 1 (and a streamed job has never had another setting),
+// so the time-scale stage only ever sees speeds >= 1: selects the walk kernel specialised for that.
 size_t spx_analysis_lds_bytes(const SpxPlanDev& P);
 int spx_analysis_tile_frames();
 

@@ -509,7 +509,7 @@ __device__ __forceinline__ void emit_overlap_add(const WalkCtx& X, pos_t a_down,
   int16_t* __restrict__ dst = X.out + (size_t)out_at * C;
   const pos_t od = a_down - X.wbase, ou = a_up - X.wbase;
   const bool inwin = X.wbase >= 0 && od >= 0 && ou >= 0 && od + n <= X.wcap && ou + n <= X.wcap;
-  if (C == 1 && inwin) {
+  if (FAST || (C == 1 && inwin)) {  // FAST: ensure_window(pos, maxRequired + ...) of the search covers both ramps
     const unsigned short* wd = X.monoH + od;
     const unsigned short* wu = X.monoH + ou;
     for (int t = threadIdx.x; t < nv; t += NT) {
@@ -590,6 +590,102 @@ __device__ __forceinline__ void tsm_process(const SpxPlanDev& P, WalkCtx& X, Wal
     emit_copy<NW, FAST>(X, st, st.base, avail - st.base);
     st.base = avail;
   }
+}
+
+// ---- FAST kernels (mono, every job's speed > 1 and 0 <= nonlinear <= 1, so every speed the stage sees is >= 1) ----
+// The pitch steps one event can run = the loop of processStreamInput for speed > 1 with `avail` frames handed over.
+// The caller guarantees avail - st.base >= maxRequired.  Returns false when a step fails (n == 0): the dependency
+// then returns without removing the input it has consumed in this call, so st.base keeps its value.
+template <int NW>
+__device__ __forceinline__ bool fast_steps(const SpxPlanDev& P, WalkCtx& X, WalkState& st, float speed, pos_t avail) {
+  const int maxRequired = P.maxRequired;
+  const bool ge2 = speed >= 2.0f;
+  const float sm1 = speed - 1.0f, twom = 2.0f - speed;
+  pos_t pos = st.base;
+  do {
+    if (st.remaining > 0) {
+      int n = st.remaining;
+      if (n > maxRequired) n = maxRequired;
+      ensure_window<NW, true>(X, pos, n);
+      emit_copy<NW, true>(X, st, pos, n);
+      st.remaining -= n;
+      pos += n;
+    } else {
+      const int period = find_pitch_period<NW, true>(P, X, st, pos);
+      int n;
+      if (ge2) {
+        n = uni((int)((float)period / sm1));
+      } else {
+        n = period;
+        st.remaining = uni((int)((float)period * twom / sm1));
+      }
+      if (st.out_n + n > X.out_cap) st.overflow = 1;
+      if (n == 0) return false;
+      STAMP(11);
+      emit_overlap_add<NW, true>(X, pos, pos + period, n, st.out_n);
+      STAMP(13);
+      st.out_n += n;
+      pos += period + n;
+    }
+  } while (pos + maxRequired <= avail);
+  st.base = pos;
+  return true;
+}
+
+__device__ __forceinline__ bool speed_is_unity(float speed) {  // the dependency's pass-through test
+  return !((double)speed > 1.00001 || (double)speed < 0.99999);
+}
+
+// One event of the stage with `avail` frames handed over at `speed`.
+template <int NW>
+__device__ __forceinline__ void fast_event(const SpxPlanDev& P, WalkCtx& X, WalkState& st, float speed, bool unity,
+                                           pos_t avail) {
+  if (unity) {
+    emit_copy<NW, true>(X, st, st.base, avail - st.base);
+    st.base = avail;
+  } else if (avail - st.base >= P.maxRequired) {
+    (void)fast_steps<NW>(P, X, st, speed, avail);
+  }
+}
+
+// The ordinary events [ev0, ev1) of a nonlinear stream: event e sets the speed of tension frame e (e < K; later
+// events keep the last speed) and hands over B more frames (soniclib.c:354,369,538-550).  Most events cannot run a
+// step (a step needs maxRequired frames, an event brings B): those cost a few scalar instructions here.  The speeds
+// of 64 consecutive events sit in one VGPR (lane = event), so picking one is a v_readlane, not a memory access.
+template <int NW>
+__device__ __forceinline__ void fast_events(const SpxPlanDev& P, WalkCtx& X, WalkState& st, const float* scr, pos_t ev0,
+                                            pos_t ev1, pos_t K, pos_t& avail, int B, float& curSpeed) {
+  const int lane = threadIdx.x & 63;
+  const int maxRequired = P.maxRequired;
+  const pos_t Kc = ev1 < K ? ev1 : K;  // tension events of this chunk: [ev0, Kc)
+  float tailSpeed = curSpeed;          // what later events run at, and what the stream carries on
+  if (Kc > ev0) tailSpeed = unif(scr[4 * (size_t)(Kc - 1) + 3]);
+  const bool tailUnity = speed_is_unity(tailSpeed);
+  pos_t blk0 = ev0 - 64;
+  float spv = 0.0f;
+  unsigned long long unityMask = 0;
+  for (pos_t e = ev0; e < ev1; e++) {
+    avail += B;
+    float speed = tailSpeed;
+    bool unity = tailUnity;
+    if (e < K) {
+      int i = e - blk0;
+      if (i >= 64) {  // next 64 events' speeds into the lanes
+        blk0 = e;
+        i = 0;
+        const pos_t idx = blk0 + lane;
+        spv = (idx < K) ? scr[4 * (size_t)idx + 3] : 2.0f;
+        unityMask = __builtin_amdgcn_ballot_w64(speed_is_unity(spv));
+      }
+      unity = (unityMask >> i) & 1;
+      if (!unity && avail - st.base < maxRequired) continue;
+      speed = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, spv), i));
+    }
+    STAMP(0);
+    fast_event<NW>(P, X, st, speed, unity, avail);
+    STAMP(12);
+  }
+  curSpeed = tailSpeed;
 }
 
 // LDS layout (bytes), shared by host and device
@@ -874,39 +970,61 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
     else ev1 = (last && (pos_t)S.n_in > avail) ? 1 : 0;
     if (ev1 < ev0) ev1 = ev0;
     const pos_t ev_end = ev1 + (fin ? 1 : 0);
-    for (pos_t ev = ev0; ev < ev_end; ev++) {
-      pos_t expected = 0;
-      if (ev < ev1) {
-        if (nl != 0.0f) {
-          if (ev < K) {
-            const int i = (int)((ev - ev0) % SPX_CH);
-            if (i == 0) {  // stage the next chunk of speeds in LDS
-              __syncthreads();
-              const int n = (int)min((pos_t)SPX_CH, (pos_t)K - ev);
-              for (int t = tid; t < n; t += NT) sA[t] = scr[4 * (ev + t) + 3];
-              __syncthreads();
-            }
-            curSpeed = unif(sA[i]);
-          }
-          avail += B;
-        } else {
-          avail = (pos_t)S.n_in;
-        }
-      } else {
+    (void)ev_end;
+    if constexpr (FAST) {
+      if (nl != 0.0f) {
+        fast_events<NW>(P, X, st, scr, ev0, ev1, (pos_t)K, avail, B, curSpeed);
+      } else if (ev1 > ev0) {
+        avail = (pos_t)S.n_in;
+        fast_event<NW>(P, X, st, curSpeed, speed_is_unity(curSpeed), avail);
+      }
+      if (fin) {  // sonicIntFlushStream: pad 2*maxRequired zeros, process, truncate to the expected length
         const pos_t remainingS = avail - st.base;
-        expected = st.out_n + uni((int)(((float)remainingS / curSpeed + 0) / 1.0f + 0.5f));
+        const pos_t expected = st.out_n + uni((int)(((float)remainingS / curSpeed + 0) / 1.0f + 0.5f));
         X.limit = avail;  // everything from here on reads as the flush's zero padding
         lds_sync<NW>();
         X.wbase = -1;     // the window may hold samples past the new limit
         avail += 2 * P.maxRequired;
-      }
-      STAMP(0);
-      tsm_process<NW, FAST>(P, X, st, curSpeed, avail);
-      STAMP(12);
-      if (ev >= ev1) {
+        fast_event<NW>(P, X, st, curSpeed, speed_is_unity(curSpeed), avail);
         if (st.out_n > expected) st.out_n = expected;
         st.base = avail;  // the dependency empties its input after a flush
         st.remaining = 0;
+      }
+    } else {
+      for (pos_t ev = ev0; ev < ev_end; ev++) {
+        pos_t expected = 0;
+        if (ev < ev1) {
+          if (nl != 0.0f) {
+            if (ev < K) {
+              const int i = (int)((ev - ev0) % SPX_CH);
+              if (i == 0) {  // stage the next chunk of speeds in LDS
+                __syncthreads();
+                const int n = (int)min((pos_t)SPX_CH, (pos_t)K - ev);
+                for (int t = tid; t < n; t += NT) sA[t] = scr[4 * (ev + t) + 3];
+                __syncthreads();
+              }
+              curSpeed = unif(sA[i]);
+            }
+            avail += B;
+          } else {
+            avail = (pos_t)S.n_in;
+          }
+        } else {
+          const pos_t remainingS = avail - st.base;
+          expected = st.out_n + uni((int)(((float)remainingS / curSpeed + 0) / 1.0f + 0.5f));
+          X.limit = avail;  // everything from here on reads as the flush's zero padding
+          lds_sync<NW>();
+          X.wbase = -1;     // the window may hold samples past the new limit
+          avail += 2 * P.maxRequired;
+        }
+        STAMP(0);
+        tsm_process<NW, FAST>(P, X, st, curSpeed, avail);
+        STAMP(12);
+        if (ev >= ev1) {
+          if (st.out_n > expected) st.out_n = expected;
+          st.base = avail;  // the dependency empties its input after a flush
+          st.remaining = 0;
+        }
       }
     }
     if (nl != 0.0f) handed = ev1;
@@ -927,7 +1045,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
 
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int maxC, const int16_t* in,
                      int16_t* out, int64_t* n_out, SpxStreamState* states, const SpxFrameRec* rec,
-                     float* scratch, SpxTapsDev taps, const int* tile_flags, hipStream_t st) {
+                     float* scratch, SpxTapsDev taps, const int* tile_flags, bool speedup_only, hipStream_t st) {
   if (n_streams <= 0) return;
   if (maxC < 1) maxC = 1;
   const WalkLds LY = walk_lds_layout(P, maxC);
@@ -944,9 +1062,11 @@ void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_str
       hipLaunchKernelGGL((spx_walk_kernel<NWV, false>), dim3(n_streams), dim3(64 * NWV), LY.total, st, P, streams, \
                          in, out, n_out, states, rec, scratch, taps, maxC, tile_flags);                                      \
   } while (0)
-  // FAST: every stream mono, decimated search, and at most 64 lags in either search (rates below 32 kHz)
-  const bool fast = maxC == 1 && P.skip >= 2 && (P.maxPeriod / P.skip - P.minPeriod / P.skip + 1) <= 64 &&
-                    (8 * P.skip + 1) <= 64 && !getenv("SPX_WALK_GENERIC");
+  // FAST: every stream mono and speeding up (speed > 1, 0 <= nonlinear <= 1: the stage never sees a speed below 1),
+  // decimated search, and at most 64 lags in either search (rates below 32 kHz)
+  const bool fast = maxC == 1 && speedup_only && P.skip >= 2 &&
+                    (P.maxPeriod / P.skip - P.minPeriod / P.skip + 1) <= 64 && (8 * P.skip + 1) <= 64 &&
+                    !getenv("SPX_WALK_GENERIC");
 #ifdef SPX_STAMPS
   (void)nw;
   SPX_LAUNCH_WALK(8);  // the diagnostic build measures the 8-wave kernel only
