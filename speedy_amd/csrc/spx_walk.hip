@@ -636,25 +636,18 @@ __device__ __forceinline__ bool speed_is_unity(float speed) {  // the dependency
   return !((double)speed > 1.00001 || (double)speed < 0.99999);
 }
 
-// One event of the stage with `avail` frames handed over at `speed`.
-template <int NW>
-__device__ __forceinline__ void fast_event(const SpxPlanDev& P, WalkCtx& X, WalkState& st, float speed, bool unity,
-                                           pos_t avail) {
-  if (unity) {
-    emit_copy<NW, true>(X, st, st.base, avail - st.base);
-    st.base = avail;
-  } else if (avail - st.base >= P.maxRequired) {
-    (void)fast_steps<NW>(P, X, st, speed, avail);
-  }
-}
-
-// The ordinary events [ev0, ev1) of a nonlinear stream: event e sets the speed of tension frame e (e < K; later
-// events keep the last speed) and hands over B more frames (soniclib.c:354,369,538-550).  Most events cannot run a
-// step (a step needs maxRequired frames, an event brings B): those cost a few scalar instructions here.  The speeds
-// of 64 consecutive events sit in one VGPR (lane = event), so picking one is a v_readlane, not a memory access.
+// All events of a chunk through ONE call site of the step code (the kernel stays small):
+//   ordinary events [ev0, ev1): nonlinear -- event e sets the speed of tension frame e (e < K; later events keep the
+//     last speed) and hands over B more frames (soniclib.c:354,369,538-550); linear -- one event handing over
+//     everything new at the stream's speed (soniclib.c:397-399);
+//   then, if `fin`, sonicIntFlushStream (soniclib.c:551): pad 2*maxRequired zeros, process, truncate.
+// Most nonlinear events cannot run a step (a step needs maxRequired frames, an event brings B): those cost a few
+// scalar instructions.  The speeds of 64 consecutive events sit in one VGPR (lane = event), so picking one is a
+// v_readlane, not a memory access.
 template <int NW>
 __device__ __forceinline__ void fast_events(const SpxPlanDev& P, WalkCtx& X, WalkState& st, const float* scr, pos_t ev0,
-                                            pos_t ev1, pos_t K, pos_t& avail, int B, float& curSpeed) {
+                                            pos_t ev1, pos_t K, pos_t& avail, int B, bool linear, pos_t n_in, bool fin,
+                                            float& curSpeed) {
   const int lane = threadIdx.x & 63;
   const int maxRequired = P.maxRequired;
   const pos_t Kc = ev1 < K ? ev1 : K;  // tension events of this chunk: [ev0, Kc)
@@ -664,26 +657,48 @@ __device__ __forceinline__ void fast_events(const SpxPlanDev& P, WalkCtx& X, Wal
   pos_t blk0 = ev0 - 64;
   float spv = 0.0f;
   unsigned long long unityMask = 0;
-  for (pos_t e = ev0; e < ev1; e++) {
-    avail += B;
+  const pos_t ev_end = ev1 + (fin ? 1 : 0);
+  for (pos_t e = ev0; e < ev_end; e++) {
     float speed = tailSpeed;
     bool unity = tailUnity;
-    if (e < K) {
-      int i = e - blk0;
-      if (i >= 64) {  // next 64 events' speeds into the lanes
-        blk0 = e;
-        i = 0;
-        const pos_t idx = blk0 + lane;
-        spv = (idx < K) ? scr[4 * (size_t)idx + 3] : 2.0f;
-        unityMask = __builtin_amdgcn_ballot_w64(speed_is_unity(spv));
+    pos_t expected = 0;
+    const bool flush = e >= ev1;
+    if (!flush) {
+      avail = linear ? n_in : avail + B;
+      if (e < K) {
+        int i = e - blk0;
+        if (i >= 64) {  // next 64 events' speeds into the lanes
+          blk0 = e;
+          i = 0;
+          const pos_t idx = blk0 + lane;
+          spv = (idx < K) ? scr[4 * (size_t)idx + 3] : 2.0f;
+          unityMask = __builtin_amdgcn_ballot_w64(speed_is_unity(spv));
+        }
+        unity = (unityMask >> i) & 1;
+        if (!unity && avail - st.base < maxRequired) continue;
+        speed = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, spv), i));
       }
-      unity = (unityMask >> i) & 1;
-      if (!unity && avail - st.base < maxRequired) continue;
-      speed = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, spv), i));
+    } else {
+      const pos_t remainingS = avail - st.base;
+      expected = st.out_n + uni((int)(((float)remainingS / tailSpeed + 0) / 1.0f + 0.5f));
+      X.limit = avail;  // everything from here on reads as the flush's zero padding
+      lds_sync<NW>();
+      X.wbase = -1;     // the window may hold samples past the new limit
+      avail += 2 * maxRequired;
     }
     STAMP(0);
-    fast_event<NW>(P, X, st, speed, unity, avail);
+    if (unity) {
+      emit_copy<NW, true>(X, st, st.base, avail - st.base);
+      st.base = avail;
+    } else if (avail - st.base >= maxRequired) {
+      (void)fast_steps<NW>(P, X, st, speed, avail);
+    }
     STAMP(12);
+    if (flush) {
+      if (st.out_n > expected) st.out_n = expected;
+      st.base = avail;  // the dependency empties its input after a flush
+      st.remaining = 0;
+    }
   }
   curSpeed = tailSpeed;
 }
@@ -958,6 +973,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
       Z.des_dur = des_dur;
     }
     __syncthreads();
+    STAMP(14);  // the frame-rate passes of this chunk
     // Events, in the order the shim issues them:
     //   nonlinear: one (setSpeed, write B) per tension frame           soniclib.c:354,369
     //              at flush, the remaining complete ring buffers at the last speed   soniclib.c:538-550
@@ -972,24 +988,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
     const pos_t ev_end = ev1 + (fin ? 1 : 0);
     (void)ev_end;
     if constexpr (FAST) {
-      if (nl != 0.0f) {
-        fast_events<NW>(P, X, st, scr, ev0, ev1, (pos_t)K, avail, B, curSpeed);
-      } else if (ev1 > ev0) {
-        avail = (pos_t)S.n_in;
-        fast_event<NW>(P, X, st, curSpeed, speed_is_unity(curSpeed), avail);
-      }
-      if (fin) {  // sonicIntFlushStream: pad 2*maxRequired zeros, process, truncate to the expected length
-        const pos_t remainingS = avail - st.base;
-        const pos_t expected = st.out_n + uni((int)(((float)remainingS / curSpeed + 0) / 1.0f + 0.5f));
-        X.limit = avail;  // everything from here on reads as the flush's zero padding
-        lds_sync<NW>();
-        X.wbase = -1;     // the window may hold samples past the new limit
-        avail += 2 * P.maxRequired;
-        fast_event<NW>(P, X, st, curSpeed, speed_is_unity(curSpeed), avail);
-        if (st.out_n > expected) st.out_n = expected;
-        st.base = avail;  // the dependency empties its input after a flush
-        st.remaining = 0;
-      }
+      fast_events<NW>(P, X, st, scr, ev0, ev1, (pos_t)K, avail, B, nl == 0.0f, (pos_t)S.n_in, fin, curSpeed);
     } else {
       for (pos_t ev = ev0; ev < ev_end; ev++) {
         pos_t expected = 0;
@@ -1068,8 +1067,7 @@ void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_str
                     (P.maxPeriod / P.skip - P.minPeriod / P.skip + 1) <= 64 && (8 * P.skip + 1) <= 64 &&
                     !getenv("SPX_WALK_GENERIC");
 #ifdef SPX_STAMPS
-  (void)nw;
-  SPX_LAUNCH_WALK(8);  // the diagnostic build measures the 8-wave kernel only
+  if (nw == 4) SPX_LAUNCH_WALK(4); else SPX_LAUNCH_WALK(8);  // the diagnostic build carries two kernels only
   return;
 #endif
   switch (nw) {

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {0: "event loop (between process calls)", 1: "pre-step (copy steps, loop ctl)", 2: "ensure_window",
          3: "phase B build signals", 4: "sync c", 5: "coarse accumulate", 6: "sync e", 7: "coarse select",
          8: "refine accumulate", 9: "sync h", 10: "refine select", 11: "decision", 12: "after OLA -> end of process",
-         13: "overlap-add"}
+         13: "overlap-add", 14: "frame-rate passes (prologue)"}
 
 
 def child(sel):
@@ -41,7 +41,7 @@ if len(sys.argv) > 1:
     sys.exit(0)
 
 rows = []
-for sel in range(14):
+for sel in range(15):
     env = dict(os.environ, SPX_SERIAL="1",
                SPEEDY_HIP_LIB=os.path.join(ROOT, "speedy_amd", "lib", "stamps", "libspeedy_hip_stamps_%d.so" % sel))
     out = subprocess.run([sys.executable, os.path.abspath(__file__), str(sel)], env=env, capture_output=True, text=True)
