@@ -143,6 +143,13 @@ struct WalkCtx {
   int wcap;
   unsigned short* dnH;     // biased decimated signal of the current step (and its shifted copy)
   unsigned short* dnHB;
+  // FAST kernels: the decimated signal of EVERY window position, built once per refill.  Plane r (r < skip) holds
+  // S[m*skip + r], S[i] = mean of window samples i .. i+skip-1, so the decimated signal of a step at window offset o
+  // is plane (o % skip) from element o / skip on, contiguous.  plB is the copy shifted by one element.
+  unsigned short* pl;
+  unsigned short* plB;
+  int plStride;            // elements per plane (even)
+  int skip, skipM;         // skipM = ceil(2^16 / skip): i / skip == (i * skipM) >> 16 for i < 8192
   unsigned* diffC;    // per-lag AMDF sums, coarse search
   unsigned* diffR;    // per-lag AMDF sums, refine search
 #ifdef SPX_STAMPS
@@ -218,6 +225,23 @@ __device__ __forceinline__ void ensure_window(WalkCtx& X, pos_t pos, int need) {
   }
   X.wbase = nb;
   lds_sync<NW>();
+  if (FAST) {
+    const int skip = X.skip;
+    const double inv = 1.0 / (double)skip;
+    for (int i = threadIdx.x; i + skip <= X.wcap; i += NT) {
+      int sum = 0;
+      for (int j = 0; j < skip; j++) sum += (int)X.monoH[i + j];
+      sum -= 32768 * skip;
+      // truncating sum / skip via the exact double-reciprocal form (see emit_overlap_add)
+      const int mag = sum < 0 ? -sum : sum;
+      const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
+      const unsigned short u = (unsigned short)((sum < 0 ? -qm : qm) + 32768);
+      const int m = (i * X.skipM) >> 16, r = i - m * skip;
+      X.pl[r * X.plStride + m] = u;
+      if (m > 0) X.plB[r * X.plStride + m - 1] = u;
+    }
+    lds_sync<NW>();
+  }
 }
 
 // Sum over pairs j in [j0, j1) of |s[2j] - s[2j+p]| + |s[2j+1] - s[2j+p+1]| on biased u16 data: ap is the
@@ -385,7 +409,7 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
   const bool direct = FAST ? false : (C == 1 && skip == 1);
   // ---- phase B: the decimated, biased search signal of this step (earlier readers are past a barrier) ----
   const int cnt = maxRequired / skip;
-  if (!direct) {
+  if (!FAST && !direct) {
     const int div = skip * C;
     const double inv = 1.0 / (double)div;
     for (int t = tid; t < cnt + 2; t += NT) {
@@ -407,7 +431,9 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
     }
   }
   STAMP(3);
-  lds_sync<NW>();  // decimated signal visible; last step's buffer clearing finished
+  // FAST: nothing was built, and the sum buffers this step adds into were cleared before the previous step's last
+  // barrier, so no barrier is needed here
+  if (!FAST) lds_sync<NW>();  // decimated signal visible; last step's buffer clearing finished
   STAMP(4);
 #if defined(SPX_EXPERIMENT) && SPX_EXPERIMENT == 1
   { st.prevPeriod = 100; st.prevMinDiff = 1; return 100 + (int)(pos & 15); }
@@ -417,6 +443,13 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
   const unsigned* M1 = reinterpret_cast<const unsigned*>(X.monoHB);
   const unsigned* D0 = reinterpret_cast<const unsigned*>(X.dnH);
   const unsigned* D1 = reinterpret_cast<const unsigned*>(X.dnHB);
+  int oD = 0;  // where the decimated signal of this step starts in D0 / D1
+  if (FAST) {
+    oD = (o * X.skipM) >> 16;
+    const int r = o - oD * skip;
+    D0 = reinterpret_cast<const unsigned*>(X.pl + r * X.plStride);
+    D1 = reinterpret_cast<const unsigned*>(X.plB + r * X.plStride);
+  }
   int period, minDiff, maxDiff;
   const int minC = direct ? P.minPeriod : P.minPeriod / skip;
   const int maxC = direct ? P.maxPeriod : P.maxPeriod / skip;
@@ -429,7 +462,7 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
     select_finish(S1, &period, &minDiff, &maxDiff);
     STAMP(7);
   } else {
-    search_split<NW, false, FAST>(D0, D1, 0, minC, maxC - minC + 1, X.diffC + 256 * tg, X.diffC + 256 * (1 - tg), S1, X, 5);
+    search_split<NW, false, FAST>(D0, D1, oD, minC, maxC - minC + 1, X.diffC + 256 * tg, X.diffC + 256 * (1 - tg), S1, X, 5);
     STAMP(7);
     period = S1.bestP * skip;
     int lo = period - (skip << 2), hi = period + (skip << 2);
@@ -705,7 +738,8 @@ __device__ __forceinline__ void fast_events(const SpxPlanDev& P, WalkCtx& X, Wal
 
 // LDS layout (bytes), shared by host and device
 struct WalkLds {
-  int off_sA, off_sB, off_mono, off_monoB, off_raw, off_dn, off_dnB, off_diffC, off_diffR, off_wait, total, wcap;
+  int off_sA, off_sB, off_mono, off_monoB, off_raw, off_dn, off_dnB, off_pl, off_plB, plStride, off_diffC, off_diffR,
+      off_wait, total, wcap;
 };
 static __host__ __device__ inline WalkLds walk_lds_layout(const SpxPlanDev& P, int maxC) {
   WalkLds L;
@@ -728,6 +762,11 @@ static __host__ __device__ inline WalkLds walk_lds_layout(const SpxPlanDev& P, i
   const int dnb = ((P.maxRequired / P.skip + 8) * 2 + 15) & ~15;
   L.off_dn = o; o += dnb;
   L.off_dnB = o; o += dnb;
+  // decimated planes of the FAST kernels (allocated always: the layout does not depend on the kernel variant)
+  L.plStride = ((wcap / (P.skip > 0 ? P.skip : 1) + 4) + 1) & ~1;
+  const int plb = (L.plStride * (P.skip > 0 ? P.skip : 1) * 2 + 15) & ~15;
+  L.off_pl = o; o += plb;
+  L.off_plB = o; o += plb;
   L.off_diffC = o; o += 2 * 256 * 4;  // double-buffered per-lag sums, first search
   L.off_diffR = o; o += 2 * 256 * 4;  // double-buffered per-lag sums, refine search
   L.total = o;
@@ -789,6 +828,11 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   X.wcap = LY.wcap;
   X.dnH = reinterpret_cast<unsigned short*>(lds + LY.off_dn);
   X.dnHB = reinterpret_cast<unsigned short*>(lds + LY.off_dnB);
+  X.pl = reinterpret_cast<unsigned short*>(lds + LY.off_pl);
+  X.plB = reinterpret_cast<unsigned short*>(lds + LY.off_plB);
+  X.plStride = LY.plStride;
+  X.skip = P.skip;
+  X.skipM = (65536 + P.skip - 1) / P.skip;
   X.diffC = reinterpret_cast<unsigned*>(lds + LY.off_diffC);
   X.diffR = reinterpret_cast<unsigned*>(lds + LY.off_diffR);
   for (int t = tid; t < 512; t += NT) { X.diffR[t] = 0; X.diffC[t] = 0; }
