@@ -150,6 +150,7 @@ struct WalkCtx {
   unsigned short* plB;
   int plStride;            // elements per plane (even)
   int skip, skipM;         // skipM = ceil(2^16 / skip): i / skip == (i * skipM) >> 16 for i < 8192
+  unsigned skipM32;        // ceil(2^32 / skip): x / skip == mulhi(x, skipM32) for x < 2^18
   unsigned* diffC;    // per-lag AMDF sums, coarse search
   unsigned* diffR;    // per-lag AMDF sums, refine search
 #ifdef SPX_STAMPS
@@ -226,19 +227,26 @@ __device__ __forceinline__ void ensure_window(WalkCtx& X, pos_t pos, int need) {
   X.wbase = nb;
   lds_sync<NW>();
   if (FAST) {
+    // One thread per decimated index m: it reads the 2*skip-1 window samples m*skip .. m*skip+2*skip-2 once and slides
+    // the sum over them, giving element m of every plane.  |sum| < 2^18 and skip <= 7, so the truncating division is
+    // exactly mulhi(|sum|, ceil(2^32 / skip)).
     const int skip = X.skip;
-    const double inv = 1.0 / (double)skip;
-    for (int i = threadIdx.x; i + skip <= X.wcap; i += NT) {
+    const unsigned M = X.skipM32;
+    const int bias = 32768 * skip;
+    for (int m = threadIdx.x; (m + 1) * skip <= X.wcap; m += NT) {
+      const unsigned short* w = X.monoH + m * skip;
       int sum = 0;
-      for (int j = 0; j < skip; j++) sum += (int)X.monoH[i + j];
-      sum -= 32768 * skip;
-      // truncating sum / skip via the exact double-reciprocal form (see emit_overlap_add)
-      const int mag = sum < 0 ? -sum : sum;
-      const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
-      const unsigned short u = (unsigned short)((sum < 0 ? -qm : qm) + 32768);
-      const int m = (i * X.skipM) >> 16, r = i - m * skip;
-      X.pl[r * X.plStride + m] = u;
-      if (m > 0) X.plB[r * X.plStride + m - 1] = u;
+      for (int j = 0; j < skip; j++) sum += (int)w[j];
+      for (int r = 0; r < skip; r++) {
+        if ((m + 1) * skip + r > X.wcap) break;  // the last element of the higher planes needs samples past the window
+        const int v = sum - bias;
+        const unsigned mag = (unsigned)(v < 0 ? -v : v);
+        const int qm = (int)__umulhi(mag, M);
+        const unsigned short u = (unsigned short)((v < 0 ? -qm : qm) + 32768);
+        X.pl[r * X.plStride + m] = u;
+        if (m > 0) X.plB[r * X.plStride + m - 1] = u;
+        sum += (int)w[skip + r] - (int)w[r];
+      }
     }
     lds_sync<NW>();
   }
@@ -833,6 +841,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   X.plStride = LY.plStride;
   X.skip = P.skip;
   X.skipM = (65536 + P.skip - 1) / P.skip;
+  X.skipM32 = (unsigned)((0x100000000ull + (unsigned)P.skip - 1) / (unsigned)P.skip);
   X.diffC = reinterpret_cast<unsigned*>(lds + LY.off_diffC);
   X.diffR = reinterpret_cast<unsigned*>(lds + LY.off_diffR);
   for (int t = tid; t < 512; t += NT) { X.diffR[t] = 0; X.diffC[t] = 0; }
