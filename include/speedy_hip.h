@@ -111,6 +111,8 @@ void spx_set_pipeline_chunks(int chunks);
  * tiles are ready.  Results are identical with it on or off. */
 void spx_set_concurrent(int on);
 int spx_timing_collect(double* sum_ms_analyze, double* sum_ms_walk, int* n_calls);
+/* Sum over the same calls of the frame-rate (tension) kernel's time, as of the last spx_timing_collect. */
+double spx_timing_last_tension_ms(void);
 
 /* ---- plain device-memory helpers (so that C/C++ hosts need no HIP headers) ---- */
 void* spx_device_alloc(size_t bytes);

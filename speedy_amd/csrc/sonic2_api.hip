@@ -261,8 +261,9 @@ static int launch_job(sonicStream s, bool flush) {
     const int tiles = (int)((T - fa + TF - 1) / TF);
     spx_launch_analysis(P, s->dJob, 1, tiles, s->dIn.p, s->dRec.p, td, nullptr, nullptr, s->hs);
   }
-  spx_launch_walk(P, s->dJob, 1, s->channels, s->dIn.p, s->dOut.p, s->dNOut, s->dState, s->dRec.p, s->dScr.p, td, nullptr,
-                  s->speedupOnly, s->hs);
+  if (nonlinear) spx_launch_tension(P, s->dJob, 1, s->dState, s->dRec.p, s->dScr.p, td, nullptr, nullptr, s->hs);
+  spx_launch_walk(P, s->dJob, 1, s->channels, s->dIn.p, s->dOut.p, s->dNOut, s->dState, s->dScr.p, nullptr, s->speedupOnly,
+                  s->hs);
   if (hipGetLastError() != hipSuccess) { g_api_err = "kernel launch failed"; s->failed = true; return 0; }
   s->started = true;
   s->dirty = true;

@@ -31,6 +31,8 @@ struct spx_plan {
   // time-chunk pipelining of one batch call: the analysis of chunk c+1 runs on `side` while the walk of chunk c
   // runs on the caller's stream
   hipStream_t side = nullptr;
+  hipStream_t side2 = nullptr;   // concurrent mode: the tension kernel's stream
+  hipEvent_t ev_tension = nullptr;
   hipEvent_t ev_start = nullptr;
   hipEvent_t ev_chunk[SPX_MAX_CHUNKS] = {};
 };
@@ -145,6 +147,8 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
 void spx_plan_destroy(spx_plan_t plan) {
   if (!plan) return;
   if (plan->side) { (void)hipStreamSynchronize(plan->side); (void)hipStreamDestroy(plan->side); }
+  if (plan->side2) { (void)hipStreamSynchronize(plan->side2); (void)hipStreamDestroy(plan->side2); }
+  if (plan->ev_tension) (void)hipEventDestroy(plan->ev_tension);
   if (plan->ev_start) (void)hipEventDestroy(plan->ev_start);
   for (auto& e : plan->ev_chunk) if (e) (void)hipEventDestroy(e);
   if (plan->tables) (void)hipFree(plan->tables);
@@ -189,7 +193,7 @@ int64_t spx_internal_frames_for(const SpxPlanDev& d, int64_t n_in) { return fram
 extern "C" {
 
 struct Layout {
-  size_t off_streams, off_states, off_rec, off_scratch, off_order, off_flags, total;
+  size_t off_streams, off_states, off_rec, off_scratch, off_order, off_flags, off_ready, total;
   int64_t max_tiles;
   int64_t total_frames;
 };
@@ -207,6 +211,7 @@ static Layout layout_for(const SpxPlanDev& d, const spx_stream_job* jobs, int n)
   L.max_tiles = tf / TFr + n + 1;  // every stream may end with a partial tile
   L.off_order = o;   o += ((sizeof(int) * (size_t)L.max_tiles + 255) & ~(size_t)255);
   L.off_flags = o;   o += ((sizeof(int) * (size_t)L.max_tiles + 255) & ~(size_t)255);
+  L.off_ready = o;   o += ((sizeof(int) * (size_t)n + 255) & ~(size_t)255);
   L.total = o;
   return L;
 }
@@ -302,11 +307,14 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   const bool concurrent = g_concurrent && !env_serial && do_a && do_w && nch == 1 && tiles[0] > 0;
   int* d_order = reinterpret_cast<int*>(w + L.off_order);
   int* d_flags = reinterpret_cast<int*>(w + L.off_flags);
+  int* d_ready = reinterpret_cast<int*>(w + L.off_ready);
   hipStream_t sa = st;  // stream the analysis launches go to
   if (nch > 1 || concurrent) {
     if (!plan->side) {
       HIPCHK(hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking));
+      HIPCHK(hipStreamCreateWithFlags(&plan->side2, hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&plan->ev_start, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&plan->ev_tension, hipEventDisableTiming));
       for (auto& e : plan->ev_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     sa = plan->side;
@@ -326,12 +334,14 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
         if (t < cnt[i]) order.push_back(sv[i].first_tile + t);
     HIPCHK(hipMemcpyAsync(d_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(d_flags, 0, sizeof(int) * (size_t)tiles[0], st));
+    HIPCHK(hipMemsetAsync(d_ready, 0, sizeof(int) * (size_t)n, st));
   }
   if (sa != st) {
     // the side stream starts after everything already queued on the caller's stream (job tables, cleared flags, and
     // the previous call's walk, which still reads the frame records this call's analysis will overwrite)
     HIPCHK(hipEventRecord(plan->ev_start, st));
     HIPCHK(hipStreamWaitEvent(sa, plan->ev_start, 0));
+    if (concurrent) HIPCHK(hipStreamWaitEvent(plan->side2, plan->ev_start, 0));
   }
   for (int c = 0; c < nch; c++) {
     SpxStreamDev* dj = dstreams + (size_t)c * n;
@@ -345,14 +355,25 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     if (sa != st) HIPCHK(hipEventRecord(plan->ev_chunk[c], sa));
     if (sa != st && !concurrent) HIPCHK(hipStreamWaitEvent(st, plan->ev_chunk[c], 0));
     if (do_w) {
+      // frame-rate stage: after the analysis on the same stream, or -- concurrent -- beside it on its own stream,
+      // consuming tile flags and publishing the count of ready speeds
+      hipStream_t stn = concurrent ? plan->side2 : st;
+      hipEvent_t t0 = nullptr, t1 = nullptr;
+      if (timed) { t0 = take_event(); t1 = take_event(); (void)hipEventRecord(t0, stn); }
+      spx_launch_tension(d, dj, n, states, rec, scratch, td, concurrent ? d_flags : nullptr,
+                         concurrent ? d_ready : nullptr, stn);
+      if (timed) { (void)hipEventRecord(t1, stn); g_ev_pending.push_back({t0, t1, 2}); }
+      if (concurrent) HIPCHK(hipEventRecord(plan->ev_tension, stn));
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, st); }
-      spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, rec, scratch, td, concurrent ? d_flags : nullptr,
-                      speedup_only, st);
+      spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, concurrent ? d_ready : nullptr, speedup_only, st);
       if (timed) { (void)hipEventRecord(e1, st); g_ev_pending.push_back({e0, e1, 1}); }
     }
-    // the caller's stream is "done" only when the analysis launch has retired too
-    if (concurrent) HIPCHK(hipStreamWaitEvent(st, plan->ev_chunk[c], 0));
+    // the caller's stream is "done" only when the side launches have retired too
+    if (concurrent) {
+      HIPCHK(hipStreamWaitEvent(st, plan->ev_chunk[c], 0));
+      HIPCHK(hipStreamWaitEvent(st, plan->ev_tension, 0));
+    }
   }
   if (timed) g_calls_pending++;
   HIPCHK(hipGetLastError());
@@ -375,17 +396,20 @@ int spx_batch_walk(spx_plan_t plan, const spx_stream_job* jobs, int n, const int
 void spx_set_timing(int enabled) { g_timing = enabled != 0; }
 void spx_set_concurrent(int on) { g_concurrent = on != 0; }
 void spx_set_pipeline_chunks(int chunks) { g_chunks = chunks < 1 ? 1 : (chunks > SPX_MAX_CHUNKS ? SPX_MAX_CHUNKS : chunks); }
+static double g_last_tension_ms = 0.0;
+double spx_timing_last_tension_ms(void) { return g_last_tension_ms; }
 int spx_timing_collect(double* sum_ms_analyze, double* sum_ms_walk, int* n_calls) {
-  double a = 0, w = 0;
+  double a = 0, w = 0, t = 0;
   for (auto& ev : g_ev_pending) {
     HIPCHK(hipEventSynchronize(ev.b));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ev.a, ev.b));
-    if (ev.kind == 0) a += ms; else w += ms;
+    if (ev.kind == 0) a += ms; else if (ev.kind == 1) w += ms; else t += ms;
     g_ev_free.push_back(ev.a);
     g_ev_free.push_back(ev.b);
   }
   g_ev_pending.clear();
+  g_last_tension_ms = t;
   if (sum_ms_analyze) *sum_ms_analyze = a;
   if (sum_ms_walk) *sum_ms_walk = w;
   if (n_calls) *n_calls = g_calls_pending;

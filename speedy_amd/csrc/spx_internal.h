@@ -86,12 +86,16 @@ struct SpxTapsDev {
 void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int n_tiles,
                          const int16_t* in, SpxFrameRec* rec, SpxTapsDev taps, const int* tile_order, int* tile_flags,
                          hipStream_t st);
-void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int max_channels,
-                     const int16_t* in,
-                     int16_t* out, int64_t* n_out, SpxStreamState* states, const SpxFrameRec* rec, float* scratch,
-                     SpxTapsDev taps, const int* tile_flags, bool speedup_only, hipStream_t st);
+// Frame-rate stage: energy / hysteresis / difference filters -> tension -> speed per tension frame (scratch[4k+3]) and
+// the tension, speed and feature taps.  tile_flags / speed_ready: the concurrent-mode hand-off (nullptr = sequential).
+void spx_launch_tension(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, SpxStreamState* states,
+                        const SpxFrameRec* rec, float* scratch, SpxTapsDev taps, const int* tile_flags, int* speed_ready,
+                        hipStream_t st);
 // speedup_only: every job has speed > 1 and 0 <= nonlinear <= 1 (and a streamed job has never had another setting),
 // so the time-scale stage only ever sees speeds >= 1: selects the walk kernel specialised for that.
+void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int max_channels,
+                     const int16_t* in, int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
+                     const int* speed_ready, bool speedup_only, hipStream_t st);
 size_t spx_analysis_lds_bytes(const SpxPlanDev& P);
 int spx_analysis_tile_frames();
 

@@ -1,0 +1,251 @@
+// Tension kernel for gfx950: the frame-rate stage between the analysis kernel and the walk kernel.
+//
+// One workgroup per stream.  O(1) work per 10 ms frame; the order-sensitive recurrences run on one lane in the
+// reference's order, everything else one lane per frame:
+//   a6  energy low-pass, local energy, sqrt compression   speedy.c:517-521,73-76
+//   a7  tapered-max temporal hysteresis                   speedy.c:590-610
+//   a8  low-energy gate, emphasis weighting, difference low-pass, relative difference, clamp
+//                                                         speedy.c:682-700,720-728
+//   a7  tension                                           speedy.c:752-766
+//   a9  speed from tension (+ duration feedback), blend   speedy.c:768-788, soniclib.c:339-345
+// Output: scratch[4*k + 3] = the speed the shim sets before handing ring buffer k to the time-scale stage
+// (soniclib.c:354), plus the tension / speed / features taps.
+//
+// It is its own kernel so that, in concurrent mode, it runs on a third HIP stream beside the other two: it takes
+// the frames in growing chunks as the analysis tiles that cover them publish their flags (agent-scope release there,
+// relaxed poll + agent-scope acquire here: cdna_hip_programming.md Guideline 16), and publishes in turn the number of
+// tension frames whose speeds are final (`speed_ready`), which the walk kernel polls.  The walk workgroups -- the
+// latency-critical chain of the whole job -- then never execute a frame-rate pass themselves.
+#include "spx_internal.h"
+
+#define SPX_CH 1024  // frames per pass chunk held in LDS
+#define SPX_TCH 64   // frames in the first chunk when the analysis kernel runs concurrently (multiple of the tile)
+#define SPX_TENSION_THREADS 256
+
+__global__ void __launch_bounds__(SPX_TENSION_THREADS)
+spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxStreamState* __restrict__ states,
+                   const SpxFrameRec* __restrict__ rec_base, float* __restrict__ scratch_base, SpxTapsDev taps,
+                   const int* tile_flags, int* speed_ready) {
+  constexpr int NT = SPX_TENSION_THREADS;
+  __shared__ float sA[SPX_CH];
+  __shared__ float sB[SPX_CH];
+  __shared__ int sWait;
+  const int tid = threadIdx.x;
+  const SpxStreamDev S = streams[blockIdx.x];
+  const int Ttot = S.n_frames, F = P.F, Pp = P.Pp;
+  const float Rg = S.speed, nl = S.nonlinear, fb = S.feedback;
+  if (nl == 0.0f) return;  // a linear stream has no frames (uniform per workgroup)
+
+  // the part of the stream state this stage owns
+  struct { float lp, lpf, cur_dur, des_dur; } Z;
+  if (S.flags & SPX_F_INIT) {
+    Z.lp = 2.14204f;    // speedy.c:263,288
+    Z.lpf = 123.837f;   // speedy.c:264,291
+    Z.cur_dur = 0.0f; Z.des_dur = 0.0f;
+  } else {
+    const SpxStreamState& in = states[blockIdx.x];
+    Z.lp = in.lp; Z.lpf = in.lpf; Z.cur_dur = in.cur_dur; Z.des_dur = in.des_dur;
+  }
+  const SpxFrameRec* rec = rec_base + S.frame_off;
+  float* scr = scratch_base + (size_t)S.frame_off * 4;  // per frame: comp, hyst, ewld->tension, speed
+  const float lowthr = (float)(0.04 * (double)1.41421f);          // speedy.c:682
+  float* tfeat = taps.features ? taps.features + (size_t)S.frame_off * SPX_FEATURE_COUNT : nullptr;
+
+  // Sequential launches (tile_flags == nullptr): one chunk with every new frame.  Concurrent: chunks of 64, 128,
+  // 192, ... frames, each started once its analysis tiles are published (the analysis is soon far ahead).
+  int fa_c = S.frame_begin;
+  int wch = SPX_TCH;
+  bool ok_all = true;
+  for (;;) {
+    int T_c = Ttot;
+    if (tile_flags != nullptr && Ttot - fa_c > wch) T_c = fa_c + wch;
+    wch += SPX_TCH;
+    const bool last = T_c >= Ttot;
+    if (tile_flags != nullptr && T_c > fa_c) {
+      const int TF = P.tile_frames;
+      const int i0 = (fa_c - S.frame_begin) / TF, i1 = (T_c - S.frame_begin + TF - 1) / TF;
+      if (tid == 0) {
+        int ok = 1;
+        for (int i = i0; i < i1 && ok; i++) {
+          unsigned spins = 0;
+          while (__hip_atomic_load(&tile_flags[S.first_tile + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > (1u << 22)) { ok = 0; break; }  // ~seconds: never hang the GPU on a lost producer
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sWait = ok;
+      }
+      __syncthreads();
+      if (sWait == 0) { ok_all = false; break; }
+    }
+    const int fa = fa_c, T = T_c;
+    const int K0 = (fa >= F) ? fa - F + 1 : 0;        // tension frames already done
+    const int K = (T >= F) ? T - F + 1 : 0;           // tension frames available (soniclib.c:317)
+    if (T > fa) {
+      // ---- pass 1: energy low-pass (sequential) -> local -> compressed ----
+      float lp = Z.lp;
+      for (int c0 = fa; c0 < T; c0 += SPX_CH) {
+        const int n = min(SPX_CH, T - c0);
+        for (int i = tid; i < n; i += NT) sA[i] = rec[c0 + i].energy;
+        __syncthreads();
+        if (tid == 0) {
+          for (int i = 0; i < n; i++) {
+            lp = P.one_minus_alpha * sA[i] + P.alpha * lp;  // speedy.c:74
+            sB[i] = lp;
+          }
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) {
+          const float e = sA[i], l = sB[i];
+          const float local = e / l;                                               // speedy.c:519
+          const float comp = (float)__builtin_sqrt(local > 2 ? 2.0 : (double)local);  // speedy.c:520
+          const int j = c0 + i;
+          scr[4 * j + 0] = comp;
+          const int k = j - F + 1;  // the tension frame whose callback sees these AddData-time values
+          if (tfeat && k >= 0) {
+            float* f = tfeat + (size_t)k * SPX_FEATURE_COUNT;
+            f[1] = l; f[2] = local; f[3] = comp; f[12] = (float)(j + 1);
+          }
+        }
+        if (n > 0) lp = sB[n - 1];  // every lane keeps the carried state
+        __syncthreads();
+      }
+      Z.lp = lp;
+      // ---- pass 2: hysteresis and emphasis-weighted difference, one lane per tension frame ----
+      for (int k = K0 + tid; k < K; k += NT) {
+        float future_max = 0.0f, past_max = 0.0f;
+        for (int i = 0; i <= F; i++) {
+          const int tau = k + i;  // hysteresis slot `tau` holds frame tau-1; slots <= 0 are the zero init
+          float v = (tau >= 1) ? scr[4 * (tau - 1) + 0] : 0.0f;
+          v *= P.taperF[i];
+          if (v > future_max) future_max = v;
+        }
+        for (int i = 0; i <= Pp; i++) {
+          const int tau = k - i;
+          float v = (tau >= 1) ? scr[4 * (tau - 1) + 0] : 0.0f;
+          v *= P.taperP[i];
+          if (v > past_max) past_max = v;
+        }
+        const float hyst = (float)((double)(past_max + future_max) / 2.0);  // speedy.c:609
+        const float e_cur = (k == 0) ? 0.0f : rec[k - 1].energy;           // history slot k holds frame k-1
+        const bool low = e_cur <= lowthr;
+        const float lsd = (k == 0 || low) ? 0.0f : rec[k - 1].lsd;
+        const float ewld = low ? 0.0f : lsd * hyst;                          // speedy.c:720
+        scr[4 * k + 1] = hyst;
+        scr[4 * k + 2] = ewld;
+        if (tfeat) {
+          float* f = tfeat + (size_t)k * SPX_FEATURE_COUNT;
+          f[0] = e_cur; f[4] = hyst; f[5] = low ? 1.0f : 0.0f; f[6] = lsd; f[7] = ewld;
+          f[13] = (float)k; f[14] = lowthr;
+        }
+      }
+      __syncthreads();
+      // ---- pass 3: difference low-pass (sequential) -> relative difference -> tension -> raw speed ----
+      float lpf = Z.lpf;
+      for (int c0 = K0; c0 < K; c0 += SPX_CH) {
+        const int n = min(SPX_CH, K - c0);
+        for (int i = tid; i < n; i += NT) sA[i] = scr[4 * (c0 + i) + 2];
+        __syncthreads();
+        if (tid == 0) {
+          for (int i = 0; i < n; i++) {
+            lpf = P.one_minus_alpha * sA[i] + P.alpha * lpf;
+            sB[i] = lpf;
+          }
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) {
+          const int k = c0 + i;
+          const float ewld = sA[i], l = sB[i];
+          const float hyst = scr[4 * k + 1];
+          const float e_cur = (k == 0) ? 0.0f : rec[k - 1].energy;
+          const bool low = e_cur <= lowthr;
+          float rel = 0.0f, sc = 0.0f;
+          if (!low) {
+            rel = (float)((double)ewld / ((double)l + 0.01 * (double)123.979f));       // speedy.c:725-726
+            sc = (float)fmin((double)rel, (double)(4 * 0.971975f));                    // speedy.c:727-728
+          }
+          const float a = 0.5f, b = 0.25f, M_E_ = 0.7f, M_S = 1.0f;
+          const float tension = a * (hyst - M_E_) + b * (sc - M_S);                    // speedy.c:761
+          float v;
+          if ((double)Rg > 1.0) {
+            v = (float)fmax(1.0, (double)(Rg + (1 - Rg) * tension));                   // speedy.c:774
+          } else {
+            v = (float)fmax(0.01, fmin(1.0, (double)(Rg - (1 - Rg) * tension)));       // speedy.c:776
+          }
+          scr[4 * k + 2] = tension;
+          scr[4 * k + 3] = v;
+          if (tfeat) {
+            float* f = tfeat + (size_t)k * SPX_FEATURE_COUNT;
+            f[8] = l; f[9] = rel; f[10] = sc; f[11] = tension;
+          }
+          if (taps.tension) taps.tension[S.frame_off + k] = tension;
+        }
+        if (n > 0) lpf = sB[n - 1];
+        __syncthreads();
+      }
+      Z.lpf = lpf;
+      // ---- pass 4: duration feedback (sequential) and blend with the global speed ----
+      float cur_dur = Z.cur_dur, des_dur = Z.des_dur;
+      const float fd = (float)(1.0 / 100.0);  // speedy.c:783
+      for (int c0 = K0; c0 < K; c0 += SPX_CH) {
+        const int n = min(SPX_CH, K - c0);
+        for (int i = tid; i < n; i += NT) sA[i] = scr[4 * (c0 + i) + 3];
+        __syncthreads();
+        if (tid == 0) {
+          for (int i = 0; i < n; i++) {
+            float req = sA[i];
+            if (fb > 0) {
+              const float excess = cur_dur - des_dur;
+              req = (float)((double)req + fmax(0.01, (double)(fb * excess)));          // speedy.c:780-781
+            }
+            cur_dur += fd / req;
+            des_dur += fd / Rg;
+            sB[i] = req * nl + Rg * (1 - nl);                                          // soniclib.c:344-345
+          }
+          sA[0] = cur_dur;  // broadcast the carried sums (sA is re-read only by the next chunk's load)
+          sA[1] = des_dur;
+        }
+        __syncthreads();
+        cur_dur = sA[0];
+        des_dur = sA[1];
+        for (int i = tid; i < n; i += NT) {
+          scr[4 * (c0 + i) + 3] = sB[i];
+          if (taps.speed) taps.speed[S.frame_off + c0 + i] = sB[i];
+        }
+        __syncthreads();
+      }
+      Z.cur_dur = cur_dur;
+      Z.des_dur = des_dur;
+    }
+    if (speed_ready != nullptr) {
+      // publish: every store of this chunk (speeds, taps) is complete and visible device-wide before the count moves
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&speed_ready[blockIdx.x], K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      __syncthreads();
+    }
+    fa_c = T_c;
+    if (last) break;
+  }
+  if (!ok_all && speed_ready != nullptr && tid == 0)  // lost producer: tell the consumer to give up as well
+    __hip_atomic_store(&speed_ready[blockIdx.x], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {
+    SpxStreamState& o = states[blockIdx.x];
+    o.lp = Z.lp; o.lpf = Z.lpf; o.cur_dur = Z.cur_dur; o.des_dur = Z.des_dur;
+  }
+}
+
+void spx_launch_tension(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, SpxStreamState* states,
+                        const SpxFrameRec* rec, float* scratch, SpxTapsDev taps, const int* tile_flags, int* speed_ready,
+                        hipStream_t st) {
+  if (n_streams <= 0) return;
+  hipLaunchKernelGGL(spx_tension_kernel, dim3(n_streams), dim3(SPX_TENSION_THREADS), 0, st, P, streams, states, rec,
+                     scratch, taps, tile_flags, speed_ready);
+}

@@ -746,7 +746,7 @@ __device__ __forceinline__ void fast_events(const SpxPlanDev& P, WalkCtx& X, Wal
 
 // LDS layout (bytes), shared by host and device
 struct WalkLds {
-  int off_sA, off_sB, off_mono, off_monoB, off_raw, off_dn, off_dnB, off_pl, off_plB, plStride, off_diffC, off_diffR,
+  int off_sA, off_mono, off_monoB, off_raw, off_dn, off_dnB, off_pl, off_plB, plStride, off_diffC, off_diffR,
       off_wait, total, wcap;
 };
 static __host__ __device__ inline WalkLds walk_lds_layout(const SpxPlanDev& P, int maxC) {
@@ -759,7 +759,6 @@ static __host__ __device__ inline WalkLds walk_lds_layout(const SpxPlanDev& P, i
   L.wcap = wcap;
   int o = 0;
   L.off_sA = o; o += SPX_CH * 4;
-  L.off_sB = o; o += SPX_CH * 4;
   L.off_wait = o; o += 16;
   L.off_mono = o;
   const int mb = ((wcap + 8) * 2 + 15) & ~15;
@@ -785,42 +784,36 @@ template <int NW, bool FAST>
 __global__ void __launch_bounds__(64 * NW)
 spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const int16_t* __restrict__ in_base,
                 int16_t* __restrict__ out_base, int64_t* __restrict__ n_out, SpxStreamState* __restrict__ states,
-                const SpxFrameRec* rec_base, float* __restrict__ scratch_base, SpxTapsDev taps, int maxC,
-                const int* tile_flags) {
+                const float* scratch_base, int maxC, const int* speed_ready) {
   constexpr int NT = 64 * NW;
   // the walk is the latency-critical chain: where the analysis kernel shares a SIMD, these waves issue first
   __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
   const SpxStreamDev S = streams[blockIdx.x];
-  const int Ttot = S.n_frames, F = P.F, Pp = P.Pp, B = P.B;
-  const float Rg = S.speed, nl = S.nonlinear, fb = S.feedback;
+  const int Ttot = S.n_frames, F = P.F, B = P.B;
+  const float Rg = S.speed, nl = S.nonlinear;
 
   const WalkLds LY = walk_lds_layout(P, maxC);
   float* sA = reinterpret_cast<float*>(lds + LY.off_sA);  // [SPX_CH]
-  float* sB = reinterpret_cast<float*>(lds + LY.off_sB);  // [SPX_CH]
 
-  // ---- state carried between jobs of one stream ----
+  // ---- the part of the stream state this stage owns (the tension kernel owns the filter states) ----
   SpxStreamState Z;
   if (S.flags & SPX_F_INIT) {
     Z.w.base = 0; Z.w.out_n = 0; Z.w.avail = 0; Z.w.remaining = 0; Z.w.prevPeriod = 0; Z.w.prevMinDiff = 0;
     Z.w.overflow = 0; Z.w.prevPeriod_toggle = 0; Z.w.pad_ = 0;
-    Z.lp = 2.14204f;    // speedy.c:263,288
-    Z.lpf = 123.837f;   // speedy.c:264,291
-    Z.cur_dur = 0.0f; Z.des_dur = 0.0f;
     Z.curSpeed = Rg;    // sonicSetSpeed -> sonicIntSetSpeed, soniclib.c:182
     Z.handed = 0;
   } else {
-    Z = states[blockIdx.x];
+    Z.w = states[blockIdx.x].w;
+    Z.curSpeed = states[blockIdx.x].curSpeed;
+    Z.handed = states[blockIdx.x].handed;
     // sonicSetSpeed between writes reaches the TSM stage at once (soniclib.c:182); in nonlinear mode the
     // next tension frame overrides it (soniclib.c:354)
     if (nl == 0.0f) Z.curSpeed = Rg;
   }
 
-  const SpxFrameRec* rec = rec_base + S.frame_off;
-  float* scr = scratch_base + (size_t)S.frame_off * 4;  // per frame: comp, hyst, ewld->tension, speed
-  const float lowthr = (float)(0.04 * (double)1.41421f);          // speedy.c:682
-  float* tfeat = taps.features ? taps.features + (size_t)S.frame_off * SPX_FEATURE_COUNT : nullptr;
+  const float* scr = scratch_base + (size_t)S.frame_off * 4;  // per frame: ..., speed (written by the tension kernel)
   int* sWait = reinterpret_cast<int*>(lds + LY.off_wait);
   // ---------------------------------- TSM stage context ----------------------------------
   WalkCtx X;
@@ -855,178 +848,34 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   pos_t avail = st.avail;
   pos_t handed = (nl != 0.0f) ? Z.handed : 0;
   const bool do_flush = (S.flags & SPX_F_FLUSH) != 0;
-  // The frames are taken in chunks.  Sequential launches (tile_flags == nullptr) use one chunk.  When the analysis
-  // kernel runs CONCURRENTLY on another HIP stream, a chunk is SPX_WCH frames and starts only once the analysis
-  // tiles that cover it have published their records (agent-scope release there, one relaxed poll + agent-scope
-  // acquire here: cdna_hip_programming.md Guideline 16).  The walk consumes 10 s of audio in milliseconds while the
-  // analysis delivers it in about one, so after the first chunk it never waits.
-  int fa_c = S.frame_begin;
-  int wch = SPX_WCH;  // grows: the analysis is soon far ahead, and every chunk costs a round of prologue passes
+  // The speeds come from the tension kernel.  Sequential launches (speed_ready == nullptr): all of them are there.
+  // Concurrent launches: the tension kernel runs beside this one and publishes the number of tension frames whose
+  // speeds are final (agent-scope release there; one relaxed poll + agent-scope acquire here, Guideline 16); the walk
+  // takes whatever is ready, and only waits when it has caught up -- after the first frames it never does.
+  const int K_total = (nl != 0.0f && Ttot >= F) ? Ttot - F + 1 : 0;   // soniclib.c:317
   for (;;) {
-    int T_c = Ttot;
-    if (tile_flags != nullptr && nl != 0.0f && Ttot - fa_c > wch) T_c = fa_c + wch;
-    wch += SPX_WCH;  // 64, 128, 192, ...: each chunk needs its tiles ready when it starts, so grow gently
-    const bool last = T_c >= Ttot;
-    if (tile_flags != nullptr && nl != 0.0f && T_c > fa_c) {
-      const int TF = P.tile_frames;
-      const int i0 = (fa_c - S.frame_begin) / TF, i1 = (T_c - S.frame_begin + TF - 1) / TF;
+    int K = K_total;
+    if (speed_ready != nullptr && K_total > 0) {
       if (tid == 0) {
-        int ok = 1;
-        for (int i = i0; i < i1 && ok; i++) {
-          unsigned spins = 0;
-          while (__hip_atomic_load(&tile_flags[S.first_tile + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-            __builtin_amdgcn_s_sleep(32);
-            if (++spins > (1u << 22)) { ok = 0; break; }  // ~seconds: never hang the GPU on a lost producer
-          }
+        int got;
+        unsigned spins = 0;
+        for (;;) {
+          got = __hip_atomic_load(&speed_ready[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (got < 0 || got > (int)handed || got >= K_total) break;
+          __builtin_amdgcn_s_sleep(32);
+          if (++spins > (1u << 22)) { got = -1; break; }  // ~seconds: never hang the GPU on a lost producer
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        *sWait = ok;
+        *sWait = got;
       }
       __syncthreads();
-      if (*sWait == 0) { st.overflow = 1; break; }
+      K = uni(*sWait);
+      __syncthreads();  // sWait may be rewritten by the next round
+      if (K < 0) { st.overflow = 1; break; }
+      if (K > K_total) K = K_total;
     }
-    const int fa = fa_c, T = T_c;
-    const int K0 = (nl != 0.0f && fa >= F) ? fa - F + 1 : 0;        // tension frames already done
-    const int K = (nl != 0.0f && T >= F) ? T - F + 1 : 0;           // tension frames available (soniclib.c:317)
-    if (nl != 0.0f && T > fa) {
-      // ---- pass 1: energy low-pass (sequential) -> local -> compressed ----
-      float lp = Z.lp;
-      for (int c0 = fa; c0 < T; c0 += SPX_CH) {
-        const int n = min(SPX_CH, T - c0);
-        for (int i = tid; i < n; i += NT) sA[i] = rec[c0 + i].energy;
-        __syncthreads();
-        if (tid == 0) {
-          for (int i = 0; i < n; i++) {
-            lp = P.one_minus_alpha * sA[i] + P.alpha * lp;  // speedy.c:74
-            sB[i] = lp;
-          }
-        }
-        __syncthreads();
-        for (int i = tid; i < n; i += NT) {
-          const float e = sA[i], l = sB[i];
-          const float local = e / l;                                               // speedy.c:519
-          const float comp = (float)__builtin_sqrt(local > 2 ? 2.0 : (double)local);  // speedy.c:520
-          const int j = c0 + i;
-          scr[4 * j + 0] = comp;
-          const int k = j - F + 1;  // the tension frame whose callback sees these AddData-time values
-          if (tfeat && k >= 0) {
-            float* f = tfeat + (size_t)k * SPX_FEATURE_COUNT;
-            f[1] = l; f[2] = local; f[3] = comp; f[12] = (float)(j + 1);
-          }
-        }
-        if (n > 0) lp = sB[n - 1];  // every lane keeps the carried state
-        __syncthreads();
-      }
-      Z.lp = lp;
-      // ---- pass 2: hysteresis and emphasis-weighted difference, one lane per tension frame ----
-      for (int k = K0 + tid; k < K; k += NT) {
-        float future_max = 0.0f, past_max = 0.0f;
-        for (int i = 0; i <= F; i++) {
-          const int tau = k + i;  // hysteresis slot `tau` holds frame tau-1; slots <= 0 are the zero init
-          float v = (tau >= 1) ? scr[4 * (tau - 1) + 0] : 0.0f;
-          v *= P.taperF[i];
-          if (v > future_max) future_max = v;
-        }
-        for (int i = 0; i <= Pp; i++) {
-          const int tau = k - i;
-          float v = (tau >= 1) ? scr[4 * (tau - 1) + 0] : 0.0f;
-          v *= P.taperP[i];
-          if (v > past_max) past_max = v;
-        }
-        const float hyst = (float)((double)(past_max + future_max) / 2.0);  // speedy.c:609
-        const float e_cur = (k == 0) ? 0.0f : rec[k - 1].energy;           // history slot k holds frame k-1
-        const bool low = e_cur <= lowthr;
-        const float lsd = (k == 0 || low) ? 0.0f : rec[k - 1].lsd;
-        const float ewld = low ? 0.0f : lsd * hyst;                          // speedy.c:720
-        scr[4 * k + 1] = hyst;
-        scr[4 * k + 2] = ewld;
-        if (tfeat) {
-          float* f = tfeat + (size_t)k * SPX_FEATURE_COUNT;
-          f[0] = e_cur; f[4] = hyst; f[5] = low ? 1.0f : 0.0f; f[6] = lsd; f[7] = ewld;
-          f[13] = (float)k; f[14] = lowthr;
-        }
-      }
-      __syncthreads();
-      // ---- pass 3: difference low-pass (sequential) -> relative difference -> tension -> raw speed ----
-      float lpf = Z.lpf;
-      for (int c0 = K0; c0 < K; c0 += SPX_CH) {
-        const int n = min(SPX_CH, K - c0);
-        for (int i = tid; i < n; i += NT) sA[i] = scr[4 * (c0 + i) + 2];
-        __syncthreads();
-        if (tid == 0) {
-          for (int i = 0; i < n; i++) {
-            lpf = P.one_minus_alpha * sA[i] + P.alpha * lpf;
-            sB[i] = lpf;
-          }
-        }
-        __syncthreads();
-        for (int i = tid; i < n; i += NT) {
-          const int k = c0 + i;
-          const float ewld = sA[i], l = sB[i];
-          const float hyst = scr[4 * k + 1];
-          const float e_cur = (k == 0) ? 0.0f : rec[k - 1].energy;
-          const bool low = e_cur <= lowthr;
-          float rel = 0.0f, sc = 0.0f;
-          if (!low) {
-            rel = (float)((double)ewld / ((double)l + 0.01 * (double)123.979f));       // speedy.c:725-726
-            sc = (float)fmin((double)rel, (double)(4 * 0.971975f));                    // speedy.c:727-728
-          }
-          const float a = 0.5f, b = 0.25f, M_E_ = 0.7f, M_S = 1.0f;
-          const float tension = a * (hyst - M_E_) + b * (sc - M_S);                    // speedy.c:761
-          float v;
-          if ((double)Rg > 1.0) {
-            v = (float)fmax(1.0, (double)(Rg + (1 - Rg) * tension));                   // speedy.c:774
-          } else {
-            v = (float)fmax(0.01, fmin(1.0, (double)(Rg - (1 - Rg) * tension)));       // speedy.c:776
-          }
-          scr[4 * k + 2] = tension;
-          scr[4 * k + 3] = v;
-          if (tfeat) {
-            float* f = tfeat + (size_t)k * SPX_FEATURE_COUNT;
-            f[8] = l; f[9] = rel; f[10] = sc; f[11] = tension;
-          }
-          if (taps.tension) taps.tension[S.frame_off + k] = tension;
-        }
-        if (n > 0) lpf = sB[n - 1];
-        __syncthreads();
-      }
-      Z.lpf = lpf;
-      // ---- pass 4: duration feedback (sequential) and blend with the global speed ----
-      float cur_dur = Z.cur_dur, des_dur = Z.des_dur;
-      const float fd = (float)(1.0 / 100.0);  // speedy.c:783
-      for (int c0 = K0; c0 < K; c0 += SPX_CH) {
-        const int n = min(SPX_CH, K - c0);
-        for (int i = tid; i < n; i += NT) sA[i] = scr[4 * (c0 + i) + 3];
-        __syncthreads();
-        if (tid == 0) {
-          for (int i = 0; i < n; i++) {
-            float req = sA[i];
-            if (fb > 0) {
-              const float excess = cur_dur - des_dur;
-              req = (float)((double)req + fmax(0.01, (double)(fb * excess)));          // speedy.c:780-781
-            }
-            cur_dur += fd / req;
-            des_dur += fd / Rg;
-            sB[i] = req * nl + Rg * (1 - nl);                                          // soniclib.c:344-345
-          }
-          sA[0] = cur_dur;  // broadcast the carried sums (sA is re-read only by the next chunk's load)
-          sA[1] = des_dur;
-        }
-        __syncthreads();
-        cur_dur = sA[0];
-        des_dur = sA[1];
-        for (int i = tid; i < n; i += NT) {
-          scr[4 * (c0 + i) + 3] = sB[i];
-          if (taps.speed) taps.speed[S.frame_off + c0 + i] = sB[i];
-        }
-        __syncthreads();
-      }
-      Z.cur_dur = cur_dur;
-      Z.des_dur = des_dur;
-    }
-    __syncthreads();
-    STAMP(14);  // the frame-rate passes of this chunk
+    const bool last = K >= K_total;
     // Events, in the order the shim issues them:
     //   nonlinear: one (setSpeed, write B) per tension frame           soniclib.c:354,369
     //              at flush, the remaining complete ring buffers at the last speed   soniclib.c:538-550
@@ -1080,7 +929,6 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
       }
     }
     if (nl != 0.0f) handed = ev1;
-    fa_c = T_c;
     if (last) break;
   }
   STAMP_FLUSH
@@ -1088,16 +936,16 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
     Z.w.base = st.base; Z.w.out_n = st.out_n; Z.w.avail = avail; Z.w.remaining = st.remaining;
     Z.w.prevPeriod = st.prevPeriod; Z.w.prevMinDiff = st.prevMinDiff; Z.w.overflow = st.overflow;
     Z.w.prevPeriod_toggle = st.prevPeriod_toggle; Z.w.pad_ = 0;
-    Z.curSpeed = curSpeed;
-    if (nl != 0.0f) Z.handed = (int)handed;
-    states[blockIdx.x] = Z;
+    states[blockIdx.x].w = Z.w;  // field-wise: the tension kernel may be writing its own fields of this record
+    states[blockIdx.x].curSpeed = curSpeed;
+    if (nl != 0.0f) states[blockIdx.x].handed = (int)handed;
     if (n_out) n_out[blockIdx.x] = st.overflow ? -(int64_t)st.out_n : (int64_t)st.out_n;
   }
 }
 
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int maxC, const int16_t* in,
-                     int16_t* out, int64_t* n_out, SpxStreamState* states, const SpxFrameRec* rec,
-                     float* scratch, SpxTapsDev taps, const int* tile_flags, bool speedup_only, hipStream_t st) {
+                     int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
+                     const int* speed_ready, bool speedup_only, hipStream_t st) {
   if (n_streams <= 0) return;
   if (maxC < 1) maxC = 1;
   const WalkLds LY = walk_lds_layout(P, maxC);
@@ -1109,10 +957,10 @@ void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_str
   do {                                                                                                           \
     if (fast)                                                                                                    \
       hipLaunchKernelGGL((spx_walk_kernel<NWV, true>), dim3(n_streams), dim3(64 * NWV), LY.total, st, P, streams,  \
-                         in, out, n_out, states, rec, scratch, taps, maxC, tile_flags);                                      \
+                         in, out, n_out, states, scratch, maxC, speed_ready);                                      \
     else                                                                                                         \
       hipLaunchKernelGGL((spx_walk_kernel<NWV, false>), dim3(n_streams), dim3(64 * NWV), LY.total, st, P, streams, \
-                         in, out, n_out, states, rec, scratch, taps, maxC, tile_flags);                                      \
+                         in, out, n_out, states, scratch, maxC, speed_ready);                                      \
   } while (0)
   // FAST: every stream mono and speeding up (speed > 1, 0 <= nonlinear <= 1: the stage never sees a speed below 1),
   // decimated search, and at most 64 lags in either search (rates below 32 kHz)
