@@ -127,6 +127,7 @@ def main():
     L.spx_set_timing(0)
     sa, sw, nc = C.c_double(0), C.c_double(0), C.c_int(0)
     L.spx_timing_collect(C.byref(sa), C.byref(sw), C.byref(nc))
+    ms_tension = float(L.spx_timing_last_tension_ms()) / max(1, nc.value)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -187,12 +188,15 @@ def main():
                        "realtime_factor_per_stream": SECONDS / (ms_step * 1e-3),
                        "out_samples_per_gpu": n_out, "pipeline_chunks": args.chunks,
                        "kernel_launches_per_step": {"spx_analysis_kernel": args.chunks,
+                                                    "spx_tension_kernel": args.chunks,
                                                     "spx_walk_kernel": args.chunks}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "kernel_ms_per_step": {"spx_analysis_kernel": ms_analyze, "spx_walk_kernel": ms_walk},
+                         "kernel_ms_per_step": {"spx_analysis_kernel": ms_analyze, "spx_tension_kernel": ms_tension,
+                                                "spx_walk_kernel": ms_walk},
                          "kernel_avg_launch_ms": {"spx_analysis_kernel": ms_analyze / args.chunks,
+                                                  "spx_tension_kernel": ms_tension / args.chunks,
                                                   "spx_walk_kernel": ms_walk / args.chunks},
                          "note": "latency-bound at this size: 256 sequential per-stream walks, one workgroup "
                                  "each (DESIGN.md)"},
