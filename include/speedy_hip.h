@@ -98,7 +98,7 @@ int spx_batch_walk(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, c
                    const spx_taps* taps, void* hip_stream);
 
 /* Timing hooks for bench.py: while enabled, every spx_batch_run records HIP events on hip_stream around
- * each of its two kernels (no host synchronisation is added to the call).  spx_timing_collect waits for the
+ * each of its kernels (no host synchronisation is added to the call).  spx_timing_collect waits for the
  * recorded events, returns the summed kernel milliseconds (over all launches of each kernel) and the number of
  * spx_batch_run calls since the last collect. */
 void spx_set_timing(int enabled);
@@ -106,9 +106,9 @@ void spx_set_timing(int enabled);
  * analysis of range c+1 (on an internal HIP stream) with the walk of range c (on hip_stream); results are
  * identical for any value, the state record is carried exactly as in the streaming API. */
 void spx_set_pipeline_chunks(int chunks);
-/* Concurrent mode of spx_batch_run (default on): the analysis kernel runs on an internal HIP stream and publishes one
- * flag per tile; the walk kernel runs at the same time on hip_stream and takes each 128-frame chunk as soon as its
- * tiles are ready.  Results are identical with it on or off. */
+/* Concurrent mode of spx_batch_run (default on): the analysis kernel and the frame-rate (tension) kernel run on two
+ * internal HIP streams, the walk kernel at the same time on hip_stream; tiles of frames and then per-frame speeds are
+ * handed over through device-scope flags as they become ready.  Results are identical with it on or off. */
 void spx_set_concurrent(int on);
 int spx_timing_collect(double* sum_ms_analyze, double* sum_ms_walk, int* n_calls);
 /* Sum over the same calls of the frame-rate (tension) kernel's time, as of the last spx_timing_collect. */
