@@ -258,15 +258,38 @@ __device__ __forceinline__ void ensure_window(WalkCtx& X, pos_t pos, int need) {
 __device__ __forceinline__ unsigned sad_run(const unsigned* ap, const unsigned* bp, int j0, int j1) {
   unsigned acc = 0;
   int j = j0;
-  for (; j + 4 <= j1; j += 4) {
-    const unsigned a0 = ap[j], a1 = ap[j + 1], a2 = ap[j + 2], a3 = ap[j + 3];
-    const unsigned b0 = bp[j], b1 = bp[j + 1], b2 = bp[j + 2], b3 = bp[j + 3];
+  if (j + 4 <= j1) {
+    // software-pipelined: the loads of group g+1 are issued before the SADs of group g, so the LDS latency of all
+    // but the first group hides behind arithmetic
+    unsigned a0 = ap[j], a1 = ap[j + 1], a2 = ap[j + 2], a3 = ap[j + 3];
+    unsigned b0 = bp[j], b1 = bp[j + 1], b2 = bp[j + 2], b3 = bp[j + 3];
+    j += 4;
+    while (j + 4 <= j1) {
+      const unsigned c0 = ap[j], c1 = ap[j + 1], c2 = ap[j + 2], c3 = ap[j + 3];
+      const unsigned e0 = bp[j], e1 = bp[j + 1], e2 = bp[j + 2], e3 = bp[j + 3];
+      acc = __builtin_amdgcn_sad_u16(a0, b0, acc);
+      acc = __builtin_amdgcn_sad_u16(a1, b1, acc);
+      acc = __builtin_amdgcn_sad_u16(a2, b2, acc);
+      acc = __builtin_amdgcn_sad_u16(a3, b3, acc);
+      a0 = c0; a1 = c1; a2 = c2; a3 = c3;
+      b0 = e0; b1 = e1; b2 = e2; b3 = e3;
+      j += 4;
+    }
     acc = __builtin_amdgcn_sad_u16(a0, b0, acc);
     acc = __builtin_amdgcn_sad_u16(a1, b1, acc);
     acc = __builtin_amdgcn_sad_u16(a2, b2, acc);
     acc = __builtin_amdgcn_sad_u16(a3, b3, acc);
   }
-  for (; j < j1; j++) acc = __builtin_amdgcn_sad_u16(ap[j], bp[j], acc);
+  // up to three pairs are left: all loaded at once, a pair beyond the bound contributes |a - a| = 0
+  if (j < j1) {
+    const unsigned a0 = ap[j], a1 = ap[j + 1], a2 = ap[j + 2];
+    unsigned b0 = bp[j], b1 = bp[j + 1], b2 = bp[j + 2];
+    b1 = (j + 1 < j1) ? b1 : a1;
+    b2 = (j + 2 < j1) ? b2 : a2;
+    acc = __builtin_amdgcn_sad_u16(a0, b0, acc);
+    acc = __builtin_amdgcn_sad_u16(a1, b1, acc);
+    acc = __builtin_amdgcn_sad_u16(a2, b2, acc);
+  }
   return acc;
 }
 
