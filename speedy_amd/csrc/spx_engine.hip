@@ -304,7 +304,26 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // publishes a flag per tile; the walk kernel starts at once on the caller's stream and consumes chunks of frames
   // as their tiles become ready.  Same arithmetic, same results; only the serialisation of the two kernels goes.
   static const bool env_serial = getenv("SPX_SERIAL") != nullptr;  // tuning: kernels back to back on one stream
-  const bool concurrent = g_concurrent && !env_serial && do_a && do_w && nch == 1 && tiles[0] > 0;
+  // The three kernels hand frames over through flags that consumers poll, so every consumer workgroup must be able
+  // to be resident TOGETHER with at least one producer workgroup, or the producers could starve behind spinning
+  // consumers.  Allow for the dispatcher putting twice the average number of per-stream workgroups on a CU; batches
+  // that do not fit that bound run the kernels back to back instead (same results).
+  static int cu_count = 0;
+  static size_t lds_per_cu = 0;
+  if (cu_count == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+      cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+      lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? (size_t)prop.maxSharedMemoryPerMultiProcessor : 65536;
+    } else {
+      cu_count = 1; lds_per_cu = 65536;
+    }
+  }
+  const size_t per_stream_lds = spx_walk_lds_bytes(d, maxC) + spx_tension_lds_bytes();
+  const size_t k_per_cu = 2 * (((size_t)n + cu_count - 1) / cu_count);
+  const bool co_resident = k_per_cu * per_stream_lds + spx_analysis_lds_bytes(d) <= lds_per_cu && k_per_cu * 12 + 4 <= 32;
+  const bool concurrent = g_concurrent && !env_serial && co_resident && do_a && do_w && nch == 1 && tiles[0] > 0;
   int* d_order = reinterpret_cast<int*>(w + L.off_order);
   int* d_flags = reinterpret_cast<int*>(w + L.off_flags);
   int* d_ready = reinterpret_cast<int*>(w + L.off_ready);

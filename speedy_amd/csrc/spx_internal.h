@@ -97,6 +97,8 @@ void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_str
                      const int16_t* in, int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
                      const int* speed_ready, bool speedup_only, hipStream_t st);
 size_t spx_analysis_lds_bytes(const SpxPlanDev& P);
+size_t spx_walk_lds_bytes(const SpxPlanDev& P, int max_channels);
+size_t spx_tension_lds_bytes();
 int spx_analysis_tile_frames();
 
 // Shared, cached plan per (sample rate, hysteresis mode); owned by the library for the process lifetime.

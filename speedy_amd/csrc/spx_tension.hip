@@ -242,6 +242,8 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
   }
 }
 
+size_t spx_tension_lds_bytes() { return sizeof(float) * 2 * SPX_CH + 64; }
+
 void spx_launch_tension(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, SpxStreamState* states,
                         const SpxFrameRec* rec, float* scratch, SpxTapsDev taps, const int* tile_flags, int* speed_ready,
                         hipStream_t st) {

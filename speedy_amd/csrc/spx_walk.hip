@@ -966,6 +966,8 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   }
 }
 
+size_t spx_walk_lds_bytes(const SpxPlanDev& P, int maxC) { return (size_t)walk_lds_layout(P, maxC < 1 ? 1 : maxC).total; }
+
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int maxC, const int16_t* in,
                      int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
                      const int* speed_ready, bool speedup_only, hipStream_t st) {

@@ -273,3 +273,17 @@ def test_concurrent_handoff_under_uneven_load():
             assert np.array_equal(out[i], ref_out[i]), (reps, i)
         for a, r in zip(taps, ref_taps):
             assert np.array_equal(a["tension"], r["tension"]) and np.array_equal(a["speed"], r["speed"])
+
+
+def test_many_streams_fall_back_to_sequential_launches(orc):
+    """More streams than the chip can keep resident next to the producer kernels (600 short streams, default =
+    concurrent mode requested): the engine must run the three kernels back to back instead of letting spinning consumer
+    workgroups starve the producers.  Checked against the oracle on a sample of the streams."""
+    from speedy_amd.synth import speech_like
+    rate = 16000
+    base = [speech_like(12000 + 500 * i, rate, seed=700 + i) for i in range(12)]
+    streams = [base[i % 12] for i in range(600)]
+    outs, b = _batch(streams, rate, 1, 3.5, 1.0, 0.0, False, taps=False)
+    refs = [_oracle(orc, x, rate, 1, 3.5, 1.0, 0.0, False)["out"] for x in base]
+    for i in range(600):
+        assert np.array_equal(outs[i], refs[i % 12]), i
