@@ -48,7 +48,9 @@ size_t spx_analysis_lds_bytes(const SpxPlanDev& P) {
   size_t mags = (size_t)(SPX_TF + 1) * (P.W + 1) * sizeof(float);
   size_t small = (size_t)3 * (SPX_TF + 1) * sizeof(float);
   size_t stage = (stage_samples(P) * sizeof(short) + 15) & ~(size_t)15;
-  return work_bytes(P.W) + ((mags + 15) & ~(size_t)15) + ((small + 15) & ~(size_t)15) + stage;
+  size_t pad = 0;  // tuning only (fewer workgroups per CU); part of the size so that the co-residency rule sees it
+  if (const char* e = getenv("SPX_ANALYSIS_LDS_PAD")) pad = (size_t)atoi(e);
+  return work_bytes(P.W) + ((mags + 15) & ~(size_t)15) + ((small + 15) & ~(size_t)15) + stage + pad;
 }
 
 __device__ __forceinline__ void wave_sync() {
@@ -446,8 +448,7 @@ void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n
                          const int16_t* in, SpxFrameRec* rec, SpxTapsDev taps, const int* tile_order, int* tile_flags,
                          hipStream_t st) {
   if (n_tiles <= 0) return;
-  size_t lds = spx_analysis_lds_bytes(P);
-  if (const char* e = getenv("SPX_ANALYSIS_LDS_PAD")) lds += (size_t)atoi(e);  // tuning: fewer workgroups per CU
+  const size_t lds = spx_analysis_lds_bytes(P);
   hipLaunchKernelGGL(spx_analysis_kernel, dim3(n_tiles), dim3(SPX_BLOCK), lds, st, P, streams, n_streams, in,
                      rec, taps, tile_order, tile_flags);
 }

@@ -19,7 +19,10 @@
 #include "spx_internal.h"
 
 #define SPX_CH 1024  // frames per pass chunk held in LDS
-#define SPX_TCH 64   // frames in the first chunk when the analysis kernel runs concurrently (multiple of the tile)
+// Frames per chunk when the analysis kernel runs concurrently (a multiple of the 16-frame tile).  Measured on the
+// bench batch (ms per step): 16 constant 2.87 | 16,32,48.. 2.95 | 64,128,192.. 3.10 | 16,32,64.. 3.26 -- the finer the
+// hand-off, the less the walk kernel ever waits for speeds; this kernel has the slack for the extra passes.
+#define SPX_TCH 16
 #define SPX_TENSION_THREADS 256
 
 __global__ void __launch_bounds__(SPX_TENSION_THREADS)
@@ -51,15 +54,14 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
   const float lowthr = (float)(0.04 * (double)1.41421f);          // speedy.c:682
   float* tfeat = taps.features ? taps.features + (size_t)S.frame_off * SPX_FEATURE_COUNT : nullptr;
 
-  // Sequential launches (tile_flags == nullptr): one chunk with every new frame.  Concurrent: chunks of 64, 128,
-  // 192, ... frames, each started once its analysis tiles are published (the analysis is soon far ahead).
+  // Sequential launches (tile_flags == nullptr): one chunk with every new frame.  Concurrent: chunks of SPX_TCH
+  // frames, each started once its analysis tile is published.
   int fa_c = S.frame_begin;
   int wch = SPX_TCH;
   bool ok_all = true;
   for (;;) {
     int T_c = Ttot;
     if (tile_flags != nullptr && Ttot - fa_c > wch) T_c = fa_c + wch;
-    wch += SPX_TCH;
     const bool last = T_c >= Ttot;
     if (tile_flags != nullptr && T_c > fa_c) {
       const int TF = P.tile_frames;
