@@ -41,6 +41,7 @@ struct spx_plan {
 // spx_timing_collect (so that the timed region itself carries no host synchronisation).
 static bool g_timing = false;
 static int g_concurrent = 1;  // spx_set_concurrent: analysis and walk kernels on two streams, tile-flag hand-off
+static bool g_chunks_set = false;  // the caller chose a chunk count (spx_set_pipeline_chunks)
 static int g_chunks = 1;  // spx_set_pipeline_chunks (measured on MI355X, 256 x 10 s: 1 -> 5.09 ms, 2 -> 5.25, 4 -> 5.54 per step)
 struct EvPair { hipEvent_t a, b; int kind; };  // kind 0 = analysis launch, 1 = walk launch
 static std::vector<EvPair> g_ev_pending;
@@ -277,32 +278,16 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   const SpxPlanDev& d = plan->dev;
   Layout L = layout_for(d, jobs, n);
   if (ws_bytes < L.total || !ws) return fail(-1, "spx_batch: workspace too small");
-  // Pipelining in time needs both stages in one call; the separate entry points run one chunk.
-  int nch = (do_a && do_w) ? g_chunks : 1;
-  if (nch < 1) nch = 1;
-  if (nch > SPX_MAX_CHUNKS) nch = SPX_MAX_CHUNKS;
-  std::vector<SpxStreamDev> sv;
-  std::vector<int> tiles;
-  int rc = build_streams(d, jobs, n, nch, sv, tiles);
-  if (rc) return rc;
-  hipStream_t st = static_cast<hipStream_t>(hs);
-  unsigned char* w = static_cast<unsigned char*>(ws);
-  SpxStreamDev* dstreams = reinterpret_cast<SpxStreamDev*>(w + L.off_streams);
-  SpxStreamState* states = reinterpret_cast<SpxStreamState*>(w + L.off_states);
-  SpxFrameRec* rec = reinterpret_cast<SpxFrameRec*>(w + L.off_rec);
-  float* scratch = reinterpret_cast<float*>(w + L.off_scratch);
-  HIPCHK(hipMemcpyAsync(dstreams, sv.data(), sizeof(SpxStreamDev) * sv.size(), hipMemcpyHostToDevice, st));
-  SpxTapsDev td = taps_of(taps);
-  const bool timed = g_timing && do_a && do_w;
   int maxC = 1;
   bool speedup_only = true;  // every job speeds up: the walk kernel specialised for speeds >= 1 applies
   for (int i = 0; i < n; i++) {
     if (jobs[i].channels > maxC) maxC = jobs[i].channels;
     if (!(jobs[i].speed > 1.0f && jobs[i].nonlinear >= 0.0f && jobs[i].nonlinear <= 1.0f)) speedup_only = false;
   }
-  // Concurrent mode: the analysis kernel goes to the plan's side stream in "earliest frames first" tile order and
-  // publishes a flag per tile; the walk kernel starts at once on the caller's stream and consumes chunks of frames
-  // as their tiles become ready.  Same arithmetic, same results; only the serialisation of the two kernels goes.
+  // Concurrent mode: the analysis kernel goes to a side stream in "earliest frames first" tile order and publishes a
+  // flag per tile; the tension kernel (second side stream) turns ready tiles into per-frame speeds and publishes their
+  // count; the walk kernel starts at once on the caller's stream and runs every event whose speed is there.  Same
+  // arithmetic, same results; only the serialisation of the kernels goes.
   static const bool env_serial = getenv("SPX_SERIAL") != nullptr;  // tuning: kernels back to back on one stream
   // The three kernels hand frames over through flags that consumers poll, so every consumer workgroup must be able
   // to be resident TOGETHER with at least one producer workgroup, or the producers could starve behind spinning
@@ -323,7 +308,29 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   const size_t per_stream_lds = spx_walk_lds_bytes(d, maxC) + spx_tension_lds_bytes();
   const size_t k_per_cu = 2 * (((size_t)n + cu_count - 1) / cu_count);
   const bool co_resident = k_per_cu * per_stream_lds + spx_analysis_lds_bytes(d) <= lds_per_cu && k_per_cu * 12 + 4 <= 32;
-  const bool concurrent = g_concurrent && !env_serial && co_resident && do_a && do_w && nch == 1 && tiles[0] > 0;
+  const bool want_concurrent = g_concurrent && !env_serial && co_resident && do_a && do_w;
+  // Pipelining in time needs both stages in one call; the separate entry points run one chunk.  A batch too large for
+  // the concurrent mode gets four time chunks unless the caller chose a count: the analysis of chunk c+1 then overlaps
+  // the walk of chunk c through ordinary stream ordering (measured at 512 / 1024 streams x 10 s: 5.32 -> 4.76 ms and
+  // 9.94 -> 9.28 ms per call; no difference at 2048).
+  int nch = (do_a && do_w) ? g_chunks : 1;
+  if (do_a && do_w && !g_chunks_set && !want_concurrent && n > cu_count) nch = 4;
+  if (nch < 1) nch = 1;
+  if (nch > SPX_MAX_CHUNKS) nch = SPX_MAX_CHUNKS;
+  std::vector<SpxStreamDev> sv;
+  std::vector<int> tiles;
+  int rc = build_streams(d, jobs, n, nch, sv, tiles);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(hs);
+  unsigned char* w = static_cast<unsigned char*>(ws);
+  SpxStreamDev* dstreams = reinterpret_cast<SpxStreamDev*>(w + L.off_streams);
+  SpxStreamState* states = reinterpret_cast<SpxStreamState*>(w + L.off_states);
+  SpxFrameRec* rec = reinterpret_cast<SpxFrameRec*>(w + L.off_rec);
+  float* scratch = reinterpret_cast<float*>(w + L.off_scratch);
+  HIPCHK(hipMemcpyAsync(dstreams, sv.data(), sizeof(SpxStreamDev) * sv.size(), hipMemcpyHostToDevice, st));
+  SpxTapsDev td = taps_of(taps);
+  const bool timed = g_timing && do_a && do_w;
+  const bool concurrent = want_concurrent && nch == 1 && tiles[0] > 0;
   int* d_order = reinterpret_cast<int*>(w + L.off_order);
   int* d_flags = reinterpret_cast<int*>(w + L.off_flags);
   int* d_ready = reinterpret_cast<int*>(w + L.off_ready);
@@ -414,7 +421,7 @@ int spx_batch_walk(spx_plan_t plan, const spx_stream_job* jobs, int n, const int
 
 void spx_set_timing(int enabled) { g_timing = enabled != 0; }
 void spx_set_concurrent(int on) { g_concurrent = on != 0; }
-void spx_set_pipeline_chunks(int chunks) { g_chunks = chunks < 1 ? 1 : (chunks > SPX_MAX_CHUNKS ? SPX_MAX_CHUNKS : chunks); }
+void spx_set_pipeline_chunks(int chunks) { g_chunks_set = true; g_chunks = chunks < 1 ? 1 : (chunks > SPX_MAX_CHUNKS ? SPX_MAX_CHUNKS : chunks); }
 static double g_last_tension_ms = 0.0;
 double spx_timing_last_tension_ms(void) { return g_last_tension_ms; }
 int spx_timing_collect(double* sum_ms_analyze, double* sum_ms_walk, int* n_calls) {
