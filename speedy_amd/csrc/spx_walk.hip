@@ -974,9 +974,11 @@ void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_str
   if (n_streams <= 0) return;
   if (maxC < 1) maxC = 1;
   const WalkLds LY = walk_lds_layout(P, maxC);
-  // Waves per stream: few streams -> several waves per stream use the otherwise idle SIMDs; many streams -> one
-  // wave each and more streams per CU.  SPX_WALK_NW overrides (tuning only).
-  int nw = (n_streams <= 256) ? 8 : (n_streams <= 1024) ? 4 : 1;  // measured on MI355X: 5.14 / 5.34 / 6.77 ms at 256 streams
+  // Waves per stream.  Measured on MI355X, 10 s streams (ms per call; 2 / 4 / 8 waves): 256 streams 3.67 / 3.19 / 2.91
+  // (walk kernel alone), 512: 5.40 / 4.78 / 5.63, 1024: 10.3 / 9.3 / 10.5, 2048: 19.7 / 17.7 / - (1 wave: 21.4).
+  // One workgroup per CU wants all eight wave slots of two-per-SIMD; several workgroups per CU hide each other's
+  // latencies and do best with four.  SPX_WALK_NW overrides (tuning only).
+  int nw = (n_streams <= 256) ? 8 : 4;
   if (const char* e = getenv("SPX_WALK_NW")) nw = atoi(e);
 #define SPX_LAUNCH_WALK(NWV)                                                                                     \
   do {                                                                                                           \
