@@ -408,10 +408,13 @@ __device__ __forceinline__ void search_split(const unsigned* A0, const unsigned*
     const int ob = o + p;
     const unsigned* bp = (ob & 1) ? A1 + ((ob - 1) >> 1) : A0 + (ob >> 1);
     const int nfull = valid ? (p >> 1) : 0;
-    int j1 = (wave + 1) * CH;
+    // Chunk c of the pairs goes to wave c for c < 4 and to wave 11 - c above (8 waves): low chunks are the busy ones
+    // (every lag has those pairs), and waves w and w + 4 share a SIMD, so each SIMD gets a busy and a light chunk.
+    const int cw = (NW == 8) ? (wave < 4 ? wave : 11 - wave) : wave;
+    int j1 = (cw + 1) * CH;
     if (j1 > nfull) j1 = nfull;
-    unsigned d = sad_run(ap, bp, wave * CH, j1);
-    if (wave == NW - 1 && valid && (p & 1))
+    unsigned d = sad_run(ap, bp, cw * CH, j1);
+    if (cw == NW - 1 && valid && (p & 1))
       d = __builtin_amdgcn_sad_u16(ap[nfull] & 0xffffu, bp[nfull] & 0xffffu, d);  // the lone term i = p-1
     if (valid) atomicAdd(&buf[base + lane], d);
   }
