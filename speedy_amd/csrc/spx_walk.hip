@@ -579,12 +579,14 @@ __device__ __forceinline__ void emit_overlap_add(const WalkCtx& X, pos_t a_down,
   if (FAST || (C == 1 && inwin)) {  // FAST: ensure_window(pos, maxRequired + ...) of the search covers both ramps
     const unsigned short* wd = X.monoH + od;
     const unsigned short* wu = X.monoH + ou;
+    // FAST: n <= maxPeriod < 512 (rates below 32 kHz), so with eight waves this is one predicated pass, no loop
     for (int t = threadIdx.x; t < nv; t += NT) {
       const int d = (int)wd[t] - 32768, u = (int)wu[t] - 32768;
       const int num = d * (n - t) + u * t;
       const int mag = num < 0 ? -num : num;
       const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
       dst[t] = (int16_t)(num < 0 ? -qm : qm);
+      if (FAST && NT >= 512) break;
     }
   } else {
     const int total = nv * C;
