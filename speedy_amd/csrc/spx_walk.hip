@@ -1,19 +1,15 @@
-// Walk kernel for gfx950: one workgroup of NW wavefronts (NW = 1 or 4) per stream.
+// Walk kernel for gfx950: one workgroup of NW wavefronts (NW = 1, 2, 4, 8 or 16) per stream.
 //
-// Prologue (frame rate, O(1) work per 10 ms frame; order-sensitive recurrences run on one lane in the
-// reference's order, everything else one lane per frame):
-//   a6  energy low-pass, local energy, sqrt compression   speedy.c:517-521,73-76
-//   a7  tapered-max temporal hysteresis                   speedy.c:590-610
-//   a8  low-energy gate, emphasis weighting, difference low-pass, relative difference, clamp
-//                                                         speedy.c:682-700,720-728
-//   a7  tension                                           speedy.c:752-766
-//   a9  speed from tension (+ duration feedback), blend   speedy.c:768-788, soniclib.c:339-345
-// Walk (sample rate, inherently sequential per stream: each step's position depends on the last period):
+// The sample-rate stage, inherently sequential per stream (each step's position depends on the last period):
 //   a10 AMDF pitch search on the decimated then the full-rate signal   (libsonic)
 //   a11 skip / insert pitch periods with a linear cross-fade, FIFO bookkeeping, flush padding
 //       driven exactly as the shim drives it: one (setSpeed, write frameStep samples) pair per tension
 //       frame (soniclib.c:354,369), the un-analysed tail at the last speed (soniclib.c:538-550), then
 //       sonicIntFlushStream (soniclib.c:551).
+// The speed of every tension frame comes from the tension kernel (spx_tension.hip) through scratch[4k + 3]; in
+// concurrent mode that kernel runs beside this one and publishes how many speeds are final (`speed_ready`).
+// Two variants: FAST (all streams mono and speeding up, rates below 32 kHz; the bench and the usual case) and the
+// general one (any channel count, slow-down, any rate).
 //
 // How a pitch step maps to the hardware:
 //   * the input lives in an LDS sliding window (int16, refilled with coalesced loads every ~25 steps), so a
