@@ -25,6 +25,29 @@
 #define SPX_TCH 16
 #define SPX_TENSION_THREADS 256
 
+// y[i] = a*x[i] + b*y[i-1] for i < n in the reference's rounding order (float product, float product, float sum --
+// the recurrence cannot be re-associated), x in sA, y to sB.  Run by the 64 lanes of wave 0: 64 products a*x[i] are
+// formed in parallel, then the chain runs on uniform values with a v_readlane per element -- two dependent VALU
+// operations per element instead of an LDS round trip.  Returns the last y.
+__device__ __forceinline__ float iir_wave(const float* sA, float* sB, int n, float a, float b, float y) {
+  const int lane = threadIdx.x;
+  for (int b0 = 0; b0 < n; b0 += 64) {
+    const int m = n - b0 < 64 ? n - b0 : 64;
+    const float ax = a * ((lane < m) ? sA[b0 + lane] : 0.0f);
+    float out = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+      if (j < m) {  // uniform
+        const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ax), j));
+        y = s + b * y;
+        out = (lane == j) ? y : out;
+      }
+    }
+    if (lane < m) sB[b0 + lane] = out;
+  }
+  return y;
+}
+
 __global__ void __launch_bounds__(SPX_TENSION_THREADS)
 spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxStreamState* __restrict__ states,
                    const SpxFrameRec* __restrict__ rec_base, float* __restrict__ scratch_base, SpxTapsDev taps,
@@ -92,12 +115,7 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
         const int n = min(SPX_CH, T - c0);
         for (int i = tid; i < n; i += NT) sA[i] = rec[c0 + i].energy;
         __syncthreads();
-        if (tid == 0) {
-          for (int i = 0; i < n; i++) {
-            lp = P.one_minus_alpha * sA[i] + P.alpha * lp;  // speedy.c:74
-            sB[i] = lp;
-          }
-        }
+        if (tid < 64) lp = iir_wave(sA, sB, n, P.one_minus_alpha, P.alpha, lp);  // speedy.c:74
         __syncthreads();
         for (int i = tid; i < n; i += NT) {
           const float e = sA[i], l = sB[i];
@@ -150,12 +168,7 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
         const int n = min(SPX_CH, K - c0);
         for (int i = tid; i < n; i += NT) sA[i] = scr[4 * (c0 + i) + 2];
         __syncthreads();
-        if (tid == 0) {
-          for (int i = 0; i < n; i++) {
-            lpf = P.one_minus_alpha * sA[i] + P.alpha * lpf;
-            sB[i] = lpf;
-          }
-        }
+        if (tid < 64) lpf = iir_wave(sA, sB, n, P.one_minus_alpha, P.alpha, lpf);
         __syncthreads();
         for (int i = tid; i < n; i += NT) {
           const int k = c0 + i;
@@ -195,7 +208,27 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
         const int n = min(SPX_CH, K - c0);
         for (int i = tid; i < n; i += NT) sA[i] = scr[4 * (c0 + i) + 3];
         __syncthreads();
-        if (tid == 0) {
+        if (!(fb > 0)) {
+          // open loop (speedy.c:779 not taken): the requested speeds do not depend on the running sums, so only the
+          // two float sums are sequential; quotients and blended speeds are formed 64 at a time
+          if (tid < 64) {
+            const float cstep = fd / Rg;
+            for (int b0 = 0; b0 < n; b0 += 64) {
+              const int m = n - b0 < 64 ? n - b0 : 64;
+              const float req = (tid < m) ? sA[b0 + tid] : 1.0f;
+              const float q = fd / req;
+#pragma unroll
+              for (int j = 0; j < 64; j++) {
+                if (j < m) {  // uniform
+                  cur_dur += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q), j));
+                  des_dur += cstep;
+                }
+              }
+              if (tid < m) sB[b0 + tid] = req * nl + Rg * (1 - nl);                      // soniclib.c:344-345
+            }
+            if (tid == 0) { sA[0] = cur_dur; sA[1] = des_dur; }
+          }
+        } else if (tid == 0) {
           for (int i = 0; i < n; i++) {
             float req = sA[i];
             if (fb > 0) {
