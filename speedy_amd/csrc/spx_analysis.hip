@@ -17,7 +17,9 @@
 
 #include "spx_internal.h"
 
+#ifndef SPX_TF
 #define SPX_TF 16  // frames per tile (plus one halo slot)
+#endif
 
 #ifdef SPX_STAMPS
 __device__ unsigned long long g_spx_astamps[16];

@@ -22,7 +22,9 @@
 // Frames per chunk when the analysis kernel runs concurrently (a multiple of the 16-frame tile).  Measured on the
 // bench batch (ms per step): 16 constant 2.87 | 16,32,48.. 2.95 | 64,128,192.. 3.10 | 16,32,64.. 3.26 -- the finer the
 // hand-off, the less the walk kernel ever waits for speeds; this kernel has the slack for the extra passes.
+#ifndef SPX_TCH
 #define SPX_TCH 16
+#endif
 #define SPX_TENSION_THREADS 256
 
 // y[i] = a*x[i] + b*y[i-1] for i < n in the reference's rounding order (float product, float product, float sum --
