@@ -151,6 +151,20 @@ def test_full_size_round_trip_properties():
         assert np.array_equal(r1[i], r2[i])
         assert np.array_equal(r1[i], r1[i % 8])  # same input, any slot of the batch -> same bytes
         assert 2.5 < n / r1[i].size < 4.5
+    # the bench workload itself: three kernels on three HIP streams (default) against back-to-back launches,
+    # and one of the streams against the oracle
+    from speedy_amd._lib import lib
+    lib().spx_set_concurrent(0)
+    try:
+        b.run()
+        r3 = b.results()
+    finally:
+        lib().spx_set_concurrent(1)
+    for i in range(B):
+        assert np.array_equal(r1[i], r3[i]), i
+    from oracle import pyorc
+    ref = pyorc.compress_sound(base[3], rate, 1, 3.5, 1.0, 0.0, False, chunk=1000)["out"]
+    assert np.array_equal(r1[3], ref)
 
 
 @pytest.mark.parametrize("chunks", [2, 5])
