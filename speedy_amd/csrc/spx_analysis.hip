@@ -216,15 +216,42 @@ __device__ void dft_stage(const SpxPlanDev& P, const double* tw, int r, int s, i
       st_tw(y, o + 4 * s, b4, tw, 4 * tp);
     }
   } else {
-    // generic prime radix: one lane per (butterfly, output) pair, inputs accumulated in ascending order
+    // generic prime radix: one lane per (butterfly, output) pair, inputs accumulated in ascending order.  The twiddle
+    // index (i*j) mod r advances by j per input (one add and one conditional subtract instead of a modulo), and the
+    // loop runs four inputs at a time so that four twiddle loads are in flight; the sums are formed in the same order.
     const int step = W / r;
     for (int item = lane; item < W; item += SPX_WAVE) {
       const int b = item / r, j = item - b * r;
       const int p = (int)(((unsigned)b * inv_s) >> 20), q = b - p * s;
       cplx acc = ld(x, b);
-      for (int i = 1; i < r; i++) {
-        cplx a = ld(x, b + i * span);
-        const double2 w = *reinterpret_cast<const double2*>(tw + 2 * (((i * j) % r) * step));
+      int t = 0;  // (i*j) mod r
+      int i = 1;
+      for (; i + 3 < r; i += 4) {
+        int t0 = t + j;  t0 -= (t0 >= r) ? r : 0;
+        int t1 = t0 + j; t1 -= (t1 >= r) ? r : 0;
+        int t2 = t1 + j; t2 -= (t2 >= r) ? r : 0;
+        int t3 = t2 + j; t3 -= (t3 >= r) ? r : 0;
+        t = t3;
+        const double2 w0 = *reinterpret_cast<const double2*>(tw + 2 * (t0 * step));
+        const double2 w1 = *reinterpret_cast<const double2*>(tw + 2 * (t1 * step));
+        const double2 w2 = *reinterpret_cast<const double2*>(tw + 2 * (t2 * step));
+        const double2 w3 = *reinterpret_cast<const double2*>(tw + 2 * (t3 * step));
+        const cplx a0 = ld(x, b + i * span), a1 = ld(x, b + (i + 1) * span), a2 = ld(x, b + (i + 2) * span),
+                   a3 = ld(x, b + (i + 3) * span);
+        acc.r = acc.r + (a0.r * w0.x - a0.i * w0.y);
+        acc.i = acc.i + (a0.r * w0.y + a0.i * w0.x);
+        acc.r = acc.r + (a1.r * w1.x - a1.i * w1.y);
+        acc.i = acc.i + (a1.r * w1.y + a1.i * w1.x);
+        acc.r = acc.r + (a2.r * w2.x - a2.i * w2.y);
+        acc.i = acc.i + (a2.r * w2.y + a2.i * w2.x);
+        acc.r = acc.r + (a3.r * w3.x - a3.i * w3.y);
+        acc.i = acc.i + (a3.r * w3.y + a3.i * w3.x);
+      }
+      for (; i < r; i++) {
+        t += j;
+        t -= (t >= r) ? r : 0;
+        const cplx a = ld(x, b + i * span);
+        const double2 w = *reinterpret_cast<const double2*>(tw + 2 * (t * step));
         acc.r = acc.r + (a.r * w.x - a.i * w.y);
         acc.i = acc.i + (a.r * w.y + a.i * w.x);
       }

@@ -1,0 +1,33 @@
+"""Throughput of one 256-stream batch call for the stream kinds of BASELINE configs[4] and beyond (10 s each)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from speedy_amd.batch import Batch, Plan  # noqa: E402
+from speedy_amd.synth import speech_like  # noqa: E402
+
+ns = 256
+for rate, ch, speed, nl in [(16000, 1, 3.5, 1.0), (16000, 1, 1.5, 1.0), (22050, 1, 1.5, 1.0), (22050, 1, 3.5, 1.0),
+                            (16000, 2, 3.5, 1.0), (22050, 2, 1.5, 1.0), (44100, 1, 3.5, 1.0), (48000, 2, 3.5, 1.0),
+                            (16000, 1, 2.0, 0.0), (16000, 1, 0.5, 1.0)]:
+    n = 10 * rate
+    plan = Plan(rate, False)
+    base = [speech_like(n, rate, seed=i, channels=ch) for i in range(4)]
+    b = Batch(plan, [n] * ns, ch, speed, nl, 0.0)
+    b.upload([base[i % 4] for i in range(ns)])
+    for _ in range(2):
+        b.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        b.run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    print("rate=%5d ch=%d speed=%.1f nl=%.0f  %.3f ms/call  %.0f Msamples/s (frames)" %
+          (rate, ch, speed, nl, dt * 1e3, ns * n / dt / 1e6))
+    del b
+    torch.cuda.empty_cache()
