@@ -115,12 +115,19 @@ double orc_log(double x) {
 /* DFT spec.  Stockham autosort, decimation in frequency, mixed radix.             */
 /* Radix order: all 4s, then a 2, then 3s, then 5s, then remaining primes ascending.           */
 #define ORC_MAX_STAGES 32
-typedef struct {
+typedef struct orc_plan_s {
   int n;
   int nstages;
   int radix[ORC_MAX_STAGES];
   double* tw;   /* tw[2t], tw[2t+1] = cos(2 pi t/n), -sin(2 pi t/n) */
   double* work; /* 2 * 2n doubles ping-pong */
+  /* Rader's algorithm for a large prime n whose n-1 is smooth (DESIGN.md "DFT spec"): the n-point transform as a cyclic
+   * convolution of length n-1 done with the (n-1)-point plan.  NULL otherwise. */
+  struct orc_plan_s* sub; /* (n-1)-point plan */
+  int* perm;              /* perm[p]  = g^p  mod n, p < n-1, g the smallest primitive root */
+  int* iperm;             /* iperm[q] = g^-q mod n */
+  double* bfft;           /* forward transform of b[q] = tw[iperm[q]], 2(n-1) doubles */
+  double* rwork;          /* 3 * 2(n-1) doubles */
 } orc_plan;
 
 static int orc_factor(int n, int* radix) {
@@ -135,6 +142,28 @@ static int orc_factor(int n, int* radix) {
   return ns;
 }
 
+static void orc_plan_execute(orc_plan* P, const double* in, double* out);
+static orc_plan* orc_plan_create(int n);
+static void orc_plan_destroy(orc_plan* p);
+
+/* Rader applies to a prime n > 64 whose n - 1 has no prime factor above 13 (44.1 kHz: W = 661, 660 = 4*3*5*11). */
+static int orc_use_rader(int n) {
+  if (n <= 64) return 0;
+  for (int d = 2; (long)d * d <= n; d++) if (n % d == 0) return 0;
+  int m = n - 1;
+  for (int d = 2; d <= 13; d++) while (m % d == 0) m /= d;
+  return m == 1;
+}
+static int orc_primitive_root(int n) { /* smallest g whose powers visit all of 1 .. n-1 */
+  for (int g = 2; g < n; g++) {
+    long v = 1;
+    int k = 0;
+    do { v = (v * g) % n; k++; } while (v != 1);
+    if (k == n - 1) return g;
+  }
+  return 0;
+}
+
 static orc_plan* orc_plan_create(int n) {
   orc_plan* p = (orc_plan*)calloc(1, sizeof(orc_plan));
   p->n = n;
@@ -145,10 +174,26 @@ static orc_plan* orc_plan_create(int n) {
     p->tw[2 * t] = cos(2.0 * M_PI * t / n);
     p->tw[2 * t + 1] = -sin(2.0 * M_PI * t / n);
   }
+  if (orc_use_rader(n)) {
+    int m = n - 1;
+    p->sub = orc_plan_create(m);
+    p->perm = (int*)malloc(sizeof(int) * m);
+    p->iperm = (int*)malloc(sizeof(int) * m);
+    p->bfft = (double*)malloc(sizeof(double) * 2 * m);
+    p->rwork = (double*)malloc(sizeof(double) * 6 * m);
+    int g = orc_primitive_root(n);
+    long v = 1;
+    for (int k = 0; k < m; k++) { p->perm[k] = (int)v; v = (v * g) % n; }
+    for (int q = 0; q < m; q++) p->iperm[q] = p->perm[(m - q) % m]; /* g^-q = g^(m-q) */
+    double* b = p->rwork;
+    for (int q = 0; q < m; q++) { b[2 * q] = p->tw[2 * p->iperm[q]]; b[2 * q + 1] = p->tw[2 * p->iperm[q] + 1]; }
+    orc_plan_execute(p->sub, b, p->bfft);
+  }
   return p;
 }
 static void orc_plan_destroy(orc_plan* p) {
   if (!p) return;
+  if (p->sub) { orc_plan_destroy(p->sub); free(p->perm); free(p->iperm); free(p->bfft); free(p->rwork); }
   free(p->tw);
   free(p->work);
   free(p);
@@ -212,9 +257,37 @@ static void orc_butterfly(const orc_plan* P, int r, const double* ar, const doub
   }
 }
 
+/* X[0] = x[0] + A[0];  X[g^-q] = x[0] + c[q],  c = a (*) b cyclically, a[p] = x[g^p], b[q] = w^(g^-q):
+ * A = F(a), C = A .* F(b), c = conj(F(conj(C))) / (n-1), all with the (n-1)-point plan.  Fixed operation order. */
+static void orc_plan_execute_rader(orc_plan* P, const double* in, double* out) {
+  int n = P->n, m = n - 1;
+  double* a = P->rwork;
+  double* A = a + 2 * m;
+  double* c = A + 2 * m;
+  for (int p = 0; p < m; p++) { a[2 * p] = in[2 * P->perm[p]]; a[2 * p + 1] = in[2 * P->perm[p] + 1]; }
+  orc_plan_execute(P->sub, a, A);
+  double x0r = in[0], x0i = in[1];
+  double A0r = A[0], A0i = A[1];
+  for (int k = 0; k < m; k++) {
+    double br = P->bfft[2 * k], bi = P->bfft[2 * k + 1];
+    double cr = A[2 * k] * br - A[2 * k + 1] * bi;
+    double ci = A[2 * k] * bi + A[2 * k + 1] * br;
+    a[2 * k] = cr; a[2 * k + 1] = -ci; /* conj(C) */
+  }
+  orc_plan_execute(P->sub, a, c);
+  double inv = 1.0 / (double)m;
+  out[0] = x0r + A0r; out[1] = x0i + A0i;
+  for (int q = 0; q < m; q++) {
+    double cr = c[2 * q] * inv, ci = -c[2 * q + 1] * inv;
+    out[2 * P->iperm[q]] = x0r + cr;
+    out[2 * P->iperm[q] + 1] = x0i + ci;
+  }
+}
+
 static void orc_plan_execute(orc_plan* P, const double* in, double* out) {
   int n = P->n;
   if (n == 1) { out[0] = in[0]; out[1] = in[1]; return; }
+  if (P->sub) { orc_plan_execute_rader(P, in, out); return; }
   double* x = P->work;
   double* y = P->work + 2 * n;
   memcpy(x, in, sizeof(double) * 2 * n);

@@ -133,11 +133,11 @@ struct cplx {
   double r, i;
 };
 
-__device__ __forceinline__ cplx ld(const double* buf, int idx) {
+__host__ __device__ __forceinline__ cplx ld(const double* buf, int idx) {
   const double2 v = *reinterpret_cast<const double2*>(buf + 2 * idx);
   return {v.x, v.y};
 }
-__device__ __forceinline__ void st_tw(double* buf, int idx, cplx b, const double* tw, int t) {
+__host__ __device__ __forceinline__ void st_tw(double* buf, int idx, cplx b, const double* tw, int t) {
   const double2 w = *reinterpret_cast<const double2*>(tw + 2 * t);
   double2 o;
   o.x = b.r * w.x - b.i * w.y;
@@ -148,14 +148,14 @@ __device__ __forceinline__ void st_tw(double* buf, int idx, cplx b, const double
 // One Stockham stage of radix r over the W-point transform held in x (-> y).  s = product of earlier radices.
 // b / s for b < 4096 by an exact multiply-shift (inv = ceil(2^20 / s), s | W).  The twiddle index j*s*p is
 // always below W (s*p < W/r), so no reduction modulo W is needed.
-__device__ void dft_stage(const SpxPlanDev& P, const double* tw, int r, int s, int cur, const double* x, double* y,
-                          int lane) {
-  const int W = P.W;
+// `lane` of `nl` cooperating lanes (a wavefront in the kernel; 0 of 1 on the host, where it builds the Rader tables).
+__host__ __device__ void dft_stage(const int W, const double* tw, int r, int s, int cur, const double* x, double* y,
+                                   int lane, const int nl) {
   const int m = cur / r;
   const int span = W / r;
   const unsigned inv_s = ((1u << 20) + (unsigned)s - 1u) / (unsigned)s;
   if (r == 4) {
-    for (int b = lane; b < span; b += SPX_WAVE) {
+    for (int b = lane; b < span; b += nl) {
       const int p = (int)(((unsigned)b * inv_s) >> 20), q = b - p * s;
       cplx a0 = ld(x, b), a1 = ld(x, b + span), a2 = ld(x, b + 2 * span), a3 = ld(x, b + 3 * span);
       cplx t0 = {a0.r + a2.r, a0.i + a2.i}, t1 = {a0.r - a2.r, a0.i - a2.i};
@@ -170,7 +170,7 @@ __device__ void dft_stage(const SpxPlanDev& P, const double* tw, int r, int s, i
       st_tw(y, o + 3 * s, b3, tw, 3 * tp);
     }
   } else if (r == 2) {
-    for (int b = lane; b < span; b += SPX_WAVE) {
+    for (int b = lane; b < span; b += nl) {
       const int p = (int)(((unsigned)b * inv_s) >> 20), q = b - p * s;
       cplx a0 = ld(x, b), a1 = ld(x, b + span);
       cplx b0 = {a0.r + a1.r, a0.i + a1.i}, b1 = {a0.r - a1.r, a0.i - a1.i};
@@ -179,7 +179,7 @@ __device__ void dft_stage(const SpxPlanDev& P, const double* tw, int r, int s, i
       st_tw(y, o + s, b1, tw, s * p);
     }
   } else if (r == 3) {
-    for (int b = lane; b < span; b += SPX_WAVE) {
+    for (int b = lane; b < span; b += nl) {
       const int p = (int)(((unsigned)b * inv_s) >> 20), q = b - p * s;
       cplx a0 = ld(x, b), a1 = ld(x, b + span), a2 = ld(x, b + 2 * span);
       cplx t1 = {a1.r + a2.r, a1.i + a2.i};
@@ -194,7 +194,7 @@ __device__ void dft_stage(const SpxPlanDev& P, const double* tw, int r, int s, i
       st_tw(y, o + 2 * s, b2, tw, 2 * tp);
     }
   } else if (r == 5) {
-    for (int b = lane; b < span; b += SPX_WAVE) {
+    for (int b = lane; b < span; b += nl) {
       const int p = (int)(((unsigned)b * inv_s) >> 20), q = b - p * s;
       cplx a0 = ld(x, b), a1 = ld(x, b + span), a2 = ld(x, b + 2 * span), a3 = ld(x, b + 3 * span),
            a4 = ld(x, b + 4 * span);
@@ -220,7 +220,7 @@ __device__ void dft_stage(const SpxPlanDev& P, const double* tw, int r, int s, i
     // index (i*j) mod r advances by j per input (one add and one conditional subtract instead of a modulo), and the
     // loop runs four inputs at a time so that four twiddle loads are in flight; the sums are formed in the same order.
     const int step = W / r;
-    for (int item = lane; item < W; item += SPX_WAVE) {
+    for (int item = lane; item < W; item += nl) {
       const int b = item / r, j = item - b * r;
       const int p = (int)(((unsigned)b * inv_s) >> 20), q = b - p * s;
       cplx acc = ld(x, b);
@@ -259,6 +259,22 @@ __device__ void dft_stage(const SpxPlanDev& P, const double* tw, int r, int s, i
     }
   }
   (void)m;
+}
+
+void spx_host_dft(int n, const int* radix, int nstages, const double* tw, const double* in, double* out) {
+  double* a = new double[4 * (size_t)n];
+  double* x = a;
+  double* y = a + 2 * (size_t)n;
+  for (int i = 0; i < 2 * n; i++) x[i] = in[i];
+  int s = 1, cur = n;
+  for (int st = 0; st < nstages; st++) {
+    dft_stage(n, tw, radix[st], s, cur, x, y, 0, 1);
+    double* t = x; x = y; y = t;
+    s *= radix[st];
+    cur /= radix[st];
+  }
+  for (int i = 0; i < 2 * n; i++) out[i] = x[i];
+  delete[] a;
 }
 
 __device__ __forceinline__ int mono_sample(const int16_t* __restrict__ in, int64_t a, int C) {
@@ -356,14 +372,66 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
     ASTAMP(0);
     double* x = bufA;
     double* y = bufB;
-    int sprod = 1, cur = W;
-    for (int stg = 0; stg < P.nstages; stg++) {
-      const int r = P.radix[stg];
-      dft_stage(P, ltw, r, sprod, cur, x, y, lane);
+    if (P.rader) {
+      // W prime: X[0] = x[0] + A[0], X[g^-q] = x[0] + c[q] with c = a (*) b cyclically over M = W-1 points,
+      // a[p] = x[g^p], b[q] = w^(g^-q); A = F(a), C = A .* F(b), c = conj(F(conj(C))) / M (oracle: orc_plan_execute_rader)
+      const int M = W - 1;
+      const cplx x0 = ld(x, 0);
+      for (int p = lane; p < M; p += SPX_WAVE) {
+        const cplx v = ld(x, P.perm[p]);
+        *reinterpret_cast<double2*>(y + 2 * p) = make_double2(v.r, v.i);
+      }
       wave_sync();
-      double* t = x; x = y; y = t;
-      sprod *= r;
-      cur /= r;
+      { double* t = x; x = y; y = t; }
+      for (int pass = 0; pass < 2; pass++) {
+        int sprod = 1, cur = M;
+        for (int stg = 0; stg < P.nstagesM; stg++) {
+          const int r = P.radixM[stg];
+          dft_stage(M, P.twM, r, sprod, cur, x, y, lane, SPX_WAVE);
+          wave_sync();
+          double* t = x; x = y; y = t;
+          sprod *= r;
+          cur /= r;
+        }
+        if (pass == 0) {
+          // x holds A: keep A[0] in slot M (free: the buffers have W slots), then conj(A .* F(b)) in place
+          if (lane == 0) *reinterpret_cast<double2*>(x + 2 * M) = *reinterpret_cast<const double2*>(x);
+          wave_sync();
+          for (int k = lane; k < M; k += SPX_WAVE) {
+            const cplx a = ld(x, k);
+            const double2 b = *reinterpret_cast<const double2*>(P.bfft + 2 * k);
+            const double cr = a.r * b.x - a.i * b.y;
+            const double ci = a.r * b.y + a.i * b.x;
+            *reinterpret_cast<double2*>(x + 2 * k) = make_double2(cr, -ci);
+          }
+          wave_sync();
+        }
+      }
+      // x holds F(conj(C)), slot M of the buffer that held A holds A[0]: with an even number of stages that is x
+      // itself, otherwise y -- both cases: the A buffer is the one the second transform started from
+      const double inv = 1.0 / (double)M;
+      const double* abuf = (P.nstagesM & 1) ? y : x;
+      const cplx A0 = ld(abuf, M);
+      wave_sync();
+      // scatter into the other buffer (the transform result must stay readable while it is permuted)
+      for (int q = lane; q < M; q += SPX_WAVE) {
+        const cplx c = ld(x, q);
+        const double cr = c.r * inv, ci = -c.i * inv;
+        *reinterpret_cast<double2*>(y + 2 * P.iperm[q]) = make_double2(x0.r + cr, x0.i + ci);
+      }
+      if (lane == 0) *reinterpret_cast<double2*>(y) = make_double2(x0.r + A0.r, x0.i + A0.i);
+      wave_sync();
+      { double* t = x; x = y; y = t; }
+    } else {
+      int sprod = 1, cur = W;
+      for (int stg = 0; stg < P.nstages; stg++) {
+        const int r = P.radix[stg];
+        dft_stage(W, ltw, r, sprod, cur, x, y, lane, SPX_WAVE);
+        wave_sync();
+        double* t = x; x = y; y = t;
+        sprod *= r;
+        cur /= r;
+      }
     }
     ASTAMP(1);
     // untangle the packed transform:  X[k] = E[k] + e^{-2 pi i k/N} O[k]

@@ -112,20 +112,59 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
   d.one_minus_alpha = 1 - d.alpha;                     // float, speedy.c:74
 
   const int W = d.W;
+  // Rader applies to a prime W > 64 whose W - 1 has no prime factor above 13 (DESIGN.md "DFT spec")
+  const int M = W - 1;
+  bool rader = W > 64;
+  for (int q = 2; rader && (long)q * q <= W; q++) if (W % q == 0) rader = false;
+  if (rader) {
+    int m = M;
+    for (int q = 2; q <= 13; q++) while (m % q == 0) m /= q;
+    rader = (m == 1);
+  }
+  if (rader) {
+    d.rader = 1;
+    d.nstagesM = factor_radices(M, d.radixM);
+  }
   const size_t n_tw = 2 * (size_t)W, n_win = (size_t)W, n_tf = d.F + 1, n_tp = d.Pp + 1;
-  const size_t bytes = sizeof(double) * 2 * n_tw + sizeof(float) * (n_win + n_tf + n_tp + 8);
+  const size_t n_rd = rader ? 2 * (size_t)M : 0;  // doubles in each of twM and bfft
+  const size_t n_ri = rader ? (size_t)M : 0;      // ints in each of perm and iperm
+  const size_t bytes = sizeof(double) * (2 * n_tw + 2 * n_rd) + sizeof(float) * (n_win + n_tf + n_tp + 8) +
+                       sizeof(int) * 2 * n_ri;
   std::vector<unsigned char> host(bytes, 0);
   double* tw = reinterpret_cast<double*>(host.data());
   double* tw2 = tw + n_tw;
-  float* win = reinterpret_cast<float*>(tw2 + n_tw);
+  double* twM = tw2 + n_tw;
+  double* bfft = twM + n_rd;
+  float* win = reinterpret_cast<float*>(bfft + n_rd);
   float* tf = win + n_win;
   float* tp = tf + n_tf;
+  int* perm = reinterpret_cast<int*>(tp + n_tp + 8);
+  int* iperm = perm + n_ri;
   for (int t = 0; t < W; t++) {
     tw[2 * t] = cos(2.0 * M_PI * t / W);
     tw[2 * t + 1] = -sin(2.0 * M_PI * t / W);
     tw2[2 * t] = cos(2.0 * M_PI * t / (2.0 * W));
     tw2[2 * t + 1] = -sin(2.0 * M_PI * t / (2.0 * W));
     win[t] = 0.54 - 0.46 * cos(2 * M_PI * t / (W - 1.0));  // speedy.c:256-258
+  }
+  if (rader) {
+    for (int t = 0; t < M; t++) {
+      twM[2 * t] = cos(2.0 * M_PI * t / M);
+      twM[2 * t + 1] = -sin(2.0 * M_PI * t / M);
+    }
+    int g = 2;  // smallest primitive root of W
+    for (; g < W; g++) {
+      long v = 1;
+      int k = 0;
+      do { v = (v * g) % W; k++; } while (v != 1);
+      if (k == M) break;
+    }
+    long v = 1;
+    for (int k = 0; k < M; k++) { perm[k] = (int)v; v = (v * g) % W; }
+    for (int q = 0; q < M; q++) iperm[q] = perm[(M - q) % M];  // g^-q = g^(M-q)
+    std::vector<double> b(2 * (size_t)M);
+    for (int q = 0; q < M; q++) { b[2 * q] = tw[2 * iperm[q]]; b[2 * q + 1] = tw[2 * iperm[q] + 1]; }
+    spx_host_dft(M, d.radixM, d.nstagesM, twM, b.data(), bfft);
   }
   for (int i = 0; i <= d.F; i++) tf[i] = (d.F - i) / (float)d.F;    // speedy.c:597
   for (int i = 0; i <= d.Pp; i++) tp[i] = (d.Pp - i) / (float)d.Pp;  // speedy.c:604
@@ -139,9 +178,13 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
   unsigned char* base = static_cast<unsigned char*>(p->tables);
   d.tw = reinterpret_cast<const double*>(base);
   d.tw2 = d.tw + n_tw;
-  d.window = reinterpret_cast<const float*>(d.tw2 + n_tw);
+  d.twM = d.tw2 + n_tw;
+  d.bfft = d.twM + n_rd;
+  d.window = reinterpret_cast<const float*>(d.bfft + n_rd);
   d.taperF = d.window + n_win;
   d.taperP = d.taperF + n_tf;
+  d.perm = reinterpret_cast<const int*>(d.taperP + n_tp + 8);
+  d.iperm = d.perm + n_ri;
   return p;
 }
 

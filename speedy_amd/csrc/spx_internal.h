@@ -27,6 +27,15 @@ struct SpxPlanDev {
   const float* window; // [W]  Hamming                         (speedy.c:256-258)
   const float* taperF; // [F+1]  (F-i)/(float)F               (speedy.c:597)
   const float* taperP; // [P+1]  (P-i)/(float)P               (speedy.c:604)
+  // Rader's algorithm for a large prime W whose W-1 is smooth (44.1 kHz: W = 661, 660 = 4*3*5*11; DESIGN.md "DFT
+  // spec"): the W-point transform as a cyclic convolution of length M = W-1 done with an M-point plan.
+  int rader;                     // 0: plain mixed-radix stages
+  int nstagesM;
+  int radixM[SPX_MAX_STAGES];
+  const double* twM;   // [M]  (cos, -sin)(2 pi t / M)
+  const double* bfft;  // [M]  M-point transform of b[q] = tw[iperm[q]]
+  const int* perm;     // [M]  perm[p]  = g^p  mod W, g the smallest primitive root
+  const int* iperm;    // [M]  iperm[q] = g^-q mod W
 };
 
 // Per-stream job in device memory.  A job covers "everything new since the last call": batch jobs start
@@ -97,6 +106,8 @@ void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_str
                      const int16_t* in, int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
                      const int* speed_ready, bool speedup_only, hipStream_t st);
 size_t spx_analysis_lds_bytes(const SpxPlanDev& P);
+// The DFT of the spec run on the host (same operation order as the kernel): used to build the Rader tables.
+void spx_host_dft(int n, const int* radix, int nstages, const double* tw, const double* in, double* out);
 size_t spx_walk_lds_bytes(const SpxPlanDev& P, int max_channels);
 size_t spx_tension_lds_bytes();
 int spx_analysis_tile_frames();
