@@ -332,10 +332,14 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // count; the walk kernel starts at once on the caller's stream and runs every event whose speed is there.  Same
   // arithmetic, same results; only the serialisation of the kernels goes.
   static const bool env_serial = getenv("SPX_SERIAL") != nullptr;  // tuning: kernels back to back on one stream
-  // The three kernels hand frames over through flags that consumers poll, so every consumer workgroup must be able
-  // to be resident TOGETHER with at least one producer workgroup, or the producers could starve behind spinning
-  // consumers.  Allow for the dispatcher putting twice the average number of per-stream workgroups on a CU; batches
-  // that do not fit that bound run the kernels back to back instead (same results).
+  // The three kernels hand frames over through flags that consumers poll.  Polling workgroups hold their CU resources
+  // while they wait, so the mode is only safe if the analysis kernel -- which waits for nothing -- can always place a
+  // workgroup somewhere: then it runs to completion whatever happens, and everything downstream follows.  A CU is
+  // closed to it once the consumers (walk + tension workgroup of a stream) hold more than lds_per_cu - analysis_lds
+  // bytes of its LDS or more than 32 - 4 of its wave slots; however the dispatcher packs them, n streams can close at
+  // most (their total LDS) / (that LDS bound) plus (their total waves) / 29 CUs.  Concurrent iff that leaves a CU open
+  // (in practice the dispatcher spreads 256 workgroups one per CU and none is closed).  Batches beyond the bound run
+  // the kernels in stream order instead (same results).
   static int cu_count = 0;
   static size_t lds_per_cu = 0;
   if (cu_count == 0) {
@@ -349,8 +353,16 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     }
   }
   const size_t per_stream_lds = spx_walk_lds_bytes(d, maxC) + spx_tension_lds_bytes();
-  const size_t k_per_cu = 2 * (((size_t)n + cu_count - 1) / cu_count);
-  const bool co_resident = k_per_cu * per_stream_lds + spx_analysis_lds_bytes(d) <= lds_per_cu && k_per_cu * 12 + 4 <= 32;
+  const size_t per_stream_waves = (n <= 256 ? 8 : 4) + 4;  // walk (spx_launch_walk's choice) + tension
+  bool co_resident = false;
+  if (spx_analysis_lds_bytes(d) < lds_per_cu) {
+    const size_t lds_closing = lds_per_cu - spx_analysis_lds_bytes(d) + 1;
+    const size_t closed = ((size_t)n * per_stream_lds) / lds_closing + ((size_t)n * per_stream_waves) / 29;
+    co_resident = closed < (size_t)cu_count;
+    // ... and only worth it when the analysis keeps its throughput beside the consumers: a stream's workgroups and
+    // still two analysis workgroups on a CU (measured at 22.05 kHz, where only one fits: 4.1 ms back to back, 5.2 ms concurrent)
+    if (per_stream_lds + 2 * spx_analysis_lds_bytes(d) > lds_per_cu) co_resident = false;
+  }
   const bool want_concurrent = g_concurrent && !env_serial && co_resident && do_a && do_w;
   // Pipelining in time needs both stages in one call; the separate entry points run one chunk.  A batch too large for
   // the concurrent mode gets four time chunks unless the caller chose a count: the analysis of chunk c+1 then overlaps

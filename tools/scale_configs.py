@@ -23,11 +23,16 @@ for rate, ch, speed, nl in [(16000, 1, 3.5, 1.0), (16000, 1, 1.5, 1.0), (22050, 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     reps = 3
+    plan.L.spx_set_timing(1)
     for _ in range(reps):
         b.run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    print("rate=%5d ch=%d speed=%.1f nl=%.0f  %.3f ms/call  %.0f Msamples/s (frames)" %
-          (rate, ch, speed, nl, dt * 1e3, ns * n / dt / 1e6))
+    plan.L.spx_set_timing(0)
+    import ctypes as C
+    sa, sw, nc = C.c_double(0), C.c_double(0), C.c_int(0)
+    plan.L.spx_timing_collect(C.byref(sa), C.byref(sw), C.byref(nc))
+    print("rate=%5d ch=%d speed=%.1f nl=%.0f  %.3f ms/call  %.0f Msamples/s (frames)   analysis %.2f walk %.2f ms" %
+          (rate, ch, speed, nl, dt * 1e3, ns * n / dt / 1e6, sa.value / reps, sw.value / reps))
     del b
     torch.cuda.empty_cache()
