@@ -170,13 +170,13 @@ __device__ __forceinline__ int any_sample(const WalkCtx& X, pos_t a, int c) {
 
 // Make the window cover [pos, pos + need).  Uniform across the workgroup.  The biased mono signal and its
 // shifted copy are built here, once per refill, so a pitch step never touches HBM for its input.
-template <int NW, bool FAST>
+template <int NW, int FAST>
 __device__ __forceinline__ void ensure_window(WalkCtx& X, pos_t pos, int need) {
   constexpr int NT = 64 * NW;
   if (X.wbase >= 0 && pos >= X.wbase && pos + need <= X.wbase + X.wcap) return;
   lds_sync<NW>();  // everyone is done reading the old window
   const pos_t nb = pos & ~7;
-  const int C = FAST ? 1 : X.C;
+  const int C = (FAST == 1) ? 1 : X.C;
   if (C == 1) {
     const int16_t* __restrict__ src = X.in + nb;
     const pos_t room = X.limit - nb;  // frames of real input from nb on
@@ -222,7 +222,7 @@ __device__ __forceinline__ void ensure_window(WalkCtx& X, pos_t pos, int need) {
   }
   X.wbase = nb;
   lds_sync<NW>();
-  if (FAST) {
+  if (FAST == 1 || (FAST == 2 && C == 1)) {
     // One thread per decimated index m: it reads the 2*skip-1 window samples m*skip .. m*skip+2*skip-2 once and slides
     // the sum over them, giving element m of every plane.  |sum| < 2^18 and skip <= 7, so the truncating division is
     // exactly mulhi(|sum|, ceil(2^32 / skip)).
@@ -244,6 +244,28 @@ __device__ __forceinline__ void ensure_window(WalkCtx& X, pos_t pos, int need) {
         sum += (int)w[skip + r] - (int)w[r];
       }
     }
+  } else if (FAST == 2) {
+    // Several channels: the decimated sample is the sum of skip*C RAW samples divided ONCE by skip*C (the dependency's
+    // downSampleInput), not the mean of the per-frame channel means.  |sum| < 2^21, skip*C <= 56: mulhi is still exact.
+    const int skip = X.skip, div = skip * C;
+    const unsigned M = (unsigned)((0x100000000ull + (unsigned)div - 1) / (unsigned)div);
+    for (int m = threadIdx.x; (m + 1) * skip <= X.wcap; m += NT) {
+      const short* w = X.raw + (size_t)m * div;
+      int sum = 0;
+      for (int j = 0; j < div; j++) sum += (int)w[j];
+      for (int r = 0; r < skip; r++) {
+        if ((m + 1) * skip + r > X.wcap) break;
+        const unsigned mag = (unsigned)(sum < 0 ? -sum : sum);
+        const int qm = (int)__umulhi(mag, M);
+        const unsigned short u = (unsigned short)((sum < 0 ? -qm : qm) + 32768);
+        X.pl[r * X.plStride + m] = u;
+        if (m > 0) X.plB[r * X.plStride + m - 1] = u;
+        // slide by one frame: drop frame r, take frame skip + r (its samples may lie past the window: unused then)
+        for (int c = 0; c < C; c++) sum += (int)w[(skip + r) * C + c] - (int)w[r * C + c];
+      }
+    }
+  }
+  if (FAST) {
     lds_sync<NW>();
   }
 }
@@ -363,7 +385,7 @@ __device__ __forceinline__ void select_finish(const Sel& S, int* retBest, int* r
 // One lane per lag, the whole sum in the lane (no cross-lane traffic): used for the coarse search, which every
 // wave runs redundantly.  A0/A1: dword views of the signal array and of its copy shifted by one sample; o = offset
 // of the search position inside them.
-template <bool WANT_MAX, bool FAST>
+template <bool WANT_MAX, int FAST>
 __device__ __forceinline__ void search_lane_per_lag(const unsigned* A0, const unsigned* A1, int o, int minP, int nl,
                                                     Sel& S, unsigned* dlane = nullptr) {
   const int lane = threadIdx.x & 63;
@@ -377,7 +399,7 @@ __device__ __forceinline__ void search_lane_per_lag(const unsigned* A0, const un
     unsigned d = sad_run(ap, bp, 0, nfull);
     if (valid && (p & 1)) d = __builtin_amdgcn_sad_u16(ap[nfull] & 0xffffu, bp[nfull] & 0xffffu, d);  // term i = p-1
     if (dlane && base == 0) *dlane = d;
-    select_fold<WANT_MAX, FAST>(S, d, minP + base, valid);
+    select_fold<WANT_MAX, (FAST != 0)>(S, d, minP + base, valid);
   }
 }
 
@@ -385,7 +407,7 @@ __device__ __forceinline__ void search_lane_per_lag(const unsigned* A0, const un
 // (one lane per lag), the partial sums meet in LDS (ds_add_u32 into `buf`, which is all zero on entry), one
 // LDS barrier, then every wave folds the totals itself.  `other` is the buffer the PREVIOUS step used; every wave
 // is past reading it once this step's barrier is crossed, so it is cleared here for the next step.
-template <int NW, bool WANT_MAX, bool FAST>
+template <int NW, bool WANT_MAX, int FAST>
 __device__ __forceinline__ void search_split(const unsigned* A0, const unsigned* A1, int o, int minP, int nl,
                                              unsigned* buf, unsigned* other, Sel& S, WalkCtx& X, int sb, unsigned* dlane = nullptr) {
   (void)X; (void)sb;
@@ -422,12 +444,12 @@ __device__ __forceinline__ void search_split(const unsigned* A0, const unsigned*
     const bool valid = base + lane < nl;
     const unsigned d = valid ? buf[base + lane] : 0u;
     if (dlane && base == 0) *dlane = d;
-    select_fold<WANT_MAX, FAST>(S, d, minP + base, valid);
+    select_fold<WANT_MAX, (FAST != 0)>(S, d, minP + base, valid);
   }
 }
 
 // findPitchPeriod at absolute position pos (all threads return the same value).
-template <int NW, bool FAST>
+template <int NW, int FAST>
 __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X, WalkState& st, pos_t pos) {
   constexpr int NT = 64 * NW;
   const int tid = threadIdx.x;
@@ -534,10 +556,10 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
 }
 
 // Append n frames copied from absolute input position a.
-template <int NW, bool FAST>
+template <int NW, int FAST>
 __device__ __forceinline__ void emit_copy(const WalkCtx& X, WalkState& st, pos_t a, pos_t n) {
   constexpr int NT = 64 * NW;
-  const int C = FAST ? 1 : X.C;
+  const int C = (FAST == 1) ? 1 : X.C;
   if (st.out_n + n > X.out_cap) st.overflow = 1;
   pos_t nv = X.out_cap - st.out_n;  // frames that still fit
   if (nv > n) nv = n;
@@ -546,6 +568,10 @@ __device__ __forceinline__ void emit_copy(const WalkCtx& X, WalkState& st, pos_t
   if (C == 1 && X.wbase >= 0 && o >= 0 && o + n <= X.wcap) {  // whole run inside the LDS window
     const unsigned short* w = X.monoH + o;
     for (int t = threadIdx.x; t < (int)nv; t += NT) dst[t] = (int16_t)((int)w[t] - 32768);
+  } else if (FAST == 2 && X.wbase >= 0 && o >= 0 && o + n <= X.wcap) {  // multi-channel run inside the window
+    const short* w = X.raw + (size_t)o * C;
+    const int total = (int)nv * C;
+    for (int e = threadIdx.x; e < total; e += NT) dst[e] = w[e];
   } else {
     const pos_t total = nv * C;
     for (pos_t e = threadIdx.x; e < total; e += NT) {
@@ -561,18 +587,18 @@ __device__ __forceinline__ void emit_copy(const WalkCtx& X, WalkState& st, pos_t
 // Append n frames of cross-fade: out[t] = (down[t]*(n-t) + up[t]*t)/n, integer, truncating toward zero.
 // |numerator| <= 32768*n < 2^31; the quotient is taken as trunc(|num| * (1/n) + 2^-20) in double, which is exact:
 // non-integer quotients are at least 1/n >= 2^-11 below the next integer, integer ones land 2^-20 above.
-template <int NW, bool FAST>
+template <int NW, int FAST>
 __device__ __forceinline__ void emit_overlap_add(const WalkCtx& X, pos_t a_down, pos_t a_up, int n,
                                                  pos_t out_at) {
   constexpr int NT = 64 * NW;
-  const int C = FAST ? 1 : X.C;
+  const int C = (FAST == 1) ? 1 : X.C;
   const double inv = 1.0 / (double)n;
   pos_t nv64 = X.out_cap - out_at;
   const int nv = nv64 > n ? n : (nv64 < 0 ? 0 : (int)nv64);
   int16_t* __restrict__ dst = X.out + (size_t)out_at * C;
   const pos_t od = a_down - X.wbase, ou = a_up - X.wbase;
   const bool inwin = X.wbase >= 0 && od >= 0 && ou >= 0 && od + n <= X.wcap && ou + n <= X.wcap;
-  if (FAST || (C == 1 && inwin)) {  // FAST: ensure_window(pos, maxRequired + ...) of the search covers both ramps
+  if (FAST == 1 || (C == 1 && inwin)) {  // FAST: ensure_window(pos, maxRequired + ...) of the search covers both ramps
     const unsigned short* wd = X.monoH + od;
     const unsigned short* wu = X.monoH + ou;
     // FAST: n <= maxPeriod < 512 (rates below 32 kHz), so with eight waves this is one predicated pass, no loop
@@ -583,6 +609,20 @@ __device__ __forceinline__ void emit_overlap_add(const WalkCtx& X, pos_t a_down,
       const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
       dst[t] = (int16_t)(num < 0 ? -qm : qm);
       if (FAST && NT >= 512) break;
+    }
+  } else if (FAST == 2) {
+    // multi-channel speed-up kernel: both ramps lie in the window; element e = t*C + c of each is contiguous in `raw`
+    const short* rd = X.raw + (size_t)od * C;
+    const short* ru = X.raw + (size_t)ou * C;
+    const int total = nv * C;
+    const unsigned invC = (0x10000u + (unsigned)C - 1u) / (unsigned)C;  // e / C for e < 8192, C <= 8
+    for (int e = threadIdx.x; e < total; e += NT) {
+      const int t = (C == 2) ? (e >> 1) : (int)(((unsigned)e * invC) >> 16);
+      const int d = rd[e], u = ru[e];
+      const int num = d * (n - t) + u * t;
+      const int mag = num < 0 ? -num : num;
+      const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
+      dst[e] = (int16_t)(num < 0 ? -qm : qm);
     }
   } else {
     const int total = nv * C;
@@ -599,7 +639,7 @@ __device__ __forceinline__ void emit_overlap_add(const WalkCtx& X, pos_t a_down,
 }
 
 // processStreamInput with `avail` frames handed over so far (absolute count).
-template <int NW, bool FAST>
+template <int NW, int FAST>
 __device__ __forceinline__ void tsm_process(const SpxPlanDev& P, WalkCtx& X, WalkState& st, float speed, pos_t avail) {
   const int maxRequired = P.maxRequired;
   if ((double)speed > 1.00001 || (double)speed < 0.99999) {
@@ -661,7 +701,7 @@ __device__ __forceinline__ void tsm_process(const SpxPlanDev& P, WalkCtx& X, Wal
 // The pitch steps one event can run = the loop of processStreamInput for speed > 1 with `avail` frames handed over.
 // The caller guarantees avail - st.base >= maxRequired.  Returns false when a step fails (n == 0): the dependency
 // then returns without removing the input it has consumed in this call, so st.base keeps its value.
-template <int NW>
+template <int NW, int FAST>
 __device__ __forceinline__ bool fast_steps(const SpxPlanDev& P, WalkCtx& X, WalkState& st, float speed, pos_t avail) {
   const int maxRequired = P.maxRequired;
   const bool ge2 = speed >= 2.0f;
@@ -671,12 +711,12 @@ __device__ __forceinline__ bool fast_steps(const SpxPlanDev& P, WalkCtx& X, Walk
     if (st.remaining > 0) {
       int n = st.remaining;
       if (n > maxRequired) n = maxRequired;
-      ensure_window<NW, true>(X, pos, n);
-      emit_copy<NW, true>(X, st, pos, n);
+      ensure_window<NW, FAST>(X, pos, n);
+      emit_copy<NW, FAST>(X, st, pos, n);
       st.remaining -= n;
       pos += n;
     } else {
-      const int period = find_pitch_period<NW, true>(P, X, st, pos);
+      const int period = find_pitch_period<NW, FAST>(P, X, st, pos);
       int n;
       if (ge2) {
         n = uni((int)((float)period / sm1));
@@ -687,7 +727,7 @@ __device__ __forceinline__ bool fast_steps(const SpxPlanDev& P, WalkCtx& X, Walk
       if (st.out_n + n > X.out_cap) st.overflow = 1;
       if (n == 0) return false;
       STAMP(11);
-      emit_overlap_add<NW, true>(X, pos, pos + period, n, st.out_n);
+      emit_overlap_add<NW, FAST>(X, pos, pos + period, n, st.out_n);
       STAMP(13);
       st.out_n += n;
       pos += period + n;
@@ -709,7 +749,7 @@ __device__ __forceinline__ bool speed_is_unity(float speed) {  // the dependency
 // Most nonlinear events cannot run a step (a step needs maxRequired frames, an event brings B): those cost a few
 // scalar instructions.  The speeds of 64 consecutive events sit in one VGPR (lane = event), so picking one is a
 // v_readlane, not a memory access.
-template <int NW>
+template <int NW, int FAST>
 __device__ __forceinline__ void fast_events(const SpxPlanDev& P, WalkCtx& X, WalkState& st, const float* scr, pos_t ev0,
                                             pos_t ev1, pos_t K, pos_t& avail, int B, bool linear, pos_t n_in, bool fin,
                                             float& curSpeed) {
@@ -753,10 +793,10 @@ __device__ __forceinline__ void fast_events(const SpxPlanDev& P, WalkCtx& X, Wal
     }
     STAMP(0);
     if (unity) {
-      emit_copy<NW, true>(X, st, st.base, avail - st.base);
+      emit_copy<NW, FAST>(X, st, st.base, avail - st.base);
       st.base = avail;
     } else if (avail - st.base >= maxRequired) {
-      (void)fast_steps<NW>(P, X, st, speed, avail);
+      (void)fast_steps<NW, FAST>(P, X, st, speed, avail);
     }
     STAMP(12);
     if (flush) {
@@ -804,7 +844,7 @@ static __host__ __device__ inline WalkLds walk_lds_layout(const SpxPlanDev& P, i
   return L;
 }
 
-template <int NW, bool FAST>
+template <int NW, int FAST>
 __global__ void __launch_bounds__(64 * NW)
 spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const int16_t* __restrict__ in_base,
                 int16_t* __restrict__ out_base, int64_t* __restrict__ n_out, SpxStreamState* __restrict__ states,
@@ -913,8 +953,8 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
     if (ev1 < ev0) ev1 = ev0;
     const pos_t ev_end = ev1 + (fin ? 1 : 0);
     (void)ev_end;
-    if constexpr (FAST) {
-      fast_events<NW>(P, X, st, scr, ev0, ev1, (pos_t)K, avail, B, nl == 0.0f, (pos_t)S.n_in, fin, curSpeed);
+    if constexpr (FAST != 0) {
+      fast_events<NW, FAST>(P, X, st, scr, ev0, ev1, (pos_t)K, avail, B, nl == 0.0f, (pos_t)S.n_in, fin, curSpeed);
     } else {
       for (pos_t ev = ev0; ev < ev_end; ev++) {
         pos_t expected = 0;
@@ -983,18 +1023,23 @@ void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_str
   if (const char* e = getenv("SPX_WALK_NW")) nw = atoi(e);
 #define SPX_LAUNCH_WALK(NWV)                                                                                     \
   do {                                                                                                           \
-    if (fast)                                                                                                    \
-      hipLaunchKernelGGL((spx_walk_kernel<NWV, true>), dim3(n_streams), dim3(64 * NWV), LY.total, st, P, streams,  \
-                         in, out, n_out, states, scratch, maxC, speed_ready);                                      \
+    if (fast == 1)                                                                                               \
+      hipLaunchKernelGGL((spx_walk_kernel<NWV, 1>), dim3(n_streams), dim3(64 * NWV), LY.total, st, P, streams,   \
+                         in, out, n_out, states, scratch, maxC, speed_ready);                                    \
+    else if (fast == 2)                                                                                          \
+      hipLaunchKernelGGL((spx_walk_kernel<NWV, 2>), dim3(n_streams), dim3(64 * NWV), LY.total, st, P, streams,   \
+                         in, out, n_out, states, scratch, maxC, speed_ready);                                    \
     else                                                                                                         \
-      hipLaunchKernelGGL((spx_walk_kernel<NWV, false>), dim3(n_streams), dim3(64 * NWV), LY.total, st, P, streams, \
-                         in, out, n_out, states, scratch, maxC, speed_ready);                                      \
+      hipLaunchKernelGGL((spx_walk_kernel<NWV, 0>), dim3(n_streams), dim3(64 * NWV), LY.total, st, P, streams,   \
+                         in, out, n_out, states, scratch, maxC, speed_ready);                                    \
   } while (0)
-  // FAST: every stream mono and speeding up (speed > 1, 0 <= nonlinear <= 1: the stage never sees a speed below 1),
-  // decimated search, and at most 64 lags in either search (rates below 32 kHz)
-  const bool fast = maxC == 1 && speedup_only && P.skip >= 2 &&
-                    (P.maxPeriod / P.skip - P.minPeriod / P.skip + 1) <= 64 && (8 * P.skip + 1) <= 64 &&
-                    !getenv("SPX_WALK_GENERIC");
+  // FAST (1: every stream mono, 2: some multi-channel): all streams speeding up (speed > 1, 0 <= nonlinear <= 1: the
+  // stage never sees a speed below 1), decimated search, at most 64 lags in either search (rates below 32 kHz), and the
+  // usual 4096-frame window
+  int fast = 0;
+  if (speedup_only && P.skip >= 2 && (P.maxPeriod / P.skip - P.minPeriod / P.skip + 1) <= 64 && (8 * P.skip + 1) <= 64 &&
+      LY.wcap == 4096 && maxC <= 8 && !getenv("SPX_WALK_GENERIC"))
+    fast = (maxC == 1) ? 1 : 2;
 #ifdef SPX_STAMPS
   if (nw == 4) SPX_LAUNCH_WALK(4); else SPX_LAUNCH_WALK(8);  // the diagnostic build carries two kernels only
   return;
