@@ -117,6 +117,15 @@ double spx_timing_last_tension_ms(void);
 /* ---- plain device-memory helpers (so that C/C++ hosts need no HIP headers) ---- */
 void* spx_device_alloc(size_t bytes);
 void spx_device_free(void* p);
+/* Gather the produced frames of a finished batch into one contiguous buffer so that a single device-to-host copy
+ * moves them: packed[offsets[i] .. offsets[i+1]) = the n_out[i]*channels[i] int16 values of stream i.
+ *   jobs      HOST  the job table the batch ran with (out_off, channels)
+ *   out,n_out DEVICE as written by spx_batch_run
+ *   packed    DEVICE int16, at least sum(max(n_out,0)*channels) values (the size of `out` always suffices)
+ *   offsets   DEVICE int64[n_streams + 1], written here: exclusive prefix sums in int16 values
+ * Runs on hip_stream after the batch; returns 0 or a negative error. */
+int spx_batch_pack_outputs(const spx_stream_job* jobs, int n_streams, const int16_t* out, const int64_t* n_out,
+                           int16_t* packed, int64_t* offsets, void* hip_stream);
 int spx_copy_to_device(void* dst, const void* src, size_t bytes, void* hip_stream);
 int spx_copy_to_host(void* dst, const void* src, size_t bytes, void* hip_stream);
 int spx_stream_synchronize(void* hip_stream);

@@ -55,6 +55,7 @@ SYMBOLS = {
     "spx_device_free": (None, [C.c_void_p]),
     "spx_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "spx_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "spx_batch_pack_outputs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spx_stream_synchronize": (C.c_int, [C.c_void_p]),
     # include/sonic2.h
     "sonicCreateStream": (C.c_void_p, [C.c_int, C.c_int]),

@@ -122,6 +122,20 @@ class Batch:
             res.append(out[self.out_offs[i]:self.out_offs[i] + int(nout[i]) * c].copy())
         return res
 
+    def pack_outputs(self, stream=None):
+        """Enqueue the gather of all produced frames into one contiguous device buffer (after run() on the same
+        stream).  Returns (packed int16 device tensor, offsets int64[n+1] device tensor); stream i is
+        packed[offsets[i]:offsets[i+1]].  One device-to-host copy then moves a whole batch's output."""
+        if getattr(self, "d_packed", None) is None:
+            self.d_packed = torch.empty_like(self.d_out)
+            self.d_offsets = torch.zeros(self.n + 1, dtype=torch.int64, device=self.device)
+        hs = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        rc = self.plan.L.spx_batch_pack_outputs(self.jobs, self.n, self.d_out.data_ptr(), self.d_nout.data_ptr(),
+                                                self.d_packed.data_ptr(), self.d_offsets.data_ptr(), hs)
+        if rc != 0:
+            raise RuntimeError("spx_batch_pack_outputs: " + self.plan.L.spx_last_error().decode())
+        return self.d_packed, self.d_offsets
+
     def tap_arrays(self, i):
         """tension/speed/features rows of stream i (host numpy)."""
         torch.cuda.synchronize(self.device)

@@ -508,6 +508,60 @@ int spx_copy_to_device(void* dst, const void* src, size_t bytes, void* hs) {
   HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(hs)));
   return 0;
 }
+}  // extern "C"
+
+// ---- output packing: offsets by one workgroup (serial prefix over <= a few thousand streams), then one workgroup per
+// stream copying its frames with coalesced loads/stores ----
+__global__ void spx_pack_offsets_kernel(const int64_t* __restrict__ n_out, const int* __restrict__ channels, int n,
+                                        int64_t* __restrict__ offsets) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int64_t acc = 0;
+    for (int i = 0; i < n; i++) {
+      offsets[i] = acc;
+      const int64_t k = n_out[i];
+      acc += (k > 0 ? k : -k) * channels[i];  // a negative count flags an overflowed stream: its frames are still there
+    }
+    offsets[n] = acc;
+  }
+}
+__global__ void __launch_bounds__(256)
+spx_pack_copy_kernel(const int16_t* __restrict__ out, const int64_t* __restrict__ out_offs,
+                     const int64_t* __restrict__ offsets, int16_t* __restrict__ packed) {
+  const int i = blockIdx.x;
+  const int16_t* src = out + out_offs[i];
+  int16_t* dst = packed + offsets[i];
+  const int64_t cnt = offsets[i + 1] - offsets[i];
+  for (int64_t e = threadIdx.x; e < cnt; e += 256) dst[e] = src[e];
+}
+
+extern "C" {
+int spx_batch_pack_outputs(const spx_stream_job* jobs, int n, const int16_t* out, const int64_t* n_out, int16_t* packed,
+                           int64_t* offsets, void* hs) {
+  if (!jobs || n <= 0 || !out || !n_out || !packed || !offsets) return fail(-1, "spx_batch_pack_outputs: bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(hs);
+  // small per-stream tables (channels, output offsets): staged through one device allocation kept for reuse
+  static void* d_tab = nullptr;
+  static size_t d_tab_cap = 0;
+  const size_t need = (size_t)n * (sizeof(int64_t) + sizeof(int));
+  if (need > d_tab_cap) {
+    if (d_tab) (void)hipFree(d_tab);
+    d_tab = nullptr;
+    if (hipMalloc(&d_tab, need) != hipSuccess) { d_tab_cap = 0; return fail(-2, "spx_batch_pack_outputs: allocation failed"); }
+    d_tab_cap = need;
+  }
+  std::vector<unsigned char> h(need);
+  int64_t* h_off = reinterpret_cast<int64_t*>(h.data());
+  int* h_ch = reinterpret_cast<int*>(h.data() + (size_t)n * sizeof(int64_t));
+  for (int i = 0; i < n; i++) { h_off[i] = jobs[i].out_off; h_ch[i] = jobs[i].channels; }
+  HIPCHK(hipMemcpyAsync(d_tab, h.data(), need, hipMemcpyHostToDevice, st));
+  const int64_t* d_off = reinterpret_cast<const int64_t*>(d_tab);
+  const int* d_ch = reinterpret_cast<const int*>(static_cast<unsigned char*>(d_tab) + (size_t)n * sizeof(int64_t));
+  hipLaunchKernelGGL(spx_pack_offsets_kernel, dim3(1), dim3(64), 0, st, n_out, d_ch, n, offsets);
+  hipLaunchKernelGGL(spx_pack_copy_kernel, dim3(n), dim3(256), 0, st, out, d_off, offsets, packed);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int spx_copy_to_host(void* dst, const void* src, size_t bytes, void* hs) {
   HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(hs)));
   return 0;

@@ -301,3 +301,24 @@ def test_many_streams_fall_back_to_sequential_launches(orc):
     refs = [_oracle(orc, x, rate, 1, 3.5, 1.0, 0.0, False)["out"] for x in base]
     for i in range(600):
         assert np.array_equal(outs[i], refs[i % 12]), i
+
+
+def test_pack_outputs_matches_per_stream_results():
+    """spx_batch_pack_outputs: the device-side gather of all produced frames (one D2H for a whole batch)."""
+    from speedy_amd.batch import Batch, Plan
+    from speedy_amd.synth import speech_like
+    rate = 16000
+    chs = [1, 2, 1, 3, 1]
+    lens = [0, 5000, 20000, 7001, 300]
+    streams = [speech_like(n, rate, seed=40 + i, channels=c) for i, (n, c) in enumerate(zip(lens, chs))]
+    b = Batch(Plan(rate, False), lens, chs, [3.5, 1.5, 2.0, 3.5, 3.5], 1.0, 0.0)
+    b.upload(streams)
+    b.run()
+    packed, offs = b.pack_outputs()
+    outs = b.results()
+    offs = offs.cpu().numpy()
+    packed = packed.cpu().numpy()
+    assert offs[0] == 0 and offs[-1] == sum(o.size for o in outs)
+    for i, o in enumerate(outs):
+        assert offs[i + 1] - offs[i] == o.size
+        assert np.array_equal(packed[offs[i]:offs[i + 1]], o), i
