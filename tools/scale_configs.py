@@ -10,11 +10,14 @@ from speedy_amd.batch import Batch, Plan  # noqa: E402
 from speedy_amd.synth import speech_like  # noqa: E402
 
 ns = 256
+chunks = int(os.environ.get("SPX_CHUNKS", "0"))  # 0 = the engine's own choice
 for rate, ch, speed, nl in [(16000, 1, 3.5, 1.0), (16000, 1, 1.5, 1.0), (22050, 1, 1.5, 1.0), (22050, 1, 3.5, 1.0),
                             (16000, 2, 3.5, 1.0), (22050, 2, 1.5, 1.0), (44100, 1, 3.5, 1.0), (48000, 2, 3.5, 1.0),
                             (16000, 1, 2.0, 0.0), (16000, 1, 0.5, 1.0)]:
     n = 10 * rate
     plan = Plan(rate, False)
+    if chunks:
+        plan.L.spx_set_pipeline_chunks(chunks)
     base = [speech_like(n, rate, seed=i, channels=ch) for i in range(4)]
     b = Batch(plan, [n] * ns, ch, speed, nl, 0.0)
     b.upload([base[i % 4] for i in range(ns)])
