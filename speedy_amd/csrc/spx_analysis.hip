@@ -36,23 +36,28 @@ extern "C" void spx_debug_astamps(unsigned long long* out, int reset) {
 #define ASTAMP_FLUSH
 #endif
 
+// Two tile sizes are compiled: SPX_TF frames (default) and SPX_TF_SMALL, which the engine picks when the smaller LDS
+// footprint is what lets two analysis workgroups sit beside a stream's walk and tension workgroups (concurrent mode).
+#define SPX_TF_SMALL 8
 int spx_analysis_tile_frames() { return SPX_TF; }
+int spx_analysis_small_tile_frames() { return SPX_TF_SMALL; }
 
-static __host__ __device__ inline size_t work_bytes(int W) {
+static __host__ __device__ inline size_t work_bytes(int W, int tf) {
   size_t a = (size_t)4 * 2 * 2 * W * sizeof(double);         // 4 waves x ping-pong x W complex
-  size_t b = (size_t)SPX_TF * (W + 1) * sizeof(double);      // aliased: log terms
+  size_t b = (size_t)tf * (W + 1) * sizeof(double);          // aliased: log terms
   return (a > b ? a : b);
 }
-static __host__ __device__ inline size_t stage_samples(const SpxPlanDev& P) {
-  return (size_t)(SPX_TF + 1) * P.B + (P.W - P.B) + 8;  // mono samples of frames j0-1 .. j0+TF-1
+static __host__ __device__ inline size_t stage_samples(const SpxPlanDev& P, int tf) {
+  return (size_t)(tf + 1) * P.B + (P.W - P.B) + 8;  // mono samples of frames j0-1 .. j0+TF-1
 }
-size_t spx_analysis_lds_bytes(const SpxPlanDev& P) {
-  size_t mags = (size_t)(SPX_TF + 1) * (P.W + 1) * sizeof(float);
-  size_t small = (size_t)3 * (SPX_TF + 1) * sizeof(float);
-  size_t stage = (stage_samples(P) * sizeof(short) + 15) & ~(size_t)15;
+size_t spx_analysis_lds_bytes(const SpxPlanDev& P) {  // for the tile size the plan copy carries (P.tile_frames)
+  const int tf = P.tile_frames > 0 ? P.tile_frames : SPX_TF;
+  size_t mags = (size_t)(tf + 1) * (P.W + 1) * sizeof(float);
+  size_t small = (size_t)3 * (tf + 1) * sizeof(float);
+  size_t stage = (stage_samples(P, tf) * sizeof(short) + 15) & ~(size_t)15;
   size_t pad = 0;  // tuning only (fewer workgroups per CU); part of the size so that the co-residency rule sees it
   if (const char* e = getenv("SPX_ANALYSIS_LDS_PAD")) pad = (size_t)atoi(e);
-  return work_bytes(P.W) + ((mags + 15) & ~(size_t)15) + ((small + 15) & ~(size_t)15) + stage + pad;
+  return work_bytes(P.W, tf) + ((mags + 15) & ~(size_t)15) + ((small + 15) & ~(size_t)15) + stage + pad;
 }
 
 __device__ __forceinline__ void wave_sync() {
@@ -285,6 +290,7 @@ __device__ __forceinline__ int mono_sample(const int16_t* __restrict__ in, int64
   return sum / C;
 }
 
+template <int TF>
 __global__ void __launch_bounds__(SPX_BLOCK)
 spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int n_streams,
                     const int16_t* __restrict__ in_base, SpxFrameRec* __restrict__ rec, SpxTapsDev taps,
@@ -304,21 +310,21 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   }
   const SpxStreamDev S = streams[lo];
   const int T = S.n_frames;
-  const int j0 = S.frame_begin + (tile - S.first_tile) * SPX_TF;
-  const int j1 = min(j0 + SPX_TF, T);
+  const int j0 = S.frame_begin + (tile - S.first_tile) * TF;
+  const int j1 = min(j0 + TF, T);
   const int C = S.channels;
   const int16_t* __restrict__ in = in_base + S.in_off;
 
   double* work = reinterpret_cast<double*>(lds);
-  const size_t wb = work_bytes(W);
+  const size_t wb = work_bytes(W, TF);
   float* mags = reinterpret_cast<float*>(lds + wb);
-  const size_t mags_b = (((size_t)(SPX_TF + 1) * (W + 1) * sizeof(float)) + 15) & ~(size_t)15;
+  const size_t mags_b = (((size_t)(TF + 1) * (W + 1) * sizeof(float)) + 15) & ~(size_t)15;
   float* fE = reinterpret_cast<float*>(lds + wb + mags_b);
-  float* fThr = fE + (SPX_TF + 1);
-  float* fInv = fThr + (SPX_TF + 1);
+  float* fThr = fE + (TF + 1);
+  float* fInv = fThr + (TF + 1);
   const int MS = W + 1;  // mags row stride (floats)
 
-  const size_t small_b = (((size_t)3 * (SPX_TF + 1) * sizeof(float)) + 15) & ~(size_t)15;
+  const size_t small_b = (((size_t)3 * (TF + 1) * sizeof(float)) + 15) & ~(size_t)15;
   const double* ltw = P.tw;    // twiddles stay in global memory (L1-resident, 16 B per lane per use)
   const double* ltw2 = P.tw2;
   short* smono = reinterpret_cast<short*>(lds + wb + mags_b + small_b);    // mono mix of the tile's input span
@@ -346,7 +352,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
 
   ASTAMP_DECL
   // ---------------- phase 1: spectra of slots 0..TF (slot s = frame j0-1+s), one wave per slot ----------
-  for (int s = wave; s <= SPX_TF; s += 4) {
+  for (int s = wave; s <= TF; s += 4) {
     const int j = j0 - 1 + s;
     float* mrow = mags + (size_t)s * MS;
     if (j < 0 || j >= j1) {  // outside the stream (or the tile's tail): zero spectrum
@@ -462,7 +468,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   ASTAMP(4);
 
   // ---------------- phase 2: per-slot energy (float, index order), max, inverse norm ----------------
-  if (tid <= SPX_TF) {
+  if (tid <= TF) {
     const float* mrow = mags + (size_t)tid * MS;
     float e = 0.0f, mx = 0.0f;
     for (int i = 1; i < W; i++) {
@@ -479,7 +485,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   ASTAMP(5);
 
   // ---------------- phase 3: gated |log ratio| terms, one lane per (slot, bin) ----------------
-  double* terms = work;  // aliases the DFT buffers, [SPX_TF][W+1]
+  double* terms = work;  // aliases the DFT buffers, [TF][W+1]
   const int nfr = j1 - j0;
   for (int idx = tid; idx < nfr * (W - 1); idx += SPX_BLOCK) {
     const int f = idx / (W - 1);
@@ -546,6 +552,10 @@ void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n
                          hipStream_t st) {
   if (n_tiles <= 0) return;
   const size_t lds = spx_analysis_lds_bytes(P);
-  hipLaunchKernelGGL(spx_analysis_kernel, dim3(n_tiles), dim3(SPX_BLOCK), lds, st, P, streams, n_streams, in,
-                     rec, taps, tile_order, tile_flags);
+  if (P.tile_frames == SPX_TF_SMALL)
+    hipLaunchKernelGGL(spx_analysis_kernel<SPX_TF_SMALL>, dim3(n_tiles), dim3(SPX_BLOCK), lds, st, P, streams, n_streams, in,
+                       rec, taps, tile_order, tile_flags);
+  else
+    hipLaunchKernelGGL(spx_analysis_kernel<SPX_TF>, dim3(n_tiles), dim3(SPX_BLOCK), lds, st, P, streams, n_streams, in,
+                       rec, taps, tile_order, tile_flags);
 }

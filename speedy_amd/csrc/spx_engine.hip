@@ -251,7 +251,7 @@ static Layout layout_for(const SpxPlanDev& d, const spx_stream_job* jobs, int n)
   L.off_states = o;  o += ((sizeof(SpxStreamState) * (size_t)n + 255) & ~(size_t)255);
   L.off_rec = o;     o += ((sizeof(SpxFrameRec) * (size_t)(tf + 1) + 255) & ~(size_t)255);
   L.off_scratch = o; o += ((sizeof(float) * 4 * (size_t)(tf + 1) + 255) & ~(size_t)255);
-  const int TFr = spx_analysis_tile_frames();
+  const int TFr = spx_analysis_small_tile_frames();  // the smaller of the two tile sizes: an upper bound on tiles
   L.max_tiles = tf / TFr + n + 1;  // every stream may end with a partial tile
   L.off_order = o;   o += ((sizeof(int) * (size_t)L.max_tiles + 255) & ~(size_t)255);
   L.off_flags = o;   o += ((sizeof(int) * (size_t)L.max_tiles + 255) & ~(size_t)255);
@@ -271,7 +271,7 @@ static int build_streams(const SpxPlanDev& d, const spx_stream_job* jobs, int n,
   v.resize((size_t)n * nch);
   tiles_per_chunk.assign(nch, 0);
   int64_t fo = 0;
-  const int TF = spx_analysis_tile_frames();
+  const int TF = d.tile_frames;
   for (int i = 0; i < n; i++) {
     const spx_stream_job& j = jobs[i];
     if (j.channels < 1 || j.n_in < 0) return fail(-1, "spx_batch: bad job");
@@ -318,7 +318,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
                     int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs, bool do_a,
                     bool do_w) {
   if (!plan || !jobs || n <= 0) return fail(-1, "spx_batch: bad arguments");
-  const SpxPlanDev& d = plan->dev;
+  SpxPlanDev d = plan->dev;  // a copy: the tile size is chosen per call
   Layout L = layout_for(d, jobs, n);
   if (ws_bytes < L.total || !ws) return fail(-1, "spx_batch: workspace too small");
   int maxC = 1;
@@ -355,6 +355,14 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   const size_t per_stream_lds = spx_walk_lds_bytes(d, maxC) + spx_tension_lds_bytes();
   const size_t per_stream_waves = (n <= 256 ? 8 : 4) + 4;  // walk (spx_launch_walk's choice) + tension
   bool co_resident = false;
+  // Two tile sizes: the smaller one costs the analysis about a fifth more time (one halo frame per 8 instead of per 16)
+  // but a quarter less LDS; it is taken when that is what lets two analysis workgroups sit beside a stream's
+  // workgroups, i.e. when it buys the concurrent mode (16 kHz stereo, for instance).
+  if (per_stream_lds + 2 * spx_analysis_lds_bytes(d) > lds_per_cu && do_a && do_w) {
+    SpxPlanDev d8 = d;
+    d8.tile_frames = spx_analysis_small_tile_frames();
+    if (per_stream_lds + 2 * spx_analysis_lds_bytes(d8) <= lds_per_cu) d.tile_frames = d8.tile_frames;
+  }
   if (spx_analysis_lds_bytes(d) < lds_per_cu) {
     const size_t lds_closing = lds_per_cu - spx_analysis_lds_bytes(d) + 1;
     const size_t closed = ((size_t)n * per_stream_lds) / lds_closing + ((size_t)n * per_stream_waves) / 29;
@@ -363,6 +371,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     // still two analysis workgroups on a CU (measured at 22.05 kHz, where only one fits: 4.1 ms back to back, 5.2 ms concurrent)
     if (per_stream_lds + 2 * spx_analysis_lds_bytes(d) > lds_per_cu) co_resident = false;
   }
+  if (!co_resident || !g_concurrent || env_serial) d.tile_frames = plan->dev.tile_frames;  // no concurrency: default tile
   const bool want_concurrent = g_concurrent && !env_serial && co_resident && do_a && do_w;
   // Pipelining in time needs both stages in one call; the separate entry points run one chunk.  A batch too large for
   // the concurrent mode gets four time chunks unless the caller chose a count: the analysis of chunk c+1 then overlaps

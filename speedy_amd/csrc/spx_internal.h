@@ -111,6 +111,7 @@ void spx_host_dft(int n, const int* radix, int nstages, const double* tw, const 
 size_t spx_walk_lds_bytes(const SpxPlanDev& P, int max_channels);
 size_t spx_tension_lds_bytes();
 int spx_analysis_tile_frames();
+int spx_analysis_small_tile_frames();
 
 // Shared, cached plan per (sample rate, hysteresis mode); owned by the library for the process lifetime.
 struct spx_plan;
