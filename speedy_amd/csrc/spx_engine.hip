@@ -352,16 +352,20 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       cu_count = 1; lds_per_cu = 65536;
     }
   }
-  const size_t per_stream_lds = spx_walk_lds_bytes(d, maxC) + spx_tension_lds_bytes();
+  const size_t per_stream_lds = spx_walk_lds_bytes(d, maxC, speedup_only) + spx_tension_lds_bytes();
   const size_t per_stream_waves = (n <= 256 ? 8 : 4) + 4;  // walk (spx_launch_walk's choice) + tension
   bool co_resident = false;
   // Two tile sizes: the smaller one costs the analysis about a fifth more time (one halo frame per 8 instead of per 16)
   // but a quarter less LDS; it is taken when that is what lets two analysis workgroups sit beside a stream's
   // workgroups, i.e. when it buys the concurrent mode (16 kHz stereo, for instance).
-  if (per_stream_lds + 2 * spx_analysis_lds_bytes(d) > lds_per_cu && do_a && do_w) {
+  // (6 KB of slack in the occupancy condition: filled to the last kilobyte, a CU that happens to hold two tension
+  // workgroups has no room for the walk workgroup, which then only starts when the analysis drains -- measured at
+  // 22.05 kHz, where the small tile fits with 2 KB to spare and the call got slower, not faster)
+  const size_t lds_usable = lds_per_cu > 6144 ? lds_per_cu - 6144 : lds_per_cu;
+  if (per_stream_lds + 2 * spx_analysis_lds_bytes(d) > lds_usable && do_a && do_w) {
     SpxPlanDev d8 = d;
     d8.tile_frames = spx_analysis_small_tile_frames();
-    if (per_stream_lds + 2 * spx_analysis_lds_bytes(d8) <= lds_per_cu) d.tile_frames = d8.tile_frames;
+    if (per_stream_lds + 2 * spx_analysis_lds_bytes(d8) <= lds_usable) d.tile_frames = d8.tile_frames;
   }
   if (spx_analysis_lds_bytes(d) < lds_per_cu) {
     const size_t lds_closing = lds_per_cu - spx_analysis_lds_bytes(d) + 1;
@@ -369,7 +373,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     co_resident = closed < (size_t)cu_count;
     // ... and only worth it when the analysis keeps its throughput beside the consumers: a stream's workgroups and
     // still two analysis workgroups on a CU (measured at 22.05 kHz, where only one fits: 4.1 ms back to back, 5.2 ms concurrent)
-    if (per_stream_lds + 2 * spx_analysis_lds_bytes(d) > lds_per_cu) co_resident = false;
+    if (per_stream_lds + 2 * spx_analysis_lds_bytes(d) > lds_usable) co_resident = false;
   }
   if (!co_resident || !g_concurrent || env_serial) d.tile_frames = plan->dev.tile_frames;  // no concurrency: default tile
   const bool want_concurrent = g_concurrent && !env_serial && co_resident && do_a && do_w;

@@ -108,7 +108,7 @@ void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_str
 size_t spx_analysis_lds_bytes(const SpxPlanDev& P);
 // The DFT of the spec run on the host (same operation order as the kernel): used to build the Rader tables.
 void spx_host_dft(int n, const int* radix, int nstages, const double* tw, const double* in, double* out);
-size_t spx_walk_lds_bytes(const SpxPlanDev& P, int max_channels);
+size_t spx_walk_lds_bytes(const SpxPlanDev& P, int max_channels, bool speedup_only);
 size_t spx_tension_lds_bytes();
 int spx_analysis_tile_frames();
 int spx_analysis_small_tile_frames();

@@ -18,7 +18,7 @@
 // latency-critical chain of the whole job -- then never execute a frame-rate pass themselves.
 #include "spx_internal.h"
 
-#define SPX_CH 1024  // frames per pass chunk held in LDS
+#define SPX_CH 512   // frames per pass chunk held in LDS
 // Frames per chunk when the analysis kernel runs concurrently (a multiple of the 16-frame tile).  Measured on the
 // bench batch (ms per step): 16 constant 2.87 | 16,32,48.. 2.95 | 64,128,192.. 3.10 | 16,32,64.. 3.26 -- the finer the
 // hand-off, the less the walk kernel ever waits for speeds; this kernel has the slack for the extra passes.

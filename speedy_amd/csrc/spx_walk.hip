@@ -813,7 +813,8 @@ struct WalkLds {
   int off_sA, off_mono, off_monoB, off_raw, off_dn, off_dnB, off_pl, off_plB, plStride, off_diffC, off_diffR,
       off_wait, total, wcap;
 };
-static __host__ __device__ inline WalkLds walk_lds_layout(const SpxPlanDev& P, int maxC) {
+// fast != 0: the speed-up kernels, which need neither the speed staging array nor the per-step decimated signal.
+static __host__ __device__ inline WalkLds walk_lds_layout(const SpxPlanDev& P, int maxC, int fast = 0) {
   WalkLds L;
   const int need = P.maxRequired + 2 * P.skip + 2;
   int wcap = 4096;
@@ -822,7 +823,7 @@ static __host__ __device__ inline WalkLds walk_lds_layout(const SpxPlanDev& P, i
   wcap = (wcap + 7) & ~7;
   L.wcap = wcap;
   int o = 0;
-  L.off_sA = o; o += SPX_CH * 4;
+  L.off_sA = o; if (!fast) o += SPX_CH * 4;
   L.off_wait = o; o += 16;
   L.off_mono = o;
   const int mb = ((wcap + 8) * 2 + 15) & ~15;
@@ -830,7 +831,7 @@ static __host__ __device__ inline WalkLds walk_lds_layout(const SpxPlanDev& P, i
   L.off_monoB = o; o += mb;
   L.off_raw = o;
   if (maxC > 1) o += ((wcap + 1) * maxC * 2 + 15) & ~15;
-  const int dnb = ((P.maxRequired / P.skip + 8) * 2 + 15) & ~15;
+  const int dnb = fast ? 0 : ((P.maxRequired / P.skip + 8) * 2 + 15) & ~15;
   L.off_dn = o; o += dnb;
   L.off_dnB = o; o += dnb;
   // decimated planes of the FAST kernels (allocated always: the layout does not depend on the kernel variant)
@@ -858,7 +859,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   const int Ttot = S.n_frames, F = P.F, B = P.B;
   const float Rg = S.speed, nl = S.nonlinear;
 
-  const WalkLds LY = walk_lds_layout(P, maxC);
+  const WalkLds LY = walk_lds_layout(P, maxC, FAST);
   float* sA = reinterpret_cast<float*>(lds + LY.off_sA);  // [SPX_CH]
 
   // ---- the part of the stream state this stage owns (the tension kernel owns the filter states) ----
@@ -1007,14 +1008,26 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   }
 }
 
-size_t spx_walk_lds_bytes(const SpxPlanDev& P, int maxC) { return (size_t)walk_lds_layout(P, maxC < 1 ? 1 : maxC).total; }
+// Which kernel variant a batch gets: 0 general, 1 speed-up mono, 2 speed-up multi-channel.  FAST: all streams speeding
+// up (speed > 1, 0 <= nonlinear <= 1: the stage never sees a speed below 1), decimated search, at most 64 lags in either
+// search (rates below 32 kHz), and the usual 4096-frame window.
+static int walk_mode(const SpxPlanDev& P, int maxC, bool speedup_only) {
+  if (speedup_only && P.skip >= 2 && (P.maxPeriod / P.skip - P.minPeriod / P.skip + 1) <= 64 && (8 * P.skip + 1) <= 64 &&
+      walk_lds_layout(P, maxC).wcap == 4096 && maxC <= 8 && !getenv("SPX_WALK_GENERIC"))
+    return (maxC == 1) ? 1 : 2;
+  return 0;
+}
+size_t spx_walk_lds_bytes(const SpxPlanDev& P, int maxC, bool speedup_only) {
+  if (maxC < 1) maxC = 1;
+  return (size_t)walk_lds_layout(P, maxC, walk_mode(P, maxC, speedup_only)).total;
+}
 
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int maxC, const int16_t* in,
                      int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
                      const int* speed_ready, bool speedup_only, hipStream_t st) {
   if (n_streams <= 0) return;
   if (maxC < 1) maxC = 1;
-  const WalkLds LY = walk_lds_layout(P, maxC);
+  WalkLds LY = walk_lds_layout(P, maxC);
   // Waves per stream.  Measured on MI355X, 10 s streams (ms per call; 2 / 4 / 8 waves): 256 streams 3.67 / 3.19 / 2.91
   // (walk kernel alone), 512: 5.40 / 4.78 / 5.63, 1024: 10.3 / 9.3 / 10.5, 2048: 19.7 / 17.7 / - (1 wave: 21.4).
   // One workgroup per CU wants all eight wave slots of two-per-SIMD; several workgroups per CU hide each other's
@@ -1033,13 +1046,8 @@ void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_str
       hipLaunchKernelGGL((spx_walk_kernel<NWV, 0>), dim3(n_streams), dim3(64 * NWV), LY.total, st, P, streams,   \
                          in, out, n_out, states, scratch, maxC, speed_ready);                                    \
   } while (0)
-  // FAST (1: every stream mono, 2: some multi-channel): all streams speeding up (speed > 1, 0 <= nonlinear <= 1: the
-  // stage never sees a speed below 1), decimated search, at most 64 lags in either search (rates below 32 kHz), and the
-  // usual 4096-frame window
-  int fast = 0;
-  if (speedup_only && P.skip >= 2 && (P.maxPeriod / P.skip - P.minPeriod / P.skip + 1) <= 64 && (8 * P.skip + 1) <= 64 &&
-      LY.wcap == 4096 && maxC <= 8 && !getenv("SPX_WALK_GENERIC"))
-    fast = (maxC == 1) ? 1 : 2;
+  const int fast = walk_mode(P, maxC, speedup_only);
+  LY = walk_lds_layout(P, maxC, fast);
 #ifdef SPX_STAMPS
   if (nw == 4) SPX_LAUNCH_WALK(4); else SPX_LAUNCH_WALK(8);  // the diagnostic build carries two kernels only
   return;
