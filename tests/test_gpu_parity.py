@@ -322,3 +322,16 @@ def test_pack_outputs_matches_per_stream_results():
     for i, o in enumerate(outs):
         assert offs[i + 1] - offs[i] == o.size
         assert np.array_equal(packed[offs[i]:offs[i + 1]], o), i
+
+
+def test_ten_minute_stream(orc):
+    """One 10-minute stream (9.6 M frames, 60 000 analysis frames): large positions, many window refills, the
+    hand-off between the three kernels over a long run.  Bit-exact output and speed taps against the oracle."""
+    from speedy_amd.synth import speech_like
+    rate = 16000
+    piece = speech_like(60 * rate, rate, seed=77)
+    x = np.tile(piece, 10)
+    outs, b = _batch([x], rate, 1, 3.5, 1.0, 0.1, False, taps=True)
+    ref = _oracle(orc, x, rate, 1, 3.5, 1.0, 0.1, False)
+    assert np.array_equal(b.tap_arrays(0)["speed"], ref["speed"])
+    assert np.array_equal(outs[0], ref["out"])
