@@ -553,8 +553,8 @@ int spx_batch_pack_outputs(const spx_stream_job* jobs, int n, const int16_t* out
   if (!jobs || n <= 0 || !out || !n_out || !packed || !offsets) return fail(-1, "spx_batch_pack_outputs: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(hs);
   // small per-stream tables (channels, output offsets): staged through one device allocation kept for reuse
-  static void* d_tab = nullptr;
-  static size_t d_tab_cap = 0;
+  static thread_local void* d_tab = nullptr;  // per host thread: concurrent callers do not share it
+  static thread_local size_t d_tab_cap = 0;
   const size_t need = (size_t)n * (sizeof(int64_t) + sizeof(int));
   if (need > d_tab_cap) {
     if (d_tab) (void)hipFree(d_tab);
