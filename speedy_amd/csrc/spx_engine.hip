@@ -552,16 +552,11 @@ int spx_batch_pack_outputs(const spx_stream_job* jobs, int n, const int16_t* out
                            int64_t* offsets, void* hs) {
   if (!jobs || n <= 0 || !out || !n_out || !packed || !offsets) return fail(-1, "spx_batch_pack_outputs: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(hs);
-  // small per-stream tables (channels, output offsets): staged through one device allocation kept for reuse
-  static thread_local void* d_tab = nullptr;  // per host thread: concurrent callers do not share it
-  static thread_local size_t d_tab_cap = 0;
+  // small per-stream tables (channels, output offsets): a stream-ordered allocation, freed in stream order after the
+  // kernels that read it, so concurrent calls on other streams never share it
   const size_t need = (size_t)n * (sizeof(int64_t) + sizeof(int));
-  if (need > d_tab_cap) {
-    if (d_tab) (void)hipFree(d_tab);
-    d_tab = nullptr;
-    if (hipMalloc(&d_tab, need) != hipSuccess) { d_tab_cap = 0; return fail(-2, "spx_batch_pack_outputs: allocation failed"); }
-    d_tab_cap = need;
-  }
+  void* d_tab = nullptr;
+  if (hipMallocAsync(&d_tab, need, st) != hipSuccess) return fail(-2, "spx_batch_pack_outputs: allocation failed");
   std::vector<unsigned char> h(need);
   int64_t* h_off = reinterpret_cast<int64_t*>(h.data());
   int* h_ch = reinterpret_cast<int*>(h.data() + (size_t)n * sizeof(int64_t));
@@ -571,6 +566,7 @@ int spx_batch_pack_outputs(const spx_stream_job* jobs, int n, const int16_t* out
   const int* d_ch = reinterpret_cast<const int*>(static_cast<unsigned char*>(d_tab) + (size_t)n * sizeof(int64_t));
   hipLaunchKernelGGL(spx_pack_offsets_kernel, dim3(1), dim3(64), 0, st, n_out, d_ch, n, offsets);
   hipLaunchKernelGGL(spx_pack_copy_kernel, dim3(n), dim3(256), 0, st, out, d_off, offsets, packed);
+  (void)hipFreeAsync(d_tab, st);
   HIPCHK(hipGetLastError());
   return 0;
 }
