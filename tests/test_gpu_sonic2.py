@@ -253,3 +253,39 @@ def test_stereo_original_sonic_entry_points():
             break
     L.sonicIntDestroyStream(h)
     assert abs(total - x.size / speed) <= x.size / speed * 0.01
+
+
+@pytest.mark.parametrize("nl", [1.0, 0.0])
+def test_speed_changes_between_writes(orc, nl):
+    """sonicSetSpeed between writes, across 1 (3.0 -> 0.7 -> 1.0 -> 2.2 -> 0.5 -> 4.0): the stream moves from the
+    speed-up kernel to the general one and carries its state across; every read must equal the oracle shim's."""
+    from speedy_amd.sonic2 import SonicStream
+    from speedy_amd.synth import speech_like
+    rate, ch = 16000, 1
+    x = speech_like(6 * rate, rate, seed=91)
+    L = orc.lib()
+    h = L.orc_sonicCreateStream(rate, ch, 0)
+    L.orc_sonicEnableNonlinearSpeedup(h, nl)
+    s = SonicStream(rate, ch, False)
+    s.enable_nonlinear(nl)
+    speeds = [3.0, 0.7, 1.0, 2.2, 0.5, 4.0]
+    buf = np.zeros(200000, np.int16)
+    seg_len = x.size // len(speeds)
+    for k, sp_ in enumerate(speeds):
+        L.orc_sonicSetSpeed(h, sp_)
+        s.set_speed(sp_)
+        seg = x[k * seg_len:(k + 1) * seg_len]
+        for pos in range(0, seg.size, 1500):
+            part = np.ascontiguousarray(seg[pos:pos + 1500])
+            assert L.orc_sonicWriteShortToStream(h, orc.sptr(part), part.size) == 1
+            s.write_short(part)
+            n = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), 100000)
+            got = s.read_short(100000)
+            assert got.size == n and np.array_equal(got, buf[:n]), (nl, k, pos)
+    L.orc_sonicFlushStream(h)
+    s.flush()
+    n = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), 200000)
+    got = s.read_short(200000)
+    assert got.size == n and np.array_equal(got, buf[:n])
+    L.orc_sonicDestroyStream(h)
+    s.close()
