@@ -335,3 +335,20 @@ def test_ten_minute_stream(orc):
     ref = _oracle(orc, x, rate, 1, 3.5, 1.0, 0.1, False)
     assert np.array_equal(b.tap_arrays(0)["speed"], ref["speed"])
     assert np.array_equal(outs[0], ref["out"])
+
+
+def test_thousand_tiny_streams(orc):
+    """1000 streams of 0 .. 0.25 s in one call (the large-batch path: four pipelined time chunks, most of them empty
+    for streams this short), every stream against the oracle."""
+    from speedy_amd.synth import speech_like
+    rate = 16000
+    rng = np.random.default_rng(5)
+    lens = [int(v) for v in rng.integers(0, 4000, 1000)]
+    base = speech_like(4000, rate, seed=123)
+    streams = [base[:n] for n in lens]
+    outs, b = _batch(streams, rate, 1, 3.5, 1.0, 0.0, False, taps=False)
+    cache = {}
+    for i, n in enumerate(lens):
+        if n not in cache:
+            cache[n] = _oracle(orc, streams[i], rate, 1, 3.5, 1.0, 0.0, False)["out"]
+        assert np.array_equal(outs[i], cache[n]), (i, n)
