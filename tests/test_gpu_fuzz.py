@@ -121,3 +121,31 @@ def test_streaming_fuzz(orc, seed):
                 break
         L.orc_sonicDestroyStream(h)
         s.close()
+
+
+@pytest.mark.parametrize("seed", list(range(21, 27)) + list(range(2000, 2000 + SOAK)))
+def test_batch_mixture_fuzz(orc, seed):
+    """Random BATCHES: 3 .. 12 streams of one rate with per-stream channels, length, speed (some below 1), nonlinear
+    factor and feedback in one call -- which kernel variant the batch gets depends on the mix -- each stream against
+    the oracle."""
+    from speedy_amd.batch import compress_batch
+    rng = np.random.default_rng(seed)
+    for rep in range(4):
+        rate = int(rng.choice(RATES))
+        k = int(rng.integers(3, 13))
+        slow = bool(rng.integers(0, 3) == 0)          # one batch in three contains slow-down jobs
+        multi = bool(rng.integers(0, 2))
+        chs, speeds, nls, fbs, xs = [], [], [], [], []
+        for i in range(k):
+            ch = int(rng.choice([1, 2, 3])) if multi else 1
+            n = int(rng.integers(0, int(1.0 * rate)))
+            sp_ = float(np.round(rng.uniform(0.4, 0.95) if (slow and rng.integers(0, 2)) else rng.uniform(1.05, 5.0), 3))
+            chs.append(ch); speeds.append(sp_)
+            nls.append(float(rng.choice([0.0, 1.0, 1.0, 0.5]))); fbs.append(float(rng.choice([0.0, 0.1])))
+            xs.append(_signal(KINDS[int(rng.integers(0, len(KINDS)))], n, rate, ch, rng))
+        mm = bool(rng.integers(0, 2))
+        outs, b = compress_batch(xs, rate, chs, speeds, nls, fbs, mm, taps=False)
+        for i in range(k):
+            ref = orc.compress_sound(xs[i], rate, chs[i], speeds[i], nls[i], fbs[i], mm,
+                                     chunk=1000 if nls[i] != 0 else max(xs[i].size // chs[i], 1))
+            assert np.array_equal(outs[i], ref["out"]), (seed, rep, i, rate, chs[i], speeds[i], nls[i], fbs[i], mm)
