@@ -1,11 +1,14 @@
-"""bench.py — the headline metric of BASELINE.json on MI355X.
+"""bench.py -- the headline metric of BASELINE.json on MI355X.
 
-Workload (config.workload): BASELINE.json configs[3] per GPU — 256 concurrent 16 kHz mono streams x 10 s of
-synthetic speech-like int16, speed 3.5, nonlinear on, duration feedback 0 (speedy_wave.cc:33 default) —
+Workload (config.workload): BASELINE.json configs[3] per GPU -- 256 concurrent 16 kHz mono streams x 10 s of
+synthetic speech-like int16, speed 3.5, nonlinear on, duration feedback 0 (speedy_wave.cc:33 default) --
 the configuration the metric "Msamples/s processed (16 kHz mono, 3.5x nonlinear)" is quoted on.  One "step" =
-one pass of the whole hot path (analysis kernel + walk kernel) over the batch, inputs already resident in HBM.
+one pass of the whole hot path (analysis, tension and walk kernels) over the batch, inputs already resident in HBM.
+
 N > 1: one process per GPU, each with its own 256 streams (weak scaling, streams share nothing; the only
-collective is the barrier / MAX-reduce of the timing, over RCCL).
+collectives are the work-partition handshake and the barrier / MAX-reduce of the timing, over RCCL).  Launched either
+by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or directly: `python bench.py --gpus N`
+starts the N rank processes itself, before anything touches the GPU.
 
 Prints ONE JSON line on rank 0.
 """
@@ -13,8 +16,11 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -36,32 +42,140 @@ def make_streams(n_streams, n, rank):
     return out
 
 
-def cpu_baseline(streams, budget_s=12.0):
-    """The CPU oracle (kind "port": C restatement of the reference path, the reference itself is unbuildable
-    here) over a bounded sample of the SAME streams, one stream per task over all host cores."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import pyorc
-    pyorc.build()
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(streams, gpu_outputs, budget_s=12.0):
+    """The CPU oracle (kind "port": C restatement of the reference path; the reference itself is unbuildable here,
+    DESIGN.md "Oracle") on the host cores of this machine: oracle/orc_bench.c -- POSIX threads, one stream per task,
+    the speedy_wave.cc write-1000/read loop per stream -- built here with -O3 -march=native -ffp-contract=off.
+    A bounded sample of the SAME streams; the output CRC of each sampled stream is compared with the GPU's."""
+    subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "liborc_bench.so"])
+    L = C.CDLL(os.path.join(ROOT, "oracle", "liborc_bench.so"))
+    L.orc_bench_run.restype = C.c_double
+    L.orc_bench_run.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     cores = os.cpu_count() or 1
-    # probe one stream to size the sample
-    t0 = time.perf_counter()
-    pyorc.compress_sound(streams[0], RATE, 1, SPEED, 1.0, 0.0, False, taps=False)
-    one = time.perf_counter() - t0
-    n = int(max(cores, min(len(streams), budget_s * cores / max(one, 1e-4))))
-    sample = streams[:n]
+    n = streams[0].size
 
-    def run(x):
-        return pyorc.compress_sound(x, RATE, 1, SPEED, 1.0, 0.0, False, taps=False)["out"].size
+    def run(sample, threads):
+        buf = np.ascontiguousarray(np.concatenate(sample), np.int16)
+        frames = (C.c_long * len(sample))()
+        crcs = (C.c_uint32 * len(sample))()
+        dt = L.orc_bench_run(buf.ctypes.data, n, len(sample), RATE, 1, SPEED, 1.0, 0.0, 0, 1000, threads, frames, crcs)
+        return dt, list(crcs)
 
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(run, sample))
-    dt = time.perf_counter() - t0
-    total = sum(x.size for x in sample)
-    return {"value": total / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%d of the %d bench streams (%d s each), one stream per task on %d threads; "
-                      "single-thread rate %.2f Msamples/s" % (n, len(streams), SECONDS, cores,
-                                                              streams[0].size / one / 1e6)}
+    one, _ = run(streams[:1], 1)                       # single-thread rate, also sizes the sample
+    k = int(max(cores, min(4 * len(streams), budget_s * cores / max(one, 1e-4))))
+    sample = [streams[i % len(streams)] for i in range(k)]
+    dt, crcs = run(sample, cores)
+    mismatched = sum(1 for i, c in enumerate(crcs)
+                     if c != zlib.crc32(np.ascontiguousarray(gpu_outputs[i % len(streams)]).tobytes()))
+    return {"value": k * n / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(), "single_thread_msamples_s": n / one / 1e6,
+            "thread_scaling": (k * n / dt) / (n / one),
+            "output_crc_mismatches_vs_gpu": mismatched,
+            "sample": "%d streams (the %d bench streams%s, %d s each), one stream per task on %d POSIX threads, "
+                      "oracle built -O3 -march=native -ffp-contract=off (oracle/orc_bench.c)"
+                      % (k, len(streams), ", cycled" if k > len(streams) else "", SECONDS, cores)}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (this process never touches the GPU),
+    wait for them, exit non-zero if any failed.  Rank 0 prints the JSON line on the inherited stdout."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    deadline = time.time() + 3600
+    while procs:
+        for p in list(procs):
+            code = p.poll()
+            if code is None:
+                continue
+            procs.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in procs:          # one rank failed: the others would wait in a collective for ever
+                    q.terminate()
+        if time.time() > deadline:
+            for q in procs:
+                q.kill()
+            rc = rc or 124
+            break
+        time.sleep(0.05)
+    sys.exit(rc)
+
+
+def pcie_pipeline(plan, streams, n, reps, warm=2):
+    """PCIe-inclusive steady state (SURVEY.md 8d "first write to last drained read"): pinned host input -> HBM, the step,
+    a device-side gather of the produced frames, one copy to pinned host memory -- double-buffered on three HIP
+    streams, so that the H2D of batch k+1 and the D2H of batch k-1 overlap the step of batch k.
+    Returns seconds per batch."""
+    import torch
+    from speedy_amd.batch import Batch
+    bs = [Batch(plan, [n] * len(streams), 1, SPEED, 1.0, 0.0) for _ in range(2)]
+    h_in = torch.empty(bs[0].d_in.numel(), dtype=torch.int16).pin_memory()
+    h_in.zero_()
+    off = 0
+    for x in streams:
+        h_in[off:off + x.size] = torch.from_numpy(x)
+        off += x.size
+    h_out = [torch.zeros(b.d_out.numel(), dtype=torch.int16).pin_memory() for b in bs]
+    h_offs = [torch.zeros(b.n + 1, dtype=torch.int64).pin_memory() for b in bs]
+    s_h2d, s_run, s_d2h = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    ev_in = [torch.cuda.Event() for _ in bs]
+    ev_done = [torch.cuda.Event() for _ in bs]
+    ev_out = [torch.cuda.Event() for _ in bs]
+    packed = [None, None]
+    totals = []
+    t0 = 0.0
+
+    def drain(k):  # output of batch k: wait for its step (long finished in steady state), then one D2H of the exact size
+        i = k % 2
+        ev_done[i].synchronize()
+        total = int(h_offs[i][-1])
+        totals.append(total)
+        with torch.cuda.stream(s_d2h):
+            h_out[i][:total].copy_(packed[i][:total], non_blocking=True)
+            ev_out[i].record(s_d2h)
+
+    for k in range(warm + reps):
+        if k == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        i = k % 2
+        with torch.cuda.stream(s_h2d):
+            if k >= 2:
+                s_h2d.wait_event(ev_done[i])      # the step of batch k-2 has finished reading this input buffer
+            bs[i].d_in.copy_(h_in, non_blocking=True)
+            ev_in[i].record(s_h2d)
+        with torch.cuda.stream(s_run):
+            s_run.wait_event(ev_in[i])
+            if k >= 2:
+                s_run.wait_event(ev_out[i])       # the output of batch k-2 has left this buffer
+            bs[i].run(stream=s_run)
+            packed[i], d_offs = bs[i].pack_outputs(stream=s_run)
+            h_offs[i].copy_(d_offs, non_blocking=True)
+            ev_done[i].record(s_run)
+        if k >= 1:
+            drain(k - 1)
+    drain(warm + reps - 1)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return dt, totals[-1]
 
 
 def main():
@@ -70,11 +184,17 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true")
     ap.add_argument("--chunks", type=int, default=int(os.environ.get("SPX_CHUNKS", "1")),
                     help="time chunks per stream inside one spx_batch_run (analysis of chunk c+1 overlaps the walk of c)")
+    ap.add_argument("--crc-out", default=None, help="write this rank's per-stream output CRC-32s to CRC_OUT.rank<r>.json "
+                    "(tests: N-rank runs must produce the same bytes per stream as solo runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for "
-                    "a functional check of the N > 1 path on a single GPU)")
+                    "a functional check of the N > 1 path when several ranks share one GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)   # never returns
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -83,22 +203,25 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (the product has no CPU path)")
     ndev = torch.cuda.device_count()
-    dev_index = local_rank if local_rank < ndev else local_rank % max(1, ndev)
+    dev_index = local_rank % max(1, ndev)
     torch.cuda.set_device(dev_index)
     dist = None
     red_dev = "cuda"
+    backend = args.backend
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
+        if backend == "nccl" and world > ndev:
+            backend = "gloo"   # several ranks on one GPU (functional check only): RCCL needs one device per rank
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(backend)
             red_dev = "cpu"
         # work-partition handshake: every rank announces its shard (stream count, input frames)
         from speedy_amd.dist import handshake
         layout = handshake(dist, STREAMS_PER_GPU, STREAMS_PER_GPU * RATE * SECONDS, device=red_dev)
-        assert layout.shape == (world, 2)
+        assert layout.shape == (world, 2) and int(layout[:, 0].sum()) == world * STREAMS_PER_GPU
 
     from speedy_amd.batch import Batch, Plan
     n = RATE * SECONDS
@@ -115,6 +238,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         b.run()
     barrier()
@@ -128,41 +258,27 @@ def main():
     sa, sw, nc = C.c_double(0), C.c_double(0), C.c_int(0)
     L.spx_timing_collect(C.byref(sa), C.byref(sw), C.byref(nc))
     ms_tension = float(L.spx_timing_last_tension_ms()) / max(1, nc.value)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    n_in_local = n * STREAMS_PER_GPU
+    dt = max_over_ranks(dt)
+    n_in = n * STREAMS_PER_GPU
     outs = b.results()
     n_out = int(sum(o.size for o in outs))
+    if args.crc_out:
+        with open("%s.rank%d.json" % (args.crc_out, rank), "w") as f:
+            json.dump([zlib.crc32(np.ascontiguousarray(o).tobytes()) for o in outs], f)
 
-    # PCIe-inclusive rate (reported beside, never as `value`): pinned host input -> HBM, the same step, produced
-    # output -> pinned host memory.
+    # PCIe-inclusive steady state on every rank, MAX over ranks (reported beside `value`, which by the bench contract is
+    # the rate with inputs already resident in HBM)
     pcie = None
-    if rank == 0:
-        h_in = torch.empty(b.d_in.numel(), dtype=torch.int16).pin_memory()
-        h_in.copy_(b.d_in.cpu())
-        h_out = torch.zeros(b.d_out.numel(), dtype=torch.int16).pin_memory()  # zeros: every page touched before timing
-        reps = 5
-        h_offs = torch.empty(b.n + 1, dtype=torch.int64).pin_memory()
-        t1 = 0.0
-        for rep in range(reps + 2):
-            if rep == 2:  # two warm-up reps: first touch of the pinned buffers, allocator pools, host page cache
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-            b.d_in.copy_(h_in, non_blocking=True)
-            b.run()
-            d_packed, d_offs = b.pack_outputs()          # gather on the device: one copy instead of one per stream
-            h_offs.copy_(d_offs, non_blocking=True)
-            torch.cuda.synchronize()
-            total = int(h_offs[-1])
-            h_out[:total].copy_(d_packed[:total], non_blocking=True)
-            torch.cuda.synchronize()
-        dt1 = (time.perf_counter() - t1) / reps
-        pcie = {"value": n_in_local / dt1 / 1e6, "unit": "Msamples/s", "ms_per_step": dt1 * 1e3,
-                "note": "rank 0 only: H2D of the int16 input + the step + device-side gather + one D2H of the produced "
-                        "int16 output, pinned host buffers; not the headline value"}
-    n_in = n * STREAMS_PER_GPU
+    if not args.no_pcie:
+        barrier()
+        dt1, total = pcie_pipeline(plan, streams, n, reps=max(4, min(args.steps, 10)))
+        assert total == n_out, (total, n_out)
+        dt1 = max_over_ranks(dt1)
+        pcie = {"value": n_in * world / dt1 / 1e6, "unit": "Msamples/s", "ms_per_step": dt1 * 1e3,
+                "vs_resident_step": dt1 / (dt / args.steps),
+                "note": "every rank, MAX over ranks: pinned host int16 input -> HBM, the step, device-side gather, one D2H "
+                        "of the produced int16 output; double-buffered on three HIP streams (H2D of batch k+1 and D2H "
+                        "of batch k-1 overlap the step of batch k)"}
 
     if rank == 0:
         total_in = n_in * world * args.steps
@@ -173,10 +289,13 @@ def main():
         dom, dom_ms = ("spx_walk_kernel", ms_walk) if ms_walk >= ms_analyze else ("spx_analysis_kernel", ms_analyze)
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
+        traffic_note = None
         pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pj):
             try:
-                traffic = json.load(open(pj)).get(dom, {}).get("hbm_bytes_per_launch")
+                pt = json.load(open(pj))
+                traffic = pt.get(dom, {}).get("hbm_bytes_per_launch")
+                traffic_note = pt.get("_note")
             except Exception:
                 traffic = None
         line = {
@@ -189,27 +308,31 @@ def main():
                                    "nonlinear 1.0, feedback 0" % (STREAMS_PER_GPU, SECONDS),
                        "streams_per_gpu": STREAMS_PER_GPU, "samples_per_stream": n,
                        "parallelism": "streams sharded %d/GPU, no data-path collective" % STREAMS_PER_GPU,
+                       "launcher": "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else
+                                   ("bench.py --gpus (self-spawned ranks)" if world > 1 else "single process"),
+                       "backend": (backend if world > 1 else None),
                        "realtime_factor_per_stream": SECONDS / (ms_step * 1e-3),
                        "out_samples_per_gpu": n_out, "pipeline_chunks": args.chunks,
                        "kernel_launches_per_step": {"spx_analysis_kernel": args.chunks,
                                                     "spx_tension_kernel": args.chunks,
                                                     "spx_walk_kernel": args.chunks}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "kernel_ms_per_step": {"spx_analysis_kernel": ms_analyze, "spx_tension_kernel": ms_tension,
                                                 "spx_walk_kernel": ms_walk},
                          "kernel_avg_launch_ms": {"spx_analysis_kernel": ms_analyze / args.chunks,
                                                   "spx_tension_kernel": ms_tension / args.chunks,
                                                   "spx_walk_kernel": ms_walk / args.chunks},
-                         "note": "latency-bound at this size: 256 sequential per-stream walks, one workgroup "
-                                 "each (DESIGN.md)"},
+                         "limiter": "latency, not HBM: 256 per-stream chains of ~1300 dependent pitch steps, one "
+                                    "workgroup per CU (DESIGN.md 5.3, 6); `bound` names the roofline the contract asks "
+                                    "to be priced against"},
         }
         if pcie is not None:
             line["pcie_inclusive"] = pcie
-        if not args.no_cpu_baseline and world >= 1:
-            line["cpu_baseline"] = cpu_baseline(streams)
-        print(json.dumps(line))
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (bench contract)
+            line["cpu_baseline"] = cpu_baseline(streams, outs)
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

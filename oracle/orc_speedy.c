@@ -120,7 +120,7 @@ typedef struct orc_plan_s {
   int nstages;
   int radix[ORC_MAX_STAGES];
   double* tw;   /* tw[2t], tw[2t+1] = cos(2 pi t/n), -sin(2 pi t/n) */
-  double* work; /* 2 * 2n doubles ping-pong */
+  double* work; /* 2 * 2n doubles ping-pong, then 4n doubles of butterfly scratch (allocated once per plan) */
   /* Rader's algorithm for a large prime n whose n-1 is smooth (DESIGN.md "DFT spec"): the n-point transform as a cyclic
    * convolution of length n-1 done with the (n-1)-point plan.  NULL otherwise. */
   struct orc_plan_s* sub; /* (n-1)-point plan */
@@ -169,7 +169,7 @@ static orc_plan* orc_plan_create(int n) {
   p->n = n;
   p->nstages = (n > 1) ? orc_factor(n, p->radix) : 0;
   p->tw = (double*)malloc(sizeof(double) * 2 * n);
-  p->work = (double*)malloc(sizeof(double) * 4 * n);
+  p->work = (double*)malloc(sizeof(double) * 8 * n);
   for (int t = 0; t < n; t++) {
     p->tw[2 * t] = cos(2.0 * M_PI * t / n);
     p->tw[2 * t + 1] = -sin(2.0 * M_PI * t / n);
@@ -293,7 +293,7 @@ static void orc_plan_execute(orc_plan* P, const double* in, double* out) {
   memcpy(x, in, sizeof(double) * 2 * n);
   int s = 1;   /* product of the radices of the stages already done */
   int cur = n; /* length of the sub-transforms still to do */
-  double* ar = (double*)malloc(sizeof(double) * 4 * n);
+  double* ar = P->work + 4 * n;
   double* ai = ar + n; double* br = ai + n; double* bi = br + n;
   for (int st = 0; st < P->nstages; st++) {
     int r = P->radix[st];
@@ -318,7 +318,6 @@ static void orc_plan_execute(orc_plan* P, const double* in, double* out) {
     s *= r;
     cur = m;
   }
-  free(ar);
   memcpy(out, x, sizeof(double) * 2 * n);
 }
 

@@ -1,0 +1,39 @@
+"""N > 1 on real hardware with the HIP library as the compute: `python bench.py --gpus 2` starts two rank processes
+itself (before anything touches the GPU); on a 1-GPU box both ranks share the device and the collectives run over gloo
+(RCCL needs one device per rank).  Each rank drives libspeedy_hip.so on its own 256-stream shard at the same time as the
+other; the per-stream output CRCs must equal those of solo runs of the same streams."""
+import json
+import os
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_same_bytes_as_solo(tmp_path):
+    import bench
+    from speedy_amd.batch import Batch, Plan
+    crc = str(tmp_path / "crc")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-pcie", "--no-cpu-baseline", "--crc-out", crc]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["streams_per_gpu"] == bench.STREAMS_PER_GPU
+    n = bench.RATE * bench.SECONDS
+    plan = Plan(bench.RATE, False)
+    for rank in (0, 1):
+        got = json.load(open("%s.rank%d.json" % (crc, rank)))
+        streams = bench.make_streams(bench.STREAMS_PER_GPU, n, rank)
+        b = Batch(plan, [n] * len(streams), 1, bench.SPEED, 1.0, 0.0)
+        b.upload(streams)
+        b.run()
+        solo = [zlib.crc32(np.ascontiguousarray(o).tobytes()) for o in b.results()]
+        assert got == solo, rank

@@ -163,8 +163,82 @@ def test_full_size_round_trip_properties():
     for i in range(B):
         assert np.array_equal(r1[i], r3[i]), i
     from oracle import pyorc
-    ref = pyorc.compress_sound(base[3], rate, 1, 3.5, 1.0, 0.0, False, chunk=1000)["out"]
-    assert np.array_equal(r1[3], ref)
+    for k in range(8):   # every distinct input of the batch against the oracle
+        ref = pyorc.compress_sound(base[k], rate, 1, 3.5, 1.0, 0.0, False, chunk=1000)["out"]
+        assert np.array_equal(r1[k], ref), k
+
+
+def test_bench_streams_match_oracle(orc):
+    """The bench workload's own inputs (bench.make_streams: 32 generated bases + rotations, 256 x 10 s): a sample of
+    bases AND rotated copies against the oracle, so the number bench.py reports is for bytes the oracle agrees with."""
+    import bench
+    from speedy_amd.batch import Batch, Plan
+    n = bench.RATE * bench.SECONDS
+    streams = bench.make_streams(bench.STREAMS_PER_GPU, n, 0)
+    b = Batch(Plan(bench.RATE, False), [n] * len(streams), 1, bench.SPEED, 1.0, 0.0)
+    b.upload(streams)
+    b.run()
+    outs = b.results()
+    for i in list(range(0, 32, 3)) + [32, 77, 130, 201, 255]:
+        ref = orc.compress_sound(streams[i], bench.RATE, 1, bench.SPEED, 1.0, 0.0, False, taps=False)["out"]
+        assert np.array_equal(outs[i], ref), i
+
+
+def _config4_stream_cfg(i):
+    """SURVEY.md 8(d), config 5 (= BASELINE configs[4]): rate by i%2, channels by (i/2)%2, speed by (i/4)%2."""
+    return (16000 if i % 2 == 0 else 22050, 1 if (i // 2) % 2 == 0 else 2, 1.5 if (i // 4) % 2 == 0 else 3.5)
+
+
+def _run_config4_shard(ids, cache):
+    """One rank's shard of configs[4]: the streams `ids` (global indices), 10 s each, one plan / launch set per sample
+    rate.  Returns {global index: int16 output}."""
+    from speedy_amd.batch import Batch, Plan
+    from speedy_amd.synth import speech_like
+    out = {}
+    for rate in (16000, 22050):
+        idx = [i for i in ids if _config4_stream_cfg(i)[0] == rate]
+        if not idx:
+            continue
+        streams = []
+        for i in idx:
+            _, ch, _ = _config4_stream_cfg(i)
+            key = (rate, ch, i % 24)      # 24 distinct signals per kind; slots differ in the mix they sit in
+            if key not in cache:
+                cache[key] = speech_like(10 * rate, rate, seed=5000 + i % 24, channels=ch)
+            streams.append(cache[key])
+        b = Batch(Plan(rate, False), [10 * rate] * len(idx), [_config4_stream_cfg(i)[1] for i in idx],
+                  [_config4_stream_cfg(i)[2] for i in idx], 1.0, 0.0)
+        b.upload(streams)
+        b.run()
+        for k, o in zip(idx, b.results()):
+            out[k] = o
+    return out
+
+
+def test_config4_one_gpu_shard_full_size(orc):
+    """BASELINE configs[4], one GPU's shard at FULL size: 256 mixed streams x 10 s (16 k / 22.05 k, mono / stereo,
+    1.5x / 3.5x, nonlinear).  Per-stream bytes identical for the partitions {256} and {128, 128}; at least 8 streams of
+    each of the 8 kinds against the oracle."""
+    import zlib
+    cache = {}
+    whole = _run_config4_shard(list(range(256)), cache)
+    halves = {}
+    halves.update(_run_config4_shard(list(range(0, 128)), cache))
+    halves.update(_run_config4_shard(list(range(128, 256)), cache))
+    assert sorted(whole) == list(range(256)) == sorted(halves)
+    for i in range(256):
+        assert zlib.crc32(whole[i].tobytes()) == zlib.crc32(halves[i].tobytes()), i
+    checked = {}
+    for i in range(256):
+        rate, ch, speed = _config4_stream_cfg(i)
+        kind = (rate, ch, speed)
+        if checked.get(kind, 0) >= 8:
+            continue
+        x = cache[(rate, ch, i % 24)]
+        ref = orc.compress_sound(x, rate, ch, speed, 1.0, 0.0, False, taps=False)["out"]
+        assert np.array_equal(whole[i], ref), (i, kind)
+        checked[kind] = checked.get(kind, 0) + 1
+    assert len(checked) == 8 and all(v >= 8 for v in checked.values()), checked
 
 
 @pytest.mark.parametrize("chunks", [2, 5])
