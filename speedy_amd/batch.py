@@ -113,6 +113,10 @@ class Batch:
         """Synchronise and return per-stream int16 outputs (host numpy)."""
         torch.cuda.synchronize(self.device)
         nout = self.d_nout.cpu().numpy()
+        lost = nout == np.iinfo(np.int64).min   # SPX_NOUT_LOST_PRODUCER
+        if lost.any():
+            raise RuntimeError("a producer kernel never delivered its frames to streams %s (device-side poll limit)"
+                               % np.nonzero(lost)[0][:8])
         if (nout < 0).any():
             raise RuntimeError("output capacity exceeded for streams %s" % np.nonzero(nout < 0)[0][:8])
         out = self.d_out.cpu().numpy()

@@ -161,7 +161,11 @@ static bool sync_stream(sonicStream s) {
     s->failed = true;
     return false;
   }
-  if (n < 0) {
+  if (n == SPX_NOUT_LOST_PRODUCER) {
+    g_api_err = "a producer kernel never delivered its frames (device-side poll limit reached)";
+    s->failed = true;
+    n = s->outKnown;
+  } else if (n < 0) {
     g_api_err = "output capacity exceeded on the device";
     s->failed = true;
     n = -n;

@@ -55,8 +55,8 @@ size_t spx_analysis_lds_bytes(const SpxPlanDev& P) {  // for the tile size the p
   size_t mags = (size_t)(tf + 1) * (P.W + 1) * sizeof(float);
   size_t small = (size_t)3 * (tf + 1) * sizeof(float);
   size_t stage = (stage_samples(P, tf) * sizeof(short) + 15) & ~(size_t)15;
-  size_t pad = 0;  // tuning only (fewer workgroups per CU); part of the size so that the co-residency rule sees it
-  if (const char* e = getenv("SPX_ANALYSIS_LDS_PAD")) pad = (size_t)atoi(e);
+  // tuning only (fewer workgroups per CU); part of the size so that the co-residency rule sees it; read once per process
+  static const size_t pad = [] { const char* e = getenv("SPX_ANALYSIS_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
   return work_bytes(P.W, tf) + ((mags + 15) & ~(size_t)15) + ((small + 15) & ~(size_t)15) + stage + pad;
 }
 

@@ -352,8 +352,9 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       cu_count = 1; lds_per_cu = 65536;
     }
   }
-  const size_t per_stream_lds = spx_walk_lds_bytes(d, maxC, speedup_only) + spx_tension_lds_bytes();
-  const size_t per_stream_waves = (n <= 256 ? 8 : 4) + 4;  // walk (spx_launch_walk's choice) + tension
+  const SpxWalkConfig wcfg = spx_walk_config(d, n, maxC, speedup_only);
+  const size_t per_stream_lds = wcfg.lds + spx_tension_lds_bytes();
+  const size_t per_stream_waves = (size_t)wcfg.waves + 4;  // walk (spx_launch_walk's choice) + tension
   bool co_resident = false;
   // Two tile sizes: the smaller one costs the analysis about a fifth more time (one halo frame per 8 instead of per 16)
   // but a quarter less LDS; it is taken when that is what lets two analysis workgroups sit beside a stream's
@@ -532,7 +533,8 @@ __global__ void spx_pack_offsets_kernel(const int64_t* __restrict__ n_out, const
     for (int i = 0; i < n; i++) {
       offsets[i] = acc;
       const int64_t k = n_out[i];
-      acc += (k > 0 ? k : -k) * channels[i];  // a negative count flags an overflowed stream: its frames are still there
+      // a negative count flags an overflowed stream (its frames are still there); INT64_MIN a lost producer (nothing)
+      acc += (k == INT64_MIN ? 0 : (k > 0 ? k : -k)) * channels[i];
     }
     offsets[n] = acc;
   }

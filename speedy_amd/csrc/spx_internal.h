@@ -109,6 +109,23 @@ size_t spx_analysis_lds_bytes(const SpxPlanDev& P);
 // The DFT of the spec run on the host (same operation order as the kernel): used to build the Rader tables.
 void spx_host_dft(int n, const int* radix, int nstages, const double* tw, const double* in, double* out);
 size_t spx_walk_lds_bytes(const SpxPlanDev& P, int max_channels, bool speedup_only);
+// What spx_launch_walk will do for a batch (kernel variant, waves and LDS per stream).
+struct SpxWalkConfig {
+  int mode;          // 0 general, 1 mono speed-up, 2 multi-channel speed-up
+  bool fast_kernel;  // mode 1 on spx_walk_fast_kernel
+  int nw;            // waves per stream of spx_walk_kernel
+  int nwm, nwc, wcap;  // spx_walk_fast_kernel: search waves, output waves, window frames
+  int waves;         // waves per stream of the kernel that will run
+  size_t lds;        // its LDS bytes per stream
+};
+SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only);
+// spx_walk_fast.hip
+size_t spx_walk_fast_lds_bytes(const SpxPlanDev& P, int wcap);
+void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, const int16_t* in,
+                          int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
+                          const int* speed_ready, int nwm, int nwc, int wcap, hipStream_t st);
+// n_out value of a stream whose producer kernel never delivered (concurrent mode poll limit): not an overflow
+#define SPX_NOUT_LOST_PRODUCER INT64_MIN
 size_t spx_tension_lds_bytes();
 int spx_analysis_tile_frames();
 int spx_analysis_small_tile_frames();

@@ -29,25 +29,7 @@
 #define SPX_CH 1024  // frames per prologue chunk held in LDS
 #define SPX_WCH 64   // frames in the first walk chunk when the analysis kernel runs concurrently (multiple of the tile)
 
-// In-kernel positions are 32-bit (the host rejects streams of 2^30 frames or more): half the SGPRs and none of the
-// 64-bit add/compare sequences in the per-step bookkeeping.  The carried state record stays 64-bit.
-typedef int pos_t;
-struct WalkState {
-  pos_t base, out_n, avail;
-  int remaining, prevPeriod, prevMinDiff, overflow, prevPeriod_toggle;
-};
-
-// Values that are the same in every lane but that the compiler cannot prove uniform (they come from LDS or from
-// lane-indexed loads): pin them to SGPRs so the bookkeeping around a pitch step runs on the scalar unit.
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float unif(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
-}
-__device__ __forceinline__ int64_t uni64(int64_t v) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
-  return (int64_t)(((unsigned long long)hi << 32) | lo);
-}
+#include "spx_walk_common.h"
 
 // Diagnostic build only (-DSPX_STAMPS): per-phase shader-cycle sums of workgroup 0, lane 0.  Never in the product.
 #ifdef SPX_STAMPS
@@ -86,44 +68,6 @@ extern "C" void spx_debug_stamps(unsigned long long* out, int reset) {
 #define STAMP(i)
 #define STAMP_FLUSH
 #endif
-
-template <int NW>
-__device__ __forceinline__ void lds_sync() {
-  if (NW > 1) {
-    // LDS-only workgroup barrier: outstanding global stores stay in flight
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  } else {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-}
-
-// ---- wave-level min / max over 64 lanes of NON-NEGATIVE floats, done on their bit patterns (same order as
-// unsigned integers, and v_min_u32 / v_max_u32 take the DPP operand directly: one instruction per stage, no float
-// canonicalisation).  Rows of 16 by quad_perm / mirror, then row_bcast:15 and row_bcast:31 carry the row results
-// to lane 63.  Every lane gets the result (readlane 63 -> SGPR).
-// Written as inline assembly because the compiler keeps a v_mov_b32_dpp + v_min pair (and a copy) per stage; the
-// s_nop 1 in front of every stage is the VALU-write -> DPP-read hazard distance the assembler does not insert here.
-#define SPX_WAVE_REDUCE(OP, v)                                                            \
-  asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
-               "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
-               "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"     \
-               "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"          \
-               "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"        \
-               "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"        \
-               "s_nop 1"                                                                  \
-               : "+v"(v))
-__device__ __forceinline__ float wave_min_f(float f) {
-  unsigned v = __builtin_bit_cast(unsigned, f);
-  SPX_WAVE_REDUCE("v_min_u32_dpp", v);
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)v, 63));
-}
-__device__ __forceinline__ float wave_max_f(float f) {
-  unsigned v = __builtin_bit_cast(unsigned, f);
-  SPX_WAVE_REDUCE("v_max_u32_dpp", v);
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)v, 63));
-}
 
 struct WalkCtx {
   const int16_t* in;  // stream input (interleaved)
@@ -268,62 +212,6 @@ __device__ __forceinline__ void ensure_window(WalkCtx& X, pos_t pos, int need) {
   if (FAST) {
     lds_sync<NW>();
   }
-}
-
-// Sum over pairs j in [j0, j1) of |s[2j] - s[2j+p]| + |s[2j+1] - s[2j+p+1]| on biased u16 data: ap is the
-// (wave-uniform) dword view of the signal at the search position, bp the lane's own dword view at lag p.
-// j1 differs per lane: the EXEC mask does the predication, no per-term compare/select instructions.
-__device__ __forceinline__ unsigned sad_run(const unsigned* ap, const unsigned* bp, int j0, int j1) {
-  unsigned acc = 0;
-  int j = j0;
-  if (j + 4 <= j1) {
-    // software-pipelined: the loads of group g+1 are issued before the SADs of group g, so the LDS latency of all
-    // but the first group hides behind arithmetic
-    unsigned a0 = ap[j], a1 = ap[j + 1], a2 = ap[j + 2], a3 = ap[j + 3];
-    unsigned b0 = bp[j], b1 = bp[j + 1], b2 = bp[j + 2], b3 = bp[j + 3];
-    j += 4;
-    while (j + 4 <= j1) {
-      const unsigned c0 = ap[j], c1 = ap[j + 1], c2 = ap[j + 2], c3 = ap[j + 3];
-      const unsigned e0 = bp[j], e1 = bp[j + 1], e2 = bp[j + 2], e3 = bp[j + 3];
-      acc = __builtin_amdgcn_sad_u16(a0, b0, acc);
-      acc = __builtin_amdgcn_sad_u16(a1, b1, acc);
-      acc = __builtin_amdgcn_sad_u16(a2, b2, acc);
-      acc = __builtin_amdgcn_sad_u16(a3, b3, acc);
-      a0 = c0; a1 = c1; a2 = c2; a3 = c3;
-      b0 = e0; b1 = e1; b2 = e2; b3 = e3;
-      j += 4;
-    }
-    acc = __builtin_amdgcn_sad_u16(a0, b0, acc);
-    acc = __builtin_amdgcn_sad_u16(a1, b1, acc);
-    acc = __builtin_amdgcn_sad_u16(a2, b2, acc);
-    acc = __builtin_amdgcn_sad_u16(a3, b3, acc);
-  }
-  // up to three pairs are left: all loaded at once, a pair beyond the bound contributes |a - a| = 0
-  if (j < j1) {
-    const unsigned a0 = ap[j], a1 = ap[j + 1], a2 = ap[j + 2];
-    unsigned b0 = bp[j], b1 = bp[j + 1], b2 = bp[j + 2];
-    b1 = (j + 1 < j1) ? b1 : a1;
-    b2 = (j + 2 < j1) ? b2 : a2;
-    acc = __builtin_amdgcn_sad_u16(a0, b0, acc);
-    acc = __builtin_amdgcn_sad_u16(a1, b1, acc);
-    acc = __builtin_amdgcn_sad_u16(a2, b2, acc);
-  }
-  return acc;
-}
-
-// Exact division of small unsigned numbers (x < 2^31, 1 <= d < 2^12) without the 30-instruction integer
-// division expansion: float estimate, then at most one correction each way.
-__device__ __forceinline__ unsigned udiv_small(unsigned x, unsigned d) {
-  // x < 2^27 (an AMDF sum) and d >= 10 (a lag), q < 2^19, so the estimate is off by at most 2: two branch-free fix-ups each
-  // way in wrapping 32-bit arithmetic (the true remainder lies in (-2d, 3d), far from the wrap)
-  unsigned q = (unsigned)((float)x * __builtin_amdgcn_rcpf((float)d));
-  int r = (int)(x - q * d);
-  const int di = (int)d;
-  q -= r < 0; r += r < 0 ? di : 0;
-  q -= r < 0; r += r < 0 ? di : 0;
-  q += r >= di; r -= r >= di ? di : 0;
-  q += r >= di; r -= r >= di ? di : 0;
-  return q;
 }
 
 // Running result of the dependency's sequential arg-min / arg-max scan over lags.
@@ -487,9 +375,6 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
   // barrier, so no barrier is needed here
   if (!FAST) lds_sync<NW>();  // decimated signal visible; last step's buffer clearing finished
   STAMP(4);
-#if defined(SPX_EXPERIMENT) && SPX_EXPERIMENT == 1
-  { st.prevPeriod = 100; st.prevMinDiff = 1; return 100 + (int)(pos & 15); }
-#endif
   // ---- first search ----
   const unsigned* M0 = reinterpret_cast<const unsigned*>(X.monoH);
   const unsigned* M1 = reinterpret_cast<const unsigned*>(X.monoHB);
@@ -520,9 +405,6 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
     int lo = period - (skip << 2), hi = period + (skip << 2);
     if (lo < P.minPeriod) lo = P.minPeriod;
     if (hi > P.maxPeriod) hi = P.maxPeriod;
-#if defined(SPX_EXPERIMENT) && SPX_EXPERIMENT == 2
-    { st.prevPeriod = period; st.prevMinDiff = 1; return period; }
-#endif
     // ---- refine at full rate ----
     Sel S2 = {0u, 0u, 0, 0};
     if (FAST) {
@@ -667,9 +549,7 @@ __device__ __forceinline__ void tsm_process(const SpxPlanDev& P, WalkCtx& X, Wal
           if (st.out_n + n > X.out_cap) st.overflow = 1;
           if (n == 0) return;  // the dependency treats this as failure and leaves the input untouched
           STAMP(11);
-#if !(defined(SPX_EXPERIMENT) && SPX_EXPERIMENT == 3)
           emit_overlap_add<NW, FAST>(X, pos, pos + period, n, st.out_n);
-#endif
           STAMP(13);
           st.out_n += n;
           position += period + n;
@@ -737,9 +617,6 @@ __device__ __forceinline__ bool fast_steps(const SpxPlanDev& P, WalkCtx& X, Walk
   return true;
 }
 
-__device__ __forceinline__ bool speed_is_unity(float speed) {  // the dependency's pass-through test
-  return !((double)speed > 1.00001 || (double)speed < 0.99999);
-}
 
 // All events of a chunk through ONE call site of the step code (the kernel stays small):
 //   ordinary events [ev0, ev1): nonlinear -- event e sets the speed of tension frame e (e < K; later events keep the
@@ -928,7 +805,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
           got = __hip_atomic_load(&speed_ready[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (got < 0 || got > (int)handed || got >= K_total) break;
           __builtin_amdgcn_s_sleep(32);
-          if (++spins > (1u << 22)) { got = -1; break; }  // ~seconds: never hang the GPU on a lost producer
+          if (++spins > (1u << 22)) { got = -2; break; }  // ~seconds: never hang the GPU on a lost producer
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -937,7 +814,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
       __syncthreads();
       K = uni(*sWait);
       __syncthreads();  // sWait may be rewritten by the next round
-      if (K < 0) { st.overflow = 1; break; }
+      if (K < 0) { st.overflow = 2; break; }  // the producer was lost: its own status, not an overflow
       if (K > K_total) K = K_total;
     }
     const bool last = K >= K_total;
@@ -1004,8 +881,28 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
     states[blockIdx.x].w = Z.w;  // field-wise: the tension kernel may be writing its own fields of this record
     states[blockIdx.x].curSpeed = curSpeed;
     if (nl != 0.0f) states[blockIdx.x].handed = (int)handed;
-    if (n_out) n_out[blockIdx.x] = st.overflow ? -(int64_t)st.out_n : (int64_t)st.out_n;
+    if (n_out) n_out[blockIdx.x] = st.overflow == 2 ? INT64_MIN : (st.overflow ? -(int64_t)st.out_n : (int64_t)st.out_n);
   }
+}
+
+// Tuning knobs from the environment, read ONCE per process (never on the launch path).
+struct WalkTuning {
+  bool generic, old_fast;
+  int nw, nwm, nwc, wcap;
+};
+static const WalkTuning& walk_tuning() {
+  static const WalkTuning T = [] {
+    WalkTuning t;
+    auto geti = [](const char* k) { const char* e = getenv(k); return e ? atoi(e) : -1; };
+    t.generic = getenv("SPX_WALK_GENERIC") != nullptr;   // force the general kernel
+    t.old_fast = getenv("SPX_WALK_OLD") != nullptr;      // mono speed-up batches on spx_walk_kernel<NW, 1> (A/B only)
+    t.nw = geti("SPX_WALK_NW");
+    t.nwm = geti("SPX_WALK_NWM");
+    t.nwc = geti("SPX_WALK_NWC");
+    t.wcap = geti("SPX_WALK_WCAP");
+    return t;
+  }();
+  return T;
 }
 
 // Which kernel variant a batch gets: 0 general, 1 speed-up mono, 2 speed-up multi-channel.  FAST: all streams speeding
@@ -1013,13 +910,44 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
 // search (rates below 32 kHz), and the usual 4096-frame window.
 static int walk_mode(const SpxPlanDev& P, int maxC, bool speedup_only) {
   if (speedup_only && P.skip >= 2 && (P.maxPeriod / P.skip - P.minPeriod / P.skip + 1) <= 64 && (8 * P.skip + 1) <= 64 &&
-      walk_lds_layout(P, maxC).wcap == 4096 && maxC <= 8 && !getenv("SPX_WALK_GENERIC"))
+      walk_lds_layout(P, maxC).wcap == 4096 && maxC <= 8 && !walk_tuning().generic)
     return (maxC == 1) ? 1 : 2;
   return 0;
 }
-size_t spx_walk_lds_bytes(const SpxPlanDev& P, int maxC, bool speedup_only) {
+
+// Kernel variant, waves per stream and LDS per stream for a batch: the one place the launcher and the engine's
+// co-residency arithmetic both ask.
+SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only) {
   if (maxC < 1) maxC = 1;
-  return (size_t)walk_lds_layout(P, maxC, walk_mode(P, maxC, speedup_only)).total;
+  const WalkTuning& T = walk_tuning();
+  SpxWalkConfig c;
+  c.mode = walk_mode(P, maxC, speedup_only);
+  c.fast_kernel = (c.mode == 1 && !T.old_fast);
+  // Waves per stream of spx_walk_kernel.  Measured on MI355X, 10 s streams (ms per call; 2 / 4 / 8 waves): 256 streams
+  // 3.67 / 3.19 / 2.91 (walk kernel alone), 512: 5.40 / 4.78 / 5.63, 1024: 10.3 / 9.3 / 10.5, 2048: 19.7 / 17.7 / -.
+  c.nw = (n_streams <= 256) ? 8 : 4;
+  if (T.nw > 0) c.nw = T.nw;
+  // spx_walk_fast_kernel: search waves + output waves, window frames
+  c.nwm = 4;
+  c.nwc = (n_streams <= 256) ? 4 : 1;
+  c.wcap = 4096;
+  if (T.nwm > 0) c.nwm = T.nwm;
+  if (T.nwc >= 0) c.nwc = T.nwc;
+  if (T.wcap > 0) c.wcap = T.wcap;
+  const int need = P.maxRequired + 2 * P.skip + 2;
+  if (c.wcap < 2 * need) c.wcap = 2 * need;
+  c.wcap = (c.wcap + 7) & ~7;
+  if (c.fast_kernel) {
+    c.waves = c.nwm + c.nwc;
+    c.lds = spx_walk_fast_lds_bytes(P, c.wcap);
+  } else {
+    c.waves = c.nw;
+    c.lds = (size_t)walk_lds_layout(P, maxC, c.mode).total;
+  }
+  return c;
+}
+size_t spx_walk_lds_bytes(const SpxPlanDev& P, int maxC, bool speedup_only) {
+  return spx_walk_config(P, 256, maxC, speedup_only).lds;
 }
 
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int maxC, const int16_t* in,
@@ -1027,13 +955,15 @@ void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_str
                      const int* speed_ready, bool speedup_only, hipStream_t st) {
   if (n_streams <= 0) return;
   if (maxC < 1) maxC = 1;
-  WalkLds LY = walk_lds_layout(P, maxC);
-  // Waves per stream.  Measured on MI355X, 10 s streams (ms per call; 2 / 4 / 8 waves): 256 streams 3.67 / 3.19 / 2.91
-  // (walk kernel alone), 512: 5.40 / 4.78 / 5.63, 1024: 10.3 / 9.3 / 10.5, 2048: 19.7 / 17.7 / - (1 wave: 21.4).
-  // One workgroup per CU wants all eight wave slots of two-per-SIMD; several workgroups per CU hide each other's
-  // latencies and do best with four.  SPX_WALK_NW overrides (tuning only).
-  int nw = (n_streams <= 256) ? 8 : 4;
-  if (const char* e = getenv("SPX_WALK_NW")) nw = atoi(e);
+  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC, speedup_only);
+  if (cfg.fast_kernel) {
+    spx_launch_walk_fast(P, streams, n_streams, in, out, n_out, states, scratch, speed_ready, cfg.nwm, cfg.nwc, cfg.wcap,
+                         st);
+    return;
+  }
+  const int fast = cfg.mode;
+  const int nw = cfg.nw;
+  const WalkLds LY = walk_lds_layout(P, maxC, fast);
 #define SPX_LAUNCH_WALK(NWV)                                                                                     \
   do {                                                                                                           \
     if (fast == 1)                                                                                               \
@@ -1046,8 +976,6 @@ void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_str
       hipLaunchKernelGGL((spx_walk_kernel<NWV, 0>), dim3(n_streams), dim3(64 * NWV), LY.total, st, P, streams,   \
                          in, out, n_out, states, scratch, maxC, speed_ready);                                    \
   } while (0)
-  const int fast = walk_mode(P, maxC, speedup_only);
-  LY = walk_lds_layout(P, maxC, fast);
 #ifdef SPX_STAMPS
   if (nw == 4) SPX_LAUNCH_WALK(4); else SPX_LAUNCH_WALK(8);  // the diagnostic build carries two kernels only
   return;

@@ -14,6 +14,17 @@ NAMES = {0: "event loop (between process calls)", 1: "pre-step (copy steps, loop
          13: "overlap-add", 14: "frame-rate passes (prologue)"}
 
 
+KIND = os.environ.get("STAMP_KIND", "fast")   # "fast": spx_walk_fast.hip (make fstamps); "old": spx_walk.hip (make stamps)
+if KIND == "fast":
+    NAMES = {0: "event loop (between events)", 1: "step entry / loop control", 2: "window check + refill",
+             3: "publish + coarse accumulate", 4: "barrier A wait", 5: "coarse sums read + select",
+             6: "refine setup + accumulate", 7: "barrier B wait", 8: "refine sums read + select",
+             9: "previous-period rule", 10: "n, state update", 11: "after the steps of an event"}
+FN = "spx_debug_fstamps" if KIND == "fast" else "spx_debug_stamps"
+PREFIX = "libspeedy_hip_fstamps_%d.so" if KIND == "fast" else "libspeedy_hip_stamps_%d.so"
+NSEL = 12 if KIND == "fast" else 15
+
+
 def child(sel):
     sys.path.insert(0, ROOT)
     import torch
@@ -27,12 +38,13 @@ def child(sel):
     b.run()
     torch.cuda.synchronize()
     L = plan.L
-    L.spx_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    dbg = getattr(L, FN)
+    dbg.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     buf = (C.c_ulonglong * 32)()
-    L.spx_debug_stamps(buf, 1)
+    dbg(buf, 1)
     b.run()
     torch.cuda.synchronize()
-    L.spx_debug_stamps(buf, 1)
+    dbg(buf, 1)
     print("STAMP %d %d %d %d" % (sel, buf[sel], buf[30], buf[31]))
 
 
@@ -41,9 +53,9 @@ if len(sys.argv) > 1:
     sys.exit(0)
 
 rows = []
-for sel in range(15):
+for sel in range(NSEL):
     env = dict(os.environ, SPX_SERIAL="1",
-               SPEEDY_HIP_LIB=os.path.join(ROOT, "speedy_amd", "lib", "stamps", "libspeedy_hip_stamps_%d.so" % sel))
+               SPEEDY_HIP_LIB=os.path.join(ROOT, "speedy_amd", "lib", "stamps", PREFIX % sel))
     out = subprocess.run([sys.executable, os.path.abspath(__file__), str(sel)], env=env, capture_output=True, text=True)
     for line in out.stdout.splitlines():
         if line.startswith("STAMP"):
