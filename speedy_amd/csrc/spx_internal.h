@@ -121,6 +121,7 @@ struct SpxWalkConfig {
 SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only);
 // spx_walk_fast.hip
 size_t spx_walk_fast_lds_bytes(const SpxPlanDev& P, int wcap);
+bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm);
 void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, const int16_t* in,
                           int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
                           const int* speed_ready, int nwm, int nwc, int wcap, hipStream_t st);

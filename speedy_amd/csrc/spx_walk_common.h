@@ -156,3 +156,68 @@ __device__ __forceinline__ unsigned sad_share(const unsigned* ap, const unsigned
     acc = sad_flight<MAXG, MASKED>(ap + 4 * g0, bp + 4 * g0, nG - g0, cnt - 4 * g0, acc);
   return acc;
 }
+
+// Exact-count flights: NG groups of four pairs, all loads first, then all SADs; dispatched on the (wave-uniform) group
+// count so that no flight computes groups it does not have.
+template <int NG, bool MASKED>
+__device__ __forceinline__ unsigned sad_flight_n(const unsigned* ap, const unsigned* bp, int cnt, unsigned acc) {
+  unsigned a[NG > 0 ? NG : 1][4], b[NG > 0 ? NG : 1][4];
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) { a[g][k] = ap[4 * g + k]; b[g][k] = bp[4 * g + k]; }
+  }
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      unsigned bb = b[g][k];
+      if (MASKED) bb = (4 * g + k < cnt) ? bb : a[g][k];
+      acc = __builtin_amdgcn_sad_u16(a[g][k], bb, acc);
+    }
+  }
+  return acc;
+}
+template <bool MASKED>
+__device__ __forceinline__ unsigned sad_groups(const unsigned* ap, const unsigned* bp, int nG, int cnt, unsigned acc) {
+  while (nG > 8) {  // longer shares (high sample rates, few search waves): flights of eight groups
+    acc = sad_flight_n<8, MASKED>(ap, bp, cnt, acc);
+    ap += 32; bp += 32; cnt -= 32; nG -= 8;
+  }
+  switch (nG) {
+    case 1: return sad_flight_n<1, MASKED>(ap, bp, cnt, acc);
+    case 2: return sad_flight_n<2, MASKED>(ap, bp, cnt, acc);
+    case 3: return sad_flight_n<3, MASKED>(ap, bp, cnt, acc);
+    case 4: return sad_flight_n<4, MASKED>(ap, bp, cnt, acc);
+    case 5: return sad_flight_n<5, MASKED>(ap, bp, cnt, acc);
+    case 6: return sad_flight_n<6, MASKED>(ap, bp, cnt, acc);
+    case 7: return sad_flight_n<7, MASKED>(ap, bp, cnt, acc);
+    case 8: return sad_flight_n<8, MASKED>(ap, bp, cnt, acc);
+    default: return acc;
+  }
+}
+
+// A wave-uniform range of pairs [0, n) at ap / bp, n <= 4 * NG: every load first (groups the range does not reach read
+// the `a` operand twice, so they add |a - a| = 0 -- one address select per group instead of a branch), then all SADs;
+// the pairs of the last, partial group are switched off by wave-uniform selects.  One LDS round trip, no dispatch.
+template <int NG>
+__device__ __forceinline__ unsigned sad_uniform(const unsigned* ap, const unsigned* bp, int n, unsigned acc) {
+  unsigned a[NG][4], b[NG][4];
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    const unsigned* bg = (4 * g < n) ? bp : ap;   // uniform condition
+#pragma unroll
+    for (int k = 0; k < 4; k++) { a[g][k] = ap[4 * g + k]; b[g][k] = bg[4 * g + k]; }
+  }
+  const int tail = n & ~3;  // first pair of the partial group (if any)
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      unsigned bb = b[g][k];
+      if (k > 0) bb = (4 * g == tail && 4 * g + k >= n) ? a[g][k] : bb;   // uniform: pairs past n in the partial group
+      acc = __builtin_amdgcn_sad_u16(a[g][k], bb, acc);
+    }
+  }
+  return acc;
+}

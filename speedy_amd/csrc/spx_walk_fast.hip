@@ -1,29 +1,42 @@
 // Walk kernel for the common case -- mono streams that only ever speed up (every job speed > 1, 0 <= nonlinear <= 1),
 // rates below 32 kHz (at most 64 lags in either pitch search): BASELINE configs[1..3] and the mono half of configs[4].
 // Same stage as spx_walk.hip (a10 AMDF pitch search, a11 skip + cross-fade, FIFO bookkeeping, flush; driven by the
-// shim's event sequence soniclib.c:354,369,538-551), same results bit for bit; what differs is how a pitch step is laid
-// on the hardware, because a stream is a chain of ~130 dependent pitch steps per second of audio and at 256 streams per
-// GPU (one workgroup per CU) the length of that chain is the run time:
+// shim's event sequence soniclib.c:354,369,538-551), same results bit for bit.  What differs is how a pitch step is laid
+// on the hardware: a stream is a chain of ~130 dependent pitch steps per second of audio, at 256 streams per GPU (one
+// workgroup per CU) the length of that chain is the run time, and on gfx950 a wave issues one instruction every 4-5
+// cycles whatever the instruction is (tools/ubench/issue_costs.hip: s_add 4.1, v_add 5.1, a taken branch 20, a
+// v_readlane feeding the scalar unit 12+, an LDS round trip 67) -- so the chain is priced in INSTRUCTIONS per step:
 //
 //   * two kinds of wavefronts in a workgroup.  NWM "search" waves run the chain: the two AMDF searches, the decision,
 //     the event bookkeeping -- all control flow, redundantly and uniformly.  NWC "output" waves never take part in a
-//     search: they wait at the workgroup barrier (a waiting wave uses no issue slots, so each SIMD's search wave issues
-//     alone), receive {cross-fade, copy, refill, poll, exit} commands through two LDS slots and produce every output
-//     sample.  Output work is thereby off the chain.
+//     search: they wait at the workgroup barrier (a waiting wave uses no issue slots), receive {cross-fade, copy,
+//     refill, poll, exit} commands through two LDS slots and produce every output sample.  Output work is off the chain.
+//   * coarse search: the lags x sample-pairs triangle is cut into groups of four pairs and dealt to the lanes of the
+//     search waves ONCE, at kernel start (16 kHz: 254 groups for 256 lanes): a lane's operand offsets and byte masks are
+//     constants, a step is two address computations, four ds_read2_b32, four masked v_sad_u16 and one ds_add_u32.
+//   * refine search: lane = lag, wave = share of the sample pairs, every operand load of the share in flight before
+//     the first SAD (one LDS round trip per share, not one per group).
 //   * arg-min of diff/lag without floats or a resolve loop: key = floor(diff * 2^16 / lag) as an exact integer
 //     (one fp64 fma against a 65536/lag table + truncation); keys order exactly like the rationals whenever
 //     lag1*lag2 < 2^16 (16 kHz: 246^2) and never invert the order otherwise (ties are then resolved exactly, rarely);
 //     one v_min_u32 DPP reduction, one ballot, first set bit = the lag a sequential scan would have chosen;
 //     minDiff = key >> 16 comes for free.
-//   * the rest as in spx_walk.hip: LDS sliding window of biased u16 samples kept twice (shifted by one) so that any lag
-//     reads aligned pairs for v_sad_u16, decimated planes built at refill time, partial sums of the waves met with
-//     ds_add_u32, LDS-only barriers (output stores are never waited for).
+//   * what the step does with the chosen period (n = (int)(period / (speed - 1)), an exact IEEE division) is evaluated
+//     for EVERY candidate period (lane = candidate) while the refine sums are still on their way; the chain pays a
+//     v_readlane for it.
+//   * the next event that can do anything (most bring too little input for a step) is found with one ballot over the
+//     64 events whose speeds sit in a VGPR.
+//   * as in spx_walk.hip: LDS sliding window of biased u16 samples kept twice (shifted by one) so that any lag reads
+//     aligned pairs for v_sad_u16, decimated planes built at refill time, partial sums met with ds_add_u32, LDS-only
+//     barriers (output stores are never waited for).
 #include <stdlib.h>
 
 #include "spx_walk_common.h"
 
 enum { FCMD_STEP = 1, FCMD_COPY = 2, FCMD_REFILL = 3, FCMD_POLL = 4, FCMD_EXIT = 5 };
-#define FCMD_INTS 16  // ints per command slot
+#define FCMD_INTS 64  // ints per command slot: field k is written by lane k of the publishing wave
+#define FCG 2         // at most this many coarse groups per lane (22.05 kHz: 303 groups on 256 lanes)
+#define FRG 2         // at most this many ragged refine tasks per lane (22.05 kHz: 420 tasks on 256 lanes)
 
 // Diagnostic build only (-DSPX_STAMPS): per-phase shader-cycle sums of workgroup 0, wave 0.  Never in the product.
 #ifdef SPX_STAMPS
@@ -38,22 +51,22 @@ extern "C" void spx_debug_fstamps(unsigned long long* out, int reset) {
 #ifndef SPX_STAMP_SEL
 #define SPX_STAMP_SEL 0
 #endif
-#define FSTAMP_DECL X.stamp_acc = 0; X.stamp_steps = 0; X.stamp_last = __builtin_readcyclecounter(); X.stamp_t0 = X.stamp_last;
-#define FSTAMP(i)                                                          \
-  do {                                                                     \
-    const unsigned long long t_ = __builtin_readcyclecounter();            \
-    if ((i) == SPX_STAMP_SEL) X.stamp_acc += t_ - X.stamp_last;            \
-    if ((i) == 1) X.stamp_steps++;                                         \
-    X.stamp_last = t_;                                                     \
+#define FSTAMP_VARS unsigned long long stamp_acc = 0, stamp_last = __builtin_readcyclecounter(), stamp_t0 = stamp_last; unsigned stamp_steps = 0;
+#define FSTAMP(i)                                                        \
+  do {                                                                   \
+    const unsigned long long t_ = __builtin_readcyclecounter();          \
+    if ((i) == SPX_STAMP_SEL) stamp_acc += t_ - stamp_last;              \
+    if ((i) == 1) stamp_steps++;                                         \
+    stamp_last = t_;                                                     \
   } while (0)
-#define FSTAMP_FLUSH                                                       \
-  if (threadIdx.x == 0 && blockIdx.x == 0) {                               \
-    g_spx_fstamps[SPX_STAMP_SEL] += X.stamp_acc;                            \
-    g_spx_fstamps[30] += __builtin_readcyclecounter() - X.stamp_t0;         \
-    g_spx_fstamps[31] += X.stamp_steps;                                     \
+#define FSTAMP_FLUSH                                                     \
+  if (threadIdx.x == 0 && blockIdx.x == 0) {                             \
+    g_spx_fstamps[SPX_STAMP_SEL] += stamp_acc;                           \
+    g_spx_fstamps[30] += __builtin_readcyclecounter() - stamp_t0;        \
+    g_spx_fstamps[31] += stamp_steps;                                    \
   }
 #else
-#define FSTAMP_DECL
+#define FSTAMP_VARS
 #define FSTAMP(i)
 #define FSTAMP_FLUSH
 #endif
@@ -62,7 +75,7 @@ extern "C" void spx_debug_fstamps(unsigned long long* out, int reset) {
 struct FastLds {
   int off_cmd, off_wait, off_sumC, off_sumR, off_inv, off_mono, off_monoB, off_pl, off_plB, plStrideB, total, wcap;
 };
-static __host__ __device__ inline FastLds fast_lds_layout(const SpxPlanDev& P, int wcap) {
+static __host__ __device__ inline FastLds fast_lds_layout_i(int maxPeriod, int skip_, int wcap) {
   FastLds L;
   L.wcap = wcap;
   int o = 0;
@@ -70,11 +83,11 @@ static __host__ __device__ inline FastLds fast_lds_layout(const SpxPlanDev& P, i
   L.off_wait = o; o += 16;
   L.off_sumC = o; o += 2 * 64 * 4;
   L.off_sumR = o; o += 2 * 64 * 4;
-  L.off_inv = o; o += ((P.maxPeriod + 2) * 8 + 15) & ~15;
+  L.off_inv = o; o += ((maxPeriod + 2) * 8 + 15) & ~15;
   const int mb = ((wcap + 8) * 2 + 15) & ~15;
   L.off_mono = o; o += mb;
   L.off_monoB = o; o += mb;
-  const int skip = P.skip > 0 ? P.skip : 1;
+  const int skip = skip_ > 0 ? skip_ : 1;
   const int plStride = ((wcap / skip + 4) + 1) & ~1;  // elements per plane (even)
   L.plStrideB = plStride * 2;
   const int plb = (plStride * skip * 2 + 15) & ~15;
@@ -83,25 +96,17 @@ static __host__ __device__ inline FastLds fast_lds_layout(const SpxPlanDev& P, i
   L.total = o;
   return L;
 }
+static __host__ __device__ inline FastLds fast_lds_layout(const SpxPlanDev& P, int wcap) {
+  return fast_lds_layout_i(P.maxPeriod, P.skip, wcap);
+}
 
-struct FastCtx {
+// What the output side needs to know about the stream.
+struct FastOut {
   const int16_t* in;
   int16_t* out;
   unsigned char* lds;
-  pos_t out_cap, limit, wbase;
-  int wcap, offA0, offA1, offPl, offPlB, plStrideB;
-  int skip, skipM;
-  unsigned skipM32;
-  unsigned* sumC;
-  unsigned* sumR;
-  const double* inv;
-  int* cmd;
-  int seq;                              // commands published (search waves) / consumed (output waves)
-  int xf_n, xf_down, xf_period, xf_out;  // cross-fade decided but not yet handed to the output waves
-#ifdef SPX_STAMPS
-  unsigned long long stamp_last, stamp_acc, stamp_t0;
-  unsigned stamp_steps;
-#endif
+  pos_t out_cap;
+  int offA0;
 };
 
 __device__ __forceinline__ void fast_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -118,7 +123,7 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 //     exact: non-integer quotients are at least 1/n >= 2^-11 below the next integer, integer ones land 2^-20 above.
 //   copy: n frames from absolute input position src (straight from HBM, coalesced; beyond `limit` = flush padding = 0).
 template <int NTO>
-__device__ __forceinline__ void fast_outputs(const FastCtx& X, int t0, int xf_n, int xf_down, int xf_period, pos_t xf_out,
+__device__ __forceinline__ void fast_outputs(const FastOut& X, int t0, int xf_n, int xf_down, int xf_period, pos_t xf_out,
                                              int cp_n, pos_t cp_src, pos_t cp_out, pos_t limit) {
   if (xf_n > 0) {
     const double inv = 1.0 / (double)xf_n;
@@ -150,14 +155,15 @@ __device__ __forceinline__ void fast_outputs(const FastCtx& X, int t0, int xf_n,
 // search signal of a step at window offset o is plane (o % skip) from element o / skip on, contiguous.  All NT threads
 // of the workgroup; three LDS barriers.
 template <int NT>
-__device__ __forceinline__ void fast_refill(FastCtx& X, pos_t nb, pos_t limit) {
+__device__ __forceinline__ void fast_refill(const FastOut& X, const FastLds& LY, int skip, pos_t nb, pos_t limit) {
   fast_sync();  // everyone is done reading the old window
-  unsigned short* monoH = reinterpret_cast<unsigned short*>(X.lds + X.offA0);
-  unsigned short* monoHB = reinterpret_cast<unsigned short*>(X.lds + X.offA1);
+  const int wcap = LY.wcap;
+  unsigned short* monoH = reinterpret_cast<unsigned short*>(X.lds + LY.off_mono);
+  unsigned short* monoHB = reinterpret_cast<unsigned short*>(X.lds + LY.off_monoB);
   const int16_t* __restrict__ src = X.in + nb;
   const pos_t room = limit - nb;  // frames of real input from nb on
-  const int last = (int)(room < X.wcap + 1 ? room : X.wcap + 1) - 1;  // last index holding real input
-  for (int k0 = threadIdx.x; k0 < X.wcap + 1; k0 += 8 * NT) {
+  const int last = (int)(room < wcap + 1 ? room : wcap + 1) - 1;  // last index holding real input
+  for (int k0 = threadIdx.x; k0 < wcap + 1; k0 += 8 * NT) {
     int v[8];
     if (last >= 0) {  // uniform
 #pragma unroll
@@ -178,27 +184,25 @@ __device__ __forceinline__ void fast_refill(FastCtx& X, pos_t nb, pos_t limit) {
     for (int u = 0; u < 8; u++) {
       const int k = k0 + u * NT;
       const unsigned short w = (unsigned short)(v[u] + 32768);
-      if (k < X.wcap) monoH[k] = w;
-      if (k > 0 && k < X.wcap + 1) monoHB[k - 1] = w;
+      if (k < wcap) monoH[k] = w;
+      if (k > 0 && k < wcap + 1) monoHB[k - 1] = w;
     }
   }
-  X.wbase = nb;
   fast_sync();
   // One thread per decimated index m: it reads the 2*skip-1 window samples m*skip .. m*skip+2*skip-2 once and slides
   // the sum over them, giving element m of every plane.  |sum| < 2^18 and skip <= 7, so the truncating division is
   // exactly mulhi(|sum|, ceil(2^32 / skip)).
-  const int skip = X.skip;
-  const unsigned M = X.skipM32;
+  const unsigned M = (unsigned)((0x100000000ull + (unsigned)skip - 1) / (unsigned)skip);
   const int bias = 32768 * skip;
-  const int plStride = X.plStrideB >> 1;
-  unsigned short* pl = reinterpret_cast<unsigned short*>(X.lds + X.offPl);
-  unsigned short* plB = reinterpret_cast<unsigned short*>(X.lds + X.offPlB);
-  for (int m = threadIdx.x; (m + 1) * skip <= X.wcap; m += NT) {
+  const int plStride = LY.plStrideB >> 1;
+  unsigned short* pl = reinterpret_cast<unsigned short*>(X.lds + LY.off_pl);
+  unsigned short* plB = reinterpret_cast<unsigned short*>(X.lds + LY.off_plB);
+  for (int m = threadIdx.x; (m + 1) * skip <= wcap; m += NT) {
     const unsigned short* w = monoH + m * skip;
     int sum = 0;
     for (int j = 0; j < skip; j++) sum += (int)w[j];
     for (int r = 0; r < skip; r++) {
-      if ((m + 1) * skip + r > X.wcap) break;  // the last element of the higher planes needs samples past the window
+      if ((m + 1) * skip + r > wcap) break;  // the last element of the higher planes needs samples past the window
       const int v = sum - bias;
       const unsigned mag = (unsigned)(v < 0 ? -v : v);
       const int qm = (int)__umulhi(mag, M);
@@ -210,35 +214,6 @@ __device__ __forceinline__ void fast_refill(FastCtx& X, pos_t nb, pos_t limit) {
   }
   fast_sync();
 }
-
-// Search waves: hand the pending cross-fade (and, for FCMD_COPY, a plain copy) to the output waves.  Every command is
-// followed by exactly one workgroup barrier before the next command is published, and the two slots alternate, so a
-// slot is rewritten only after the output waves have consumed it.  NWC == 0: the search waves do the work themselves.
-template <int NWM, int NWC>
-__device__ __forceinline__ void fast_publish(FastCtx& X, int type, int cp_n, pos_t cp_src, pos_t cp_out, pos_t nb) {
-  if constexpr (NWC > 0) {
-    if (threadIdx.x == 64 * (NWM - 1)) {
-      int* c = X.cmd + (X.seq & 1) * FCMD_INTS;
-      c[0] = type; c[1] = X.xf_n; c[2] = X.xf_down; c[3] = X.xf_period;
-      c[4] = X.xf_out; c[5] = cp_n; c[6] = cp_src; c[7] = cp_out;
-      c[8] = X.limit; c[9] = nb;
-    }
-    X.seq++;
-  } else {
-    fast_outputs<64 * NWM>(X, threadIdx.x, X.xf_n, X.xf_down, X.xf_period, X.xf_out, cp_n, cp_src, cp_out, X.limit);
-  }
-  X.xf_n = 0;
-}
-
-// Per-lane constants of the search waves.
-struct FastLane {
-  int lane, cw;            // cw: which chunk of the sample pairs this wave sums
-  int pC;                  // coarse lag of this lane
-  bool validC, loneC;
-  int nfullC;              // coarse: whole pairs of this lag
-  int j0C, nGC, cntC;      // this wave's share: pairs [j0C, j0C + 4*nGC), of which the first cntC belong to this lag
-  double scaleC;           // 65536 / pC
-};
 
 // arg-min over the lanes of diff/lag (first lag wins ties, as the dependency's sequential scan).  Returns the lane.
 __device__ __forceinline__ int fast_select(unsigned dsum, double scale, bool valid, bool needResolve, int p0,
@@ -263,208 +238,61 @@ __device__ __forceinline__ int fast_select(unsigned dsum, double scale, bool val
   return idx;
 }
 
-// What a step does once its period is chosen, for every speed > 1 (libsonic skipPitchPeriod): n frames of cross-fade,
-// and for 1 < speed < 2 `rem` frames copied through afterwards.  Both are exact IEEE float divisions followed by a
-// truncation; they are evaluated for EVERY candidate period of the refine search (lane = candidate, lane 63 = the
-// previous period) while the sums are still on their way, so that the step's chain only pays a v_readlane for them.
-struct FastSpeed {
-  bool ge2;
-  float sm1, twom;  // speed - 1, 2 - speed
-};
+// lane `LANE` of `old` replaced by the wave-uniform value v (v_writelane_b32: no EXEC change)
+template <typename T>
+__device__ __forceinline__ int fast_writelane_impl(int v, int old, T) { return old; }
+#define fast_writelane(V, LANE, OLD) ([&] { int o_ = (OLD); const int v_ = uni((int)(V)); \
+  asm volatile("v_writelane_b32 %0, %1, " #LANE : "+v"(o_) : "s"(v_)); return o_; }())
 
-// findPitchPeriod at absolute position pos (search waves; every wave returns the same values).
-template <int NWM, int NWC>
-__device__ __forceinline__ int fast_find_period(const SpxPlanDev& P, FastCtx& X, WalkState& st, const FastLane& LN,
-                                                pos_t pos, bool needResolve, const FastSpeed& SP, int& n_out,
-                                                int& rem_out) {
-  constexpr int NT = 64 * (NWM + NWC);
-  constexpr int MAXGC = NWM >= 8 ? 2 : (NWM == 4 ? 3 : 5);   // coarse share: groups of four pairs in one flight
-  constexpr int MAXGR = NWM >= 8 ? 4 : 8;                     // refine share
-  const int skip = P.skip;
-  FSTAMP(1);
-  const int need = P.maxRequired + 2 * skip + 2;
-  if (!(X.wbase >= 0 && pos >= X.wbase && pos + need <= X.wbase + X.wcap)) {
-    const pos_t nb = pos & ~7;
-    fast_publish<NWM, NWC>(X, FCMD_REFILL, 0, 0, 0, nb);
-    if (NWC > 0) fast_sync();
-    fast_refill<NT>(X, nb, X.limit);
-  }
-  FSTAMP(2);
-  fast_publish<NWM, NWC>(X, FCMD_STEP, 0, 0, 0, 0);  // the previous step's cross-fade rides on this step's first barrier
-  const int o = (int)(pos - X.wbase);
-  const int lane = LN.lane;
-  const int tg = st.prevPeriod_toggle & 1;
-  st.prevPeriod_toggle ^= 1;
-  // ---- coarse search on the decimated signal: lane = lag, this wave's share of the sample pairs ----
-  int bestC;
-  {
-    const int oD = (o * X.skipM) >> 16;
-    const int r = o - oD * skip;
-    const int plr = X.offPl + r * X.plStrideB, plBr = X.offPlB + r * X.plStrideB;
-    const int aoff = (oD & 1) ? plBr + 2 * (oD - 1) : plr + 2 * oD;
-    const int e = oD + LN.pC;
-    const int boff = (e & 1) ? plBr + 2 * (e - 1) : plr + 2 * e;
-    const unsigned* ap = reinterpret_cast<const unsigned*>(X.lds + aoff);
-    const unsigned* bp = reinterpret_cast<const unsigned*>(X.lds + boff);
-    unsigned ah = 0, bh = 0;
-    if (LN.cw == NWM - 1) { ah = ap[LN.nfullC]; bh = bp[LN.nfullC]; }  // the lone term i = p-1 of the odd lags
-    unsigned d = sad_share<MAXGC, true>(ap + LN.j0C, bp + LN.j0C, LN.nGC, LN.cntC, 0u);
-    if (LN.cw == NWM - 1) d = __builtin_amdgcn_sad_u16(ah & 0xffffu, (LN.loneC ? bh : ah) & 0xffffu, d);
-    if (LN.validC) atomicAdd(&X.sumC[tg * 64 + lane], d);
-    FSTAMP(3);
-    fast_sync();
-    FSTAMP(4);
-    if (threadIdx.x < 64) X.sumC[(1 - tg) * 64 + lane] = 0;  // the buffer the previous step used: everyone is past it
-    const unsigned dsum = X.sumC[tg * 64 + lane];
-    unsigned kmin;
-    bestC = fast_select(dsum, LN.scaleC, LN.validC, false, P.minPeriod / skip, kmin);
-  }
-  FSTAMP(5);
-  // ---- refine at full rate around the coarse winner ----
-  int period = (P.minPeriod / skip + bestC) * skip;
-  int lo = period - (skip << 2), hi = period + (skip << 2);
-  if (lo < P.minPeriod) lo = P.minPeriod;
-  if (hi > P.maxPeriod) hi = P.maxPeriod;
-  const int nl = hi - lo + 1;
-  const bool valid = lane < nl;
-  const int p = lo + lane;
-  const double scale = X.inv[valid ? p : lo];
-  unsigned dsum;
-  int nLane, remLane;
-  {
-    const int CH = (((hi >> 1) + NWM) / NWM + 3) & ~3;
-    const int aoff = (o & 1) ? X.offA1 + 2 * (o - 1) : X.offA0 + 2 * o;
-    const int e = o + p;
-    const int boff = (e & 1) ? X.offA1 + 2 * (e - 1) : X.offA0 + 2 * e;
-    const unsigned* ap = reinterpret_cast<const unsigned*>(X.lds + aoff);
-    const unsigned* bp = reinterpret_cast<const unsigned*>(X.lds + boff);
-    const int nfull = p >> 1;
-    const int j0 = LN.cw * CH;
-    unsigned ah = 0, bh = 0;
-    if (LN.cw == NWM - 1) { ah = ap[nfull]; bh = bp[nfull]; }
-    unsigned d;
-    // every valid lag has at least (lo >> 1) whole pairs: shares that end below that need no per-pair masks
-    if ((lo >> 1) >= j0 + CH) d = sad_share<MAXGR, false>(ap + j0, bp + j0, CH >> 2, 0, 0u);
-    else d = sad_share<MAXGR, true>(ap + j0, bp + j0, CH >> 2, nfull - j0, 0u);
-    if (LN.cw == NWM - 1) d = __builtin_amdgcn_sad_u16(ah & 0xffffu, ((p & 1) ? bh : ah) & 0xffffu, d);
-    if (valid) atomicAdd(&X.sumR[tg * 64 + lane], d);
-    // what the step will do for each candidate period (see FastSpeed); lane 63 holds the previous period
-    {
-      const int pc = (lane == 63) ? st.prevPeriod : p;
-      const float fp = (float)pc;
-      nLane = SP.ge2 ? (int)(fp / SP.sm1) : pc;
-      remLane = SP.ge2 ? 0 : (int)(fp * SP.twom / SP.sm1);
-    }
-    FSTAMP(6);
-    fast_sync();
-    FSTAMP(7);
-    if (threadIdx.x < 64) X.sumR[(1 - tg) * 64 + lane] = 0;
-    dsum = X.sumR[tg * 64 + lane];
-  }
-  unsigned kmin;
-  const int best = fast_select(dsum, scale, valid, needResolve, lo, kmin);
-  period = lo + best;
-  const int minDiff = (int)(kmin >> 16);  // floor(diff / lag) of the winner
-  FSTAMP(8);
-  // Previous-period rule (libsonic prevPeriodBetter, preferNewPeriod = 1).  Only "maxDiff > 3*minDiff" is ever asked of
-  // the worst lag, and max_p floor(d_p/p) = floor(max_p d_p/p), so the test is "some lag has d_p >= (3*minDiff+1)*p".
-  int ret = period, sel = best;
-  if (minDiff != 0 && st.prevPeriod != 0 && minDiff * 2 > st.prevMinDiff * 3) {
-    const unsigned need3 = 3u * (unsigned)minDiff + 1u;
-    if (__builtin_amdgcn_ballot_w64(valid && dsum >= need3 * (unsigned)p) == 0) { ret = st.prevPeriod; sel = 63; }
-  }
-  st.prevMinDiff = minDiff;
-  st.prevPeriod = period;
-  n_out = __builtin_amdgcn_readlane(nLane, sel);
-  rem_out = __builtin_amdgcn_readlane(remLane, sel);
-  FSTAMP(9);
-  return ret;
-}
+// byte address of the aligned dword holding elements (e, e+1) of a u16 array kept twice, the second copy shifted by one
+// element: base + 2e for even e, (base of the shifted copy - 2) + 2e for odd e;  d2 = shiftedBase - 2 - base
+__device__ __forceinline__ int pair_addr(int base, int d2, int e) { return base + 2 * e + (e & 1) * d2; }
 
-// The pitch steps one event can run = the loop of libsonic's processStreamInput for speed > 1 with `avail` frames handed
-// over.  The caller guarantees avail - st.base >= maxRequired.  A step that fails (n == 0) ends the event without
-// removing the input consumed in this call (the dependency returns 0 there), so st.base keeps its value.
-template <int NWM, int NWC>
-__device__ __forceinline__ void fast_run_steps(const SpxPlanDev& P, FastCtx& X, WalkState& st, const FastLane& LN,
-                                               float speed, pos_t avail, bool needResolve) {
-  const int maxRequired = P.maxRequired;
-  FastSpeed SP;
-  SP.ge2 = speed >= 2.0f;
-  SP.sm1 = speed - 1.0f;
-  SP.twom = 2.0f - speed;
-  pos_t pos = st.base;
-  do {
-    if (st.remaining > 0) {
-      int n = st.remaining;
-      if (n > maxRequired) n = maxRequired;
-      if (st.out_n + n > X.out_cap) st.overflow = 1;
-      fast_publish<NWM, NWC>(X, FCMD_COPY, n, pos, st.out_n, 0);
-      if (NWC > 0) fast_sync();
-      st.out_n += n;
-      st.remaining -= n;
-      pos += n;
-    } else {
-      int n, rem;
-      const int period = fast_find_period<NWM, NWC>(P, X, st, LN, pos, needResolve, SP, n, rem);
-      if (!SP.ge2) st.remaining = rem;
-      if (st.out_n + n > X.out_cap) st.overflow = 1;
-      if (n == 0) return;
-      X.xf_n = n; X.xf_down = (int)(pos - X.wbase); X.xf_period = period; X.xf_out = st.out_n;
-      st.out_n += n;
-      pos += period + n;
-      FSTAMP(10);
-    }
-  } while (pos + maxRequired <= avail);
-  st.base = pos;
-}
-
-template <int NWM, int NWC>
+// RATE != 0: the kernel is compiled for that sample rate and a 4096-frame window -- every LDS offset, period limit and
+// divisor an immediate, which frees some thirty scalar registers in the step loop; RATE == 0 takes them from the plan.
+template <int NWM, int NWC, int RATE>
 __global__ void __launch_bounds__(64 * (NWM + NWC))
 spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const int16_t* __restrict__ in_base,
                      int16_t* __restrict__ out_base, int64_t* __restrict__ n_out, SpxStreamState* __restrict__ states,
                      const float* scratch_base, const int* speed_ready, int wcap) {
   constexpr int NT = 64 * (NWM + NWC);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool is_search = wave < NWM;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6);  // wave-uniform, and the compiler must know it: everything keyed on it stays scalar
   const SpxStreamDev S = streams[blockIdx.x];
-  const int Ttot = S.n_frames, F = P.F, B = P.B;
-  const float Rg = S.speed, nl = S.nonlinear;
-  const FastLds LY = fast_lds_layout(P, wcap);
+  constexpr bool CT = RATE != 0;
+  const int skip = CT ? (RATE > 4000 ? RATE / 4000 : 1) : P.skip;
+  const int minP = CT ? RATE / 400 : P.minPeriod, maxP = CT ? RATE / 65 : P.maxPeriod;
+  const int maxRequired = 2 * maxP;
+  const int B = CT ? (int)(RATE / 100.0) : P.B;
+  if (CT) wcap = 4096;
+  const FastLds LY = fast_lds_layout_i(maxP, skip, wcap);
 
-  FastCtx X;
+  FastOut X;
   X.in = in_base + S.in_off;
   X.out = out_base + S.out_off;
   X.lds = lds;
   X.out_cap = (pos_t)(S.out_cap > 0x7fffffff ? 0x7fffffff : S.out_cap);
-  X.limit = (pos_t)S.n_in;
-  X.wbase = -1;
-  X.wcap = LY.wcap;
-  X.offA0 = LY.off_mono; X.offA1 = LY.off_monoB; X.offPl = LY.off_pl; X.offPlB = LY.off_plB; X.plStrideB = LY.plStrideB;
-  X.skip = P.skip;
-  X.skipM = (65536 + P.skip - 1) / P.skip;
-  X.skipM32 = (unsigned)((0x100000000ull + (unsigned)P.skip - 1) / (unsigned)P.skip);
-  X.sumC = reinterpret_cast<unsigned*>(lds + LY.off_sumC);
-  X.sumR = reinterpret_cast<unsigned*>(lds + LY.off_sumR);
-  X.inv = reinterpret_cast<const double*>(lds + LY.off_inv);
-  X.cmd = reinterpret_cast<int*>(lds + LY.off_cmd);
-  X.seq = 0;
-  X.xf_n = 0; X.xf_down = 0; X.xf_period = 0; X.xf_out = 0;
+  X.offA0 = LY.off_mono;
+  unsigned* sumC = reinterpret_cast<unsigned*>(lds + LY.off_sumC);
+  unsigned* sumR = reinterpret_cast<unsigned*>(lds + LY.off_sumR);
+  int* cmd = reinterpret_cast<int*>(lds + LY.off_cmd);
   int* sWait = reinterpret_cast<int*>(lds + LY.off_wait);
   {
     double* invw = reinterpret_cast<double*>(lds + LY.off_inv);
-    for (int t = tid; t <= P.maxPeriod; t += NT) invw[t] = t > 0 ? 65536.0 / (double)t : 0.0;
-    for (int t = tid; t < 128; t += NT) { X.sumC[t] = 0; X.sumR[t] = 0; }
+    for (int t = tid; t <= maxP; t += NT) invw[t] = t > 0 ? 65536.0 / (double)t : 0.0;
+    for (int t = tid; t < 128; t += NT) { sumC[t] = 0; sumR[t] = 0; }
   }
   __syncthreads();
 
-  if (!is_search) {
+  if (wave >= NWM) {
     // ------------------------------ output waves: obey commands until FCMD_EXIT ------------------------------
     if constexpr (NWC > 0) {
+      int seq = 0;
       for (;;) {
         fast_sync();  // the barrier that follows every published command
-        const int* c = X.cmd + (X.seq & 1) * FCMD_INTS;
-        X.seq++;
+        const int* c = cmd + (seq & 1) * FCMD_INTS;
+        seq++;
         const int type = uni(c[0]);
         const int xf_n = uni(c[1]), xf_down = uni(c[2]), xf_period = uni(c[3]), xf_out = uni(c[4]);
         const int cp_n = uni(c[5]), cp_src = uni(c[6]), cp_out = uni(c[7]);
@@ -473,7 +301,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         if (type == FCMD_STEP) {
           fast_sync();            // the step's second barrier (refine sums complete)
         } else if (type == FCMD_REFILL) {
-          fast_refill<NT>(X, nb, limit);
+          fast_refill<NT>(X, LY, skip, nb, limit);
         } else if (type == FCMD_POLL) {
           fast_sync();            // the polled count is in LDS
         } else if (type == FCMD_EXIT) {
@@ -487,48 +315,314 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   // ---------------------------------------- search waves: the chain ----------------------------------------
   // the walk is the latency-critical chain: where another kernel shares a SIMD, these waves issue first
   __builtin_amdgcn_s_setprio(3);
-  // the part of the stream state this stage owns (the tension kernel owns the filter states)
-  SpxStreamState Z;
-  if (S.flags & SPX_F_INIT) {
-    Z.w.base = 0; Z.w.out_n = 0; Z.w.avail = 0; Z.w.remaining = 0; Z.w.prevPeriod = 0; Z.w.prevMinDiff = 0;
-    Z.w.overflow = 0; Z.w.prevPeriod_toggle = 0; Z.w.pad_ = 0;
-    Z.curSpeed = Rg;  // sonicSetSpeed -> sonicIntSetSpeed, soniclib.c:182
-    Z.handed = 0;
-  } else {
-    Z.w = states[blockIdx.x].w;
-    Z.curSpeed = states[blockIdx.x].curSpeed;
-    Z.handed = states[blockIdx.x].handed;
-    if (nl == 0.0f) Z.curSpeed = Rg;  // sonicSetSpeed between writes reaches the TSM stage at once (soniclib.c:182)
-  }
-  const float* scr = scratch_base + (size_t)S.frame_off * 4;  // per frame: ..., speed (written by the tension kernel)
-  WalkState st;
-  st.base = uni((pos_t)Z.w.base); st.out_n = uni((pos_t)Z.w.out_n); st.avail = uni((pos_t)Z.w.avail);
-  st.remaining = uni(Z.w.remaining); st.prevPeriod = uni(Z.w.prevPeriod); st.prevMinDiff = uni(Z.w.prevMinDiff);
-  st.overflow = uni(Z.w.overflow); st.prevPeriod_toggle = 0;  // both lag-sum buffers are clear at kernel start
-  float tailSpeed = unif(Z.curSpeed);  // the speed in force in the TSM stage
-  pos_t avail = st.avail;
-  pos_t handed = (nl != 0.0f) ? uni(Z.handed) : 0;
-  const bool do_flush = (S.flags & SPX_F_FLUSH) != 0;
+  const int Ttot = S.n_frames, F = P.F;
+  const float Rg = S.speed, nl = S.nonlinear;
   const bool linear = nl == 0.0f;
-  const int maxRequired = P.maxRequired;
-  const bool needResolve = (long)P.maxPeriod * P.maxPeriod >= 65536;
+  const bool do_flush = (S.flags & SPX_F_FLUSH) != 0;
+  const int minC = minP / skip, nC = maxP / skip - minC + 1;
+  const bool needResolve = (long)maxP * maxP >= 65536;
+  const int need = maxRequired + 2 * skip + 2;           // window frames a step needs from its position on
+  const int skipM = (65536 + skip - 1) / skip;           // i / skip == (i * skipM) >> 16 for i < 8192
+  const int dA = LY.off_monoB - 2 - LY.off_mono;         // see pair_addr
+  const int dPl = LY.off_plB - 2 - LY.off_pl;
+  const double* invTab = reinterpret_cast<const double*>(lds + LY.off_inv);
+  const float* scr = scratch_base + (size_t)S.frame_off * 4;  // per frame: ..., speed (written by the tension kernel)
 
-  FastLane LN;
-  LN.lane = lane;
-  LN.cw = (NWM == 8) ? (wave < 4 ? wave : 11 - wave) : wave;  // 8 waves: a busy and a light chunk on every SIMD
-  {
-    const int minC = P.minPeriod / P.skip, maxC = P.maxPeriod / P.skip;
-    LN.pC = minC + lane;
-    LN.validC = lane < maxC - minC + 1;
-    const int CH = (((maxC >> 1) + NWM) / NWM + 3) & ~3;
-    LN.nfullC = LN.validC ? (LN.pC >> 1) : 0;
-    LN.j0C = LN.cw * CH;
-    LN.nGC = CH >> 2;
-    LN.cntC = LN.nfullC - LN.j0C;   // may be negative or beyond the share: sad_flight compares pair indices with it
-    LN.loneC = LN.validC && (LN.pC & 1);
-    LN.scaleC = 65536.0 / (double)LN.pC;
+  // the part of the stream state this stage owns (the tension kernel owns the filter states)
+  pos_t base, out_n, avail, handed;
+  int remaining, prevPeriod, prevMinDiff, overflow;
+  float tailSpeed;  // the speed in force in the TSM stage
+  if (S.flags & SPX_F_INIT) {
+    base = 0; out_n = 0; avail = 0; handed = 0; remaining = 0; prevPeriod = 0; prevMinDiff = 0; overflow = 0;
+    tailSpeed = Rg;  // sonicSetSpeed -> sonicIntSetSpeed, soniclib.c:182
+  } else {
+    const SpxStreamState& Z = states[blockIdx.x];
+    base = uni((pos_t)Z.w.base); out_n = uni((pos_t)Z.w.out_n); avail = uni((pos_t)Z.w.avail);
+    remaining = uni(Z.w.remaining); prevPeriod = uni(Z.w.prevPeriod); prevMinDiff = uni(Z.w.prevMinDiff);
+    overflow = uni(Z.w.overflow);
+    handed = linear ? 0 : uni(Z.handed);
+    tailSpeed = linear ? Rg : unif(Z.curSpeed);  // sonicSetSpeed between writes reaches the TSM stage at once (soniclib.c:182)
   }
-  FSTAMP_DECL
+  pos_t limit = (pos_t)S.n_in;   // frames of real input; reads beyond are the flush's zero padding
+  pos_t wbase = -1;              // window covers [wbase, wbase + wcap); -1 = invalid
+  int tg = 0;                    // which of the two lag-sum buffers this step adds into (both clear at kernel start)
+  int seq = 0;                   // commands published
+  int xf_n = 0, xf_down = 0, xf_period = 0;  // cross-fade decided but not yet handed to the output waves
+  pos_t xf_out = 0;
+
+  // ---- coarse search, dealt once: task T = g * 64 * NWM + tid is group (T - first group of its lag) of the lag whose
+  // groups contain T; a group is four consecutive pair slots of that lag (slot j = samples 2j, 2j+1; an odd lag's last
+  // slot holds one sample).  cOffA / cOffB: element offsets of the two operands from the step's decimated position;
+  // cMask: per-slot byte masks (all / low half / none); cLag: lag index (= lane of the sum it adds into). ----
+  int cOffA[FCG], cOffB[FCG], cLag[FCG];
+  unsigned cMask[FCG][4];
+  int nGC;  // groups per lane (uniform)
+  {
+    int total = 0;
+    for (int q = 0; q < nC; q++) { const int p = minC + q; total += ((p >> 1) + (p & 1) + 3) >> 2; }
+    nGC = (total + 64 * NWM - 1) / (64 * NWM);
+    if (nGC > FCG) nGC = FCG;  // spx_walk_config keeps such plans off this kernel
+#pragma unroll
+    for (int g = 0; g < FCG; g++) {
+      const int T = g * 64 * NWM + tid;
+      int first = 0, found = 0, fq = 0, ff = 0;
+      for (int q = 0; q < nC; q++) {
+        const int p = minC + q;
+        const int ng = ((p >> 1) + (p & 1) + 3) >> 2;
+        if (!found && T < first + ng) { found = 1; fq = q; ff = first; }
+        first += ng;
+      }
+      const int p = minC + fq, gi = T - ff;
+      cOffA[g] = 8 * gi;
+      cOffB[g] = p + 8 * gi;
+      cLag[g] = found ? fq : 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int j = 4 * gi + k;
+        cMask[g][k] = !found ? 0u : (j < (p >> 1) ? 0xffffffffu : ((j == (p >> 1) && (p & 1)) ? 0xffffu : 0u));
+      }
+      if (!found) { cOffA[g] = 0; cOffB[g] = 0; }
+    }
+  }
+  const double scaleC = 65536.0 / (double)(minC + lane);
+  const bool validC = lane < nC;
+  int nRG;  // ragged refine tasks per lane (uniform)
+  {
+    const int nlMax = 8 * skip + 1;
+    int total = 0;
+    for (int t = 0; t < nlMax; t++) total += (t + 2) >> 1;  // the larger of the two parities
+    nRG = (total + 64 * NWM - 1) / (64 * NWM);
+    if (nRG > FRG) nRG = FRG;
+  }
+  // ---- refine search, the ragged part dealt once.  Lag t of a search (p = lo + t) shares its first lo >> 1 pairs with
+  // every other lag (summed lane = lag, wave = share); what is left is floor((t + (lo & 1)) / 2) whole pairs and, for an
+  // odd p, the lone sample i = p - 1.  That triangle depends on lo only through its parity, so its enumeration over the
+  // lanes of the search waves is a constant: task FRG * par + k of a lane = (lag t, pair r beyond lo >> 1, half?).
+  // rT < 0: no task. ----
+  int rT[2][FRG], rR[2][FRG];
+  unsigned rM[2][FRG];
+#pragma unroll
+  for (int par = 0; par < 2; par++) {
+#pragma unroll
+    for (int k = 0; k < FRG; k++) {
+      const int T = k * 64 * NWM + tid;
+      const int nlMax = 8 * skip + 1;
+      int first = 0, ft = -1, fr = 0;
+      unsigned fm = 0u;
+      for (int t = 0; t < nlMax; t++) {
+        const int full = (t + par) >> 1;             // whole pairs beyond lo >> 1
+        const int cnt = full + ((t + par) & 1);      // + the lone sample of an odd lag (lo + t odd <=> t + par odd)
+        if (ft < 0 && T < first + cnt) {
+          ft = t; fr = T - first;
+          fm = (fr < full) ? 0xffffffffu : 0xffffu;
+        }
+        first += cnt;
+      }
+      rT[par][k] = ft; rR[par][k] = fr; rM[par][k] = ft < 0 ? 0u : fm;
+    }
+  }
+  FSTAMP_VARS
+
+  // Hand the pending cross-fade (and, for FCMD_COPY, a plain copy) to the output waves.  Every command is followed by
+  // exactly one workgroup barrier before the next command is published, and the two slots alternate, so a slot is
+  // rewritten only after the output waves have consumed it.  Field k of a command is written by lane k of the last
+  // search wave (v_writelane: no EXEC juggling).  NWC == 0: the search waves do the output work themselves.
+#define FAST_PUBLISH(TYPE, CP_N, CP_SRC, CP_OUT, NB)                                                                   \
+  do {                                                                                                                 \
+    if constexpr (NWC > 0) {                                                                                           \
+      if (wave == NWM - 1) {                                                                                           \
+        int rec_ = 0;                                                                                                  \
+        rec_ = fast_writelane((TYPE), 0, rec_);                                                            \
+        rec_ = fast_writelane(xf_n, 1, rec_);                                                              \
+        rec_ = fast_writelane(xf_down, 2, rec_);                                                           \
+        rec_ = fast_writelane(xf_period, 3, rec_);                                                         \
+        rec_ = fast_writelane((int)xf_out, 4, rec_);                                                       \
+        if ((TYPE) != FCMD_STEP) {                                                                                     \
+          rec_ = fast_writelane((int)(CP_N), 5, rec_);                                                     \
+          rec_ = fast_writelane((int)(CP_SRC), 6, rec_);                                                   \
+          rec_ = fast_writelane((int)(CP_OUT), 7, rec_);                                                   \
+          rec_ = fast_writelane((int)limit, 8, rec_);                                                      \
+          rec_ = fast_writelane((int)(NB), 9, rec_);                                                       \
+        }                                                                                                              \
+        cmd[(seq & 1) * FCMD_INTS + lane] = rec_;                                                                      \
+      }                                                                                                                \
+      seq++;                                                                                                           \
+    } else {                                                                                                           \
+      fast_outputs<64 * NWM>(X, tid, xf_n, xf_down, xf_period, xf_out, (int)(CP_N), (pos_t)(CP_SRC), (pos_t)(CP_OUT),  \
+                             limit);                                                                                   \
+    }                                                                                                                  \
+    xf_n = 0;                                                                                                          \
+  } while (0)
+
+  // findPitchPeriod at absolute position pos; every search wave computes the same result.  Also returns what the step
+  // then does: n frames of cross-fade and, for 1 < speed < 2, `rem` frames copied through afterwards.
+  auto find_period = [&](pos_t pos, bool ge2, float sm1, float twom, int& n_ret, int& rem_ret)
+                         __attribute__((always_inline)) -> int {
+    FSTAMP(1);
+    if (!(wbase >= 0 && pos >= wbase && pos + need <= wbase + LY.wcap)) {
+      const pos_t nb = pos & ~7;
+      FAST_PUBLISH(FCMD_REFILL, 0, 0, 0, nb);
+      if (NWC > 0) fast_sync();
+      fast_refill<NT>(X, LY, skip, nb, limit);
+      wbase = nb;
+    }
+    FSTAMP(2);
+    FAST_PUBLISH(FCMD_STEP, 0, 0, 0, 0);  // the previous step's cross-fade rides on this step's first barrier
+    const int o = (int)(pos - wbase);
+    // ---- coarse search on the decimated signal: each lane its constant group(s) of pair slots ----
+    int bestC;
+    {
+      const int oD = (o * skipM) >> 16;
+      const int r = o - oD * skip;
+      const int plr = LY.off_pl + r * LY.plStrideB;
+      unsigned a[FCG][4], b[FCG][4];
+#pragma unroll
+      for (int g = 0; g < FCG; g++) {
+        if (g < nGC) {
+          const unsigned* ap = reinterpret_cast<const unsigned*>(lds + pair_addr(plr, dPl, oD + cOffA[g]));
+          const unsigned* bp = reinterpret_cast<const unsigned*>(lds + pair_addr(plr, dPl, oD + cOffB[g]));
+#pragma unroll
+          for (int k = 0; k < 4; k++) { a[g][k] = ap[k]; b[g][k] = bp[k]; }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < FCG; g++) {
+        if (g < nGC) {
+          unsigned d = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) d = __builtin_amdgcn_sad_u16(a[g][k] & cMask[g][k], b[g][k] & cMask[g][k], d);
+          atomicAdd(&sumC[tg * 64 + cLag[g]], d);  // idle lanes add 0 to lag 0
+        }
+      }
+      FSTAMP(3);
+      fast_sync();
+      FSTAMP(4);
+      if (wave == 0) sumC[(1 - tg) * 64 + lane] = 0;  // the buffer the previous step used: everyone is past it
+      const unsigned dsum = sumC[tg * 64 + lane];
+      unsigned kmin;
+      bestC = fast_select(dsum, scaleC, validC, false, minC, kmin);
+    }
+    FSTAMP(5);
+    // ---- refine at full rate around the coarse winner: lane = lag, wave = share of the pairs ----
+    int period = (minC + bestC) * skip;
+    int lo = period - (skip << 2), hi = period + (skip << 2);
+    if (lo < minP) lo = minP;
+    if (hi > maxP) hi = maxP;
+    const bool valid = lane <= hi - lo;
+    const int p = lo + lane;
+    const double scale = invTab[valid ? p : lo];
+    unsigned dsum;
+    int nLane, remLane;
+    {
+      const int c0 = lo >> 1;  // pairs every lag of this search has
+      const int par = lo & 1;
+      const int nl = hi - lo + 1;
+      // the ragged tasks first: their operands are in flight while the common share is summed
+      unsigned ra[FRG], rb[FRG];
+      int rt[FRG];
+      unsigned rm[FRG];
+#pragma unroll
+      for (int k = 0; k < FRG; k++) {
+        if (k >= nRG) { rt[k] = 0; rm[k] = 0u; ra[k] = 0u; rb[k] = 0u; continue; }
+        rt[k] = par ? rT[1][k] : rT[0][k];
+        const int rr = par ? rR[1][k] : rR[0][k];
+        rm[k] = par ? rM[1][k] : rM[0][k];
+        if (rt[k] < 0 || rt[k] >= nl) { rt[k] = 0; rm[k] = 0u; }   // no task, or a lag the clamped search does not have
+        const int ea = o + 2 * (c0 + rr);
+        ra[k] = *reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea));
+        rb[k] = *reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea + lo + rt[k]));
+      }
+      FSTAMP(12);
+      // common share: lane = lag, this wave's pairs [j0, j1) of [0, c0) -- the same range for every lane, no masks
+      const unsigned* ap = reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, o));
+      const unsigned* bp = reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, o + p));
+      const int CHc = (c0 + NWM - 1) / NWM;
+      const int j0 = wave * CHc;
+      int j1 = j0 + CHc;
+      if (j1 > c0) j1 = c0;
+      unsigned d;
+      if (j1 - j0 <= 16) {
+        d = sad_uniform<4>(ap + j0, bp + j0, j1 - j0 < 0 ? 0 : j1 - j0, 0u);
+      } else {  // long periods: the first sixteen pairs in one flight, the rest in a pipelined loop
+        d = sad_uniform<4>(ap + j0, bp + j0, 16, 0u);
+        d += sad_run(ap, bp, j0 + 16, j1);
+      }
+      atomicAdd(&sumR[tg * 64 + lane], valid ? d : 0u);
+      FSTAMP(13);
+#pragma unroll
+      for (int k = 0; k < FRG; k++) {
+        if (k < nRG) {
+          const unsigned dr = __builtin_amdgcn_sad_u16(ra[k] & rm[k], rb[k] & rm[k], 0u);
+          atomicAdd(&sumR[tg * 64 + rt[k]], dr);
+        }
+      }
+      FSTAMP(14);
+      // what the step will do for each candidate period: exact IEEE divisions, off the chain; lane 63 = previous period
+      {
+        const int pc = (lane == 63) ? prevPeriod : p;
+        const float fp = (float)pc;
+        nLane = ge2 ? (int)(fp / sm1) : pc;
+        remLane = ge2 ? 0 : (int)(fp * twom / sm1);
+      }
+      FSTAMP(6);
+      fast_sync();
+      FSTAMP(7);
+      if (wave == 0) sumR[(1 - tg) * 64 + lane] = 0;
+      dsum = sumR[tg * 64 + lane];
+    }
+    tg ^= 1;
+    unsigned kmin;
+    const int best = fast_select(dsum, scale, valid, needResolve, lo, kmin);
+    period = lo + best;
+    const int minDiff = (int)(kmin >> 16);  // floor(diff / lag) of the winner
+    FSTAMP(8);
+    // Previous-period rule (libsonic prevPeriodBetter, preferNewPeriod = 1).  Only "maxDiff > 3*minDiff" is ever asked
+    // of the worst lag, and max_p floor(d_p/p) = floor(max_p d_p/p), so the test is "some lag has d_p >= (3*minDiff+1)*p".
+    int ret = period, sel = best;
+    if (minDiff != 0 && prevPeriod != 0 && minDiff * 2 > prevMinDiff * 3) {
+      const unsigned need3 = 3u * (unsigned)minDiff + 1u;
+      if (__builtin_amdgcn_ballot_w64(valid && dsum >= need3 * (unsigned)p) == 0) { ret = prevPeriod; sel = 63; }
+    }
+    prevMinDiff = minDiff;
+    prevPeriod = period;
+    n_ret = __builtin_amdgcn_readlane(nLane, sel);
+    rem_ret = __builtin_amdgcn_readlane(remLane, sel);
+    FSTAMP(9);
+    return ret;
+  };
+
+  // The pitch steps one event can run = the loop of libsonic's processStreamInput for speed > 1 with `availE` frames
+  // handed over (the caller guarantees availE - base >= maxRequired).  A step that fails (n == 0) ends the event without
+  // removing the input consumed in this call (the dependency returns 0 there), so `base` keeps its value.
+  auto run_event = [&](float speed, pos_t availE) __attribute__((always_inline)) {
+    const bool ge2 = speed >= 2.0f;
+    const float sm1 = speed - 1.0f, twom = 2.0f - speed;
+    pos_t pos = base;
+    bool failed = false;
+    do {
+      if (remaining > 0) {
+        int n = remaining;
+        if (n > maxRequired) n = maxRequired;
+        if (out_n + n > X.out_cap) overflow = 1;
+        FAST_PUBLISH(FCMD_COPY, n, pos, out_n, 0);
+        if (NWC > 0) fast_sync();
+        out_n += n;
+        remaining -= n;
+        pos += n;
+      } else {
+        int n, rem;
+        const int period = find_period(pos, ge2, sm1, twom, n, rem);
+        if (!ge2) remaining = rem;
+        if (out_n + n > X.out_cap) overflow = 1;
+        if (n == 0) { failed = true; break; }
+        xf_n = n; xf_down = (int)(pos - wbase); xf_period = period; xf_out = out_n;
+        out_n += n;
+        pos += period + n;
+        FSTAMP(10);
+      }
+    } while (pos + maxRequired <= availE);
+    if (!failed) base = pos;
+  };
 
   // The speeds come from the tension kernel.  Sequential launches (speed_ready == nullptr): all of them are there.
   // Concurrent launches: that kernel runs beside this one and publishes the number of tension frames whose speeds are
@@ -537,7 +631,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   for (;;) {
     int K = K_total;
     if (speed_ready != nullptr && K_total > 0) {
-      fast_publish<NWM, NWC>(X, FCMD_POLL, 0, 0, 0, 0);
+      FAST_PUBLISH(FCMD_POLL, 0, 0, 0, 0);
       fast_sync();
       if (tid == 0) {
         int got;
@@ -554,7 +648,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       }
       fast_sync();
       K = uni(*sWait);
-      if (K < 0) { st.overflow = 2; break; }  // the producer was lost (or failed): reported as its own status
+      if (K < 0) { overflow = 2; break; }  // the producer was lost (or failed): reported as its own status
       if (K > K_total) K = K_total;
     }
     const bool last = K >= K_total;
@@ -569,110 +663,122 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     if (!linear) ev1 = fin ? (pos_t)(S.n_in / B) : (pos_t)K;  // complete ring buffers written: soniclib.c:446-449
     else ev1 = (last && (pos_t)S.n_in > avail) ? 1 : 0;
     if (ev1 < ev0) ev1 = ev0;
-    {
-      // Most nonlinear events cannot run a step (a step needs maxRequired frames, an event brings B).  The speeds of 64
-      // consecutive events sit in one VGPR (lane = event, tail events at the last speed), and the next event that does
-      // anything -- a pass-through at unity speed, or one with enough input for a step -- is found with one ballot.
-      const pos_t Kc = ev1 < (pos_t)K ? ev1 : (pos_t)K;  // tension events of this round: [ev0, Kc)
-      if (Kc > ev0) tailSpeed = unif(scr[4 * (size_t)(Kc - 1) + 3]);  // what later events run at / the stream carries on
-      for (pos_t blk0 = ev0; blk0 < ev1; blk0 += 64) {
-        const int nIn = (int)(ev1 - blk0 < 64 ? ev1 - blk0 : 64);
-        const pos_t idx = blk0 + lane;
-        float spv = tailSpeed;
-        if (lane < nIn && idx < (pos_t)K) spv = scr[4 * (size_t)idx + 3];
-        const bool unityLane = lane < nIn && speed_is_unity(spv);
-        const unsigned long long unityMask = __builtin_amdgcn_ballot_w64(unityLane);
-        const pos_t availBlk = avail;
-        const pos_t availLane = linear ? (pos_t)S.n_in : availBlk + (lane + 1) * B;  // frames handed over after event `lane`
-        int i = 0;
-        while (i < nIn) {
-          const unsigned long long runnable = __builtin_amdgcn_ballot_w64(
-              lane >= i && lane < nIn && (unityLane || availLane - st.base >= maxRequired));
-          if (runnable == 0) break;
-          i = __builtin_ctzll(runnable);
-          const pos_t availE = linear ? (pos_t)S.n_in : availBlk + (i + 1) * B;
-          FSTAMP(0);
-          if ((unityMask >> i) & 1) {
-            const pos_t n = availE - st.base;
-            if (n > 0) {
-              if (st.out_n + n > X.out_cap) st.overflow = 1;
-              fast_publish<NWM, NWC>(X, FCMD_COPY, (int)n, st.base, st.out_n, 0);
-              if (NWC > 0) fast_sync();
-              st.out_n += n;
-            }
-            st.base = availE;
-          } else {
-            const float speed = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, spv), i));
-            fast_run_steps<NWM, NWC>(P, X, st, LN, speed, availE, needResolve);
-          }
-          FSTAMP(11);
-          i++;
-        }
-        avail = linear ? (pos_t)S.n_in : availBlk + nIn * B;
+    // Most nonlinear events cannot run a step (a step needs maxRequired frames, an event brings B).  The speeds of 64
+    // consecutive events sit in one VGPR (lane = event, tail events at the last speed), and the next event that does
+    // anything -- a pass-through at unity speed, or one with enough input for a step -- is found with one ballot.
+    const pos_t Kc = ev1 < (pos_t)K ? ev1 : (pos_t)K;  // tension events of this round: [ev0, Kc)
+    if (Kc > ev0) tailSpeed = unif(scr[4 * (size_t)(Kc - 1) + 3]);  // what later events run at / the stream carries on
+    // The flush is one more block of a single event: sonicIntFlushStream pads 2*maxRequired zeros, processes at the
+    // last speed, truncates to the expected length and empties its input.
+    const int nBlk = (int)((ev1 - ev0 + 63) >> 6);
+    for (int bI = 0; bI < nBlk + (fin ? 1 : 0); bI++) {
+      const bool flushBlk = bI == nBlk;
+      const pos_t blk0 = ev0 + 64 * (pos_t)bI;
+      int nIn = (int)(ev1 - blk0 < 64 ? ev1 - blk0 : 64);
+      pos_t expected = 0;
+      if (flushBlk) {
+        nIn = 1;
+        const pos_t remainingS = avail - base;
+        expected = out_n + uni((int)(((float)remainingS / tailSpeed + 0) / 1.0f + 0.5f));
+        limit = avail;  // everything from here on reads as the flush's zero padding
+        wbase = -1;     // the window may hold samples past the new limit: the next step refills it
       }
-      if (fin) {  // sonicIntFlushStream
-        const pos_t remainingS = avail - st.base;
-        const pos_t expected = st.out_n + uni((int)(((float)remainingS / tailSpeed + 0) / 1.0f + 0.5f));
-        X.limit = avail;  // everything from here on reads as the flush's zero padding
-        X.wbase = -1;     // the window may hold samples past the new limit: the next step refills it
-        avail += 2 * maxRequired;
-        if (speed_is_unity(tailSpeed)) {
-          const pos_t n = avail - st.base;
-          if (st.out_n + n > X.out_cap) st.overflow = 1;
-          fast_publish<NWM, NWC>(X, FCMD_COPY, (int)n, st.base, st.out_n, 0);
-          if (NWC > 0) fast_sync();
-          st.out_n += n;
-        } else if (avail - st.base >= maxRequired) {
-          fast_run_steps<NWM, NWC>(P, X, st, LN, tailSpeed, avail, needResolve);
+      const pos_t idx = blk0 + lane;
+      float spv = tailSpeed;
+      if (!flushBlk && lane < nIn && idx < (pos_t)K) spv = scr[4 * (size_t)idx + 3];
+      const bool unityLane = lane < nIn && speed_is_unity(spv);
+      const unsigned long long unityMask = __builtin_amdgcn_ballot_w64(unityLane);
+      const pos_t availBlk = avail;
+      const int perEvent = flushBlk ? 2 * maxRequired : B;
+      const pos_t availLane = (linear && !flushBlk) ? (pos_t)S.n_in : availBlk + (lane + 1) * perEvent;  // frames handed over after event `lane`
+      int i = 0;
+      while (i < nIn) {
+        const unsigned long long runnable = __builtin_amdgcn_ballot_w64(
+            lane >= i && lane < nIn && (unityLane || availLane - base >= maxRequired));
+        if (runnable == 0) break;
+        i = __builtin_ctzll(runnable);
+        const pos_t availE = (linear && !flushBlk) ? (pos_t)S.n_in : availBlk + (i + 1) * perEvent;
+        FSTAMP(0);
+        if ((unityMask >> i) & 1) {
+          const pos_t n = availE - base;
+          if (n > 0) {
+            if (out_n + n > X.out_cap) overflow = 1;
+            FAST_PUBLISH(FCMD_COPY, n, base, out_n, 0);
+            if (NWC > 0) fast_sync();
+            out_n += n;
+          }
+          base = availE;
+        } else {
+          const float speed = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, spv), i));
+          run_event(speed, availE);
         }
-        if (st.out_n > expected) st.out_n = expected;
-        st.base = avail;  // the dependency empties its input after a flush
-        st.remaining = 0;
+        FSTAMP(11);
+        i++;
+      }
+      avail = (linear && !flushBlk) ? (pos_t)S.n_in : availBlk + nIn * perEvent;
+      if (flushBlk) {
+        if (out_n > expected) out_n = expected;
+        base = avail;  // the dependency empties its input after a flush
+        remaining = 0;
       }
     }
     if (!linear) handed = ev1;
     if (last) break;
   }
-  fast_publish<NWM, NWC>(X, FCMD_EXIT, 0, 0, 0, 0);
+  FAST_PUBLISH(FCMD_EXIT, 0, 0, 0, 0);
   if (NWC > 0) fast_sync();
   FSTAMP_FLUSH
   if (tid == 0) {
-    Z.w.base = st.base; Z.w.out_n = st.out_n; Z.w.avail = avail; Z.w.remaining = st.remaining;
-    Z.w.prevPeriod = st.prevPeriod; Z.w.prevMinDiff = st.prevMinDiff; Z.w.overflow = st.overflow;
-    Z.w.prevPeriod_toggle = 0; Z.w.pad_ = 0;
-    states[blockIdx.x].w = Z.w;  // field-wise: the tension kernel may be writing its own fields of this record
+    SpxWalkState W;
+    W.base = base; W.out_n = out_n; W.avail = avail; W.remaining = remaining;
+    W.prevPeriod = prevPeriod; W.prevMinDiff = prevMinDiff; W.overflow = overflow;
+    W.prevPeriod_toggle = 0; W.pad_ = 0;
+    states[blockIdx.x].w = W;  // field-wise: the tension kernel may be writing its own fields of this record
     states[blockIdx.x].curSpeed = tailSpeed;
     if (!linear) states[blockIdx.x].handed = (int)handed;
     // a truncated output is reported as a negative count; a lost producer as INT64_MIN (SPX_NOUT_LOST_PRODUCER)
-    if (n_out) n_out[blockIdx.x] = st.overflow == 2 ? INT64_MIN : (st.overflow ? -(int64_t)st.out_n : (int64_t)st.out_n);
+    if (n_out) n_out[blockIdx.x] = overflow == 2 ? INT64_MIN : (overflow ? -(int64_t)out_n : (int64_t)out_n);
   }
+#undef FAST_PUBLISH
 }
 
 size_t spx_walk_fast_lds_bytes(const SpxPlanDev& P, int wcap) { return (size_t)fast_lds_layout(P, wcap).total; }
+
+// Can this kernel serve the plan with `nwm` search waves?  (The coarse triangle must fit FCG groups per lane.)
+bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm) {
+  const int skip = P.skip > 0 ? P.skip : 1;
+  const int minC = P.minPeriod / skip, maxC = P.maxPeriod / skip;
+  int total = 0;
+  for (int p = minC; p <= maxC; p++) total += ((p >> 1) + (p & 1) + 3) >> 2;
+  int ragged = 0;  // the refine search's ragged triangle (the larger parity) must fit FRG tasks per lane
+  for (int t = 0; t < 8 * skip + 1; t++) ragged += (t + 2) >> 1;
+  return total <= FCG * 64 * nwm && ragged <= FRG * 64 * nwm;
+}
 
 void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, const int16_t* in,
                           int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
                           const int* speed_ready, int nwm, int nwc, int wcap, hipStream_t st) {
   if (n_streams <= 0) return;
   const FastLds LY = fast_lds_layout(P, wcap);
-#define SPX_LAUNCH_FAST(M, C)                                                                                         \
-  hipLaunchKernelGGL((spx_walk_fast_kernel<M, C>), dim3(n_streams), dim3(64 * (M + C)), LY.total, st, P, streams, in,  \
+#define SPX_LAUNCH_FAST_R(M, C, R)                                                                                        \
+  hipLaunchKernelGGL((spx_walk_fast_kernel<M, C, R>), dim3(n_streams), dim3(64 * (M + C)), LY.total, st, P, streams, in,  \
                      out, n_out, states, scratch, speed_ready, wcap)
+  // the two rates of the BASELINE configs get their own specialisation (with the default 4096-frame window)
+#define SPX_LAUNCH_FAST(M, C)                                              \
+  do {                                                                     \
+    if (P.rate == 16000 && wcap == 4096) SPX_LAUNCH_FAST_R(M, C, 16000);   \
+    else if (P.rate == 22050 && wcap == 4096) SPX_LAUNCH_FAST_R(M, C, 22050); \
+    else SPX_LAUNCH_FAST_R(M, C, 0);                                       \
+  } while (0)
 #ifdef SPX_STAMPS
   SPX_LAUNCH_FAST(4, 4);
   return;
 #endif
   if (nwm == 8) {
-    if (nwc >= 4) SPX_LAUNCH_FAST(8, 4);
-    else if (nwc >= 2) SPX_LAUNCH_FAST(8, 2);
-    else SPX_LAUNCH_FAST(8, 0);
+    SPX_LAUNCH_FAST(8, 4);
   } else if (nwm == 2) {
-    if (nwc >= 2) SPX_LAUNCH_FAST(2, 2);
-    else if (nwc >= 1) SPX_LAUNCH_FAST(2, 1);
+    if (nwc >= 1) SPX_LAUNCH_FAST(2, 1);
     else SPX_LAUNCH_FAST(2, 0);
-  } else if (nwm == 1) {
-    if (nwc >= 1) SPX_LAUNCH_FAST(1, 1);
-    else SPX_LAUNCH_FAST(1, 0);
   } else {
     if (nwc >= 4) SPX_LAUNCH_FAST(4, 4);
     else if (nwc >= 2) SPX_LAUNCH_FAST(4, 2);
@@ -680,4 +786,5 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
     else SPX_LAUNCH_FAST(4, 0);
   }
 #undef SPX_LAUNCH_FAST
+#undef SPX_LAUNCH_FAST_R
 }

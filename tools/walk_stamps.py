@@ -18,11 +18,13 @@ KIND = os.environ.get("STAMP_KIND", "fast")   # "fast": spx_walk_fast.hip (make 
 if KIND == "fast":
     NAMES = {0: "event loop (between events)", 1: "step entry / loop control", 2: "window check + refill",
              3: "publish + coarse accumulate", 4: "barrier A wait", 5: "coarse sums read + select",
-             6: "refine setup + accumulate", 7: "barrier B wait", 8: "refine sums read + select",
-             9: "previous-period rule", 10: "n, state update", 11: "after the steps of an event"}
+             6: "refine: candidate n / rem divisions", 7: "barrier B wait", 8: "refine sums read + select",
+             9: "previous-period rule", 10: "n, state update", 11: "after the steps of an event",
+             12: "refine: setup + ragged loads issued", 13: "refine: common share summed + added",
+             14: "refine: ragged tasks summed + added"}
 FN = "spx_debug_fstamps" if KIND == "fast" else "spx_debug_stamps"
 PREFIX = "libspeedy_hip_fstamps_%d.so" if KIND == "fast" else "libspeedy_hip_stamps_%d.so"
-NSEL = 12 if KIND == "fast" else 15
+NSEL = 15 if KIND == "fast" else 15
 
 
 def child(sel):
