@@ -1,14 +1,27 @@
 // The reference-compatible streaming API (include/sonic2.h) on top of the HIP kernels.
 //
-// Mirrors the reference shim, soniclib.c: same entry points, same units, same return conventions.  Where
-// the shim keeps a ring of host buffers and calls the analysis and the TSM stage synchronously per 10 ms
-// frame (soniclib.c:246-373), this implementation keeps the whole stream device-resident and, on every
-// write, enqueues ONE analysis launch and ONE walk launch that cover all frames the new samples complete,
-// resuming from the state record (SpxStreamState) the previous launch left in device memory.
+// Mirrors the reference shim, soniclib.c: same entry points, same units, same return conventions.  Where the shim
+// keeps a ring of host buffers and calls the analysis and the TSM stage synchronously per 10 ms frame
+// (soniclib.c:246-373), this implementation keeps a sliding part of the stream device-resident and, on every write,
+// enqueues ONE analysis, ONE tension and ONE walk launch that cover all frames the new samples complete, resuming from
+// the state record (SpxStreamState) the previous launch left in device memory.
+//
+// Memory is bounded: the device buffers slide.  Input before the oldest frame either stage can still touch (the
+// analysis halo, the TSM stage's buffered input), delivered output, and frame records behind the hysteresis look-back
+// are dropped -- the buffers are indexed through negative base offsets (SpxStreamDev::in_off / out_off / frame_off), so
+// the kernels keep using absolute stream coordinates.  The reference holds F+2 ring buffers plus libsonic's FIFOs;
+// here a stream holds O(maxRequired + chunk) frames however long it runs (tests/test_gpu_sonic2.py soak test).
+//
+// Life cycle as in the reference: a stream stays usable after sonicFlushStream (soniclib.c:529-552 only moves the
+// shim's read index to its write index and flushes the TSM stage), the nonlinear factor is re-read on every write
+// (soniclib.c:397), sonicSetSpeed takes effect at once (soniclib.c:177-183).  Deviations are listed in INTEGRATION.md:
+// switching between factor == 0 and factor != 0 inside one stream and sonicSetRate != 1 fail at the next write with a
+// message (speedyHipLastError); they never produce wrong audio.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -18,29 +31,46 @@
 static thread_local std::string g_api_err;
 static int g_match_matlab = 0;
 
+// A device array holding elements [origin, origin + cap) of a conceptually unbounded sequence.  ensure(lo, hi) makes
+// [lo, hi) addressable and keeps what is already valid from lo on ([lo, filled)); it slides -- a stream-ordered copy
+// into a fresh allocation, the old one freed in stream order -- when hi does not fit or when more than half the
+// allocation is dead prefix.  base() is the pointer that, indexed with ABSOLUTE element numbers, lands in the allocation.
 template <class T>
-struct DevBuf {  // growable device array, contents preserved on growth
+struct SlideBuf {
   T* p = nullptr;
-  size_t cap = 0;
-  bool reserve(size_t n, size_t keep, hipStream_t st) {
-    if (n <= cap) return true;
-    size_t ncap = cap ? cap : 4096;
-    while (ncap < n) ncap *= 2;
+  int64_t origin = 0;  // absolute index of p[0]
+  int64_t cap = 0;     // elements
+  int64_t filled = 0;  // absolute end of valid data (set by the owner before ensure)
+  // does [lo, hi) fit as things are (and is the dead prefix still small)?
+  bool fits(int64_t lo, int64_t hi) const {
+    return p && lo >= origin && hi <= origin + cap && lo - origin <= cap / 2;
+  }
+  // move the window so that it starts at lo and holds at least [lo, hi), keeping [lo, filled)
+  bool slide_to(int64_t lo, int64_t hi, hipStream_t st, int64_t min_cap) {
+    const int64_t ncap = std::max<int64_t>(min_cap, 2 * (hi - lo));
     T* np = nullptr;
-    if (hipMalloc(&np, ncap * sizeof(T)) != hipSuccess) return false;
-    if (p && keep) {
-      if (hipMemcpyAsync(np, p, keep * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+    if (hipMallocAsync(reinterpret_cast<void**>(&np), (size_t)ncap * sizeof(T), st) != hipSuccess) return false;
+    if (p && filled > lo && lo >= origin) {
+      if (hipMemcpyAsync(np, p + (lo - origin), (size_t)(std::min(filled, origin + cap) - lo) * sizeof(T),
+                         hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return false;
     }
-    if (p) {
-      (void)hipStreamSynchronize(st);
-      (void)hipFree(p);
-    }
+    if (p) (void)hipFreeAsync(p, st);
     p = np;
+    origin = lo;
     cap = ncap;
     return true;
   }
-  void release() {
-    if (p) (void)hipFree(p);
+  bool ensure(int64_t lo, int64_t hi, hipStream_t st, int64_t min_cap = 4096) {
+    if (p && lo < origin) lo = origin;  // what was dropped stays dropped
+    if (lo < 0) lo = 0;
+    if (hi < lo) hi = lo;
+    if (fits(lo, hi)) return true;
+    return slide_to(lo, hi, st, min_cap);
+  }
+  T* base() const { return p - origin; }  // only ever dereferenced at indices >= origin
+  void release(hipStream_t st) {
+    if (p) (void)hipFreeAsync(p, st);
     p = nullptr;
     cap = 0;
   }
@@ -48,6 +78,7 @@ struct DevBuf {  // growable device array, contents preserved on growth
 
 struct sonicStreamStruct {  // speedyConnectionStruct + the parts of libsonic's stream the API exposes
   const SpxPlanDev* plan = nullptr;
+  int device = 0;
   int sampleRate = 0, channels = 0;
   float globalSpeed = 1.0f;         // soniclib.c:114
   bool speedupOnly = true;          // every launch so far had speed > 1 and 0 <= nonlinear factor <= 1
@@ -56,35 +87,63 @@ struct sonicStreamStruct {  // speedyConnectionStruct + the parts of libsonic's 
   float rate = 1.0f;
   int bufferSize = 0;               // 0 until the first nonlinear write (soniclib.c:195, sonic_test.cc:496)
   int mode = -1;                    // -1 unknown, 0 linear, 1 nonlinear (fixed by the first write)
-  bool flushed = false;
   tensionFunction cbTension = nullptr;
   speedFunction cbSpeed = nullptr;
   featuresFunction cbFeatures = nullptr;
   spectrogramFunction cbSpectrogram = nullptr, cbNormalized = nullptr;
 
   hipStream_t hs = nullptr;
-  DevBuf<int16_t> dIn, dOut;
-  DevBuf<SpxFrameRec> dRec;
-  DevBuf<float> dScr;
-  DevBuf<float> tTension, tSpeed, tFeatures, tSpec, tNorm;
-  SpxStreamDev* dJob = nullptr;     // 1 entry
-  SpxStreamState* dState = nullptr; // 1 entry
-  int64_t* dNOut = nullptr;         // 1 entry
+  SlideBuf<int16_t> dIn, dOut;      // elements = int16 values (frames * channels)
+  SlideBuf<SpxFrameRec> dRec;       // elements = analysis frames
+  SlideBuf<float> dScr;             // 4 floats per frame
+  SlideBuf<float> tTension, tSpeed, tFeatures, tSpec, tNorm;
+  unsigned char* dSmall = nullptr;  // SpxStreamDev job | SpxStreamState | int64 n_out, one allocation
+  SpxStreamDev* dJob = nullptr;
+  SpxStreamState* dState = nullptr;
+  int64_t* dNOut = nullptr;
+  unsigned char* hPinned = nullptr;  // pinned staging: job table (first 256 B), then input chunk / callback rows
+  size_t hPinnedBytes = 0;
+  hipEvent_t evStaged = nullptr;     // the last copy out of the staging area has been consumed
 
   int64_t nIn = 0;          // frames written so far
   int64_t framesDone = 0;   // analysis frames already launched
+  int64_t tensionDone = 0;  // tension frames already computed (or skipped for good by a flush)
+  int64_t tensionSkip = 0;  // SpxStreamDev::tension_skip
+  int64_t tsmShift = 0;     // SpxStreamDev::tsm_shift
   int64_t outKnown = 0;     // frames produced, as of the last synchronisation
   int64_t outBound = 0;     // upper bound on frames produced by everything launched
   int64_t outRead = 0;      // frames already delivered to the caller
+  int64_t tsmBase = 0;      // TSM stage's oldest buffered frame (TSM position), as of the last synchronisation
+  int writesSinceSync = 0;
   bool dirty = false;       // launches in flight since the last synchronisation
   bool started = false;     // a job has been launched (state record valid)
   bool failed = false;
-  std::vector<float> hostRow;  // callback scratch
   void* userData = nullptr;    // sonicIntSetUserData (soniclib.c:98,106)
 };
 
 static bool any_callback(sonicStream s) {
   return s->cbTension || s->cbSpeed || s->cbFeatures || s->cbSpectrogram || s->cbNormalized;
+}
+
+#define SPX_STAGE_JOB 256  // the job table lives in the first bytes of the staging area
+// Staging area in pinned host memory: waits until the previous user's copies have left it, grows on demand (contents are
+// not preserved).  Returns the part behind the job-table slot.
+static unsigned char* staging(sonicStream s, size_t bytes) {
+  if (s->evStaged) (void)hipEventSynchronize(s->evStaged);
+  bytes += SPX_STAGE_JOB;
+  if (bytes > s->hPinnedBytes) {
+    if (s->hPinned) (void)hipHostFree(s->hPinned);
+    s->hPinned = nullptr;
+    size_t n = s->hPinnedBytes ? s->hPinnedBytes : 65536;
+    while (n < bytes) n *= 2;
+    if (hipHostMalloc(reinterpret_cast<void**>(&s->hPinned), n, hipHostMallocDefault) != hipSuccess) {
+      s->hPinnedBytes = 0;
+      g_api_err = "pinned staging allocation failed";
+      return nullptr;
+    }
+    s->hPinnedBytes = n;
+  }
+  return s->hPinned + SPX_STAGE_JOB;
 }
 
 extern "C" {
@@ -103,27 +162,34 @@ sonicStream sonicCreateStream(int sampleRate, int numChannels) {
   if (!plan) { g_api_err = "sonicCreateStream: plan creation failed"; return nullptr; }
   sonicStream s = new sonicStreamStruct();
   s->plan = plan;
+  (void)hipGetDevice(&s->device);
   s->sampleRate = sampleRate;
   s->channels = numChannels;
+  const size_t small = 256 + sizeof(SpxStreamState) + 64;
   if (hipStreamCreateWithFlags(&s->hs, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc(&s->dJob, sizeof(SpxStreamDev)) != hipSuccess ||
-      hipMalloc(&s->dState, sizeof(SpxStreamState)) != hipSuccess ||
-      hipMalloc(&s->dNOut, sizeof(int64_t)) != hipSuccess) {
+      hipEventCreateWithFlags(&s->evStaged, hipEventDisableTiming) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&s->dSmall), small) != hipSuccess) {
     g_api_err = "sonicCreateStream: device allocation failed";
     sonicDestroyStream(s);
     return nullptr;
   }
+  s->dJob = reinterpret_cast<SpxStreamDev*>(s->dSmall);
+  s->dState = reinterpret_cast<SpxStreamState*>(s->dSmall + 256);
+  s->dNOut = reinterpret_cast<int64_t*>(s->dSmall + 256 + sizeof(SpxStreamState));  // directly behind the state
   return s;
 }
 
 void sonicDestroyStream(sonicStream s) {
   if (!s) return;
+  (void)hipSetDevice(s->device);
   if (s->hs) (void)hipStreamSynchronize(s->hs);
-  s->dIn.release(); s->dOut.release(); s->dRec.release(); s->dScr.release();
-  s->tTension.release(); s->tSpeed.release(); s->tFeatures.release(); s->tSpec.release(); s->tNorm.release();
-  if (s->dJob) (void)hipFree(s->dJob);
-  if (s->dState) (void)hipFree(s->dState);
-  if (s->dNOut) (void)hipFree(s->dNOut);
+  s->dIn.release(s->hs); s->dOut.release(s->hs); s->dRec.release(s->hs); s->dScr.release(s->hs);
+  s->tTension.release(s->hs); s->tSpeed.release(s->hs); s->tFeatures.release(s->hs); s->tSpec.release(s->hs);
+  s->tNorm.release(s->hs);
+  if (s->hs) (void)hipStreamSynchronize(s->hs);
+  if (s->dSmall) (void)hipFree(s->dSmall);
+  if (s->hPinned) (void)hipHostFree(s->hPinned);
+  if (s->evStaged) (void)hipEventDestroy(s->evStaged);
   if (s->hs) (void)hipStreamDestroy(s->hs);
   delete s;
 }
@@ -151,16 +217,19 @@ spectrogramFunction getSonicNormalizedSpectrogramCallback(sonicStream s) { retur
 
 }  // extern "C"
 
-// Bring outKnown up to date (synchronises the stream).
+// Bring outKnown / tsmBase up to date: ONE device-to-host copy of {state record, produced count}, one synchronisation.
 static bool sync_stream(sonicStream s) {
   if (!s->dirty) return true;
-  int64_t n = 0;
-  if (hipMemcpyAsync(&n, s->dNOut, sizeof(n), hipMemcpyDeviceToHost, s->hs) != hipSuccess ||
+  (void)hipSetDevice(s->device);
+  struct { SpxStreamState st; int64_t n; } h;
+  static_assert(sizeof(h) == sizeof(SpxStreamState) + sizeof(int64_t), "state and count are read back in one copy");
+  if (hipMemcpyAsync(&h, s->dState, sizeof(h), hipMemcpyDeviceToHost, s->hs) != hipSuccess ||
       hipStreamSynchronize(s->hs) != hipSuccess) {
     g_api_err = std::string("stream synchronisation failed: ") + hipGetErrorString(hipGetLastError());
     s->failed = true;
     return false;
   }
+  int64_t n = h.n;
   if (n == SPX_NOUT_LOST_PRODUCER) {
     g_api_err = "a producer kernel never delivered its frames (device-side poll limit reached)";
     s->failed = true;
@@ -172,93 +241,134 @@ static bool sync_stream(sonicStream s) {
   }
   s->outKnown = n;
   s->outBound = n;
+  s->tsmBase = h.st.w.base;
   s->dirty = false;
+  s->writesSinceSync = 0;
   return true;
 }
 
-// Fire the monitoring callbacks for analysis calls [j0, j1) in the order of soniclib.c:297-353.
-static void run_callbacks(sonicStream s, int64_t j0, int64_t j1) {
+// Fire the monitoring callbacks for analysis calls [j0, j1) in the order of soniclib.c:297-353; the tension frames this
+// job computed are [k_first, j1 - F + 1).  All rows the calls need are fetched with one batch of asynchronous copies
+// into pinned memory and one synchronisation.
+static void run_callbacks(sonicStream s, int64_t j0, int64_t j1, int64_t k_first) {
   const SpxPlanDev& P = *s->plan;
   const int N = P.N, W = P.W, F = P.F;
-  s->hostRow.resize((size_t)N);
+  const int64_t nj = j1 - j0;
+  if (nj <= 0) return;
+  const int64_t k_end = (j1 >= F) ? j1 - F + 1 : 0;
+  const int64_t nk = std::max<int64_t>(0, k_end - k_first);
+  const int64_t kp0 = std::max<int64_t>(0, j0 - F), kp1 = std::max<int64_t>(kp0, j1 - F);  // rows of tNorm the calls hand out
+  const size_t o_spec = 0;
+  const size_t o_norm = o_spec + (s->cbSpectrogram ? sizeof(float) * (size_t)nj * N : 0);
+  const size_t o_ten = o_norm + (s->cbNormalized ? sizeof(float) * (size_t)(kp1 - kp0) * W : 0);
+  const size_t o_spd = o_ten + sizeof(float) * (size_t)nk;
+  const size_t o_feat = o_spd + sizeof(float) * (size_t)nk;
+  const size_t total = o_feat + sizeof(float) * (size_t)nk * SPX_FEATURE_COUNT + (size_t)N * sizeof(float);
+  unsigned char* h = staging(s, total);
+  if (!h) return;
+  float* hSpec = reinterpret_cast<float*>(h + o_spec);
+  float* hNorm = reinterpret_cast<float*>(h + o_norm);
+  float* hTen = reinterpret_cast<float*>(h + o_ten);
+  float* hSpd = reinterpret_cast<float*>(h + o_spd);
+  float* hFeat = reinterpret_cast<float*>(h + o_feat);
+  float* hRow = hFeat + (size_t)nk * SPX_FEATURE_COUNT;  // scratch row handed to the normalised-spectrum callback
+  if (s->cbSpectrogram)
+    (void)hipMemcpyAsync(hSpec, s->tSpec.base() + (size_t)j0 * N, sizeof(float) * (size_t)nj * N, hipMemcpyDeviceToHost, s->hs);
+  if (s->cbNormalized && kp1 > kp0)
+    (void)hipMemcpyAsync(hNorm, s->tNorm.base() + (size_t)kp0 * W, sizeof(float) * (size_t)(kp1 - kp0) * W,
+                         hipMemcpyDeviceToHost, s->hs);
+  if (nk > 0) {
+    (void)hipMemcpyAsync(hTen, s->tTension.base() + k_first, sizeof(float) * (size_t)nk, hipMemcpyDeviceToHost, s->hs);
+    (void)hipMemcpyAsync(hSpd, s->tSpeed.base() + k_first, sizeof(float) * (size_t)nk, hipMemcpyDeviceToHost, s->hs);
+    (void)hipMemcpyAsync(hFeat, s->tFeatures.base() + (size_t)k_first * SPX_FEATURE_COUNT,
+                         sizeof(float) * (size_t)nk * SPX_FEATURE_COUNT, hipMemcpyDeviceToHost, s->hs);
+  }
+  (void)hipStreamSynchronize(s->hs);
   for (int64_t j = j0; j < j1; j++) {
     const int at_time = (int)(j + 1);  // writeBufferFrameIndex at that moment
-    if (s->cbSpectrogram) {
-      (void)hipMemcpy(s->hostRow.data(), s->tSpec.p + (size_t)j * N, sizeof(float) * N, hipMemcpyDeviceToHost);
-      s->cbSpectrogram(s, at_time, s->hostRow.data());
-    }
+    if (s->cbSpectrogram) s->cbSpectrogram(s, at_time, hSpec + (size_t)(j - j0) * N);
     if (s->cbNormalized) {
       // the buffer the reference hands out here was filled by the PREVIOUS tension computation
       // (soniclib.c:303-310), i.e. tension frame j-F; before the first one it is uninitialised there, zero here
       const int64_t kprev = j - F;
-      std::fill(s->hostRow.begin(), s->hostRow.end(), 0.0f);
-      if (kprev >= 0)
-        (void)hipMemcpy(s->hostRow.data(), s->tNorm.p + (size_t)kprev * W, sizeof(float) * W, hipMemcpyDeviceToHost);
-      s->cbNormalized(s, at_time, s->hostRow.data());
+      std::fill(hRow, hRow + N, 0.0f);
+      if (kprev >= kp0 && kprev < kp1) memcpy(hRow, hNorm + (size_t)(kprev - kp0) * W, sizeof(float) * W);
+      s->cbNormalized(s, at_time, hRow);
     }
     const int64_t k = j - F + 1;
-    if (k >= 0) {
-      if (s->cbTension) {
-        float v = 0;
-        (void)hipMemcpy(&v, s->tTension.p + k, sizeof(float), hipMemcpyDeviceToHost);
-        s->cbTension(s, (int)k, v);
-      }
-      if (s->cbFeatures) {
-        float f[SPX_FEATURE_COUNT];
-        (void)hipMemcpy(f, s->tFeatures.p + (size_t)k * SPX_FEATURE_COUNT, sizeof(f), hipMemcpyDeviceToHost);
-        s->cbFeatures(s, (int)k, f);
-      }
-      if (s->cbSpeed) {
-        float v = 0;
-        (void)hipMemcpy(&v, s->tSpeed.p + k, sizeof(float), hipMemcpyDeviceToHost);
-        s->cbSpeed(s, (int)k, v);
-      }
+    if (k >= k_first && k < k_end) {
+      if (s->cbTension) s->cbTension(s, (int)k, hTen[k - k_first]);
+      if (s->cbFeatures) s->cbFeatures(s, (int)k, hFeat + (size_t)(k - k_first) * SPX_FEATURE_COUNT);
+      if (s->cbSpeed) s->cbSpeed(s, (int)k, hSpd[k - k_first]);
     }
   }
 }
 
-// Enqueue the analysis + walk launches for everything written since the last job.
+// Enqueue the analysis + tension + walk launches for everything written since the last job.  The caller has made sure
+// the staging area exists and nobody reads its job-table slot any more.
 static int launch_job(sonicStream s, bool flush) {
   const SpxPlanDev& P = *s->plan;
   const bool nonlinear = s->mode == 1;
+  const int64_t C = s->channels;
   const int64_t T = nonlinear ? spx_internal_frames_for(P, s->nIn) : 0;
   const int64_t fa = s->framesDone;
   const bool taps = nonlinear && any_callback(s);
+  const int F = P.F, Pp = P.Pp;
 
-  // output capacity: the bound of spx_internal_out_bound on the total produced since the stream start
-  const int64_t bound = spx_internal_out_bound(P, s->nIn + 2 * (int64_t)P.maxRequired, s->globalSpeed, nonlinear);
-  // `bound` limits the TOTAL output since the stream start, so it is the capacity to provide
+  // ---- output window [outRead, need): what was produced as of the last synchronisation plus the most the TSM stage
+  // can make of the input it had not consumed by then (flush padding included) ----
+  const int64_t unconsumed = s->nIn + s->tsmShift + 2 * (int64_t)P.maxRequired - s->tsmBase;
+  const int64_t bound = s->outKnown + spx_internal_out_bound(P, unconsumed, s->globalSpeed, nonlinear);
   if (s->outBound < s->outKnown) s->outBound = s->outKnown;
-  const int64_t need = bound > s->outBound ? bound : s->outBound;
-  size_t keep = (size_t)s->outBound * s->channels;
-  if (keep > s->dOut.cap) keep = s->dOut.cap;
-  if (!s->dOut.reserve((size_t)need * s->channels, keep, s->hs)) return 0;
+  const int64_t need = std::max(bound, s->outBound);
+  s->dOut.filled = s->outBound * C;
+  if (!s->dOut.ensure(s->outRead * C, need * C, s->hs, 1 << 16)) return 0;
+  // ---- frame records: the tension kernel looks back Pp + 1 frames of compressed energy and one record ----
   if (nonlinear) {
-    if (!s->dRec.reserve((size_t)T + 1, (size_t)fa, s->hs)) return 0;
-    if (!s->dScr.reserve(4 * ((size_t)T + 1), 4 * (size_t)fa, s->hs)) return 0;
-    if (taps) {
-      if (!s->tTension.reserve((size_t)T + 1, (size_t)fa, s->hs) || !s->tSpeed.reserve((size_t)T + 1, (size_t)fa, s->hs) ||
-          !s->tFeatures.reserve(((size_t)T + 1) * SPX_FEATURE_COUNT, (size_t)fa * SPX_FEATURE_COUNT, s->hs) ||
-          !s->tSpec.reserve(((size_t)T + 1) * P.N, (size_t)fa * P.N, s->hs) ||
-          !s->tNorm.reserve(((size_t)T + 1) * P.W, (size_t)fa * P.W, s->hs))
-        return 0;
+    // The kernels index all per-frame arrays (records, scratch, taps) through ONE frame_off, so they slide together:
+    // all of them start at frame `keep`, or none moves.
+    int64_t keep = std::max<int64_t>(0, std::min(fa, s->tensionDone) - Pp - F - 4);
+    if (s->dRec.p && keep < s->dRec.origin) keep = s->dRec.origin;
+    const int64_t hi = T + 2;
+    struct Member { SlideBuf<float>* b; int64_t stride; int64_t filled_frames; };
+    Member tapm[5] = {{&s->tTension, 1, fa}, {&s->tSpeed, 1, fa}, {&s->tFeatures, SPX_FEATURE_COUNT, fa},
+                      {&s->tSpec, P.N, fa}, {&s->tNorm, P.W, fa + 1}};
+    bool move = !s->dRec.fits(keep, hi) || !s->dScr.fits(4 * keep, 4 * hi);
+    if (taps)
+      for (auto& m : tapm) move = move || !m.b->fits(keep * m.stride, hi * m.stride);
+    if (move) {
+      s->dRec.filled = fa; s->dScr.filled = 4 * fa;
+      if (!s->dRec.slide_to(keep, hi, s->hs, 4096) || !s->dScr.slide_to(4 * keep, 4 * hi, s->hs, 4 * 4096)) return 0;
+      if (taps)
+        for (auto& m : tapm) {
+          m.b->filled = m.filled_frames * m.stride;
+          if (!m.b->slide_to(keep * m.stride, hi * m.stride, s->hs, 4096 * m.stride)) return 0;
+        }
     }
   }
-  SpxStreamDev J;
+  // ---- the job: absolute stream coordinates through (possibly negative) base offsets ----
+  SpxStreamDev& J = *reinterpret_cast<SpxStreamDev*>(s->hPinned);
+  static_assert(sizeof(SpxStreamDev) <= SPX_STAGE_JOB, "job table slot");
   memset(&J, 0, sizeof(J));
-  J.in_off = 0; J.n_in = s->nIn; J.out_off = 0; J.out_cap = (int64_t)(s->dOut.cap / s->channels);
-  J.frame_off = 0; J.n_frames = (int32_t)T; J.frame_begin = (int32_t)fa;
-  J.channels = s->channels;
+  J.in_off = -s->dIn.origin; J.n_in = s->nIn;
+  J.out_off = -s->dOut.origin; J.out_cap = (s->dOut.origin + s->dOut.cap) / C;
+  J.frame_off = -s->dRec.origin; J.n_frames = (int32_t)T; J.frame_begin = (int32_t)fa;
+  J.channels = (int32_t)C;
   J.flags = (s->started ? 0 : SPX_F_INIT) | (flush ? SPX_F_FLUSH : 0);
   J.speed = s->globalSpeed; J.nonlinear = nonlinear ? s->nonlinearFactor : 0.0f; J.feedback = s->feedbackStrength;
+  J.tsm_shift = s->tsmShift;
+  J.tension_skip = (int32_t)s->tensionSkip;
   // once a stream has run at a speed <= 1 its carried speed may be below 1: stay on the general kernel from then on
   if (!(J.speed > 1.0f && J.nonlinear >= 0.0f && J.nonlinear <= 1.0f)) s->speedupOnly = false;
   J.first_tile = 0;
   if (hipMemcpyAsync(s->dJob, &J, sizeof(J), hipMemcpyHostToDevice, s->hs) != hipSuccess) return 0;
+  (void)hipEventRecord(s->evStaged, s->hs);
   SpxTapsDev td = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  if (taps) {
-    td.tension = s->tTension.p; td.speed = s->tSpeed.p; td.features = s->tFeatures.p;
-    td.spectrogram = s->tSpec.p; td.normalized = s->tNorm.p;
+  const int64_t fo = J.frame_off;
+  if (taps) {  // tap rows are indexed frame_off + k: give the kernels bases that make that land in the sliding buffers
+    td.tension = s->tTension.base() - fo; td.speed = s->tSpeed.base() - fo;
+    td.features = s->tFeatures.base() - fo * SPX_FEATURE_COUNT;
+    td.spectrogram = s->tSpec.base() - fo * P.N; td.normalized = s->tNorm.base() - fo * P.W;
   }
   if (nonlinear && T > fa) {
     const int TF = spx_analysis_tile_frames();
@@ -266,22 +376,32 @@ static int launch_job(sonicStream s, bool flush) {
     spx_launch_analysis(P, s->dJob, 1, tiles, s->dIn.p, s->dRec.p, td, nullptr, nullptr, s->hs);
   }
   if (nonlinear) spx_launch_tension(P, s->dJob, 1, s->dState, s->dRec.p, s->dScr.p, td, nullptr, nullptr, s->hs);
-  spx_launch_walk(P, s->dJob, 1, s->channels, s->dIn.p, s->dOut.p, s->dNOut, s->dState, s->dScr.p, nullptr, s->speedupOnly,
+  spx_launch_walk(P, s->dJob, 1, (int)C, s->dIn.p, s->dOut.p, s->dNOut, s->dState, s->dScr.p, nullptr, s->speedupOnly,
                   s->hs);
   if (hipGetLastError() != hipSuccess) { g_api_err = "kernel launch failed"; s->failed = true; return 0; }
   s->started = true;
   s->dirty = true;
   s->outBound = need;
+  const int64_t k_first = std::max(s->tensionDone, s->tensionSkip);
   s->framesDone = T;
-  if (taps && T > fa) {
-    (void)hipStreamSynchronize(s->hs);
-    run_callbacks(s, fa, T);
+  if (nonlinear) s->tensionDone = std::max<int64_t>(k_first, (T >= F) ? T - F + 1 : 0);
+  if (flush) {
+    // soniclib.c:538-550: every complete ring buffer goes to the TSM stage at the last speed and the shim's read index
+    // moves to its write index -- tension frames below it that were not computed yet never will be; sonicIntFlushStream
+    // then pads 2*maxRequired zeros, which later input follows in TSM coordinates
+    if (nonlinear) {
+      s->tensionSkip = std::max(s->tensionSkip, s->nIn / P.B);
+      s->tensionDone = std::max(s->tensionDone, s->tensionSkip);
+    }
+    s->tsmShift += 2 * (int64_t)P.maxRequired;
   }
+  if (taps && T > fa) run_callbacks(s, fa, T, k_first);
   return 1;
 }
 
 static int write_shorts(sonicStream s, const short* in, int sampleCount) {
   if (s->failed) return 0;
+  (void)hipSetDevice(s->device);
   if (s->rate != 1.0f) {
     g_api_err = "sonicSetRate != 1 is not supported (libsonic's resampler is outside the hot path)";
     return 0;
@@ -289,24 +409,32 @@ static int write_shorts(sonicStream s, const short* in, int sampleCount) {
   const int want = (s->nonlinearFactor != 0.0f) ? 1 : 0;  // soniclib.c:397
   if (s->mode < 0) s->mode = want;
   if (s->mode != want) {
-    g_api_err = "switching between linear and nonlinear mode inside one stream is not supported";
-    return 0;
-  }
-  if (s->flushed) {
-    g_api_err = "writing after sonicFlushStream is not supported";
+    g_api_err = "switching between linear (factor 0) and nonlinear mode inside one stream is not supported";
     return 0;
   }
   if (s->mode == 1 && s->bufferSize == 0) s->bufferSize = s->plan->B;  // sonicAllocateBuffers, soniclib.c:195
   if (!in || sampleCount <= 0) return 1;
-  if (s->nIn + sampleCount >= (1ll << 30)) {
+  if (s->nIn + sampleCount + s->tsmShift >= (1ll << 30)) {
     g_api_err = "stream longer than 2^30 frames is not supported";
     return 0;
   }
-  const size_t C = (size_t)s->channels;
-  if (!s->dIn.reserve((size_t)(s->nIn + sampleCount) * C + 64, (size_t)s->nIn * C, s->hs)) return 0;
-  if (hipMemcpyAsync(s->dIn.p + (size_t)s->nIn * C, in, sizeof(short) * (size_t)sampleCount * C,
-                     hipMemcpyHostToDevice, s->hs) != hipSuccess)
-    return 0;
+  const SpxPlanDev& P = *s->plan;
+  const int64_t C = s->channels;
+  // Without a read the host does not know how far the TSM stage has consumed its input: look every so often
+  if (++s->writesSinceSync > 64 && !sync_stream(s)) return 0;
+  // oldest input frame either stage can still touch: the analysis halo (frame framesDone-1 starts at (framesDone-1)*B)
+  // and the TSM stage's buffered input (the window refill aligns down by 8 frames)
+  int64_t keepFrom = s->tsmBase - s->tsmShift - 16;
+  if (s->mode == 1) keepFrom = std::min(keepFrom, (s->framesDone - 1) * (int64_t)P.B - 16);
+  if (s->dirty || !s->started) keepFrom = std::min(keepFrom, s->dIn.origin / C);  // unknown progress: keep what is there
+  if (keepFrom < 0) keepFrom = 0;
+  s->dIn.filled = s->nIn * C;
+  if (!s->dIn.ensure(keepFrom * C, (s->nIn + sampleCount) * C + 64, s->hs, 1 << 16)) return 0;
+  const size_t bytes = sizeof(short) * (size_t)sampleCount * C;
+  unsigned char* h = staging(s, bytes);
+  if (!h) return 0;
+  memcpy(h, in, bytes);  // the caller's buffer is free again when this call returns
+  if (hipMemcpyAsync(s->dIn.base() + s->nIn * C, h, bytes, hipMemcpyHostToDevice, s->hs) != hipSuccess) return 0;
   s->nIn += sampleCount;
   return launch_job(s, false);
 }
@@ -326,7 +454,7 @@ int sonicWriteFloatToStream(sonicStream s, const float* in, int sampleCount) {
   } else {
     for (size_t i = 0; i < n; i++) tmp[i] = (short)(in[i] * 32767.0f);  // libsonic's float input scale
   }
-  return write_shorts(s, tmp.data(), sampleCount);
+  return write_shorts(s, tmp.data(), sampleCount);  // copied into the pinned staging area before this returns
 }
 
 int sonicSamplesAvailable(sonicStream s) {
@@ -340,8 +468,10 @@ int sonicReadShortFromStream(sonicStream s, short* out, int bufferSize) {
   if (n <= 0) return 0;
   if (n > bufferSize) n = bufferSize;
   const size_t C = (size_t)s->channels;
-  if (hipMemcpy(out, s->dOut.p + (size_t)s->outRead * C, sizeof(short) * (size_t)n * C, hipMemcpyDeviceToHost) !=
-      hipSuccess)
+  (void)hipSetDevice(s->device);
+  if (hipMemcpyAsync(out, s->dOut.base() + (size_t)s->outRead * C, sizeof(short) * (size_t)n * C, hipMemcpyDeviceToHost,
+                     s->hs) != hipSuccess ||
+      hipStreamSynchronize(s->hs) != hipSuccess)
     return 0;
   s->outRead += n;
   return (int)n;
@@ -382,11 +512,10 @@ void* sonicIntGetUserData(sonicStream s) { return s->userData; }
 
 int sonicFlushStream(sonicStream s) {
   if (s->failed) return 0;
+  (void)hipSetDevice(s->device);
   if (s->mode < 0) s->mode = (s->nonlinearFactor != 0.0f) ? 1 : 0;
-  if (s->flushed) return 1;
-  const int rc = launch_job(s, true);
-  s->flushed = true;
-  return rc;
+  if (!staging(s, 0)) return 0;  // the job-table slot
+  return launch_job(s, true);    // the stream stays usable: a later write continues behind the flush's padding
 }
 int sonicIntFlushStream(sonicStream s) { return linear_only(s, "sonicIntFlushStream") ? sonicFlushStream(s) : 0; }
 

@@ -52,6 +52,11 @@ struct SpxStreamDev {
   int32_t flags;
   float speed, nonlinear, feedback;
   int32_t first_tile;   // index of this job's first analysis tile
+  // Streams that are written again after sonicFlushStream (soniclib.c:529-552 leaves the stream usable):
+  int64_t tsm_shift;     // frames of flush padding the TSM stage has seen so far: TSM position = input frame + tsm_shift
+  int32_t tension_skip;  // tension frames below this index that were not computed before the last flush never are:
+                         // the shim's read index jumps to its write index there (soniclib.c:538-550)
+  int32_t pad2;
 };
 
 // TSM-stage state (libsonic's stream struct) in absolute stream coordinates.

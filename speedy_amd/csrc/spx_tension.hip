@@ -108,7 +108,8 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
       if (sWait == 0) { ok_all = false; break; }
     }
     const int fa = fa_c, T = T_c;
-    const int K0 = (fa >= F) ? fa - F + 1 : 0;        // tension frames already done
+    int K0 = (fa >= F) ? fa - F + 1 : 0;              // tension frames already done
+    if (K0 < S.tension_skip) K0 = S.tension_skip;     // ... or skipped for good by a flush (soniclib.c:538-550)
     const int K = (T >= F) ? T - F + 1 : 0;           // tension frames available (soniclib.c:317)
     if (T > fa) {
       // ---- pass 1: energy low-pass (sequential) -> local -> compressed ----

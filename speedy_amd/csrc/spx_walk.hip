@@ -759,10 +759,10 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   int* sWait = reinterpret_cast<int*>(lds + LY.off_wait);
   // ---------------------------------- TSM stage context ----------------------------------
   WalkCtx X;
-  X.in = in_base + S.in_off;
+  X.in = in_base + S.in_off - S.tsm_shift * S.channels;  // indexed by TSM position (= input frame + flush padding so far)
   X.out = out_base + S.out_off;
   X.out_cap = (pos_t)(S.out_cap > 0x7fffffff ? 0x7fffffff : S.out_cap);
-  X.limit = (pos_t)S.n_in;
+  X.limit = (pos_t)(S.n_in + S.tsm_shift);
   X.C = S.channels;
   X.monoH = reinterpret_cast<unsigned short*>(lds + LY.off_mono);
   X.monoHB = reinterpret_cast<unsigned short*>(lds + LY.off_monoB);
@@ -827,12 +827,13 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
     const pos_t ev0 = handed;
     pos_t ev1;  // one past the last ordinary event of this chunk
     if (nl != 0.0f) ev1 = fin ? (pos_t)(S.n_in / B) : K;  // complete ring buffers written: soniclib.c:446-449
-    else ev1 = (last && (pos_t)S.n_in > avail) ? 1 : 0;
+    else ev1 = (last && (pos_t)(S.n_in + S.tsm_shift) > avail) ? 1 : 0;
     if (ev1 < ev0) ev1 = ev0;
     const pos_t ev_end = ev1 + (fin ? 1 : 0);
     (void)ev_end;
     if constexpr (FAST != 0) {
-      fast_events<NW, FAST>(P, X, st, scr, ev0, ev1, (pos_t)K, avail, B, nl == 0.0f, (pos_t)S.n_in, fin, curSpeed);
+      fast_events<NW, FAST>(P, X, st, scr, ev0, ev1, (pos_t)K, avail, B, nl == 0.0f, (pos_t)(S.n_in + S.tsm_shift), fin,
+                            curSpeed);
     } else {
       for (pos_t ev = ev0; ev < ev_end; ev++) {
         pos_t expected = 0;
@@ -850,7 +851,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
             }
             avail += B;
           } else {
-            avail = (pos_t)S.n_in;
+            avail = (pos_t)(S.n_in + S.tsm_shift);
           }
         } else {
           const pos_t remainingS = avail - st.base;

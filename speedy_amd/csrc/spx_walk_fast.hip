@@ -269,7 +269,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   const FastLds LY = fast_lds_layout_i(maxP, skip, wcap);
 
   FastOut X;
-  X.in = in_base + S.in_off;
+  X.in = in_base + S.in_off - S.tsm_shift;  // indexed by TSM position (= input frame + flush padding so far); mono
   X.out = out_base + S.out_off;
   X.lds = lds;
   X.out_cap = (pos_t)(S.out_cap > 0x7fffffff ? 0x7fffffff : S.out_cap);
@@ -343,7 +343,8 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     handed = linear ? 0 : uni(Z.handed);
     tailSpeed = linear ? Rg : unif(Z.curSpeed);  // sonicSetSpeed between writes reaches the TSM stage at once (soniclib.c:182)
   }
-  pos_t limit = (pos_t)S.n_in;   // frames of real input; reads beyond are the flush's zero padding
+  const pos_t n_tsm = (pos_t)(S.n_in + S.tsm_shift);  // the written input in TSM positions
+  pos_t limit = n_tsm;           // frames of real input; reads beyond are the flush's zero padding
   pos_t wbase = -1;              // window covers [wbase, wbase + wcap); -1 = invalid
   int tg = 0;                    // which of the two lag-sum buffers this step adds into (both clear at kernel start)
   int seq = 0;                   // commands published
@@ -661,7 +662,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     const pos_t ev0 = handed;
     pos_t ev1;  // one past the last ordinary event of this round
     if (!linear) ev1 = fin ? (pos_t)(S.n_in / B) : (pos_t)K;  // complete ring buffers written: soniclib.c:446-449
-    else ev1 = (last && (pos_t)S.n_in > avail) ? 1 : 0;
+    else ev1 = (last && n_tsm > avail) ? 1 : 0;
     if (ev1 < ev0) ev1 = ev0;
     // Most nonlinear events cannot run a step (a step needs maxRequired frames, an event brings B).  The speeds of 64
     // consecutive events sit in one VGPR (lane = event, tail events at the last speed), and the next event that does
@@ -690,14 +691,14 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       const unsigned long long unityMask = __builtin_amdgcn_ballot_w64(unityLane);
       const pos_t availBlk = avail;
       const int perEvent = flushBlk ? 2 * maxRequired : B;
-      const pos_t availLane = (linear && !flushBlk) ? (pos_t)S.n_in : availBlk + (lane + 1) * perEvent;  // frames handed over after event `lane`
+      const pos_t availLane = (linear && !flushBlk) ? n_tsm : availBlk + (lane + 1) * perEvent;  // frames handed over after event `lane`
       int i = 0;
       while (i < nIn) {
         const unsigned long long runnable = __builtin_amdgcn_ballot_w64(
             lane >= i && lane < nIn && (unityLane || availLane - base >= maxRequired));
         if (runnable == 0) break;
         i = __builtin_ctzll(runnable);
-        const pos_t availE = (linear && !flushBlk) ? (pos_t)S.n_in : availBlk + (i + 1) * perEvent;
+        const pos_t availE = (linear && !flushBlk) ? n_tsm : availBlk + (i + 1) * perEvent;
         FSTAMP(0);
         if ((unityMask >> i) & 1) {
           const pos_t n = availE - base;
@@ -715,7 +716,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         FSTAMP(11);
         i++;
       }
-      avail = (linear && !flushBlk) ? (pos_t)S.n_in : availBlk + nIn * perEvent;
+      avail = (linear && !flushBlk) ? n_tsm : availBlk + nIn * perEvent;
       if (flushBlk) {
         if (out_n > expected) out_n = expected;
         base = avail;  // the dependency empties its input after a flush

@@ -289,3 +289,137 @@ def test_speed_changes_between_writes(orc, nl):
     assert got.size == n and np.array_equal(got, buf[:n])
     L.orc_sonicDestroyStream(h)
     s.close()
+
+
+def _drive_both(orc, L, h, s, ops, buf):
+    """Run the same op list through the oracle shim (handle h) and the HIP stream s; every read must agree."""
+    for i, op in enumerate(ops):
+        kind = op[0]
+        if kind == "w":
+            part = np.ascontiguousarray(op[1])
+            assert L.orc_sonicWriteShortToStream(h, orc.sptr(part), part.size // s.channels) == 1
+            assert s.write_short(part) == 1, (i, s.L.speedyHipLastError())
+        elif kind == "f":
+            L.orc_sonicFlushStream(h)
+            assert s.flush() == 1
+        elif kind == "speed":
+            L.orc_sonicSetSpeed(h, op[1]); s.set_speed(op[1])
+        elif kind == "nl":
+            L.orc_sonicEnableNonlinearSpeedup(h, op[1]); s.enable_nonlinear(op[1])
+        elif kind == "r":
+            n = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), op[1])
+            got = s.read_short(op[1])
+            assert got.size == n * s.channels, (i, op, got.size, n)
+            assert np.array_equal(got, buf[: n * s.channels]), (i, op)
+
+
+@pytest.mark.parametrize("nl,ch,speed,fb", [(1.0, 1, 3.5, 0.0), (1.0, 2, 1.6, 0.1), (0.0, 1, 2.0, 0.0), (0.5, 1, 0.7, 0.0)])
+def test_write_after_flush_matches_the_reference_life_cycle(orc, nl, ch, speed, fb):
+    """soniclib.c:529-552 leaves a stream usable after sonicFlushStream: the shim's read index jumps to its write
+    index (tension frames in between are never computed), the TSM stage pads, truncates and empties its input, and later
+    writes continue -- including the partial ring buffer that was pending at the flush.  Three flushes, ragged chunks,
+    reads in between; every read equals the oracle shim's."""
+    from speedy_amd.sonic2 import SonicStream
+    from speedy_amd.synth import speech_like
+    rate = 16000
+    x = speech_like(9 * rate, rate, seed=321, channels=ch)
+    L = orc.lib()
+    h = L.orc_sonicCreateStream(rate, ch, 0)
+    s = SonicStream(rate, ch, False)
+    L.orc_sonicSetSpeed(h, speed); s.set_speed(speed)
+    L.orc_sonicEnableNonlinearSpeedup(h, nl); s.enable_nonlinear(nl)
+    L.orc_sonicSetDurationFeedbackStrength(h, fb); s.set_feedback(fb)
+    buf = np.zeros(400000 * ch, np.int16)
+    ops, pos, n = [], 0, x.size // ch
+    rng = np.random.default_rng(7)
+    cuts = [int(2.3 * rate) + 77, int(5.1 * rate) + 3, int(5.1 * rate) + 3 + 1000]   # flush points (one right after another write)
+    while pos < n:
+        k = int(rng.choice([1000, 1537, 160, 4000]))
+        end = min(n, pos + k)
+        for c in cuts:
+            if pos < c <= end:
+                end = c
+        ops.append(("w", x[pos * ch:end * ch]))
+        ops.append(("r", int(rng.integers(1, 5000))))
+        if end in cuts:
+            ops.append(("f",))
+            ops.append(("r", 400000))
+        pos = end
+    ops += [("f",), ("r", 400000), ("r", 10)]
+    _drive_both(orc, L, h, s, ops, buf)
+    L.orc_sonicDestroyStream(h)
+    s.close()
+
+
+def test_nonlinear_factor_changes_between_writes(orc):
+    """The shim re-reads the nonlinear factor on every write (soniclib.c:397,343-345): 1.0 -> 0.3 -> 0.8 mid-stream."""
+    from speedy_amd.sonic2 import SonicStream
+    from speedy_amd.synth import speech_like
+    rate, ch = 22050, 1
+    x = speech_like(6 * rate, rate, seed=55)
+    L = orc.lib()
+    h = L.orc_sonicCreateStream(rate, ch, 1)
+    s = SonicStream(rate, ch, True)
+    L.orc_sonicSetSpeed(h, 3.0); s.set_speed(3.0)
+    buf = np.zeros(300000, np.int16)
+    ops = []
+    third = x.size // 3
+    for k, f in enumerate([1.0, 0.3, 0.8]):
+        ops.append(("nl", f))
+        seg = x[k * third:(k + 1) * third]
+        for p in range(0, seg.size, 2048):
+            ops.append(("w", seg[p:p + 2048]))
+            ops.append(("r", 100000))
+    ops += [("f",), ("r", 300000)]
+    _drive_both(orc, L, h, s, ops, buf)
+    L.orc_sonicDestroyStream(h)
+    s.close()
+
+
+def test_documented_deviations_fail_loudly_not_silently():
+    """sonicSetRate != 1 and switching between factor 0 and a nonzero factor inside one stream are not
+    supported; the next write returns 0 with a message -- no audio is ever produced on a wrong path."""
+    from speedy_amd.sonic2 import SonicStream
+    x = np.zeros(4000, np.int16)
+    s = SonicStream(16000, 1, False)
+    s.set_speed(2.0)
+    s.L.sonicSetRate(s.h, 1.5)
+    assert s.write_short(x) == 0 and b"sonicSetRate" in s.L.speedyHipLastError()
+    s.close()
+    s = SonicStream(16000, 1, False)
+    s.set_speed(2.0)
+    assert s.write_short(x) == 1          # linear
+    s.enable_nonlinear(1.0)
+    assert s.write_short(x) == 0 and b"switching" in s.L.speedyHipLastError()
+    s.close()
+
+
+def test_ten_minute_soak_memory_stays_flat(orc):
+    """10 minutes of 16 kHz audio in 1000-frame writes, each followed by a read (the reference CLI's loop): the device
+    buffers slide, so free device memory after minute 2 and after minute 10 agree, and the bytes equal the oracle's."""
+    import torch
+    from speedy_amd.sonic2 import SonicStream
+    from speedy_amd.synth import speech_like
+    rate = 16000
+    piece = speech_like(60 * rate, rate, seed=808)
+    x = np.tile(piece, 10)
+    ref = orc.compress_sound(x, rate, 1, 3.5, 1.0, 0.1, False, chunk=1000, taps=False)["out"]
+    s = SonicStream(rate, 1, False)
+    s.set_speed(3.5); s.enable_nonlinear(1.0); s.set_feedback(0.1)
+    outs, free_at = [], {}
+    for pos in range(0, x.size, 1000):
+        assert s.write_short(x[pos:pos + 1000]) == 1
+        outs.append(s.read_short(1000))
+        if pos in (120 * rate, 600 * rate - 1000):
+            torch.cuda.synchronize()
+            free_at[pos] = torch.cuda.mem_get_info()[0]
+    s.flush()
+    while True:
+        got = s.read_short(4096)
+        if got.size == 0:
+            break
+        outs.append(got)
+    s.close()
+    assert np.array_equal(np.concatenate(outs), ref)
+    a, b = free_at[120 * rate], free_at[600 * rate - 1000]
+    assert abs(a - b) <= 8 << 20, (a, b)   # the whole 10-minute input alone would be 19 MB, its taps far more
