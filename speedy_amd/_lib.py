@@ -95,6 +95,28 @@ SYMBOLS = {
     "sonicIntFlushStream": (C.c_int, [C.c_void_p]),
     "sonicIntSetUserData": (None, [C.c_void_p, C.c_void_p]),
     "sonicIntGetUserData": (C.c_void_p, [C.c_void_p]),
+    # include/speedy.h
+    "speedyCreateStream": (C.c_void_p, [C.c_int]),
+    "speedyDestroyStream": (None, [C.c_void_p]),
+    "speedyInputFrameSize": (C.c_int, [C.c_void_p]),
+    "speedyInputFrameStep": (C.c_int, [C.c_void_p]),
+    "speedyFFTSize": (C.c_int, [C.c_void_p]),
+    "speedyBinToFreq": (C.c_float, [C.c_void_p, C.c_int]),
+    "speedyFreqToBin": (C.c_int, [C.c_void_p, C.c_float]),
+    "speedyAddData": (None, [C.c_void_p, c_float_p, C.c_int64]),
+    "speedyAddDataShort": (None, [C.c_void_p, c_short_p, C.c_int64]),
+    "speedyComputeTension": (C.c_int, [C.c_void_p, C.c_int64, c_float_p]),
+    "speedyComputeSpeedFromTension": (C.c_float, [C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "speedyGetCurrentTime": (C.c_int64, [C.c_void_p]),
+    "speedySpectrogram": (c_float_p, [C.c_void_p, c_float_p]),
+    "speedyGetSpectrogram": (c_float_p, [C.c_void_p]),
+    "speedyGetSpectrogramAtTime": (c_float_p, [C.c_void_p, C.c_int64]),
+    "speedyGetNormalizedSpectrogram": (c_float_p, [C.c_void_p]),
+    "speedyGetInternalState": (c_float_p, [C.c_void_p]),
+    "speedyGetEnergyCompressed": (C.c_float, [C.c_void_p]),
+    "speedyGetSpeechChanges": (C.c_float, [C.c_void_p]),
+    "speedyHipHysteresisFuture": (C.c_int, [C.c_void_p]),
+    "speedyHipHysteresisPast": (C.c_int, [C.c_void_p]),
     "speedyHipSetMatchMatlab": (None, [C.c_int]),
     "sonicSamplesAvailable": (C.c_int, [C.c_void_p]),
     "speedyHipLastError": (C.c_char_p, []),

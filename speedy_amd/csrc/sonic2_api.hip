@@ -121,6 +121,10 @@ struct sonicStreamStruct {  // speedyConnectionStruct + the parts of libsonic's 
   void* userData = nullptr;    // sonicIntSetUserData (soniclib.c:98,106)
 };
 
+// shared with speedy_api.hip
+void spx_internal_set_api_error(const std::string& msg) { g_api_err = msg; }
+int spx_internal_match_matlab() { return g_match_matlab; }
+
 static bool any_callback(sonicStream s) {
   return s->cbTension || s->cbSpeed || s->cbFeatures || s->cbSpectrogram || s->cbNormalized;
 }

@@ -294,7 +294,8 @@ template <int TF>
 __global__ void __launch_bounds__(SPX_BLOCK)
 spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int n_streams,
                     const int16_t* __restrict__ in_base, SpxFrameRec* __restrict__ rec, SpxTapsDev taps,
-                    const int* __restrict__ tile_order, int* tile_flags) {
+                    const int* __restrict__ tile_order, int* tile_flags, const float* __restrict__ frames,
+                    int frame_mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int W = P.W, B = P.B, N = P.N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -336,7 +337,9 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   const int jfirst = (j0 > 0) ? j0 - 1 : 0;            // first frame whose samples are needed
   const int64_t sbase = (int64_t)jfirst * B;           // absolute index of smono[0]
   const int nstage = (j1 - jfirst) * B + (W - B);      // frames jfirst .. j1-1
-  if (C == 1) {
+  if (frames != nullptr) {
+    // explicit float frames (unit-level API): nothing to stage
+  } else if (C == 1) {
     const int16_t* __restrict__ src = in + sbase;
     for (int k0 = tid; k0 < nstage; k0 += 8 * SPX_BLOCK) {
       short v[8];
@@ -363,13 +366,21 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
     for (int i = lane; i < 2 * W; i += SPX_WAVE) {
       double v = 0.0;
       if (i < W) {
-        const int m = fr[i];
-        int mp;
-        if (i > 0) mp = fr[i - 1];
-        else mp = (j > 0) ? (int)fr[(W - B) - 1] : 0;
-        const float x = (float)(m / 32768.0);
-        const float xp = (float)(mp / 32768.0);
-        const float y = (float)(1.0 * (double)x - 0.97 * (double)xp);  // speedy.c:422
+        float x, xp;
+        if (frames != nullptr) {  // uniform: frame j is frames[j*W ..), the filter state the previous frame's last sample
+          const float* ff = frames + (size_t)j * W;
+          x = ff[i];
+          if (i > 0) xp = ff[i - 1];
+          else xp = (j > 0) ? ff[-1] : 0.0f;
+        } else {
+          const int m = fr[i];
+          int mp;
+          if (i > 0) mp = fr[i - 1];
+          else mp = (j > 0) ? (int)fr[(W - B) - 1] : 0;
+          x = (float)(m / 32768.0);
+          xp = (float)(mp / 32768.0);
+        }
+        const float y = (frame_mode == 2) ? x : (float)(1.0 * (double)x - 0.97 * (double)xp);  // speedy.c:422
         v = (double)(y * P.window[i]);                                  // speedy.c:442 / :462
       }
       bufA[i] = v;
@@ -507,9 +518,13 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
     for (int idx = tid; idx < nfr * W; idx += SPX_BLOCK) {
       const int f = idx / W, i = idx - f * W;
       const int j = j0 + f;
-      if (j + 1 < T) taps.normalized[(size_t)(S.frame_off + j + 1) * W + i] = mags[(size_t)(f + 1) * MS + i] * fInv[f + 1];
+      const int row = j + (S.unit_time0 ? 0 : 1);  // the tension frame whose `cur` spectrum frame j is
+      if (row < T + (S.unit_time0 ? 1 : 0))
+        taps.normalized[(size_t)(S.frame_off + row) * W + i] = mags[(size_t)(f + 1) * MS + i] * fInv[f + 1];
     }
-    if (j0 == 0) {
+    if (S.unit_time0) {
+      // unit-level time base: tension t uses frame t itself, there is no all-zero row
+    } else if (j0 == 0) {
       for (int i = tid; i < W; i += SPX_BLOCK) taps.normalized[(size_t)S.frame_off * W + i] = 0.0f;
     } else if (j0 == S.frame_begin) {
       // a resumed stream: the launch that analysed frame j0-1 stopped before row j0; the halo slot holds it
@@ -554,8 +569,18 @@ void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n
   const size_t lds = spx_analysis_lds_bytes(P);
   if (P.tile_frames == SPX_TF_SMALL)
     hipLaunchKernelGGL(spx_analysis_kernel<SPX_TF_SMALL>, dim3(n_tiles), dim3(SPX_BLOCK), lds, st, P, streams, n_streams, in,
-                       rec, taps, tile_order, tile_flags);
+                       rec, taps, tile_order, tile_flags, (const float*)nullptr, 0);
   else
     hipLaunchKernelGGL(spx_analysis_kernel<SPX_TF>, dim3(n_tiles), dim3(SPX_BLOCK), lds, st, P, streams, n_streams, in,
-                       rec, taps, tile_order, tile_flags);
+                       rec, taps, tile_order, tile_flags, (const float*)nullptr, 0);
+}
+
+void spx_launch_analysis_frames(const SpxPlanDev& P, const SpxStreamDev* streams, int n_tiles, const float* frames,
+                                bool preemph, SpxFrameRec* rec, SpxTapsDev taps, hipStream_t st) {
+  if (n_tiles <= 0) return;
+  SpxPlanDev Q = P;
+  Q.tile_frames = SPX_TF;
+  const size_t lds = spx_analysis_lds_bytes(Q);
+  hipLaunchKernelGGL(spx_analysis_kernel<SPX_TF>, dim3(n_tiles), dim3(SPX_BLOCK), lds, st, Q, streams, 1,
+                     (const int16_t*)nullptr, rec, taps, (const int*)nullptr, (int*)nullptr, frames, preemph ? 1 : 2);
 }

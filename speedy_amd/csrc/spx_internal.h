@@ -43,6 +43,8 @@ struct SpxPlanDev {
 // per sonicWrite*/sonicFlush call with the state record carried in device memory between calls.
 #define SPX_F_INIT 1   // ignore the stored state, start a fresh stream
 #define SPX_F_FLUSH 2  // after the new input: sonicFlushStream (soniclib.c:529-552)
+#define SPX_F_TENSION_RANGE 4  // unit-level API: compute exactly the tension frames [tension_skip, tension_to)
+#define SPX_F_NO_SPEED 8       // unit-level API: no speed / duration pass (speedyComputeSpeedFromTension is its own call)
 struct SpxStreamDev {
   int64_t in_off, n_in, out_off, out_cap;  // n_in = input frames present so far (from the stream start)
   int64_t frame_off;    // index of this stream's analysis frame 0 in the per-frame arrays
@@ -56,7 +58,11 @@ struct SpxStreamDev {
   int64_t tsm_shift;     // frames of flush padding the TSM stage has seen so far: TSM position = input frame + tsm_shift
   int32_t tension_skip;  // tension frames below this index that were not computed before the last flush never are:
                          // the shim's read index jumps to its write index there (soniclib.c:538-550)
-  int32_t pad2;
+  // The unit-level API of include/speedy.h (reference speedy.h:61-133) adds frames and asks for tensions one call at
+  // a time, with its own time base:
+  int32_t unit_time0;    // 0: frame j is added at time j + 1 (the shim, soniclib.c:288-296); 1: at time j (speedyAddData(.., j))
+  int32_t tension_to;    // SPX_F_TENSION_RANGE: compute tension frames [tension_skip, tension_to)
+  int32_t pad3;
 };
 
 // TSM-stage state (libsonic's stream struct) in absolute stream coordinates.
@@ -100,6 +106,11 @@ struct SpxTapsDev {
 void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int n_tiles,
                          const int16_t* in, SpxFrameRec* rec, SpxTapsDev taps, const int* tile_order, int* tile_flags,
                          hipStream_t st);
+// The same kernel fed with explicit float frames (unit-level API): frame j = frames[j*W .. j*W + W), pre-emphasis state
+// carried from the previous frame's last sample (speedy.c:416-425); preemph = false: the frame is windowed as it is
+// (speedySpectrogram, speedy.c:438-473).
+void spx_launch_analysis_frames(const SpxPlanDev& P, const SpxStreamDev* streams, int n_tiles, const float* frames,
+                                bool preemph, SpxFrameRec* rec, SpxTapsDev taps, hipStream_t st);
 // Frame-rate stage: energy / hysteresis / difference filters -> tension -> speed per tension frame (scratch[4k+3]) and
 // the tension, speed and feature taps.  tile_flags / speed_ready: the concurrent-mode hand-off (nullptr = sequential).
 void spx_launch_tension(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, SpxStreamState* states,
@@ -133,6 +144,10 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
 // n_out value of a stream whose producer kernel never delivered (concurrent mode poll limit): not an overflow
 #define SPX_NOUT_LOST_PRODUCER INT64_MIN
 size_t spx_tension_lds_bytes();
+// speedyComputeSpeedFromTension (speedy.c:768-788) on the stream's state record: *speed_out = requested speed, the
+// duration sums of the record advance.
+void spx_launch_speed_from_tension(SpxStreamState* state, float tension, float Rg, float feedback, float* speed_out,
+                                   hipStream_t st);
 int spx_analysis_tile_frames();
 int spx_analysis_small_tile_frames();
 

@@ -61,6 +61,7 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
   const int tid = threadIdx.x;
   const SpxStreamDev S = streams[blockIdx.x];
   const int Ttot = S.n_frames, F = P.F, Pp = P.Pp;
+  const int t0 = S.unit_time0 ? 0 : 1;  // frame j is added at time j + t0; history / hysteresis slot tau holds frame tau - t0
   const float Rg = S.speed, nl = S.nonlinear, fb = S.feedback;
   if (nl == 0.0f) return;  // a linear stream has no frames (uniform per workgroup)
 
@@ -108,10 +109,14 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
       if (sWait == 0) { ok_all = false; break; }
     }
     const int fa = fa_c, T = T_c;
-    int K0 = (fa >= F) ? fa - F + 1 : 0;              // tension frames already done
+    int K0 = (fa + t0 >= F) ? fa + t0 - F : 0;        // tension frames already done
     if (K0 < S.tension_skip) K0 = S.tension_skip;     // ... or skipped for good by a flush (soniclib.c:538-550)
-    const int K = (T >= F) ? T - F + 1 : 0;           // tension frames available (soniclib.c:317)
-    if (T > fa) {
+    int K = (T + t0 >= F) ? T + t0 - F : 0;           // tension frames available: t + F <= current time (speedy.c:756)
+    if (S.flags & SPX_F_TENSION_RANGE) {              // the unit-level API asks for its tension frames explicitly
+      K0 = S.tension_skip;
+      if (K > S.tension_to) K = S.tension_to;
+    }
+    if (T > fa || (S.flags & SPX_F_TENSION_RANGE)) {  // (a unit-level tension request brings no new frame)
       // ---- pass 1: energy low-pass (sequential) -> local -> compressed ----
       float lp = Z.lp;
       for (int c0 = fa; c0 < T; c0 += SPX_CH) {
@@ -126,10 +131,10 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
           const float comp = (float)__builtin_sqrt(local > 2 ? 2.0 : (double)local);  // speedy.c:520
           const int j = c0 + i;
           scr[4 * j + 0] = comp;
-          const int k = j - F + 1;  // the tension frame whose callback sees these AddData-time values
+          const int k = j + t0 - F;  // the tension frame whose callback sees these AddData-time values
           if (tfeat && k >= 0) {
             float* f = tfeat + (size_t)k * SPX_FEATURE_COUNT;
-            f[1] = l; f[2] = local; f[3] = comp; f[12] = (float)(j + 1);
+            f[1] = l; f[2] = local; f[3] = comp; f[12] = (float)(j + t0);
           }
         }
         if (n > 0) lp = sB[n - 1];  // every lane keeps the carried state
@@ -140,21 +145,21 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
       for (int k = K0 + tid; k < K; k += NT) {
         float future_max = 0.0f, past_max = 0.0f;
         for (int i = 0; i <= F; i++) {
-          const int tau = k + i;  // hysteresis slot `tau` holds frame tau-1; slots <= 0 are the zero init
-          float v = (tau >= 1) ? scr[4 * (tau - 1) + 0] : 0.0f;
+          const int tau = k + i;  // hysteresis slot `tau` holds frame tau - t0; earlier slots are the zero init
+          float v = (tau >= t0) ? scr[4 * (tau - t0) + 0] : 0.0f;
           v *= P.taperF[i];
           if (v > future_max) future_max = v;
         }
         for (int i = 0; i <= Pp; i++) {
           const int tau = k - i;
-          float v = (tau >= 1) ? scr[4 * (tau - 1) + 0] : 0.0f;
+          float v = (tau >= t0) ? scr[4 * (tau - t0) + 0] : 0.0f;
           v *= P.taperP[i];
           if (v > past_max) past_max = v;
         }
         const float hyst = (float)((double)(past_max + future_max) / 2.0);  // speedy.c:609
-        const float e_cur = (k == 0) ? 0.0f : rec[k - 1].energy;           // history slot k holds frame k-1
-        const bool low = e_cur <= lowthr;
-        const float lsd = (k == 0 || low) ? 0.0f : rec[k - 1].lsd;
+        const float e_cur = (k < t0) ? 0.0f : rec[k - t0].energy;          // history slot k holds frame k - t0
+        const bool low = e_cur <= lowthr || k == 0;                        // the very first call is skipped (speedy.c:692)
+        const float lsd = low ? 0.0f : rec[k - t0].lsd;
         const float ewld = low ? 0.0f : lsd * hyst;                          // speedy.c:720
         scr[4 * k + 1] = hyst;
         scr[4 * k + 2] = ewld;
@@ -177,8 +182,8 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
           const int k = c0 + i;
           const float ewld = sA[i], l = sB[i];
           const float hyst = scr[4 * k + 1];
-          const float e_cur = (k == 0) ? 0.0f : rec[k - 1].energy;
-          const bool low = e_cur <= lowthr;
+          const float e_cur = (k < t0) ? 0.0f : rec[k - t0].energy;
+          const bool low = e_cur <= lowthr || k == 0;
           float rel = 0.0f, sc = 0.0f;
           if (!low) {
             rel = (float)((double)ewld / ((double)l + 0.01 * (double)123.979f));       // speedy.c:725-726
@@ -207,7 +212,7 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
       // ---- pass 4: duration feedback (sequential) and blend with the global speed ----
       float cur_dur = Z.cur_dur, des_dur = Z.des_dur;
       const float fd = (float)(1.0 / 100.0);  // speedy.c:783
-      for (int c0 = K0; c0 < K; c0 += SPX_CH) {
+      for (int c0 = K0; c0 < ((S.flags & SPX_F_NO_SPEED) ? K0 : K); c0 += SPX_CH) {
         const int n = min(SPX_CH, K - c0);
         for (int i = tid; i < n; i += NT) sA[i] = scr[4 * (c0 + i) + 3];
         __syncthreads();
@@ -281,6 +286,32 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
 }
 
 size_t spx_tension_lds_bytes() { return sizeof(float) * 2 * SPX_CH + 64; }
+
+// speedyComputeSpeedFromTension (speedy.c:768-788), one lane, the arithmetic of passes 3 and 4 above for one frame.
+__global__ void spx_speed_kernel(SpxStreamState* state, float tension, float Rg, float fb, float* speed_out) {
+  if (threadIdx.x != 0) return;
+  float v;
+  if ((double)Rg > 1.0) {
+    v = (float)fmax(1.0, (double)(Rg + (1 - Rg) * tension));                   // speedy.c:774
+  } else {
+    v = (float)fmax(0.01, fmin(1.0, (double)(Rg - (1 - Rg) * tension)));       // speedy.c:776
+  }
+  float cur_dur = state->cur_dur, des_dur = state->des_dur;
+  if (fb > 0) {
+    const float excess = cur_dur - des_dur;
+    v = (float)((double)v + fmax(0.01, (double)(fb * excess)));                // speedy.c:780-781
+  }
+  const float fd = (float)(1.0 / 100.0);                                       // speedy.c:783
+  cur_dur += fd / v;
+  des_dur += fd / Rg;
+  state->cur_dur = cur_dur;
+  state->des_dur = des_dur;
+  *speed_out = v;
+}
+void spx_launch_speed_from_tension(SpxStreamState* state, float tension, float Rg, float feedback, float* speed_out,
+                                   hipStream_t st) {
+  hipLaunchKernelGGL(spx_speed_kernel, dim3(1), dim3(64), 0, st, state, tension, Rg, feedback, speed_out);
+}
 
 void spx_launch_tension(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, SpxStreamState* states,
                         const SpxFrameRec* rec, float* scratch, SpxTapsDev taps, const int* tile_flags, int* speed_ready,

@@ -1,0 +1,144 @@
+"""GPU: the unit-level API (include/speedy.h = reference speedy.h:61-100) of the HIP library, put through the
+reference's own unit tests (speedy_test.cc) and its Matlab fixture comparison (speedy_test.cc:859-1057), and compared
+bit for bit with the CPU oracle's restatement of speedy.c driven the same way."""
+import math
+
+import numpy as np
+import pytest
+
+from test_oracle_kat import _decaying_sine, cround
+from test_oracle_matlab_fixture import _snr, _xcorr
+from util import matlab_fixture, read_wav
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip(rate, mm=True):
+    from speedy_amd.speedy import Speedy
+    return Speedy(rate, mm)
+
+
+def test_spectrogram_known_answers():
+    """speedy_test.cc:197-254: sin(10 pi i / N) -> bin 10 = 88.8677; a 2200 Hz sine peaks at speedyFreqToBin."""
+    rate = 22050
+    s = _hip(rate)
+    W, N = s.frame_size, s.fft_size
+    assert (W, N) == (330, 660) and s.frame_step == 220            # speedy_test.cc:228-230
+    i = np.arange(W, dtype=np.float32)
+    spec = s.spectrogram(np.sin(10 * 2 * np.pi * i / np.float32(N)).astype(np.float32))
+    assert int(np.argmax(spec[: N // 2])) == 10 and abs(spec[10] - 88.8677) < 1e-3
+    x = np.sin(2 * np.pi * 2200.0 * i / np.float32(rate)).astype(np.float32)
+    spec = s.spectrogram(x)
+    pos = int(np.argmax(spec[: N // 2]))
+    assert pos == s.FreqToBin(2200.0) and abs(spec[pos] - 88.48474) < 1e-3
+    assert abs(spec[pos - 1] - 76.94) < 0.1 and abs(spec[pos + 1] - 68.02) < 0.1
+    s.close()
+
+
+@pytest.mark.parametrize("mm", [True, False])
+def test_tension_known_answer_and_oracle_equality(orc, mm):
+    """speedy_test.cc:457-530 (decaying 220 Hz sine: tension min -0.6, max 0.14273257, last -0.31351471 with the
+    MATCH_MATLAB shape) -- and every tension, feature row and spectrum equal to the oracle's, bit for bit."""
+    rate, x = 22050, _decaying_sine()
+    g, o = _hip(rate, mm), orc.Speedy(rate, mm)
+    W = g.frame_size
+    step = np.float32(rate / np.float32(100))
+    frame_count = int((x.size - W) / step + 1)
+    tg, out_t = [], 0
+    for t in range(frame_count):
+        start = cround(np.float32(t) * step)
+        g.add_data(x[start:start + W], t)
+        o.add_data(x[start:start + W], t)
+        assert g.GetCurrentTime() == t
+        assert np.array_equal(g.spectrogram(), o.spectrogram()), t
+        okg, vg = g.compute_tension(out_t)
+        oko, vo = o.compute_tension(out_t)
+        assert okg == oko
+        if okg:
+            assert np.float32(vg) == np.float32(vo), (t, vg, vo)
+            assert np.array_equal(g.features(), o.features()), (t, g.features(), o.features())
+            assert np.array_equal(g.normalized(), o.normalized()), t
+            tg.append(vg)
+            out_t += 1
+    assert frame_count == out_t + g.HysteresisFuture() and len(tg) == out_t     # speedy_test.cc:714-757
+    if mm:
+        assert abs(min(tg) + 0.6) < 1e-5 and abs(max(tg) - 0.14273257) < 1e-6 and abs(tg[-1] + 0.31351471) < 1e-5
+    g.close()
+
+
+def test_speed_from_tension_and_feedback(orc):
+    """speedy.c:768-788 through the device state record: same speeds as the oracle for a tension sequence, with feedback."""
+    g, o = _hip(16000), orc.Speedy(16000, True)
+    rng = np.random.default_rng(1)
+    for fb in (0.0, 0.3):
+        for ten in rng.uniform(-0.6, 0.9, 50):
+            a = g.speed_from_tension(ten, 3.0, fb)
+            b = o.L.orc_speedyComputeSpeedFromTension(float(ten), 3.0, fb, o.h)
+            assert np.float32(a) == np.float32(b), (fb, ten, a, b)
+    g.close()
+
+
+def test_tapestry_feature_computations_against_the_matlab_fixture():
+    """speedy_test.cc:859-1057 with the HIP unit-level API in place of speedy.c: 314 frames in, 306 tension frames out,
+    spectrogram / normalised spectrogram SNR > 27 dB at delay 0 and best there, every feature's best delay and SNR
+    threshold as the reference's test demands."""
+    fx = matlab_fixture()
+    exp_spec, exp_norm, exp_feat = fx["spectrogram"], fx["normalized"], fx["features"]
+    data, rate, ch = read_wav("tapestry22050.wav")
+    x = (data.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    s = _hip(rate, True)
+    W = s.frame_size
+    step = np.float32(rate / np.float32(100))
+    frame_count = int((x.size - W) / step + 1)
+    spec, norm, feat, out_t, half = [], [], [], 0, s.fft_size // 2
+    for t in range(frame_count):
+        start = cround(np.float32(t) * step)
+        s.add_data(x[start:start + W], t)
+        spec.append(s.spectrogram()[:half])
+        ok, v = s.compute_tension(out_t)
+        if ok:
+            norm.append(s.normalized())
+            feat.append(s.features())
+            out_t += 1
+    s.close()
+    spec, norm, feat = np.array(spec), np.array(norm), np.array(feat)
+    assert spec.shape[0] == 314 and norm.shape[0] == 306 and feat.shape[0] == 306
+    col, max_delay = 150, 20
+    snrs = [10 * math.log10(_snr(exp_spec[col], spec[col + d])) for d in range(-max_delay, max_delay)]
+    assert snrs[max_delay] > 27 and all(snrs[max_delay] > v for i, v in enumerate(snrs) if i != max_delay)
+    for fr in range(norm.shape[0]):
+        assert abs(float(np.sum(norm[fr] * norm[fr], dtype=np.float32)) - 1) < 4e-3
+    nsnrs = [10 * math.log10(_snr(exp_norm[col], norm[col + d])) for d in range(-max_delay, max_delay)]
+    assert nsnrs[max_delay] > 27 and all(nsnrs[max_delay] > v for i, v in enumerate(nsnrs) if i != max_delay)
+    feature_list = [("Spectrogram energy", 0, 2e5), ("Energy Lowpass", 8, 7e5), ("Energy Local", 8, 4e4),
+                    ("Energy Compressed", 8, 9e5), ("Energy Hysteresis", 0, 320), ("Low Energy Frame", 0, 1e8),
+                    ("Local Spectral Difference", 0, 19), ("Emphasis Weighted Local Difference", 0, 29),
+                    ("Emphasis Weighted Lowpass Filter", -1, 2300), ("Relative Spectral Difference", 0, 28),
+                    ("Speech Changes", 0, 7), ("Audio Tension", 0, 8)]
+    for k, (name, best_delay, thr) in enumerate(feature_list):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r = _xcorr(list(feat[:, k]), list(exp_feat[:, k]), 10)
+        r = [(-1 if (v != v) else v) for v in r]
+        best = int(np.argmax(r))
+        assert best - 10 == best_delay, (name, best - 10, r[best])
+        assert r[best] > thr, (name, r[best])
+
+
+def test_shim_time_base_and_short_input(orc):
+    """speedyAddDataShort with at_time starting at 1, as the shim drives it (soniclib.c:288-296)."""
+    x, rate, _ = read_wav("tapestry.wav")
+    g, o = _hip(rate, False), orc.Speedy(rate, False)
+    W, B = g.frame_size, g.frame_step
+    out_t = 0
+    for j in range(60):
+        fr = x[j * B:j * B + W]
+        g.add_data_short(fr, j + 1)
+        o.add_data_short(fr, j + 1)
+        okg, vg = g.compute_tension(out_t)
+        oko, vo = o.compute_tension(out_t)
+        assert okg == oko
+        if okg:
+            assert np.float32(vg) == np.float32(vo), (j, vg, vo)
+            out_t += 1
+    assert out_t > 30
+    g.close()
