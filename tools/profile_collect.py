@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 src = os.path.join(ROOT, "gpurun_out")
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
@@ -36,7 +36,8 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = {}
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
-        key = next((k for k in ("spx_analysis_kernel", "spx_tension_kernel", "spx_walk_kernel") if k in name), None)
+        key = next((k for k, pat in (("spx_analysis_kernel", "spx_analysis_kernel"), ("spx_tension_kernel", "spx_tension_kernel"),
+                                     ("spx_walk_kernel", "spx_walk")) if pat in name), None)  # spx_walk_kernel / spx_walk_fast_kernel
         if key and row["Counter_Name"] == counter:
             acc.setdefault(key, []).append(float(row["Counter_Value"]))
     for key, vals in acc.items():
@@ -47,7 +48,8 @@ for key, t in traffic.items():
     t["correction"] = ("FETCH_SIZE doubled (gfx950 reports half the bytes of a coalesced streaming read, "
                        "MI355X_MICROARCH.md HBM section); WRITE_SIZE used as is.")
     t["source"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py "
-                   "--steps 3 --warmup 1 --no-cpu-baseline; profiles/%s/%s_pmc_*.csv (concurrent mode)" % (rnd, tag))
+                   "--steps 3 --warmup 1 --no-cpu-baseline --no-pcie, SPX_SERIAL=1 (one kernel in flight at a time); "
+                   "profiles/%s/%s_pmc_*.csv" % (rnd, tag))
 if traffic:
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print("collected into", dst, "kernels:", sorted(traffic))
