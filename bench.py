@@ -52,6 +52,29 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes show 256
+    hardware threads but run the job under cpu.max = 16 CPUs; 256 runnable threads are then throttled to 9x one thread,
+    16 threads scale 15x -- tools/cpu_scaling.py)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def cpu_baseline(streams, gpu_outputs, budget_s=12.0):
     """The CPU oracle (kind "port": C restatement of the reference path; the reference itself is unbuildable here,
     DESIGN.md "Oracle") on the host cores of this machine: oracle/orc_bench.c -- POSIX threads, one stream per task,
@@ -62,7 +85,7 @@ def cpu_baseline(streams, gpu_outputs, budget_s=12.0):
     L.orc_bench_run.restype = C.c_double
     L.orc_bench_run.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                 C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    cores = os.cpu_count() or 1
+    cores, quota = usable_cpus()
     n = streams[0].size
 
     def run(sample, threads):
@@ -79,7 +102,8 @@ def cpu_baseline(streams, gpu_outputs, budget_s=12.0):
     mismatched = sum(1 for i, c in enumerate(crcs)
                      if c != zlib.crc32(np.ascontiguousarray(gpu_outputs[i % len(streams)]).tobytes()))
     return {"value": k * n / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "cpu_model": cpu_model(), "single_thread_msamples_s": n / one / 1e6,
+            "cpu_model": cpu_model(), "host_hw_threads": os.cpu_count(), "cgroup_cpu_quota": quota,
+            "single_thread_msamples_s": n / one / 1e6,
             "thread_scaling": (k * n / dt) / (n / one),
             "output_crc_mismatches_vs_gpu": mismatched,
             "sample": "%d streams (the %d bench streams%s, %d s each), one stream per task on %d POSIX threads, "

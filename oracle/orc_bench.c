@@ -4,6 +4,7 @@
  * soniclib.c:61-82, speedy.c:130-176).  bench.py compiles this file together with the oracle sources with
  * -O3 -march=native -ffp-contract=off on the machine it runs on and times it as `cpu_baseline` (kind "port").
  * Never linked into, or called from, the product. */
+#include <malloc.h>
 #include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -82,6 +83,12 @@ static void* worker(void* arg) {
 double orc_bench_run(const short* in, long n_in, int n_streams, int rate, int channels, float speed, float nonlinear,
                      float feedback, int match_matlab, int chunk, int threads, long* out_frames, uint32_t* out_crc) {
   crc_init();
+  /* The oracle grows its FIFOs with realloc; by default glibc serves such blocks with mmap/munmap and trims the heap
+   * on free, and with a few hundred threads those system calls (and the page faults of the fresh pages) serialise on
+   * the process's address-space lock: 256 threads then run 9x one thread.  Keep the blocks in the per-thread arenas. */
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  mallopt(M_TOP_PAD, 64 << 20);
   bench_job J;
   memset(&J, 0, sizeof(J));
   J.in = in; J.n_in = n_in; J.n_streams = n_streams; J.rate = rate; J.channels = channels;

@@ -14,8 +14,10 @@
 //   * coarse search: the lags x sample-pairs triangle is cut into groups of four pairs and dealt to the lanes of the
 //     search waves ONCE, at kernel start (16 kHz: 254 groups for 256 lanes): a lane's operand offsets and byte masks are
 //     constants, a step is two address computations, four ds_read2_b32, four masked v_sad_u16 and one ds_add_u32.
-//   * refine search: lane = lag, wave = share of the sample pairs, every operand load of the share in flight before
-//     the first SAD (one LDS round trip per share, not one per group).
+//   * refine search: the pairs EVERY lag of the search has form a rectangle (lags x pairs) that is dealt to all search
+//     lanes as (lag, chunk of consecutive pairs) -- equal chunks, so no masks, and every operand load of a lane in flight
+//     before its first SAD (one LDS round trip); the few pairs only the longer lags have are a constant ragged
+//     triangle dealt once at kernel start.  Lag sums meet in LDS with ds_add_u32; the arg-min runs lane = lag.
 //   * arg-min of diff/lag without floats or a resolve loop: key = floor(diff * 2^16 / lag) as an exact integer
 //     (one fp64 fma against a 65536/lag table + truncation); keys order exactly like the rationals whenever
 //     lag1*lag2 < 2^16 (16 kHz: 246^2) and never invert the order otherwise (ties are then resolved exactly, rarely);
@@ -422,6 +424,13 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       rT[par][k] = ft; rR[par][k] = fr; rM[par][k] = ft < 0 ? 0u : fm;
     }
   }
+  // ---- refine search, the common rectangle: lane -> (lag myT, chunk myC), constant.  NLAG = 8*skip + 1 lags at most,
+  // NCH = (search lanes) / NLAG chunks (16 kHz: 33 lags x 7 chunks = 231 of 256 lanes; 22.05 kHz: 41 x 6 = 246). ----
+  const int NLAG = 8 * skip + 1;
+  const int NCH = (64 * NWM) / NLAG;
+  const int myT = tid % NLAG, myC = tid / NLAG;
+  const bool myOn = myC < NCH;
+  const int chM = (65536 + NCH - 1) / NCH;  // c0 / NCH == (c0 * chM) >> 16 for c0 < 1024 (checked by spx_walk_fast_supports)
   FSTAMP_VARS
 
   // Hand the pending cross-fade (and, for FCMD_COPY, a plain copy) to the output waves.  Every command is followed by
@@ -504,7 +513,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       bestC = fast_select(dsum, scaleC, validC, false, minC, kmin);
     }
     FSTAMP(5);
-    // ---- refine at full rate around the coarse winner: lane = lag, wave = share of the pairs ----
+    // ---- refine at full rate around the coarse winner ----
     int period = (minC + bestC) * skip;
     int lo = period - (skip << 2), hi = period + (skip << 2);
     if (lo < minP) lo = minP;
@@ -534,21 +543,28 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         rb[k] = *reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea + lo + rt[k]));
       }
       FSTAMP(12);
-      // common share: lane = lag, this wave's pairs [j0, j1) of [0, c0) -- the same range for every lane, no masks
-      const unsigned* ap = reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, o));
-      const unsigned* bp = reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, o + p));
-      const int CHc = (c0 + NWM - 1) / NWM;
-      const int j0 = wave * CHc;
-      int j1 = j0 + CHc;
-      if (j1 > c0) j1 = c0;
+      // common share: the c0 pairs every lag of the search has, as a rectangle of NLAG lags x c0 pairs dealt to ALL search
+      // lanes: lane = (lag myT, chunk myC), NCH chunks of CH = c0 / NCH consecutive pairs each -- the same count for every
+      // lane, so no masks and one flight of loads -- plus one of the L = c0 - NCH*CH left-over pairs for chunks myC < L.
+      const int CH = CT ? c0 / NCH : (c0 * chM) >> 16;
+      const int L = c0 - NCH * CH;
+      const bool tOk = myOn && myT < nl;
+      const int pT = lo + myT;
+      const int ea = o + 2 * myC * CH;  // first sample of the chunk (same parity as o)
+      const unsigned* ap = reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea));
+      const unsigned* bp = reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea + pT));
+      const int lOff = NCH * CH + myC - myC * CH;  // dwords from the chunk's first pair to the lane's left-over pair
+      const unsigned la = ap[lOff], lb = bp[lOff];
+      const unsigned lm = (myC < L) ? 0xffffffffu : 0u;
       unsigned d;
-      if (j1 - j0 <= 16) {
-        d = sad_uniform<4>(ap + j0, bp + j0, j1 - j0 < 0 ? 0 : j1 - j0, 0u);
-      } else {  // long periods: the first sixteen pairs in one flight, the rest in a pipelined loop
-        d = sad_uniform<4>(ap + j0, bp + j0, 16, 0u);
-        d += sad_run(ap, bp, j0 + 16, j1);
+      if (CH <= 8) {
+        d = sad_uniform<2>(ap, bp, CH, 0u);
+      } else {
+        d = sad_uniform<4>(ap, bp, CH < 16 ? CH : 16, 0u);
+        for (int j = 16; j < CH; j += 16) d = sad_uniform<4>(ap + j, bp + j, CH - j < 16 ? CH - j : 16, d);
       }
-      atomicAdd(&sumR[tg * 64 + lane], valid ? d : 0u);
+      d = __builtin_amdgcn_sad_u16(la & lm, lb & lm, d);
+      atomicAdd(&sumR[tg * 64 + myT], tOk ? d : 0u);
       FSTAMP(13);
 #pragma unroll
       for (int k = 0; k < FRG; k++) {
@@ -753,6 +769,12 @@ bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm) {
   for (int p = minC; p <= maxC; p++) total += ((p >> 1) + (p & 1) + 3) >> 2;
   int ragged = 0;  // the refine search's ragged triangle (the larger parity) must fit FRG tasks per lane
   for (int t = 0; t < 8 * skip + 1; t++) ragged += (t + 2) >> 1;
+  // the refine search's common rectangle: at least one chunk per lag, and the multiply-shift division by NCH exact
+  const int nlag = 8 * skip + 1, nch = (64 * nwm) / nlag;
+  if (nch < 1) return false;
+  const int chM = (65536 + nch - 1) / nch;
+  for (int c0 = 0; c0 <= P.maxPeriod / 2 + 1; c0++)
+    if (((c0 * chM) >> 16) != c0 / nch) return false;
   return total <= FCG * 64 * nwm && ragged <= FRG * 64 * nwm;
 }
 
