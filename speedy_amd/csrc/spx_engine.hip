@@ -3,6 +3,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -25,8 +28,21 @@ static int fail(int code, const std::string& msg) {
   } while (0)
 
 #define SPX_MAX_CHUNKS 16
+// Pinned staging slot for the small host tables of a call (job tables, tile order): the async copies read it after the
+// call has returned, so it is plan-owned and reused only once its copies have retired.
+struct SpxStage {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipEvent_t done = nullptr;
+};
 struct spx_plan {
   SpxPlanDev dev;
+  int device = 0;           // the HIP device the tables live on; calls must be made with it current
+  int cu_count = 1;
+  size_t lds_per_cu = 65536;
+  std::mutex mu;            // one launch sequence at a time per plan: side streams, events and staging are plan-owned
+  SpxStage stage[2];
+  int stage_next = 0;
   void* tables = nullptr;  // one device allocation behind dev.tw/tw2/window/taper*
   // time-chunk pipelining of one batch call: the analysis of chunk c+1 runs on `side` while the walk of chunk c
   // runs on the caller's stream
@@ -39,14 +55,29 @@ struct spx_plan {
 
 // Timing: one set of four HIP events per timed call, recorded on the launch stream and resolved lazily by
 // spx_timing_collect (so that the timed region itself carries no host synchronisation).
-static bool g_timing = false;
-static int g_concurrent = 1;  // spx_set_concurrent: analysis and walk kernels on two streams, tile-flag hand-off
-static bool g_chunks_set = false;  // the caller chose a chunk count (spx_set_pipeline_chunks)
-static int g_chunks = 1;  // spx_set_pipeline_chunks (measured on MI355X, 256 x 10 s: 1 -> 5.09 ms, 2 -> 5.25, 4 -> 5.54 per step)
-struct EvPair { hipEvent_t a, b; int kind; };  // kind 0 = analysis launch, 1 = walk launch
+// Process-wide switches are atomics; the event lists behind spx_timing_collect are guarded by g_tmu.  spx_batch_run may be
+// called from several host threads (one plan per thread, or one plan shared: launches on a plan are serialised by its mutex).
+static std::atomic<bool> g_timing{false};
+static std::atomic<int> g_concurrent{1};  // spx_set_concurrent: analysis and walk kernels on two streams, tile-flag hand-off
+static std::atomic<bool> g_chunks_set{false};  // the caller chose a chunk count (spx_set_pipeline_chunks)
+static std::atomic<int> g_chunks{1};  // spx_set_pipeline_chunks (measured on MI355X, 256 x 10 s: 1 -> 5.09 ms, 2 -> 5.25, 4 -> 5.54 per step)
+struct EvPair { hipEvent_t a, b; int kind; };  // kind 0 = analysis launch, 1 = walk launch, 2 = tension launch
+static std::mutex g_tmu;
 static std::vector<EvPair> g_ev_pending;
 static std::vector<hipEvent_t> g_ev_free;
 static int g_calls_pending = 0;
+
+// Concurrent mode keeps polling workgroups resident; its deadlock-freedom bound (run_impl) counts the streams of ONE
+// call.  A second concurrent-mode call in flight on the same device (another plan, thread or stream) would break it, so
+// per device the last concurrent call leaves an event behind, and a call that finds it unfinished on a different stream
+// takes the sequential launch order instead (same results).  Calls on the same stream are ordered by the stream.
+struct SpxDevGuard {
+  std::mutex mu;
+  hipEvent_t last = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool valid = false;
+};
+static SpxDevGuard g_guard[64];
 
 // Upper bound on the frames a stream can produce from n_in input frames (flush padding included here).
 // speed >= 1: the stage never emits more than it consumes (the nonlinear speed stays >= 1, speedy.c:772).
@@ -86,6 +117,13 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
   spx_plan* p = new spx_plan();
   SpxPlanDev& d = p->dev;
   memset(&d, 0, sizeof(d));
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&p->device) == hipSuccess && hipGetDeviceProperties(&prop, p->device) == hipSuccess) {
+      p->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+      p->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? (size_t)prop.maxSharedMemoryPerMultiProcessor : 65536;
+    }
+  }
   d.rate = sample_rate;
   d.B = (int)(sample_rate / 100.0);                    // speedy.c:335-338
   d.W = (int)(1.5 * sample_rate / (float)100.0);       // speedy.c:213
@@ -195,6 +233,10 @@ void spx_plan_destroy(spx_plan_t plan) {
   if (plan->ev_tension) (void)hipEventDestroy(plan->ev_tension);
   if (plan->ev_start) (void)hipEventDestroy(plan->ev_start);
   for (auto& e : plan->ev_chunk) if (e) (void)hipEventDestroy(e);
+  for (auto& g : plan->stage) {
+    if (g.done) { (void)hipEventSynchronize(g.done); (void)hipEventDestroy(g.done); }
+    if (g.p) (void)hipHostFree(g.p);
+  }
   if (plan->tables) (void)hipFree(plan->tables);
   delete plan;
 }
@@ -219,13 +261,13 @@ int64_t spx_plan_out_capacity(spx_plan_t p, int64_t n_in, float speed) {
 }
 
 }  // extern "C"
-#include <map>
-#include <mutex>
 const SpxPlanDev* spx_internal_shared_plan(int sample_rate, int match_matlab) {
   static std::mutex mu;
-  static std::map<std::pair<int, int>, spx_plan*> cache;
+  static std::map<std::pair<int, std::pair<int, int>>, spx_plan*> cache;  // (device, (rate, mode)): tables are per device
   std::lock_guard<std::mutex> g(mu);
-  auto key = std::make_pair(sample_rate, match_matlab ? 1 : 0);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  auto key = std::make_pair(dev, std::make_pair(sample_rate, match_matlab ? 1 : 0));
   auto it = cache.find(key);
   if (it != cache.end()) return &it->second->dev;
   spx_plan* p = spx_plan_create(sample_rate, match_matlab);
@@ -307,7 +349,21 @@ static SpxTapsDev taps_of(const spx_taps* t) {
   return d;
 }
 
+}  // extern "C"
+// Job tables (and tile order) from the plan's pinned staging slot into the workspace, hand-off flags cleared.
+__global__ void __launch_bounds__(256)
+spx_stage_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst_a, unsigned n_a, unsigned* __restrict__ dst_b,
+                 unsigned n_b, unsigned* __restrict__ zero_a, unsigned nz_a, unsigned* __restrict__ zero_b, unsigned nz_b) {
+  const unsigned stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  for (unsigned i = t0; i < n_a; i += stride) dst_a[i] = src[i];
+  for (unsigned i = t0; i < n_b; i += stride) dst_b[i] = src[n_a + i];
+  for (unsigned i = t0; i < nz_a; i += stride) zero_a[i] = 0u;
+  for (unsigned i = t0; i < nz_b; i += stride) zero_b[i] = 0u;
+}
+extern "C" {
+
 static hipEvent_t take_event() {
+  std::lock_guard<std::mutex> g(g_tmu);
   if (!g_ev_free.empty()) { hipEvent_t e = g_ev_free.back(); g_ev_free.pop_back(); return e; }
   hipEvent_t e;
   (void)hipEventCreate(&e);
@@ -340,18 +396,9 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // most (their total LDS) / (that LDS bound) plus (their total waves) / 29 CUs.  Concurrent iff that leaves a CU open
   // (in practice the dispatcher spreads 256 workgroups one per CU and none is closed).  Batches beyond the bound run
   // the kernels in stream order instead (same results).
-  static int cu_count = 0;
-  static size_t lds_per_cu = 0;
-  if (cu_count == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
-      cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
-      lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? (size_t)prop.maxSharedMemoryPerMultiProcessor : 65536;
-    } else {
-      cu_count = 1; lds_per_cu = 65536;
-    }
-  }
+  std::lock_guard<std::mutex> plan_lock(plan->mu);
+  const int cu_count = plan->cu_count;
+  const size_t lds_per_cu = plan->lds_per_cu;
   const SpxWalkConfig wcfg = spx_walk_config(d, n, maxC, speedup_only);
   const size_t per_stream_lds = wcfg.lds + spx_tension_lds_bytes();
   const size_t per_stream_waves = (size_t)wcfg.waves + 4;  // walk (spx_launch_walk's choice) + tension
@@ -376,29 +423,38 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     // still two analysis workgroups on a CU (measured at 22.05 kHz, where only one fits: 4.1 ms back to back, 5.2 ms concurrent)
     if (per_stream_lds + 2 * spx_analysis_lds_bytes(d) > lds_usable) co_resident = false;
   }
-  if (!co_resident || !g_concurrent || env_serial) d.tile_frames = plan->dev.tile_frames;  // no concurrency: default tile
-  const bool want_concurrent = g_concurrent && !env_serial && co_resident && do_a && do_w;
+  bool want_concurrent = g_concurrent.load() && !env_serial && co_resident && do_a && do_w;
+  hipStream_t st = static_cast<hipStream_t>(hs);
+  // another concurrent-mode call still in flight on this device, on a different stream?  Then this one runs its kernels
+  // in sequence (SpxDevGuard above); the guard stays locked until this call has left its own event behind.
+  SpxDevGuard& guard = g_guard[(plan->device >= 0 && plan->device < 64) ? plan->device : 0];
+  std::unique_lock<std::mutex> guard_lock(guard.mu, std::defer_lock);
+  if (want_concurrent) {
+    guard_lock.lock();
+    if (guard.valid && guard.last_stream != st && hipEventQuery(guard.last) == hipErrorNotReady) want_concurrent = false;
+    (void)hipGetLastError();  // hipErrorNotReady is not an error of this call
+    if (!want_concurrent) guard_lock.unlock();
+  }
+  if (!want_concurrent) d.tile_frames = plan->dev.tile_frames;  // no concurrency: default tile
   // Pipelining in time needs both stages in one call; the separate entry points run one chunk.  A batch too large for
   // the concurrent mode gets four time chunks unless the caller chose a count: the analysis of chunk c+1 then overlaps
   // the walk of chunk c through ordinary stream ordering (measured at 512 / 1024 streams x 10 s: 5.32 -> 4.76 ms and
   // 9.94 -> 9.28 ms per call; no difference at 2048).
-  int nch = (do_a && do_w) ? g_chunks : 1;
-  if (do_a && do_w && !g_chunks_set && !want_concurrent && n > cu_count) nch = 4;
+  int nch = (do_a && do_w) ? g_chunks.load() : 1;
+  if (do_a && do_w && !g_chunks_set.load() && !want_concurrent && n > cu_count) nch = 4;
   if (nch < 1) nch = 1;
   if (nch > SPX_MAX_CHUNKS) nch = SPX_MAX_CHUNKS;
   std::vector<SpxStreamDev> sv;
   std::vector<int> tiles;
   int rc = build_streams(d, jobs, n, nch, sv, tiles);
   if (rc) return rc;
-  hipStream_t st = static_cast<hipStream_t>(hs);
   unsigned char* w = static_cast<unsigned char*>(ws);
   SpxStreamDev* dstreams = reinterpret_cast<SpxStreamDev*>(w + L.off_streams);
   SpxStreamState* states = reinterpret_cast<SpxStreamState*>(w + L.off_states);
   SpxFrameRec* rec = reinterpret_cast<SpxFrameRec*>(w + L.off_rec);
   float* scratch = reinterpret_cast<float*>(w + L.off_scratch);
-  HIPCHK(hipMemcpyAsync(dstreams, sv.data(), sizeof(SpxStreamDev) * sv.size(), hipMemcpyHostToDevice, st));
   SpxTapsDev td = taps_of(taps);
-  const bool timed = g_timing && do_a && do_w;
+  const bool timed = g_timing.load() && do_a && do_w;
   const bool concurrent = want_concurrent && nch == 1 && tiles[0] > 0;
   int* d_order = reinterpret_cast<int*>(w + L.off_order);
   int* d_flags = reinterpret_cast<int*>(w + L.off_flags);
@@ -414,9 +470,11 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     }
     sa = plan->side;
   }
+  // job tables (and, concurrent mode, the tile order) go through a plan-owned pinned slot: the copies are asynchronous
+  // and must not read host memory that dies when this function returns
+  std::vector<int> order;
   if (concurrent) {
     // tile ids in launch order: tile t of every stream before tile t+1 of any
-    std::vector<int> order;
     order.reserve((size_t)tiles[0]);
     std::vector<int> cnt(n);
     int maxT = 0;
@@ -427,9 +485,31 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     for (int t = 0; t < maxT; t++)
       for (int i = 0; i < n; i++)
         if (t < cnt[i]) order.push_back(sv[i].first_tile + t);
-    HIPCHK(hipMemcpyAsync(d_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(d_flags, 0, sizeof(int) * (size_t)tiles[0], st));
-    HIPCHK(hipMemsetAsync(d_ready, 0, sizeof(int) * (size_t)n, st));
+  }
+  {
+    const size_t b_sv = sizeof(SpxStreamDev) * sv.size(), b_or = sizeof(int) * order.size();
+    SpxStage& G = plan->stage[plan->stage_next];
+    plan->stage_next ^= 1;
+    if (G.done) HIPCHK(hipEventSynchronize(G.done));  // the copies that last read this slot (two calls ago) have retired
+    else HIPCHK(hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
+    if (G.cap < b_sv + b_or) {
+      if (G.p) (void)hipHostFree(G.p);
+      G.p = nullptr; G.cap = 0;
+      const size_t cap = (b_sv + b_or) * 2 + 4096;
+      HIPCHK(hipHostMalloc(&G.p, cap, hipHostMallocDefault));
+      G.cap = cap;
+    }
+    unsigned char* hp = static_cast<unsigned char*>(G.p);
+    memcpy(hp, sv.data(), b_sv);
+    if (b_or) memcpy(hp + b_sv, order.data(), b_or);
+    // one small kernel reads the pinned slot over PCIe and clears the hand-off flags: a single stream operation where
+    // two copies and two fills (each its own DMA packet with barriers around it) cost the concurrent mode 0.13 ms a call
+    const unsigned w_sv = (unsigned)(b_sv / 4), w_or = concurrent ? (unsigned)(b_or / 4) : 0u;
+    const unsigned z_fl = concurrent ? (unsigned)tiles[0] : 0u, z_rd = concurrent ? (unsigned)n : 0u;
+    hipLaunchKernelGGL(spx_stage_kernel, dim3(64), dim3(256), 0, st, reinterpret_cast<const unsigned*>(hp),
+                       reinterpret_cast<unsigned*>(dstreams), w_sv, reinterpret_cast<unsigned*>(d_order), w_or,
+                       reinterpret_cast<unsigned*>(d_flags), z_fl, reinterpret_cast<unsigned*>(d_ready), z_rd);
+    HIPCHK(hipEventRecord(G.done, st));
   }
   if (sa != st) {
     // the side stream starts after everything already queued on the caller's stream (job tables, cleared flags, and
@@ -445,7 +525,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, sa); }
       spx_launch_analysis(d, dj, n, tiles[c], in, rec, td, concurrent ? d_order : nullptr,
                           concurrent ? d_flags : nullptr, sa);
-      if (timed) { (void)hipEventRecord(e1, sa); g_ev_pending.push_back({e0, e1, 0}); }
+      if (timed) { (void)hipEventRecord(e1, sa); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({e0, e1, 0}); } }
     }
     if (sa != st) HIPCHK(hipEventRecord(plan->ev_chunk[c], sa));
     if (sa != st && !concurrent) HIPCHK(hipStreamWaitEvent(st, plan->ev_chunk[c], 0));
@@ -457,12 +537,12 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       if (timed) { t0 = take_event(); t1 = take_event(); (void)hipEventRecord(t0, stn); }
       spx_launch_tension(d, dj, n, states, rec, scratch, td, concurrent ? d_flags : nullptr,
                          concurrent ? d_ready : nullptr, stn);
-      if (timed) { (void)hipEventRecord(t1, stn); g_ev_pending.push_back({t0, t1, 2}); }
+      if (timed) { (void)hipEventRecord(t1, stn); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({t0, t1, 2}); } }
       if (concurrent) HIPCHK(hipEventRecord(plan->ev_tension, stn));
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, st); }
       spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, concurrent ? d_ready : nullptr, speedup_only, st);
-      if (timed) { (void)hipEventRecord(e1, st); g_ev_pending.push_back({e0, e1, 1}); }
+      if (timed) { (void)hipEventRecord(e1, st); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({e0, e1, 1}); } }
     }
     // the caller's stream is "done" only when the side launches have retired too
     if (concurrent) {
@@ -470,7 +550,14 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       HIPCHK(hipStreamWaitEvent(st, plan->ev_tension, 0));
     }
   }
-  if (timed) g_calls_pending++;
+  if (concurrent) {
+    // leave this call's completion behind for the next concurrent-mode call on the device (guard still locked)
+    if (!guard.last) HIPCHK(hipEventCreateWithFlags(&guard.last, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(guard.last, st));
+    guard.last_stream = st;
+    guard.valid = true;
+  }
+  if (timed) { std::lock_guard<std::mutex> g(g_tmu); g_calls_pending++; }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -494,6 +581,7 @@ void spx_set_pipeline_chunks(int chunks) { g_chunks_set = true; g_chunks = chunk
 static double g_last_tension_ms = 0.0;
 double spx_timing_last_tension_ms(void) { return g_last_tension_ms; }
 int spx_timing_collect(double* sum_ms_analyze, double* sum_ms_walk, int* n_calls) {
+  std::lock_guard<std::mutex> g(g_tmu);
   double a = 0, w = 0, t = 0;
   for (auto& ev : g_ev_pending) {
     HIPCHK(hipEventSynchronize(ev.b));
@@ -559,11 +647,22 @@ int spx_batch_pack_outputs(const spx_stream_job* jobs, int n, const int16_t* out
   const size_t need = (size_t)n * (sizeof(int64_t) + sizeof(int));
   void* d_tab = nullptr;
   if (hipMallocAsync(&d_tab, need, st) != hipSuccess) return fail(-2, "spx_batch_pack_outputs: allocation failed");
-  std::vector<unsigned char> h(need);
-  int64_t* h_off = reinterpret_cast<int64_t*>(h.data());
-  int* h_ch = reinterpret_cast<int*>(h.data() + (size_t)n * sizeof(int64_t));
+  // host side of the table: a per-thread pinned slot, reused once the copy that last read it has retired
+  static thread_local SpxStage G;
+  if (G.done) HIPCHK(hipEventSynchronize(G.done));
+  else HIPCHK(hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
+  if (G.cap < need) {
+    if (G.p) (void)hipHostFree(G.p);
+    G.p = nullptr; G.cap = 0;
+    HIPCHK(hipHostMalloc(&G.p, need * 2 + 1024, hipHostMallocDefault));
+    G.cap = need * 2 + 1024;
+  }
+  unsigned char* h = static_cast<unsigned char*>(G.p);
+  int64_t* h_off = reinterpret_cast<int64_t*>(h);
+  int* h_ch = reinterpret_cast<int*>(h + (size_t)n * sizeof(int64_t));
   for (int i = 0; i < n; i++) { h_off[i] = jobs[i].out_off; h_ch[i] = jobs[i].channels; }
-  HIPCHK(hipMemcpyAsync(d_tab, h.data(), need, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_tab, h, need, hipMemcpyHostToDevice, st));
+  HIPCHK(hipEventRecord(G.done, st));
   const int64_t* d_off = reinterpret_cast<const int64_t*>(d_tab);
   const int* d_ch = reinterpret_cast<const int*>(static_cast<unsigned char*>(d_tab) + (size_t)n * sizeof(int64_t));
   hipLaunchKernelGGL(spx_pack_offsets_kernel, dim3(1), dim3(64), 0, st, n_out, d_ch, n, offsets);

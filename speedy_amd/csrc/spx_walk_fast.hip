@@ -35,6 +35,9 @@
 
 #include "spx_walk_common.h"
 
+#ifndef SPX_CT_WCAP
+#define SPX_CT_WCAP 4096  // window frames of the rate-specialised kernels
+#endif
 enum { FCMD_STEP = 1, FCMD_COPY = 2, FCMD_REFILL = 3, FCMD_POLL = 4, FCMD_EXIT = 5 };
 #define FCMD_INTS 64  // ints per command slot: field k is written by lane k of the publishing wave
 #define FCG 2         // at most this many coarse groups per lane (22.05 kHz: 303 groups on 256 lanes)
@@ -267,7 +270,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   const int minP = CT ? RATE / 400 : P.minPeriod, maxP = CT ? RATE / 65 : P.maxPeriod;
   const int maxRequired = 2 * maxP;
   const int B = CT ? (int)(RATE / 100.0) : P.B;
-  if (CT) wcap = 4096;
+  if (CT) wcap = SPX_CT_WCAP;
   const FastLds LY = fast_lds_layout_i(maxP, skip, wcap);
 
   FastOut X;
@@ -789,8 +792,8 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
   // the two rates of the BASELINE configs get their own specialisation (with the default 4096-frame window)
 #define SPX_LAUNCH_FAST(M, C)                                              \
   do {                                                                     \
-    if (P.rate == 16000 && wcap == 4096) SPX_LAUNCH_FAST_R(M, C, 16000);   \
-    else if (P.rate == 22050 && wcap == 4096) SPX_LAUNCH_FAST_R(M, C, 22050); \
+    if (P.rate == 16000 && wcap == SPX_CT_WCAP) SPX_LAUNCH_FAST_R(M, C, 16000);   \
+    else if (P.rate == 22050 && wcap == SPX_CT_WCAP) SPX_LAUNCH_FAST_R(M, C, 22050); \
     else SPX_LAUNCH_FAST_R(M, C, 0);                                       \
   } while (0)
 #ifdef SPX_STAMPS
