@@ -197,6 +197,28 @@ __device__ __forceinline__ unsigned sad_groups(const unsigned* ap, const unsigne
   }
 }
 
+// NG whole groups at ap / bp, one more group at apx / bpx and one more pair at app / bpp (per-lane pointers; a lane
+// without the extra group or pair passes the a pointer twice): every load first, then all SADs -- one LDS round trip.
+template <int NG>
+__device__ __forceinline__ unsigned sad_rect(const unsigned* ap, const unsigned* bp, const unsigned* apx, const unsigned* bpx,
+                                             const unsigned* app, const unsigned* bpp, unsigned acc) {
+  unsigned a[NG + 1][4], b[NG + 1][4];
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) { a[g][k] = ap[4 * g + k]; b[g][k] = bp[4 * g + k]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) { a[NG][k] = apx[k]; b[NG][k] = bpx[k]; }
+  const unsigned pa = *app, pb = *bpp;
+#pragma unroll
+  for (int g = 0; g <= NG; g++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc = __builtin_amdgcn_sad_u16(a[g][k], b[g][k], acc);
+  }
+  return __builtin_amdgcn_sad_u16(pa, pb, acc);
+}
+
 // A wave-uniform range of pairs [0, n) at ap / bp, n <= 4 * NG: every load first (groups the range does not reach read
 // the `a` operand twice, so they add |a - a| = 0 -- one address select per group instead of a branch), then all SADs;
 // the pairs of the last, partial group are switched off by wave-uniform selects.  One LDS round trip, no dispatch.

@@ -433,7 +433,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   const int NCH = (64 * NWM) / NLAG;
   const int myT = tid % NLAG, myC = tid / NLAG;
   const bool myOn = myC < NCH;
-  const int chM = (65536 + NCH - 1) / NCH;  // c0 / NCH == (c0 * chM) >> 16 for c0 < 1024 (checked by spx_walk_fast_supports)
+  const int chM = (65536 + NCH - 1) / NCH;  // g / NCH == (g * chM) >> 16 for every group count (checked by spx_walk_fast_supports)
   FSTAMP_VARS
 
   // Hand the pending cross-fade (and, for FCMD_COPY, a plain copy) to the output waves.  Every command is followed by
@@ -546,27 +546,36 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         rb[k] = *reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea + lo + rt[k]));
       }
       FSTAMP(12);
-      // common share: the c0 pairs every lag of the search has, as a rectangle of NLAG lags x c0 pairs dealt to ALL search
-      // lanes: lane = (lag myT, chunk myC), NCH chunks of CH = c0 / NCH consecutive pairs each -- the same count for every
-      // lane, so no masks and one flight of loads -- plus one of the L = c0 - NCH*CH left-over pairs for chunks myC < L.
-      const int CH = CT ? c0 / NCH : (c0 * chM) >> 16;
-      const int L = c0 - NCH * CH;
+      // common share: the c0 pairs every lag of the search has form a rectangle of lags x pairs, cut into groups of four
+      // pairs and dealt to ALL search lanes: lane = (lag myT, chunk myC) takes NGL = (c0 / 4) / NCH consecutive groups --
+      // the same count for every lane, so no masks -- plus, for the first chunks, one of the left-over groups and one of
+      // the c0 % 4 left-over pairs (switched off by reading the a operand twice: |a - a| = 0).  One flight of loads.
+      const int G = c0 >> 2, rho = c0 & 3;
+      int NGL = CT ? G / NCH : (G * chM) >> 16;
+      const int LG = G - NCH * NGL;
+      asm volatile("" : "+s"(NGL));  // opaque: keeps the branch conditions below scalar compares of this value
       const bool tOk = myOn && myT < nl;
       const int pT = lo + myT;
-      const int ea = o + 2 * myC * CH;  // first sample of the chunk (same parity as o)
+      const int ea = o + 8 * myC * NGL;  // first sample of the lane's groups (same parity as o)
       const unsigned* ap = reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea));
       const unsigned* bp = reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea + pT));
-      const int lOff = NCH * CH + myC - myC * CH;  // dwords from the chunk's first pair to the lane's left-over pair
-      const unsigned la = ap[lOff], lb = bp[lOff];
-      const unsigned lm = (myC < L) ? 0xffffffffu : 0u;
-      unsigned d;
-      if (CH <= 8) {
-        d = sad_uniform<2>(ap, bp, CH, 0u);
-      } else {
-        d = sad_uniform<4>(ap, bp, CH < 16 ? CH : 16, 0u);
-        for (int j = 16; j < CH; j += 16) d = sad_uniform<4>(ap + j, bp + j, CH - j < 16 ? CH - j : 16, d);
+      const int xOff = 4 * (NCH * NGL + myC - myC * NGL);   // dwords from the lane's first pair to its left-over group
+      const int pOff = 4 * G + myC - 4 * myC * NGL;         // ... and to its left-over pair
+      const unsigned* apx = ap + xOff;
+      const unsigned* bpx = (myC < LG) ? bp + xOff : apx;
+      const unsigned* app = ap + pOff;
+      const unsigned* bpp = (myC < rho) ? bp + pOff : app;
+      unsigned d = 0u;
+      while (NGL > 3) {  // long periods at the higher rates only
+        d = sad_flight_n<4, false>(ap, bp, 0, d);
+        ap += 16; bp += 16; NGL -= 4;
       }
-      d = __builtin_amdgcn_sad_u16(la & lm, lb & lm, d);
+      switch (NGL) {
+        case 0: d = sad_rect<0>(ap, bp, apx, bpx, app, bpp, d); break;
+        case 1: d = sad_rect<1>(ap, bp, apx, bpx, app, bpp, d); break;
+        case 2: d = sad_rect<2>(ap, bp, apx, bpx, app, bpp, d); break;
+        default: d = sad_rect<3>(ap, bp, apx, bpx, app, bpp, d); break;
+      }
       atomicAdd(&sumR[tg * 64 + myT], tOk ? d : 0u);
       FSTAMP(13);
 #pragma unroll
