@@ -290,14 +290,21 @@ __device__ __forceinline__ int mono_sample(const int16_t* __restrict__ in, int64
   return sum / C;
 }
 
-template <int TF>
+// cplx helpers of the specialised transform (same operation order as dft_stage / st_tw)
+__device__ __forceinline__ cplx cmul_tw(cplx b, double2 w) { return {b.r * w.x - b.i * w.y, b.r * w.y + b.i * w.x}; }
+__device__ __forceinline__ void st(double* buf, int idx, cplx v) {
+  *reinterpret_cast<double2*>(buf + 2 * idx) = make_double2(v.r, v.i);
+}
+
+// WCT != 0: the kernel is compiled for that window size (16 kHz: W = 240 = 4*4*3*5) -- see the phase-1 comment.
+template <int TF, int WCT>
 __global__ void __launch_bounds__(SPX_BLOCK)
 spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int n_streams,
                     const int16_t* __restrict__ in_base, SpxFrameRec* __restrict__ rec, SpxTapsDev taps,
                     const int* __restrict__ tile_order, int* tile_flags, const float* __restrict__ frames,
                     int frame_mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int W = P.W, B = P.B, N = P.N;
+  const int W = WCT ? WCT : P.W, B = P.B, N = 2 * W;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   // tile -> (stream, first frame): binary search over streams[].first_tile
@@ -355,6 +362,142 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
 
   ASTAMP_DECL
   // ---------------- phase 1: spectra of slots 0..TF (slot s = frame j0-1+s), one wave per slot ----------
+  if constexpr (WCT == 240) {
+    // W = 240 = 4*4*3*5, compiled in: every butterfly index, twiddle index and loop bound is a constant of the lane, the
+    // twiddles, window values and untangle factors a lane needs are loaded ONCE (they are the same for every frame) and
+    // live in registers; the window / pre-emphasis pass is fused into the first radix-4 stage, whose upper two inputs
+    // are the zero padding (x + 0 and x - 0 are x); multiplications by the twiddle 1 (output 0 of every butterfly, all
+    // of the last stage) are skipped (x*1 - y*(-0) is x).  Same operations in the same order otherwise -- the
+    // magnitudes are bit-identical to the generic path and to the oracle (signs of exact zeros aside, which no
+    // magnitude depends on).
+    const double2* twp = reinterpret_cast<const double2*>(P.tw);
+    const double2* tw2p = reinterpret_cast<const double2*>(P.tw2);
+    const int b = lane;
+    const bool on60 = b < 60, on48 = b < 48;
+    const int bb = on60 ? b : 0;
+    double2 w1[3], w2[3], w3[2][2], wu[4];
+    float wn[4];
+#pragma unroll
+    for (int j = 1; j < 4; j++) { w1[j - 1] = twp[bb * j]; w2[j - 1] = twp[4 * (bb >> 2) * j]; }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int b3 = lane + 64 * u, p3 = (b3 < 80) ? (b3 >> 4) : 0;
+      w3[u][0] = twp[16 * p3];
+      w3[u][1] = twp[32 * p3];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int k = lane + 64 * u; wu[u] = tw2p[k < 240 ? k : 0]; }
+    wn[0] = P.window[2 * bb]; wn[1] = P.window[2 * bb + 1]; wn[2] = P.window[2 * bb + 120]; wn[3] = P.window[2 * bb + 121];
+    for (int s = wave; s <= TF; s += 4) {
+      const int j = j0 - 1 + s;
+      float* mrow = mags + (size_t)s * MS;
+      if (j < 0 || j >= j1) {  // outside the stream (or the tile's tail): zero spectrum
+        for (int k = lane; k < 240; k += SPX_WAVE) mrow[k] = 0.0f;
+        continue;
+      }
+      const short* fr = smono + (size_t)(j - jfirst) * B;  // this frame's 240 mono samples
+      // stage 1 (radix 4, s = 1) on packed points z[n] = v[2n] + i v[2n+1]; v = windowed pre-emphasised samples,
+      // z[n] = 0 for n >= 120: butterfly b takes z[b], z[b+60], 0, 0 and writes points 4b .. 4b+3
+      if (on60) {
+        const int i0 = 2 * b, i1 = 2 * b + 120;
+        const int m0 = fr[i0], m1 = fr[i0 + 1], m2 = fr[i1], m3 = fr[i1 + 1];
+        const int mp0 = (i0 > 0) ? (int)fr[i0 - 1] : ((j > 0) ? (int)fr[(240 - B) - 1] : 0);
+        const int mp2 = fr[i1 - 1];
+        const float x0 = (float)(m0 / 32768.0), x1 = (float)(m1 / 32768.0), x2 = (float)(m2 / 32768.0),
+                    x3 = (float)(m3 / 32768.0), xp0 = (float)(mp0 / 32768.0), xp2 = (float)(mp2 / 32768.0);
+        const float y0 = (float)(1.0 * (double)x0 - 0.97 * (double)xp0), y1 = (float)(1.0 * (double)x1 - 0.97 * (double)x0);
+        const float y2 = (float)(1.0 * (double)x2 - 0.97 * (double)xp2), y3 = (float)(1.0 * (double)x3 - 0.97 * (double)x2);
+        const cplx a0 = {(double)(y0 * wn[0]), (double)(y1 * wn[1])}, a1 = {(double)(y2 * wn[2]), (double)(y3 * wn[3])};
+        const cplx b0 = {a0.r + a1.r, a0.i + a1.i}, b2 = {a0.r - a1.r, a0.i - a1.i};
+        const cplx b1 = {a0.r + a1.i, a0.i - a1.r}, b3 = {a0.r - a1.i, a0.i + a1.r};
+        st(bufA, 4 * b, b0);
+        st(bufA, 4 * b + 1, cmul_tw(b1, w1[0]));
+        st(bufA, 4 * b + 2, cmul_tw(b2, w1[1]));
+        st(bufA, 4 * b + 3, cmul_tw(b3, w1[2]));
+      }
+      wave_sync();
+      ASTAMP(0);
+      // stage 2 (radix 4, s = 4): bufA -> bufB
+      if (on60) {
+        const cplx a0 = ld(bufA, b), a1 = ld(bufA, b + 60), a2 = ld(bufA, b + 120), a3 = ld(bufA, b + 180);
+        const cplx t0 = {a0.r + a2.r, a0.i + a2.i}, t1 = {a0.r - a2.r, a0.i - a2.i};
+        const cplx t2 = {a1.r + a3.r, a1.i + a3.i}, t3 = {a1.r - a3.r, a1.i - a3.i};
+        const cplx b0 = {t0.r + t2.r, t0.i + t2.i}, b2 = {t0.r - t2.r, t0.i - t2.i};
+        const cplx b1 = {t1.r + t3.i, t1.i - t3.r}, b3 = {t1.r - t3.i, t1.i + t3.r};
+        const int o = (b & 3) + 16 * (b >> 2);
+        st(bufB, o, b0);
+        st(bufB, o + 4, cmul_tw(b1, w2[0]));
+        st(bufB, o + 8, cmul_tw(b2, w2[1]));
+        st(bufB, o + 12, cmul_tw(b3, w2[2]));
+      }
+      wave_sync();
+      // stage 3 (radix 3, s = 16): bufB -> bufA, 80 butterflies
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int b3i = lane + 64 * u;
+        if (b3i < 80) {
+          const cplx a0 = ld(bufB, b3i), a1 = ld(bufB, b3i + 80), a2 = ld(bufB, b3i + 160);
+          const cplx t1 = {a1.r + a2.r, a1.i + a2.i};
+          const cplx t2 = {a0.r - 0.5 * t1.r, a0.i - 0.5 * t1.i};
+          const cplx t3 = {S3_1 * (a1.r - a2.r), S3_1 * (a1.i - a2.i)};
+          const cplx b0 = {a0.r + t1.r, a0.i + t1.i};
+          const cplx b1 = {t2.r + t3.i, t2.i - t3.r}, b2 = {t2.r - t3.i, t2.i + t3.r};
+          const int o = (b3i & 15) + 48 * (b3i >> 4);
+          st(bufA, o, b0);
+          st(bufA, o + 16, cmul_tw(b1, w3[u][0]));
+          st(bufA, o + 32, cmul_tw(b2, w3[u][1]));
+        }
+      }
+      wave_sync();
+      // stage 4 (radix 5, s = 48, last: every twiddle is 1): bufA -> bufB
+      if (on48) {
+        const cplx a0 = ld(bufA, b), a1 = ld(bufA, b + 48), a2 = ld(bufA, b + 96), a3 = ld(bufA, b + 144),
+                   a4 = ld(bufA, b + 192);
+        const cplx t1 = {a1.r + a4.r, a1.i + a4.i}, t2 = {a2.r + a3.r, a2.i + a3.i};
+        const cplx t3 = {a1.r - a4.r, a1.i - a4.i}, t4 = {a2.r - a3.r, a2.i - a3.i};
+        const cplx b0 = {(a0.r + t1.r) + t2.r, (a0.i + t1.i) + t2.i};
+        const cplx m1 = {(a0.r + C5_1 * t1.r) + C5_2 * t2.r, (a0.i + C5_1 * t1.i) + C5_2 * t2.i};
+        const cplx m2 = {(a0.r + C5_2 * t1.r) + C5_1 * t2.r, (a0.i + C5_2 * t1.i) + C5_1 * t2.i};
+        const cplx n1 = {S5_1 * t3.r + S5_2 * t4.r, S5_1 * t3.i + S5_2 * t4.i};
+        const cplx n2 = {S5_2 * t3.r - S5_1 * t4.r, S5_2 * t3.i - S5_1 * t4.i};
+        const cplx b1 = {m1.r + n1.i, m1.i - n1.r}, b4 = {m1.r - n1.i, m1.i + n1.r};
+        const cplx b2 = {m2.r + n2.i, m2.i - n2.r}, b3 = {m2.r - n2.i, m2.i + n2.r};
+        st(bufB, b, b0);
+        st(bufB, b + 48, b1);
+        st(bufB, b + 96, b2);
+        st(bufB, b + 144, b3);
+        st(bufB, b + 192, b4);
+      }
+      wave_sync();
+      ASTAMP(1);
+      // untangle the packed transform:  X[k] = E[k] + e^{-2 pi i k/N} O[k]
+      float* spec_out = taps.spectrogram ? taps.spectrogram + (size_t)(S.frame_off + j) * 480 : nullptr;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = lane + 64 * u;
+        if (k < 240) {
+          const int k2 = (k == 0) ? 0 : 240 - k;
+          const cplx a = ld(bufB, k), c = ld(bufB, k2);
+          const double b_r = c.r, b_i = -c.i;
+          const double er = 0.5 * (a.r + b_r), ei = 0.5 * (a.i + b_i);
+          const double dr = a.r - b_r, di = a.i - b_i;
+          const double o_r = 0.5 * di, o_i = -0.5 * dr;
+          const double2 w = wu[u];
+          const double xr = er + (w.x * o_r - w.y * o_i);
+          const double xi = ei + (w.x * o_i + w.y * o_r);
+          const float mag = (float)__builtin_sqrt(xr * xr + xi * xi);
+          mrow[k] = mag;
+          if (spec_out) {
+            spec_out[k] = mag;
+            if (k > 0) spec_out[480 - k] = mag;
+            else spec_out[240] = (float)__builtin_fabs(a.r - a.i);
+          }
+        }
+      }
+      wave_sync();
+      ASTAMP(2);
+    }
+  } else
   for (int s = wave; s <= TF; s += 4) {
     const int j = j0 - 1 + s;
     float* mrow = mags + (size_t)s * MS;
@@ -567,12 +710,19 @@ void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n
                          hipStream_t st) {
   if (n_tiles <= 0) return;
   const size_t lds = spx_analysis_lds_bytes(P);
-  if (P.tile_frames == SPX_TF_SMALL)
-    hipLaunchKernelGGL(spx_analysis_kernel<SPX_TF_SMALL>, dim3(n_tiles), dim3(SPX_BLOCK), lds, st, P, streams, n_streams, in,
-                       rec, taps, tile_order, tile_flags, (const float*)nullptr, 0);
-  else
-    hipLaunchKernelGGL(spx_analysis_kernel<SPX_TF>, dim3(n_tiles), dim3(SPX_BLOCK), lds, st, P, streams, n_streams, in,
-                       rec, taps, tile_order, tile_flags, (const float*)nullptr, 0);
+  // 16 kHz (W = 240 = 4*4*3*5) has its own instantiation; every other window size takes the plan-driven kernel
+  static const bool generic_only = getenv("SPX_ANALYSIS_GENERIC") != nullptr;  // A/B and tests of the plan-driven path
+  const bool w240 = !generic_only && P.W == 240 && !P.rader && P.nstages == 4 && P.radix[0] == 4 && P.radix[1] == 4 &&
+                    P.radix[2] == 3 && P.radix[3] == 5;
+#define SPX_LAUNCH_ANALYSIS(TFV, WV)                                                                                   \
+  hipLaunchKernelGGL((spx_analysis_kernel<TFV, WV>), dim3(n_tiles), dim3(SPX_BLOCK), lds, st, P, streams, n_streams, in, \
+                     rec, taps, tile_order, tile_flags, (const float*)nullptr, 0)
+  if (P.tile_frames == SPX_TF_SMALL) {
+    if (w240) SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 240); else SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 0);
+  } else {
+    if (w240) SPX_LAUNCH_ANALYSIS(SPX_TF, 240); else SPX_LAUNCH_ANALYSIS(SPX_TF, 0);
+  }
+#undef SPX_LAUNCH_ANALYSIS
 }
 
 void spx_launch_analysis_frames(const SpxPlanDev& P, const SpxStreamDev* streams, int n_tiles, const float* frames,
@@ -581,6 +731,6 @@ void spx_launch_analysis_frames(const SpxPlanDev& P, const SpxStreamDev* streams
   SpxPlanDev Q = P;
   Q.tile_frames = SPX_TF;
   const size_t lds = spx_analysis_lds_bytes(Q);
-  hipLaunchKernelGGL(spx_analysis_kernel<SPX_TF>, dim3(n_tiles), dim3(SPX_BLOCK), lds, st, Q, streams, 1,
+  hipLaunchKernelGGL((spx_analysis_kernel<SPX_TF, 0>), dim3(n_tiles), dim3(SPX_BLOCK), lds, st, Q, streams, 1,
                      (const int16_t*)nullptr, rec, taps, (const int*)nullptr, (int*)nullptr, frames, preemph ? 1 : 2);
 }

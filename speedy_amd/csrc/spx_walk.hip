@@ -930,7 +930,9 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   if (T.nw > 0) c.nw = T.nw;
   // spx_walk_fast_kernel: search waves + output waves, window frames
   c.nwm = 4;
-  c.nwc = (n_streams <= 256) ? 4 : 1;
+  // output waves: 4 while a stream has a CU to itself; none in large batches (2048 streams x 10 s: walk 11.8 -> 9.1 ms per call,
+  // the output work rides on the search waves and four workgroups of four waves share a CU)
+  c.nwc = (n_streams <= 256) ? 4 : 0;
   c.wcap = 4096;
   if (T.nwm > 0) c.nwm = T.nwm;
   if (T.nwc >= 0) c.nwc = T.nwc;

@@ -1,4 +1,5 @@
 """Throughput against the number of streams in one batch call on one GPU (16 kHz mono, 10 s, 3.5x nonlinear)."""
+import ctypes as C
 import os
 import sys
 import time
@@ -21,12 +22,18 @@ for ns in [int(a) for a in sys.argv[1:]] or [64, 128, 256, 512, 1024, 2048]:
     for _ in range(2):
         b.run()
     torch.cuda.synchronize()
+    plan.L.spx_set_timing(1)
     t0 = time.perf_counter()
     reps = 5
     for _ in range(reps):
         b.run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    print("chunks=%d streams=%5d  %.3f ms/call  %.0f Msamples/s" % (chunks, ns, dt * 1e3, ns * n / dt / 1e6))
+    plan.L.spx_set_timing(0)
+    sa, sw, nc = C.c_double(0), C.c_double(0), C.c_int(0)
+    plan.L.spx_timing_collect(C.byref(sa), C.byref(sw), C.byref(nc))
+    k = max(1, nc.value)
+    print("chunks=%d streams=%5d  %.3f ms/call  %.0f Msamples/s   (kernel sums per call: analysis %.2f ms, walk %.2f ms)"
+          % (chunks, ns, dt * 1e3, ns * n / dt / 1e6, sa.value / k, sw.value / k))
     del b
     torch.cuda.empty_cache()
