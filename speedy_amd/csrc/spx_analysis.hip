@@ -42,23 +42,38 @@ extern "C" void spx_debug_astamps(unsigned long long* out, int reset) {
 int spx_analysis_tile_frames() { return SPX_TF; }
 int spx_analysis_small_tile_frames() { return SPX_TF_SMALL; }
 
-static __host__ __device__ inline size_t work_bytes(int W, int tf) {
+#define SPX_CB 24  // W = 240 kernel: |log ratio| terms are handed from the waves that compute them to the wave that sums
+                   // them in blocks of SPX_CB bins (two blocks in flight); row stride SPX_CB + 1 doubles (LDS banks)
+static __host__ __device__ inline size_t work_bytes(int W, int tf, bool w240 = false) {
+  if (w240) {
+    size_t a = (size_t)4 * 2 * W * sizeof(double);             // 4 waves x W complex, stages in place
+    size_t b = (size_t)2 * tf * (SPX_CB + 1) * sizeof(double); // aliased: two blocks of log terms
+    return (a > b ? a : b);
+  }
   size_t a = (size_t)4 * 2 * 2 * W * sizeof(double);         // 4 waves x ping-pong x W complex
   size_t b = (size_t)tf * (W + 1) * sizeof(double);          // aliased: log terms
   return (a > b ? a : b);
 }
+// 16 kHz (W = 240 = 4*4*3*5) has its own instantiation of the kernel; every other window size takes the plan-driven one
+static inline bool plan_is_w240(const SpxPlanDev& P) {
+  static const bool generic_only = getenv("SPX_ANALYSIS_GENERIC") != nullptr;  // A/B and tests of the plan-driven path
+  return !generic_only && P.W == 240 && !P.rader && P.nstages == 4 && P.radix[0] == 4 && P.radix[1] == 4 &&
+         P.radix[2] == 3 && P.radix[3] == 5;
+}
 static __host__ __device__ inline size_t stage_samples(const SpxPlanDev& P, int tf) {
   return (size_t)(tf + 1) * P.B + (P.W - P.B) + 8;  // mono samples of frames j0-1 .. j0+TF-1
 }
-size_t spx_analysis_lds_bytes(const SpxPlanDev& P) {  // for the tile size the plan copy carries (P.tile_frames)
+static size_t analysis_lds_bytes(const SpxPlanDev& P, bool w240) {  // for the tile size the plan copy carries (P.tile_frames)
   const int tf = P.tile_frames > 0 ? P.tile_frames : SPX_TF;
   size_t mags = (size_t)(tf + 1) * (P.W + 1) * sizeof(float);
   size_t small = (size_t)3 * (tf + 1) * sizeof(float);
   size_t stage = (stage_samples(P, tf) * sizeof(short) + 15) & ~(size_t)15;
   // tuning only (fewer workgroups per CU); part of the size so that the co-residency rule sees it; read once per process
   static const size_t pad = [] { const char* e = getenv("SPX_ANALYSIS_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
-  return work_bytes(P.W, tf) + ((mags + 15) & ~(size_t)15) + ((small + 15) & ~(size_t)15) + stage + pad;
+  return work_bytes(P.W, tf, w240) + ((mags + 15) & ~(size_t)15) + ((small + 15) & ~(size_t)15) + stage + pad;
 }
+// what spx_launch_analysis (int16 input) will ask for: the engine's co-residency arithmetic uses this
+size_t spx_analysis_lds_bytes(const SpxPlanDev& P) { return analysis_lds_bytes(P, plan_is_w240(P)); }
 
 __device__ __forceinline__ void wave_sync() {
   // LDS traffic of one wave is serviced in issue order; only the compiler must not reorder across this.
@@ -324,7 +339,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   const int16_t* __restrict__ in = in_base + S.in_off;
 
   double* work = reinterpret_cast<double*>(lds);
-  const size_t wb = work_bytes(W, TF);
+  const size_t wb = work_bytes(W, TF, WCT == 240);
   float* mags = reinterpret_cast<float*>(lds + wb);
   const size_t mags_b = (((size_t)(TF + 1) * (W + 1) * sizeof(float)) + 15) & ~(size_t)15;
   float* fE = reinterpret_cast<float*>(lds + wb + mags_b);
@@ -337,8 +352,8 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   const double* ltw2 = P.tw2;
   short* smono = reinterpret_cast<short*>(lds + wb + mags_b + small_b);    // mono mix of the tile's input span
 
-  double* bufA = work + (size_t)wave * 4 * W;
-  double* bufB = bufA + 2 * W;
+  double* bufA = work + (size_t)wave * (WCT == 240 ? 2 : 4) * W;
+  double* bufB = (WCT == 240) ? bufA : bufA + 2 * W;  // W = 240: one buffer per wave, every stage in place
 
   // ---------------- phase 0: the tile's input span into LDS (all loads in flight) -------------
   const int jfirst = (j0 > 0) ? j0 - 1 : 0;            // first frame whose samples are needed
@@ -369,7 +384,8 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
     // are the zero padding (x + 0 and x - 0 are x); multiplications by the twiddle 1 (output 0 of every butterfly, all
     // of the last stage) are skipped (x*1 - y*(-0) is x).  Same operations in the same order otherwise -- the
     // magnitudes are bit-identical to the generic path and to the oracle (signs of exact zeros aside, which no
-    // magnitude depends on).
+    // magnitude depends on).  The stages work IN PLACE on one buffer per wave: a wave's LDS operations are served in
+    // issue order, so a stage that issues all its loads before its first store needs no second buffer (bufB == bufA).
     const double2* twp = reinterpret_cast<const double2*>(P.tw);
     const double2* tw2p = reinterpret_cast<const double2*>(P.tw2);
     const int b = lane;
@@ -420,6 +436,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       // stage 2 (radix 4, s = 4): bufA -> bufB
       if (on60) {
         const cplx a0 = ld(bufA, b), a1 = ld(bufA, b + 60), a2 = ld(bufA, b + 120), a3 = ld(bufA, b + 180);
+        wave_sync();  // in place: every lane's loads are issued before any store
         const cplx t0 = {a0.r + a2.r, a0.i + a2.i}, t1 = {a0.r - a2.r, a0.i - a2.i};
         const cplx t2 = {a1.r + a3.r, a1.i + a3.i}, t3 = {a1.r - a3.r, a1.i - a3.i};
         const cplx b0 = {t0.r + t2.r, t0.i + t2.i}, b2 = {t0.r - t2.r, t0.i - t2.i};
@@ -431,21 +448,30 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
         st(bufB, o + 12, cmul_tw(b3, w2[2]));
       }
       wave_sync();
-      // stage 3 (radix 3, s = 16): bufB -> bufA, 80 butterflies
+      // stage 3 (radix 3, s = 16), 80 butterflies = two passes: both passes' loads first, then the stores (in place)
+      {
+        cplx q0[2], q1[2], q2[2];
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const int b3i = lane + 64 * u;
-        if (b3i < 80) {
-          const cplx a0 = ld(bufB, b3i), a1 = ld(bufB, b3i + 80), a2 = ld(bufB, b3i + 160);
-          const cplx t1 = {a1.r + a2.r, a1.i + a2.i};
-          const cplx t2 = {a0.r - 0.5 * t1.r, a0.i - 0.5 * t1.i};
-          const cplx t3 = {S3_1 * (a1.r - a2.r), S3_1 * (a1.i - a2.i)};
-          const cplx b0 = {a0.r + t1.r, a0.i + t1.i};
-          const cplx b1 = {t2.r + t3.i, t2.i - t3.r}, b2 = {t2.r - t3.i, t2.i + t3.r};
-          const int o = (b3i & 15) + 48 * (b3i >> 4);
-          st(bufA, o, b0);
-          st(bufA, o + 16, cmul_tw(b1, w3[u][0]));
-          st(bufA, o + 32, cmul_tw(b2, w3[u][1]));
+        for (int u = 0; u < 2; u++) {
+          const int b3i = (lane + 64 * u < 80) ? lane + 64 * u : 0;
+          q0[u] = ld(bufB, b3i); q1[u] = ld(bufB, b3i + 80); q2[u] = ld(bufB, b3i + 160);
+        }
+        wave_sync();  // compiler: no store of this stage above the loads
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int b3i = lane + 64 * u;
+          if (b3i < 80) {
+            const cplx a0 = q0[u], a1 = q1[u], a2 = q2[u];
+            const cplx t1 = {a1.r + a2.r, a1.i + a2.i};
+            const cplx t2 = {a0.r - 0.5 * t1.r, a0.i - 0.5 * t1.i};
+            const cplx t3 = {S3_1 * (a1.r - a2.r), S3_1 * (a1.i - a2.i)};
+            const cplx b0 = {a0.r + t1.r, a0.i + t1.i};
+            const cplx b1 = {t2.r + t3.i, t2.i - t3.r}, b2 = {t2.r - t3.i, t2.i + t3.r};
+            const int o = (b3i & 15) + 48 * (b3i >> 4);
+            st(bufA, o, b0);
+            st(bufA, o + 16, cmul_tw(b1, w3[u][0]));
+            st(bufA, o + 32, cmul_tw(b2, w3[u][1]));
+          }
         }
       }
       wave_sync();
@@ -453,6 +479,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       if (on48) {
         const cplx a0 = ld(bufA, b), a1 = ld(bufA, b + 48), a2 = ld(bufA, b + 96), a3 = ld(bufA, b + 144),
                    a4 = ld(bufA, b + 192);
+        wave_sync();
         const cplx t1 = {a1.r + a4.r, a1.i + a4.i}, t2 = {a2.r + a3.r, a2.i + a3.i};
         const cplx t3 = {a1.r - a4.r, a1.i - a4.i}, t4 = {a2.r - a3.r, a2.i - a3.i};
         const cplx b0 = {(a0.r + t1.r) + t2.r, (a0.i + t1.i) + t2.i};
@@ -638,24 +665,29 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   __syncthreads();
   ASTAMP(5);
 
-  // ---------------- phase 3: gated |log ratio| terms, one lane per (slot, bin) ----------------
-  double* terms = work;  // aliases the DFT buffers, [TF][W+1]
   const int nfr = j1 - j0;
-  for (int idx = tid; idx < nfr * (W - 1); idx += SPX_BLOCK) {
-    const int f = idx / (W - 1);
-    const int i = 1 + (idx - f * (W - 1));
-    const int s = f + 1;
-    const float cur = mags[(size_t)s * MS + i], last = mags[(size_t)(s - 1) * MS + i];
-    const float thr = fThr[s];
+  // gated |log ratio| term of (frame f of the tile, bin i): speedy.c:705-717
+  auto log_term = [&](int f, int i) -> double {
+    const int sl = f + 1;
+    const float cur = mags[(size_t)sl * MS + i], last = mags[(size_t)(sl - 1) * MS + i];
+    const float thr = fThr[sl];
     double term = 0.0;
     if (cur > thr && last > thr) {
       const float eps = 2.2204e-16f;
-      const float nc = cur * fInv[s], nl = last * fInv[s - 1];
+      const float nc = cur * fInv[sl], nl = last * fInv[sl - 1];
       const float ratio = (nc + eps) / (nl + eps);
       term = __builtin_fabs(spx_log((double)ratio));                           // speedy.c:715-717
     }
-    terms[(size_t)f * (W + 1) + i] = term;
-  }
+    return term;
+  };
+  auto write_rec = [&](int f, float lsd) {
+    const float lowthr = (float)(0.04 * (double)1.41421f);                     // speedy.c:682
+    const float e = fE[f + 1];
+    SpxFrameRec r;
+    r.energy = e;
+    r.lsd = (e <= lowthr) ? 0.0f : lsd;
+    rec[S.frame_off + j0 + f] = r;
+  };
   if (taps.normalized) {
     // normalised spectrum of frame j is the one used for tension k = j+1 (speedy.c:673-675)
     for (int idx = tid; idx < nfr * W; idx += SPX_BLOCK) {
@@ -675,6 +707,42 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
         taps.normalized[(size_t)(S.frame_off + j0) * W + i] = mags[i] * fInv[0];
     }
   }
+  if constexpr (WCT == 240) {
+    // ---------------- phases 3 + 4, pipelined: waves 1..3 compute the terms of a block of SPX_CB bins (all frames)
+    // while wave 0 -- one lane per frame, bin order, the float accumulation of speedy.c:715 -- sums the previous block.
+    // Two blocks in flight in the (now free) transform buffers; one workgroup barrier per block. ----------------
+    constexpr int CBS = SPX_CB + 1;
+    double* tblk = work;  // [2][TF][CBS]
+    constexpr int NBLK = (240 - 1 + SPX_CB - 1) / SPX_CB;
+    float lsd = 0.0f;
+    for (int k = 0; k <= NBLK; k++) {
+      if (wave > 0) {
+        if (k < NBLK) {
+          double* tb = tblk + (size_t)(k & 1) * TF * CBS;
+          for (int it = tid - SPX_WAVE; it < nfr * SPX_CB; it += SPX_BLOCK - SPX_WAVE) {
+            const int f = it / SPX_CB, c = it - f * SPX_CB;
+            const int i = 1 + k * SPX_CB + c;
+            if (i < 240) tb[f * CBS + c] = log_term(f, i);
+          }
+        }
+      } else if (k > 0 && tid < nfr) {
+        const double* tb = tblk + (size_t)((k - 1) & 1) * TF * CBS + tid * CBS;
+        const int i0 = 1 + (k - 1) * SPX_CB;
+#pragma unroll 8
+        for (int c = 0; c < SPX_CB; c++)
+          if (i0 + c < 240) lsd = (float)((double)lsd + tb[c]);                // speedy.c:715 (float +=)
+      }
+      __syncthreads();
+    }
+    if (tid < nfr) write_rec(tid, lsd);
+  } else {
+  // ---------------- phase 3: gated |log ratio| terms, one lane per (slot, bin) ----------------
+  double* terms = work;  // aliases the DFT buffers, [TF][W+1]
+  for (int idx = tid; idx < nfr * (W - 1); idx += SPX_BLOCK) {
+    const int f = idx / (W - 1);
+    const int i = 1 + (idx - f * (W - 1));
+    terms[(size_t)f * (W + 1) + i] = log_term(f, i);
+  }
   __syncthreads();
   ASTAMP(6);
 
@@ -683,12 +751,8 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
     const double* trow = terms + (size_t)tid * (W + 1);
     float lsd = 0.0f;
     for (int i = 1; i < W; i++) lsd = (float)((double)lsd + trow[i]);          // speedy.c:715 (float +=)
-    const float lowthr = (float)(0.04 * (double)1.41421f);                     // speedy.c:682
-    const float e = fE[tid + 1];
-    SpxFrameRec r;
-    r.energy = e;
-    r.lsd = (e <= lowthr) ? 0.0f : lsd;
-    rec[S.frame_off + j0 + tid] = r;
+    write_rec(tid, lsd);
+  }
   }
   if (tile_flags) {
     // publish the tile's records to the concurrently running walk kernel (cdna_hip_programming.md Guideline 16):
@@ -710,10 +774,7 @@ void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n
                          hipStream_t st) {
   if (n_tiles <= 0) return;
   const size_t lds = spx_analysis_lds_bytes(P);
-  // 16 kHz (W = 240 = 4*4*3*5) has its own instantiation; every other window size takes the plan-driven kernel
-  static const bool generic_only = getenv("SPX_ANALYSIS_GENERIC") != nullptr;  // A/B and tests of the plan-driven path
-  const bool w240 = !generic_only && P.W == 240 && !P.rader && P.nstages == 4 && P.radix[0] == 4 && P.radix[1] == 4 &&
-                    P.radix[2] == 3 && P.radix[3] == 5;
+  const bool w240 = plan_is_w240(P);
 #define SPX_LAUNCH_ANALYSIS(TFV, WV)                                                                                   \
   hipLaunchKernelGGL((spx_analysis_kernel<TFV, WV>), dim3(n_tiles), dim3(SPX_BLOCK), lds, st, P, streams, n_streams, in, \
                      rec, taps, tile_order, tile_flags, (const float*)nullptr, 0)
@@ -730,7 +791,7 @@ void spx_launch_analysis_frames(const SpxPlanDev& P, const SpxStreamDev* streams
   if (n_tiles <= 0) return;
   SpxPlanDev Q = P;
   Q.tile_frames = SPX_TF;
-  const size_t lds = spx_analysis_lds_bytes(Q);
+  const size_t lds = analysis_lds_bytes(Q, false);  // the plan-driven instantiation
   hipLaunchKernelGGL((spx_analysis_kernel<SPX_TF, 0>), dim3(n_tiles), dim3(SPX_BLOCK), lds, st, Q, streams, 1,
                      (const int16_t*)nullptr, rec, taps, (const int*)nullptr, (int*)nullptr, frames, preemph ? 1 : 2);
 }

@@ -541,7 +541,10 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       if (concurrent) HIPCHK(hipEventRecord(plan->ev_tension, stn));
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, st); }
-      spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, concurrent ? d_ready : nullptr, speedup_only, st);
+      static const bool diag_nowait = getenv("SPX_DIAG_NOWAIT") != nullptr;  // DIAGNOSTIC ONLY: the walk reads the speeds
+      // the previous identical call left in the scratch array instead of waiting for this call's (timing experiments)
+      spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, (concurrent && !diag_nowait) ? d_ready : nullptr,
+                      speedup_only, st);
       if (timed) { (void)hipEventRecord(e1, st); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({e0, e1, 1}); } }
     }
     // the caller's stream is "done" only when the side launches have retired too

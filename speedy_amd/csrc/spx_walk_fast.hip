@@ -35,6 +35,9 @@
 
 #include "spx_walk_common.h"
 
+#ifndef SPX_WALK_PRIO
+#define SPX_WALK_PRIO 3  // the search waves are the latency-critical chain: they issue first where another kernel shares a SIMD
+#endif
 #ifndef SPX_CT_WCAP
 #define SPX_CT_WCAP 4096  // window frames of the rate-specialised kernels
 #endif
@@ -255,8 +258,11 @@ __device__ __forceinline__ int pair_addr(int base, int d2, int e) { return base 
 
 // RATE != 0: the kernel is compiled for that sample rate and a 4096-frame window -- every LDS offset, period limit and
 // divisor an immediate, which frees some thirty scalar registers in the step loop; RATE == 0 takes them from the plan.
+// At most 96 VGPRs: in concurrent mode a SIMD holds two waves of this kernel (a search and an output wave), one of the
+// tension kernel (56 registers) and analysis waves of 128 -- with 96 here two of those fit in the 512-register file,
+// with the 97 the compiler would take by itself only one (and the analysis then runs at a third of its speed: measured).
 template <int NWM, int NWC, int RATE>
-__global__ void __launch_bounds__(64 * (NWM + NWC))
+__global__ void __launch_bounds__(64 * (NWM + NWC)) __attribute__((amdgpu_waves_per_eu(RATE == 16000 ? 5 : 4, RATE == 16000 ? 5 : 8)))
 spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const int16_t* __restrict__ in_base,
                      int16_t* __restrict__ out_base, int64_t* __restrict__ n_out, SpxStreamState* __restrict__ states,
                      const float* scratch_base, const int* speed_ready, int wcap) {
@@ -319,7 +325,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
 
   // ---------------------------------------- search waves: the chain ----------------------------------------
   // the walk is the latency-critical chain: where another kernel shares a SIMD, these waves issue first
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(SPX_WALK_PRIO);
   const int Ttot = S.n_frames, F = P.F;
   const float Rg = S.speed, nl = S.nonlinear;
   const bool linear = nl == 0.0f;
