@@ -29,7 +29,8 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.path.join(_HERE, "liborc.so")
+    # ORC_LIB: another build of the same sources, e.g. oracle/liborc_asan.so (make -C oracle asan-test)
+    path = os.environ.get("ORC_LIB") or os.path.join(_HERE, "liborc.so")
     if not os.path.exists(path):
         build()
     L = C.CDLL(path)
