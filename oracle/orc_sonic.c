@@ -27,6 +27,8 @@ typedef struct {
 
 struct orc_sonic {
   orc_vec in, out;
+  orc_vec pitch;            /* rate != 1: speed-changed samples waiting to be resampled (the dependency's pitchBuffer) */
+  int oldRatePosition, newRatePosition;
   short* down; /* mono / decimated scratch, maxRequired entries */
   void* userData;
   float speed, rate;
@@ -66,7 +68,7 @@ orc_sonicStream orc_sonicIntCreateStream(int sampleRate, int numChannels) {
 }
 void orc_sonicIntDestroyStream(orc_sonicStream s) {
   if (!s) return;
-  free(s->in.d); free(s->out.d); free(s->down); free(s);
+  free(s->in.d); free(s->out.d); free(s->pitch.d); free(s->down); free(s);
 }
 void orc_sonicIntSetUserData(orc_sonicStream s, void* p) { s->userData = p; }
 void* orc_sonicIntGetUserData(orc_sonicStream s) { return s->userData; }
@@ -74,7 +76,11 @@ int orc_sonicIntGetNumChannels(orc_sonicStream s) { return s->numChannels; }
 int orc_sonicIntGetSampleRate(orc_sonicStream s) { return s->sampleRate; }
 void orc_sonicIntSetSpeed(orc_sonicStream s, float speed) { s->speed = speed; }
 float orc_sonicIntGetSpeed(orc_sonicStream s) { return s->speed; }
-void orc_sonicIntSetRate(orc_sonicStream s, float rate) { s->rate = rate; }
+void orc_sonicIntSetRate(orc_sonicStream s, float rate) {
+  s->rate = rate;
+  s->oldRatePosition = 0;
+  s->newRatePosition = 0;
+}
 int orc_sonicIntSamplesAvailable(orc_sonicStream s) { return (int)s->out.n; }
 long orc_sonicIntStepCount(orc_sonicStream s) { return s->steps; }
 void orc_sonicIntSetPeriodLog(orc_sonicStream s, int* log, long capacity) {
@@ -230,14 +236,70 @@ static int change_speed(orc_sonicStream s, float speed) {
   return 1;
 }
 
+/* Rate stage (playback-rate change by resampling), the classic revision of the dependency: everything the speed stage
+ * has just appended to the output is moved to a pitch buffer and re-emitted by LINEAR interpolation at
+ * newSampleRate/oldSampleRate, both halved until they fit 14 bits; the two positions run modulo the (reduced) rates;
+ * one input sample always stays behind (the interpolation needs its right neighbour).  Integer arithmetic, truncating
+ * division.  PARITY UNPINNED like the rest of this file (newer revisions of the dependency interpolate with a windowed
+ * sinc instead); the reference only forwards sonicSetRate (soniclib.c:169-175) and tests nothing about it. */
+static short interpolate(orc_sonicStream s, const short* in, int oldSampleRate, int newSampleRate) {
+  short left = *in, right = in[s->numChannels];
+  int position = s->newRatePosition * oldSampleRate;
+  int leftPosition = s->oldRatePosition * newSampleRate;
+  int rightPosition = (s->oldRatePosition + 1) * newSampleRate;
+  int ratio = rightPosition - position;
+  int width = rightPosition - leftPosition;
+  return (short)((ratio * left + (width - ratio) * right) / width);
+}
+
+static int adjust_rate(orc_sonicStream s, float rate, long originalNumOutput) {
+  int newSampleRate = (int)(s->sampleRate / rate);
+  int oldSampleRate = s->sampleRate;
+  int ch = s->numChannels;
+  long position;
+  while (newSampleRate > (1 << 14) || oldSampleRate > (1 << 14)) { newSampleRate >>= 1; oldSampleRate >>= 1; }
+  if (s->out.n == originalNumOutput) return 1;
+  /* move the new samples to the pitch buffer */
+  long moved = s->out.n - originalNumOutput;
+  if (!vec_reserve(&s->pitch, moved, ch)) return 0;
+  memcpy(s->pitch.d + s->pitch.n * ch, s->out.d + originalNumOutput * ch, sizeof(short) * (size_t)moved * ch);
+  s->pitch.n += moved;
+  s->out.n = originalNumOutput;
+  for (position = 0; position < s->pitch.n - 1; position++) {
+    while ((s->oldRatePosition + 1) * newSampleRate > s->newRatePosition * oldSampleRate) {
+      if (!vec_reserve(&s->out, 1, ch)) return 0;
+      short* out = s->out.d + s->out.n * ch;
+      const short* in = s->pitch.d + position * ch;
+      for (int i = 0; i < ch; i++) out[i] = interpolate(s, in + i, oldSampleRate, newSampleRate);
+      s->newRatePosition++;
+      s->out.n++;
+    }
+    s->oldRatePosition++;
+    if (s->oldRatePosition == oldSampleRate) {
+      s->oldRatePosition = 0;
+      s->newRatePosition = 0;  /* == newSampleRate here, by construction */
+    }
+  }
+  /* remove the consumed pitch samples */
+  if (position > 0) {
+    long rem = s->pitch.n - position;
+    if (rem > 0) memmove(s->pitch.d, s->pitch.d + position * ch, sizeof(short) * (size_t)rem * ch);
+    s->pitch.n = rem;
+  }
+  return 1;
+}
+
 static int process_input(orc_sonicStream s) {
+  long originalNumOutput = s->out.n;
   float speed = s->speed;
+  float rate = s->rate;
   if (speed > 1.00001 || speed < 0.99999) {
     change_speed(s, speed);
   } else {
     if (!copy_to_output(s, s->in.d, (int)s->in.n)) return 0;
     s->in.n = 0;
   }
+  if (rate != 1.0f) return adjust_rate(s, rate, originalNumOutput);
   return 1;
 }
 
@@ -286,7 +348,8 @@ int orc_sonicIntFlushStream(orc_sonicStream s) {
   int maxRequired = s->maxRequired;
   long remaining = s->in.n;
   float speed = s->speed;
-  long expected = s->out.n + (int)((remaining / speed + 0) / 1.0f + 0.5f);
+  float rate = s->rate;
+  long expected = s->out.n + (int)((remaining / speed + s->pitch.n) / rate + 0.5f);
   if (!vec_reserve(&s->in, 2 * maxRequired, s->numChannels)) return 0;
   memset(s->in.d + remaining * s->numChannels, 0, sizeof(short) * 2 * (size_t)maxRequired * s->numChannels);
   s->in.n += 2 * maxRequired;
@@ -294,5 +357,6 @@ int orc_sonicIntFlushStream(orc_sonicStream s) {
   if (s->out.n > expected) s->out.n = expected;
   s->in.n = 0;
   s->remainingInputToCopy = 0;
+  s->pitch.n = 0;
   return 1;
 }

@@ -14,8 +14,9 @@
  * tests of sonic_classic_test.cc / sonic_test.cc (lengths, Teager purity, mono==stereo bit identity),
  * restated in tests/test_oracle_sonic_properties.py.  No golden int16 vectors exist in the reference.
  *
- * Scope: speed != 1 (skip / insert pitch periods), volume = pitch = rate = 1.  sonicIntSetRate is
- * accepted and stored but resampling (the dependency's sinc interpolator) is not restated.
+ * Scope: speed != 1 (skip / insert pitch periods) and rate != 1 (the classic revision's linear-interpolation
+ * resampler behind sonicIntSetRate; newer revisions use a windowed sinc -- unpinned like everything here);
+ * volume = pitch = 1.
  */
 #ifndef ORC_SONIC_H_
 #define ORC_SONIC_H_

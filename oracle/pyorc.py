@@ -71,6 +71,7 @@ def lib():
         "orc_sonicIntDestroyStream": (None, [vp]),
         "orc_sonicIntGetNumChannels": (i, [vp]),
         "orc_sonicIntSetSpeed": (None, [vp, f]),
+        "orc_sonicIntSetRate": (None, [vp, f]),
         "orc_sonicIntWriteShortToStream": (i, [vp, c_short_p, i]),
         "orc_sonicIntWriteFloatToStream": (i, [vp, c_float_p, i]),
         "orc_sonicIntReadShortFromStream": (i, [vp, c_short_p, i]),

@@ -14,9 +14,11 @@
 //
 // Life cycle as in the reference: a stream stays usable after sonicFlushStream (soniclib.c:529-552 only moves the
 // shim's read index to its write index and flushes the TSM stage), the nonlinear factor is re-read on every write
-// (soniclib.c:397), sonicSetSpeed takes effect at once (soniclib.c:177-183).  Deviations are listed in INTEGRATION.md:
-// switching between factor == 0 and factor != 0 inside one stream and sonicSetRate != 1 fail at the next write with a
-// message (speedyHipLastError); they never produce wrong audio.
+// (soniclib.c:397), sonicSetSpeed takes effect at once (soniclib.c:177-183), sonicSetRate is forwarded to the TSM stage
+// (soniclib.c:169-175): from the first write with a rate != 1 on, the TSM stage's output passes through the rate stage
+// (spx_rate.hip) into a second sliding buffer, which is then what the stream delivers.  One deviation:
+// switching between factor == 0 and factor != 0 inside one stream fails at the next write with a message
+// (speedyHipLastError); it never produces wrong audio.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -93,7 +95,13 @@ struct sonicStreamStruct {  // speedyConnectionStruct + the parts of libsonic's 
   spectrogramFunction cbSpectrogram = nullptr, cbNormalized = nullptr;
 
   hipStream_t hs = nullptr;
-  SlideBuf<int16_t> dIn, dOut;      // elements = int16 values (frames * channels)
+  SlideBuf<int16_t> dIn, dOut;      // elements = int16 values (frames * channels); dOut = what the TSM stage produces
+  SlideBuf<int16_t> dFinal;         // rate mode: what the rate stage produces = what the stream delivers
+  SpxRateState* dRate = nullptr;    // device record of the rate stage (directly behind dNOut)
+  bool rateMode = false;            // a write or flush has seen rate != 1: outputs go through the rate stage from then on
+  int64_t finKnown = 0;             // rate mode: final frames produced / TSM frames taken, as of the last synchronisation
+  int64_t finBound = 0;
+  int64_t tsmSeenKnown = 0;
   SlideBuf<SpxFrameRec> dRec;       // elements = analysis frames
   SlideBuf<float> dScr;             // 4 floats per frame
   SlideBuf<float> tTension, tSpeed, tFeatures, tSpec, tNorm;
@@ -169,7 +177,7 @@ sonicStream sonicCreateStream(int sampleRate, int numChannels) {
   (void)hipGetDevice(&s->device);
   s->sampleRate = sampleRate;
   s->channels = numChannels;
-  const size_t small = 256 + sizeof(SpxStreamState) + 64;
+  const size_t small = 256 + sizeof(SpxStreamState) + sizeof(int64_t) + sizeof(SpxRateState) + 64;
   if (hipStreamCreateWithFlags(&s->hs, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&s->evStaged, hipEventDisableTiming) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&s->dSmall), small) != hipSuccess) {
@@ -180,6 +188,7 @@ sonicStream sonicCreateStream(int sampleRate, int numChannels) {
   s->dJob = reinterpret_cast<SpxStreamDev*>(s->dSmall);
   s->dState = reinterpret_cast<SpxStreamState*>(s->dSmall + 256);
   s->dNOut = reinterpret_cast<int64_t*>(s->dSmall + 256 + sizeof(SpxStreamState));  // directly behind the state
+  s->dRate = reinterpret_cast<SpxRateState*>(s->dSmall + 256 + sizeof(SpxStreamState) + sizeof(int64_t));
   return s;
 }
 
@@ -187,7 +196,7 @@ void sonicDestroyStream(sonicStream s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   if (s->hs) (void)hipStreamSynchronize(s->hs);
-  s->dIn.release(s->hs); s->dOut.release(s->hs); s->dRec.release(s->hs); s->dScr.release(s->hs);
+  s->dIn.release(s->hs); s->dOut.release(s->hs); s->dFinal.release(s->hs); s->dRec.release(s->hs); s->dScr.release(s->hs);
   s->tTension.release(s->hs); s->tSpeed.release(s->hs); s->tFeatures.release(s->hs); s->tSpec.release(s->hs);
   s->tNorm.release(s->hs);
   if (s->hs) (void)hipStreamSynchronize(s->hs);
@@ -198,7 +207,14 @@ void sonicDestroyStream(sonicStream s) {
   delete s;
 }
 
-void sonicSetRate(sonicStream s, float rate) { s->rate = rate; }
+// sonicIntSetRate also restarts the two rate positions (the dependency does; a sample waiting in its pitch buffer stays)
+void sonicSetRate(sonicStream s, float rate) {
+  s->rate = rate;
+  if (s->rateMode) {
+    (void)hipSetDevice(s->device);
+    (void)hipMemsetAsync(&s->dRate->old_pos, 0, 2 * sizeof(int32_t), s->hs);
+  }
+}
 void sonicSetSpeed(sonicStream s, float speed) { s->globalSpeed = speed; }
 void sonicEnableNonlinearSpeedup(sonicStream s, float f) { s->nonlinearFactor = f; }
 void sonicSetDurationFeedbackStrength(sonicStream s, float f) { s->feedbackStrength = f; }
@@ -225,9 +241,11 @@ spectrogramFunction getSonicNormalizedSpectrogramCallback(sonicStream s) { retur
 static bool sync_stream(sonicStream s) {
   if (!s->dirty) return true;
   (void)hipSetDevice(s->device);
-  struct { SpxStreamState st; int64_t n; } h;
-  static_assert(sizeof(h) == sizeof(SpxStreamState) + sizeof(int64_t), "state and count are read back in one copy");
-  if (hipMemcpyAsync(&h, s->dState, sizeof(h), hipMemcpyDeviceToHost, s->hs) != hipSuccess ||
+  struct { SpxStreamState st; int64_t n; SpxRateState r; } h;
+  static_assert(sizeof(h) == sizeof(SpxStreamState) + sizeof(int64_t) + sizeof(SpxRateState),
+                "state, count and rate record are read back in one copy");
+  const size_t hbytes = s->rateMode ? sizeof(h) : sizeof(SpxStreamState) + sizeof(int64_t);
+  if (hipMemcpyAsync(&h, s->dState, hbytes, hipMemcpyDeviceToHost, s->hs) != hipSuccess ||
       hipStreamSynchronize(s->hs) != hipSuccess) {
     g_api_err = std::string("stream synchronisation failed: ") + hipGetErrorString(hipGetLastError());
     s->failed = true;
@@ -245,6 +263,13 @@ static bool sync_stream(sonicStream s) {
   }
   s->outKnown = n;
   s->outBound = n;
+  if (s->rateMode) {
+    if (h.r.overflow == 2 && !s->failed) { g_api_err = "a producer kernel never delivered its frames (device-side poll limit reached)"; s->failed = true; }
+    else if (h.r.overflow && !s->failed) { g_api_err = "output capacity exceeded on the device (rate stage)"; s->failed = true; }
+    s->finKnown = h.r.final_n;
+    s->finBound = h.r.final_n;
+    s->tsmSeenKnown = h.r.tsm_seen;
+  }
   s->tsmBase = h.st.w.base;
   s->dirty = false;
   s->writesSinceSync = 0;
@@ -326,7 +351,21 @@ static int launch_job(sonicStream s, bool flush) {
   if (s->outBound < s->outKnown) s->outBound = s->outKnown;
   const int64_t need = std::max(bound, s->outBound);
   s->dOut.filled = s->outBound * C;
-  if (!s->dOut.ensure(s->outRead * C, need * C, s->hs, 1 << 16)) return 0;
+  // rate mode: the TSM output is dead once the rate stage has taken it (one frame stays as its left neighbour's source)
+  const int64_t tsmKeep = s->rateMode ? std::max<int64_t>(0, s->tsmSeenKnown - 1) : s->outRead;
+  if (!s->dOut.ensure(tsmKeep * C, need * C, s->hs, 1 << 16)) return 0;
+  int oldR = s->sampleRate, newR = s->sampleRate;
+  if (s->rateMode) {
+    newR = (int)(s->sampleRate / s->rate);               // the dependency's adjustRate: both halved down to 14 bits
+    while (newR > (1 << 14) || oldR > (1 << 14)) { newR >>= 1; oldR >>= 1; }
+    if (newR < 1) { g_api_err = "sonicSetRate: rate too large for this sample rate"; return 0; }
+    // final frames: what is known plus the most the rate stage can make of the TSM frames it has not taken yet
+    const double per = (s->rate != 1.0f) ? (double)newR / (double)oldR : 1.0;
+    const int64_t fneed = std::max(s->finBound, s->finKnown + (int64_t)((double)(need - s->tsmSeenKnown + 2) * per) + 16);
+    s->dFinal.filled = s->finBound * C;
+    if (!s->dFinal.ensure(s->outRead * C, fneed * C, s->hs, 1 << 16)) return 0;
+    s->finBound = fneed;
+  }
   // ---- frame records: the tension kernel looks back Pp + 1 frames of compressed energy and one record ----
   if (nonlinear) {
     // The kernels index all per-frame arrays (records, scratch, taps) through ONE frame_off, so they slide together:
@@ -358,12 +397,14 @@ static int launch_job(sonicStream s, bool flush) {
   J.out_off = -s->dOut.origin; J.out_cap = (s->dOut.origin + s->dOut.cap) / C;
   J.frame_off = -s->dRec.origin; J.n_frames = (int32_t)T; J.frame_begin = (int32_t)fa;
   J.channels = (int32_t)C;
-  J.flags = (s->started ? 0 : SPX_F_INIT) | (flush ? SPX_F_FLUSH : 0);
+  J.flags = (s->started ? 0 : SPX_F_INIT) | (flush ? SPX_F_FLUSH : 0) | (s->rateMode ? SPX_F_NO_TRUNC : 0);
   J.speed = s->globalSpeed; J.nonlinear = nonlinear ? s->nonlinearFactor : 0.0f; J.feedback = s->feedbackStrength;
   J.tsm_shift = s->tsmShift;
   J.tension_skip = (int32_t)s->tensionSkip;
   // once a stream has run at a speed <= 1 its carried speed may be below 1: stay on the general kernel from then on
   if (!(J.speed > 1.0f && J.nonlinear >= 0.0f && J.nonlinear <= 1.0f)) s->speedupOnly = false;
+  // SPX_F_NO_TRUNC is the general walk kernel's (the mono speed-up kernel is tuned to its register budget)
+  const bool speedupKernel = s->speedupOnly && !s->rateMode;
   J.first_tile = 0;
   if (hipMemcpyAsync(s->dJob, &J, sizeof(J), hipMemcpyHostToDevice, s->hs) != hipSuccess) return 0;
   (void)hipEventRecord(s->evStaged, s->hs);
@@ -380,8 +421,12 @@ static int launch_job(sonicStream s, bool flush) {
     spx_launch_analysis(P, s->dJob, 1, tiles, s->dIn.p, s->dRec.p, td, nullptr, nullptr, s->hs);
   }
   if (nonlinear) spx_launch_tension(P, s->dJob, 1, s->dState, s->dRec.p, s->dScr.p, td, nullptr, nullptr, s->hs);
-  spx_launch_walk(P, s->dJob, 1, (int)C, s->dIn.p, s->dOut.p, s->dNOut, s->dState, s->dScr.p, nullptr, s->speedupOnly,
+  spx_launch_walk(P, s->dJob, 1, (int)C, s->dIn.p, s->dOut.p, s->dNOut, s->dState, s->dScr.p, nullptr, speedupKernel,
                   s->hs);
+  if (s->rateMode)
+    spx_launch_rate(s->dRate, s->dState, s->dNOut, s->dOut.base(), s->dFinal.base(),
+                    (s->dFinal.origin + s->dFinal.cap) / C, (int)C, oldR, newR, s->rate, s->rate == 1.0f ? 1 : 0,
+                    flush ? 1 : 0, s->hs);
   if (hipGetLastError() != hipSuccess) { g_api_err = "kernel launch failed"; s->failed = true; return 0; }
   s->started = true;
   s->dirty = true;
@@ -403,13 +448,36 @@ static int launch_job(sonicStream s, bool flush) {
   return 1;
 }
 
+// First use of a rate != 1: from here on the stream delivers the rate stage's output.  What the TSM stage has produced
+// so far (and the caller has not read yet) becomes the head of the final buffer; the rate stage starts behind it.
+static bool enter_rate_mode(sonicStream s) {
+  if (s->channels > SPX_RATE_MAX_CHANNELS) {
+    g_api_err = "sonicSetRate != 1 supports at most 16 channels";
+    return false;
+  }
+  if (!sync_stream(s)) return false;
+  const int64_t C = s->channels;
+  const int64_t n = s->outKnown - s->outRead;
+  if (!s->dFinal.ensure(s->outRead * C, (s->outKnown + 4096) * C, s->hs, 1 << 16)) return false;
+  if (n > 0 && hipMemcpyAsync(s->dFinal.base() + s->outRead * C, s->dOut.base() + s->outRead * C,
+                              sizeof(int16_t) * (size_t)(n * C), hipMemcpyDeviceToDevice, s->hs) != hipSuccess)
+    return false;
+  SpxRateState* h = reinterpret_cast<SpxRateState*>(staging(s, sizeof(SpxRateState)));
+  if (!h) return false;
+  memset(h, 0, sizeof(*h));
+  h->tsm_seen = s->outKnown;
+  h->final_n = s->outKnown;
+  if (hipMemcpyAsync(s->dRate, h, sizeof(*h), hipMemcpyHostToDevice, s->hs) != hipSuccess) return false;
+  (void)hipEventRecord(s->evStaged, s->hs);
+  s->finKnown = s->finBound = s->tsmSeenKnown = s->outKnown;
+  s->rateMode = true;
+  return true;
+}
+
 static int write_shorts(sonicStream s, const short* in, int sampleCount) {
   if (s->failed) return 0;
   (void)hipSetDevice(s->device);
-  if (s->rate != 1.0f) {
-    g_api_err = "sonicSetRate != 1 is not supported (libsonic's resampler is outside the hot path)";
-    return 0;
-  }
+  if (s->rate != 1.0f && !s->rateMode && !enter_rate_mode(s)) return 0;
   const int want = (s->nonlinearFactor != 0.0f) ? 1 : 0;  // soniclib.c:397
   if (s->mode < 0) s->mode = want;
   if (s->mode != want) {
@@ -463,17 +531,18 @@ int sonicWriteFloatToStream(sonicStream s, const float* in, int sampleCount) {
 
 int sonicSamplesAvailable(sonicStream s) {
   if (!sync_stream(s)) return 0;
-  return (int)(s->outKnown - s->outRead);
+  return (int)((s->rateMode ? s->finKnown : s->outKnown) - s->outRead);
 }
 
 int sonicReadShortFromStream(sonicStream s, short* out, int bufferSize) {
   if (!sync_stream(s)) return 0;
-  int64_t n = s->outKnown - s->outRead;
+  int64_t n = (s->rateMode ? s->finKnown : s->outKnown) - s->outRead;
   if (n <= 0) return 0;
   if (n > bufferSize) n = bufferSize;
   const size_t C = (size_t)s->channels;
   (void)hipSetDevice(s->device);
-  if (hipMemcpyAsync(out, s->dOut.base() + (size_t)s->outRead * C, sizeof(short) * (size_t)n * C, hipMemcpyDeviceToHost,
+  const int16_t* src = s->rateMode ? s->dFinal.base() : s->dOut.base();
+  if (hipMemcpyAsync(out, src + (size_t)s->outRead * C, sizeof(short) * (size_t)n * C, hipMemcpyDeviceToHost,
                      s->hs) != hipSuccess ||
       hipStreamSynchronize(s->hs) != hipSuccess)
     return 0;
@@ -501,7 +570,7 @@ static bool linear_only(sonicStream s, const char* who) {
 sonicStream sonicIntCreateStream(int sampleRate, int numChannels) { return sonicCreateStream(sampleRate, numChannels); }
 void sonicIntDestroyStream(sonicStream s) { sonicDestroyStream(s); }
 void sonicIntSetSpeed(sonicStream s, float speed) { s->globalSpeed = speed; }
-void sonicIntSetRate(sonicStream s, float rate) { s->rate = rate; }
+void sonicIntSetRate(sonicStream s, float rate) { sonicSetRate(s, rate); }
 int sonicIntWriteShortToStream(sonicStream s, const short* in, int n) {
   return linear_only(s, "sonicIntWriteShortToStream") ? write_shorts(s, in, n) : 0;
 }
@@ -518,6 +587,7 @@ int sonicFlushStream(sonicStream s) {
   if (s->failed) return 0;
   (void)hipSetDevice(s->device);
   if (s->mode < 0) s->mode = (s->nonlinearFactor != 0.0f) ? 1 : 0;
+  if (s->rate != 1.0f && !s->rateMode && !enter_rate_mode(s)) return 0;
   if (!staging(s, 0)) return 0;  // the job-table slot
   return launch_job(s, true);    // the stream stays usable: a later write continues behind the flush's padding
 }

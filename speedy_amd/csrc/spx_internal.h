@@ -45,6 +45,8 @@ struct SpxPlanDev {
 #define SPX_F_FLUSH 2  // after the new input: sonicFlushStream (soniclib.c:529-552)
 #define SPX_F_TENSION_RANGE 4  // unit-level API: compute exactly the tension frames [tension_skip, tension_to)
 #define SPX_F_NO_SPEED 8       // unit-level API: no speed / duration pass (speedyComputeSpeedFromTension is its own call)
+#define SPX_F_NO_TRUNC 16      // a rate stage follows (sonicSetRate != 1): the flush does not truncate the TSM output -- the
+                               // dependency truncates the FINAL output there -- and leaves `flush_remaining` in the state record
 struct SpxStreamDev {
   int64_t in_off, n_in, out_off, out_cap;  // n_in = input frames present so far (from the stream start)
   int64_t frame_off;    // index of this stream's analysis frame 0 in the per-frame arrays
@@ -85,8 +87,27 @@ struct SpxStreamState {
   float des_dur;   // speedy.c:171
   float curSpeed;  // speed currently set in the TSM stage
   int handed;      // ring buffers handed to the TSM stage so far (readBufferFrameIndex, soniclib.c:73)
-  int pad[2];
+  int flush_remaining;  // frames the TSM stage held when its last flush began (the rate stage's expected length needs it)
+  int flush_out_mark;   // ... and the frames it had produced by then (events of the same job before the flush included)
 };
+
+// Rate stage (sonicSetRate != 1: the dependency's adjustRate, oracle/orc_sonic.c adjust_rate): the TSM stage's output
+// is the input sequence, one sample always stays behind as the next call's left neighbour.
+#define SPX_RATE_MAX_CHANNELS 16
+struct SpxRateState {
+  int64_t tsm_seen;   // TSM output frames already taken
+  int64_t final_n;    // frames of final output produced so far
+  int32_t old_pos, new_pos;  // oldRatePosition / newRatePosition
+  int32_t has_left;   // a sample is waiting in the pitch buffer
+  int32_t overflow;
+  int16_t left[SPX_RATE_MAX_CHANNELS];
+};
+// One workgroup: takes TSM output frames [tsm_seen, |*tsm_n|) from `tsm` and appends to `fin` -- resampled at new_rate /
+// old_rate (already reduced to 14 bits), or copied when `bypass`.  `flush`: sonicIntFlushStream's truncation to the
+// expected length and emptying of the pitch buffer.
+void spx_launch_rate(SpxRateState* rs, const SpxStreamState* st, const int64_t* tsm_n, const int16_t* tsm, int16_t* fin,
+                     int64_t fin_cap, int channels, int old_rate, int new_rate, float rate, int bypass, int flush,
+                     hipStream_t hs);
 
 // Per-analysis-frame record written by the analysis kernel and consumed by the walk kernel.
 struct SpxFrameRec {

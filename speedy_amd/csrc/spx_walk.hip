@@ -70,6 +70,7 @@ extern "C" void spx_debug_stamps(unsigned long long* out, int reset) {
 #endif
 
 struct WalkCtx {
+  int* flush_rem;     // SPX_F_NO_TRUNC: where the flush leaves {frames the stage held, frames produced so far} (nullptr: truncate as usual)
   const int16_t* in;  // stream input (interleaved)
   int16_t* out;       // stream output
   pos_t out_cap;
@@ -663,6 +664,10 @@ __device__ __forceinline__ void fast_events(const SpxPlanDev& P, WalkCtx& X, Wal
     } else {
       const pos_t remainingS = avail - st.base;
       expected = st.out_n + uni((int)(((float)remainingS / tailSpeed + 0) / 1.0f + 0.5f));
+      if (X.flush_rem) {  // a rate stage follows: it truncates its own output (and needs the count)
+        expected = 0x7fffffff;
+        if (threadIdx.x == 0) { X.flush_rem[0] = (int)remainingS; X.flush_rem[1] = (int)st.out_n; }
+      }
       X.limit = avail;  // everything from here on reads as the flush's zero padding
       lds_sync<NW>();
       X.wbase = -1;     // the window may hold samples past the new limit
@@ -759,6 +764,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   int* sWait = reinterpret_cast<int*>(lds + LY.off_wait);
   // ---------------------------------- TSM stage context ----------------------------------
   WalkCtx X;
+  X.flush_rem = (S.flags & SPX_F_NO_TRUNC) ? &states[blockIdx.x].flush_remaining : nullptr;
   X.in = in_base + S.in_off - S.tsm_shift * S.channels;  // indexed by TSM position (= input frame + flush padding so far)
   X.out = out_base + S.out_off;
   X.out_cap = (pos_t)(S.out_cap > 0x7fffffff ? 0x7fffffff : S.out_cap);
@@ -856,6 +862,10 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
         } else {
           const pos_t remainingS = avail - st.base;
           expected = st.out_n + uni((int)(((float)remainingS / curSpeed + 0) / 1.0f + 0.5f));
+          if (X.flush_rem) {  // a rate stage follows: it truncates its own output (and needs the count)
+            expected = 0x7fffffff;
+            if (threadIdx.x == 0) { X.flush_rem[0] = (int)remainingS; X.flush_rem[1] = (int)st.out_n; }
+          }
           X.limit = avail;  // everything from here on reads as the flush's zero padding
           lds_sync<NW>();
           X.wbase = -1;     // the window may hold samples past the new limit

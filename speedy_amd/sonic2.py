@@ -28,6 +28,9 @@ class SonicStream:
     def set_speed(self, v):
         self.L.sonicSetSpeed(self.h, float(v))
 
+    def set_rate(self, v):
+        self.L.sonicSetRate(self.h, float(v))
+
     def enable_nonlinear(self, v):
         self.L.sonicEnableNonlinearSpeedup(self.h, float(v))
 

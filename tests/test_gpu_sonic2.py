@@ -376,16 +376,85 @@ def test_nonlinear_factor_changes_between_writes(orc):
     s.close()
 
 
+def _rate_streams(orc, x, rate_hz, ch, speed, nl, mm, chunk, plan):
+    """Drive the oracle shim and the HIP API with the same call sequence: `plan` maps a write index to a sonicSetRate
+    value issued before that write; a flush + further writes if plan has key "flush_at".  Returns both outputs and the
+    per-write read counts."""
+    from speedy_amd.sonic2 import SonicStream
+    L = orc.lib()
+    h = L.orc_sonicCreateStream(rate_hz, ch, int(mm))
+    s = SonicStream(rate_hz, ch, mm)
+    for f in (lambda v: L.orc_sonicSetSpeed(h, v), s.set_speed):
+        f(speed)
+    L.orc_sonicEnableNonlinearSpeedup(h, nl)
+    s.enable_nonlinear(nl)
+    L.orc_sonicSetDurationFeedbackStrength(h, 0.0)
+    s.set_feedback(0.0)
+    buf = np.zeros(4 * chunk * ch, np.int16)
+    ro, rg, co, cg = [], [], [], []
+    n = x.size // ch
+    for w, pos in enumerate(range(0, n, chunk)):
+        if w in plan:
+            L.orc_sonicSetRate(h, plan[w])
+            s.set_rate(plan[w])
+        if plan.get("flush_at") == w:
+            L.orc_sonicFlushStream(h)
+            assert s.flush() == 1
+        seg = np.ascontiguousarray(x[pos * ch:(pos + chunk) * ch])
+        L.orc_sonicWriteShortToStream(h, orc.sptr(seg), seg.size // ch)
+        assert s.write_short(seg) == 1
+        got = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), 4 * chunk)
+        co.append(got)
+        ro.append(buf[: got * ch].copy())
+        g = s.read_short(4 * chunk)
+        cg.append(g.size // ch)
+        rg.append(g)
+    L.orc_sonicFlushStream(h)
+    assert s.flush() == 1
+    while True:
+        got = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), 4 * chunk)
+        if got == 0:
+            break
+        ro.append(buf[: got * ch].copy())
+    while True:
+        g = s.read_short(4 * chunk)
+        if g.size == 0:
+            break
+        rg.append(g)
+    L.orc_sonicDestroyStream(h)
+    s.close()
+    return np.concatenate(ro), np.concatenate(rg), co, cg
+
+
+@pytest.mark.parametrize("name,ch,speed,nl,chunk,plan", [
+    ("tapestry.wav", 1, 2.0, 0.0, 1000, {0: 1.25}),              # linear mode, faster playback rate
+    ("tapestry.wav", 1, 1.0, 0.0, 777, {0: 0.8}),                # rate stage alone (speed 1 copies through)
+    ("tapestry.wav", 1, 3.5, 1.0, 1000, {0: 0.5}),               # nonlinear speed-up, an octave down
+    ("tapestry22050.wav", 1, 1.5, 1.0, 500, {0: 2.0}),
+    ("tapestry.wav", 2, 3.0, 1.0, 640, {0: 1.1}),                # stereo
+    ("tapestry.wav", 1, 2.5, 1.0, 1000, {5: 1.3, 20: 1.0, 30: 0.7}),           # set, back to 1, set again mid-stream
+    ("tapestry.wav", 1, 2.0, 0.0, 1000, {0: 1.5, "flush_at": 12}),            # flush in the middle, then more input
+    ("tapestry.wav", 1, 0.7, 0.0, 1000, {3: 1.2}),               # slow-down + rate
+])
+def test_set_rate_matches_the_oracle(orc, name, ch, speed, nl, chunk, plan):
+    """sonicSetRate != 1 (soniclib.c:169-175 forwards it to the TSM dependency): the rate stage after the HIP walk
+    kernel against the oracle's restatement of the dependency's adjustRate -- same bytes, same readable counts after
+    every write (PARITY UNPINNED like the whole TSM stage: the dependency's source is not in the reference tree)."""
+    x, rate_hz, _ = read_wav(name)
+    x = x[: 40 * chunk]
+    if ch == 2:
+        x = np.repeat(x, 2)
+    ro, rg, co, cg = _rate_streams(orc, x, rate_hz, ch, speed, nl, True, chunk, plan)
+    assert co == cg
+    assert np.array_equal(ro, rg)
+    assert ro.size > 0
+
+
 def test_documented_deviations_fail_loudly_not_silently():
-    """sonicSetRate != 1 and switching between factor 0 and a nonzero factor inside one stream are not
-    supported; the next write returns 0 with a message -- no audio is ever produced on a wrong path."""
+    """switching between factor 0 and a nonzero factor inside one stream is not supported; the next
+    write returns 0 with a message -- no audio is ever produced on a wrong path."""
     from speedy_amd.sonic2 import SonicStream
     x = np.zeros(4000, np.int16)
-    s = SonicStream(16000, 1, False)
-    s.set_speed(2.0)
-    s.L.sonicSetRate(s.h, 1.5)
-    assert s.write_short(x) == 0 and b"sonicSetRate" in s.L.speedyHipLastError()
-    s.close()
     s = SonicStream(16000, 1, False)
     s.set_speed(2.0)
     assert s.write_short(x) == 1          # linear

@@ -116,3 +116,33 @@ class _OrcStream:
 
 def test_chirp_speed_changes(orc):
     sp.check_chirp_speedup(lambda rate, ch: _OrcStream(orc, rate, ch))
+
+
+@pytest.mark.parametrize("speed,rate", [(1.0, 2.0), (1.0, 0.5), (2.0, 1.25), (1.5, 0.8)])
+def test_rate_stage_scales_length_and_pitch(speed, rate):
+    """The rate stage behind sonicIntSetRate (the dependency's adjustRate, restated in orc_sonic.c): the output is
+    1/(speed*rate) as long and a sinusoid comes out `rate` times higher -- the defining properties of a playback-rate
+    change.  (No reference test exercises sonicSetRate; PARITY UNPINNED.)"""
+    from oracle import pyorc
+    L = pyorc.lib()
+    fs, f0 = 16000, 440.0
+    x = (8000 * np.sin(2 * np.pi * f0 * np.arange(2 * fs) / fs)).astype(np.int16)
+    h = L.orc_sonicIntCreateStream(fs, 1)
+    L.orc_sonicIntSetSpeed(h, speed)
+    L.orc_sonicIntSetRate(h, rate)
+    buf = np.zeros(1 << 17, np.int16)
+    out = []
+    for pos in range(0, x.size, 1000):
+        seg = np.ascontiguousarray(x[pos:pos + 1000])
+        assert L.orc_sonicIntWriteShortToStream(h, pyorc.sptr(seg), seg.size) == 1
+        n = L.orc_sonicIntReadShortFromStream(h, pyorc.sptr(buf), buf.size)
+        out.append(buf[:n].copy())
+    L.orc_sonicIntFlushStream(h)
+    n = L.orc_sonicIntReadShortFromStream(h, pyorc.sptr(buf), buf.size)
+    out.append(buf[:n].copy())
+    L.orc_sonicIntDestroyStream(h)
+    y = np.concatenate(out)
+    assert abs(y.size - x.size / speed / rate) <= 0.01 * x.size / speed / rate + 2
+    spec = np.abs(np.fft.rfft(y * np.hanning(y.size)))
+    peak = np.argmax(spec) * fs / y.size
+    assert abs(peak - f0 * rate) < 0.02 * f0 * rate
