@@ -242,17 +242,34 @@ static void orc_butterfly(const orc_plan* P, int r, const double* ar, const doub
     br[2] = m2r + n2i; bi[2] = m2i - n2r;
     br[3] = m2r - n2i; bi[3] = m2i + n2r;
   } else {
-    /* generic prime radix: b[j] = a[0] + sum_{i>=1} a[i] * w_r^{(i j) mod r}, i ascending */
+    /* odd prime radix r = 2h+1 (DESIGN.md "DFT spec"), conjugate-symmetric pairs: with u_i = a_i + a_{r-i},
+     * v_i = a_i - a_{r-i} (i = 1..h) and w^k = c_k + i s_k the table entry of k = (i j) mod r,
+     *   b_0     = ((a_0 + u_1) + u_2) + ... + u_h
+     *   P_j     = ((a_0 + c u_1) + c u_2) + ...          (c = c_{(i j) mod r}, i ascending)
+     *   Q_j     = (s v_1 + s v_2) + ...                  (s = s_{(i j) mod r})
+     *   b_j     = P_j + i Q_j,   b_{r-j} = P_j - i Q_j    (j = 1..h)
+     * -- a quarter of the multiplications of the plain sum over all r-1 inputs. */
     int step = P->n / r;
-    for (int j = 0; j < r; j++) {
-      double accr = ar[0], acci = ai[0];
-      for (int i = 1; i < r; i++) {
+    int h = (r - 1) / 2;
+    double ur[h + 1], ui[h + 1], vr[h + 1], vi[h + 1];
+    double b0r = ar[0], b0i = ai[0];
+    for (int i = 1; i <= h; i++) {
+      ur[i] = ar[i] + ar[r - i]; ui[i] = ai[i] + ai[r - i];
+      vr[i] = ar[i] - ar[r - i]; vi[i] = ai[i] - ai[r - i];
+      b0r = b0r + ur[i]; b0i = b0i + ui[i];
+    }
+    br[0] = b0r; bi[0] = b0i;
+    for (int j = 1; j <= h; j++) {
+      double pr = ar[0], pi = ai[0], qr = 0.0, qi = 0.0;
+      for (int i = 1; i <= h; i++) {
         int t = ((i * j) % r) * step;
-        double wr = P->tw[2 * t], wi = P->tw[2 * t + 1];
-        accr = accr + (ar[i] * wr - ai[i] * wi);
-        acci = acci + (ar[i] * wi + ai[i] * wr);
+        double c = P->tw[2 * t], sn = P->tw[2 * t + 1];
+        pr = pr + c * ur[i]; pi = pi + c * ui[i];
+        if (i == 1) { qr = sn * vr[i]; qi = sn * vi[i]; }
+        else { qr = qr + sn * vr[i]; qi = qi + sn * vi[i]; }
       }
-      br[j] = accr; bi[j] = acci;
+      br[j] = pr - qi; bi[j] = pi + qr;
+      br[r - j] = pr + qi; bi[r - j] = pi - qr;
     }
   }
 }

@@ -236,46 +236,36 @@ __host__ __device__ void dft_stage(const int W, const double* tw, int r, int s, 
       st_tw(y, o + 4 * s, b4, tw, 4 * tp);
     }
   } else {
-    // generic prime radix: one lane per (butterfly, output) pair, inputs accumulated in ascending order.  The twiddle
-    // index (i*j) mod r advances by j per input (one add and one conditional subtract instead of a modulo), and the
-    // loop runs four inputs at a time so that four twiddle loads are in flight; the sums are formed in the same order.
+    // odd prime radix r = 2h+1, conjugate-symmetric pairs (DESIGN.md "DFT spec"; oracle/orc_speedy.c orc_butterfly):
+    //   u_i = a_i + a_{r-i}, v_i = a_i - a_{r-i};  b_0 = ((a_0 + u_1) + u_2) + ...;
+    //   P_j = ((a_0 + c u_1) + c u_2) + ..., Q_j = (s v_1 + s v_2) + ... with c + i s = w_r^{(i j) mod r};
+    //   b_j = P_j + i Q_j, b_{r-j} = P_j - i Q_j.
+    // One lane per (butterfly, j) with j = 1..h; the lane with j = 1 also produces b_0.  The table index (i j) mod r
+    // advances by j per input (one add and one conditional subtract instead of a modulo).
     const int step = W / r;
-    for (int item = lane; item < W; item += nl) {
-      const int b = item / r, j = item - b * r;
+    const int h = (r - 1) >> 1;
+    for (int item = lane; item < span * h; item += nl) {
+      const int b = item / h, j = item - b * h + 1;
       const int p = (int)(((unsigned)b * inv_s) >> 20), q = b - p * s;
-      cplx acc = ld(x, b);
+      const cplx a0 = ld(x, b);
+      cplx P = a0, Q = {0.0, 0.0}, B0 = a0;
       int t = 0;  // (i*j) mod r
-      int i = 1;
-      for (; i + 3 < r; i += 4) {
-        int t0 = t + j;  t0 -= (t0 >= r) ? r : 0;
-        int t1 = t0 + j; t1 -= (t1 >= r) ? r : 0;
-        int t2 = t1 + j; t2 -= (t2 >= r) ? r : 0;
-        int t3 = t2 + j; t3 -= (t3 >= r) ? r : 0;
-        t = t3;
-        const double2 w0 = *reinterpret_cast<const double2*>(tw + 2 * (t0 * step));
-        const double2 w1 = *reinterpret_cast<const double2*>(tw + 2 * (t1 * step));
-        const double2 w2 = *reinterpret_cast<const double2*>(tw + 2 * (t2 * step));
-        const double2 w3 = *reinterpret_cast<const double2*>(tw + 2 * (t3 * step));
-        const cplx a0 = ld(x, b + i * span), a1 = ld(x, b + (i + 1) * span), a2 = ld(x, b + (i + 2) * span),
-                   a3 = ld(x, b + (i + 3) * span);
-        acc.r = acc.r + (a0.r * w0.x - a0.i * w0.y);
-        acc.i = acc.i + (a0.r * w0.y + a0.i * w0.x);
-        acc.r = acc.r + (a1.r * w1.x - a1.i * w1.y);
-        acc.i = acc.i + (a1.r * w1.y + a1.i * w1.x);
-        acc.r = acc.r + (a2.r * w2.x - a2.i * w2.y);
-        acc.i = acc.i + (a2.r * w2.y + a2.i * w2.x);
-        acc.r = acc.r + (a3.r * w3.x - a3.i * w3.y);
-        acc.i = acc.i + (a3.r * w3.y + a3.i * w3.x);
-      }
-      for (; i < r; i++) {
+      for (int i = 1; i <= h; i++) {
         t += j;
         t -= (t >= r) ? r : 0;
-        const cplx a = ld(x, b + i * span);
+        const cplx ai = ld(x, b + i * span), ar = ld(x, b + (r - i) * span);
+        const cplx u = {ai.r + ar.r, ai.i + ar.i}, v = {ai.r - ar.r, ai.i - ar.i};
         const double2 w = *reinterpret_cast<const double2*>(tw + 2 * (t * step));
-        acc.r = acc.r + (a.r * w.x - a.i * w.y);
-        acc.i = acc.i + (a.r * w.y + a.i * w.x);
+        B0.r = B0.r + u.r; B0.i = B0.i + u.i;
+        P.r = P.r + w.x * u.r; P.i = P.i + w.x * u.i;
+        if (i == 1) { Q.r = w.y * v.r; Q.i = w.y * v.i; }
+        else { Q.r = Q.r + w.y * v.r; Q.i = Q.i + w.y * v.i; }
       }
-      st_tw(y, q + s * (r * p + j), acc, tw, s * p * j);
+      const cplx bj = {P.r - Q.i, P.i + Q.r}, brj = {P.r + Q.i, P.i - Q.r};
+      const int o = q + s * r * p;
+      st_tw(y, o + s * j, bj, tw, s * p * j);
+      st_tw(y, o + s * (r - j), brj, tw, s * p * (r - j));
+      if (j == 1) st_tw(y, o, B0, tw, 0);
     }
   }
   (void)m;

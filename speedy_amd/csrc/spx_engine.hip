@@ -415,6 +415,8 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     d8.tile_frames = spx_analysis_small_tile_frames();
     if (per_stream_lds + 2 * spx_analysis_lds_bytes(d8) <= lds_usable) d.tile_frames = d8.tile_frames;
   }
+  static const bool env_small_tile = getenv("SPX_TILE_SMALL") != nullptr;  // tuning: the 8-frame tile whenever concurrent
+  if (env_small_tile && do_a && do_w) d.tile_frames = spx_analysis_small_tile_frames();
   if (spx_analysis_lds_bytes(d) < lds_per_cu) {
     const size_t lds_closing = lds_per_cu - spx_analysis_lds_bytes(d) + 1;
     const size_t closed = ((size_t)n * per_stream_lds) / lds_closing + ((size_t)n * per_stream_waves) / 29;
