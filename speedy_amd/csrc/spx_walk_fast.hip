@@ -38,6 +38,17 @@
 #ifndef SPX_WALK_PRIO
 #define SPX_WALK_PRIO 3  // the search waves are the latency-critical chain: they issue first where another kernel shares a SIMD
 #endif
+// LDS bank placement of the shifted copies relative to the originals (bytes added between the two): lanes of adjacent lags
+// read alternately from a signal and from its shifted copy, so the copies' bank offset decides the conflicts.
+#ifndef SPX_PAD_MONO
+#define SPX_PAD_MONO 0
+#endif
+#ifndef SPX_PAD_PL
+#define SPX_PAD_PL 0
+#endif
+#ifndef SPX_SPEC_DELAY
+#define SPX_SPEC_DELAY 0
+#endif
 #ifndef SPX_CT_WCAP
 #define SPX_CT_WCAP 4096  // window frames of the rate-specialised kernels
 #endif
@@ -81,7 +92,7 @@ extern "C" void spx_debug_fstamps(unsigned long long* out, int reset) {
 
 // LDS layout (bytes), shared by host and device
 struct FastLds {
-  int off_cmd, off_wait, off_sumC, off_sumR, off_inv, off_mono, off_monoB, off_pl, off_plB, plStrideB, total, wcap;
+  int off_cmd, off_wait, off_sumC, off_sumR, off_sumS, off_inv, off_mono, off_monoB, off_pl, off_plB, plStrideB, total, wcap;
 };
 static __host__ __device__ inline FastLds fast_lds_layout_i(int maxPeriod, int skip_, int wcap) {
   FastLds L;
@@ -91,15 +102,16 @@ static __host__ __device__ inline FastLds fast_lds_layout_i(int maxPeriod, int s
   L.off_wait = o; o += 16;
   L.off_sumC = o; o += 2 * 64 * 4;
   L.off_sumR = o; o += 2 * 64 * 4;
+  L.off_sumS = o; o += 2 * 64 * 4;   // speculative refine sums (SPEC kernels)
   L.off_inv = o; o += ((maxPeriod + 2) * 8 + 15) & ~15;
   const int mb = ((wcap + 8) * 2 + 15) & ~15;
-  L.off_mono = o; o += mb;
+  L.off_mono = o; o += mb + SPX_PAD_MONO;
   L.off_monoB = o; o += mb;
   const int skip = skip_ > 0 ? skip_ : 1;
   const int plStride = ((wcap / skip + 4) + 1) & ~1;  // elements per plane (even)
   L.plStrideB = plStride * 2;
   const int plb = (plStride * skip * 2 + 15) & ~15;
-  L.off_pl = o; o += plb;
+  L.off_pl = o; o += plb + SPX_PAD_PL;
   L.off_plB = o; o += plb;
   L.total = o;
   return L;
@@ -116,6 +128,14 @@ struct FastOut {
   pos_t out_cap;
   int offA0;
 };
+
+// One LDS word, read again on every call (a spin loop's probe): ds_read_b32 on the word's LDS offset -- the low half of
+// its generic address.  (A volatile C++ load through the generic pointer compiles to a system-coherent FLAT load.)
+__device__ __forceinline__ int lds_probe(const int* p) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+  return __builtin_amdgcn_readfirstlane(v);
+}
 
 __device__ __forceinline__ void fast_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -261,12 +281,17 @@ __device__ __forceinline__ int pair_addr(int base, int d2, int e) { return base 
 // At most 96 VGPRs: in concurrent mode a SIMD holds two waves of this kernel (a search and an output wave), one of the
 // tension kernel (56 registers) and analysis waves of 128 -- with 96 here two of those fit in the 512-register file,
 // with the 97 the compiler would take by itself only one (and the analysis then runs at a third of its speed: measured).
-template <int NWM, int NWC, int RATE>
-__global__ void __launch_bounds__(64 * (NWM + NWC)) __attribute__((amdgpu_waves_per_eu(RATE == 16000 ? 5 : 4, RATE == 16000 ? 5 : 8)))
+// SPEC: the output waves run the refine search of every step SPECULATIVELY, for the window the previous step's coarse
+// winner predicts, while the search waves are still busy with the coarse search; when the prediction holds (the coarse
+// winner repeats in 30-60 % of steps on speech) the step skips its refine phase -- half of its time.  See the protocol
+// comment at the output waves' loop.  Needs as many output waves as search waves (the same dealing of the refine tasks).
+template <int NWM, int NWC, int RATE, int SPEC>
+__global__ void __launch_bounds__(64 * (NWM + NWC)) __attribute__((amdgpu_waves_per_eu((RATE == 16000 && NWC > 0) ? 5 : 4, (RATE == 16000 && NWC > 0) ? 5 : 8)))
 spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const int16_t* __restrict__ in_base,
                      int16_t* __restrict__ out_base, int64_t* __restrict__ n_out, SpxStreamState* __restrict__ states,
                      const float* scratch_base, const int* speed_ready, int wcap) {
   constexpr int NT = 64 * (NWM + NWC);
+  constexpr bool SP = SPEC != 0 && NWC == NWM;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);  // wave-uniform, and the compiler must know it: everything keyed on it stays scalar
@@ -287,18 +312,182 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   X.offA0 = LY.off_mono;
   unsigned* sumC = reinterpret_cast<unsigned*>(lds + LY.off_sumC);
   unsigned* sumR = reinterpret_cast<unsigned*>(lds + LY.off_sumR);
+  unsigned* sumS = reinterpret_cast<unsigned*>(lds + LY.off_sumS);
   int* cmd = reinterpret_cast<int*>(lds + LY.off_cmd);
-  int* sWait = reinterpret_cast<int*>(lds + LY.off_wait);
+  int* sWait = reinterpret_cast<int*>(lds + LY.off_wait);  // [0] polled count, [1] search-wave arrivals, [2] speculation done
   {
     double* invw = reinterpret_cast<double*>(lds + LY.off_inv);
     for (int t = tid; t <= maxP; t += NT) invw[t] = t > 0 ? 65536.0 / (double)t : 0.0;
-    for (int t = tid; t < 128; t += NT) { sumC[t] = 0; sumR[t] = 0; }
+    for (int t = tid; t < 128; t += NT) { sumC[t] = 0; sumR[t] = 0; sumS[t] = 0; }
+    if (tid < 4) sWait[tid] = 0;
+    for (int t = tid; t < 2 * FCMD_INTS; t += NT) cmd[t] = 0;
   }
   __syncthreads();
+  const int dA = LY.off_monoB - 2 - LY.off_mono;         // see pair_addr
+
+  // ---- refine search: the dealing of its tasks to lanes (constants of the lane).  `sid` = index of the thread among
+  // the 64 * NWM threads that run the refine SADs: the search waves, and (SPEC) the output waves with the same dealing ----
+  const int sid = (wave >= NWM) ? tid - 64 * NWM : tid;
+  int nRG;  // ragged refine tasks per lane (uniform)
+  {
+    const int nlMax = 8 * skip + 1;
+    int total = 0;
+    for (int t = 0; t < nlMax; t++) total += (t + 2) >> 1;  // the larger of the two parities
+    nRG = (total + 64 * NWM - 1) / (64 * NWM);
+    if (nRG > FRG) nRG = FRG;
+  }
+  // ---- refine search, the ragged part dealt once.  Lag t of a search (p = lo + t) shares its first lo >> 1 pairs with
+  // every other lag (summed lane = lag, wave = share); what is left is floor((t + (lo & 1)) / 2) whole pairs and, for an
+  // odd p, the lone sample i = p - 1.  That triangle depends on lo only through its parity, so its enumeration over the
+  // lanes of the search waves is a constant: task FRG * par + k of a lane = (lag t, pair r beyond lo >> 1, half?).
+  // rT < 0: no task. ----
+  // One packed word per task and parity: lag t (bits 0-7), pair r (8-15), lone-sample flag (16), task present (17) --
+  // two plain arrays indexed by unrolled constants only, so they stay in registers in both copies of refine_sads.
+  int rP0[FRG], rP1[FRG];
+#pragma unroll
+  for (int par = 0; par < 2; par++) {
+#pragma unroll
+    for (int k = 0; k < FRG; k++) {
+      const int T = k * 64 * NWM + sid;
+      const int nlMax = 8 * skip + 1;
+      int first = 0, ft = -1, fr = 0, half = 0;
+      for (int t = 0; t < nlMax; t++) {
+        const int full = (t + par) >> 1;             // whole pairs beyond lo >> 1
+        const int cnt = full + ((t + par) & 1);      // + the lone sample of an odd lag (lo + t odd <=> t + par odd)
+        if (ft < 0 && T < first + cnt) {
+          ft = t; fr = T - first;
+          half = (fr < full) ? 0 : 1;
+        }
+        first += cnt;
+      }
+      const int w = (ft < 0) ? 0 : ((ft & 0xff) | ((fr & 0xff) << 8) | (half << 16) | (1 << 17));
+      if (par == 0) rP0[k] = w; else rP1[k] = w;
+    }
+  }
+  // ---- refine search, the common rectangle: lane -> (lag myT, chunk myC), constant.  NLAG = 8*skip + 1 lags at most,
+  // NCH = (search lanes) / NLAG chunks (16 kHz: 33 lags x 7 chunks = 231 of 256 lanes; 22.05 kHz: 41 x 6 = 246). ----
+  const int NLAG = 8 * skip + 1;
+  const int NCH = (64 * NWM) / NLAG;
+  const int myT = sid % NLAG, myC = sid / NLAG;
+  const bool myOn = myC < NCH;
+  const int chM = (65536 + NCH - 1) / NCH;  // g / NCH == (g * chM) >> 16 for every group count (checked by spx_walk_fast_supports)
+  FSTAMP_VARS
+  // The SAD phase of a refine search at window offset o over the lags lo..hi: the ragged tasks and the rectangle of the
+  // calling lane, added into sums[lag - lo].  Search waves (every step whose window was not predicted) and, SPEC,
+  // output waves (the predicted window of every step) run the same code on the same dealing.
+  auto refine_sads = [&](int o, int lo, int hi, unsigned* sums) __attribute__((always_inline)) {
+    const int c0 = lo >> 1;  // pairs every lag of this search has
+    const int par = lo & 1;
+    const int nl = hi - lo + 1;
+    // the ragged tasks first: their operands are in flight while the common share is summed
+    unsigned ra[FRG], rb[FRG];
+    int rt[FRG];
+    unsigned rm[FRG];
+#pragma unroll
+    for (int k = 0; k < FRG; k++) {
+      if (k >= nRG) { rt[k] = 0; rm[k] = 0u; ra[k] = 0u; rb[k] = 0u; continue; }
+      const int w = par ? rP1[k] : rP0[k];
+      rt[k] = w & 0xff;
+      const int rr = (w >> 8) & 0xff;
+      rm[k] = (w & (1 << 17)) ? ((w & (1 << 16)) ? 0xffffu : 0xffffffffu) : 0u;
+      if (!(w & (1 << 17)) || rt[k] >= nl) { rt[k] = 0; rm[k] = 0u; }   // no task, or a lag the clamped search does not have
+      const int ea = o + 2 * (c0 + rr);
+      ra[k] = *reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea));
+      rb[k] = *reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea + lo + rt[k]));
+    }
+    FSTAMP(12);
+    // common share: the c0 pairs every lag of the search has form a rectangle of lags x pairs, cut into groups of four
+    // pairs and dealt to ALL search lanes: lane = (lag myT, chunk myC) takes NGL = (c0 / 4) / NCH consecutive groups --
+    // the same count for every lane, so no masks -- plus, for the first chunks, one of the left-over groups and one of
+    // the c0 % 4 left-over pairs (switched off by reading the a operand twice: |a - a| = 0).  One flight of loads.
+    const int G = c0 >> 2, rho = c0 & 3;
+    int NGL = CT ? G / NCH : (G * chM) >> 16;
+    const int LG = G - NCH * NGL;
+    asm volatile("" : "+s"(NGL));  // opaque: keeps the branch conditions below scalar compares of this value
+    const bool tOk = myOn && myT < nl;
+    const int pT = lo + myT;
+    const int ea = o + 8 * myC * NGL;  // first sample of the lane's groups (same parity as o)
+    const unsigned* ap = reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea));
+    const unsigned* bp = reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea + pT));
+    const int xOff = 4 * (NCH * NGL + myC - myC * NGL);   // dwords from the lane's first pair to its left-over group
+    const int pOff = 4 * G + myC - 4 * myC * NGL;         // ... and to its left-over pair
+    const unsigned* apx = ap + xOff;
+    const unsigned* bpx = (myC < LG) ? bp + xOff : apx;
+    const unsigned* app = ap + pOff;
+    const unsigned* bpp = (myC < rho) ? bp + pOff : app;
+    unsigned d = 0u;
+    while (NGL > 3) {  // long periods at the higher rates only
+      d = sad_flight_n<4, false>(ap, bp, 0, d);
+      ap += 16; bp += 16; NGL -= 4;
+    }
+    switch (NGL) {
+      case 0: d = sad_rect<0>(ap, bp, apx, bpx, app, bpp, d); break;
+      case 1: d = sad_rect<1>(ap, bp, apx, bpx, app, bpp, d); break;
+      case 2: d = sad_rect<2>(ap, bp, apx, bpx, app, bpp, d); break;
+      default: d = sad_rect<3>(ap, bp, apx, bpx, app, bpp, d); break;
+    }
+    atomicAdd(&sums[myT], tOk ? d : 0u);
+    FSTAMP(13);
+#pragma unroll
+    for (int k = 0; k < FRG; k++) {
+      if (k < nRG) {
+        const unsigned dr = __builtin_amdgcn_sad_u16(ra[k] & rm[k], rb[k] & rm[k], 0u);
+        atomicAdd(&sums[rt[k]], dr);
+      }
+    }
+    FSTAMP(14);
+  };
 
   if (wave >= NWM) {
     // ------------------------------ output waves: obey commands until FCMD_EXIT ------------------------------
-    if constexpr (NWC > 0) {
+    if constexpr (SP) {
+      // SPEC protocol.  The search waves publish a command into one of two LDS slots (alternating; field 13 = its
+      // sequence number, written by the same store as the rest) and carry on; the output waves POLL for it instead of
+      // sleeping in a barrier, so they can start at once:
+      //   STEP    speculative refine SADs for the predicted window (fields 10..12) into sumS[parity], arrival counter
+      //           sWait[2] += 1 per wave (behind the sums: a wave's LDS operations are served in order); then the
+      //           previous step's cross-fade; then the step's ONE workgroup barrier.  The search waves meanwhile meet
+      //           among themselves on sWait[1] after the coarse SADs, select, and either find the prediction right --
+      //           wait for sWait[2], barrier, read sumS -- or run the refine SADs themselves, barrier, read sumR.
+      //   others  the barrier that follows the command, then as without SPEC.
+      // A slot is rewritten two commands later, i.e. behind a barrier the output waves joined after reading it.
+      int seq = 0, nspec = 0;
+      for (;;) {
+        const int* c = cmd + (seq & 1) * FCMD_INTS;
+        seq++;
+        while (lds_probe(c + 13) != seq) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const int type = uni(c[0]);
+        const int xf_n = uni(c[1]), xf_down = uni(c[2]), xf_period = uni(c[3]), xf_out = uni(c[4]);
+        if (type == FCMD_STEP) {
+          const int so = uni(c[10]), slo = uni(c[11]), shi = uni(c[12]);
+          if (slo >= 0) {
+            const int sg = nspec & 1;
+            nspec++;
+            if (wave == NWM) sumS[(1 - sg) * 64 + lane] = 0;  // the buffer of the speculation before: everyone is past it
+#if SPX_SPEC_DELAY > 0
+            __builtin_amdgcn_s_sleep(SPX_SPEC_DELAY);  // let the search waves' coarse loads through first (LDS is shared)
+#endif
+            refine_sads(so, slo, shi, sumS + sg * 64);
+            if (lane == 0) atomicAdd(reinterpret_cast<unsigned*>(sWait) + 2, 1u);
+          }
+          fast_outputs<64 * NWC>(X, tid - 64 * NWM, xf_n, xf_down, xf_period, xf_out, 0, 0, 0, 0);
+          fast_sync();
+          continue;
+        }
+        fast_sync();  // the barrier that follows every other command
+        const int cp_n = uni(c[5]), cp_src = uni(c[6]), cp_out = uni(c[7]);
+        const pos_t limit = uni(c[8]), nb = uni(c[9]);
+        fast_outputs<64 * NWC>(X, tid - 64 * NWM, xf_n, xf_down, xf_period, xf_out, cp_n, cp_src, cp_out, limit);
+        if (type == FCMD_REFILL) {
+          fast_refill<NT>(X, LY, skip, nb, limit);
+        } else if (type == FCMD_POLL) {
+          fast_sync();            // the polled count is in LDS
+        } else if (type == FCMD_EXIT) {
+          break;
+        }
+      }
+    } else if constexpr (NWC > 0) {
       int seq = 0;
       for (;;) {
         fast_sync();  // the barrier that follows every published command
@@ -334,7 +523,6 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   const bool needResolve = (long)maxP * maxP >= 65536;
   const int need = maxRequired + 2 * skip + 2;           // window frames a step needs from its position on
   const int skipM = (65536 + skip - 1) / skip;           // i / skip == (i * skipM) >> 16 for i < 8192
-  const int dA = LY.off_monoB - 2 - LY.off_mono;         // see pair_addr
   const int dPl = LY.off_plB - 2 - LY.off_pl;
   const double* invTab = reinterpret_cast<const double*>(lds + LY.off_inv);
   const float* scr = scratch_base + (size_t)S.frame_off * 4;  // per frame: ..., speed (written by the tension kernel)
@@ -359,6 +547,9 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   pos_t wbase = -1;              // window covers [wbase, wbase + wcap); -1 = invalid
   int tg = 0;                    // which of the two lag-sum buffers this step adds into (both clear at kernel start)
   int seq = 0;                   // commands published
+  int spO = 0, spLo = -1, spHi = -1;  // SPEC: the refine window handed to the output waves with the step command (set just before)
+  int qPrev = -1;                // SPEC: the previous step's coarse winner = the prediction
+  int stepNo = 0;                // SPEC: steps so far; every step but a stream's first carries a speculation
   int xf_n = 0, xf_down = 0, xf_period = 0;  // cross-fade decided but not yet handed to the output waves
   pos_t xf_out = 0;
 
@@ -398,49 +589,6 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   }
   const double scaleC = 65536.0 / (double)(minC + lane);
   const bool validC = lane < nC;
-  int nRG;  // ragged refine tasks per lane (uniform)
-  {
-    const int nlMax = 8 * skip + 1;
-    int total = 0;
-    for (int t = 0; t < nlMax; t++) total += (t + 2) >> 1;  // the larger of the two parities
-    nRG = (total + 64 * NWM - 1) / (64 * NWM);
-    if (nRG > FRG) nRG = FRG;
-  }
-  // ---- refine search, the ragged part dealt once.  Lag t of a search (p = lo + t) shares its first lo >> 1 pairs with
-  // every other lag (summed lane = lag, wave = share); what is left is floor((t + (lo & 1)) / 2) whole pairs and, for an
-  // odd p, the lone sample i = p - 1.  That triangle depends on lo only through its parity, so its enumeration over the
-  // lanes of the search waves is a constant: task FRG * par + k of a lane = (lag t, pair r beyond lo >> 1, half?).
-  // rT < 0: no task. ----
-  int rT[2][FRG], rR[2][FRG];
-  unsigned rM[2][FRG];
-#pragma unroll
-  for (int par = 0; par < 2; par++) {
-#pragma unroll
-    for (int k = 0; k < FRG; k++) {
-      const int T = k * 64 * NWM + tid;
-      const int nlMax = 8 * skip + 1;
-      int first = 0, ft = -1, fr = 0;
-      unsigned fm = 0u;
-      for (int t = 0; t < nlMax; t++) {
-        const int full = (t + par) >> 1;             // whole pairs beyond lo >> 1
-        const int cnt = full + ((t + par) & 1);      // + the lone sample of an odd lag (lo + t odd <=> t + par odd)
-        if (ft < 0 && T < first + cnt) {
-          ft = t; fr = T - first;
-          fm = (fr < full) ? 0xffffffffu : 0xffffu;
-        }
-        first += cnt;
-      }
-      rT[par][k] = ft; rR[par][k] = fr; rM[par][k] = ft < 0 ? 0u : fm;
-    }
-  }
-  // ---- refine search, the common rectangle: lane -> (lag myT, chunk myC), constant.  NLAG = 8*skip + 1 lags at most,
-  // NCH = (search lanes) / NLAG chunks (16 kHz: 33 lags x 7 chunks = 231 of 256 lanes; 22.05 kHz: 41 x 6 = 246). ----
-  const int NLAG = 8 * skip + 1;
-  const int NCH = (64 * NWM) / NLAG;
-  const int myT = tid % NLAG, myC = tid / NLAG;
-  const bool myOn = myC < NCH;
-  const int chM = (65536 + NCH - 1) / NCH;  // g / NCH == (g * chM) >> 16 for every group count (checked by spx_walk_fast_supports)
-  FSTAMP_VARS
 
   // Hand the pending cross-fade (and, for FCMD_COPY, a plain copy) to the output waves.  Every command is followed by
   // exactly one workgroup barrier before the next command is published, and the two slots alternate, so a slot is
@@ -462,6 +610,12 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
           rec_ = fast_writelane((int)(CP_OUT), 7, rec_);                                                   \
           rec_ = fast_writelane((int)limit, 8, rec_);                                                      \
           rec_ = fast_writelane((int)(NB), 9, rec_);                                                       \
+        }                                                                                                              \
+        if constexpr (SP) {                                                                                            \
+          rec_ = fast_writelane(spO, 10, rec_);                                                            \
+          rec_ = fast_writelane(spLo, 11, rec_);                                                           \
+          rec_ = fast_writelane(spHi, 12, rec_);                                                           \
+          rec_ = fast_writelane(seq + 1, 13, rec_);   /* what the output waves poll for */                 \
         }                                                                                                              \
         cmd[(seq & 1) * FCMD_INTS + lane] = rec_;                                                                      \
       }                                                                                                                \
@@ -486,8 +640,18 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       wbase = nb;
     }
     FSTAMP(2);
-    FAST_PUBLISH(FCMD_STEP, 0, 0, 0, 0);  // the previous step's cross-fade rides on this step's first barrier
     const int o = (int)(pos - wbase);
+    if constexpr (SP) {
+      spO = o;
+      spLo = -1;
+      if (qPrev >= 0 && SPEC != 2) {  // SPEC == 2 (diagnostic): the protocol without speculation
+        const int pp = (minC + qPrev) * skip;
+        spLo = pp - (skip << 2); spHi = pp + (skip << 2);
+        if (spLo < minP) spLo = minP;
+        if (spHi > maxP) spHi = maxP;
+      }
+    }
+    FAST_PUBLISH(FCMD_STEP, 0, 0, 0, 0);  // the previous step's cross-fade rides on this step's command
     // ---- coarse search on the decimated signal: each lane its constant group(s) of pair slots ----
     int bestC;
     {
@@ -514,7 +678,16 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         }
       }
       FSTAMP(3);
-      fast_sync();
+      if constexpr (SP) {
+        // the output waves are busy speculating: the search waves meet among themselves on an LDS counter (a wave's LDS
+        // operations are served in order, so its arrival lands after its lag sums)
+        stepNo++;
+        if (lane == 0) atomicAdd(reinterpret_cast<unsigned*>(sWait) + 1, 1u);
+        const int target = NWM * stepNo;
+        while (lds_probe(sWait + 1) - target < 0) {}
+      } else {
+        fast_sync();
+      }
       FSTAMP(4);
       if (wave == 0) sumC[(1 - tg) * 64 + lane] = 0;  // the buffer the previous step used: everyone is past it
       const unsigned dsum = sumC[tg * 64 + lane];
@@ -532,66 +705,13 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     const double scale = invTab[valid ? p : lo];
     unsigned dsum;
     int nLane, remLane;
+    bool hit = false;
+    if constexpr (SP) {
+      hit = qPrev == bestC && SPEC == 1;  // (SPEC == 3, diagnostic: speculate, never use it)  same coarse winner as the previous step: the output waves have this search's sums
+      qPrev = bestC;
+    }
     {
-      const int c0 = lo >> 1;  // pairs every lag of this search has
-      const int par = lo & 1;
-      const int nl = hi - lo + 1;
-      // the ragged tasks first: their operands are in flight while the common share is summed
-      unsigned ra[FRG], rb[FRG];
-      int rt[FRG];
-      unsigned rm[FRG];
-#pragma unroll
-      for (int k = 0; k < FRG; k++) {
-        if (k >= nRG) { rt[k] = 0; rm[k] = 0u; ra[k] = 0u; rb[k] = 0u; continue; }
-        rt[k] = par ? rT[1][k] : rT[0][k];
-        const int rr = par ? rR[1][k] : rR[0][k];
-        rm[k] = par ? rM[1][k] : rM[0][k];
-        if (rt[k] < 0 || rt[k] >= nl) { rt[k] = 0; rm[k] = 0u; }   // no task, or a lag the clamped search does not have
-        const int ea = o + 2 * (c0 + rr);
-        ra[k] = *reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea));
-        rb[k] = *reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea + lo + rt[k]));
-      }
-      FSTAMP(12);
-      // common share: the c0 pairs every lag of the search has form a rectangle of lags x pairs, cut into groups of four
-      // pairs and dealt to ALL search lanes: lane = (lag myT, chunk myC) takes NGL = (c0 / 4) / NCH consecutive groups --
-      // the same count for every lane, so no masks -- plus, for the first chunks, one of the left-over groups and one of
-      // the c0 % 4 left-over pairs (switched off by reading the a operand twice: |a - a| = 0).  One flight of loads.
-      const int G = c0 >> 2, rho = c0 & 3;
-      int NGL = CT ? G / NCH : (G * chM) >> 16;
-      const int LG = G - NCH * NGL;
-      asm volatile("" : "+s"(NGL));  // opaque: keeps the branch conditions below scalar compares of this value
-      const bool tOk = myOn && myT < nl;
-      const int pT = lo + myT;
-      const int ea = o + 8 * myC * NGL;  // first sample of the lane's groups (same parity as o)
-      const unsigned* ap = reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea));
-      const unsigned* bp = reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea + pT));
-      const int xOff = 4 * (NCH * NGL + myC - myC * NGL);   // dwords from the lane's first pair to its left-over group
-      const int pOff = 4 * G + myC - 4 * myC * NGL;         // ... and to its left-over pair
-      const unsigned* apx = ap + xOff;
-      const unsigned* bpx = (myC < LG) ? bp + xOff : apx;
-      const unsigned* app = ap + pOff;
-      const unsigned* bpp = (myC < rho) ? bp + pOff : app;
-      unsigned d = 0u;
-      while (NGL > 3) {  // long periods at the higher rates only
-        d = sad_flight_n<4, false>(ap, bp, 0, d);
-        ap += 16; bp += 16; NGL -= 4;
-      }
-      switch (NGL) {
-        case 0: d = sad_rect<0>(ap, bp, apx, bpx, app, bpp, d); break;
-        case 1: d = sad_rect<1>(ap, bp, apx, bpx, app, bpp, d); break;
-        case 2: d = sad_rect<2>(ap, bp, apx, bpx, app, bpp, d); break;
-        default: d = sad_rect<3>(ap, bp, apx, bpx, app, bpp, d); break;
-      }
-      atomicAdd(&sumR[tg * 64 + myT], tOk ? d : 0u);
-      FSTAMP(13);
-#pragma unroll
-      for (int k = 0; k < FRG; k++) {
-        if (k < nRG) {
-          const unsigned dr = __builtin_amdgcn_sad_u16(ra[k] & rm[k], rb[k] & rm[k], 0u);
-          atomicAdd(&sumR[tg * 64 + rt[k]], dr);
-        }
-      }
-      FSTAMP(14);
+      if (!hit) refine_sads(o, lo, hi, sumR + tg * 64);
       // what the step will do for each candidate period: exact IEEE divisions, off the chain; lane 63 = previous period
       {
         const int pc = (lane == 63) ? prevPeriod : p;
@@ -600,10 +720,17 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         remLane = ge2 ? 0 : (int)(fp * twom / sm1);
       }
       FSTAMP(6);
-      fast_sync();
+      if constexpr (SP) {
+        if (hit) {  // every output wave has added its share (arrival counter behind its sums, in order)
+          const int target = NWC * (stepNo - 1);  // speculations published so far (all steps but the first)
+          while (lds_probe(sWait + 2) - target < 0) {}
+        }
+      }
+      fast_sync();  // the step's one workgroup barrier: refine sums complete, the output waves done with the command
       FSTAMP(7);
       if (wave == 0) sumR[(1 - tg) * 64 + lane] = 0;
-      dsum = sumR[tg * 64 + lane];
+      if (hit) dsum = sumS[(stepNo & 1) * 64 + lane];  // speculation number stepNo - 1 (from 1) -> buffer (stepNo - 2) & 1
+      else dsum = sumR[tg * 64 + lane];
     }
     tg ^= 1;
     unsigned kmin;
@@ -801,9 +928,10 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
                           const int* speed_ready, int nwm, int nwc, int wcap, hipStream_t st) {
   if (n_streams <= 0) return;
   const FastLds LY = fast_lds_layout(P, wcap);
-#define SPX_LAUNCH_FAST_R(M, C, R)                                                                                        \
-  hipLaunchKernelGGL((spx_walk_fast_kernel<M, C, R>), dim3(n_streams), dim3(64 * (M + C)), LY.total, st, P, streams, in,  \
-                     out, n_out, states, scratch, speed_ready, wcap)
+#define SPX_LAUNCH_FAST_RS(M, C, R, SPECV)                                                                                \
+  hipLaunchKernelGGL((spx_walk_fast_kernel<M, C, R, SPECV>), dim3(n_streams), dim3(64 * (M + C)), LY.total, st, P, streams, \
+                     in, out, n_out, states, scratch, speed_ready, wcap)
+#define SPX_LAUNCH_FAST_R(M, C, R) SPX_LAUNCH_FAST_RS(M, C, R, 0)
   // the two rates of the BASELINE configs get their own specialisation (with the default 4096-frame window)
 #define SPX_LAUNCH_FAST(M, C)                                              \
   do {                                                                     \
@@ -814,6 +942,25 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
 #ifdef SPX_STAMPS
   SPX_LAUNCH_FAST(4, 4);
   return;
+#endif
+#ifdef SPX_WITH_SPEC
+  // Speculative refine searches on the output waves (template parameter SPEC; bit-exact, all parity and fuzz tests pass) --
+  // MEASURED SLOWER and therefore not built by default (make CXXFLAGS=-DSPX_WITH_SPEC to try): walk 2.44 ms against
+  // 2.06; the polling protocol alone costs 6 % (2.18 ms, SPX_WALK_SPEC=2), the speculative SADs another 25 % even when
+  // their result is never used (2.70 ms, SPX_WALK_SPEC=3) -- the second refine search per step competes with the chain
+  // for the CU's one LDS pipe (SQ counters: more than half of its busy cycles are bank conflicts already) -- and a 45 %
+  // hit rate wins back only part of it.  Skipping every refine phase outright (an upper bound, wrong results) runs
+  // in 0.94 ms, so the idea is right about where the time is; it needs a cheaper second search.  DESIGN.md 5.3.
+  static const bool no_spec = getenv("SPX_WALK_NOSPEC") != nullptr;
+  static const int spec_diag = getenv("SPX_WALK_SPEC") ? atoi(getenv("SPX_WALK_SPEC")) : 1;
+  if (nwm == 4 && nwc >= 4 && !no_spec) {
+    if (P.rate == 16000 && wcap == SPX_CT_WCAP && spec_diag == 2) SPX_LAUNCH_FAST_RS(4, 4, 16000, 2);
+    else if (P.rate == 16000 && wcap == SPX_CT_WCAP && spec_diag == 3) SPX_LAUNCH_FAST_RS(4, 4, 16000, 3);
+    else if (P.rate == 16000 && wcap == SPX_CT_WCAP) SPX_LAUNCH_FAST_RS(4, 4, 16000, 1);
+    else if (P.rate == 22050 && wcap == SPX_CT_WCAP) SPX_LAUNCH_FAST_RS(4, 4, 22050, 1);
+    else SPX_LAUNCH_FAST_RS(4, 4, 0, 1);
+    return;
+  }
 #endif
   if (nwm == 8) {
     SPX_LAUNCH_FAST(8, 4);
@@ -827,5 +974,6 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
     else SPX_LAUNCH_FAST(4, 0);
   }
 #undef SPX_LAUNCH_FAST
+#undef SPX_LAUNCH_FAST_RS
 #undef SPX_LAUNCH_FAST_R
 }
