@@ -44,8 +44,8 @@ int spx_analysis_small_tile_frames() { return SPX_TF_SMALL; }
 
 #define SPX_CB 24  // W = 240 kernel: |log ratio| terms are handed from the waves that compute them to the wave that sums
                    // them in blocks of SPX_CB bins (two blocks in flight); row stride SPX_CB + 1 doubles (LDS banks)
-static __host__ __device__ inline size_t work_bytes(int W, int tf, bool w240 = false) {
-  if (w240) {
+static __host__ __device__ inline size_t work_bytes(int W, int tf, bool ct = false) {
+  if (ct) {
     size_t a = (size_t)4 * 2 * W * sizeof(double);             // 4 waves x W complex, stages in place
     size_t b = (size_t)2 * tf * (SPX_CB + 1) * sizeof(double); // aliased: two blocks of log terms
     return (a > b ? a : b);
@@ -54,26 +54,29 @@ static __host__ __device__ inline size_t work_bytes(int W, int tf, bool w240 = f
   size_t b = (size_t)tf * (W + 1) * sizeof(double);          // aliased: log terms
   return (a > b ? a : b);
 }
-// 16 kHz (W = 240 = 4*4*3*5) has its own instantiation of the kernel; every other window size takes the plan-driven one
-static inline bool plan_is_w240(const SpxPlanDev& P) {
+// 16 kHz (W = 240 = 4*4*3*5) and 22.05 kHz (W = 330 = 2*3*5*11) have their own instantiations of the kernel; every
+// other window size takes the plan-driven one.  Returns the compiled-in window size, or 0.
+static inline int plan_ct_window(const SpxPlanDev& P) {
   static const bool generic_only = getenv("SPX_ANALYSIS_GENERIC") != nullptr;  // A/B and tests of the plan-driven path
-  return !generic_only && P.W == 240 && !P.rader && P.nstages == 4 && P.radix[0] == 4 && P.radix[1] == 4 &&
-         P.radix[2] == 3 && P.radix[3] == 5;
+  if (generic_only || P.rader || P.nstages != 4) return 0;
+  if (P.W == 240 && P.radix[0] == 4 && P.radix[1] == 4 && P.radix[2] == 3 && P.radix[3] == 5) return 240;
+  if (P.W == 330 && P.radix[0] == 2 && P.radix[1] == 3 && P.radix[2] == 5 && P.radix[3] == 11) return 330;
+  return 0;
 }
 static __host__ __device__ inline size_t stage_samples(const SpxPlanDev& P, int tf) {
   return (size_t)(tf + 1) * P.B + (P.W - P.B) + 8;  // mono samples of frames j0-1 .. j0+TF-1
 }
-static size_t analysis_lds_bytes(const SpxPlanDev& P, bool w240) {  // for the tile size the plan copy carries (P.tile_frames)
+static size_t analysis_lds_bytes(const SpxPlanDev& P, bool ct) {  // for the tile size the plan copy carries (P.tile_frames)
   const int tf = P.tile_frames > 0 ? P.tile_frames : SPX_TF;
   size_t mags = (size_t)(tf + 1) * (P.W + 1) * sizeof(float);
   size_t small = (size_t)3 * (tf + 1) * sizeof(float);
   size_t stage = (stage_samples(P, tf) * sizeof(short) + 15) & ~(size_t)15;
   // tuning only (fewer workgroups per CU); part of the size so that the co-residency rule sees it; read once per process
   static const size_t pad = [] { const char* e = getenv("SPX_ANALYSIS_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
-  return work_bytes(P.W, tf, w240) + ((mags + 15) & ~(size_t)15) + ((small + 15) & ~(size_t)15) + stage + pad;
+  return work_bytes(P.W, tf, ct) + ((mags + 15) & ~(size_t)15) + ((small + 15) & ~(size_t)15) + stage + pad;
 }
 // what spx_launch_analysis (int16 input) will ask for: the engine's co-residency arithmetic uses this
-size_t spx_analysis_lds_bytes(const SpxPlanDev& P) { return analysis_lds_bytes(P, plan_is_w240(P)); }
+size_t spx_analysis_lds_bytes(const SpxPlanDev& P) { return analysis_lds_bytes(P, plan_ct_window(P) != 0); }
 
 __device__ __forceinline__ void wave_sync() {
   // LDS traffic of one wave is serviced in issue order; only the compiler must not reorder across this.
@@ -329,7 +332,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   const int16_t* __restrict__ in = in_base + S.in_off;
 
   double* work = reinterpret_cast<double*>(lds);
-  const size_t wb = work_bytes(W, TF, WCT == 240);
+  const size_t wb = work_bytes(W, TF, WCT != 0);
   float* mags = reinterpret_cast<float*>(lds + wb);
   const size_t mags_b = (((size_t)(TF + 1) * (W + 1) * sizeof(float)) + 15) & ~(size_t)15;
   float* fE = reinterpret_cast<float*>(lds + wb + mags_b);
@@ -342,8 +345,8 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   const double* ltw2 = P.tw2;
   short* smono = reinterpret_cast<short*>(lds + wb + mags_b + small_b);    // mono mix of the tile's input span
 
-  double* bufA = work + (size_t)wave * (WCT == 240 ? 2 : 4) * W;
-  double* bufB = (WCT == 240) ? bufA : bufA + 2 * W;  // W = 240: one buffer per wave, every stage in place
+  double* bufA = work + (size_t)wave * (WCT != 0 ? 2 : 4) * W;
+  double* bufB = (WCT != 0) ? bufA : bufA + 2 * W;  // compiled-in sizes: one buffer per wave, every stage in place
 
   // ---------------- phase 0: the tile's input span into LDS (all loads in flight) -------------
   const int jfirst = (j0 > 0) ? j0 - 1 : 0;            // first frame whose samples are needed
@@ -508,6 +511,183 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
             spec_out[k] = mag;
             if (k > 0) spec_out[480 - k] = mag;
             else spec_out[240] = (float)__builtin_fabs(a.r - a.i);
+          }
+        }
+      }
+      wave_sync();
+      ASTAMP(2);
+    }
+  } else if constexpr (WCT == 330) {
+    // W = 330 = 2*3*5*11 (22.05 kHz), compiled in like W = 240: constant butterfly indices, the first two stages'
+    // twiddles and the window values in registers, the window pass fused into the first (radix-2) stage whose second
+    // input is the zero padding, unit twiddles skipped, every stage in place on one buffer per wave -- the radix-11 stage
+    // (conjugate-symmetric pairs, DESIGN.md "DFT spec") by one lane per butterfly, which reads its eleven points and
+    // writes the same eleven.  Same operations in the same order as the plan-driven path otherwise.
+    const double2* twp = reinterpret_cast<const double2*>(P.tw);
+    const double2* tw2p = reinterpret_cast<const double2*>(P.tw2);
+    double2 w1[3], w2[2][2];
+    float wn[3][2];
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+      const int b1 = (lane + 64 * u < 165) ? lane + 64 * u : 0;
+      w1[u] = twp[b1];
+      wn[u][0] = P.window[2 * b1]; wn[u][1] = P.window[2 * b1 + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int p2 = (lane + 64 * u < 110) ? ((lane + 64 * u) >> 1) : 0;
+      w2[u][0] = twp[2 * p2];
+      w2[u][1] = twp[4 * p2];
+    }
+    // the ten eleventh roots of unity the last stage multiplies by: wave-uniform, pinned to scalar registers
+    double wc[10], ws[10];
+#pragma unroll
+    for (int k = 1; k <= 10; k++) {
+      const double2 w = twp[k * 30];
+      wc[k - 1] = __longlong_as_double(((long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(w.x) >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)__double_as_longlong(w.x)));
+      ws[k - 1] = __longlong_as_double(((long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(w.y) >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)__double_as_longlong(w.y)));
+    }
+    for (int s = wave; s <= TF; s += 4) {
+      const int j = j0 - 1 + s;
+      float* mrow = mags + (size_t)s * MS;
+      if (j < 0 || j >= j1) {  // outside the stream (or the tile's tail): zero spectrum
+        for (int k = lane; k < 330; k += SPX_WAVE) mrow[k] = 0.0f;
+        continue;
+      }
+      const short* fr = smono + (size_t)(j - jfirst) * B;  // this frame's 330 mono samples
+      // stage 1 (radix 2, s = 1) on packed points z[n] = v[2n] + i v[2n+1], z[n] = 0 for n >= 165: butterfly b takes
+      // z[b] and 0 and writes points 2b (z[b]) and 2b+1 (z[b] times its twiddle)
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int b = lane + 64 * u;
+        if (b < 165) {
+          const int i0 = 2 * b;
+          const int m0 = fr[i0], m1 = fr[i0 + 1];
+          const int mp0 = (i0 > 0) ? (int)fr[i0 - 1] : ((j > 0) ? (int)fr[(330 - B) - 1] : 0);
+          const float x0 = (float)(m0 / 32768.0), x1 = (float)(m1 / 32768.0), xp0 = (float)(mp0 / 32768.0);
+          const float y0 = (float)(1.0 * (double)x0 - 0.97 * (double)xp0), y1 = (float)(1.0 * (double)x1 - 0.97 * (double)x0);
+          const cplx a0 = {(double)(y0 * wn[u][0]), (double)(y1 * wn[u][1])};
+          st(bufA, 2 * b, a0);
+          st(bufA, 2 * b + 1, cmul_tw(a0, w1[u]));
+        }
+      }
+      wave_sync();
+      ASTAMP(0);
+      // stage 2 (radix 3, s = 2), 110 butterflies = two passes: both passes' loads first, then the stores (in place)
+      {
+        cplx q0[2], q1[2], q2[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int b = (lane + 64 * u < 110) ? lane + 64 * u : 0;
+          q0[u] = ld(bufA, b); q1[u] = ld(bufA, b + 110); q2[u] = ld(bufA, b + 220);
+        }
+        wave_sync();
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int b = lane + 64 * u;
+          if (b < 110) {
+            const cplx a0 = q0[u], a1 = q1[u], a2 = q2[u];
+            const cplx t1 = {a1.r + a2.r, a1.i + a2.i};
+            const cplx t2 = {a0.r - 0.5 * t1.r, a0.i - 0.5 * t1.i};
+            const cplx t3 = {S3_1 * (a1.r - a2.r), S3_1 * (a1.i - a2.i)};
+            const cplx b0 = {a0.r + t1.r, a0.i + t1.i};
+            const cplx b1 = {t2.r + t3.i, t2.i - t3.r}, b2 = {t2.r - t3.i, t2.i + t3.r};
+            const int o = (b & 1) + 6 * (b >> 1);
+            st(bufA, o, b0);
+            st(bufA, o + 2, cmul_tw(b1, w2[u][0]));
+            st(bufA, o + 4, cmul_tw(b2, w2[u][1]));
+          }
+        }
+      }
+      wave_sync();
+      // stage 3 (radix 5, s = 6), 66 butterflies = two passes (the second with two lanes), loads first
+      {
+        cplx q[2][5];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int b = (lane + 64 * u < 66) ? lane + 64 * u : 0;
+#pragma unroll
+          for (int i = 0; i < 5; i++) q[u][i] = ld(bufA, b + 66 * i);
+        }
+        wave_sync();
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int b = lane + 64 * u;
+          if (b < 66) {
+            const cplx a0 = q[u][0], a1 = q[u][1], a2 = q[u][2], a3 = q[u][3], a4 = q[u][4];
+            const cplx t1 = {a1.r + a4.r, a1.i + a4.i}, t2 = {a2.r + a3.r, a2.i + a3.i};
+            const cplx t3 = {a1.r - a4.r, a1.i - a4.i}, t4 = {a2.r - a3.r, a2.i - a3.i};
+            const cplx b0 = {(a0.r + t1.r) + t2.r, (a0.i + t1.i) + t2.i};
+            const cplx m1 = {(a0.r + C5_1 * t1.r) + C5_2 * t2.r, (a0.i + C5_1 * t1.i) + C5_2 * t2.i};
+            const cplx m2 = {(a0.r + C5_2 * t1.r) + C5_1 * t2.r, (a0.i + C5_2 * t1.i) + C5_1 * t2.i};
+            const cplx n1 = {S5_1 * t3.r + S5_2 * t4.r, S5_1 * t3.i + S5_2 * t4.i};
+            const cplx n2 = {S5_2 * t3.r - S5_1 * t4.r, S5_2 * t3.i - S5_1 * t4.i};
+            const cplx b1 = {m1.r + n1.i, m1.i - n1.r}, b4 = {m1.r - n1.i, m1.i + n1.r};
+            const cplx b2 = {m2.r + n2.i, m2.i - n2.r}, b3 = {m2.r - n2.i, m2.i + n2.r};
+            const int p = (int)(((unsigned)b * 10923u) >> 16);  // b / 6 for b < 66
+            const int o = (b - 6 * p) + 30 * p, tp = 6 * p;
+            st(bufA, o, b0);
+            st(bufA, o + 6, cmul_tw(b1, twp[tp]));
+            st(bufA, o + 12, cmul_tw(b2, twp[2 * tp]));
+            st(bufA, o + 18, cmul_tw(b3, twp[3 * tp]));
+            st(bufA, o + 24, cmul_tw(b4, twp[4 * tp]));
+          }
+        }
+      }
+      wave_sync();
+      // stage 4 (radix 11, s = 30, last: every twiddle is 1): one lane per butterfly, its eleven points in place
+      if (lane < 30) {
+        cplx a[11];
+#pragma unroll
+        for (int i = 0; i < 11; i++) a[i] = ld(bufA, lane + 30 * i);
+        cplx u5[5], v5[5];
+        cplx B0 = a[0];
+#pragma unroll
+        for (int i = 1; i <= 5; i++) {
+          u5[i - 1] = {a[i].r + a[11 - i].r, a[i].i + a[11 - i].i};
+          v5[i - 1] = {a[i].r - a[11 - i].r, a[i].i - a[11 - i].i};
+          B0.r = B0.r + u5[i - 1].r; B0.i = B0.i + u5[i - 1].i;
+        }
+        st(bufA, lane, B0);
+#pragma unroll
+        for (int jj = 1; jj <= 5; jj++) {
+          cplx Pj = a[0], Qj = {0.0, 0.0};
+#pragma unroll
+          for (int i = 1; i <= 5; i++) {
+            const double wx = wc[(i * jj) % 11 - 1], wy = ws[(i * jj) % 11 - 1];  // (cos, -sin)(2 pi k / 11), k = (i jj) mod 11
+            Pj.r = Pj.r + wx * u5[i - 1].r; Pj.i = Pj.i + wx * u5[i - 1].i;
+            if (i == 1) { Qj.r = wy * v5[0].r; Qj.i = wy * v5[0].i; }
+            else { Qj.r = Qj.r + wy * v5[i - 1].r; Qj.i = Qj.i + wy * v5[i - 1].i; }
+          }
+          st(bufA, lane + 30 * jj, cplx{Pj.r - Qj.i, Pj.i + Qj.r});
+          st(bufA, lane + 30 * (11 - jj), cplx{Pj.r + Qj.i, Pj.i - Qj.r});
+        }
+      }
+      wave_sync();
+      ASTAMP(1);
+      // untangle the packed transform:  X[k] = E[k] + e^{-2 pi i k/N} O[k]
+      float* spec_out = taps.spectrogram ? taps.spectrogram + (size_t)(S.frame_off + j) * 660 : nullptr;
+#pragma unroll
+      for (int u = 0; u < 6; u++) {
+        const int k = lane + 64 * u;
+        if (k < 330) {
+          const int k2 = (k == 0) ? 0 : 330 - k;
+          const cplx a = ld(bufA, k), c = ld(bufA, k2);
+          const double b_r = c.r, b_i = -c.i;
+          const double er = 0.5 * (a.r + b_r), ei = 0.5 * (a.i + b_i);
+          const double dr = a.r - b_r, di = a.i - b_i;
+          const double o_r = 0.5 * di, o_i = -0.5 * dr;
+          const double2 w = tw2p[k];
+          const double xr = er + (w.x * o_r - w.y * o_i);
+          const double xi = ei + (w.x * o_i + w.y * o_r);
+          const float mag = (float)__builtin_sqrt(xr * xr + xi * xi);
+          mrow[k] = mag;
+          if (spec_out) {
+            spec_out[k] = mag;
+            if (k > 0) spec_out[660 - k] = mag;
+            else spec_out[330] = (float)__builtin_fabs(a.r - a.i);
           }
         }
       }
@@ -697,13 +877,13 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
         taps.normalized[(size_t)(S.frame_off + j0) * W + i] = mags[i] * fInv[0];
     }
   }
-  if constexpr (WCT == 240) {
+  if constexpr (WCT != 0) {
     // ---------------- phases 3 + 4, pipelined: waves 1..3 compute the terms of a block of SPX_CB bins (all frames)
     // while wave 0 -- one lane per frame, bin order, the float accumulation of speedy.c:715 -- sums the previous block.
     // Two blocks in flight in the (now free) transform buffers; one workgroup barrier per block. ----------------
     constexpr int CBS = SPX_CB + 1;
     double* tblk = work;  // [2][TF][CBS]
-    constexpr int NBLK = (240 - 1 + SPX_CB - 1) / SPX_CB;
+    constexpr int NBLK = (WCT - 1 + SPX_CB - 1) / SPX_CB;
     float lsd = 0.0f;
     for (int k = 0; k <= NBLK; k++) {
       if (wave > 0) {
@@ -712,7 +892,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
           for (int it = tid - SPX_WAVE; it < nfr * SPX_CB; it += SPX_BLOCK - SPX_WAVE) {
             const int f = it / SPX_CB, c = it - f * SPX_CB;
             const int i = 1 + k * SPX_CB + c;
-            if (i < 240) tb[f * CBS + c] = log_term(f, i);
+            if (i < WCT) tb[f * CBS + c] = log_term(f, i);
           }
         }
       } else if (k > 0 && tid < nfr) {
@@ -720,7 +900,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
         const int i0 = 1 + (k - 1) * SPX_CB;
 #pragma unroll 8
         for (int c = 0; c < SPX_CB; c++)
-          if (i0 + c < 240) lsd = (float)((double)lsd + tb[c]);                // speedy.c:715 (float +=)
+          if (i0 + c < WCT) lsd = (float)((double)lsd + tb[c]);                // speedy.c:715 (float +=)
       }
       __syncthreads();
     }
@@ -764,16 +944,33 @@ void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n
                          hipStream_t st) {
   if (n_tiles <= 0) return;
   const size_t lds = spx_analysis_lds_bytes(P);
-  const bool w240 = plan_is_w240(P);
+  const int ctw = plan_ct_window(P);
 #define SPX_LAUNCH_ANALYSIS(TFV, WV)                                                                                   \
   hipLaunchKernelGGL((spx_analysis_kernel<TFV, WV>), dim3(n_tiles), dim3(SPX_BLOCK), lds, st, P, streams, n_streams, in, \
                      rec, taps, tile_order, tile_flags, (const float*)nullptr, 0)
   if (P.tile_frames == SPX_TF_SMALL) {
-    if (w240) SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 240); else SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 0);
+    if (ctw == 240) SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 240); else if (ctw == 330) SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 330);
+    else SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 0);
   } else {
-    if (w240) SPX_LAUNCH_ANALYSIS(SPX_TF, 240); else SPX_LAUNCH_ANALYSIS(SPX_TF, 0);
+    if (ctw == 240) SPX_LAUNCH_ANALYSIS(SPX_TF, 240); else if (ctw == 330) SPX_LAUNCH_ANALYSIS(SPX_TF, 330);
+    else SPX_LAUNCH_ANALYSIS(SPX_TF, 0);
   }
 #undef SPX_LAUNCH_ANALYSIS
+}
+
+int spx_analysis_vgprs(const SpxPlanDev& P) {
+  const int ctw = plan_ct_window(P);
+  const bool small = P.tile_frames == SPX_TF_SMALL;
+  const void* fn;
+  if (small) fn = ctw == 240 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_SMALL, 240>)
+                : ctw == 330 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_SMALL, 330>)
+                             : reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_SMALL, 0>);
+  else fn = ctw == 240 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF, 240>)
+          : ctw == 330 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF, 330>)
+                       : reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF, 0>);
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, fn) != hipSuccess) return 128;
+  return (a.numRegs + 7) & ~7;
 }
 
 void spx_launch_analysis_frames(const SpxPlanDev& P, const SpxStreamDev* streams, int n_tiles, const float* frames,

@@ -43,6 +43,16 @@ struct spx_plan {
   std::mutex mu;            // one launch sequence at a time per plan: side streams, events and staging are plan-owned
   SpxStage stage[2];
   int stage_next = 0;
+  // Mode trial for batch shapes where the register file admits only ONE analysis wave per SIMD beside the consumers:
+  // whether the concurrent mode pays then depends on how long the walk is (16 kHz stereo: 3.4 ms concurrent, 3.8 in
+  // sequence; 22.05 kHz mono: 3.0-4.6 against 2.3-3.2), so the second call of a shape runs concurrently and the third in
+  // sequence, both bracketed by events on the caller's stream, and later calls take the faster.  Results do not depend on it.
+  struct Trial {
+    long long key = -1;
+    int calls = 0;
+    int choice = -1;  // -1 undecided, 0 sequential, 1 concurrent
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // [mode][begin / end]
+  } trial;
   void* tables = nullptr;  // one device allocation behind dev.tw/tw2/window/taper*
   // time-chunk pipelining of one batch call: the analysis of chunk c+1 runs on `side` while the walk of chunk c
   // runs on the caller's stream
@@ -233,6 +243,7 @@ void spx_plan_destroy(spx_plan_t plan) {
   if (plan->ev_tension) (void)hipEventDestroy(plan->ev_tension);
   if (plan->ev_start) (void)hipEventDestroy(plan->ev_start);
   for (auto& e : plan->ev_chunk) if (e) (void)hipEventDestroy(e);
+  for (auto& e : plan->trial.ev) if (e) (void)hipEventDestroy(e);
   for (auto& g : plan->stage) {
     if (g.done) { (void)hipEventSynchronize(g.done); (void)hipEventDestroy(g.done); }
     if (g.p) (void)hipHostFree(g.p);
@@ -402,7 +413,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   const SpxWalkConfig wcfg = spx_walk_config(d, n, maxC, speedup_only);
   const size_t per_stream_lds = wcfg.lds + spx_tension_lds_bytes();
   const size_t per_stream_waves = (size_t)wcfg.waves + 4;  // walk (spx_launch_walk's choice) + tension
-  bool co_resident = false;
+  bool co_resident = false, doubtful = false;
   // Two tile sizes: the smaller one costs the analysis about a fifth more time (one halo frame per 8 instead of per 16)
   // but a quarter less LDS; it is taken when that is what lets two analysis workgroups sit beside a stream's
   // workgroups, i.e. when it buys the concurrent mode (16 kHz stereo, for instance).
@@ -424,6 +435,40 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     // ... and only worth it when the analysis keeps its throughput beside the consumers: a stream's workgroups and
     // still two analysis workgroups on a CU (measured at 22.05 kHz, where only one fits: 4.1 ms back to back, 5.2 ms concurrent)
     if (per_stream_lds + 2 * spx_analysis_lds_bytes(d) > lds_usable) co_resident = false;
+    // ... and the same for the register file: a SIMD holds ceil(waves / 4) waves of the walk workgroup and one of the
+    // tension workgroup; two analysis waves must fit the rest of its 512 registers per lane.  (16 kHz: 2 x 96 + 56 + 2 x 128
+    // = 504.  22.05 kHz: 2 x 112 + 56 + 2 x 168 does not fit -- one analysis wave per SIMD stretched the analysis from
+    // 1.0 to 2.5-3.2 ms and the walk waited: 3.0-4.6 ms per call against 2.3-3.2 in sequence.)
+    if (co_resident) {
+      const int walk_regs = ((wcfg.waves + 3) / 4) * spx_walk_vgprs(d, n, maxC, speedup_only);
+      if (walk_regs + spx_tension_vgprs() + 2 * spx_analysis_vgprs(d) > 512) {
+        if (walk_regs + spx_tension_vgprs() + spx_analysis_vgprs(d) > 512) co_resident = false;  // not even one
+        else doubtful = true;  // one analysis wave per SIMD: decided by trial (spx_plan::Trial)
+      }
+    }
+  }
+  int trial_slot = -1;  // 0 / 1: this call is the timed trial of the sequential / concurrent mode
+  if (co_resident && doubtful && do_a && do_w && g_concurrent.load() && !env_serial) {
+    spx_plan::Trial& T = plan->trial;
+    const long long key = ((long long)n << 40) ^ ((long long)L.total_frames << 8) ^ (maxC << 1) ^ (speedup_only ? 1 : 0);
+    static const int force = getenv("SPX_TRIAL_FORCE") ? atoi(getenv("SPX_TRIAL_FORCE")) : -1;  // tuning: 0 / 1 = no trial
+    if (T.key != key) { T.key = key; T.calls = 0; T.choice = force; }
+    if (T.choice < 0 && T.calls >= 3 && hipEventQuery(T.ev[1]) == hipSuccess && hipEventQuery(T.ev[3]) == hipSuccess) {
+      float ms_seq = 0, ms_con = 0;
+      if (hipEventElapsedTime(&ms_seq, T.ev[0], T.ev[1]) == hipSuccess &&
+          hipEventElapsedTime(&ms_con, T.ev[2], T.ev[3]) == hipSuccess)
+        T.choice = ms_con < ms_seq ? 1 : 0;
+      static const bool dbg = getenv("SPX_DEBUG_TRIAL") != nullptr;
+      if (dbg) fprintf(stderr, "[spx trial] n=%d maxC=%d: concurrent %.3f ms, in sequence %.3f ms -> %s\n", n, maxC, ms_con,
+                       ms_seq, T.choice ? "concurrent" : "sequence");
+    }
+    (void)hipGetLastError();
+    if (T.choice >= 0) co_resident = T.choice == 1;
+    else if (T.calls == 0) { }                                      // first call of the shape: concurrent, untimed (cold)
+    else if (T.calls == 1) { trial_slot = 1; }                      // second: concurrent, timed
+    else if (T.calls == 2) { trial_slot = 0; co_resident = false; } // third: in sequence, timed
+    else co_resident = false;                                       // timings not in yet: in sequence
+    T.calls++;
   }
   bool want_concurrent = g_concurrent.load() && !env_serial && co_resident && do_a && do_w;
   hipStream_t st = static_cast<hipStream_t>(hs);
@@ -513,6 +558,11 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
                        reinterpret_cast<unsigned*>(d_flags), z_fl, reinterpret_cast<unsigned*>(d_ready), z_rd);
     HIPCHK(hipEventRecord(G.done, st));
   }
+  if (trial_slot >= 0) {  // bracket this call on the caller's stream (spx_plan::Trial)
+    hipEvent_t& e0 = plan->trial.ev[2 * trial_slot];
+    if (!e0) HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventRecord(e0, st));
+  }
   if (sa != st) {
     // the side stream starts after everything already queued on the caller's stream (job tables, cleared flags, and
     // the previous call's walk, which still reads the frame records this call's analysis will overwrite)
@@ -561,6 +611,11 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     HIPCHK(hipEventRecord(guard.last, st));
     guard.last_stream = st;
     guard.valid = true;
+  }
+  if (trial_slot >= 0) {
+    hipEvent_t& e1 = plan->trial.ev[2 * trial_slot + 1];
+    if (!e1) HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e1, st));
   }
   if (timed) { std::lock_guard<std::mutex> g(g_tmu); g_calls_pending++; }
   HIPCHK(hipGetLastError());

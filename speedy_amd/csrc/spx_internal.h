@@ -165,6 +165,11 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
 // n_out value of a stream whose producer kernel never delivered (concurrent mode poll limit): not an overflow
 #define SPX_NOUT_LOST_PRODUCER INT64_MIN
 size_t spx_tension_lds_bytes();
+// VGPRs per lane the hardware allocates to a wave of the kernel that would be launched (hipFuncGetAttributes, rounded up
+// to the allocation granule of 8): the engine's co-residency rule needs them
+int spx_tension_vgprs();
+int spx_analysis_vgprs(const SpxPlanDev& P);
+int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only);
 // speedyComputeSpeedFromTension (speedy.c:768-788) on the stream's state record: *speed_out = requested speed, the
 // duration sums of the record advance.
 void spx_launch_speed_from_tension(SpxStreamState* state, float tension, float Rg, float feedback, float* speed_out,

@@ -963,6 +963,26 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   }
   return c;
 }
+int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap);
+int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only) {
+  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC < 1 ? 1 : maxC, speedup_only);
+  if (cfg.fast_kernel) return spx_walk_fast_vgprs(P, cfg.nwm, cfg.nwc, cfg.wcap);
+  const void* fn;
+#define SPX_FN_W(NWV) (cfg.mode == 1 ? reinterpret_cast<const void*>(spx_walk_kernel<NWV, 1>)   \
+                       : cfg.mode == 2 ? reinterpret_cast<const void*>(spx_walk_kernel<NWV, 2>) \
+                                       : reinterpret_cast<const void*>(spx_walk_kernel<NWV, 0>))
+  switch (cfg.nw) {
+    case 1: fn = SPX_FN_W(1); break;
+    case 2: fn = SPX_FN_W(2); break;
+    case 8: fn = SPX_FN_W(8); break;
+    case 16: fn = SPX_FN_W(16); break;
+    default: fn = SPX_FN_W(4); break;
+  }
+#undef SPX_FN_W
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, fn) != hipSuccess) return 128;
+  return (a.numRegs + 7) & ~7;
+}
 size_t spx_walk_lds_bytes(const SpxPlanDev& P, int maxC, bool speedup_only) {
   return spx_walk_config(P, 256, maxC, speedup_only).lds;
 }

@@ -923,6 +923,21 @@ bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm) {
   return total <= FCG * 64 * nwm && ragged <= FRG * 64 * nwm;
 }
 
+// numRegs of the instantiation spx_launch_walk_fast picks for (nwm, nwc) at this plan's rate
+int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap) {
+  const void* fn = nullptr;
+#define SPX_FN_R(M, C) (P.rate == 16000 && wcap == SPX_CT_WCAP ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 16000, 0>) \
+                        : P.rate == 22050 && wcap == SPX_CT_WCAP ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 22050, 0>) \
+                        : reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 0, 0>))
+  if (nwm == 8) fn = SPX_FN_R(8, 4);
+  else if (nwm == 2) fn = nwc >= 1 ? SPX_FN_R(2, 1) : SPX_FN_R(2, 0);
+  else fn = nwc >= 4 ? SPX_FN_R(4, 4) : nwc >= 2 ? SPX_FN_R(4, 2) : nwc >= 1 ? SPX_FN_R(4, 1) : SPX_FN_R(4, 0);
+#undef SPX_FN_R
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, fn) != hipSuccess) return 128;
+  return (a.numRegs + 7) & ~7;
+}
+
 void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, const int16_t* in,
                           int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
                           const int* speed_ready, int nwm, int nwc, int wcap, hipStream_t st) {

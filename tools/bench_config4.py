@@ -36,10 +36,10 @@ for rate in (16000, 22050):
     batches.append(b)
     frames += n * len(idx)
 ss = [torch.cuda.Stream(), torch.cuda.Stream()] if two_streams else [None, None]
-for _ in range(3):
+for _ in range(4):   # the engine's mode trial needs three calls of a shape
     for b, s in zip(batches, ss):
         b.run(stream=s)
-torch.cuda.synchronize()
+    torch.cuda.synchronize()
 reps = 10
 t0 = time.perf_counter()
 for _ in range(reps):
