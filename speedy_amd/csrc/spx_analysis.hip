@@ -968,9 +968,7 @@ int spx_analysis_vgprs(const SpxPlanDev& P) {
   else fn = ctw == 240 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF, 240>)
           : ctw == 330 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF, 330>)
                        : reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF, 0>);
-  hipFuncAttributes a;
-  if (hipFuncGetAttributes(&a, fn) != hipSuccess) return 128;
-  return (a.numRegs + 7) & ~7;
+  return spx_kernel_vgprs(fn);
 }
 
 void spx_launch_analysis_frames(const SpxPlanDev& P, const SpxStreamDev* streams, int n_tiles, const float* frames,

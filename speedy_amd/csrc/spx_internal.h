@@ -167,6 +167,18 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
 size_t spx_tension_lds_bytes();
 // VGPRs per lane the hardware allocates to a wave of the kernel that would be launched (hipFuncGetAttributes, rounded up
 // to the allocation granule of 8): the engine's co-residency rule needs them
+// (helper: allocated VGPRs of a kernel, cached per function -- the query is not free and the engine asks on every call)
+static inline int spx_kernel_vgprs(const void* fn) {
+  struct Slot { const void* fn; int regs; };
+  static Slot cache[32];
+  static int n_cached = 0;
+  for (int i = 0; i < n_cached; i++) if (cache[i].fn == fn) return cache[i].regs;   // benign race: same value rewritten
+  hipFuncAttributes a;
+  int regs = 128;
+  if (hipFuncGetAttributes(&a, fn) == hipSuccess) regs = (a.numRegs + 7) & ~7;
+  if (n_cached < 32) { cache[n_cached].fn = fn; cache[n_cached].regs = regs; n_cached++; }
+  return regs;
+}
 int spx_tension_vgprs();
 int spx_analysis_vgprs(const SpxPlanDev& P);
 int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only);

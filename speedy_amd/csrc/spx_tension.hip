@@ -287,12 +287,7 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
 
 size_t spx_tension_lds_bytes() { return sizeof(float) * 2 * SPX_CH + 64; }
 int spx_tension_vgprs() {
-  static const int v = [] {
-    hipFuncAttributes a;
-    if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(spx_tension_kernel)) != hipSuccess) return 64;
-    return (a.numRegs + 7) & ~7;
-  }();
-  return v;
+  return spx_kernel_vgprs(reinterpret_cast<const void*>(spx_tension_kernel));
 }
 
 // speedyComputeSpeedFromTension (speedy.c:768-788), one lane, the arithmetic of passes 3 and 4 above for one frame.

@@ -979,9 +979,7 @@ int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_on
     default: fn = SPX_FN_W(4); break;
   }
 #undef SPX_FN_W
-  hipFuncAttributes a;
-  if (hipFuncGetAttributes(&a, fn) != hipSuccess) return 128;
-  return (a.numRegs + 7) & ~7;
+  return spx_kernel_vgprs(fn);
 }
 size_t spx_walk_lds_bytes(const SpxPlanDev& P, int maxC, bool speedup_only) {
   return spx_walk_config(P, 256, maxC, speedup_only).lds;

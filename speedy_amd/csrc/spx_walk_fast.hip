@@ -933,9 +933,7 @@ int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap) {
   else if (nwm == 2) fn = nwc >= 1 ? SPX_FN_R(2, 1) : SPX_FN_R(2, 0);
   else fn = nwc >= 4 ? SPX_FN_R(4, 4) : nwc >= 2 ? SPX_FN_R(4, 2) : nwc >= 1 ? SPX_FN_R(4, 1) : SPX_FN_R(4, 0);
 #undef SPX_FN_R
-  hipFuncAttributes a;
-  if (hipFuncGetAttributes(&a, fn) != hipSuccess) return 128;
-  return (a.numRegs + 7) & ~7;
+  return spx_kernel_vgprs(fn);
 }
 
 void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, const int16_t* in,
