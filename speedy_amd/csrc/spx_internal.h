@@ -161,7 +161,7 @@ size_t spx_walk_fast_lds_bytes(const SpxPlanDev& P, int wcap);
 bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm);
 void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, const int16_t* in,
                           int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
-                          const int* speed_ready, int nwm, int nwc, int wcap, hipStream_t st);
+                          const int* speed_ready, int nwm, int nwc, int wcap, int max_channels, hipStream_t st);
 // n_out value of a stream whose producer kernel never delivered (concurrent mode poll limit): not an overflow
 #define SPX_NOUT_LOST_PRODUCER INT64_MIN
 size_t spx_tension_lds_bytes();

@@ -933,7 +933,7 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   const WalkTuning& T = walk_tuning();
   SpxWalkConfig c;
   c.mode = walk_mode(P, maxC, speedup_only);
-  c.fast_kernel = (c.mode == 1 && !T.old_fast);
+  c.fast_kernel = ((c.mode == 1 || c.mode == 2) && !T.old_fast);  // spx_walk_fast_kernel: mono and (round 2) multi-channel
   // Waves per stream of spx_walk_kernel.  Measured on MI355X, 10 s streams (ms per call; 2 / 4 / 8 waves): 256 streams
   // 3.67 / 3.19 / 2.91 (walk kernel alone), 512: 5.40 / 4.78 / 5.63, 1024: 10.3 / 9.3 / 10.5, 2048: 19.7 / 17.7 / -.
   c.nw = (n_streams <= 256) ? 8 : 4;
@@ -955,6 +955,7 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
     if (c.nwm < 4) c.nwm = 4; else if (c.nwm < 8) c.nwm = 8; else c.fast_kernel = false;
   }
   if (c.fast_kernel) {
+    c.mode = 1;
     c.waves = c.nwm + c.nwc;
     c.lds = spx_walk_fast_lds_bytes(P, c.wcap);
   } else {
@@ -963,10 +964,10 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   }
   return c;
 }
-int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap);
+int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC);
 int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only) {
   const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC < 1 ? 1 : maxC, speedup_only);
-  if (cfg.fast_kernel) return spx_walk_fast_vgprs(P, cfg.nwm, cfg.nwc, cfg.wcap);
+  if (cfg.fast_kernel) return spx_walk_fast_vgprs(P, cfg.nwm, cfg.nwc, cfg.wcap, maxC);
   const void* fn;
 #define SPX_FN_W(NWV) (cfg.mode == 1 ? reinterpret_cast<const void*>(spx_walk_kernel<NWV, 1>)   \
                        : cfg.mode == 2 ? reinterpret_cast<const void*>(spx_walk_kernel<NWV, 2>) \
@@ -993,7 +994,7 @@ void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_str
   const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC, speedup_only);
   if (cfg.fast_kernel) {
     spx_launch_walk_fast(P, streams, n_streams, in, out, n_out, states, scratch, speed_ready, cfg.nwm, cfg.nwc, cfg.wcap,
-                         st);
+                         maxC, st);
     return;
   }
   const int fast = cfg.mode;

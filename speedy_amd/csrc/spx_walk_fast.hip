@@ -122,11 +122,12 @@ static __host__ __device__ inline FastLds fast_lds_layout(const SpxPlanDev& P, i
 
 // What the output side needs to know about the stream.
 struct FastOut {
-  const int16_t* in;
+  const int16_t* in;   // interleaved, indexed by (TSM position) * C + channel
   int16_t* out;
   unsigned char* lds;
   pos_t out_cap;
   int offA0;
+  int C;               // channels of this stream (1 .. 8)
 };
 
 // One LDS word, read again on every call (a spin loop's probe): ds_read_b32 on the word's LDS offset -- the low half of
@@ -150,31 +151,53 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 //     lie in the LDS window.  |numerator| <= 32768*n < 2^31; the quotient is trunc(|num| * (1/n) + 2^-20) in double,
 //     exact: non-integer quotients are at least 1/n >= 2^-11 below the next integer, integer ones land 2^-20 above.
 //   copy: n frames from absolute input position src (straight from HBM, coalesced; beyond `limit` = flush padding = 0).
-template <int NTO>
+template <int NTO, bool MC>
 __device__ __forceinline__ void fast_outputs(const FastOut& X, int t0, int xf_n, int xf_down, int xf_period, pos_t xf_out,
-                                             int cp_n, pos_t cp_src, pos_t cp_out, pos_t limit) {
+                                             int cp_n, pos_t cp_src, pos_t cp_out, pos_t limit, pos_t wbase) {
+  const int C = MC ? X.C : 1;  // MC = false: the mono-only instantiation (no channel arithmetic at all)
   if (xf_n > 0) {
     const double inv = 1.0 / (double)xf_n;
     pos_t room = X.out_cap - xf_out;
     const int nv = room > xf_n ? xf_n : (room < 0 ? 0 : (int)room);
-    int16_t* __restrict__ dst = X.out + (size_t)xf_out;
-    const unsigned short* wd = reinterpret_cast<const unsigned short*>(X.lds + X.offA0) + xf_down;
-    const unsigned short* wu = wd + xf_period;
-    for (int t = t0; t < nv; t += NTO) {
-      const int d = (int)wd[t] - 32768, u = (int)wu[t] - 32768;
-      const int num = d * (xf_n - t) + u * t;
-      const int mag = num < 0 ? -num : num;
-      const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
-      dst[t] = (int16_t)(num < 0 ? -qm : qm);
+    if (C == 1) {
+      int16_t* __restrict__ dst = X.out + (size_t)xf_out;
+      const unsigned short* wd = reinterpret_cast<const unsigned short*>(X.lds + X.offA0) + xf_down;
+      const unsigned short* wu = wd + xf_period;
+      for (int t = t0; t < nv; t += NTO) {
+        const int d = (int)wd[t] - 32768, u = (int)wu[t] - 32768;
+        const int num = d * (xf_n - t) + u * t;
+        const int mag = num < 0 ? -num : num;
+        const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
+        dst[t] = (int16_t)(num < 0 ? -qm : qm);
+      }
+    } else {
+      // several channels: the window holds the channel mean only; the two ramps come from the input itself (these waves
+      // are off the chain, the samples were read moments ago), element e = t*C + c, zeros past `limit`
+      int16_t* __restrict__ dst = X.out + (size_t)xf_out * C;
+      const pos_t ad = wbase + xf_down, au = ad + xf_period;  // absolute first frames of the two ramps
+      const int16_t* __restrict__ rd = X.in + (size_t)ad * C;
+      const int16_t* __restrict__ ru = X.in + (size_t)au * C;
+      const int total = nv * C;
+      const unsigned invC = (0x10000u + (unsigned)C - 1u) / (unsigned)C;  // e / C for e < 8192, C <= 8
+      const int realD = (int)((limit - ad) * C), realU = (int)((limit - au) * C);  // elements of real input (may be <= 0)
+      for (int e = t0; e < total; e += NTO) {
+        const int t = (C == 2) ? (e >> 1) : (int)(((unsigned)e * invC) >> 16);
+        const int d = (e < realD) ? (int)rd[e] : 0, u = (e < realU) ? (int)ru[e] : 0;
+        const int num = d * (xf_n - t) + u * t;
+        const int mag = num < 0 ? -num : num;
+        const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
+        dst[e] = (int16_t)(num < 0 ? -qm : qm);
+      }
     }
   }
   if (cp_n > 0) {
     pos_t room = X.out_cap - cp_out;
     const int nv = room > cp_n ? cp_n : (room < 0 ? 0 : (int)room);
-    int16_t* __restrict__ dst = X.out + (size_t)cp_out;
-    const int16_t* __restrict__ src = X.in + (size_t)cp_src;
-    const pos_t real = limit - cp_src;  // frames of real input from cp_src on (may be <= 0: all padding)
-    for (int t = t0; t < nv; t += NTO) dst[t] = (t < real) ? src[t] : (int16_t)0;
+    int16_t* __restrict__ dst = X.out + (size_t)cp_out * C;
+    const int16_t* __restrict__ src = X.in + (size_t)cp_src * C;
+    const pos_t real = (limit - cp_src) * C;  // elements of real input from cp_src on (may be <= 0: all padding)
+    const int total = nv * C;
+    for (int e = t0; e < total; e += NTO) dst[e] = (e < real) ? src[e] : (int16_t)0;
   }
 }
 
@@ -182,62 +205,101 @@ __device__ __forceinline__ void fast_outputs(const FastOut& X, int t0, int xf_n,
 // plane r (r < skip) holds S[m*skip + r], S[i] = truncated mean of window samples i .. i+skip-1, so the decimated
 // search signal of a step at window offset o is plane (o % skip) from element o / skip on, contiguous.  All NT threads
 // of the workgroup; three LDS barriers.
-template <int NT>
+template <int NT, bool MC>
 __device__ __forceinline__ void fast_refill(const FastOut& X, const FastLds& LY, int skip, pos_t nb, pos_t limit) {
   fast_sync();  // everyone is done reading the old window
   const int wcap = LY.wcap;
+  const int C = MC ? X.C : 1;
   unsigned short* monoH = reinterpret_cast<unsigned short*>(X.lds + LY.off_mono);
   unsigned short* monoHB = reinterpret_cast<unsigned short*>(X.lds + LY.off_monoB);
-  const int16_t* __restrict__ src = X.in + nb;
   const pos_t room = limit - nb;  // frames of real input from nb on
   const int last = (int)(room < wcap + 1 ? room : wcap + 1) - 1;  // last index holding real input
-  for (int k0 = threadIdx.x; k0 < wcap + 1; k0 += 8 * NT) {
-    int v[8];
-    if (last >= 0) {  // uniform
+  const int plStride = LY.plStrideB >> 1;
+  unsigned short* pl = reinterpret_cast<unsigned short*>(X.lds + LY.off_pl);
+  unsigned short* plB = reinterpret_cast<unsigned short*>(X.lds + LY.off_plB);
+  if (C == 1) {
+    const int16_t* __restrict__ src = X.in + nb;
+    for (int k0 = threadIdx.x; k0 < wcap + 1; k0 += 8 * NT) {
+      int v[8];
+      if (last >= 0) {  // uniform
 #pragma unroll
-      for (int u = 0; u < 8; u++) {  // eight coalesced loads in flight before the first LDS write:
-        const int k = k0 + u * NT;   // clamped address, unconditional load, so nothing serialises them
-        v[u] = (int)src[k < last ? k : last];
+        for (int u = 0; u < 8; u++) {  // eight coalesced loads in flight before the first LDS write:
+          const int k = k0 + u * NT;   // clamped address, unconditional load, so nothing serialises them
+          v[u] = (int)src[k < last ? k : last];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int k = k0 + u * NT;
+          if (k > last) v[u] = 0;
+        }
+      } else {  // the whole window lies in the zero padding: no address there may be touched
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = 0;
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int k = k0 + u * NT;
-        if (k > last) v[u] = 0;
+        const unsigned short w = (unsigned short)(v[u] + 32768);
+        if (k < wcap) monoH[k] = w;
+        if (k > 0 && k < wcap + 1) monoHB[k - 1] = w;
       }
-    } else {  // the whole window lies in the zero padding: no address there may be touched
-#pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = 0;
     }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int k = k0 + u * NT;
-      const unsigned short w = (unsigned short)(v[u] + 32768);
-      if (k < wcap) monoH[k] = w;
-      if (k > 0 && k < wcap + 1) monoHB[k - 1] = w;
+    fast_sync();
+    // One thread per decimated index m: it reads the 2*skip-1 window samples m*skip .. m*skip+2*skip-2 once and slides
+    // the sum over them, giving element m of every plane.  |sum| < 2^18 and skip <= 7, so the truncating division is
+    // exactly mulhi(|sum|, ceil(2^32 / skip)).
+    const unsigned M = (unsigned)((0x100000000ull + (unsigned)skip - 1) / (unsigned)skip);
+    const int bias = 32768 * skip;
+    for (int m = threadIdx.x; (m + 1) * skip <= wcap; m += NT) {
+      const unsigned short* w = monoH + m * skip;
+      int sum = 0;
+      for (int j = 0; j < skip; j++) sum += (int)w[j];
+      for (int r = 0; r < skip; r++) {
+        if ((m + 1) * skip + r > wcap) break;  // the last element of the higher planes needs samples past the window
+        const int v = sum - bias;
+        const unsigned mag = (unsigned)(v < 0 ? -v : v);
+        const int qm = (int)__umulhi(mag, M);
+        const unsigned short u = (unsigned short)((v < 0 ? -qm : qm) + 32768);
+        pl[r * plStride + m] = u;
+        if (m > 0) plB[r * plStride + m - 1] = u;
+        sum += (int)w[skip + r] - (int)w[r];
+      }
     }
-  }
-  fast_sync();
-  // One thread per decimated index m: it reads the 2*skip-1 window samples m*skip .. m*skip+2*skip-2 once and slides
-  // the sum over them, giving element m of every plane.  |sum| < 2^18 and skip <= 7, so the truncating division is
-  // exactly mulhi(|sum|, ceil(2^32 / skip)).
-  const unsigned M = (unsigned)((0x100000000ull + (unsigned)skip - 1) / (unsigned)skip);
-  const int bias = 32768 * skip;
-  const int plStride = LY.plStrideB >> 1;
-  unsigned short* pl = reinterpret_cast<unsigned short*>(X.lds + LY.off_pl);
-  unsigned short* plB = reinterpret_cast<unsigned short*>(X.lds + LY.off_plB);
-  for (int m = threadIdx.x; (m + 1) * skip <= wcap; m += NT) {
-    const unsigned short* w = monoH + m * skip;
-    int sum = 0;
-    for (int j = 0; j < skip; j++) sum += (int)w[j];
-    for (int r = 0; r < skip; r++) {
-      if ((m + 1) * skip + r > wcap) break;  // the last element of the higher planes needs samples past the window
-      const int v = sum - bias;
-      const unsigned mag = (unsigned)(v < 0 ? -v : v);
-      const int qm = (int)__umulhi(mag, M);
-      const unsigned short u = (unsigned short)((v < 0 ? -qm : qm) + 32768);
-      pl[r * plStride + m] = u;
-      if (m > 0) plB[r * plStride + m - 1] = u;
-      sum += (int)w[skip + r] - (int)w[r];
+  } else {
+    // Several channels.  Search signal at full rate: the channel mean, truncated (the dependency's downSampleInput with
+    // skip 1).  Decimated planes: skip*C RAW samples summed and divided ONCE by skip*C -- not the mean of the per-frame
+    // channel means (|sum| < 2^21, skip*C <= 56: mulhi is still exact).  The raw samples are not kept in LDS: both
+    // passes read the input (the second one out of the cache), the cross-fades later too (fast_outputs).
+    const int16_t* __restrict__ src = X.in + (size_t)nb * C;
+    for (int k = threadIdx.x; k < wcap + 1; k += NT) {
+      int sum = 0;
+      if (k <= last)
+        for (int c = 0; c < C; c++) sum += (int)src[(size_t)k * C + c];
+      const unsigned short u = (unsigned short)(sum / C + 32768);
+      if (k < wcap) monoH[k] = u;
+      if (k > 0) monoHB[k - 1] = u;
+    }
+    const int div = skip * C;
+    const unsigned M = (unsigned)((0x100000000ull + (unsigned)div - 1) / (unsigned)div);
+    for (int m = threadIdx.x; (m + 1) * skip <= wcap; m += NT) {
+      const int f0 = m * skip;  // first frame of the decimated sample (window-relative)
+      int sum = 0;
+      for (int j = 0; j < skip; j++)
+        if (f0 + j <= last)
+          for (int c = 0; c < C; c++) sum += (int)src[(size_t)(f0 + j) * C + c];
+      for (int r = 0; r < skip; r++) {
+        if ((m + 1) * skip + r > wcap) break;
+        const unsigned mag = (unsigned)(sum < 0 ? -sum : sum);
+        const int qm = (int)__umulhi(mag, M);
+        const unsigned short u = (unsigned short)((sum < 0 ? -qm : qm) + 32768);
+        pl[r * plStride + m] = u;
+        if (m > 0) plB[r * plStride + m - 1] = u;
+        // slide by one frame: drop frame f0 + r, take frame f0 + skip + r (zeros past the input)
+        for (int c = 0; c < C; c++) {
+          const int fa = f0 + skip + r, fd = f0 + r;
+          sum += ((fa <= last) ? (int)src[(size_t)fa * C + c] : 0) - ((fd <= last) ? (int)src[(size_t)fd * C + c] : 0);
+        }
+      }
     }
   }
   fast_sync();
@@ -285,13 +347,15 @@ __device__ __forceinline__ int pair_addr(int base, int d2, int e) { return base 
 // winner predicts, while the search waves are still busy with the coarse search; when the prediction holds (the coarse
 // winner repeats in 30-60 % of steps on speech) the step skips its refine phase -- half of its time.  See the protocol
 // comment at the output waves' loop.  Needs as many output waves as search waves (the same dealing of the refine tasks).
-template <int NWM, int NWC, int RATE, int SPEC>
+// MC: 0 = mono streams only (the instantiation of the bench), 1 = any channel count up to 8 per stream.
+template <int NWM, int NWC, int RATE, int SPEC, int MC>
 __global__ void __launch_bounds__(64 * (NWM + NWC)) __attribute__((amdgpu_waves_per_eu((RATE == 16000 && NWC > 0) ? 5 : 4, (RATE == 16000 && NWC > 0) ? 5 : 8)))
 spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const int16_t* __restrict__ in_base,
                      int16_t* __restrict__ out_base, int64_t* __restrict__ n_out, SpxStreamState* __restrict__ states,
                      const float* scratch_base, const int* speed_ready, int wcap) {
   constexpr int NT = 64 * (NWM + NWC);
   constexpr bool SP = SPEC != 0 && NWC == NWM;
+  constexpr bool MCH = MC != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);  // wave-uniform, and the compiler must know it: everything keyed on it stays scalar
@@ -305,7 +369,8 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   const FastLds LY = fast_lds_layout_i(maxP, skip, wcap);
 
   FastOut X;
-  X.in = in_base + S.in_off - S.tsm_shift;  // indexed by TSM position (= input frame + flush padding so far); mono
+  X.C = MCH ? S.channels : 1;
+  X.in = in_base + S.in_off - S.tsm_shift * X.C;  // indexed by (TSM position = input frame + flush padding so far) * C
   X.out = out_base + S.out_off;
   X.lds = lds;
   X.out_cap = (pos_t)(S.out_cap > 0x7fffffff ? 0x7fffffff : S.out_cap);
@@ -452,6 +517,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       //   others  the barrier that follows the command, then as without SPEC.
       // A slot is rewritten two commands later, i.e. behind a barrier the output waves joined after reading it.
       int seq = 0, nspec = 0;
+      pos_t wb = -1, lim = (pos_t)(S.n_in + S.tsm_shift);  // window base / input limit as the commands have announced them
       for (;;) {
         const int* c = cmd + (seq & 1) * FCMD_INTS;
         seq++;
@@ -471,16 +537,18 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
             refine_sads(so, slo, shi, sumS + sg * 64);
             if (lane == 0) atomicAdd(reinterpret_cast<unsigned*>(sWait) + 2, 1u);
           }
-          fast_outputs<64 * NWC>(X, tid - 64 * NWM, xf_n, xf_down, xf_period, xf_out, 0, 0, 0, 0);
+          fast_outputs<64 * NWC, MCH>(X, tid - 64 * NWM, xf_n, xf_down, xf_period, xf_out, 0, 0, 0, lim, wb);
           fast_sync();
           continue;
         }
         fast_sync();  // the barrier that follows every other command
         const int cp_n = uni(c[5]), cp_src = uni(c[6]), cp_out = uni(c[7]);
         const pos_t limit = uni(c[8]), nb = uni(c[9]);
-        fast_outputs<64 * NWC>(X, tid - 64 * NWM, xf_n, xf_down, xf_period, xf_out, cp_n, cp_src, cp_out, limit);
+        lim = limit;
+        fast_outputs<64 * NWC, MCH>(X, tid - 64 * NWM, xf_n, xf_down, xf_period, xf_out, cp_n, cp_src, cp_out, limit, wb);
         if (type == FCMD_REFILL) {
-          fast_refill<NT>(X, LY, skip, nb, limit);
+          fast_refill<NT, MCH>(X, LY, skip, nb, limit);
+          wb = nb;
         } else if (type == FCMD_POLL) {
           fast_sync();            // the polled count is in LDS
         } else if (type == FCMD_EXIT) {
@@ -489,6 +557,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       }
     } else if constexpr (NWC > 0) {
       int seq = 0;
+      pos_t wb = -1, lim = (pos_t)(S.n_in + S.tsm_shift);  // window base / input limit as the commands have announced them
       for (;;) {
         fast_sync();  // the barrier that follows every published command
         const int* c = cmd + (seq & 1) * FCMD_INTS;
@@ -496,12 +565,15 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         const int type = uni(c[0]);
         const int xf_n = uni(c[1]), xf_down = uni(c[2]), xf_period = uni(c[3]), xf_out = uni(c[4]);
         const int cp_n = uni(c[5]), cp_src = uni(c[6]), cp_out = uni(c[7]);
-        const pos_t limit = uni(c[8]), nb = uni(c[9]);
-        fast_outputs<64 * NWC>(X, tid - 64 * NWM, xf_n, xf_down, xf_period, xf_out, cp_n, cp_src, cp_out, limit);
+        const pos_t nb = uni(c[9]);
+        if (type != FCMD_STEP) lim = uni(c[8]);  // a step command carries fields 0..4 only
+        fast_outputs<64 * NWC, MCH>(X, tid - 64 * NWM, xf_n, xf_down, xf_period, xf_out, type == FCMD_STEP ? 0 : cp_n, cp_src,
+                               cp_out, lim, wb);
         if (type == FCMD_STEP) {
           fast_sync();            // the step's second barrier (refine sums complete)
         } else if (type == FCMD_REFILL) {
-          fast_refill<NT>(X, LY, skip, nb, limit);
+          fast_refill<NT, MCH>(X, LY, skip, nb, lim);
+          wb = nb;
         } else if (type == FCMD_POLL) {
           fast_sync();            // the polled count is in LDS
         } else if (type == FCMD_EXIT) {
@@ -621,8 +693,8 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       }                                                                                                                \
       seq++;                                                                                                           \
     } else {                                                                                                           \
-      fast_outputs<64 * NWM>(X, tid, xf_n, xf_down, xf_period, xf_out, (int)(CP_N), (pos_t)(CP_SRC), (pos_t)(CP_OUT),  \
-                             limit);                                                                                   \
+      fast_outputs<64 * NWM, MCH>(X, tid, xf_n, xf_down, xf_period, xf_out, (int)(CP_N), (pos_t)(CP_SRC), (pos_t)(CP_OUT),  \
+                             limit, wbase);                                                                            \
     }                                                                                                                  \
     xf_n = 0;                                                                                                          \
   } while (0)
@@ -636,7 +708,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       const pos_t nb = pos & ~7;
       FAST_PUBLISH(FCMD_REFILL, 0, 0, 0, nb);
       if (NWC > 0) fast_sync();
-      fast_refill<NT>(X, LY, skip, nb, limit);
+      fast_refill<NT, MCH>(X, LY, skip, nb, limit);
       wbase = nb;
     }
     FSTAMP(2);
@@ -924,26 +996,30 @@ bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm) {
 }
 
 // numRegs of the instantiation spx_launch_walk_fast picks for (nwm, nwc) at this plan's rate
-int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap) {
+int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC) {
   const void* fn = nullptr;
-#define SPX_FN_R(M, C) (P.rate == 16000 && wcap == SPX_CT_WCAP ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 16000, 0>) \
-                        : P.rate == 22050 && wcap == SPX_CT_WCAP ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 22050, 0>) \
-                        : reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 0, 0>))
+#define SPX_FN_RM(M, C, MCV) (P.rate == 16000 && wcap == SPX_CT_WCAP ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 16000, 0, MCV>) \
+                        : P.rate == 22050 && wcap == SPX_CT_WCAP ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 22050, 0, MCV>) \
+                        : reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 0, 0, MCV>))
+#define SPX_FN_R(M, C) (maxC > 1 ? SPX_FN_RM(M, C, 1) : SPX_FN_RM(M, C, 0))
   if (nwm == 8) fn = SPX_FN_R(8, 4);
   else if (nwm == 2) fn = nwc >= 1 ? SPX_FN_R(2, 1) : SPX_FN_R(2, 0);
   else fn = nwc >= 4 ? SPX_FN_R(4, 4) : nwc >= 2 ? SPX_FN_R(4, 2) : nwc >= 1 ? SPX_FN_R(4, 1) : SPX_FN_R(4, 0);
 #undef SPX_FN_R
+#undef SPX_FN_RM
   return spx_kernel_vgprs(fn);
 }
 
 void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, const int16_t* in,
                           int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
-                          const int* speed_ready, int nwm, int nwc, int wcap, hipStream_t st) {
+                          const int* speed_ready, int nwm, int nwc, int wcap, int maxC, hipStream_t st) {
   if (n_streams <= 0) return;
   const FastLds LY = fast_lds_layout(P, wcap);
-#define SPX_LAUNCH_FAST_RS(M, C, R, SPECV)                                                                                \
-  hipLaunchKernelGGL((spx_walk_fast_kernel<M, C, R, SPECV>), dim3(n_streams), dim3(64 * (M + C)), LY.total, st, P, streams, \
+#define SPX_LAUNCH_FAST_RSM(M, C, R, SPECV, MCV)                                                                               \
+  hipLaunchKernelGGL((spx_walk_fast_kernel<M, C, R, SPECV, MCV>), dim3(n_streams), dim3(64 * (M + C)), LY.total, st, P, streams, \
                      in, out, n_out, states, scratch, speed_ready, wcap)
+#define SPX_LAUNCH_FAST_RS(M, C, R, SPECV)                                                                                \
+  do { if (maxC > 1) SPX_LAUNCH_FAST_RSM(M, C, R, SPECV, 1); else SPX_LAUNCH_FAST_RSM(M, C, R, SPECV, 0); } while (0)
 #define SPX_LAUNCH_FAST_R(M, C, R) SPX_LAUNCH_FAST_RS(M, C, R, 0)
   // the two rates of the BASELINE configs get their own specialisation (with the default 4096-frame window)
 #define SPX_LAUNCH_FAST(M, C)                                              \
@@ -988,5 +1064,6 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
   }
 #undef SPX_LAUNCH_FAST
 #undef SPX_LAUNCH_FAST_RS
+#undef SPX_LAUNCH_FAST_RSM
 #undef SPX_LAUNCH_FAST_R
 }
