@@ -27,6 +27,31 @@ static int fail(int code, const std::string& msg) {
     if (e_ != hipSuccess) return fail(-2, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+// roctx ranges around the host side of a batch call (rocprofv3 --marker-trace shows them next to the kernels).  The
+// tracer library is looked up at run time: the product has no link-time dependency on it and works without it.
+#include <dlfcn.h>
+struct SpxRoctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  SpxRoctx() {
+    // rocprofv3 follows the rocprofiler-sdk flavour of the API; the roctracer one (libroctx64) is the fallback
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_LOCAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_LOCAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_LOCAL);
+    if (!h) h = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_LOCAL);
+    if (h) {
+      push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+      pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+  }
+};
+struct SpxRange {
+  static SpxRoctx& api() { static SpxRoctx a; return a; }
+  explicit SpxRange(const char* name) { if (api().push) api().push(name); }
+  ~SpxRange() { if (api().pop) api().pop(); }
+};
+
 #define SPX_MAX_CHUNKS 16
 // Pinned staging slot for the small host tables of a call (job tables, tile order): the async copies read it after the
 // call has returned, so it is plan-owned and reused only once its copies have retired.
@@ -385,6 +410,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
                     int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs, bool do_a,
                     bool do_w) {
   if (!plan || !jobs || n <= 0) return fail(-1, "spx_batch: bad arguments");
+  SpxRange range_(do_a && do_w ? "spx_batch_run" : (do_a ? "spx_batch_analyze" : "spx_batch_walk"));
   SpxPlanDev d = plan->dev;  // a copy: the tile size is chosen per call
   Layout L = layout_for(d, jobs, n);
   if (ws_bytes < L.total || !ws) return fail(-1, "spx_batch: workspace too small");
