@@ -10,8 +10,9 @@
  * speedyHipSetMatchMatlab (include/sonic2.h) read at speedyCreateStream.
  *
  * Call pattern (as in the reference's tests and shim): speedyAddData with at_time = t0, t0+1, t0+2, ... (t0 = 0 or 1),
- * speedyComputeTension with at_time = 0, 1, 2, ... each exactly once, in order.  Anything else returns 0 / is ignored
- * with a message in speedyHipLastError().
+ * speedyComputeTension with increasing at_time, each at most once; times may be left out (the shim does after a flush,
+ * soniclib.c:538-550) and are then never computed -- as in the reference, the first call that succeeds is the one treated
+ * as a low-energy frame (speedy.c:293,691).  Anything else returns 0 / is ignored with a message in speedyHipLastError().
  *
  * NOT provided -- the reference's test-only hooks that pass intermediate arrays between stages on the host
  * (speedy.h:102-133: speedyEvaluateHysteresis, speedyAddToHysteresisBuffer, speedyComputeSpectralDifference,

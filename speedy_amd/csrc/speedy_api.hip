@@ -37,7 +37,7 @@ struct speedyStreamStruct {
   int64_t T = 0;            // frames added
   int64_t time0 = -1;       // at_time of frame 0 (0 or 1), -1 = not known yet
   int64_t current_time = 0;
-  int64_t tensionDone = 0;  // next tension frame expected
+  int64_t tensionDone = 0;  // lowest tension frame that may still be asked for
   bool started = false;
   std::vector<float> hSpec, hSpecAt, hNorm, hFeat, hTmp;
 };
@@ -182,8 +182,8 @@ void speedyAddDataShort(speedyStream s, const int16_t input[], int64_t at_time) 
 int speedyComputeTension(speedyStream s, int64_t at_time, float* tension) {
   (void)hipSetDevice(s->device);
   if (s->T == 0 || !(at_time + s->plan->F <= s->current_time)) return 0;  // speedy.c:756
-  if (at_time != s->tensionDone) {
-    spx_internal_set_api_error("speedyComputeTension: tensions must be asked for in order, each once");
+  if (at_time < s->tensionDone) {
+    spx_internal_set_api_error("speedyComputeTension: tensions must be asked for in increasing time order, each once");
     return 0;
   }
   if (!launch(s, false, at_time, at_time + 1)) return 0;
@@ -202,6 +202,7 @@ float speedyComputeSpeedFromTension(float tension, float R_g, float fb, speedySt
     SpxStreamState z;
     memset(&z, 0, sizeof(z));
     z.lp = 2.14204f; z.lpf = 123.837f;  // speedy.c:263-264
+    z.tension_first = -1;
     (void)hipMemcpyAsync(s->dState, &z, sizeof(z), hipMemcpyHostToDevice, s->hs);
     (void)hipStreamSynchronize(s->hs);
     s->started = true;

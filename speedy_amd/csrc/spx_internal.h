@@ -89,6 +89,9 @@ struct SpxStreamState {
   int handed;      // ring buffers handed to the TSM stage so far (readBufferFrameIndex, soniclib.c:73)
   int flush_remaining;  // frames the TSM stage held when its last flush began (the rate stage's expected length needs it)
   int flush_out_mark;   // ... and the frames it had produced by then (events of the same job before the flush included)
+  int tension_first;    // time index of the first tension frame ever computed (-1: none yet): that call alone is "skipped"
+                        // (skip_frame_count starts at 1, speedy.c:293,691) -- frame 0 unless a flush came before it
+  int pad2_;
 };
 
 // Rate stage (sonicSetRate != 1: the dependency's adjustRate, oracle/orc_sonic.c adjust_rate): the TSM stage's output

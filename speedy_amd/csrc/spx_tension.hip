@@ -66,14 +66,16 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
   if (nl == 0.0f) return;  // a linear stream has no frames (uniform per workgroup)
 
   // the part of the stream state this stage owns
-  struct { float lp, lpf, cur_dur, des_dur; } Z;
+  struct { float lp, lpf, cur_dur, des_dur; int first_k; } Z;
   if (S.flags & SPX_F_INIT) {
     Z.lp = 2.14204f;    // speedy.c:263,288
     Z.lpf = 123.837f;   // speedy.c:264,291
     Z.cur_dur = 0.0f; Z.des_dur = 0.0f;
+    Z.first_k = -1;
   } else {
     const SpxStreamState& in = states[blockIdx.x];
     Z.lp = in.lp; Z.lpf = in.lpf; Z.cur_dur = in.cur_dur; Z.des_dur = in.des_dur;
+    Z.first_k = in.tension_first;
   }
   const SpxFrameRec* rec = rec_base + S.frame_off;
   float* scr = scratch_base + (size_t)S.frame_off * 4;  // per frame: comp, hyst, ewld->tension, speed
@@ -116,6 +118,10 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
       K0 = S.tension_skip;
       if (K > S.tension_to) K = S.tension_to;
     }
+    // the first speedyComputeTension call that succeeds finds skip_frame_count == 1 (speedy.c:293) and is treated as a
+    // low-energy frame whatever its time index: frame 0, or the first frame behind a flush that came before any tension
+    if (Z.first_k < 0 && K > K0) Z.first_k = K0;
+    const int first_k = Z.first_k;
     if (T > fa || (S.flags & SPX_F_TENSION_RANGE)) {  // (a unit-level tension request brings no new frame)
       // ---- pass 1: energy low-pass (sequential) -> local -> compressed ----
       float lp = Z.lp;
@@ -158,7 +164,7 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
         }
         const float hyst = (float)((double)(past_max + future_max) / 2.0);  // speedy.c:609
         const float e_cur = (k < t0) ? 0.0f : rec[k - t0].energy;          // history slot k holds frame k - t0
-        const bool low = e_cur <= lowthr || k == 0;                        // the very first call is skipped (speedy.c:692)
+        const bool low = e_cur <= lowthr || k == first_k;                  // the very first call is skipped (speedy.c:692)
         const float lsd = low ? 0.0f : rec[k - t0].lsd;
         const float ewld = low ? 0.0f : lsd * hyst;                          // speedy.c:720
         scr[4 * k + 1] = hyst;
@@ -183,7 +189,7 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
           const float ewld = sA[i], l = sB[i];
           const float hyst = scr[4 * k + 1];
           const float e_cur = (k < t0) ? 0.0f : rec[k - t0].energy;
-          const bool low = e_cur <= lowthr || k == 0;
+          const bool low = e_cur <= lowthr || k == first_k;
           float rel = 0.0f, sc = 0.0f;
           if (!low) {
             rel = (float)((double)ewld / ((double)l + 0.01 * (double)123.979f));       // speedy.c:725-726
@@ -282,6 +288,7 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
   if (tid == 0) {
     SpxStreamState& o = states[blockIdx.x];
     o.lp = Z.lp; o.lpf = Z.lpf; o.cur_dur = Z.cur_dur; o.des_dur = Z.des_dur;
+    o.tension_first = Z.first_k;
   }
 }
 

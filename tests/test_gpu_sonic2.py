@@ -351,6 +351,19 @@ def test_write_after_flush_matches_the_reference_life_cycle(orc, nl, ch, speed, 
     s.close()
 
 
+@pytest.mark.parametrize("rate_hz,chunk,flush_at", [(22050, 160, 17), (22050, 160, 10), (16000, 100, 12), (22050, 500, 3)])
+def test_flush_before_the_first_tension_frame(orc, rate_hz, chunk, flush_at):
+    """A flush that arrives before any tension frame exists (fewer than F analysis calls so far): the ring buffers go to
+    the TSM stage at the global speed, and the first tension the shim computes afterwards is for a time > 0 -- that call
+    is the one speedy.c:691 skips."""
+    from speedy_amd.synth import speech_like
+    x = speech_like(36 * chunk, rate_hz, seed=71)
+    ro, rg, co, cg = _rate_streams(orc, x, rate_hz, 1, 2.0, 1.0, False, chunk, {"flush_at": flush_at})
+    assert co == cg
+    assert np.array_equal(ro, rg)
+    assert ro.size > 0
+
+
 def test_nonlinear_factor_changes_between_writes(orc):
     """The shim re-reads the nonlinear factor on every write (soniclib.c:397,343-345): 1.0 -> 0.3 -> 0.8 mid-stream."""
     from speedy_amd.sonic2 import SonicStream
@@ -448,6 +461,31 @@ def test_set_rate_matches_the_oracle(orc, name, ch, speed, nl, chunk, plan):
     assert co == cg
     assert np.array_equal(ro, rg)
     assert ro.size > 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_set_rate_fuzz(orc, seed):
+    """Random rates (changed a few times mid-stream, sometimes back to 1), speeds, channel counts, chunk sizes and an
+    optional flush in the middle: the HIP streaming API against the oracle shim, bytes and per-write counts."""
+    rng = np.random.default_rng(900 + seed)
+    rate_hz = int(rng.choice([16000, 22050, 8000]))
+    ch = int(rng.choice([1, 1, 2, 3]))
+    nl = float(rng.choice([0.0, 1.0]))
+    speed = float(rng.choice([0.6, 1.0, 1.3, 2.0, 3.5]))
+    if speed == 1.0:
+        nl = 0.0
+    chunk = int(rng.choice([160, 500, 1000, 1777]))
+    writes = 36
+    from speedy_amd.synth import speech_like
+    x = speech_like(writes * chunk, rate_hz, seed=70 + seed, channels=ch)
+    plan = {}
+    for w in sorted(rng.choice(np.arange(writes), size=4, replace=False)):
+        plan[int(w)] = float(rng.choice([0.5, 0.75, 1.0, 1.2, 1.5, 2.0]))
+    if rng.random() < 0.5:
+        plan["flush_at"] = int(rng.integers(5, writes - 5))
+    ro, rg, co, cg = _rate_streams(orc, x, rate_hz, ch, speed, nl, bool(rng.integers(0, 2)), chunk, plan)
+    assert co == cg, (rate_hz, ch, speed, nl, chunk, plan)
+    assert np.array_equal(ro, rg), (rate_hz, ch, speed, nl, chunk, plan)
 
 
 def test_documented_deviations_fail_loudly_not_silently():

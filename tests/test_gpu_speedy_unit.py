@@ -142,3 +142,31 @@ def test_shim_time_base_and_short_input(orc):
             out_t += 1
     assert out_t > 30
     g.close()
+
+
+def test_first_tension_call_is_the_skipped_one_whatever_its_time(orc):
+    """speedy.c:293,691: skip_frame_count starts at 1, so the FIRST speedyComputeTension that succeeds is treated as a
+    low-energy frame -- also when that call is not for time 0 (the shim after an early flush, soniclib.c:538-550) --
+    and times left out later are simply never computed."""
+    x, rate, _ = read_wav("tapestry.wav")
+    g, o = _hip(rate, False), orc.Speedy(rate, False)
+    W, B = g.frame_size, g.frame_step
+    base = 100 * B                                     # speech, not the leading silence
+    asked = [5, 6, 7, 10, 11, 15] + list(range(16, 40))
+    got = 0
+    for j in range(60):
+        fr = x[base + j * B:base + j * B + W]
+        g.add_data_short(fr, j + 1)
+        o.add_data_short(fr, j + 1)
+        while asked:
+            okg, vg = g.compute_tension(asked[0])
+            oko, vo = o.compute_tension(asked[0])
+            assert okg == oko
+            if not okg:
+                break
+            assert np.float32(vg) == np.float32(vo), (asked[0], vg, vo)
+            assert np.array_equal(g.features(), o.features()), asked[0]
+            asked.pop(0)
+            got += 1
+    assert got == 30 and not asked
+    g.close()
