@@ -37,12 +37,15 @@ static int g_match_matlab = 0;
 // [lo, hi) addressable and keeps what is already valid from lo on ([lo, filled)); it slides -- a stream-ordered copy
 // into a fresh allocation, the old one freed in stream order -- when hi does not fit or when more than half the
 // allocation is dead prefix.  base() is the pointer that, indexed with ABSOLUTE element numbers, lands in the allocation.
+// `guard` elements in front of p[0] belong to the allocation too (zeroed, never meaningful): a reader that aligns its
+// first position down may touch them.
 template <class T>
 struct SlideBuf {
   T* p = nullptr;
   int64_t origin = 0;  // absolute index of p[0]
   int64_t cap = 0;     // elements
   int64_t filled = 0;  // absolute end of valid data (set by the owner before ensure)
+  int64_t guard = 0;   // addressable elements in front of p[0]
   // does [lo, hi) fit as things are (and is the dead prefix still small)?
   bool fits(int64_t lo, int64_t hi) const {
     return p && lo >= origin && hi <= origin + cap && lo - origin <= cap / 2;
@@ -51,13 +54,17 @@ struct SlideBuf {
   bool slide_to(int64_t lo, int64_t hi, hipStream_t st, int64_t min_cap) {
     const int64_t ncap = std::max<int64_t>(min_cap, 2 * (hi - lo));
     T* np = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void**>(&np), (size_t)ncap * sizeof(T), st) != hipSuccess) return false;
+    if (hipMallocAsync(reinterpret_cast<void**>(&np), (size_t)(ncap + guard) * sizeof(T), st) != hipSuccess) return false;
+    if (guard) {
+      (void)hipMemsetAsync(np, 0, (size_t)guard * sizeof(T), st);
+      np += guard;
+    }
     if (p && filled > lo && lo >= origin) {
       if (hipMemcpyAsync(np, p + (lo - origin), (size_t)(std::min(filled, origin + cap) - lo) * sizeof(T),
                          hipMemcpyDeviceToDevice, st) != hipSuccess)
         return false;
     }
-    if (p) (void)hipFreeAsync(p, st);
+    if (p) (void)hipFreeAsync(p - guard, st);
     p = np;
     origin = lo;
     cap = ncap;
@@ -72,7 +79,7 @@ struct SlideBuf {
   }
   T* base() const { return p - origin; }  // only ever dereferenced at indices >= origin
   void release(hipStream_t st) {
-    if (p) (void)hipFreeAsync(p, st);
+    if (p) (void)hipFreeAsync(p - guard, st);
     p = nullptr;
     cap = 0;
   }
@@ -98,6 +105,7 @@ struct sonicStreamStruct {  // speedyConnectionStruct + the parts of libsonic's 
   SlideBuf<int16_t> dIn, dOut;      // elements = int16 values (frames * channels); dOut = what the TSM stage produces
   SlideBuf<int16_t> dFinal;         // rate mode: what the rate stage produces = what the stream delivers
   SpxRateState* dRate = nullptr;    // device record of the rate stage (directly behind dNOut)
+  bool speedSet = false;            // sonicSetSpeed since the last job (SPX_F_SPEED_SET)
   bool rateMode = false;            // a write or flush has seen rate != 1: outputs go through the rate stage from then on
   int64_t finKnown = 0;             // rate mode: final frames produced / TSM frames taken, as of the last synchronisation
   int64_t finBound = 0;
@@ -177,6 +185,9 @@ sonicStream sonicCreateStream(int sampleRate, int numChannels) {
   (void)hipGetDevice(&s->device);
   s->sampleRate = sampleRate;
   s->channels = numChannels;
+  // the walk kernels refill their window from a position aligned down by 8 frames; right behind a flush that found
+  // (almost) no input that lies up to 7 frames in front of the first input frame
+  s->dIn.guard = 64 * (int64_t)numChannels;
   const size_t small = 256 + sizeof(SpxStreamState) + sizeof(int64_t) + sizeof(SpxRateState) + 64;
   if (hipStreamCreateWithFlags(&s->hs, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&s->evStaged, hipEventDisableTiming) != hipSuccess ||
@@ -215,7 +226,7 @@ void sonicSetRate(sonicStream s, float rate) {
     (void)hipMemsetAsync(&s->dRate->old_pos, 0, 2 * sizeof(int32_t), s->hs);
   }
 }
-void sonicSetSpeed(sonicStream s, float speed) { s->globalSpeed = speed; }
+void sonicSetSpeed(sonicStream s, float speed) { s->globalSpeed = speed; s->speedSet = true; }
 void sonicEnableNonlinearSpeedup(sonicStream s, float f) { s->nonlinearFactor = f; }
 void sonicSetDurationFeedbackStrength(sonicStream s, float f) { s->feedbackStrength = f; }
 int getSonicBufferSize(sonicStream s) { return s ? s->bufferSize : 0; }
@@ -389,6 +400,8 @@ static int launch_job(sonicStream s, bool flush) {
         }
     }
   }
+  if (!s->dIn.p && !s->dIn.ensure(0, 64 * C, s->hs, 1 << 16)) return 0;  // a flush before any write: the kernels still
+                                                                         // get a real (empty, guarded) input array
   // ---- the job: absolute stream coordinates through (possibly negative) base offsets ----
   SpxStreamDev& J = *reinterpret_cast<SpxStreamDev*>(s->hPinned);
   static_assert(sizeof(SpxStreamDev) <= SPX_STAGE_JOB, "job table slot");
@@ -397,7 +410,9 @@ static int launch_job(sonicStream s, bool flush) {
   J.out_off = -s->dOut.origin; J.out_cap = (s->dOut.origin + s->dOut.cap) / C;
   J.frame_off = -s->dRec.origin; J.n_frames = (int32_t)T; J.frame_begin = (int32_t)fa;
   J.channels = (int32_t)C;
-  J.flags = (s->started ? 0 : SPX_F_INIT) | (flush ? SPX_F_FLUSH : 0) | (s->rateMode ? SPX_F_NO_TRUNC : 0);
+  J.flags = (s->started ? 0 : SPX_F_INIT) | (flush ? SPX_F_FLUSH : 0) | (s->rateMode ? SPX_F_NO_TRUNC : 0) |
+            (s->speedSet ? SPX_F_SPEED_SET : 0);
+  s->speedSet = false;
   J.speed = s->globalSpeed; J.nonlinear = nonlinear ? s->nonlinearFactor : 0.0f; J.feedback = s->feedbackStrength;
   J.tsm_shift = s->tsmShift;
   J.tension_skip = (int32_t)s->tensionSkip;
@@ -569,7 +584,7 @@ static bool linear_only(sonicStream s, const char* who) {
 }
 sonicStream sonicIntCreateStream(int sampleRate, int numChannels) { return sonicCreateStream(sampleRate, numChannels); }
 void sonicIntDestroyStream(sonicStream s) { sonicDestroyStream(s); }
-void sonicIntSetSpeed(sonicStream s, float speed) { s->globalSpeed = speed; }
+void sonicIntSetSpeed(sonicStream s, float speed) { sonicSetSpeed(s, speed); }
 void sonicIntSetRate(sonicStream s, float rate) { sonicSetRate(s, rate); }
 int sonicIntWriteShortToStream(sonicStream s, const short* in, int n) {
   return linear_only(s, "sonicIntWriteShortToStream") ? write_shorts(s, in, n) : 0;

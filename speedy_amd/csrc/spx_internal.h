@@ -47,6 +47,8 @@ struct SpxPlanDev {
 #define SPX_F_NO_SPEED 8       // unit-level API: no speed / duration pass (speedyComputeSpeedFromTension is its own call)
 #define SPX_F_NO_TRUNC 16      // a rate stage follows (sonicSetRate != 1): the flush does not truncate the TSM output -- the
                                // dependency truncates the FINAL output there -- and leaves `flush_remaining` in the state record
+#define SPX_F_SPEED_SET 32     // sonicSetSpeed was called since the last job: it reaches the TSM stage at once, in nonlinear
+                               // mode too (soniclib.c:177-182) -- a flush right behind it hands out the ring buffers at that speed
 struct SpxStreamDev {
   int64_t in_off, n_in, out_off, out_cap;  // n_in = input frames present so far (from the stream start)
   int64_t frame_off;    // index of this stream's analysis frame 0 in the per-frame arrays

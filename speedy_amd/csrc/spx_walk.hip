@@ -757,7 +757,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
     Z.handed = states[blockIdx.x].handed;
     // sonicSetSpeed between writes reaches the TSM stage at once (soniclib.c:182); in nonlinear mode the
     // next tension frame overrides it (soniclib.c:354)
-    if (nl == 0.0f) Z.curSpeed = Rg;
+    if (nl == 0.0f || (S.flags & SPX_F_SPEED_SET)) Z.curSpeed = Rg;
   }
 
   const float* scr = scratch_base + (size_t)S.frame_off * 4;  // per frame: ..., speed (written by the tension kernel)

@@ -612,7 +612,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     remaining = uni(Z.w.remaining); prevPeriod = uni(Z.w.prevPeriod); prevMinDiff = uni(Z.w.prevMinDiff);
     overflow = uni(Z.w.overflow);
     handed = linear ? 0 : uni(Z.handed);
-    tailSpeed = linear ? Rg : unif(Z.curSpeed);  // sonicSetSpeed between writes reaches the TSM stage at once (soniclib.c:182)
+    tailSpeed = (linear || (S.flags & SPX_F_SPEED_SET)) ? Rg : unif(Z.curSpeed);  // sonicSetSpeed between writes reaches the TSM stage at once (soniclib.c:182)
   }
   const pos_t n_tsm = (pos_t)(S.n_in + S.tsm_shift);  // the written input in TSM positions
   pos_t limit = n_tsm;           // frames of real input; reads beyond are the flush's zero padding

@@ -149,3 +149,83 @@ def test_batch_mixture_fuzz(orc, seed):
             ref = orc.compress_sound(xs[i], rate, chs[i], speeds[i], nls[i], fbs[i], mm,
                                      chunk=1000 if nls[i] != 0 else max(xs[i].size // chs[i], 1))
             assert np.array_equal(outs[i], ref["out"]), (seed, rep, i, rate, chs[i], speeds[i], nls[i], fbs[i], mm)
+
+
+@pytest.mark.parametrize("seed", list(range(31, 39)) + list(range(3000, 3000 + SOAK)))
+def test_life_cycle_fuzz(orc, seed):
+    """Random call sequences through the streaming API: writes from one frame to a few thousand (many shorter than an
+    analysis hop), reads of random size, flushes anywhere (also before the first tension frame, twice in a row, with
+    nothing written), and between writes new values for speed, rate (sonicSetRate), nonlinear factor (non-zero values)
+    and feedback strength.  After every call the frames delivered must equal the oracle shim's."""
+    from speedy_amd.sonic2 import SonicStream
+    L = orc.lib()
+    rng = np.random.default_rng(seed)
+    ops = os.environ.get("SPX_LC_OPS", "flush,speed,rate,nl,fb").split(",")   # debugging: leave op classes out
+    trace = os.environ.get("SPX_LC_TRACE")                                     # debugging: print every call
+    for i in range(6):
+        rate = int(rng.choice([8000, 16000, 16000, 22050, 22050, 44100]))
+        ch = int(rng.choice([1, 1, 1, 2, 3]))
+        kind = KINDS[int(rng.integers(0, len(KINDS)))]
+        n = int(rng.integers(rate // 10, int(2.5 * rate)))
+        nl = float(rng.choice([0.0, 1.0, 1.0, 0.6]))
+        speed = float(np.round(rng.choice([rng.uniform(0.4, 0.95), rng.uniform(1.05, 5.0), 2.0, 3.5]), 5))
+        fb = float(rng.choice([0.0, 0.0, 0.1]))
+        mm = bool(rng.integers(0, 2))
+        small = bool(rng.integers(0, 2))
+        x = _signal(kind, n, rate, ch, rng)
+        tag = (seed, i, rate, ch, kind, n, speed, nl, fb, mm, small)
+        h = L.orc_sonicCreateStream(rate, ch, int(mm))
+        s = SonicStream(rate, ch, mm)
+        L.orc_sonicSetSpeed(h, speed); s.set_speed(speed)
+        L.orc_sonicEnableNonlinearSpeedup(h, nl); s.enable_nonlinear(nl)
+        L.orc_sonicSetDurationFeedbackStrength(h, fb); s.set_feedback(fb)
+        buf = np.zeros(8192 * ch, np.int16)
+        pos, log = 0, []
+        if trace:
+            print("CASE", tag, flush=True)
+        while pos < n:
+            if trace and log:
+                print(" ", log[-1], flush=True)
+            op = rng.random()
+            if op < 0.06 and "flush" in ops:
+                log.append("flush")
+                L.orc_sonicFlushStream(h)
+                assert s.flush() == 1, tag
+            elif 0.06 <= op < 0.10 and "speed" in ops:
+                v = float(np.round(rng.choice([rng.uniform(0.4, 0.95), rng.uniform(1.05, 5.0), 1.0]), 5))
+                log.append(("speed", v))
+                L.orc_sonicSetSpeed(h, v); s.set_speed(v)
+            elif 0.10 <= op < 0.14 and "rate" in ops:
+                v = float(rng.choice([0.5, 0.8, 1.0, 1.0, 1.25, 2.0]))
+                log.append(("rate", v))
+                L.orc_sonicSetRate(h, v); s.set_rate(v)
+            elif 0.14 <= op < 0.17 and nl != 0.0 and "nl" in ops:
+                v = float(rng.choice([0.3, 0.7, 1.0]))
+                log.append(("nl", v))
+                L.orc_sonicEnableNonlinearSpeedup(h, v); s.enable_nonlinear(v)
+            elif 0.17 <= op < 0.19 and "fb" in ops:
+                v = float(rng.choice([0.0, 0.1, 0.3]))
+                log.append(("fb", v))
+                L.orc_sonicSetDurationFeedbackStrength(h, v); s.set_feedback(v)
+            else:
+                w = int(rng.integers(1, 400)) if (small or rng.random() < 0.3) else int(rng.integers(400, 4000))
+                seg = np.ascontiguousarray(x[pos * ch:(pos + w) * ch])
+                pos += w
+                log.append(("w", seg.size // ch))
+                assert L.orc_sonicWriteShortToStream(h, orc.sptr(seg), seg.size // ch) == 1
+                assert s.write_short(seg) == 1, tag + (s.L.speedyHipLastError(),)
+            if rng.random() < 0.7:
+                r = int(rng.integers(1, 8193))
+                k = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), r)
+                got = s.read_short(r)
+                assert got.size == k * ch and np.array_equal(got, buf[:k * ch]), tag + ("read", pos, log[-12:])
+        L.orc_sonicFlushStream(h)
+        s.flush()
+        while True:
+            k = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), 8192)
+            got = s.read_short(8192)
+            assert got.size == k * ch and np.array_equal(got, buf[:k * ch]), tag + ("drain", log[-12:])
+            if k == 0:
+                break
+        L.orc_sonicDestroyStream(h)
+        s.close()
