@@ -167,15 +167,25 @@ def test_life_cycle_fuzz(orc, seed):
         ch = int(rng.choice([1, 1, 1, 2, 3]))
         kind = KINDS[int(rng.integers(0, len(KINDS)))]
         n = int(rng.integers(rate // 10, int(2.5 * rate)))
+        if i == 5:                                    # one long stream per seed: the device buffers slide several times
+            n = int(rng.integers(6 * rate, 25 * rate))
         nl = float(rng.choice([0.0, 1.0, 1.0, 0.6]))
         speed = float(np.round(rng.choice([rng.uniform(0.4, 0.95), rng.uniform(1.05, 5.0), 2.0, 3.5]), 5))
         fb = float(rng.choice([0.0, 0.0, 0.1]))
         mm = bool(rng.integers(0, 2))
-        small = bool(rng.integers(0, 2))
+        small = bool(rng.integers(0, 2)) and i != 5
+        with_cb = nl != 0.0 and bool(rng.integers(0, 2))
         x = _signal(kind, n, rate, ch, rng)
         tag = (seed, i, rate, ch, kind, n, speed, nl, fb, mm, small)
         h = L.orc_sonicCreateStream(rate, ch, int(mm))
         s = SonicStream(rate, ch, mm)
+        ref_cb, got_cb = [], []
+        if with_cb:                                   # tension and speed callbacks: same times, same values, same order
+            keep = [orc.TENSION_FN(lambda _s, t, v: ref_cb.append(("t", t, np.float32(v)))),
+                    orc.TENSION_FN(lambda _s, t, v: ref_cb.append(("s", t, np.float32(v))))]
+            L.orc_sonicTensionCallback(h, keep[0]); L.orc_sonicSpeedCallback(h, keep[1])
+            s.on_tension(lambda t, v: got_cb.append(("t", t, np.float32(v))))
+            s.on_speed(lambda t, v: got_cb.append(("s", t, np.float32(v))))
         L.orc_sonicSetSpeed(h, speed); s.set_speed(speed)
         L.orc_sonicEnableNonlinearSpeedup(h, nl); s.enable_nonlinear(nl)
         L.orc_sonicSetDurationFeedbackStrength(h, fb); s.set_feedback(fb)
@@ -214,6 +224,7 @@ def test_life_cycle_fuzz(orc, seed):
                 log.append(("w", seg.size // ch))
                 assert L.orc_sonicWriteShortToStream(h, orc.sptr(seg), seg.size // ch) == 1
                 assert s.write_short(seg) == 1, tag + (s.L.speedyHipLastError(),)
+                assert got_cb == ref_cb, tag + ("callbacks", pos, log[-12:])
             if rng.random() < 0.7:
                 r = int(rng.integers(1, 8193))
                 k = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), r)
