@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <string>
+#include <cmath>
 #include <vector>
 
 #include "../../include/sonic2.h"
@@ -180,6 +181,10 @@ sonicStream sonicCreateStream(int sampleRate, int numChannels) {
   }
   const SpxPlanDev* plan = spx_internal_shared_plan(sampleRate, g_match_matlab);
   if (!plan) { g_api_err = "sonicCreateStream: plan creation failed"; return nullptr; }
+  if (spx_walk_lds_bytes(*plan, numChannels, false) > 160 * 1024) {  // one CU's LDS
+    g_api_err = "sonicCreateStream: too many channels for the walk kernel's LDS window";
+    return nullptr;
+  }
   sonicStream s = new sonicStreamStruct();
   s->plan = plan;
   (void)hipGetDevice(&s->device);
@@ -489,8 +494,21 @@ static bool enter_rate_mode(sonicStream s) {
   return true;
 }
 
+// The reference stores whatever float it is given; most values outside the documented ranges have no defined behaviour
+// there (a speed <= 0 makes the TSM stage's step counts negative).  Here the next write / flush refuses them.
+static bool settings_ok(sonicStream s) {
+  if (!(s->globalSpeed > 0.0f) || !std::isfinite(s->globalSpeed)) { g_api_err = "sonicSetSpeed: speed must be finite and > 0"; return false; }
+  if (!(s->nonlinearFactor >= 0.0f && s->nonlinearFactor <= 1.0f)) {
+    g_api_err = "sonicEnableNonlinearSpeedup: factor outside [0, 1] (sonic2.h:73-76; the blended speed could reach 0)";
+    return false;
+  }
+  if (!(s->rate > 0.0f) || !std::isfinite(s->rate)) { g_api_err = "sonicSetRate: rate must be finite and > 0"; return false; }
+  if (!std::isfinite(s->feedbackStrength)) { g_api_err = "sonicSetDurationFeedbackStrength: not finite"; return false; }
+  return true;
+}
+
 static int write_shorts(sonicStream s, const short* in, int sampleCount) {
-  if (s->failed) return 0;
+  if (s->failed || !settings_ok(s)) return 0;
   (void)hipSetDevice(s->device);
   if (s->rate != 1.0f && !s->rateMode && !enter_rate_mode(s)) return 0;
   const int want = (s->nonlinearFactor != 0.0f) ? 1 : 0;  // soniclib.c:397
@@ -599,7 +617,7 @@ void sonicIntSetUserData(sonicStream s, void* p) { s->userData = p; }
 void* sonicIntGetUserData(sonicStream s) { return s->userData; }
 
 int sonicFlushStream(sonicStream s) {
-  if (s->failed) return 0;
+  if (s->failed || !settings_ok(s)) return 0;
   (void)hipSetDevice(s->device);
   if (s->mode < 0) s->mode = (s->nonlinearFactor != 0.0f) ? 1 : 0;
   if (s->rate != 1.0f && !s->rateMode && !enter_rate_mode(s)) return 0;

@@ -1,5 +1,6 @@
 // C-ABI of the batch engine (include/speedy_hip.h): plan tables, workspace layout, kernel launches.
 #include <math.h>
+#include <cmath>
 #include <stdio.h>
 #include <string.h>
 
@@ -352,7 +353,14 @@ static int build_streams(const SpxPlanDev& d, const spx_stream_job* jobs, int n,
   const int TF = d.tile_frames;
   for (int i = 0; i < n; i++) {
     const spx_stream_job& j = jobs[i];
-    if (j.channels < 1 || j.n_in < 0) return fail(-1, "spx_batch: bad job");
+    if (j.channels < 1 || j.n_in < 0 || j.in_off < 0 || j.out_off < 0 || j.out_cap < 0)
+      return fail(-1, "spx_batch: bad job (channels < 1 or a negative count / offset)");
+    // The reference takes any float here and has no defined behaviour for most of them (a speed <= 0 makes the TSM
+    // stage's step counts negative).  A job is refused unless every speed the TSM stage can be given is positive:
+    if (!(j.speed > 0.0f) || !std::isfinite(j.speed)) return fail(-1, "spx_batch: speed must be finite and > 0");
+    if (!(j.nonlinear >= 0.0f && j.nonlinear <= 1.0f))
+      return fail(-1, "spx_batch: nonlinear factor outside [0, 1] (sonic2.h:73-76; the blended speed could reach 0)");
+    if (!std::isfinite(j.feedback)) return fail(-1, "spx_batch: feedback strength is not finite");
     if (j.n_in >= (1ll << 30)) return fail(-1, "spx_batch: stream of 2^30 frames or more (in-kernel positions are 32-bit)");
     const bool nonlinear = j.nonlinear != 0.0f;
     const int64_t Ttot = nonlinear ? frames_for(d, j.n_in) : 0;
@@ -437,6 +445,8 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   const int cu_count = plan->cu_count;
   const size_t lds_per_cu = plan->lds_per_cu;
   const SpxWalkConfig wcfg = spx_walk_config(d, n, maxC, speedup_only);
+  if (wcfg.lds > 160 * 1024)   // one CU's LDS; the window holds every channel of maxRequired + 64 frames at least
+    return fail(-1, "spx_batch: too many channels for the walk kernel's LDS window");
   const size_t per_stream_lds = wcfg.lds + spx_tension_lds_bytes();
   const size_t per_stream_waves = (size_t)wcfg.waves + 4;  // walk (spx_launch_walk's choice) + tension
   bool co_resident = false, doubtful = false;

@@ -701,7 +701,8 @@ static __host__ __device__ inline WalkLds walk_lds_layout(const SpxPlanDev& P, i
   const int need = P.maxRequired + 2 * P.skip + 2;
   int wcap = 4096;
   if (wcap < 4 * need) wcap = 4 * need;
-  while ((size_t)wcap * (maxC > 1 ? maxC + 2 : 2) * 2 > 48 * 1024 && wcap > need + 64) wcap /= 2;
+  // many channels: a shorter window (every channel of it sits in LDS), but never shorter than one search needs
+  while ((size_t)wcap * (maxC > 1 ? maxC + 2 : 2) * 2 > 48 * 1024 && wcap > need + 64) wcap = wcap / 2 > need + 64 ? wcap / 2 : need + 64;
   wcap = (wcap + 7) & ~7;
   L.wcap = wcap;
   int o = 0;

@@ -426,3 +426,43 @@ def test_thousand_tiny_streams(orc):
         if n not in cache:
             cache[n] = _oracle(orc, streams[i], rate, 1, 3.5, 1.0, 0.0, False)["out"]
         assert np.array_equal(outs[i], cache[n]), (i, n)
+
+
+def test_jobs_outside_the_defined_ranges_are_refused():
+    """The reference stores any float (soniclib.c:177-182,555-570) and has no defined behaviour for most of them -- a speed
+    <= 0 gives the TSM stage negative step counts.  spx_batch_run refuses such jobs before anything is launched."""
+    from speedy_amd.batch import Batch, Plan
+    plan = Plan(16000, False)
+    x = np.zeros(4000, np.int16)
+    nan, inf = float("nan"), float("inf")
+    bad = [("speed", 0.0), ("speed", -1.0), ("speed", nan), ("speed", inf), ("nonlinear", -0.1), ("nonlinear", 1.5),
+           ("nonlinear", nan), ("feedback", nan), ("feedback", inf), ("channels", 0), ("n_in", -1), ("in_off", -8),
+           ("out_off", -8), ("out_cap", -1)]
+    for field, value in bad:
+        b = Batch(plan, [x.size], 1, 2.0, 1.0, 0.0)
+        b.upload([x])
+        setattr(b.jobs[0], field, value)
+        with pytest.raises(RuntimeError):
+            b.run()
+    b = Batch(plan, [x.size], 1, 2.0, 1.0, 0.0)      # and the batch object is still good for a valid job afterwards
+    b.upload([x])
+    b.run()
+    assert b.results()[0].size > 0
+    # too many channels for one CU's LDS window (the general kernel keeps every channel of the window in LDS)
+    b = Batch(plan, [64], 1, 2.0, 0.0, 0.0)
+    b.jobs[0].channels = 400
+    with pytest.raises(RuntimeError):
+        b.run()
+
+
+@pytest.mark.parametrize("rate,ch", [(16000, 64), (22050, 40), (22050, 64), (44100, 40), (8000, 100), (48000, 24)])
+def test_many_channels(orc, rate, ch):
+    """The general walk kernel keeps every channel of its window in LDS and shortens the window as channels grow -- never
+    below what one pitch search needs (a 22.05 kHz stream with 40 channels once got a window shorter than that)."""
+    from speedy_amd.batch import compress_batch
+    from speedy_amd.synth import speech_like
+    x = speech_like(int(0.6 * rate), rate, seed=ch, channels=ch)
+    for speed, nl in ((2.0, 1.0), (0.7, 0.0), (3.5, 1.0)):
+        ref = orc.compress_sound(x, rate, ch, speed, nl, 0.0, False, chunk=1000 if nl else x.size // ch)
+        outs, _ = compress_batch([x], rate, ch, speed, nl, 0.0, False)
+        assert np.array_equal(outs[0], ref["out"]), (rate, ch, speed, nl)

@@ -530,3 +530,27 @@ def test_ten_minute_soak_memory_stays_flat(orc):
     assert np.array_equal(np.concatenate(outs), ref)
     a, b = free_at[120 * rate], free_at[600 * rate - 1000]
     assert abs(a - b) <= 8 << 20, (a, b)   # the whole 10-minute input alone would be 19 MB, its taps far more
+
+
+def test_settings_outside_the_defined_ranges_are_refused():
+    """sonicSetSpeed / sonicSetRate / sonicEnableNonlinearSpeedup return nothing (sonic2.h:70-84): the next write or
+    flush refuses a value the TSM stage has no defined behaviour for, with a message, and works again once it is fixed."""
+    from speedy_amd.sonic2 import SonicStream
+    x = np.zeros(2000, np.int16)
+    nan = float("nan")
+    for setter, bad, good in [("set_speed", [0.0, -2.0, nan, float("inf")], 2.0),
+                              ("enable_nonlinear", [-0.5, 1.01, nan], 1.0),
+                              ("set_rate", [0.0, -1.0, nan], 1.0),
+                              ("set_feedback", [nan], 0.0)]:
+        s = SonicStream(16000, 1, False)
+        s.set_speed(2.0); s.enable_nonlinear(1.0)
+        assert s.write_short(x) == 1
+        for v in bad:
+            getattr(s, setter)(v)
+            assert s.write_short(x) == 0 and s.L.speedyHipLastError() != b"", (setter, v)
+            assert s.flush() == 0, (setter, v)
+        getattr(s, setter)(good)
+        assert s.write_short(x) == 1 and s.flush() == 1
+        s.close()
+    with pytest.raises(RuntimeError):                       # more channels than one CU's LDS window can hold
+        SonicStream(16000, 400, False)
