@@ -436,7 +436,7 @@ static int launch_job(sonicStream s, bool flush) {
     td.spectrogram = s->tSpec.base() - fo * P.N; td.normalized = s->tNorm.base() - fo * P.W;
   }
   if (nonlinear && T > fa) {
-    const int TF = spx_analysis_tile_frames();
+    const int TF = P.tile_frames;
     const int tiles = (int)((T - fa + TF - 1) / TF);
     spx_launch_analysis(P, s->dJob, 1, tiles, s->dIn.p, s->dRec.p, td, nullptr, nullptr, s->hs);
   }

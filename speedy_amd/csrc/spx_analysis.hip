@@ -975,8 +975,12 @@ void spx_launch_analysis_frames(const SpxPlanDev& P, const SpxStreamDev* streams
                                 bool preemph, SpxFrameRec* rec, SpxTapsDev taps, hipStream_t st) {
   if (n_tiles <= 0) return;
   SpxPlanDev Q = P;
-  Q.tile_frames = SPX_TF;
+  if (Q.tile_frames != SPX_TF_SMALL) Q.tile_frames = SPX_TF;   // (the plan's tile is the small one above about 49 kHz)
   const size_t lds = analysis_lds_bytes(Q, false);  // the plan-driven instantiation
-  hipLaunchKernelGGL((spx_analysis_kernel<SPX_TF, 0>), dim3(n_tiles), dim3(SPX_BLOCK), lds, st, Q, streams, 1,
-                     (const int16_t*)nullptr, rec, taps, (const int*)nullptr, (int*)nullptr, frames, preemph ? 1 : 2);
+  if (Q.tile_frames == SPX_TF_SMALL)
+    hipLaunchKernelGGL((spx_analysis_kernel<SPX_TF_SMALL, 0>), dim3(n_tiles), dim3(SPX_BLOCK), lds, st, Q, streams, 1,
+                       (const int16_t*)nullptr, rec, taps, (const int*)nullptr, (int*)nullptr, frames, preemph ? 1 : 2);
+  else
+    hipLaunchKernelGGL((spx_analysis_kernel<SPX_TF, 0>), dim3(n_tiles), dim3(SPX_BLOCK), lds, st, Q, streams, 1,
+                       (const int16_t*)nullptr, rec, taps, (const int*)nullptr, (int*)nullptr, frames, preemph ? 1 : 2);
 }

@@ -172,7 +172,10 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
     fail(-1, "spx_plan_create: too many DFT stages");
     return nullptr;
   }
-  if (spx_analysis_lds_bytes(d) > 160 * 1024) {  // one CU's LDS; reached above about 49 kHz
+  d.tile_frames = spx_analysis_tile_frames();
+  if (spx_analysis_lds_bytes(d) > 160 * 1024)    // one CU's LDS: above about 49 kHz the plan's tile is the 8-frame one
+    d.tile_frames = spx_analysis_small_tile_frames();
+  if (spx_analysis_lds_bytes(d) > 160 * 1024) {  // ... and above about 61 kHz not even that fits (four waves' DFT work areas)
     delete p;
     fail(-1, "spx_plan_create: sample rate too high for the analysis tile (LDS)");
     return nullptr;
@@ -181,7 +184,6 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
   d.maxPeriod = sample_rate / 65;
   d.maxRequired = 2 * d.maxPeriod;
   d.skip = sample_rate > 4000 ? sample_rate / 4000 : 1;
-  d.tile_frames = spx_analysis_tile_frames();
   d.alpha = (float)exp(-1.0 / (float)100.0);          // speedy.c:67 with time constant kFrameRateHz
   d.one_minus_alpha = 1 - d.alpha;                     // float, speedy.c:74
 

@@ -466,3 +466,29 @@ def test_many_channels(orc, rate, ch):
         ref = orc.compress_sound(x, rate, ch, speed, nl, 0.0, False, chunk=1000 if nl else x.size // ch)
         outs, _ = compress_batch([x], rate, ch, speed, nl, 0.0, False)
         assert np.array_equal(outs[0], ref["out"]), (rate, ch, speed, nl)
+
+
+@pytest.mark.parametrize("rate", [1000, 3999, 4001, 7919, 12345, 24000, 37800, 50000, 60000])
+def test_unusual_sample_rates(orc, rate):
+    """Rates nobody tunes for: below the 4 kHz decimation threshold (skip = 1), prime window lengths (generic and Rader
+    DFT stages), and the range above 49 kHz where the plan falls back to the 8-frame analysis tile.  Mono and stereo,
+    linear and nonlinear, taps included."""
+    from speedy_amd.batch import compress_batch
+    from speedy_amd.synth import speech_like
+    for ch in (1, 2):
+        x = speech_like(int(1.0 * rate), rate, seed=rate % 97, channels=ch)
+        for speed, nl in ((2.0, 1.0), (0.7, 0.0), (3.5, 1.0), (1.3, 0.0)):
+            ref = orc.compress_sound(x, rate, ch, speed, nl, 0.0, False, chunk=1000 if nl else x.size // ch)
+            outs, b = compress_batch([x], rate, ch, speed, nl, 0.0, False, taps=(nl != 0))
+            assert np.array_equal(outs[0], ref["out"]), (rate, ch, speed, nl)
+            if nl:
+                t = b.tap_arrays(0)
+                for key in ("tension", "speed", "features"):
+                    assert np.array_equal(t[key], ref[key]), (rate, ch, speed, nl, key)
+
+
+def test_sample_rates_outside_the_supported_range_fail_loudly():
+    from speedy_amd.batch import Plan
+    for rate in (999, 62000, 96000, 128000):
+        with pytest.raises(RuntimeError):
+            Plan(rate, False)

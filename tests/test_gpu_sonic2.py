@@ -554,3 +554,13 @@ def test_settings_outside_the_defined_ranges_are_refused():
         s.close()
     with pytest.raises(RuntimeError):                       # more channels than one CU's LDS window can hold
         SonicStream(16000, 400, False)
+
+
+@pytest.mark.parametrize("rate_hz,ch", [(50000, 1), (60000, 2), (3999, 1)])
+def test_streaming_at_rates_with_the_small_analysis_tile(orc, rate_hz, ch):
+    """Above 49 kHz the plan's analysis tile is the 8-frame one (LDS); the streaming API sizes its launches from the plan."""
+    from speedy_amd.synth import speech_like
+    x = speech_like(int(1.2 * rate_hz), rate_hz, seed=5, channels=ch)
+    ro, rg, co, cg = _rate_streams(orc, x, rate_hz, ch, 3.0, 1.0, False, 1777, {"flush_at": 9})
+    assert co == cg
+    assert np.array_equal(ro, rg) and ro.size > 0

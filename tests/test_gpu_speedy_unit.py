@@ -170,3 +170,26 @@ def test_first_tension_call_is_the_skipped_one_whatever_its_time(orc):
             got += 1
     assert got == 30 and not asked
     g.close()
+
+
+def test_unit_api_at_a_rate_with_the_small_analysis_tile(orc):
+    """50 kHz: the float-frame analysis launch takes the plan's 8-frame tile (the 16-frame one does not fit the LDS)."""
+    from speedy_amd.synth import speech_like
+    rate = 50000
+    x = speech_like(rate, rate, seed=9)
+    g, o = _hip(rate, False), orc.Speedy(rate, False)
+    W, B = g.frame_size, g.frame_step
+    out_t = 0
+    for j in range(40):
+        fr = x[20 * B + j * B:20 * B + j * B + W]
+        g.add_data_short(fr, j + 1)
+        o.add_data_short(fr, j + 1)
+        assert np.array_equal(g.spectrogram(), o.spectrogram()), j
+        okg, vg = g.compute_tension(out_t)
+        oko, vo = o.compute_tension(out_t)
+        assert okg == oko
+        if okg:
+            assert np.float32(vg) == np.float32(vo), (j, vg, vo)
+            out_t += 1
+    assert out_t > 20
+    g.close()
