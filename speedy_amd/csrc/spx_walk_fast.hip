@@ -914,6 +914,14 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         nIn = 1;
         const pos_t remainingS = avail - base;
         expected = out_n + uni((int)(((float)remainingS / tailSpeed + 0) / 1.0f + 0.5f));
+        if constexpr (NWC == 0 && MCH) {
+          // a cross-fade still waiting to be written takes its ramps from the input at wbase + offset (several channels:
+          // the window holds the mean only): write it while wbase is still the window it was decided in
+          if (xf_n > 0) {
+            fast_outputs<64 * NWM, MCH>(X, tid, xf_n, xf_down, xf_period, xf_out, 0, 0, 0, limit, wbase);
+            xf_n = 0;
+          }
+        }
         limit = avail;  // everything from here on reads as the flush's zero padding
         wbase = -1;     // the window may hold samples past the new limit: the next step refills it
       }

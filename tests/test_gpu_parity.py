@@ -242,6 +242,26 @@ def test_config4_one_gpu_shard_full_size(orc):
 
 
 @pytest.mark.parametrize("chunks", [2, 5])
+def test_time_chunk_pipelining_speed_up_batch(orc, chunks):
+    """The same with every stream speeding up (the speed-up walk kernels, mono and multi-channel, carry their state from
+    one time range to the next)."""
+    from speedy_amd._lib import lib
+    from speedy_amd.synth import speech_like
+    for rate in (16000, 22050):
+        chs = [1 + (i % 3) for i in range(6)]
+        streams = [speech_like(30000 + 777 * i, rate, seed=40 + i, channels=chs[i]) for i in range(6)]
+        speeds, nls = [3.5, 1.5, 2.0, 2.6, 3.5, 1.2], [1.0, 1.0, 0.0, 1.0, 1.0, 1.0]
+        try:
+            lib().spx_set_pipeline_chunks(chunks)
+            outs, b = _batch(streams, rate, chs, speeds, nls, 0.0, False, taps=False)
+        finally:
+            lib().spx_set_pipeline_chunks(1)
+        for i, x in enumerate(streams):
+            ref = _oracle(orc, x, rate, chs[i], speeds[i], nls[i], 0.0, False)
+            assert np.array_equal(outs[i], ref["out"]), (rate, i)
+
+
+@pytest.mark.parametrize("chunks", [2, 5])
 def test_time_chunk_pipelining_is_bit_exact(orc, chunks):
     """spx_set_pipeline_chunks: the batch call split into time ranges (analysis of range c+1 overlapping the walk of
     range c on a second HIP stream) must give the same bytes as the single-range call."""
@@ -492,3 +512,26 @@ def test_sample_rates_outside_the_supported_range_fail_loudly():
     for rate in (999, 62000, 96000, 128000):
         with pytest.raises(RuntimeError):
             Plan(rate, False)
+
+
+@pytest.mark.parametrize("rate,n_streams,multi,slow", [(16000, 700, False, False), (22050, 400, True, False),
+                                                       (16000, 350, True, True)])
+def test_large_ragged_batches(orc, rate, n_streams, multi, slow):
+    """Hundreds of streams of 0 .. 2.5 s in one call -- the large-batch path (pipelined time chunks, streams that end
+    in different chunks, the sequential fallback when the co-residency bound says so) -- every stream against the oracle."""
+    from speedy_amd.batch import compress_batch
+    from speedy_amd.synth import speech_like
+    rng = np.random.default_rng(rate + n_streams)
+    chs, speeds, nls, xs = [], [], [], []
+    for i in range(n_streams):
+        ch = int(rng.choice([1, 1, 2, 3])) if multi else 1
+        n = int(rng.integers(0, int(2.5 * rate))) if i % 7 else int(rng.integers(0, 300))
+        sp_ = float(np.round(rng.uniform(0.5, 0.95) if (slow and i % 5 == 0) else rng.uniform(1.05, 4.5), 3))
+        chs.append(ch); speeds.append(sp_)
+        nls.append(float(rng.choice([0.0, 1.0, 1.0, 1.0])))
+        xs.append(speech_like(n, rate, seed=1000 + i, channels=ch))
+    outs, _ = compress_batch(xs, rate, chs, speeds, nls, 0.0, False)
+    for i in range(n_streams):
+        ref = orc.compress_sound(xs[i], rate, chs[i], speeds[i], nls[i], 0.0, False,
+                                 chunk=1000 if nls[i] != 0 else max(xs[i].size // chs[i], 1), taps=False)
+        assert np.array_equal(outs[i], ref["out"]), (i, chs[i], xs[i].size // chs[i], speeds[i], nls[i])
