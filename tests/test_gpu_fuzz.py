@@ -240,3 +240,44 @@ def test_life_cycle_fuzz(orc, seed):
                 break
         L.orc_sonicDestroyStream(h)
         s.close()
+
+
+@pytest.mark.parametrize("seed", list(range(41, 44)) + list(range(4000, 4000 + SOAK // 10)))
+def test_big_batch_fuzz(orc, seed):
+    """Batches of 257 .. 600 streams (the large-batch path: speed-up kernels without output waves, pipelined time
+    chunks, the sequential fallback) with per-stream channels, lengths 0 .. 1.5 s, speeds including exactly 1 and just
+    above it, nonlinear factors 0 / 0.5 / 1, feedback, and the taps -- every stream against the oracle."""
+    from speedy_amd.batch import compress_batch
+    rng = np.random.default_rng(seed)
+    rate = int(rng.choice([8000, 11025, 16000, 16000, 22050, 22050, 44100]))
+    k = int(rng.integers(257, 601))
+    slow = bool(rng.integers(0, 4) == 0)              # one batch in four contains slow-down jobs (general kernel)
+    multi = bool(rng.integers(0, 2))
+    with_taps = bool(rng.integers(0, 2))
+    chs, speeds, nls, fbs, xs = [], [], [], [], []
+    for i in range(k):
+        ch = int(rng.choice([1, 1, 2, 3, 5])) if multi else 1
+        n = int(rng.integers(0, int(1.5 * rate))) if rng.random() < 0.9 else int(rng.integers(0, 200))
+        u = rng.random()
+        if u < 0.05:
+            sp_ = 1.0
+        elif u < 0.10:
+            sp_ = float(np.float32(1.0 + rng.uniform(0, 3e-5)))
+        elif slow and u < 0.3:
+            sp_ = float(np.round(rng.uniform(0.4, 0.95), 3))
+        else:
+            sp_ = float(np.round(rng.uniform(1.05, 5.0), 3))
+        chs.append(ch); speeds.append(sp_)
+        nls.append(float(rng.choice([0.0, 1.0, 1.0, 0.5]))); fbs.append(float(rng.choice([0.0, 0.0, 0.1])))
+        xs.append(_signal(KINDS[int(rng.integers(0, len(KINDS)))], n, rate, ch, rng))
+    mm = bool(rng.integers(0, 2))
+    outs, b = compress_batch(xs, rate, chs, speeds, nls, fbs, mm, taps=with_taps)
+    for i in range(k):
+        ref = orc.compress_sound(xs[i], rate, chs[i], speeds[i], nls[i], fbs[i], mm,
+                                 chunk=1000 if nls[i] != 0 else max(xs[i].size // chs[i], 1), taps=with_taps)
+        tag = (seed, i, rate, chs[i], xs[i].size // chs[i], speeds[i], nls[i], fbs[i], mm)
+        assert np.array_equal(outs[i], ref["out"]), tag
+        if with_taps and nls[i] != 0:
+            taps = b.tap_arrays(i)
+            for key in ("tension", "speed", "features"):
+                assert np.array_equal(taps[key], ref[key]), tag + (key,)
