@@ -56,3 +56,48 @@ def test_two_threads_same_bytes_as_solo(shared_plan):
         t.join()
     assert not errors, errors
     assert got[0] == solo[0] and got[1] == solo[1]
+
+
+def test_streaming_api_from_four_threads(orc):
+    """Four host threads, each with its own sonicStream (different rates, channels and modes), writing and reading at
+    the same time: the streams share nothing but the cached plans, so each must deliver exactly what it delivers alone."""
+    import threading
+    from speedy_amd.sonic2 import SonicStream
+    from speedy_amd.synth import speech_like
+    cfgs = [(16000, 1, 3.5, 1.0), (22050, 2, 2.0, 1.0), (16000, 1, 0.7, 0.0), (44100, 1, 1.5, 1.0)]
+    xs = [speech_like(3 * r, r, seed=300 + i, channels=c) for i, (r, c, _, _) in enumerate(cfgs)]
+    refs = [orc.compress_sound(xs[i], r, c, sp, nl, 0.0, False, chunk=1000, taps=False)["out"]
+            for i, (r, c, sp, nl) in enumerate(cfgs)]
+    outs, errs = [None] * len(cfgs), []
+    start = threading.Barrier(len(cfgs))
+
+    def work(i):
+        try:
+            r, c, sp, nl = cfgs[i]
+            s = SonicStream(r, c, False)
+            s.set_speed(sp); s.enable_nonlinear(nl); s.set_feedback(0.0)
+            got = []
+            start.wait()
+            x = xs[i]
+            for pos in range(0, x.size // c, 1000):
+                assert s.write_short(np.ascontiguousarray(x[pos * c:(pos + 1000) * c])) == 1
+                got.append(s.read_short(4096))
+            assert s.flush() == 1
+            while True:
+                g = s.read_short(4096)
+                if g.size == 0:
+                    break
+                got.append(g)
+            s.close()
+            outs[i] = np.concatenate(got)
+        except Exception as e:   # noqa: BLE001 -- reported in the main thread
+            errs.append((i, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(cfgs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(len(cfgs)):
+        assert np.array_equal(outs[i], refs[i]), cfgs[i]
