@@ -713,8 +713,8 @@ int spx_copy_to_device(void* dst, const void* src, size_t bytes, void* hs) {
 // ---- output packing: offsets by one workgroup (serial prefix over <= a few thousand streams), then one workgroup per
 // stream copying its frames with coalesced loads/stores ----
 __global__ void __launch_bounds__(256)
-spx_pack_offsets_kernel(const int64_t* __restrict__ n_out, const int* __restrict__ channels, int n,
-                        int64_t* __restrict__ offsets) {
+spx_pack_offsets_kernel(const int64_t* __restrict__ n_out, const int* __restrict__ channels,
+                        const int64_t* __restrict__ caps, int n, int64_t* __restrict__ offsets) {
   // exclusive prefix sum of the streams' element counts: 256 streams per pass, Hillis-Steele scan in LDS, running carry
   __shared__ int64_t sh[256];
   __shared__ int64_t carry;
@@ -726,8 +726,11 @@ spx_pack_offsets_kernel(const int64_t* __restrict__ n_out, const int* __restrict
     int64_t v = 0;
     if (i < n) {
       const int64_t k = n_out[i];
-      // a negative count flags an overflowed stream (its frames are still there); INT64_MIN a lost producer (nothing)
-      v = (k == INT64_MIN ? 0 : (k > 0 ? k : -k)) * channels[i];
+      // a negative count flags an overflowed stream: the frames that fitted its capacity are there, the count says how
+      // many there would have been; INT64_MIN a lost producer (nothing)
+      int64_t f = (k == INT64_MIN ? 0 : (k > 0 ? k : -k));
+      if (f > caps[i]) f = caps[i];
+      v = f * channels[i];
     }
     sh[t] = v;
     __syncthreads();
@@ -771,7 +774,7 @@ int spx_batch_pack_outputs(const spx_stream_job* jobs, int n, const int16_t* out
   hipStream_t st = static_cast<hipStream_t>(hs);
   // small per-stream tables (channels, output offsets): a stream-ordered allocation, freed in stream order after the
   // kernels that read it, so concurrent calls on other streams never share it
-  const size_t need = (size_t)n * (sizeof(int64_t) + sizeof(int));
+  const size_t need = (size_t)n * (2 * sizeof(int64_t) + sizeof(int));
   void* d_tab = nullptr;
   if (hipMallocAsync(&d_tab, need, st) != hipSuccess) return fail(-2, "spx_batch_pack_outputs: allocation failed");
   // host side of the table: a per-thread pinned slot, reused once the copy that last read it has retired
@@ -786,13 +789,14 @@ int spx_batch_pack_outputs(const spx_stream_job* jobs, int n, const int16_t* out
   }
   unsigned char* h = static_cast<unsigned char*>(G.p);
   int64_t* h_off = reinterpret_cast<int64_t*>(h);
-  int* h_ch = reinterpret_cast<int*>(h + (size_t)n * sizeof(int64_t));
-  for (int i = 0; i < n; i++) { h_off[i] = jobs[i].out_off; h_ch[i] = jobs[i].channels; }
+  int64_t* h_cap = h_off + n;
+  int* h_ch = reinterpret_cast<int*>(h + (size_t)n * 2 * sizeof(int64_t));
+  for (int i = 0; i < n; i++) { h_off[i] = jobs[i].out_off; h_cap[i] = jobs[i].out_cap; h_ch[i] = jobs[i].channels; }
   HIPCHK(hipMemcpyAsync(d_tab, h, need, hipMemcpyHostToDevice, st));
   HIPCHK(hipEventRecord(G.done, st));
   const int64_t* d_off = reinterpret_cast<const int64_t*>(d_tab);
-  const int* d_ch = reinterpret_cast<const int*>(static_cast<unsigned char*>(d_tab) + (size_t)n * sizeof(int64_t));
-  hipLaunchKernelGGL(spx_pack_offsets_kernel, dim3(1), dim3(256), 0, st, n_out, d_ch, n, offsets);
+  const int* d_ch = reinterpret_cast<const int*>(static_cast<unsigned char*>(d_tab) + (size_t)n * 2 * sizeof(int64_t));
+  hipLaunchKernelGGL(spx_pack_offsets_kernel, dim3(1), dim3(256), 0, st, n_out, d_ch, d_off + n, n, offsets);
   hipLaunchKernelGGL(spx_pack_copy_kernel, dim3(n, 4), dim3(256), 0, st, out, d_off, offsets, packed);
   (void)hipFreeAsync(d_tab, st);
   HIPCHK(hipGetLastError());

@@ -535,3 +535,43 @@ def test_large_ragged_batches(orc, rate, n_streams, multi, slow):
         ref = orc.compress_sound(xs[i], rate, chs[i], speeds[i], nls[i], 0.0, False,
                                  chunk=1000 if nls[i] != 0 else max(xs[i].size // chs[i], 1), taps=False)
         assert np.array_equal(outs[i], ref["out"]), (i, chs[i], xs[i].size // chs[i], speeds[i], nls[i])
+
+
+@pytest.mark.parametrize("ch,speed,nl,n_streams", [(1, 3.5, 1.0, 3), (2, 1.5, 1.0, 3), (1, 0.6, 0.0, 3), (1, 2.0, 0.0, 300)])
+def test_output_capacity_too_small_is_reported_and_contained(orc, ch, speed, nl, n_streams):
+    """A job whose out_cap is smaller than what the stream produces: its n_out comes back NEGATIVE (minus the frames it
+    would have produced), the frames that fitted are the oracle's first out_cap frames, nothing is written past its
+    region (the neighbour's output is intact) and spx_batch_pack_outputs gathers no more than the capacity."""
+    import torch
+    from speedy_amd.batch import Batch, Plan
+    from speedy_amd.synth import speech_like
+    rate = 16000
+    plan = Plan(rate, False)
+    lens = [12000 + 500 * (i % 5) for i in range(n_streams)]
+    xs = [speech_like(n, rate, seed=90 + i, channels=ch) for i, n in enumerate(lens)]
+    refs = [orc.compress_sound(x, rate, ch, speed, nl, 0.0, False, chunk=1000 if nl else x.size // ch, taps=False)["out"]
+            for x in xs]
+    b = Batch(plan, lens, ch, speed, nl, 0.0)
+    b.upload(xs)
+    victim = 1
+    cap = refs[victim].size // ch // 3
+    b.jobs[victim].out_cap = cap                      # the region stays as large as before; only the declared capacity shrinks
+    b.d_out.fill_(12345)
+    b.run()
+    with pytest.raises(RuntimeError):
+        b.results()
+    nout = b.d_nout.cpu().numpy()
+    assert nout[victim] == -(refs[victim].size // ch)
+    out = b.d_out.cpu().numpy()
+    o0 = b.out_offs[victim]
+    assert np.array_equal(out[o0:o0 + cap * ch], refs[victim][:cap * ch])
+    assert (out[o0 + cap * ch:b.out_offs[victim + 1]] == 12345).all()            # nothing past the declared capacity
+    for i in range(n_streams):
+        if i != victim:
+            assert nout[i] == refs[i].size // ch
+            assert np.array_equal(out[b.out_offs[i]:b.out_offs[i] + refs[i].size], refs[i]), i
+    packed, offs = b.pack_outputs()
+    torch.cuda.synchronize()
+    offs = offs.cpu().numpy()
+    assert offs[victim + 1] - offs[victim] == cap * ch
+    assert np.array_equal(packed.cpu().numpy()[offs[victim]:offs[victim + 1]], refs[victim][:cap * ch])
