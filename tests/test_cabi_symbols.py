@@ -74,3 +74,22 @@ def test_product_does_not_import_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle|#include\s+\"[^\"]*orc_|liborc", t, flags=re.M):
                     bad.append(f)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("header", ["speedy_hip.h", "sonic2.h", "speedy.h"])
+def test_headers_are_plain_c(header, tmp_path):
+    """The boundary is a C ABI: every header compiles as strict C99 (and as C++) on its own, with no HIP header in reach."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "%s"\nint main(void) { return 0; }\n' % header)
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++",
+                           "-I", inc, str(src)])
+
+
+def test_c_example_builds():
+    """tools/batch_example.c (INTEGRATION.md section 2 as a program) builds with gcc -std=c99 -pedantic -Werror."""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "speedy_amd", "csrc"), "example"])
+    assert os.path.exists(os.path.join(ROOT, "speedy_amd", "lib", "batch_example"))

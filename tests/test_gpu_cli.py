@@ -112,3 +112,25 @@ def test_cli_feature_and_spectrogram_files(orc, tmp_path):
         assert got.shape == ref.shape, key
         bad = ~np.isclose(got, ref, rtol=1e-5, atol=1e-6, equal_nan=True)   # %g keeps 6 significant digits
         assert not bad.any(), (key, int(bad.sum()), got[bad][:4], ref[bad][:4])
+
+
+EXAMPLE = os.path.join(ROOT, "speedy_amd", "lib", "batch_example")
+
+
+@pytest.mark.parametrize("name,speed,nl,copies,split", [("tapestry.wav", 3.5, 1.0, 5, 0), ("tapestry.wav", 3.5, 1.0, 3, 1),
+                                                        ("tapestry22050.wav", 0.8, 0.0, 2, 0), ("tapestry.wav", 2.0, 1.0, 300, 1)])
+def test_c_batch_example(orc, tmp_path, name, speed, nl, copies, split):
+    """INTEGRATION.md section 2 as a plain C99 program (tools/batch_example.c: gcc -std=c99 -pedantic -Werror over
+    include/speedy_hip.h, no HIP headers): device memory through spx_device_alloc / spx_copy_*, one spx_batch_run or
+    spx_batch_analyze + spx_batch_walk, the device-side gather -- output equal to the oracle's."""
+    if not os.path.exists(EXAMPLE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "speedy_amd", "csrc"), "example"])
+    x, rate, ch = read_wav(name)
+    x = x[: 3 * rate * ch]
+    raw, out = str(tmp_path / "in.raw"), str(tmp_path / "out.raw")
+    x.astype("<i2").tofile(raw)
+    r = subprocess.run([EXAMPLE, raw, str(rate), str(ch), str(speed), str(nl), str(copies), str(split), out],
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    ref = orc.compress_sound(x, rate, ch, speed, nl, 0.0, False, chunk=1000 if nl else x.size // ch, taps=False)["out"]
+    assert np.array_equal(np.fromfile(out, dtype="<i2"), ref)
