@@ -37,3 +37,19 @@ def test_bench_two_ranks_same_bytes_as_solo(tmp_path):
         b.run()
         solo = [zlib.crc32(np.ascontiguousarray(o).tobytes()) for o in b.results()]
         assert got == solo, rank
+
+
+def test_rccl_collectives_of_the_n_rank_path_with_one_rank():
+    """The lease has one GPU, so RCCL cannot carry two ranks here -- but the calls bench.py and speedy_amd/dist.py make
+    at N > 1 (init with a bound device, device-side all_gather / all_reduce, barrier) do run on the nccl backend with a
+    world of one (tools/rccl_sanity.py, its own process: a process group is per process)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_sanity.py")], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0 and "rccl sanity ok" in r.stdout, (r.stdout[-1000:], r.stderr[-1000:])
+    assert "[[256, 40960000]]" in r.stdout
