@@ -96,7 +96,16 @@ struct sonicStreamStruct {  // speedyConnectionStruct + the parts of libsonic's 
   float feedbackStrength = 0.1f;    // soniclib.c:122
   float rate = 1.0f;
   int bufferSize = 0;               // 0 until the first nonlinear write (soniclib.c:195, sonic_test.cc:496)
-  int mode = -1;                    // -1 unknown, 0 linear, 1 nonlinear (fixed by the first write)
+  int mode = -1;                    // -1 unknown, 0 linear, 1 nonlinear: what the last write was (soniclib.c:397-399 decides per write)
+  // A stream that has been written in both modes ("mixed"): the ring sequence (what nonlinear writes brought: the
+  // analysis input, handed to the TSM stage buffer by buffer as tensions arrive) and the TSM stage's input (ring buffers
+  // in hand-over order, linear writes in between, as the reference interleaves them) are two different sequences.
+  // dIn / nIn stay the ring sequence; dTsm / tPhys hold the TSM input, filled by device-to-device copies of the ring
+  // buffers at hand-over time and by the linear writes.
+  bool mixed = false;
+  int64_t tPhys = 0;                // mixed: frames of TSM input materialised so far (physical index = TSM position - tsmShift)
+  int64_t handedHost = 0;           // ring buffers handed to the TSM stage so far (the host's mirror of the device count)
+  bool tensionStarted = false;      // the tension kernel's filter states have been initialised
   tensionFunction cbTension = nullptr;
   speedFunction cbSpeed = nullptr;
   featuresFunction cbFeatures = nullptr;
@@ -104,6 +113,7 @@ struct sonicStreamStruct {  // speedyConnectionStruct + the parts of libsonic's 
 
   hipStream_t hs = nullptr;
   SlideBuf<int16_t> dIn, dOut;      // elements = int16 values (frames * channels); dOut = what the TSM stage produces
+  SlideBuf<int16_t> dTsm;           // mixed streams: the TSM stage's input
   SlideBuf<int16_t> dFinal;         // rate mode: what the rate stage produces = what the stream delivers
   SpxRateState* dRate = nullptr;    // device record of the rate stage (directly behind dNOut)
   bool speedSet = false;            // sonicSetSpeed since the last job (SPX_F_SPEED_SET)
@@ -193,6 +203,7 @@ sonicStream sonicCreateStream(int sampleRate, int numChannels) {
   // the walk kernels refill their window from a position aligned down by 8 frames; right behind a flush that found
   // (almost) no input that lies up to 7 frames in front of the first input frame
   s->dIn.guard = 64 * (int64_t)numChannels;
+  s->dTsm.guard = s->dIn.guard;
   const size_t small = 256 + sizeof(SpxStreamState) + sizeof(int64_t) + sizeof(SpxRateState) + 64;
   if (hipStreamCreateWithFlags(&s->hs, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&s->evStaged, hipEventDisableTiming) != hipSuccess ||
@@ -212,7 +223,7 @@ void sonicDestroyStream(sonicStream s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   if (s->hs) (void)hipStreamSynchronize(s->hs);
-  s->dIn.release(s->hs); s->dOut.release(s->hs); s->dFinal.release(s->hs); s->dRec.release(s->hs); s->dScr.release(s->hs);
+  s->dIn.release(s->hs); s->dTsm.release(s->hs); s->dOut.release(s->hs); s->dFinal.release(s->hs); s->dRec.release(s->hs); s->dScr.release(s->hs);
   s->tTension.release(s->hs); s->tSpeed.release(s->hs); s->tFeatures.release(s->hs); s->tSpec.release(s->hs);
   s->tNorm.release(s->hs);
   if (s->hs) (void)hipStreamSynchronize(s->hs);
@@ -353,17 +364,43 @@ static void run_callbacks(sonicStream s, int64_t j0, int64_t j1, int64_t k_first
 // the staging area exists and nobody reads its job-table slot any more.
 static int launch_job(sonicStream s, bool flush) {
   const SpxPlanDev& P = *s->plan;
-  const bool nonlinear = s->mode == 1;
   const int64_t C = s->channels;
-  const int64_t T = nonlinear ? spx_internal_frames_for(P, s->nIn) : 0;
+  const int F = P.F, Pp = P.Pp, B = P.B;
+  // what this job is: a stream has a ring (analysis) sequence once it has been written in nonlinear mode; a job runs the
+  // analysis + tension kernels and the walk kernel's per-tension events when the stream is in nonlinear mode -- except
+  // the flush of a mixed stream: no new tension can exist then, its pending ring buffers (appended to the TSM input below)
+  // go one by one at the last speed, which the walk kernel's ring path does given a non-zero factor
+  const bool hasRing = s->mode == 1 || s->mixed;
+  const bool nonlinear = s->mode == 1 && !(s->mixed && flush);
+  const int64_t T = hasRing ? spx_internal_frames_for(P, s->nIn) : 0;
   const int64_t fa = s->framesDone;
   const bool taps = nonlinear && any_callback(s);
-  const int F = P.F, Pp = P.Pp;
+
+  // ---- ring buffers this job hands to the TSM stage (the kernel counts the same way: spx_walk.hip events) ----
+  const int64_t handedBefore = s->handedHost;
+  int64_t handedAfter = handedBefore;
+  if (hasRing) {
+    if (nonlinear) handedAfter = std::max<int64_t>(handedBefore, (T >= F) ? T - F + 1 : 0);  // one per tension frame, soniclib.c:354-369
+    if (flush) handedAfter = std::max<int64_t>(handedAfter, s->nIn / B);                    // every complete buffer, :538-550
+  }
+  if (s->mixed && handedAfter > handedBefore) {   // they join the TSM input behind whatever the linear writes put there
+    const int64_t n = (handedAfter - handedBefore) * B;
+    int64_t keepT = s->tsmBase - s->tsmShift - 16;
+    if (s->dirty) keepT = std::min(keepT, s->dTsm.origin / C);
+    if (keepT < 0) keepT = 0;
+    s->dTsm.filled = s->tPhys * C;
+    if (!s->dTsm.ensure(keepT * C, (s->tPhys + n) * C + 64, s->hs, 1 << 16)) return 0;
+    if (hipMemcpyAsync(s->dTsm.base() + s->tPhys * C, s->dIn.base() + handedBefore * B * C, sizeof(int16_t) * (size_t)(n * C),
+                       hipMemcpyDeviceToDevice, s->hs) != hipSuccess)
+      return 0;
+    s->tPhys += n;
+  }
+  const int64_t tsmLen = s->mixed ? s->tPhys : s->nIn;   // frames of TSM input that exist (flush paddings not counted)
 
   // ---- output window [outRead, need): what was produced as of the last synchronisation plus the most the TSM stage
   // can make of the input it had not consumed by then (flush padding included) ----
-  const int64_t unconsumed = s->nIn + s->tsmShift + 2 * (int64_t)P.maxRequired - s->tsmBase;
-  const int64_t bound = s->outKnown + spx_internal_out_bound(P, unconsumed, s->globalSpeed, nonlinear);
+  const int64_t unconsumed = tsmLen + s->tsmShift + 2 * (int64_t)P.maxRequired - s->tsmBase;
+  const int64_t bound = s->outKnown + spx_internal_out_bound(P, unconsumed, s->globalSpeed, hasRing);
   if (s->outBound < s->outKnown) s->outBound = s->outKnown;
   const int64_t need = std::max(bound, s->outBound);
   s->dOut.filled = s->outBound * C;
@@ -405,31 +442,46 @@ static int launch_job(sonicStream s, bool flush) {
         }
     }
   }
+  SlideBuf<int16_t>& tsmIn = s->mixed ? s->dTsm : s->dIn;   // what the walk kernel reads
   if (!s->dIn.p && !s->dIn.ensure(0, 64 * C, s->hs, 1 << 16)) return 0;  // a flush before any write: the kernels still
-                                                                         // get a real (empty, guarded) input array
-  // ---- the job: absolute stream coordinates through (possibly negative) base offsets ----
-  SpxStreamDev& J = *reinterpret_cast<SpxStreamDev*>(s->hPinned);
-  static_assert(sizeof(SpxStreamDev) <= SPX_STAGE_JOB, "job table slot");
-  memset(&J, 0, sizeof(J));
-  J.in_off = -s->dIn.origin; J.n_in = s->nIn;
-  J.out_off = -s->dOut.origin; J.out_cap = (s->dOut.origin + s->dOut.cap) / C;
-  J.frame_off = -s->dRec.origin; J.n_frames = (int32_t)T; J.frame_begin = (int32_t)fa;
-  J.channels = (int32_t)C;
-  J.flags = (s->started ? 0 : SPX_F_INIT) | (flush ? SPX_F_FLUSH : 0) | (s->rateMode ? SPX_F_NO_TRUNC : 0) |
-            (s->speedSet ? SPX_F_SPEED_SET : 0);
+  if (!tsmIn.p && !tsmIn.ensure(0, 64 * C, s->hs, 1 << 16)) return 0;    // get real (empty, guarded) input arrays
+  // ---- the jobs: absolute stream coordinates through (possibly negative) base offsets.  JA = what the analysis and
+  // tension kernels see (the ring sequence), JW = what the walk kernel sees (the TSM input): the same record unless the
+  // stream is mixed ----
+  static_assert(2 * 128 <= SPX_STAGE_JOB && sizeof(SpxStreamDev) <= 128, "job table slot");
+  SpxStreamDev& JA = *reinterpret_cast<SpxStreamDev*>(s->hPinned);
+  SpxStreamDev& JW = *reinterpret_cast<SpxStreamDev*>(s->hPinned + 128);
+  memset(s->hPinned, 0, 256);
+  JA.in_off = -s->dIn.origin; JA.n_in = s->nIn;
+  JA.out_off = -s->dOut.origin; JA.out_cap = (s->dOut.origin + s->dOut.cap) / C;
+  JA.frame_off = -s->dRec.origin; JA.n_frames = (int32_t)T; JA.frame_begin = (int32_t)fa;
+  JA.channels = (int32_t)C;
+  const int common = (flush ? SPX_F_FLUSH : 0) | (s->rateMode ? SPX_F_NO_TRUNC : 0) | (s->speedSet ? SPX_F_SPEED_SET : 0);
   s->speedSet = false;
-  J.speed = s->globalSpeed; J.nonlinear = nonlinear ? s->nonlinearFactor : 0.0f; J.feedback = s->feedbackStrength;
-  J.tsm_shift = s->tsmShift;
-  J.tension_skip = (int32_t)s->tensionSkip;
+  JA.flags = common | (s->tensionStarted ? 0 : SPX_F_INIT);
+  JA.speed = s->globalSpeed; JA.nonlinear = nonlinear ? s->nonlinearFactor : 0.0f; JA.feedback = s->feedbackStrength;
+  JA.tsm_shift = s->tsmShift;
+  JA.tension_skip = (int32_t)s->tensionSkip;
+  JA.first_tile = 0;
+  JW = JA;
+  JW.flags = common | (s->started ? 0 : SPX_F_INIT);
+  if (s->mixed) {
+    JW.in_off = -s->dTsm.origin; JW.n_in = s->tPhys;
+    JW.flags |= SPX_F_HANDED_IN | (nonlinear ? 0 : SPX_F_KEEP_SPEED);
+    JW.handed_in = (int32_t)handedBefore;
+    JW.ring_bufs = (int32_t)(s->nIn / B);
+    if (flush) JW.nonlinear = (s->nonlinearFactor != 0.0f) ? s->nonlinearFactor : 1.0f;  // the ring path; no tension event is pending
+  }
   // once a stream has run at a speed <= 1 its carried speed may be below 1: stay on the general kernel from then on
-  if (!(J.speed > 1.0f && J.nonlinear >= 0.0f && J.nonlinear <= 1.0f)) s->speedupOnly = false;
-  // SPX_F_NO_TRUNC is the general walk kernel's (the mono speed-up kernel is tuned to its register budget)
-  const bool speedupKernel = s->speedupOnly && !s->rateMode;
-  J.first_tile = 0;
-  if (hipMemcpyAsync(s->dJob, &J, sizeof(J), hipMemcpyHostToDevice, s->hs) != hipSuccess) return 0;
+  if (!(JA.speed > 1.0f && JA.nonlinear >= 0.0f && JA.nonlinear <= 1.0f)) s->speedupOnly = false;
+  // SPX_F_NO_TRUNC and the mixed-stream flags are the general walk kernel's (the speed-up kernels are tuned to their
+  // register budget)
+  const bool speedupKernel = s->speedupOnly && !s->rateMode && !s->mixed;
+  SpxStreamDev* dJobW = reinterpret_cast<SpxStreamDev*>(reinterpret_cast<unsigned char*>(s->dJob) + 128);
+  if (hipMemcpyAsync(s->dJob, s->hPinned, 256, hipMemcpyHostToDevice, s->hs) != hipSuccess) return 0;
   (void)hipEventRecord(s->evStaged, s->hs);
   SpxTapsDev td = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  const int64_t fo = J.frame_off;
+  const int64_t fo = JA.frame_off;
   if (taps) {  // tap rows are indexed frame_off + k: give the kernels bases that make that land in the sliding buffers
     td.tension = s->tTension.base() - fo; td.speed = s->tSpeed.base() - fo;
     td.features = s->tFeatures.base() - fo * SPX_FEATURE_COUNT;
@@ -440,9 +492,11 @@ static int launch_job(sonicStream s, bool flush) {
     const int tiles = (int)((T - fa + TF - 1) / TF);
     spx_launch_analysis(P, s->dJob, 1, tiles, s->dIn.p, s->dRec.p, td, nullptr, nullptr, s->hs);
   }
-  if (nonlinear) spx_launch_tension(P, s->dJob, 1, s->dState, s->dRec.p, s->dScr.p, td, nullptr, nullptr, s->hs);
-  spx_launch_walk(P, s->dJob, 1, (int)C, s->dIn.p, s->dOut.p, s->dNOut, s->dState, s->dScr.p, nullptr, speedupKernel,
-                  s->hs);
+  if (nonlinear) {
+    spx_launch_tension(P, s->dJob, 1, s->dState, s->dRec.p, s->dScr.p, td, nullptr, nullptr, s->hs);
+    s->tensionStarted = true;
+  }
+  spx_launch_walk(P, dJobW, 1, (int)C, tsmIn.p, s->dOut.p, s->dNOut, s->dState, s->dScr.p, nullptr, speedupKernel, s->hs);
   if (s->rateMode)
     spx_launch_rate(s->dRate, s->dState, s->dNOut, s->dOut.base(), s->dFinal.base(),
                     (s->dFinal.origin + s->dFinal.cap) / C, (int)C, oldR, newR, s->rate, s->rate == 1.0f ? 1 : 0,
@@ -451,14 +505,15 @@ static int launch_job(sonicStream s, bool flush) {
   s->started = true;
   s->dirty = true;
   s->outBound = need;
+  s->handedHost = handedAfter;
   const int64_t k_first = std::max(s->tensionDone, s->tensionSkip);
-  s->framesDone = T;
+  if (hasRing) s->framesDone = std::max(s->framesDone, nonlinear ? T : fa);
   if (nonlinear) s->tensionDone = std::max<int64_t>(k_first, (T >= F) ? T - F + 1 : 0);
   if (flush) {
     // soniclib.c:538-550: every complete ring buffer goes to the TSM stage at the last speed and the shim's read index
     // moves to its write index -- tension frames below it that were not computed yet never will be; sonicIntFlushStream
     // then pads 2*maxRequired zeros, which later input follows in TSM coordinates
-    if (nonlinear) {
+    if (hasRing) {
       s->tensionSkip = std::max(s->tensionSkip, s->nIn / P.B);
       s->tensionDone = std::max(s->tensionDone, s->tensionSkip);
     }
@@ -494,6 +549,32 @@ static bool enter_rate_mode(sonicStream s) {
   return true;
 }
 
+// The first write in the other mode (soniclib.c:397-399 looks at the factor on every write): from here on the TSM stage's
+// input is its own sequence.  Coming from linear mode it is everything written so far and the ring sequence starts
+// empty; coming from nonlinear mode it is the ring buffers handed over so far (the stage may still hold the last of
+// them), while the ring sequence keeps its unhanded buffers and its partial one.
+static bool enter_mixed(sonicStream s) {
+  if (!sync_stream(s)) return false;
+  const int64_t C = s->channels;
+  if (s->mode == 0) {
+    std::swap(s->dTsm, s->dIn);          // (the guards are equal)
+    s->tPhys = s->nIn;
+    s->nIn = 0;
+  } else {
+    const int64_t hi = s->handedHost * (int64_t)s->plan->B;
+    int64_t lo = std::max<int64_t>(0, s->tsmBase - s->tsmShift - 16);
+    lo = std::min(std::max(lo, s->dIn.origin / C), hi);
+    s->dTsm.filled = 0;
+    if (!s->dTsm.ensure(lo * C, hi * C + 64, s->hs, 1 << 16)) return false;
+    if (hi > lo && hipMemcpyAsync(s->dTsm.base() + lo * C, s->dIn.base() + lo * C, sizeof(int16_t) * (size_t)((hi - lo) * C),
+                                  hipMemcpyDeviceToDevice, s->hs) != hipSuccess)
+      return false;
+    s->tPhys = hi;
+  }
+  s->mixed = true;
+  return true;
+}
+
 // The reference stores whatever float it is given; most values outside the documented ranges have no defined behaviour
 // there (a speed <= 0 makes the TSM stage's step counts negative).  Here the next write / flush refuses them.
 static bool settings_ok(sonicStream s) {
@@ -511,36 +592,44 @@ static int write_shorts(sonicStream s, const short* in, int sampleCount) {
   if (s->failed || !settings_ok(s)) return 0;
   (void)hipSetDevice(s->device);
   if (s->rate != 1.0f && !s->rateMode && !enter_rate_mode(s)) return 0;
-  const int want = (s->nonlinearFactor != 0.0f) ? 1 : 0;  // soniclib.c:397
+  const int want = (s->nonlinearFactor != 0.0f) ? 1 : 0;  // soniclib.c:397: decided anew on every write
   if (s->mode < 0) s->mode = want;
-  if (s->mode != want) {
-    g_api_err = "switching between linear (factor 0) and nonlinear mode inside one stream is not supported";
-    return 0;
-  }
-  if (s->mode == 1 && s->bufferSize == 0) s->bufferSize = s->plan->B;  // sonicAllocateBuffers, soniclib.c:195
+  if (want == 1 && s->bufferSize == 0) s->bufferSize = s->plan->B;  // sonicAllocateBuffers, soniclib.c:195
   if (!in || sampleCount <= 0) return 1;
-  if (s->nIn + sampleCount + s->tsmShift >= (1ll << 30)) {
-    g_api_err = "stream longer than 2^30 frames is not supported";
-    return 0;
+  if (s->mode != want) {  // the other mode from now on: the ring sequence and the TSM input part ways
+    if (!s->mixed && !enter_mixed(s)) return 0;
+    s->mode = want;
   }
   const SpxPlanDev& P = *s->plan;
   const int64_t C = s->channels;
+  const bool toTsm = s->mixed && want == 0;   // a linear write of a mixed stream goes straight to the TSM input
+  if ((toTsm ? s->tPhys : s->nIn) + sampleCount + s->tsmShift >= (1ll << 30) ||
+      (s->mixed && s->tPhys + s->nIn + sampleCount + s->tsmShift >= (1ll << 30))) {
+    g_api_err = "stream longer than 2^30 frames is not supported";
+    return 0;
+  }
   // Without a read the host does not know how far the TSM stage has consumed its input: look every so often
   if (++s->writesSinceSync > 64 && !sync_stream(s)) return 0;
-  // oldest input frame either stage can still touch: the analysis halo (frame framesDone-1 starts at (framesDone-1)*B)
-  // and the TSM stage's buffered input (the window refill aligns down by 8 frames)
+  SlideBuf<int16_t>& dst = toTsm ? s->dTsm : s->dIn;
+  int64_t& len = toTsm ? s->tPhys : s->nIn;
+  // oldest frame still needed.  TSM input: what the stage has buffered (the window refill aligns down by 8 frames).
+  // Ring sequence: the analysis halo (frame framesDone-1 starts at (framesDone-1)*B) and, on a mixed stream, the
+  // buffers not handed over yet; on an unmixed stream it is the TSM input as well.
   int64_t keepFrom = s->tsmBase - s->tsmShift - 16;
-  if (s->mode == 1) keepFrom = std::min(keepFrom, (s->framesDone - 1) * (int64_t)P.B - 16);
-  if (s->dirty || !s->started) keepFrom = std::min(keepFrom, s->dIn.origin / C);  // unknown progress: keep what is there
+  if (!toTsm) {
+    if (s->mixed) keepFrom = s->handedHost * (int64_t)P.B;
+    if (s->mode == 1) keepFrom = std::min(keepFrom, (s->framesDone - 1) * (int64_t)P.B - 16);
+  }
+  if (s->dirty || !s->started) keepFrom = std::min(keepFrom, dst.origin / C);  // unknown progress: keep what is there
   if (keepFrom < 0) keepFrom = 0;
-  s->dIn.filled = s->nIn * C;
-  if (!s->dIn.ensure(keepFrom * C, (s->nIn + sampleCount) * C + 64, s->hs, 1 << 16)) return 0;
+  dst.filled = len * C;
+  if (!dst.ensure(keepFrom * C, (len + sampleCount) * C + 64, s->hs, 1 << 16)) return 0;
   const size_t bytes = sizeof(short) * (size_t)sampleCount * C;
   unsigned char* h = staging(s, bytes);
   if (!h) return 0;
   memcpy(h, in, bytes);  // the caller's buffer is free again when this call returns
-  if (hipMemcpyAsync(s->dIn.base() + s->nIn * C, h, bytes, hipMemcpyHostToDevice, s->hs) != hipSuccess) return 0;
-  s->nIn += sampleCount;
+  if (hipMemcpyAsync(dst.base() + len * C, h, bytes, hipMemcpyHostToDevice, s->hs) != hipSuccess) return 0;
+  len += sampleCount;
   return launch_job(s, false);
 }
 
@@ -620,6 +709,10 @@ int sonicFlushStream(sonicStream s) {
   if (s->failed || !settings_ok(s)) return 0;
   (void)hipSetDevice(s->device);
   if (s->mode < 0) s->mode = (s->nonlinearFactor != 0.0f) ? 1 : 0;
+  // the flush itself does not look at the factor (soniclib.c:529-552): pending ring buffers go to the TSM stage at its
+  // last speed.  With the factor at 0 by now there is no nonlinear job to do that in: the stream becomes a mixed one,
+  // whose flushes append the pending buffers to the TSM input
+  if (s->mode == 1 && s->nonlinearFactor == 0.0f && !s->mixed && !enter_mixed(s)) return 0;
   if (s->rate != 1.0f && !s->rateMode && !enter_rate_mode(s)) return 0;
   if (!staging(s, 0)) return 0;  // the job-table slot
   return launch_job(s, true);    // the stream stays usable: a later write continues behind the flush's padding

@@ -49,6 +49,10 @@ struct SpxPlanDev {
                                // dependency truncates the FINAL output there -- and leaves `flush_remaining` in the state record
 #define SPX_F_SPEED_SET 32     // sonicSetSpeed was called since the last job: it reaches the TSM stage at once, in nonlinear
                                // mode too (soniclib.c:177-182) -- a flush right behind it hands out the ring buffers at that speed
+#define SPX_F_KEEP_SPEED 64    // a linear job on a stream that has been nonlinear (soniclib.c:397-399 short-circuits per write): the
+                               // TSM stage keeps the speed it was last given instead of taking the global one
+#define SPX_F_HANDED_IN 128    // ... and on such a stream the ring-buffer counts come with the job (handed_in, ring_bufs): its TSM input is a
+                               // sequence of its own, n_in describes that one
 struct SpxStreamDev {
   int64_t in_off, n_in, out_off, out_cap;  // n_in = input frames present so far (from the stream start)
   int64_t frame_off;    // index of this stream's analysis frame 0 in the per-frame arrays
@@ -66,7 +70,9 @@ struct SpxStreamDev {
   // a time, with its own time base:
   int32_t unit_time0;    // 0: frame j is added at time j + 1 (the shim, soniclib.c:288-296); 1: at time j (speedyAddData(.., j))
   int32_t tension_to;    // SPX_F_TENSION_RANGE: compute tension frames [tension_skip, tension_to)
-  int32_t pad3;
+  int32_t handed_in;     // SPX_F_HANDED_IN: ring buffers handed to the TSM stage before this job ...
+  int32_t ring_bufs;     // ... and complete ring buffers that exist (n_in is the TSM input's length there, not the ring's)
+  int32_t pad4;
 };
 
 // TSM-stage state (libsonic's stream struct) in absolute stream coordinates.

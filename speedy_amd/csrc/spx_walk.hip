@@ -758,7 +758,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
     Z.handed = states[blockIdx.x].handed;
     // sonicSetSpeed between writes reaches the TSM stage at once (soniclib.c:182); in nonlinear mode the
     // next tension frame overrides it (soniclib.c:354)
-    if (nl == 0.0f || (S.flags & SPX_F_SPEED_SET)) Z.curSpeed = Rg;
+    if ((nl == 0.0f && !(S.flags & SPX_F_KEEP_SPEED)) || (S.flags & SPX_F_SPEED_SET)) Z.curSpeed = Rg;
   }
 
   const float* scr = scratch_base + (size_t)S.frame_off * 4;  // per frame: ..., speed (written by the tension kernel)
@@ -795,7 +795,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   st.overflow = uni(Z.w.overflow); st.prevPeriod_toggle = uni(Z.w.prevPeriod_toggle);
   float curSpeed = unif(Z.curSpeed);
   pos_t avail = st.avail;
-  pos_t handed = (nl != 0.0f) ? Z.handed : 0;
+  pos_t handed = (nl != 0.0f) ? ((S.flags & SPX_F_HANDED_IN) ? S.handed_in : Z.handed) : 0;
   const bool do_flush = (S.flags & SPX_F_FLUSH) != 0;
   // The speeds come from the tension kernel.  Sequential launches (speed_ready == nullptr): all of them are there.
   // Concurrent launches: the tension kernel runs beside this one and publishes the number of tension frames whose
@@ -833,7 +833,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
     const bool fin = last && do_flush;
     const pos_t ev0 = handed;
     pos_t ev1;  // one past the last ordinary event of this chunk
-    if (nl != 0.0f) ev1 = fin ? (pos_t)(S.n_in / B) : K;  // complete ring buffers written: soniclib.c:446-449
+    if (nl != 0.0f) ev1 = fin ? ((S.flags & SPX_F_HANDED_IN) ? (pos_t)S.ring_bufs : (pos_t)(S.n_in / B)) : K;  // complete ring buffers written: soniclib.c:446-449
     else ev1 = (last && (pos_t)(S.n_in + S.tsm_shift) > avail) ? 1 : 0;
     if (ev1 < ev0) ev1 = ev0;
     const pos_t ev_end = ev1 + (fin ? 1 : 0);

@@ -155,12 +155,13 @@ def test_batch_mixture_fuzz(orc, seed):
 def test_life_cycle_fuzz(orc, seed):
     """Random call sequences through the streaming API: writes from one frame to a few thousand (many shorter than an
     analysis hop), reads of random size, flushes anywhere (also before the first tension frame, twice in a row, with
-    nothing written), and between writes new values for speed, rate (sonicSetRate), nonlinear factor (non-zero values)
-    and feedback strength.  After every call the frames delivered must equal the oracle shim's."""
+    nothing written), and between writes new values for speed, rate (sonicSetRate), nonlinear factor -- including
+    switches between 0 and non-zero, which make the reference interleave ring buffers and direct writes -- and
+    feedback strength.  After every call the frames delivered must equal the oracle shim's."""
     from speedy_amd.sonic2 import SonicStream
     L = orc.lib()
     rng = np.random.default_rng(seed)
-    ops = os.environ.get("SPX_LC_OPS", "flush,speed,rate,nl,fb").split(",")   # debugging: leave op classes out
+    ops = os.environ.get("SPX_LC_OPS", "flush,speed,rate,nl,fb,mode").split(",")   # debugging: leave op classes out
     trace = os.environ.get("SPX_LC_TRACE")                                     # debugging: print every call
     for i in range(6):
         rate = int(rng.choice([8000, 16000, 16000, 22050, 22050, 44100]))
@@ -174,7 +175,7 @@ def test_life_cycle_fuzz(orc, seed):
         fb = float(rng.choice([0.0, 0.0, 0.1]))
         mm = bool(rng.integers(0, 2))
         small = bool(rng.integers(0, 2)) and i != 5
-        with_cb = nl != 0.0 and bool(rng.integers(0, 2))
+        with_cb = bool(rng.integers(0, 2))
         x = _signal(kind, n, rate, ch, rng)
         tag = (seed, i, rate, ch, kind, n, speed, nl, fb, mm, small)
         h = L.orc_sonicCreateStream(rate, ch, int(mm))
@@ -190,7 +191,7 @@ def test_life_cycle_fuzz(orc, seed):
         L.orc_sonicEnableNonlinearSpeedup(h, nl); s.enable_nonlinear(nl)
         L.orc_sonicSetDurationFeedbackStrength(h, fb); s.set_feedback(fb)
         buf = np.zeros(8192 * ch, np.int16)
-        pos, log = 0, []
+        pos, log, cur_nl = 0, [], nl
         if trace:
             print("CASE", tag, flush=True)
         while pos < n:
@@ -209,9 +210,15 @@ def test_life_cycle_fuzz(orc, seed):
                 v = float(rng.choice([0.5, 0.8, 1.0, 1.0, 1.25, 2.0]))
                 log.append(("rate", v))
                 L.orc_sonicSetRate(h, v); s.set_rate(v)
-            elif 0.14 <= op < 0.17 and nl != 0.0 and "nl" in ops:
+            elif 0.14 <= op < 0.17 and cur_nl != 0.0 and "nl" in ops:
                 v = float(rng.choice([0.3, 0.7, 1.0]))
+                cur_nl = v
                 log.append(("nl", v))
+                L.orc_sonicEnableNonlinearSpeedup(h, v); s.enable_nonlinear(v)
+            elif 0.19 <= op < 0.22 and "mode" in ops:   # linear <-> nonlinear inside one stream (soniclib.c:397-399)
+                v = 0.0 if cur_nl != 0.0 else float(rng.choice([0.5, 1.0]))
+                cur_nl = v
+                log.append(("mode", v))
                 L.orc_sonicEnableNonlinearSpeedup(h, v); s.enable_nonlinear(v)
             elif 0.17 <= op < 0.19 and "fb" in ops:
                 v = float(rng.choice([0.0, 0.1, 0.3]))
@@ -225,17 +232,25 @@ def test_life_cycle_fuzz(orc, seed):
                 assert L.orc_sonicWriteShortToStream(h, orc.sptr(seg), seg.size // ch) == 1
                 assert s.write_short(seg) == 1, tag + (s.L.speedyHipLastError(),)
                 assert got_cb == ref_cb, tag + ("callbacks", pos, log[-12:])
+            if trace:   # debugging: the frames readable after every call, not only the ones a read happens to ask for
+                a, b = L.orc_sonicIntSamplesAvailable(h), s.L.sonicSamplesAvailable(s.h)
+                assert a == b, tag + ("available", a, b, pos, log[-6:])
             if rng.random() < 0.7:
                 r = int(rng.integers(1, 8193))
+                log.append(("r", r))
                 k = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), r)
                 got = s.read_short(r)
                 assert got.size == k * ch and np.array_equal(got, buf[:k * ch]), tag + ("read", pos, log[-12:])
+        if os.environ.get("SPX_LC_DUMP"):   # debugging: the whole case for tools/lc_ddmin.py
+            import pickle
+            with open("%s_%d_%d.pkl" % (os.environ["SPX_LC_DUMP"], seed, i), "wb") as f:
+                pickle.dump({"tag": tag, "x": x, "ops": log}, f)
         L.orc_sonicFlushStream(h)
-        s.flush()
+        assert s.flush() == 1, tag + (s.L.speedyHipLastError(),)
         while True:
             k = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), 8192)
             got = s.read_short(8192)
-            assert got.size == k * ch and np.array_equal(got, buf[:k * ch]), tag + ("drain", log[-12:])
+            assert got.size == k * ch and np.array_equal(got, buf[:k * ch]), tag + ("drain", s.L.speedyHipLastError(), log[-12:])
             if k == 0:
                 break
         L.orc_sonicDestroyStream(h)

@@ -488,16 +488,47 @@ def test_set_rate_fuzz(orc, seed):
     assert np.array_equal(ro, rg), (rate_hz, ch, speed, nl, chunk, plan)
 
 
-def test_documented_deviations_fail_loudly_not_silently():
-    """switching between factor 0 and a nonzero factor inside one stream is not supported; the next
-    write returns 0 with a message -- no audio is ever produced on a wrong path."""
+@pytest.mark.parametrize("start_nl,ch,speed", [(0.0, 1, 2.0), (1.0, 1, 3.5), (1.0, 2, 0.7), (0.0, 3, 1.4)])
+def test_switching_between_linear_and_nonlinear_inside_one_stream(orc, start_nl, ch, speed):
+    """soniclib.c:397-399 looks at the nonlinear factor on every write: with 0 the samples bypass the shim's ring and
+    reach the TSM stage at once -- ahead of ring buffers written earlier that still wait for their tension -- and a
+    flush hands the waiting buffers over at the last speed.  Same interleaving here, call for call."""
     from speedy_amd.sonic2 import SonicStream
-    x = np.zeros(4000, np.int16)
-    s = SonicStream(16000, 1, False)
-    s.set_speed(2.0)
-    assert s.write_short(x) == 1          # linear
-    s.enable_nonlinear(1.0)
-    assert s.write_short(x) == 0 and b"switching" in s.L.speedyHipLastError()
+    from speedy_amd.synth import speech_like
+    rate = 16000
+    x = speech_like(6 * rate, rate, seed=31, channels=ch)
+    L = orc.lib()
+    h = L.orc_sonicCreateStream(rate, ch, 0)
+    s = SonicStream(rate, ch, False)
+    L.orc_sonicSetSpeed(h, speed); s.set_speed(speed)
+    L.orc_sonicSetDurationFeedbackStrength(h, 0.0); s.set_feedback(0.0)
+    buf = np.zeros(8192 * ch, np.int16)
+    nl, total = start_nl, 0
+    for w, pos in enumerate(range(0, x.size // ch, 700)):
+        if w % 9 == 4:
+            nl = 0.0 if nl != 0.0 else 1.0                 # the other mode for the next nine writes
+        if w == 50:
+            L.orc_sonicFlushStream(h)
+            assert s.flush() == 1
+        L.orc_sonicEnableNonlinearSpeedup(h, nl); s.enable_nonlinear(nl)
+        seg = np.ascontiguousarray(x[pos * ch:(pos + 700) * ch])
+        L.orc_sonicWriteShortToStream(h, orc.sptr(seg), seg.size // ch)
+        assert s.write_short(seg) == 1, s.L.speedyHipLastError()
+        k = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), 8192)
+        got = s.read_short(8192)
+        assert got.size == k * ch and np.array_equal(got, buf[:k * ch]), w
+        total += k
+    L.orc_sonicFlushStream(h)
+    assert s.flush() == 1
+    while True:
+        k = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), 8192)
+        got = s.read_short(8192)
+        assert got.size == k * ch and np.array_equal(got, buf[:k * ch])
+        total += k
+        if k == 0:
+            break
+    assert total > 0
+    L.orc_sonicDestroyStream(h)
     s.close()
 
 
