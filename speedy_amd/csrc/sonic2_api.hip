@@ -91,6 +91,7 @@ struct sonicStreamStruct {  // speedyConnectionStruct + the parts of libsonic's 
   int device = 0;
   int sampleRate = 0, channels = 0;
   float globalSpeed = 1.0f;         // soniclib.c:114
+  float tsmSpeed = 1.0f;            // the speed last given to the TSM stage by a setter (sonicSetSpeed sets both, sonicIntSetSpeed this one)
   bool speedupOnly = true;          // every launch so far had speed > 1 and 0 <= nonlinear factor <= 1
   float nonlinearFactor = 0.0f;     // soniclib.c:117
   float feedbackStrength = 0.1f;    // soniclib.c:122
@@ -242,7 +243,7 @@ void sonicSetRate(sonicStream s, float rate) {
     (void)hipMemsetAsync(&s->dRate->old_pos, 0, 2 * sizeof(int32_t), s->hs);
   }
 }
-void sonicSetSpeed(sonicStream s, float speed) { s->globalSpeed = speed; s->speedSet = true; }
+void sonicSetSpeed(sonicStream s, float speed) { s->globalSpeed = speed; s->tsmSpeed = speed; s->speedSet = true; }
 void sonicEnableNonlinearSpeedup(sonicStream s, float f) { s->nonlinearFactor = f; }
 void sonicSetDurationFeedbackStrength(sonicStream s, float f) { s->feedbackStrength = f; }
 int getSonicBufferSize(sonicStream s) { return s ? s->bufferSize : 0; }
@@ -362,7 +363,7 @@ static void run_callbacks(sonicStream s, int64_t j0, int64_t j1, int64_t k_first
 
 // Enqueue the analysis + tension + walk launches for everything written since the last job.  The caller has made sure
 // the staging area exists and nobody reads its job-table slot any more.
-static int launch_job(sonicStream s, bool flush) {
+static int launch_job(sonicStream s, bool flush, bool direct = false) {
   const SpxPlanDev& P = *s->plan;
   const int64_t C = s->channels;
   const int F = P.F, Pp = P.Pp, B = P.B;
@@ -370,8 +371,9 @@ static int launch_job(sonicStream s, bool flush) {
   // analysis + tension kernels and the walk kernel's per-tension events when the stream is in nonlinear mode -- except
   // the flush of a mixed stream: no new tension can exist then, its pending ring buffers (appended to the TSM input below)
   // go one by one at the last speed, which the walk kernel's ring path does given a non-zero factor
+  // `direct`: a sonicInt* call -- the TSM stage alone, the shim's ring is not touched (a direct flush hands nothing over)
   const bool hasRing = s->mode == 1 || s->mixed;
-  const bool nonlinear = s->mode == 1 && !(s->mixed && flush);
+  const bool nonlinear = s->mode == 1 && !(s->mixed && flush) && !direct;
   const int64_t T = hasRing ? spx_internal_frames_for(P, s->nIn) : 0;
   const int64_t fa = s->framesDone;
   const bool taps = nonlinear && any_callback(s);
@@ -381,7 +383,7 @@ static int launch_job(sonicStream s, bool flush) {
   int64_t handedAfter = handedBefore;
   if (hasRing) {
     if (nonlinear) handedAfter = std::max<int64_t>(handedBefore, (T >= F) ? T - F + 1 : 0);  // one per tension frame, soniclib.c:354-369
-    if (flush) handedAfter = std::max<int64_t>(handedAfter, s->nIn / B);                    // every complete buffer, :538-550
+    if (flush && !direct) handedAfter = std::max<int64_t>(handedAfter, s->nIn / B);         // every complete buffer, :538-550
   }
   if (s->mixed && handedAfter > handedBefore) {   // they join the TSM input behind whatever the linear writes put there
     const int64_t n = (handedAfter - handedBefore) * B;
@@ -400,7 +402,7 @@ static int launch_job(sonicStream s, bool flush) {
   // ---- output window [outRead, need): what was produced as of the last synchronisation plus the most the TSM stage
   // can make of the input it had not consumed by then (flush padding included) ----
   const int64_t unconsumed = tsmLen + s->tsmShift + 2 * (int64_t)P.maxRequired - s->tsmBase;
-  const int64_t bound = s->outKnown + spx_internal_out_bound(P, unconsumed, s->globalSpeed, hasRing);
+  const int64_t bound = s->outKnown + spx_internal_out_bound(P, unconsumed, std::min(s->globalSpeed, s->tsmSpeed), hasRing);
   if (s->outBound < s->outKnown) s->outBound = s->outKnown;
   const int64_t need = std::max(bound, s->outBound);
   s->dOut.filled = s->outBound * C;
@@ -464,16 +466,17 @@ static int launch_job(sonicStream s, bool flush) {
   JA.tension_skip = (int32_t)s->tensionSkip;
   JA.first_tile = 0;
   JW = JA;
+  JW.speed = s->tsmSpeed;
   JW.flags = common | (s->started ? 0 : SPX_F_INIT);
   if (s->mixed) {
     JW.in_off = -s->dTsm.origin; JW.n_in = s->tPhys;
     JW.flags |= SPX_F_HANDED_IN | (nonlinear ? 0 : SPX_F_KEEP_SPEED);
     JW.handed_in = (int32_t)handedBefore;
     JW.ring_bufs = (int32_t)(s->nIn / B);
-    if (flush) JW.nonlinear = (s->nonlinearFactor != 0.0f) ? s->nonlinearFactor : 1.0f;  // the ring path; no tension event is pending
+    if (flush && !direct) JW.nonlinear = (s->nonlinearFactor != 0.0f) ? s->nonlinearFactor : 1.0f;  // the ring path; no tension event is pending
   }
   // once a stream has run at a speed <= 1 its carried speed may be below 1: stay on the general kernel from then on
-  if (!(JA.speed > 1.0f && JA.nonlinear >= 0.0f && JA.nonlinear <= 1.0f)) s->speedupOnly = false;
+  if (!(JA.speed > 1.0f && JW.speed > 1.0f && JA.nonlinear >= 0.0f && JA.nonlinear <= 1.0f)) s->speedupOnly = false;
   // SPX_F_NO_TRUNC and the mixed-stream flags are the general walk kernel's (the speed-up kernels are tuned to their
   // register budget)
   const bool speedupKernel = s->speedupOnly && !s->rateMode && !s->mixed;
@@ -513,7 +516,7 @@ static int launch_job(sonicStream s, bool flush) {
     // soniclib.c:538-550: every complete ring buffer goes to the TSM stage at the last speed and the shim's read index
     // moves to its write index -- tension frames below it that were not computed yet never will be; sonicIntFlushStream
     // then pads 2*maxRequired zeros, which later input follows in TSM coordinates
-    if (hasRing) {
+    if (hasRing && !direct) {
       s->tensionSkip = std::max(s->tensionSkip, s->nIn / P.B);
       s->tensionDone = std::max(s->tensionDone, s->tensionSkip);
     }
@@ -578,7 +581,10 @@ static bool enter_mixed(sonicStream s) {
 // The reference stores whatever float it is given; most values outside the documented ranges have no defined behaviour
 // there (a speed <= 0 makes the TSM stage's step counts negative).  Here the next write / flush refuses them.
 static bool settings_ok(sonicStream s) {
-  if (!(s->globalSpeed > 0.0f) || !std::isfinite(s->globalSpeed)) { g_api_err = "sonicSetSpeed: speed must be finite and > 0"; return false; }
+  if (!(s->globalSpeed > 0.0f) || !std::isfinite(s->globalSpeed) || !(s->tsmSpeed > 0.0f) || !std::isfinite(s->tsmSpeed)) {
+    g_api_err = "sonicSetSpeed: speed must be finite and > 0";
+    return false;
+  }
   if (!(s->nonlinearFactor >= 0.0f && s->nonlinearFactor <= 1.0f)) {
     g_api_err = "sonicEnableNonlinearSpeedup: factor outside [0, 1] (sonic2.h:73-76; the blended speed could reach 0)";
     return false;
@@ -588,11 +594,11 @@ static bool settings_ok(sonicStream s) {
   return true;
 }
 
-static int write_shorts(sonicStream s, const short* in, int sampleCount) {
+static int write_shorts(sonicStream s, const short* in, int sampleCount, bool direct = false) {
   if (s->failed || !settings_ok(s)) return 0;
   (void)hipSetDevice(s->device);
   if (s->rate != 1.0f && !s->rateMode && !enter_rate_mode(s)) return 0;
-  const int want = (s->nonlinearFactor != 0.0f) ? 1 : 0;  // soniclib.c:397: decided anew on every write
+  const int want = (s->nonlinearFactor != 0.0f && !direct) ? 1 : 0;  // soniclib.c:397: decided anew on every write; sonicInt* bypasses
   if (s->mode < 0) s->mode = want;
   if (want == 1 && s->bufferSize == 0) s->bufferSize = s->plan->B;  // sonicAllocateBuffers, soniclib.c:195
   if (!in || sampleCount <= 0) return 1;
@@ -630,7 +636,7 @@ static int write_shorts(sonicStream s, const short* in, int sampleCount) {
   memcpy(h, in, bytes);  // the caller's buffer is free again when this call returns
   if (hipMemcpyAsync(dst.base() + len * C, h, bytes, hipMemcpyHostToDevice, s->hs) != hipSuccess) return 0;
   len += sampleCount;
-  return launch_job(s, false);
+  return launch_job(s, false, direct);
 }
 
 extern "C" {
@@ -639,17 +645,18 @@ int sonicWriteShortToStream(sonicStream s, const short* in, int sampleCount) {
   return write_shorts(s, in, sampleCount);
 }
 
-int sonicWriteFloatToStream(sonicStream s, const float* in, int sampleCount) {
-  if (!in || sampleCount <= 0) return write_shorts(s, nullptr, 0);
+static int write_floats(sonicStream s, const float* in, int sampleCount, bool direct) {
+  if (!in || sampleCount <= 0) return write_shorts(s, nullptr, 0, direct);
   const size_t n = (size_t)sampleCount * s->channels;
   std::vector<short> tmp(n);
-  if (s->nonlinearFactor != 0.0f) {
+  if (s->nonlinearFactor != 0.0f && !direct) {
     for (size_t i = 0; i < n; i++) tmp[i] = (short)(in[i] * 32768.0);   // soniclib.c:496
   } else {
     for (size_t i = 0; i < n; i++) tmp[i] = (short)(in[i] * 32767.0f);  // libsonic's float input scale
   }
-  return write_shorts(s, tmp.data(), sampleCount);  // copied into the pinned staging area before this returns
+  return write_shorts(s, tmp.data(), sampleCount, direct);  // copied into the pinned staging area before this returns
 }
+int sonicWriteFloatToStream(sonicStream s, const float* in, int sampleCount) { return write_floats(s, in, sampleCount, false); }
 
 int sonicSamplesAvailable(sonicStream s) {
   if (!sync_stream(s)) return 0;
@@ -680,24 +687,17 @@ int sonicReadFloatFromStream(sonicStream s, float* out, int bufferSize) {
   return n;
 }
 
-// ---- the libsonic entry points the reference's tests call directly (sonic_test.cc:370,735-750).  They address
-// the TSM stage alone, which is what a stream in linear mode is here. ----
-static bool linear_only(sonicStream s, const char* who) {
-  if (s->mode == 1 || (s->mode < 0 && s->nonlinearFactor != 0.0f)) {
-    g_api_err = std::string(who) + ": direct TSM-stage calls on a stream in nonlinear mode are not supported";
-    return false;
-  }
-  return true;
-}
+// ---- the libsonic entry points the reference's tests call directly (sonic_test.cc:370,735-750).  They address the TSM
+// stage alone: a write bypasses the shim's ring whatever the factor, a flush leaves waiting ring buffers where they are. ----
 sonicStream sonicIntCreateStream(int sampleRate, int numChannels) { return sonicCreateStream(sampleRate, numChannels); }
 void sonicIntDestroyStream(sonicStream s) { sonicDestroyStream(s); }
-void sonicIntSetSpeed(sonicStream s, float speed) { sonicSetSpeed(s, speed); }
+void sonicIntSetSpeed(sonicStream s, float speed) { s->tsmSpeed = speed; s->speedSet = true; }  // the TSM stage alone (the shim's global speed stays)
 void sonicIntSetRate(sonicStream s, float rate) { sonicSetRate(s, rate); }
 int sonicIntWriteShortToStream(sonicStream s, const short* in, int n) {
-  return linear_only(s, "sonicIntWriteShortToStream") ? write_shorts(s, in, n) : 0;
+  return write_shorts(s, in, n, true);
 }
 int sonicIntWriteFloatToStream(sonicStream s, const float* in, int n) {
-  return linear_only(s, "sonicIntWriteFloatToStream") ? sonicWriteFloatToStream(s, in, n) : 0;
+  return write_floats(s, in, n, true);
 }
 int sonicIntReadShortFromStream(sonicStream s, short* out, int n) { return sonicReadShortFromStream(s, out, n); }
 int sonicIntReadFloatFromStream(sonicStream s, float* out, int n) { return sonicReadFloatFromStream(s, out, n); }
@@ -717,6 +717,14 @@ int sonicFlushStream(sonicStream s) {
   if (!staging(s, 0)) return 0;  // the job-table slot
   return launch_job(s, true);    // the stream stays usable: a later write continues behind the flush's padding
 }
-int sonicIntFlushStream(sonicStream s) { return linear_only(s, "sonicIntFlushStream") ? sonicFlushStream(s) : 0; }
+int sonicIntFlushStream(sonicStream s) {
+  if (s->failed || !settings_ok(s)) return 0;
+  (void)hipSetDevice(s->device);
+  if (s->mode < 0) s->mode = 0;
+  if (s->mode == 1 && !s->mixed && !enter_mixed(s)) return 0;  // the TSM input goes its own way from here (buffers stay in the ring)
+  if (s->rate != 1.0f && !s->rateMode && !enter_rate_mode(s)) return 0;
+  if (!staging(s, 0)) return 0;
+  return launch_job(s, true, true);
+}
 
 }  // extern "C"

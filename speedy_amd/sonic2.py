@@ -64,6 +64,17 @@ class SonicStream:
     def flush(self):
         return self.L.sonicFlushStream(self.h)
 
+    # the TSM stage alone (sonicInt*, sonic_test.cc:735-750): no ring, no analysis, whatever the nonlinear factor
+    def int_write_short(self, x):
+        x = np.ascontiguousarray(x, np.int16)
+        return self.L.sonicIntWriteShortToStream(self.h, x.ctypes.data_as(c_short_p), x.size // self.channels)
+
+    def int_flush(self):
+        return self.L.sonicIntFlushStream(self.h)
+
+    def int_set_speed(self, v):
+        self.L.sonicIntSetSpeed(self.h, float(v))
+
     def on_tension(self, fn):
         cb = TENSION_FN(lambda s, t, v: fn(t, v))
         self._keep.append(cb)

@@ -151,6 +151,19 @@ def test_batch_mixture_fuzz(orc, seed):
             assert np.array_equal(outs[i], ref["out"]), (seed, rep, i, rate, chs[i], speeds[i], nls[i], fbs[i], mm)
 
 
+_case_log = []   # debugging: the case in progress, written out by the fixture below when a test fails under SPX_LC_DUMP
+
+
+@pytest.fixture(autouse=True)
+def _dump_failing_case(request):
+    yield
+    if os.environ.get("SPX_LC_DUMP") and _case_log and request.node.name.startswith("test_life_cycle_fuzz"):
+        import pickle
+        tag, x, log = _case_log
+        with open("%s_%d_%d.pkl" % (os.environ["SPX_LC_DUMP"], tag[0], tag[1]), "wb") as f:   # the last case run = the failing one
+            pickle.dump({"tag": tag, "x": x, "ops": list(log)}, f)
+
+
 @pytest.mark.parametrize("seed", list(range(31, 39)) + list(range(3000, 3000 + SOAK)))
 def test_life_cycle_fuzz(orc, seed):
     """Random call sequences through the streaming API: writes from one frame to a few thousand (many shorter than an
@@ -161,7 +174,7 @@ def test_life_cycle_fuzz(orc, seed):
     from speedy_amd.sonic2 import SonicStream
     L = orc.lib()
     rng = np.random.default_rng(seed)
-    ops = os.environ.get("SPX_LC_OPS", "flush,speed,rate,nl,fb,mode").split(",")   # debugging: leave op classes out
+    ops = os.environ.get("SPX_LC_OPS", "flush,speed,rate,nl,fb,mode,direct").split(",")   # debugging: leave op classes out
     trace = os.environ.get("SPX_LC_TRACE")                                     # debugging: print every call
     for i in range(6):
         rate = int(rng.choice([8000, 16000, 16000, 22050, 22050, 44100]))
@@ -192,6 +205,7 @@ def test_life_cycle_fuzz(orc, seed):
         L.orc_sonicSetDurationFeedbackStrength(h, fb); s.set_feedback(fb)
         buf = np.zeros(8192 * ch, np.int16)
         pos, log, cur_nl = 0, [], nl
+        _case_log[:] = [tag, x, log]
         if trace:
             print("CASE", tag, flush=True)
         while pos < n:
@@ -215,6 +229,23 @@ def test_life_cycle_fuzz(orc, seed):
                 cur_nl = v
                 log.append(("nl", v))
                 L.orc_sonicEnableNonlinearSpeedup(h, v); s.enable_nonlinear(v)
+            elif 0.22 <= op < 0.26 and "direct" in ops:   # sonicInt*: the TSM stage alone, whatever the stream is doing
+                u = rng.random()
+                if u < 0.6:
+                    w = int(rng.integers(1, 1500))
+                    seg = np.ascontiguousarray(x[pos * ch:(pos + w) * ch])
+                    pos += w
+                    log.append(("iw", seg.size // ch))
+                    assert L.orc_sonicIntWriteShortToStream(h, orc.sptr(seg), seg.size // ch) == 1
+                    assert s.int_write_short(seg) == 1, tag + (s.L.speedyHipLastError(),)
+                elif u < 0.8:
+                    log.append("iflush")
+                    L.orc_sonicIntFlushStream(h)
+                    assert s.int_flush() == 1, tag + (s.L.speedyHipLastError(),)
+                else:
+                    v = float(np.round(rng.choice([rng.uniform(0.4, 0.95), rng.uniform(1.05, 4.0)]), 5))
+                    log.append(("ispeed", v))
+                    L.orc_sonicIntSetSpeed(h, v); s.int_set_speed(v)
             elif 0.19 <= op < 0.22 and "mode" in ops:   # linear <-> nonlinear inside one stream (soniclib.c:397-399)
                 v = 0.0 if cur_nl != 0.0 else float(rng.choice([0.5, 1.0]))
                 cur_nl = v
@@ -241,10 +272,6 @@ def test_life_cycle_fuzz(orc, seed):
                 k = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), r)
                 got = s.read_short(r)
                 assert got.size == k * ch and np.array_equal(got, buf[:k * ch]), tag + ("read", pos, log[-12:])
-        if os.environ.get("SPX_LC_DUMP"):   # debugging: the whole case for tools/lc_ddmin.py
-            import pickle
-            with open("%s_%d_%d.pkl" % (os.environ["SPX_LC_DUMP"], seed, i), "wb") as f:
-                pickle.dump({"tag": tag, "x": x, "ops": log}, f)
         L.orc_sonicFlushStream(h)
         assert s.flush() == 1, tag + (s.L.speedyHipLastError(),)
         while True:

@@ -34,6 +34,13 @@ def differs(ops):
             L.orc_sonicEnableNonlinearSpeedup(h, op[1]); s.enable_nonlinear(op[1])
         elif op[0] == "fb":
             L.orc_sonicSetDurationFeedbackStrength(h, op[1]); s.set_feedback(op[1])
+        elif op == "iflush":
+            L.orc_sonicIntFlushStream(h); s.int_flush()
+        elif op[0] == "ispeed":
+            L.orc_sonicIntSetSpeed(h, op[1]); s.int_set_speed(op[1])
+        elif op[0] == "iw":
+            seg = np.ascontiguousarray(x[pos * ch:(pos + op[1]) * ch]); pos += op[1]
+            L.orc_sonicIntWriteShortToStream(h, orc.sptr(seg), op[1]); s.int_write_short(seg)
         elif op[0] == "r":
             buf0 = np.zeros(op[1] * ch, np.int16)
             k0 = L.orc_sonicReadShortFromStream(h, orc.sptr(buf0), op[1]); g0 = s.read_short(op[1])
