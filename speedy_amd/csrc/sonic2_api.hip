@@ -599,6 +599,10 @@ static int write_shorts(sonicStream s, const short* in, int sampleCount, bool di
   (void)hipSetDevice(s->device);
   if (s->rate != 1.0f && !s->rateMode && !enter_rate_mode(s)) return 0;
   const int want = (s->nonlinearFactor != 0.0f && !direct) ? 1 : 0;  // soniclib.c:397: decided anew on every write; sonicInt* bypasses
+  if (want == 1 && !spx_internal_analysis_fits(*s->plan)) {
+    g_api_err = "sample rate too high for the nonlinear path (the analysis tile does not fit one CU's LDS); linear mode only";
+    return 0;
+  }
   if (s->mode < 0) s->mode = want;
   if (want == 1 && s->bufferSize == 0) s->bufferSize = s->plan->B;  // sonicAllocateBuffers, soniclib.c:195
   if (!in || sampleCount <= 0) return 1;

@@ -112,6 +112,10 @@ speedyStream speedyCreateStream(int sample_rate) {
   }
   const SpxPlanDev* plan = spx_internal_shared_plan(sample_rate, spx_internal_match_matlab());
   if (!plan) { spx_internal_set_api_error("speedyCreateStream: plan creation failed"); return nullptr; }
+  if (!spx_internal_analysis_fits(*plan)) {
+    spx_internal_set_api_error("speedyCreateStream: sample rate too high (the analysis tile does not fit one CU's LDS)");
+    return nullptr;
+  }
   speedyStream s = new speedyStreamStruct();
   s->plan = plan;
   s->rate = sample_rate;

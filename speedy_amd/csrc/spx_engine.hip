@@ -175,11 +175,8 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
   d.tile_frames = spx_analysis_tile_frames();
   if (spx_analysis_lds_bytes(d) > 160 * 1024)    // one CU's LDS: above about 49 kHz the plan's tile is the 8-frame one
     d.tile_frames = spx_analysis_small_tile_frames();
-  if (spx_analysis_lds_bytes(d) > 160 * 1024) {  // ... and above about 61 kHz not even that fits (four waves' DFT work areas)
-    delete p;
-    fail(-1, "spx_plan_create: sample rate too high for the analysis tile (LDS)");
-    return nullptr;
-  }
+  // ... and above about 61 kHz not even that fits (four waves' DFT work areas): the plan then serves linear jobs only
+  // (the TSM stage alone, spx_internal_analysis_fits); a nonlinear job on it is refused
   d.minPeriod = sample_rate / 400;
   d.maxPeriod = sample_rate / 65;
   d.maxRequired = 2 * d.maxPeriod;
@@ -300,6 +297,8 @@ int64_t spx_plan_out_capacity(spx_plan_t p, int64_t n_in, float speed) {
 }
 
 }  // extern "C"
+bool spx_internal_analysis_fits(const SpxPlanDev& d) { return spx_analysis_lds_bytes(d) <= 160 * 1024; }
+
 const SpxPlanDev* spx_internal_shared_plan(int sample_rate, int match_matlab) {
   static std::mutex mu;
   static std::map<std::pair<int, std::pair<int, int>>, spx_plan*> cache;  // (device, (rate, mode)): tables are per device
@@ -363,6 +362,8 @@ static int build_streams(const SpxPlanDev& d, const spx_stream_job* jobs, int n,
     if (!(j.nonlinear >= 0.0f && j.nonlinear <= 1.0f))
       return fail(-1, "spx_batch: nonlinear factor outside [0, 1] (sonic2.h:73-76; the blended speed could reach 0)");
     if (!std::isfinite(j.feedback)) return fail(-1, "spx_batch: feedback strength is not finite");
+    if (j.nonlinear != 0.0f && !spx_internal_analysis_fits(d))
+      return fail(-1, "spx_batch: sample rate too high for the nonlinear path (the analysis tile does not fit one CU's LDS); linear jobs only");
     if (j.n_in >= (1ll << 30)) return fail(-1, "spx_batch: stream of 2^30 frames or more (in-kernel positions are 32-bit)");
     const bool nonlinear = j.nonlinear != 0.0f;
     const int64_t Ttot = nonlinear ? frames_for(d, j.n_in) : 0;

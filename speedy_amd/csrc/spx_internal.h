@@ -204,4 +204,6 @@ int spx_analysis_small_tile_frames();
 struct spx_plan;
 int64_t spx_internal_out_bound(const SpxPlanDev& P, int64_t n_in, float speed, bool nonlinear);
 const SpxPlanDev* spx_internal_shared_plan(int sample_rate, int match_matlab);
+// false above about 61 kHz: the analysis tile does not fit one CU's LDS, the plan serves linear (TSM-only) work
+bool spx_internal_analysis_fits(const SpxPlanDev& d);
 int64_t spx_internal_frames_for(const SpxPlanDev& d, int64_t n_in);

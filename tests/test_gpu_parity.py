@@ -507,11 +507,29 @@ def test_unusual_sample_rates(orc, rate):
                     assert np.array_equal(t[key], ref[key]), (rate, ch, speed, nl, key)
 
 
-def test_sample_rates_outside_the_supported_range_fail_loudly():
-    from speedy_amd.batch import Plan
-    for rate in (999, 62000, 96000, 128000):
+def test_sample_rates_outside_the_supported_range_fail_loudly(orc):
+    """Below 1 kHz and from 128 kHz on there is no plan.  Between about 61 kHz and 128 kHz the analysis tile does not fit
+    one CU's LDS: the plan serves linear jobs (the TSM stage alone) -- bit-exact -- and refuses nonlinear ones."""
+    from speedy_amd.batch import Plan, compress_batch
+    from speedy_amd.sonic2 import SonicStream
+    from speedy_amd.synth import speech_like
+    for rate in (999, 128000):
         with pytest.raises(RuntimeError):
             Plan(rate, False)
+    for rate in (62000, 96000):
+        x = speech_like(rate // 2, rate, seed=3)
+        for speed in (2.0, 0.7):
+            ref = orc.compress_sound(x, rate, 1, speed, 0.0, 0.0, False, chunk=x.size, taps=False)["out"]
+            outs, _ = compress_batch([x], rate, 1, speed, 0.0, 0.0, False)
+            assert np.array_equal(outs[0], ref), (rate, speed)
+        with pytest.raises(RuntimeError):
+            compress_batch([x], rate, 1, 2.0, 1.0, 0.0, False)
+        s = SonicStream(rate, 1, False)
+        s.set_speed(2.0)
+        assert s.write_short(x[:5000]) == 1                       # linear
+        s.enable_nonlinear(1.0)
+        assert s.write_short(x[5000:9000]) == 0 and b"sample rate too high" in s.L.speedyHipLastError()
+        s.close()
 
 
 @pytest.mark.parametrize("rate,n_streams,multi,slow", [(16000, 700, False, False), (22050, 400, True, False),
