@@ -144,11 +144,19 @@ def test_batch_mixture_fuzz(orc, seed):
             nls.append(float(rng.choice([0.0, 1.0, 1.0, 0.5]))); fbs.append(float(rng.choice([0.0, 0.1])))
             xs.append(_signal(KINDS[int(rng.integers(0, len(KINDS)))], n, rate, ch, rng))
         mm = bool(rng.integers(0, 2))
-        outs, b = compress_batch(xs, rate, chs, speeds, nls, fbs, mm, taps=False)
+        from speedy_amd._lib import lib
+        chunks, conc = int(rng.choice([1, 1, 2, 3])), int(rng.integers(0, 2))   # engine modes: same bytes in every one
+        try:
+            lib().spx_set_pipeline_chunks(chunks)
+            lib().spx_set_concurrent(conc)
+            outs, b = compress_batch(xs, rate, chs, speeds, nls, fbs, mm, taps=False)
+        finally:
+            lib().spx_set_pipeline_chunks(1)
+            lib().spx_set_concurrent(1)
         for i in range(k):
             ref = orc.compress_sound(xs[i], rate, chs[i], speeds[i], nls[i], fbs[i], mm,
                                      chunk=1000 if nls[i] != 0 else max(xs[i].size // chs[i], 1))
-            assert np.array_equal(outs[i], ref["out"]), (seed, rep, i, rate, chs[i], speeds[i], nls[i], fbs[i], mm)
+            assert np.array_equal(outs[i], ref["out"]), (seed, rep, i, rate, chs[i], speeds[i], nls[i], fbs[i], mm, chunks, conc)
 
 
 _case_log = []   # debugging: the case in progress, written out by the fixture below when a test fails under SPX_LC_DUMP
