@@ -70,6 +70,7 @@ def lib():
         "orc_sonicIntCreateStream": (vp, [i, i]),
         "orc_sonicIntDestroyStream": (None, [vp]),
         "orc_sonicIntGetNumChannels": (i, [vp]),
+        "orc_sonicIntGetSpeed": (f, [vp]),
         "orc_sonicIntSetSpeed": (None, [vp, f]),
         "orc_sonicIntSetRate": (None, [vp, f]),
         "orc_sonicIntWriteShortToStream": (i, [vp, c_short_p, i]),

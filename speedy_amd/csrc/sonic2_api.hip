@@ -142,6 +142,7 @@ struct sonicStreamStruct {  // speedyConnectionStruct + the parts of libsonic's 
   int64_t outBound = 0;     // upper bound on frames produced by everything launched
   int64_t outRead = 0;      // frames already delivered to the caller
   int64_t tsmBase = 0;      // TSM stage's oldest buffered frame (TSM position), as of the last synchronisation
+  float curSpeedKnown = 1.0f;  // the TSM stage's speed as of the last synchronisation
   int writesSinceSync = 0;
   bool dirty = false;       // launches in flight since the last synchronisation
   bool started = false;     // a job has been launched (state record valid)
@@ -250,7 +251,7 @@ int getSonicBufferSize(sonicStream s) { return s ? s->bufferSize : 0; }
 int sonicSpectrogramSize(sonicStream s) { return s ? s->plan->N : 0; }
 int sonicIntGetNumChannels(sonicStream s) { return s->channels; }
 int sonicIntGetSampleRate(sonicStream s) { return s->sampleRate; }
-float sonicIntGetSpeed(sonicStream s) { return s->globalSpeed; }
+float sonicIntGetSpeed(sonicStream s);  // below: the TSM stage's current speed lives on the device
 
 void sonicTensionCallback(sonicStream s, tensionFunction f) { s->cbTension = f; }
 tensionFunction getSonicTensionCallback(sonicStream s) { return s->cbTension; }
@@ -299,6 +300,7 @@ static bool sync_stream(sonicStream s) {
     s->tsmSeenKnown = h.r.tsm_seen;
   }
   s->tsmBase = h.st.w.base;
+  s->curSpeedKnown = h.st.curSpeed;
   s->dirty = false;
   s->writesSinceSync = 0;
   return true;
@@ -661,6 +663,14 @@ static int write_floats(sonicStream s, const float* in, int sampleCount, bool di
   return write_shorts(s, tmp.data(), sampleCount, direct);  // copied into the pinned staging area before this returns
 }
 int sonicWriteFloatToStream(sonicStream s, const float* in, int sampleCount) { return write_floats(s, in, sampleCount, false); }
+
+// libsonic's sonicGetSpeed: what the TSM stage runs at right now -- the last setter's value, or in nonlinear mode the
+// speed of the last tension frame handed over (soniclib.c:354)
+float sonicIntGetSpeed(sonicStream s) {
+  if (s->speedSet || !s->started) return s->tsmSpeed;
+  if (!sync_stream(s)) return s->tsmSpeed;
+  return s->curSpeedKnown;
+}
 
 int sonicSamplesAvailable(sonicStream s) {
   if (!sync_stream(s)) return 0;

@@ -274,6 +274,9 @@ def test_life_cycle_fuzz(orc, seed):
             if trace:   # debugging: the frames readable after every call, not only the ones a read happens to ask for
                 a, b = L.orc_sonicIntSamplesAvailable(h), s.L.sonicSamplesAvailable(s.h)
                 assert a == b, tag + ("available", a, b, pos, log[-6:])
+            if rng.random() < 0.1:   # the TSM stage's current speed (libsonic's sonicGetSpeed): last setter or last tension frame
+                a, b = L.orc_sonicIntGetSpeed(h), s.L.sonicIntGetSpeed(s.h)
+                assert np.float32(a) == np.float32(b), tag + ("speed now", a, b, pos, log[-6:])
             if rng.random() < 0.7:
                 r = int(rng.integers(1, 8193))
                 log.append(("r", r))
