@@ -558,6 +558,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   }
   // job tables (and, concurrent mode, the tile order) go through a plan-owned pinned slot: the copies are asynchronous
   // and must not read host memory that dies when this function returns
+  hipEvent_t staged_ev = nullptr;
   std::vector<int> order;
   if (concurrent) {
     // tile ids in launch order: tile t of every stream before tile t+1 of any
@@ -596,6 +597,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
                        reinterpret_cast<unsigned*>(dstreams), w_sv, reinterpret_cast<unsigned*>(d_order), w_or,
                        reinterpret_cast<unsigned*>(d_flags), z_fl, reinterpret_cast<unsigned*>(d_ready), z_rd);
     HIPCHK(hipEventRecord(G.done, st));
+    staged_ev = G.done;
   }
   if (trial_slot >= 0) {  // bracket this call on the caller's stream (spx_plan::Trial)
     hipEvent_t& e0 = plan->trial.ev[2 * trial_slot];
@@ -605,9 +607,12 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   if (sa != st) {
     // the side stream starts after everything already queued on the caller's stream (job tables, cleared flags, and
     // the previous call's walk, which still reads the frame records this call's analysis will overwrite)
-    HIPCHK(hipEventRecord(plan->ev_start, st));
-    HIPCHK(hipStreamWaitEvent(sa, plan->ev_start, 0));
-    if (concurrent) HIPCHK(hipStreamWaitEvent(plan->side2, plan->ev_start, 0));
+    // (the staging slot's event marks exactly that point of the caller's stream: one stream operation fewer in front of
+    // the walk kernel than a second event record)
+    hipEvent_t es = staged_ev;
+    if (!es) { es = plan->ev_start; HIPCHK(hipEventRecord(plan->ev_start, st)); }
+    HIPCHK(hipStreamWaitEvent(sa, es, 0));
+    if (concurrent) HIPCHK(hipStreamWaitEvent(plan->side2, es, 0));
   }
   for (int c = 0; c < nch; c++) {
     SpxStreamDev* dj = dstreams + (size_t)c * n;
