@@ -87,6 +87,9 @@ struct spx_plan {
   hipEvent_t ev_tension = nullptr;
   hipEvent_t ev_start = nullptr;
   hipEvent_t ev_chunk[SPX_MAX_CHUNKS] = {};
+  // Concurrent mode enqueues the walk kernel BEFORE its producers when that is safe (see run_impl): the answer of the
+  // queue probe per caller stream (HIP maps streams onto a few hardware queues; two streams that share one run in order)
+  std::vector<std::pair<hipStream_t, bool>> walk_first_ok;
 };
 
 // Timing: one set of four HIP events per timed call, recorded on the launch stream and resolved lazily by
@@ -397,6 +400,21 @@ static SpxTapsDev taps_of(const spx_taps* t) {
 }
 
 }  // extern "C"
+// Queue probe: can kernels enqueued on the two side streams AFTER a waiting kernel on the caller's stream run while it
+// waits?  (Not if a side stream shares the caller stream's hardware queue.)  The waiter gives up after about a millisecond.
+__global__ void spx_probe_wait_kernel(int* flags) {
+  if (threadIdx.x != 0) return;
+  int ok = 0;
+  for (unsigned spins = 0; spins < 4000u; spins++) {
+    if (__hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+        __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 1; break; }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  __hip_atomic_store(&flags[2], ok ? 1 : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void spx_probe_set_kernel(int* flag) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // Job tables (and tile order) from the plan's pinned staging slot into the workspace, hand-off flags cleared.
 __global__ void __launch_bounds__(256)
 spx_stage_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst_a, unsigned n_a, unsigned* __restrict__ dst_b,
@@ -556,6 +574,34 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     }
     sa = plan->side;
   }
+  // Concurrent mode, order of the launches: see the loop below.  Whether the walk kernel may go first is probed once per
+  // caller stream (one synchronisation of that stream, like the mode trial's)
+  bool walk_first_safe = false;
+  if (concurrent && do_w) {
+    bool known = false;
+    for (auto& e : plan->walk_first_ok) if (e.first == st) { walk_first_safe = e.second; known = true; }
+    if (!known) {
+      int* pf = d_flags;   // three ints of the flag array (cleared again by the staging kernel below)
+      int res = 0;
+      bool ok = hipMemsetAsync(pf, 0, 3 * sizeof(int), st) == hipSuccess && hipEventRecord(plan->ev_start, st) == hipSuccess &&
+                hipStreamWaitEvent(plan->side, plan->ev_start, 0) == hipSuccess &&
+                hipStreamWaitEvent(plan->side2, plan->ev_start, 0) == hipSuccess;
+      if (ok) {
+        hipLaunchKernelGGL(spx_probe_wait_kernel, dim3(1), dim3(64), 0, st, pf);
+        hipLaunchKernelGGL(spx_probe_set_kernel, dim3(1), dim3(64), 0, plan->side, pf);
+        hipLaunchKernelGGL(spx_probe_set_kernel, dim3(1), dim3(64), 0, plan->side2, pf + 1);
+        ok = hipEventRecord(plan->ev_chunk[0], plan->side) == hipSuccess && hipEventRecord(plan->ev_tension, plan->side2) == hipSuccess &&
+             hipStreamWaitEvent(st, plan->ev_chunk[0], 0) == hipSuccess && hipStreamWaitEvent(st, plan->ev_tension, 0) == hipSuccess &&
+             hipMemcpyAsync(&res, pf + 2, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess;
+      }
+      (void)hipGetLastError();
+      walk_first_safe = ok && res == 1;
+      plan->walk_first_ok.push_back({st, walk_first_safe});
+      static const bool dbg = getenv("SPX_DEBUG_TRIAL") != nullptr;
+      if (dbg) fprintf(stderr, "[spx probe] stream %p: walk kernel first %s\n", (void*)st, walk_first_safe ? "yes" : "no (shared hardware queue)");
+    }
+  }
   // job tables (and, concurrent mode, the tile order) go through a plan-owned pinned slot: the copies are asynchronous
   // and must not read host memory that dies when this function returns
   hipEvent_t staged_ev = nullptr;
@@ -616,6 +662,25 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   }
   for (int c = 0; c < nch; c++) {
     SpxStreamDev* dj = dstreams + (size_t)c * n;
+    auto launch_walk = [&]() {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, st); }
+      static const bool diag_nowait = getenv("SPX_DIAG_NOWAIT") != nullptr;  // DIAGNOSTIC ONLY: the walk reads the speeds
+      // the previous identical call left in the scratch array instead of waiting for this call's (timing experiments)
+      spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, (concurrent && !diag_nowait) ? d_ready : nullptr,
+                      speedup_only, st);
+      if (timed) { (void)hipEventRecord(e1, st); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({e0, e1, 1}); } }
+    };
+    // Concurrent mode: the walk kernel is enqueued FIRST.  It depends on nothing but the staging kernel in front of it on
+    // the caller's stream, and it must get its workgroups placed one per CU: when the device is idle (the first call
+    // after a synchronisation) kernels start as their launches arrive, and an analysis kernel that arrives first fills
+    // the CUs' LDS with its tiles -- the walk workgroups then land two to a CU wherever room is left and the whole step
+    // waits for those chains (3.06 instead of 2.21 ms in 40 % of such calls, tools/stall_probe3.py).  Only where the
+    // queue probe above found the side streams on hardware queues of their own: behind a waiting walk kernel in the SAME
+    // queue its producers would never start (each consumer is enqueued after its producers otherwise, which is safe).
+    static const bool walk_last = getenv("SPX_WALK_LAST") != nullptr;  // A/B only: the old order
+    const bool walk_first = concurrent && do_w && !walk_last && walk_first_safe;
+    if (walk_first) launch_walk();
     if (do_a && tiles[c] > 0) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, sa); }
@@ -635,13 +700,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
                          concurrent ? d_ready : nullptr, stn);
       if (timed) { (void)hipEventRecord(t1, stn); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({t0, t1, 2}); } }
       if (concurrent) HIPCHK(hipEventRecord(plan->ev_tension, stn));
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, st); }
-      static const bool diag_nowait = getenv("SPX_DIAG_NOWAIT") != nullptr;  // DIAGNOSTIC ONLY: the walk reads the speeds
-      // the previous identical call left in the scratch array instead of waiting for this call's (timing experiments)
-      spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, (concurrent && !diag_nowait) ? d_ready : nullptr,
-                      speedup_only, st);
-      if (timed) { (void)hipEventRecord(e1, st); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({e0, e1, 1}); } }
+      if (!walk_first) launch_walk();
     }
     // the caller's stream is "done" only when the side launches have retired too
     if (concurrent) {
