@@ -87,9 +87,6 @@ struct spx_plan {
   hipEvent_t ev_tension = nullptr;
   hipEvent_t ev_start = nullptr;
   hipEvent_t ev_chunk[SPX_MAX_CHUNKS] = {};
-  // Concurrent mode enqueues the walk kernel BEFORE its producers when that is safe (see run_impl): the answer of the
-  // queue probe per caller stream (HIP maps streams onto a few hardware queues; two streams that share one run in order)
-  std::vector<std::pair<hipStream_t, bool>> walk_first_ok;
 };
 
 // Timing: one set of four HIP events per timed call, recorded on the launch stream and resolved lazily by
@@ -400,20 +397,10 @@ static SpxTapsDev taps_of(const spx_taps* t) {
 }
 
 }  // extern "C"
-// Queue probe: can kernels enqueued on the two side streams AFTER a waiting kernel on the caller's stream run while it
-// waits?  (Not if a side stream shares the caller stream's hardware queue.)  The waiter gives up after about a millisecond.
-__global__ void spx_probe_wait_kernel(int* flags) {
-  if (threadIdx.x != 0) return;
-  int ok = 0;
-  for (unsigned spins = 0; spins < 4000u; spins++) {
-    if (__hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
-        __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 1; break; }
-    __builtin_amdgcn_s_sleep(8);
-  }
-  __hip_atomic_store(&flags[2], ok ? 1 : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__global__ void spx_probe_set_kernel(int* flag) {
-  if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Idle-start gate (run_impl): holds the analysis stream back for a few tens of microseconds.
+__global__ void spx_gate_kernel(unsigned spins) {
+  if (threadIdx.x == 0)
+    for (unsigned i = 0; i < spins; i++) __builtin_amdgcn_s_sleep(64);   // 64 * 64 clocks each, about 2 us
 }
 // Job tables (and tile order) from the plan's pinned staging slot into the workspace, hand-off flags cleared.
 __global__ void __launch_bounds__(256)
@@ -533,9 +520,12 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // in sequence (SpxDevGuard above); the guard stays locked until this call has left its own event behind.
   SpxDevGuard& guard = g_guard[(plan->device >= 0 && plan->device < 64) ? plan->device : 0];
   std::unique_lock<std::mutex> guard_lock(guard.mu, std::defer_lock);
+  bool idle_start = false;
   if (want_concurrent) {
     guard_lock.lock();
-    if (guard.valid && guard.last_stream != st && hipEventQuery(guard.last) == hipErrorNotReady) want_concurrent = false;
+    const hipError_t q = guard.valid ? hipEventQuery(guard.last) : hipSuccess;
+    idle_start = (q == hipSuccess);   // the previous concurrent-mode call (if any) has drained
+    if (guard.valid && guard.last_stream != st && q == hipErrorNotReady) want_concurrent = false;
     (void)hipGetLastError();  // hipErrorNotReady is not an error of this call
     if (!want_concurrent) guard_lock.unlock();
   }
@@ -573,34 +563,6 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       for (auto& e : plan->ev_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     sa = plan->side;
-  }
-  // Concurrent mode, order of the launches: see the loop below.  Whether the walk kernel may go first is probed once per
-  // caller stream (one synchronisation of that stream, like the mode trial's)
-  bool walk_first_safe = false;
-  if (concurrent && do_w) {
-    bool known = false;
-    for (auto& e : plan->walk_first_ok) if (e.first == st) { walk_first_safe = e.second; known = true; }
-    if (!known) {
-      int* pf = d_flags;   // three ints of the flag array (cleared again by the staging kernel below)
-      int res = 0;
-      bool ok = hipMemsetAsync(pf, 0, 3 * sizeof(int), st) == hipSuccess && hipEventRecord(plan->ev_start, st) == hipSuccess &&
-                hipStreamWaitEvent(plan->side, plan->ev_start, 0) == hipSuccess &&
-                hipStreamWaitEvent(plan->side2, plan->ev_start, 0) == hipSuccess;
-      if (ok) {
-        hipLaunchKernelGGL(spx_probe_wait_kernel, dim3(1), dim3(64), 0, st, pf);
-        hipLaunchKernelGGL(spx_probe_set_kernel, dim3(1), dim3(64), 0, plan->side, pf);
-        hipLaunchKernelGGL(spx_probe_set_kernel, dim3(1), dim3(64), 0, plan->side2, pf + 1);
-        ok = hipEventRecord(plan->ev_chunk[0], plan->side) == hipSuccess && hipEventRecord(plan->ev_tension, plan->side2) == hipSuccess &&
-             hipStreamWaitEvent(st, plan->ev_chunk[0], 0) == hipSuccess && hipStreamWaitEvent(st, plan->ev_tension, 0) == hipSuccess &&
-             hipMemcpyAsync(&res, pf + 2, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
-             hipStreamSynchronize(st) == hipSuccess;
-      }
-      (void)hipGetLastError();
-      walk_first_safe = ok && res == 1;
-      plan->walk_first_ok.push_back({st, walk_first_safe});
-      static const bool dbg = getenv("SPX_DEBUG_TRIAL") != nullptr;
-      if (dbg) fprintf(stderr, "[spx probe] stream %p: walk kernel first %s\n", (void*)st, walk_first_safe ? "yes" : "no (shared hardware queue)");
-    }
   }
   // job tables (and, concurrent mode, the tile order) go through a plan-owned pinned slot: the copies are asynchronous
   // and must not read host memory that dies when this function returns
@@ -671,16 +633,17 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
                       speedup_only, st);
       if (timed) { (void)hipEventRecord(e1, st); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({e0, e1, 1}); } }
     };
-    // Concurrent mode: the walk kernel is enqueued FIRST.  It depends on nothing but the staging kernel in front of it on
-    // the caller's stream, and it must get its workgroups placed one per CU: when the device is idle (the first call
-    // after a synchronisation) kernels start as their launches arrive, and an analysis kernel that arrives first fills
-    // the CUs' LDS with its tiles -- the walk workgroups then land two to a CU wherever room is left and the whole step
-    // waits for those chains (3.06 instead of 2.21 ms in 40 % of such calls, tools/stall_probe3.py).  Only where the
-    // queue probe above found the side streams on hardware queues of their own: behind a waiting walk kernel in the SAME
-    // queue its producers would never start (each consumer is enqueued after its producers otherwise, which is safe).
-    static const bool walk_last = getenv("SPX_WALK_LAST") != nullptr;  // A/B only: the old order
-    const bool walk_first = concurrent && do_w && !walk_last && walk_first_safe;
-    if (walk_first) launch_walk();
+    // Concurrent mode on an IDLE device (the first call after a synchronisation): kernels start as their launches arrive,
+    // and the analysis launch arrives a few tens of microseconds before the walk launch.  Its tiles then fill the CUs' LDS
+    // and the walk workgroups land two to a CU wherever room is left -- the whole step waits for those chains (3.06
+    // instead of 2.21 ms in 40 % of such calls, tools/stall_probe3.py; with the host running ahead the walk kernel sits
+    // right behind the staging kernel in its queue and is placed first by itself).  The walk kernel cannot simply be
+    // enqueued first: HIP maps streams onto a few hardware queues, and producers queued behind a waiting consumer in a
+    // shared queue never start (every consumer is enqueued after its producers, which is safe with any mapping).  So an
+    // idle start holds the analysis stream back with a gate kernel until the walk launch has had time to arrive.
+    static const bool no_gate = getenv("SPX_NO_GATE") != nullptr;  // A/B only
+    static const unsigned gate_spins = [] { const char* e = getenv("SPX_GATE_SPINS"); return e ? (unsigned)atoi(e) : 16u; }();
+    if (concurrent && do_w && idle_start && !no_gate) hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, sa, gate_spins);
     if (do_a && tiles[c] > 0) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, sa); }
@@ -700,7 +663,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
                          concurrent ? d_ready : nullptr, stn);
       if (timed) { (void)hipEventRecord(t1, stn); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({t0, t1, 2}); } }
       if (concurrent) HIPCHK(hipEventRecord(plan->ev_tension, stn));
-      if (!walk_first) launch_walk();
+      launch_walk();
     }
     // the caller's stream is "done" only when the side launches have retired too
     if (concurrent) {
