@@ -199,6 +199,8 @@ def pcie_pipeline(plan, streams, n, reps, warm=2):
     drain(warm + reps - 1)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    last = (warm + reps - 1) % 2      # what arrived in host memory is what the device packed (outside the timed region)
+    assert torch.equal(h_out[last][:totals[-1]], packed[last][:totals[-1]].cpu()), "PCIe pipeline: host copy differs"
     return dt, totals[-1]
 
 
