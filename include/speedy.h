@@ -14,11 +14,8 @@
  * soniclib.c:538-550) and are then never computed -- as in the reference, the first call that succeeds is the one treated
  * as a low-energy frame (speedy.c:293,691).  Anything else returns 0 / is ignored with a message in speedyHipLastError().
  *
- * NOT provided -- the reference's test-only hooks that pass intermediate arrays between stages on the host
- * (speedy.h:102-133: speedyEvaluateHysteresis, speedyAddToHysteresisBuffer, speedyComputeSpectralDifference,
- * speedyComputeLocalEnergy, speedySaveSpectrogramData, speedyPreemphasisFilter, speedyNormalizeByEnergy, the
- * FirstOrderFilter functions): the stages are fused on the device, there is no host-visible hand-off to hook.  Their
- * known-answer tests are restated against the CPU oracle (tests/test_oracle_kat.py). */
+ * The reference's test hooks between stages (speedy.h:102-133) are provided too, see below: with the stages fused on the
+ * device there is no host-visible hand-off to hook, so each is a small kernel of its own on the shared device state. */
 #ifndef SPEEDY_HIP_SPEEDY_H_
 #define SPEEDY_HIP_SPEEDY_H_
 #include <stdint.h>
@@ -61,6 +58,30 @@ float* speedyGetNormalizedSpectrogram(speedyStream stream);
 float* speedyGetInternalState(speedyStream stream);
 float speedyGetEnergyCompressed(speedyStream stream);                        /* of the last frame added */
 float speedyGetSpeechChanges(speedyStream stream);                           /* of the last tension */
+/* ---- the reference's hooks between stages (speedy.h:102-133), which its unit tests drive directly (speedy_test.cc:135-453).
+ * The stages are fused on the device; each hook is a small kernel of its own on the same device state the fused kernels
+ * use (filter states, hysteresis values, spectra), with the reference's arithmetic.  Times follow speedyAddData's. ---- */
+void speedyComputeSpectralDifference(speedyStream stream, const float* spectrogram, const float* last_spectrogram,
+                                     int64_t at_time);                       /* speedy.c:664-729; fft_size/2 bins of each are read */
+void speedyComputeLocalEnergy(speedyStream stream, float* spectrogram, int64_t at_time);  /* speedy.c:510-523: the LAST frame's
+                                                                                 spectrum, whatever is passed (speedy.c:515) */
+void speedySaveSpectrogramData(speedyStream stream, float spectrogram[], int64_t at_time);   /* speedy.c:476-483 */
+void speedyPreemphasisFilter(speedyStream stream, float* input, int length);  /* speedy.c:416-425, in place, state carried */
+float speedyEvaluateHysteresis(speedyStream stream, int64_t at_time);         /* speedy.c:590-610 */
+void speedyAddToHysteresisBuffer(speedyStream stream, float value, int64_t at_time);         /* speedy.c:615-619 */
+float* speedyGetInternalSpectrogram(speedyStream stream);                     /* = speedyGetSpectrogram (speedy.c:393-396) */
+float* speedyGetInternalNormalizedSpectrogram(speedyStream stream);           /* = speedyGetNormalizedSpectrogram (:398-401) */
+float speedyNormalizeByEnergy(const float* spectrogram, float* normalized, int length);      /* speedy.c:628-647 */
+
+/* A first-order low-pass filter (speedy.c:50-88); its state lives on the device, each call is one tiny launch. */
+struct FirstOrderFilterStruct;
+typedef struct FirstOrderFilterStruct* FirstOrderFilter;
+FirstOrderFilter CreateFirstOrderFilter(float time_constant_in_samples);
+void DesignFirstOrderLowpassFilter(FirstOrderFilter fof, float time_constant_in_samples);
+float IterateFirstOrderFilter(FirstOrderFilter fof, float input);
+void ResetFirstOrderFilter(FirstOrderFilter fof);
+void DeleteFirstOrderFilter(FirstOrderFilter fof);
+
 /* kTemporalHysteresisFuture / Past of this stream (compile-time constants in the reference, speedy.h:136-146). */
 int speedyHipHysteresisFuture(speedyStream stream);
 int speedyHipHysteresisPast(speedyStream stream);

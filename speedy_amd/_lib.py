@@ -117,6 +117,21 @@ SYMBOLS = {
     "speedyGetSpeechChanges": (C.c_float, [C.c_void_p]),
     "speedyHipHysteresisFuture": (C.c_int, [C.c_void_p]),
     "speedyHipHysteresisPast": (C.c_int, [C.c_void_p]),
+    # the hooks between stages (speedy.h:102-133)
+    "speedyComputeSpectralDifference": (None, [C.c_void_p, c_float_p, c_float_p, C.c_int64]),
+    "speedyComputeLocalEnergy": (None, [C.c_void_p, c_float_p, C.c_int64]),
+    "speedySaveSpectrogramData": (None, [C.c_void_p, c_float_p, C.c_int64]),
+    "speedyPreemphasisFilter": (None, [C.c_void_p, c_float_p, C.c_int]),
+    "speedyEvaluateHysteresis": (C.c_float, [C.c_void_p, C.c_int64]),
+    "speedyAddToHysteresisBuffer": (None, [C.c_void_p, C.c_float, C.c_int64]),
+    "speedyGetInternalSpectrogram": (c_float_p, [C.c_void_p]),
+    "speedyGetInternalNormalizedSpectrogram": (c_float_p, [C.c_void_p]),
+    "speedyNormalizeByEnergy": (C.c_float, [c_float_p, c_float_p, C.c_int]),
+    "CreateFirstOrderFilter": (C.c_void_p, [C.c_float]),
+    "DesignFirstOrderLowpassFilter": (None, [C.c_void_p, C.c_float]),
+    "IterateFirstOrderFilter": (C.c_float, [C.c_void_p, C.c_float]),
+    "ResetFirstOrderFilter": (None, [C.c_void_p]),
+    "DeleteFirstOrderFilter": (None, [C.c_void_p]),
     "speedyHipSetMatchMatlab": (None, [C.c_int]),
     "sonicSamplesAvailable": (C.c_int, [C.c_void_p]),
     "speedyHipLastError": (C.c_char_p, []),

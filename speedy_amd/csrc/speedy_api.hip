@@ -11,6 +11,7 @@
 
 #include "../../include/speedy.h"
 #include "spx_internal.h"
+#include "spx_log.h"
 
 extern "C" const char* speedyHipLastError(void);
 void spx_internal_set_api_error(const std::string& msg);   // sonic2_api.hip
@@ -39,6 +40,9 @@ struct speedyStreamStruct {
   int64_t current_time = 0;
   int64_t tensionDone = 0;  // lowest tension frame that may still be asked for
   bool started = false;
+  int64_t hookHi = 0;       // one past the highest row a hook has written (rows beyond T that must survive a reallocation)
+  float preemph_prev = 0.0f;  // speedyPreemphasisFilter: the last raw sample it (or speedyAddData) has seen (speedy.c:416-425)
+  float* dHook = nullptr;     // [0] scalar result of a hook kernel; [8 ..) a frame's worth of scratch floats
   std::vector<float> hSpec, hSpecAt, hNorm, hFeat, hTmp;
 };
 
@@ -48,7 +52,7 @@ static bool grow(speedyStream s, int64_t need_hi) {
   const int64_t lo = std::max<int64_t>(0, std::min(s->T, s->tensionDone) - SPD_KEEP - P.Pp - P.F);
   if (s->dFrames && need_hi <= s->origin + s->cap && lo - s->origin <= s->cap / 2) return true;
   const int64_t ncap = std::max<int64_t>(256, 2 * (need_hi - lo));
-  const int64_t keep_lo = std::max(lo, s->origin), keep_hi = s->T + 1;  // rows that hold data (+1: normalised row T)
+  const int64_t keep_lo = std::max(lo, s->origin), keep_hi = std::max(s->T + 1, s->hookHi);  // rows that hold data (+1: normalised row T)
   auto move = [&](auto*& p, int64_t stride) -> bool {
     using E = std::remove_reference_t<decltype(*p)>;
     E* np = nullptr;
@@ -102,6 +106,130 @@ static bool launch(speedyStream s, bool new_frame, int64_t k_from, int64_t k_to)
   return true;
 }
 
+
+// =====================================================================================================================
+// The reference's test hooks between stages (speedy.h:102-133, used by speedy_test.cc:135-453).  The stages are fused
+// on the device, so each hook is a small kernel of its own on the SAME device state the fused kernels use -- the energy
+// and difference filter states of the stream record, the hysteresis values in the per-frame scratch array (slot of
+// time t = frame t - time0), the spectra in the tap array -- with the reference's arithmetic (types and order as in
+// spx_analysis.hip / spx_tension.hip, which are checked against the oracle bit for bit).  One lane does the work: these
+// are per-frame scalars and a few hundred bins.
+// =====================================================================================================================
+struct FirstOrderFilterStruct { float* d; int device; };  // device: [0] alpha, [1] state
+
+__global__ void hk_fof_iterate_kernel(float* f, float input, float* out) {
+  if (threadIdx.x != 0) return;
+  const float alpha = f[0];
+  const float y = (1 - alpha) * input + alpha * f[1];   // speedy.c:74, all float
+  f[1] = y;
+  *out = y;
+}
+
+// speedyNormalizeByEnergy (speedy.c:628-647): energy over bins 1.., every bin scaled
+__global__ void hk_normalize_kernel(const float* s, float* out, int length, float* energy_out) {
+  if (threadIdx.x != 0) return;
+  float e = 0.0f;
+  for (int i = 1; i < length; i++) e += s[i] * s[i];
+  const float eps = 2.2204e-16f;
+  const float inv = (float)(1.0 / (__builtin_sqrt((double)e) + (double)eps));
+  for (int i = 0; i < length; i++) out[i] = s[i] * inv;
+  *energy_out = e;
+}
+
+// speedyPreemphasisFilter (speedy.c:416-425): y[i] = 1.0*x[i] - 0.97*x[i-1] in double, float store; x[-1] = prev
+__global__ void hk_preemph_kernel(float* x, int n, float prev) {
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < n; i++) {
+    const float cur = x[i];
+    x[i] = (float)(1.0 * (double)cur - 0.97 * (double)prev);
+    prev = cur;
+  }
+}
+
+// the hysteresis value of slot `tau` (time index): frame tau - time0 of the scratch array.  The reference keeps these in a
+// ring of 2*(F+P+1) entries (speedy.c:95,617): a time not written yet reads what was written one ring length (or several)
+// earlier -- which matters when a hook asks for a hysteresis before the F future frames exist (speedy_test.cc:443) --
+// and zero before the first write.  `hi` = the highest time written so far.
+__device__ inline float hk_slot(const SpxPlanDev& P, const float* scr, int64_t origin, int64_t cap, int64_t time0, int64_t hi,
+                                int64_t tau) {
+  const int64_t ring = 2 * (int64_t)(P.F + P.Pp + 1);
+  if (tau > hi) tau -= ring * ((tau - hi + ring - 1) / ring);
+  const int64_t j = tau - time0;
+  return (j >= origin && j < origin + cap && j >= 0) ? scr[4 * (j - origin) + 0] : 0.0f;
+}
+__device__ inline float hk_hysteresis(const SpxPlanDev& P, const float* scr, int64_t origin, int64_t cap, int64_t time0, int64_t hi,
+                                      int64_t k) {
+  float future_max = 0.0f, past_max = 0.0f;
+  for (int i = 0; i <= P.F; i++) {   // speedy.c:594-608
+    float v = hk_slot(P, scr, origin, cap, time0, hi, k + i);
+    v *= P.taperF[i];
+    if (v > future_max) future_max = v;
+  }
+  for (int i = 0; i <= P.Pp; i++) {
+    float v = hk_slot(P, scr, origin, cap, time0, hi, k - i);
+    v *= P.taperP[i];
+    if (v > past_max) past_max = v;
+  }
+  return (float)((double)(past_max + future_max) / 2.0);   // speedy.c:609
+}
+__global__ void hk_hysteresis_kernel(SpxPlanDev P, const float* scr, int64_t origin, int64_t cap, int64_t time0, int64_t hi, int64_t k,
+                                     float* out) {
+  if (threadIdx.x == 0) *out = hk_hysteresis(P, scr, origin, cap, time0, hi, k);
+}
+
+// speedyComputeLocalEnergy (speedy.c:510-523) for the LAST frame's spectrum (the reference reads stream->spectrogram, not
+// its argument, speedy.c:515): energy low-pass iterated once more, local energy, compression, hysteresis slot of `at_time`
+__global__ void hk_local_energy_kernel(SpxPlanDev P, SpxStreamState* st, float energy, float* slot, float* feat) {
+  if (threadIdx.x != 0) return;
+  const float lp = P.one_minus_alpha * energy + P.alpha * st->lp;   // speedy.c:74
+  st->lp = lp;
+  const float local = energy / lp;
+  const float comp = (float)__builtin_sqrt(local > 2 ? 2.0 : (double)local);
+  *slot = comp;
+  if (feat) { feat[1] = lp; feat[2] = local; feat[3] = comp; }
+}
+
+// speedyComputeSpectralDifference (speedy.c:664-729) for the two spectra given: features row k, normalised spectra
+__global__ void hk_spectral_difference_kernel(SpxPlanDev P, SpxStreamState* st, const float* cur, const float* last,
+                                              const float* scr, int64_t origin, int64_t cap, int64_t time0, int64_t hi, int64_t k,
+                                              float* feat, float* norm_row, float* norm_last) {
+  if (threadIdx.x != 0) return;
+  const int W = P.W;   // = fft_size / 2
+  const float hyst = hk_hysteresis(P, scr, origin, cap, time0, hi, k);
+  const float eps = 2.2204e-16f;
+  float e = 0.0f, mx = 0.0f, e2 = 0.0f;
+  for (int i = 1; i < W; i++) { e += cur[i] * cur[i]; mx = fmaxf(mx, cur[i]); }
+  for (int i = 1; i < W; i++) e2 += last[i] * last[i];
+  const float inv = (float)(1.0 / (__builtin_sqrt((double)e) + (double)eps));     // speedy.c:642
+  const float inv2 = (float)(1.0 / (__builtin_sqrt((double)e2) + (double)eps));
+  for (int i = 0; i < W; i++) { norm_row[i] = cur[i] * inv; norm_last[i] = last[i] * inv2; }
+  const float lowthr = (float)(0.04 * (double)1.41421f);               // speedy.c:682
+  int first_k = st->tension_first;
+  if (first_k < 0) { first_k = (int)k; st->tension_first = first_k; }  // the very first call is skipped (speedy.c:293,691)
+  const bool low = e <= lowthr || (int)k == first_k;
+  float lsd = 0.0f, ewld = 0.0f, rel = 0.0f, sc = 0.0f;
+  if (!low) {
+    const float thr = (float)((double)mx / 100.0);                     // speedy.c:709
+    for (int i = 1; i < W; i++) {
+      double term = 0.0;
+      if (cur[i] > thr && last[i] > thr) {
+        const float ratio = (norm_row[i] + eps) / (norm_last[i] + eps);
+        term = __builtin_fabs(spx_log((double)ratio));                 // speedy.c:715-717
+      }
+      lsd = (float)((double)lsd + term);                               // float +=
+    }
+    ewld = lsd * hyst;                                                 // speedy.c:720
+  }
+  const float lpf = P.one_minus_alpha * ewld + P.alpha * st->lpf;      // the difference filter runs on skipped frames too (0)
+  st->lpf = lpf;
+  if (!low) {
+    rel = (float)((double)ewld / ((double)lpf + 0.01 * (double)123.979f));         // speedy.c:725-726
+    sc = (float)fmin((double)rel, (double)(4 * 0.971975f));                        // speedy.c:727-728
+  }
+  feat[0] = e; feat[4] = hyst; feat[5] = low ? 1.0f : 0.0f; feat[6] = lsd; feat[7] = ewld; feat[8] = lpf; feat[9] = rel;
+  feat[10] = sc; feat[13] = (float)k; feat[14] = lowthr;
+}
+
 extern "C" {
 
 speedyStream speedyCreateStream(int sample_rate) {
@@ -124,7 +252,8 @@ speedyStream speedyCreateStream(int sample_rate) {
   if (hipStreamCreateWithFlags(&s->hs, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&s->dSmall), 1024) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&s->dScratchFrame), sizeof(float) * 2 * P.W) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&s->dScratchSpec), sizeof(float) * 2 * P.N) != hipSuccess) {
+      hipMalloc(reinterpret_cast<void**>(&s->dScratchSpec), sizeof(float) * 2 * P.N) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&s->dHook), sizeof(float) * (8 + 3 * (size_t)P.N)) != hipSuccess) {
     spx_internal_set_api_error("speedyCreateStream: device allocation failed");
     speedyDestroyStream(s);
     return nullptr;
@@ -143,7 +272,7 @@ void speedyDestroyStream(speedyStream s) {
   if (s->hs) (void)hipStreamSynchronize(s->hs);
   for (void* p : {(void*)s->dFrames, (void*)s->dRec, (void*)s->dScr, (void*)s->tTension, (void*)s->tSpeed,
                   (void*)s->tFeatures, (void*)s->tSpec, (void*)s->tNorm, (void*)s->dSmall, (void*)s->dScratchFrame,
-                  (void*)s->dScratchSpec})
+                  (void*)s->dScratchSpec, (void*)s->dHook})
     if (p) (void)hipFree(p);
   if (s->hs) (void)hipStreamDestroy(s->hs);
   delete s;
@@ -172,6 +301,7 @@ void speedyAddData(speedyStream s, const float input[], int64_t at_time) {
     return;
   (void)hipStreamSynchronize(s->hs);  // `input` is the caller's again
   if (!launch(s, true, s->tensionDone, s->tensionDone)) return;  // the new frame's analysis + its energy filter
+  s->preemph_prev = input[P.W - 1];  // what speedyPreemphasisFilter's state is after the reference's AddData (speedy.c:545)
   s->T++;
   s->current_time = at_time;
 }
@@ -267,5 +397,152 @@ float speedyGetEnergyCompressed(speedyStream s) {
   return v;
 }
 float speedyGetSpeechChanges(speedyStream s) { return speedyGetInternalState(s)[10]; }
+
+}  // extern "C"
+
+extern "C" {
+
+static float hook_scalar(speedyStream s) {   // the result a hook kernel left in dHook[0]
+  float v = 0.0f;
+  (void)hipMemcpyAsync(&v, s->dHook, sizeof(float), hipMemcpyDeviceToHost, s->hs);
+  (void)hipStreamSynchronize(s->hs);
+  return v;
+}
+static int64_t hook_time0(speedyStream s) { return s->time0 < 0 ? 0 : s->time0; }
+static int64_t hook_hi(speedyStream s) { return hook_time0(s) + std::max(s->T, s->hookHi) - 1; }   // highest time written so far
+// make row `j` of the per-frame arrays addressable for a hook (rows beyond the frames added so far included)
+static bool hook_row(speedyStream s, int64_t j) {
+  if (j < 0) return false;
+  if (j + 1 > s->hookHi) s->hookHi = j + 1;
+  return grow(s, std::max(s->T, j) + 2) && j >= s->origin;
+}
+static void hook_ensure_state(speedyStream s) {
+  if (s->started) return;   // the state record is initialised by the first launch; before it, do that here
+  SpxStreamState z;
+  memset(&z, 0, sizeof(z));
+  z.lp = 2.14204f; z.lpf = 123.837f;  // speedy.c:263-264
+  z.tension_first = -1;
+  (void)hipMemcpyAsync(s->dState, &z, sizeof(z), hipMemcpyHostToDevice, s->hs);
+  (void)hipStreamSynchronize(s->hs);
+  s->started = true;
+}
+
+FirstOrderFilter CreateFirstOrderFilter(float time_constant_in_samples) {          // speedy.c:50-60
+  FirstOrderFilter f = new FirstOrderFilterStruct();
+  (void)hipGetDevice(&f->device);
+  if (hipMalloc(reinterpret_cast<void**>(&f->d), 4 * sizeof(float)) != hipSuccess) { delete f; return nullptr; }
+  DesignFirstOrderLowpassFilter(f, time_constant_in_samples);
+  return f;
+}
+void DesignFirstOrderLowpassFilter(FirstOrderFilter f, float tc) {                 // speedy.c:62-71 (a table, like the plan's)
+  (void)hipSetDevice(f->device);
+  const float h[2] = {tc > 0 ? (float)exp(-1.0 / tc) : 0.0f, 0.0f};   // alpha: double exp, float store; state cleared
+  (void)hipMemcpy(f->d, h, sizeof(h), hipMemcpyHostToDevice);
+}
+float IterateFirstOrderFilter(FirstOrderFilter f, float input) {                   // speedy.c:73-76
+  (void)hipSetDevice(f->device);
+  hipLaunchKernelGGL(hk_fof_iterate_kernel, dim3(1), dim3(64), 0, nullptr, f->d, input, f->d + 2);
+  float v = 0.0f;
+  (void)hipMemcpy(&v, f->d + 2, sizeof(float), hipMemcpyDeviceToHost);
+  return v;
+}
+void ResetFirstOrderFilter(FirstOrderFilter f) {                                   // speedy.c:78-81
+  (void)hipSetDevice(f->device);
+  (void)hipMemset(f->d + 1, 0, sizeof(float));
+}
+void DeleteFirstOrderFilter(FirstOrderFilter f) {
+  if (!f) return;
+  (void)hipSetDevice(f->device);
+  if (f->d) (void)hipFree(f->d);
+  delete f;
+}
+
+float speedyNormalizeByEnergy(const float* spectrogram, float* normalized, int length) {   // speedy.c:628-647
+  if (length <= 0) return 0.0f;
+  float* d = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(float) * (2 * (size_t)length + 1)) != hipSuccess) return 0.0f;
+  (void)hipMemcpy(d, spectrogram, sizeof(float) * length, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(hk_normalize_kernel, dim3(1), dim3(64), 0, nullptr, d, d + length, length, d + 2 * length);
+  float e = 0.0f;
+  (void)hipMemcpy(normalized, d + length, sizeof(float) * length, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(&e, d + 2 * length, sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  return e;
+}
+
+void speedyPreemphasisFilter(speedyStream s, float* input, int length) {           // speedy.c:416-425, in place
+  if (length <= 0) return;
+  (void)hipSetDevice(s->device);
+  float* d = nullptr;
+  if (hipMallocAsync(reinterpret_cast<void**>(&d), sizeof(float) * (size_t)length, s->hs) != hipSuccess) return;
+  (void)hipMemcpyAsync(d, input, sizeof(float) * length, hipMemcpyHostToDevice, s->hs);
+  const float last_raw = input[length - 1];
+  hipLaunchKernelGGL(hk_preemph_kernel, dim3(1), dim3(64), 0, s->hs, d, length, s->preemph_prev);
+  (void)hipMemcpyAsync(input, d, sizeof(float) * length, hipMemcpyDeviceToHost, s->hs);
+  (void)hipFreeAsync(d, s->hs);
+  (void)hipStreamSynchronize(s->hs);
+  s->preemph_prev = last_raw;
+}
+
+void speedyAddToHysteresisBuffer(speedyStream s, float value, int64_t at_time) {   // speedy.c:615-619
+  (void)hipSetDevice(s->device);
+  const int64_t j = at_time - hook_time0(s);
+  if (!hook_row(s, j)) { spx_internal_set_api_error("speedyAddToHysteresisBuffer: time outside the kept range"); return; }
+  (void)hipMemcpyAsync(s->dScr + (j - s->origin) * 4, &value, sizeof(float), hipMemcpyHostToDevice, s->hs);
+  (void)hipStreamSynchronize(s->hs);
+}
+float speedyEvaluateHysteresis(speedyStream s, int64_t at_time) {                  // speedy.c:590-610
+  (void)hipSetDevice(s->device);
+  if (!grow(s, s->T + 2)) return 0.0f;
+  hipLaunchKernelGGL(hk_hysteresis_kernel, dim3(1), dim3(64), 0, s->hs, *s->plan, s->dScr, s->origin, s->cap, hook_time0(s),
+                     hook_hi(s), at_time, s->dHook);
+  return hook_scalar(s);
+}
+
+void speedySaveSpectrogramData(speedyStream s, float spectrogram[], int64_t at_time) {   // speedy.c:476-483
+  (void)hipSetDevice(s->device);
+  const int64_t j = at_time - hook_time0(s);
+  if (!hook_row(s, j)) { spx_internal_set_api_error("speedySaveSpectrogramData: time outside the kept range"); return; }
+  (void)hipMemcpyAsync(s->tSpec + (j - s->origin) * s->plan->N, spectrogram, sizeof(float) * s->plan->N, hipMemcpyHostToDevice, s->hs);
+  (void)hipStreamSynchronize(s->hs);
+}
+float* speedyGetInternalSpectrogram(speedyStream s) { return speedyGetSpectrogram(s); }                      // speedy.c:393-396
+float* speedyGetInternalNormalizedSpectrogram(speedyStream s) { return speedyGetNormalizedSpectrogram(s); }  // speedy.c:398-401
+
+void speedyComputeLocalEnergy(speedyStream s, float* spectrogram, int64_t at_time) {   // speedy.c:510-523
+  (void)spectrogram;   // the reference sums stream->spectrogram, the LAST frame's spectrum, whatever is passed (speedy.c:515)
+  (void)hipSetDevice(s->device);
+  const int64_t j = at_time - hook_time0(s);
+  if (!hook_row(s, j)) { spx_internal_set_api_error("speedyComputeLocalEnergy: time outside the kept range"); return; }
+  hook_ensure_state(s);
+  float energy = 0.0f;   // of the last frame added (the analysis kernel's sum, float, bin order); nothing added yet: 0
+  if (s->T > 0) {
+    SpxFrameRec r;
+    (void)hipMemcpyAsync(&r, s->dRec + (s->T - 1 - s->origin), sizeof(r), hipMemcpyDeviceToHost, s->hs);
+    (void)hipStreamSynchronize(s->hs);
+    energy = r.energy;
+  }
+  const int64_t k = j + (s->time0 == 0 ? 0 : 1) - s->plan->F;   // the feature row that shows this frame's AddData-time values
+  float* feat = (k >= s->origin && k >= 0) ? s->tFeatures + (k - s->origin) * SPX_FEATURE_COUNT : nullptr;
+  hipLaunchKernelGGL(hk_local_energy_kernel, dim3(1), dim3(64), 0, s->hs, *s->plan, s->dState, energy,
+                     s->dScr + (j - s->origin) * 4, feat);
+  (void)hipStreamSynchronize(s->hs);
+}
+
+void speedyComputeSpectralDifference(speedyStream s, const float* spectrogram, const float* last_spectrogram, int64_t at_time) {
+  (void)hipSetDevice(s->device);
+  const SpxPlanDev& P = *s->plan;
+  const int64_t k = at_time;   // feature / normalised-spectrum rows are indexed by tension time
+  if (k < 0 || !hook_row(s, k)) { spx_internal_set_api_error("speedyComputeSpectralDifference: time outside the kept range"); return; }
+  hook_ensure_state(s);
+  float* dc = s->dHook + 8;
+  (void)hipMemcpyAsync(dc, spectrogram, sizeof(float) * P.W, hipMemcpyHostToDevice, s->hs);
+  (void)hipMemcpyAsync(dc + P.N, last_spectrogram, sizeof(float) * P.W, hipMemcpyHostToDevice, s->hs);
+  hipLaunchKernelGGL(hk_spectral_difference_kernel, dim3(1), dim3(64), 0, s->hs, P, s->dState, dc, dc + P.N, s->dScr, s->origin,
+                     s->cap, hook_time0(s), hook_hi(s), k, s->tFeatures + (k - s->origin) * SPX_FEATURE_COUNT,
+                     s->tNorm + (k - s->origin) * P.W, dc + 2 * P.N);
+  (void)hipStreamSynchronize(s->hs);
+  if (s->tensionDone < k + 1) s->tensionDone = k + 1;   // speedyGetInternalState / speedyGetSpeechChanges now show this row
+}
 
 }  // extern "C"

@@ -92,3 +92,22 @@ class Speedy:
 
     def features(self):
         return self._arr(self.L.speedyGetInternalState(self.h), 15)
+
+    # ---- the hooks between stages (speedy.h:102-133), named as the oracle's Python view names them ----
+    def PreemphasisFilter(self, ptr, n):
+        self.L.speedyPreemphasisFilter(self.h, ptr, int(n))
+
+    def AddToHysteresisBuffer(self, v, t):
+        self.L.speedyAddToHysteresisBuffer(self.h, float(v), int(t))
+
+    def EvaluateHysteresis(self, t):
+        return self.L.speedyEvaluateHysteresis(self.h, int(t))
+
+    def ComputeLocalEnergy(self, ptr, t):
+        self.L.speedyComputeLocalEnergy(self.h, ptr, int(t))
+
+    def ComputeSpectralDifference(self, cur, last, t):
+        self.L.speedyComputeSpectralDifference(self.h, cur, last, int(t))
+
+    def SaveSpectrogramData(self, ptr, t):
+        self.L.speedySaveSpectrogramData(self.h, ptr, int(t))

@@ -25,7 +25,7 @@ def hiplib():
     return speedy_amd.lib()
 
 
-@pytest.mark.parametrize("header", ["speedy_hip.h", "sonic2.h"])
+@pytest.mark.parametrize("header", ["speedy_hip.h", "sonic2.h", "speedy.h"])
 def test_every_declared_symbol_is_exported(hiplib, header):
     names = declared_functions(header)
     assert len(names) >= 15
@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(hiplib, header):
 
 def test_python_binding_covers_the_headers():
     from speedy_amd._lib import SYMBOLS
-    declared = set(declared_functions("speedy_hip.h")) | set(declared_functions("sonic2.h"))
+    declared = set(declared_functions("speedy_hip.h")) | set(declared_functions("sonic2.h")) | set(declared_functions("speedy.h"))
     assert declared <= set(SYMBOLS), sorted(declared - set(SYMBOLS))
 
 

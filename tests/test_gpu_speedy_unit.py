@@ -193,3 +193,140 @@ def test_unit_api_at_a_rate_with_the_small_analysis_tile(orc):
             out_t += 1
     assert out_t > 20
     g.close()
+
+
+# ---- the reference's hooks between stages (speedy.h:102-133) through the HIP library: its own unit tests
+# (speedy_test.cc:135-453, the same restatements tests/test_oracle_kat.py runs on the oracle) and oracle equality ----
+K_RATE = 22050
+
+
+def _fptr(a):
+    import ctypes as C
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def test_hook_first_order_filter():
+    """speedy_test.cc:135-156"""
+    from speedy_amd._lib import lib
+    L = lib()
+    tc = 10
+    f = L.CreateFirstOrderFilter(float(tc))
+    assert f
+    out = first = L.IterateFirstOrderFilter(f, 1.0)
+    for _ in range(tc):
+        out = L.IterateFirstOrderFilter(f, 0.0)
+    assert abs(first * math.exp(-1) - out) < 1e-7
+    L.ResetFirstOrderFilter(f)
+    assert abs(L.IterateFirstOrderFilter(f, 0.0)) < 1e-7
+    L.DesignFirstOrderLowpassFilter(f, 3.0)
+    assert abs(L.IterateFirstOrderFilter(f, 1.0) - (1 - np.float32(math.exp(-1.0 / 3.0)))) < 1e-7
+    L.DeleteFirstOrderFilter(f)
+
+
+def test_hook_preemphasis(orc):
+    """speedy_test.cc:259-284, and the state after speedyAddData as the reference leaves it (speedy.c:545)."""
+    s = _hip(K_RATE)
+    x = np.array([1, 0, 0, 0], np.float32)
+    s.PreemphasisFilter(_fptr(x), 4)
+    assert np.allclose(x, [1.0, -0.97, 0, 0], atol=1e-7)
+    s2 = _hip(K_RATE)
+    outs = []
+    for v in (1.0, 0.0, 0.0, 0.0):
+        y = np.array([v], np.float32)
+        s2.PreemphasisFilter(_fptr(y), 1)
+        outs.append(float(y[0]))
+    assert np.allclose(outs, [1.0, -0.97, 0.0, 0.0], atol=1e-7)
+    g, o = _hip(K_RATE), orc.Speedy(K_RATE)
+    rng = np.random.default_rng(4)
+    fr = rng.uniform(-1, 1, g.frame_size).astype(np.float32)
+    g.add_data(fr, 0); o.add_data(fr, 0)
+    a = rng.uniform(-1, 1, 50).astype(np.float32)
+    b = a.copy()
+    g.PreemphasisFilter(_fptr(a), 50); o.PreemphasisFilter(orc.fptr(b), 50)
+    assert np.array_equal(a, b)
+    for z in (s, s2, g):
+        z.close()
+
+
+@pytest.mark.parametrize("match_matlab", [True, False])
+def test_hook_hysteresis_triangle(orc, match_matlab):
+    """speedy_test.cc:288-313, both #ifdef branches, tolerance 1e-8; equal to the oracle's values bit for bit."""
+    if match_matlab:
+        correct = [0] * 9 + [k / 16. for k in range(1, 8)] + [1] + [k / 24. for k in range(11, 0, -1)] + [0] * 4
+    else:
+        correct = [0] * 5 + [k / 24. for k in range(1, 12)] + [1.] + [k / 16. for k in range(7, 0, -1)] + [0] * 8
+    g, o = _hip(K_RATE, match_matlab), orc.Speedy(K_RATE, match_matlab)
+    for i in range(32):
+        g.AddToHysteresisBuffer(float(i == 16), i)
+        o.AddToHysteresisBuffer(float(i == 16), i)
+    for i in range(32):
+        v = g.EvaluateHysteresis(i)
+        assert abs(v - correct[i]) < 1e-8, i
+        assert np.float32(v) == np.float32(o.EvaluateHysteresis(i)), i
+    g.close()
+
+
+def test_hook_normalize_by_energy(orc):
+    """speedy_test.cc:317-328, and a random spectrum against the oracle."""
+    from speedy_amd._lib import lib
+    L = lib()
+    x = np.array([0, 0, 1, 0, 1], np.float32)
+    y = np.zeros(5, np.float32)
+    e = L.speedyNormalizeByEnergy(_fptr(x), _fptr(y), 5)
+    assert abs(e - 2.0) < 1e-7
+    assert np.allclose(y, [0, 0, math.sqrt(0.5), 0, math.sqrt(0.5)], atol=1e-7)
+    x = np.abs(np.random.default_rng(1).normal(size=330)).astype(np.float32)
+    y, y2 = np.zeros(330, np.float32), np.zeros(330, np.float32)
+    e = L.speedyNormalizeByEnergy(_fptr(x), _fptr(y), 330)
+    e2 = orc.lib().orc_speedyNormalizeByEnergy(orc.fptr(x), orc.fptr(y2), 330)
+    assert np.float32(e) == np.float32(e2) and np.array_equal(y, y2)
+
+
+def test_hook_local_energy(orc):
+    """speedy_test.cc:380-412: speedyAddData and then speedyComputeLocalEnergy on the same frame -- the energy filter runs
+    TWICE per frame; pinned at sqrt(2) for 6 frames, ends at 1.7745e-4 +- 1e-8; every value equal to the oracle's."""
+    g, o = _hip(K_RATE), orc.Speedy(K_RATE)
+    N = g.frame_size
+    i = np.arange(N)
+    amp = np.float32(1.0)
+    at_max = 0
+    for t in range(100):
+        x = (np.sin(2 * np.pi * i / np.float32(N)) * amp).astype(np.float32)
+        g.add_data(x, t); o.add_data(x, t)
+        assert g.GetCurrentTime() == t
+        spec = g.spectrogram_at(t)
+        g.ComputeLocalEnergy(_fptr(spec), t)
+        o.ComputeLocalEnergy(orc.fptr(o.spectrogram_at(t)), t)
+        assert np.float32(g.GetEnergyCompressed()) == np.float32(o.GetEnergyCompressed()), t
+        if g.GetEnergyCompressed() > 1.414:
+            at_max += 1
+        amp = np.float32(amp * np.float32(0.9))
+    assert at_max == 6
+    assert abs(g.GetEnergyCompressed() - 1.7745e-04) < 1e-8
+    g.close()
+
+
+def test_hook_spectral_difference(orc):
+    """speedy_test.cc:418-453: last speech_changes == 0 +- 1e-6; every feature row equal to the oracle's where both define it."""
+    g, o = _hip(K_RATE), orc.Speedy(K_RATE)
+    N = g.frame_size
+    i = np.arange(N)
+    amp = np.float32(1.0)
+    last = None
+    for t in range(100):
+        freq = t / 2.0
+        x = (np.sin(2 * np.pi * freq * i / np.float32(N)) * amp).astype(np.float32)
+        g.add_data(x, t); o.add_data(x, t)
+        ct = g.GetCurrentTime()
+        cur, prev = g.spectrogram_at(ct), g.spectrogram_at(ct - 1)
+        assert np.array_equal(cur, o.spectrogram_at(ct)) and np.array_equal(prev, o.spectrogram_at(ct - 1)), t
+        g.ComputeSpectralDifference(_fptr(cur), _fptr(prev), t)
+        o.ComputeSpectralDifference(orc.fptr(cur), orc.fptr(prev), t)
+        last = g.GetSpeechChanges()
+        assert np.float32(last) == np.float32(o.GetSpeechChanges()), t
+        fg, fo = g.features(), o.features()
+        for idx in (0, 4, 5, 6, 7, 8, 9, 10, 13):       # what speedyComputeSpectralDifference writes (speedy.c:664-729)
+            assert np.float32(fg[idx]) == np.float32(fo[idx]), (t, idx, fg[idx], fo[idx])
+        amp = np.float32(amp * np.float32(0.9))
+    assert abs(last) < 1e-6
+    g.close()
