@@ -12,9 +12,11 @@
  * of frames delivered (0 = nothing ready), no exceptions cross this boundary.
  * A stream is not thread-safe; distinct streams are independent.
  *
- * Execution model: every write enqueues the analysis + walk kernels for the newly completed 10 ms
- * frames on the stream's HIP stream; reads synchronise and copy from the device-resident output FIFO.
- * The sequence of output samples, and the count available after each write, equal the reference's.
+ * Execution model: a write stages its samples; the kernels for the newly completed 10 ms frames of ALL
+ * streams with staged work run as one launch sequence when a result is first asked for (see
+ * speedyHipSetCoalescing below; streams with callbacks, a rate stage or mode switches run their own
+ * sequence per write).  The sequence of output samples, and the count available after each write,
+ * equal the reference's.
  */
 #ifndef SPEEDY_HIP_SONIC2_H_
 #define SPEEDY_HIP_SONIC2_H_
@@ -81,6 +83,17 @@ void* sonicIntGetUserData(sonicStream stream);
  * here it is a process-wide default read at sonicCreateStream.  0 (default) = the shipped library's
  * (future,past) = (12,8); 1 = the test builds' (8,12). */
 void speedyHipSetMatchMatlab(int on);
+/* sonicCreateStream with the hysteresis shape given explicitly (no process-wide state involved). */
+sonicStream speedyHipCreateSonicStream(int sampleRate, int numChannels, int matchMatlab);
+/* Coalesced execution (default on; SPX_NO_POOL=1 in the environment = off), for streams created afterwards.  A plain
+ * stream -- no monitoring callbacks, rate 1, one mode, no sonicInt* calls -- only STAGES its writes and flushes; the
+ * first call that needs a result on such a stream (a read, sonicSamplesAvailable, a setter ...) runs everything that is
+ * staged on ANY stream of the device in one launch sequence.  Per-stream results are those of the reference call for
+ * call; a server that writes to all its streams and then reads from all of them pays one launch sequence per round
+ * instead of one per stream.  Streams of one device may be used from different threads (the pool is locked). */
+void speedyHipSetCoalescing(int on);
+/* Launch sequences run / stream jobs served by the current device's pool so far. */
+void speedyHipPoolStats(unsigned long long* runs, unsigned long long* jobs);
 /* Frames currently readable without blocking on new input. */
 int sonicSamplesAvailable(sonicStream stream);
 /* Text of the last failure on this thread. */

@@ -133,6 +133,9 @@ SYMBOLS = {
     "ResetFirstOrderFilter": (None, [C.c_void_p]),
     "DeleteFirstOrderFilter": (None, [C.c_void_p]),
     "speedyHipSetMatchMatlab": (None, [C.c_int]),
+    "speedyHipCreateSonicStream": (C.c_void_p, [C.c_int, C.c_int, C.c_int]),
+    "speedyHipSetCoalescing": (None, [C.c_int]),
+    "speedyHipPoolStats": (None, [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "sonicSamplesAvailable": (C.c_int, [C.c_void_p]),
     "speedyHipLastError": (C.c_char_p, []),
 }

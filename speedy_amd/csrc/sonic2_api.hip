@@ -16,9 +16,14 @@
 // shim's read index to its write index and flushes the TSM stage), the nonlinear factor is re-read on every write
 // (soniclib.c:397), sonicSetSpeed takes effect at once (soniclib.c:177-183), sonicSetRate is forwarded to the TSM stage
 // (soniclib.c:169-175): from the first write with a rate != 1 on, the TSM stage's output passes through the rate stage
-// (spx_rate.hip) into a second sliding buffer, which is then what the stream delivers.  One deviation:
-// switching between factor == 0 and factor != 0 inside one stream fails at the next write with a message
-// (speedyHipLastError); it never produces wrong audio.
+// (spx_rate.hip) into a second sliding buffer, which is then what the stream delivers.  Switching between factor == 0 and
+// factor != 0 inside one stream works as in the reference ("mixed" streams below).
+//
+// Two execution paths.  EAGER (this file): the handle's own launch sequence per write, on its own HIP stream -- what a
+// handle with monitoring callbacks, a rate stage, sonicInt* calls or a mode switch needs.  COALESCED (sonic2_pool.hip):
+// every other handle; writes and flushes are only staged, and the first call that needs results on any waiting handle
+// runs ONE launch sequence for all of them (the kernels take N-stream job tables).  Same kernels, same jobs
+// (spx_prepare_job / spx_finish_job serve both), same results call for call.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -31,128 +36,16 @@
 #include "../../include/sonic2.h"
 #include "spx_internal.h"
 
+#include <atomic>
 static thread_local std::string g_api_err;
-static int g_match_matlab = 0;
+static std::atomic<int> g_match_matlab{0};
 
-// A device array holding elements [origin, origin + cap) of a conceptually unbounded sequence.  ensure(lo, hi) makes
-// [lo, hi) addressable and keeps what is already valid from lo on ([lo, filled)); it slides -- a stream-ordered copy
-// into a fresh allocation, the old one freed in stream order -- when hi does not fit or when more than half the
-// allocation is dead prefix.  base() is the pointer that, indexed with ABSOLUTE element numbers, lands in the allocation.
-// `guard` elements in front of p[0] belong to the allocation too (zeroed, never meaningful): a reader that aligns its
-// first position down may touch them.
-template <class T>
-struct SlideBuf {
-  T* p = nullptr;
-  int64_t origin = 0;  // absolute index of p[0]
-  int64_t cap = 0;     // elements
-  int64_t filled = 0;  // absolute end of valid data (set by the owner before ensure)
-  int64_t guard = 0;   // addressable elements in front of p[0]
-  // does [lo, hi) fit as things are (and is the dead prefix still small)?
-  bool fits(int64_t lo, int64_t hi) const {
-    return p && lo >= origin && hi <= origin + cap && lo - origin <= cap / 2;
-  }
-  // move the window so that it starts at lo and holds at least [lo, hi), keeping [lo, filled)
-  bool slide_to(int64_t lo, int64_t hi, hipStream_t st, int64_t min_cap) {
-    const int64_t ncap = std::max<int64_t>(min_cap, 2 * (hi - lo));
-    T* np = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void**>(&np), (size_t)(ncap + guard) * sizeof(T), st) != hipSuccess) return false;
-    if (guard) {
-      (void)hipMemsetAsync(np, 0, (size_t)guard * sizeof(T), st);
-      np += guard;
-    }
-    if (p && filled > lo && lo >= origin) {
-      if (hipMemcpyAsync(np, p + (lo - origin), (size_t)(std::min(filled, origin + cap) - lo) * sizeof(T),
-                         hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return false;
-    }
-    if (p) (void)hipFreeAsync(p - guard, st);
-    p = np;
-    origin = lo;
-    cap = ncap;
-    return true;
-  }
-  bool ensure(int64_t lo, int64_t hi, hipStream_t st, int64_t min_cap = 4096) {
-    if (p && lo < origin) lo = origin;  // what was dropped stays dropped
-    if (lo < 0) lo = 0;
-    if (hi < lo) hi = lo;
-    if (fits(lo, hi)) return true;
-    return slide_to(lo, hi, st, min_cap);
-  }
-  T* base() const { return p - origin; }  // only ever dereferenced at indices >= origin
-  void release(hipStream_t st) {
-    if (p) (void)hipFreeAsync(p - guard, st);
-    p = nullptr;
-    cap = 0;
-  }
-};
-
-struct sonicStreamStruct {  // speedyConnectionStruct + the parts of libsonic's stream the API exposes
-  const SpxPlanDev* plan = nullptr;
-  int device = 0;
-  int sampleRate = 0, channels = 0;
-  float globalSpeed = 1.0f;         // soniclib.c:114
-  float tsmSpeed = 1.0f;            // the speed last given to the TSM stage by a setter (sonicSetSpeed sets both, sonicIntSetSpeed this one)
-  bool speedupOnly = true;          // every launch so far had speed > 1 and 0 <= nonlinear factor <= 1
-  float nonlinearFactor = 0.0f;     // soniclib.c:117
-  float feedbackStrength = 0.1f;    // soniclib.c:122
-  float rate = 1.0f;
-  int bufferSize = 0;               // 0 until the first nonlinear write (soniclib.c:195, sonic_test.cc:496)
-  int mode = -1;                    // -1 unknown, 0 linear, 1 nonlinear: what the last write was (soniclib.c:397-399 decides per write)
-  // A stream that has been written in both modes ("mixed"): the ring sequence (what nonlinear writes brought: the
-  // analysis input, handed to the TSM stage buffer by buffer as tensions arrive) and the TSM stage's input (ring buffers
-  // in hand-over order, linear writes in between, as the reference interleaves them) are two different sequences.
-  // dIn / nIn stay the ring sequence; dTsm / tPhys hold the TSM input, filled by device-to-device copies of the ring
-  // buffers at hand-over time and by the linear writes.
-  bool mixed = false;
-  int64_t tPhys = 0;                // mixed: frames of TSM input materialised so far (physical index = TSM position - tsmShift)
-  int64_t handedHost = 0;           // ring buffers handed to the TSM stage so far (the host's mirror of the device count)
-  bool tensionStarted = false;      // the tension kernel's filter states have been initialised
-  tensionFunction cbTension = nullptr;
-  speedFunction cbSpeed = nullptr;
-  featuresFunction cbFeatures = nullptr;
-  spectrogramFunction cbSpectrogram = nullptr, cbNormalized = nullptr;
-
-  hipStream_t hs = nullptr;
-  SlideBuf<int16_t> dIn, dOut;      // elements = int16 values (frames * channels); dOut = what the TSM stage produces
-  SlideBuf<int16_t> dTsm;           // mixed streams: the TSM stage's input
-  SlideBuf<int16_t> dFinal;         // rate mode: what the rate stage produces = what the stream delivers
-  SpxRateState* dRate = nullptr;    // device record of the rate stage (directly behind dNOut)
-  bool speedSet = false;            // sonicSetSpeed since the last job (SPX_F_SPEED_SET)
-  bool rateMode = false;            // a write or flush has seen rate != 1: outputs go through the rate stage from then on
-  int64_t finKnown = 0;             // rate mode: final frames produced / TSM frames taken, as of the last synchronisation
-  int64_t finBound = 0;
-  int64_t tsmSeenKnown = 0;
-  SlideBuf<SpxFrameRec> dRec;       // elements = analysis frames
-  SlideBuf<float> dScr;             // 4 floats per frame
-  SlideBuf<float> tTension, tSpeed, tFeatures, tSpec, tNorm;
-  unsigned char* dSmall = nullptr;  // SpxStreamDev job | SpxStreamState | int64 n_out, one allocation
-  SpxStreamDev* dJob = nullptr;
-  SpxStreamState* dState = nullptr;
-  int64_t* dNOut = nullptr;
-  unsigned char* hPinned = nullptr;  // pinned staging: job table (first 256 B), then input chunk / callback rows
-  size_t hPinnedBytes = 0;
-  hipEvent_t evStaged = nullptr;     // the last copy out of the staging area has been consumed
-
-  int64_t nIn = 0;          // frames written so far
-  int64_t framesDone = 0;   // analysis frames already launched
-  int64_t tensionDone = 0;  // tension frames already computed (or skipped for good by a flush)
-  int64_t tensionSkip = 0;  // SpxStreamDev::tension_skip
-  int64_t tsmShift = 0;     // SpxStreamDev::tsm_shift
-  int64_t outKnown = 0;     // frames produced, as of the last synchronisation
-  int64_t outBound = 0;     // upper bound on frames produced by everything launched
-  int64_t outRead = 0;      // frames already delivered to the caller
-  int64_t tsmBase = 0;      // TSM stage's oldest buffered frame (TSM position), as of the last synchronisation
-  float curSpeedKnown = 1.0f;  // the TSM stage's speed as of the last synchronisation
-  int writesSinceSync = 0;
-  bool dirty = false;       // launches in flight since the last synchronisation
-  bool started = false;     // a job has been launched (state record valid)
-  bool failed = false;
-  void* userData = nullptr;    // sonicIntSetUserData (soniclib.c:98,106)
-};
+#include "sonic2_stream.h"
 
 // shared with speedy_api.hip
 void spx_internal_set_api_error(const std::string& msg) { g_api_err = msg; }
-int spx_internal_match_matlab() { return g_match_matlab; }
+void spx_api_error(const std::string& msg) { g_api_err = msg; }
+int spx_internal_match_matlab() { return g_match_matlab.load(); }
 
 static bool any_callback(sonicStream s) {
   return s->cbTension || s->cbSpeed || s->cbFeatures || s->cbSpectrogram || s->cbNormalized;
@@ -184,14 +77,18 @@ extern "C" {
 const char* speedyHipLastError(void) { return g_api_err.c_str(); }
 void speedyHipSetMatchMatlab(int on) { g_match_matlab = on ? 1 : 0; }
 
+sonicStream speedyHipCreateSonicStream(int sampleRate, int numChannels, int matchMatlab);
 sonicStream sonicCreateStream(int sampleRate, int numChannels) {
+  return speedyHipCreateSonicStream(sampleRate, numChannels, g_match_matlab.load());
+}
+sonicStream speedyHipCreateSonicStream(int sampleRate, int numChannels, int matchMatlab) {
   if (numChannels < 1) { g_api_err = "sonicCreateStream: numChannels < 1"; return nullptr; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
     g_api_err = "sonicCreateStream: no HIP device (this library has no CPU path)";
     return nullptr;
   }
-  const SpxPlanDev* plan = spx_internal_shared_plan(sampleRate, g_match_matlab);
+  const SpxPlanDev* plan = spx_internal_shared_plan(sampleRate, matchMatlab ? 1 : 0);
   if (!plan) { g_api_err = "sonicCreateStream: plan creation failed"; return nullptr; }
   if (spx_walk_lds_bytes(*plan, numChannels, false) > 160 * 1024) {  // one CU's LDS
     g_api_err = "sonicCreateStream: too many channels for the walk kernel's LDS window";
@@ -218,12 +115,14 @@ sonicStream sonicCreateStream(int sampleRate, int numChannels) {
   s->dState = reinterpret_cast<SpxStreamState*>(s->dSmall + 256);
   s->dNOut = reinterpret_cast<int64_t*>(s->dSmall + 256 + sizeof(SpxStreamState));  // directly behind the state
   s->dRate = reinterpret_cast<SpxRateState*>(s->dSmall + 256 + sizeof(SpxStreamState) + sizeof(int64_t));
+  if (SpxPool* pool = spx_pool_for_device(s->device)) spx_pool_adopt(pool, s);
   return s;
 }
 
 void sonicDestroyStream(sonicStream s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
+  if (s->pooled) spx_pool_forget(s);   // off the waiting list; its buffers were only ever used on the pool's (idle) stream
   if (s->hs) (void)hipStreamSynchronize(s->hs);
   s->dIn.release(s->hs); s->dTsm.release(s->hs); s->dOut.release(s->hs); s->dFinal.release(s->hs); s->dRec.release(s->hs); s->dScr.release(s->hs);
   s->tTension.release(s->hs); s->tSpeed.release(s->hs); s->tFeatures.release(s->hs); s->tSpec.release(s->hs);
@@ -237,37 +136,41 @@ void sonicDestroyStream(sonicStream s) {
 }
 
 // sonicIntSetRate also restarts the two rate positions (the dependency does; a sample waiting in its pitch buffer stays)
+// A setting changes what the NEXT job does; work a pooled handle has only staged so far was written under the old one.
+static inline void settle(sonicStream s) { if (s->pooled && s->poolPending) (void)spx_pool_sync(s); }
 void sonicSetRate(sonicStream s, float rate) {
+  settle(s);
   s->rate = rate;
   if (s->rateMode) {
     (void)hipSetDevice(s->device);
     (void)hipMemsetAsync(&s->dRate->old_pos, 0, 2 * sizeof(int32_t), s->hs);
   }
 }
-void sonicSetSpeed(sonicStream s, float speed) { s->globalSpeed = speed; s->tsmSpeed = speed; s->speedSet = true; }
-void sonicEnableNonlinearSpeedup(sonicStream s, float f) { s->nonlinearFactor = f; }
-void sonicSetDurationFeedbackStrength(sonicStream s, float f) { s->feedbackStrength = f; }
+void sonicSetSpeed(sonicStream s, float speed) { settle(s); s->globalSpeed = speed; s->tsmSpeed = speed; s->speedSet = true; }
+void sonicEnableNonlinearSpeedup(sonicStream s, float f) { settle(s); s->nonlinearFactor = f; }
+void sonicSetDurationFeedbackStrength(sonicStream s, float f) { settle(s); s->feedbackStrength = f; }
 int getSonicBufferSize(sonicStream s) { return s ? s->bufferSize : 0; }
 int sonicSpectrogramSize(sonicStream s) { return s ? s->plan->N : 0; }
 int sonicIntGetNumChannels(sonicStream s) { return s->channels; }
 int sonicIntGetSampleRate(sonicStream s) { return s->sampleRate; }
 float sonicIntGetSpeed(sonicStream s);  // below: the TSM stage's current speed lives on the device
 
-void sonicTensionCallback(sonicStream s, tensionFunction f) { s->cbTension = f; }
+void sonicTensionCallback(sonicStream s, tensionFunction f) { settle(s); s->cbTension = f; }
 tensionFunction getSonicTensionCallback(sonicStream s) { return s->cbTension; }
-void sonicSpeedCallback(sonicStream s, speedFunction f) { s->cbSpeed = f; }
+void sonicSpeedCallback(sonicStream s, speedFunction f) { settle(s); s->cbSpeed = f; }
 tensionFunction getSonicSpeedCallback(sonicStream s) { return (tensionFunction)s->cbSpeed; }
-void sonicFeaturesCallback(sonicStream s, featuresFunction f) { s->cbFeatures = f; }
+void sonicFeaturesCallback(sonicStream s, featuresFunction f) { settle(s); s->cbFeatures = f; }
 featuresFunction getSonicFeaturesCallback(sonicStream s) { return s->cbFeatures; }
-void sonicSpectrogramCallback(sonicStream s, spectrogramFunction f) { s->cbSpectrogram = f; }
+void sonicSpectrogramCallback(sonicStream s, spectrogramFunction f) { settle(s); s->cbSpectrogram = f; }
 spectrogramFunction getSonicSpectrogramCallback(sonicStream s) { return s->cbSpectrogram; }
-void sonicNormalizedSpectrogramCallback(sonicStream s, spectrogramFunction f) { s->cbNormalized = f; }
+void sonicNormalizedSpectrogramCallback(sonicStream s, spectrogramFunction f) { settle(s); s->cbNormalized = f; }
 spectrogramFunction getSonicNormalizedSpectrogramCallback(sonicStream s) { return s->cbNormalized; }
 
 }  // extern "C"
 
 // Bring outKnown / tsmBase up to date: ONE device-to-host copy of {state record, produced count}, one synchronisation.
 static bool sync_stream(sonicStream s) {
+  if (s->pooled) return spx_pool_sync(s);
   if (!s->dirty) return true;
   (void)hipSetDevice(s->device);
   struct { SpxStreamState st; int64_t n; SpxRateState r; } h;
@@ -363,9 +266,11 @@ static void run_callbacks(sonicStream s, int64_t j0, int64_t j1, int64_t k_first
   }
 }
 
-// Enqueue the analysis + tension + walk launches for everything written since the last job.  The caller has made sure
-// the staging area exists and nobody reads its job-table slot any more.
-static int launch_job(sonicStream s, bool flush, bool direct = false) {
+// What the next job of a stream is (everything written since the last one, plus a flush): makes room in the device
+// buffers (stream-ordered on hs) and fills the two job records.  `pool`: the coalesced path -- the kernels of a pooled launch
+// get NULL base pointers, so every offset is the absolute element address of the handle's own allocation (minus the
+// sliding origin), and the frame records live in the pool's arena.
+int spx_prepare_job(sonicStream s, bool flush, bool direct, hipStream_t hs, SpxPool* pool, SpxJobPlan& J) {
   const SpxPlanDev& P = *s->plan;
   const int64_t C = s->channels;
   const int F = P.F, Pp = P.Pp, B = P.B;
@@ -379,6 +284,8 @@ static int launch_job(sonicStream s, bool flush, bool direct = false) {
   const int64_t T = hasRing ? spx_internal_frames_for(P, s->nIn) : 0;
   const int64_t fa = s->framesDone;
   const bool taps = nonlinear && any_callback(s);
+  J.hasRing = hasRing; J.nonlinear = nonlinear; J.taps = taps; J.flush = flush; J.direct = direct;
+  J.T = T; J.fa = fa;
 
   // ---- ring buffers this job hands to the TSM stage (the kernel counts the same way: spx_walk.hip events) ----
   const int64_t handedBefore = s->handedHost;
@@ -387,15 +294,16 @@ static int launch_job(sonicStream s, bool flush, bool direct = false) {
     if (nonlinear) handedAfter = std::max<int64_t>(handedBefore, (T >= F) ? T - F + 1 : 0);  // one per tension frame, soniclib.c:354-369
     if (flush && !direct) handedAfter = std::max<int64_t>(handedAfter, s->nIn / B);         // every complete buffer, :538-550
   }
+  J.handedAfter = handedAfter;
   if (s->mixed && handedAfter > handedBefore) {   // they join the TSM input behind whatever the linear writes put there
     const int64_t n = (handedAfter - handedBefore) * B;
     int64_t keepT = s->tsmBase - s->tsmShift - 16;
     if (s->dirty) keepT = std::min(keepT, s->dTsm.origin / C);
     if (keepT < 0) keepT = 0;
     s->dTsm.filled = s->tPhys * C;
-    if (!s->dTsm.ensure(keepT * C, (s->tPhys + n) * C + 64, s->hs, 1 << 16)) return 0;
+    if (!s->dTsm.ensure(keepT * C, (s->tPhys + n) * C + 64, hs, 1 << 16)) return 0;
     if (hipMemcpyAsync(s->dTsm.base() + s->tPhys * C, s->dIn.base() + handedBefore * B * C, sizeof(int16_t) * (size_t)(n * C),
-                       hipMemcpyDeviceToDevice, s->hs) != hipSuccess)
+                       hipMemcpyDeviceToDevice, hs) != hipSuccess)
       return 0;
     s->tPhys += n;
   }
@@ -407,10 +315,11 @@ static int launch_job(sonicStream s, bool flush, bool direct = false) {
   const int64_t bound = s->outKnown + spx_internal_out_bound(P, unconsumed, std::min(s->globalSpeed, s->tsmSpeed), hasRing);
   if (s->outBound < s->outKnown) s->outBound = s->outKnown;
   const int64_t need = std::max(bound, s->outBound);
+  J.need = need;
   s->dOut.filled = s->outBound * C;
   // rate mode: the TSM output is dead once the rate stage has taken it (one frame stays as its left neighbour's source)
   const int64_t tsmKeep = s->rateMode ? std::max<int64_t>(0, s->tsmSeenKnown - 1) : s->outRead;
-  if (!s->dOut.ensure(tsmKeep * C, need * C, s->hs, 1 << 16)) return 0;
+  if (!s->dOut.ensure(tsmKeep * C, need * C, hs, 1 << 16)) return 0;
   int oldR = s->sampleRate, newR = s->sampleRate;
   if (s->rateMode) {
     newR = (int)(s->sampleRate / s->rate);               // the dependency's adjustRate: both halved down to 14 bits
@@ -420,9 +329,10 @@ static int launch_job(sonicStream s, bool flush, bool direct = false) {
     const double per = (s->rate != 1.0f) ? (double)newR / (double)oldR : 1.0;
     const int64_t fneed = std::max(s->finBound, s->finKnown + (int64_t)((double)(need - s->tsmSeenKnown + 2) * per) + 16);
     s->dFinal.filled = s->finBound * C;
-    if (!s->dFinal.ensure(s->outRead * C, fneed * C, s->hs, 1 << 16)) return 0;
+    if (!s->dFinal.ensure(s->outRead * C, fneed * C, hs, 1 << 16)) return 0;
     s->finBound = fneed;
   }
+  J.oldR = oldR; J.newR = newR;
   // ---- frame records: the tension kernel looks back Pp + 1 frames of compressed energy and one record ----
   if (nonlinear) {
     // The kernels index all per-frame arrays (records, scratch, taps) through ONE frame_off, so they slide together:
@@ -436,29 +346,38 @@ static int launch_job(sonicStream s, bool flush, bool direct = false) {
     bool move = !s->dRec.fits(keep, hi) || !s->dScr.fits(4 * keep, 4 * hi);
     if (taps)
       for (auto& m : tapm) move = move || !m.b->fits(keep * m.stride, hi * m.stride);
-    if (move) {
+    if (move && pool) {
+      if (!spx_pool_slide_frames(pool, s, keep, hi, fa, hs)) return 0;
+    } else if (move) {
       s->dRec.filled = fa; s->dScr.filled = 4 * fa;
-      if (!s->dRec.slide_to(keep, hi, s->hs, 4096) || !s->dScr.slide_to(4 * keep, 4 * hi, s->hs, 4 * 4096)) return 0;
+      if (!s->dRec.slide_to(keep, hi, hs, 4096) || !s->dScr.slide_to(4 * keep, 4 * hi, hs, 4 * 4096)) return 0;
       if (taps)
         for (auto& m : tapm) {
           m.b->filled = m.filled_frames * m.stride;
-          if (!m.b->slide_to(keep * m.stride, hi * m.stride, s->hs, 4096 * m.stride)) return 0;
+          if (!m.b->slide_to(keep * m.stride, hi * m.stride, hs, 4096 * m.stride)) return 0;
         }
     }
   }
   SlideBuf<int16_t>& tsmIn = s->mixed ? s->dTsm : s->dIn;   // what the walk kernel reads
-  if (!s->dIn.p && !s->dIn.ensure(0, 64 * C, s->hs, 1 << 16)) return 0;  // a flush before any write: the kernels still
-  if (!tsmIn.p && !tsmIn.ensure(0, 64 * C, s->hs, 1 << 16)) return 0;    // get real (empty, guarded) input arrays
+  J.tsmIn = &tsmIn;
+  if (!s->dIn.p && !s->dIn.ensure(0, 64 * C, hs, 1 << 16)) return 0;  // a flush before any write: the kernels still
+  if (!tsmIn.p && !tsmIn.ensure(0, 64 * C, hs, 1 << 16)) return 0;    // get real (empty, guarded) input arrays
   // ---- the jobs: absolute stream coordinates through (possibly negative) base offsets.  JA = what the analysis and
   // tension kernels see (the ring sequence), JW = what the walk kernel sees (the TSM input): the same record unless the
   // stream is mixed ----
-  static_assert(2 * 128 <= SPX_STAGE_JOB && sizeof(SpxStreamDev) <= 128, "job table slot");
-  SpxStreamDev& JA = *reinterpret_cast<SpxStreamDev*>(s->hPinned);
-  SpxStreamDev& JW = *reinterpret_cast<SpxStreamDev*>(s->hPinned + 128);
-  memset(s->hPinned, 0, 256);
-  JA.in_off = -s->dIn.origin; JA.n_in = s->nIn;
-  JA.out_off = -s->dOut.origin; JA.out_cap = (s->dOut.origin + s->dOut.cap) / C;
-  JA.frame_off = -s->dRec.origin; JA.n_frames = (int32_t)T; JA.frame_begin = (int32_t)fa;
+  // element offset that makes `base + off + k` land on element k of the sliding buffer: base = the allocation (eager) or
+  // NULL (pooled launches: the allocation's address counted in elements; hipMalloc'ed blocks are 256-byte aligned)
+  auto off16 = [&](const SlideBuf<int16_t>& b) -> int64_t {
+    return (pool ? (int64_t)(reinterpret_cast<uintptr_t>(b.p) / sizeof(int16_t)) : 0) - b.origin;
+  };
+  SpxStreamDev& JA = J.JA;
+  SpxStreamDev& JW = J.JW;
+  memset(&JA, 0, sizeof(JA));
+  JA.in_off = off16(s->dIn); JA.n_in = s->nIn;
+  JA.out_off = off16(s->dOut); JA.out_cap = (s->dOut.origin + s->dOut.cap) / C;
+  JA.frame_off = -s->dRec.origin;
+  if (pool && s->dRec.p) JA.frame_off += s->dRec.p - spx_pool_arena_rec(pool);
+  JA.n_frames = (int32_t)T; JA.frame_begin = (int32_t)fa;
   JA.channels = (int32_t)C;
   const int common = (flush ? SPX_F_FLUSH : 0) | (s->rateMode ? SPX_F_NO_TRUNC : 0) | (s->speedSet ? SPX_F_SPEED_SET : 0);
   s->speedSet = false;
@@ -471,7 +390,7 @@ static int launch_job(sonicStream s, bool flush, bool direct = false) {
   JW.speed = s->tsmSpeed;
   JW.flags = common | (s->started ? 0 : SPX_F_INIT);
   if (s->mixed) {
-    JW.in_off = -s->dTsm.origin; JW.n_in = s->tPhys;
+    JW.in_off = off16(s->dTsm); JW.n_in = s->tPhys;
     JW.flags |= SPX_F_HANDED_IN | (nonlinear ? 0 : SPX_F_KEEP_SPEED);
     JW.handed_in = (int32_t)handedBefore;
     JW.ring_bufs = (int32_t)(s->nIn / B);
@@ -481,50 +400,68 @@ static int launch_job(sonicStream s, bool flush, bool direct = false) {
   if (!(JA.speed > 1.0f && JW.speed > 1.0f && JA.nonlinear >= 0.0f && JA.nonlinear <= 1.0f)) s->speedupOnly = false;
   // SPX_F_NO_TRUNC and the mixed-stream flags are the general walk kernel's (the speed-up kernels are tuned to their
   // register budget)
-  const bool speedupKernel = s->speedupOnly && !s->rateMode && !s->mixed;
-  SpxStreamDev* dJobW = reinterpret_cast<SpxStreamDev*>(reinterpret_cast<unsigned char*>(s->dJob) + 128);
-  if (hipMemcpyAsync(s->dJob, s->hPinned, 256, hipMemcpyHostToDevice, s->hs) != hipSuccess) return 0;
-  (void)hipEventRecord(s->evStaged, s->hs);
-  SpxTapsDev td = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  const int64_t fo = JA.frame_off;
-  if (taps) {  // tap rows are indexed frame_off + k: give the kernels bases that make that land in the sliding buffers
-    td.tension = s->tTension.base() - fo; td.speed = s->tSpeed.base() - fo;
-    td.features = s->tFeatures.base() - fo * SPX_FEATURE_COUNT;
-    td.spectrogram = s->tSpec.base() - fo * P.N; td.normalized = s->tNorm.base() - fo * P.W;
-  }
-  if (nonlinear && T > fa) {
-    const int TF = P.tile_frames;
-    const int tiles = (int)((T - fa + TF - 1) / TF);
-    spx_launch_analysis(P, s->dJob, 1, tiles, s->dIn.p, s->dRec.p, td, nullptr, nullptr, s->hs);
-  }
-  if (nonlinear) {
-    spx_launch_tension(P, s->dJob, 1, s->dState, s->dRec.p, s->dScr.p, td, nullptr, nullptr, s->hs);
-    s->tensionStarted = true;
-  }
-  spx_launch_walk(P, dJobW, 1, (int)C, tsmIn.p, s->dOut.p, s->dNOut, s->dState, s->dScr.p, nullptr, speedupKernel, s->hs);
-  if (s->rateMode)
-    spx_launch_rate(s->dRate, s->dState, s->dNOut, s->dOut.base(), s->dFinal.base(),
-                    (s->dFinal.origin + s->dFinal.cap) / C, (int)C, oldR, newR, s->rate, s->rate == 1.0f ? 1 : 0,
-                    flush ? 1 : 0, s->hs);
-  if (hipGetLastError() != hipSuccess) { g_api_err = "kernel launch failed"; s->failed = true; return 0; }
+  J.speedupKernel = s->speedupOnly && !s->rateMode && !s->mixed;
+  J.tiles = (nonlinear && T > fa) ? (int)((T - fa + P.tile_frames - 1) / P.tile_frames) : 0;
+  return 1;
+}
+
+// The host's mirror of what the job just enqueued will have done to the stream.
+void spx_finish_job(sonicStream s, const SpxJobPlan& J) {
+  const SpxPlanDev& P = *s->plan;
+  const int F = P.F;
   s->started = true;
   s->dirty = true;
-  s->outBound = need;
-  s->handedHost = handedAfter;
+  s->outBound = J.need;
+  s->handedHost = J.handedAfter;
+  if (J.nonlinear) s->tensionStarted = true;
   const int64_t k_first = std::max(s->tensionDone, s->tensionSkip);
-  if (hasRing) s->framesDone = std::max(s->framesDone, nonlinear ? T : fa);
-  if (nonlinear) s->tensionDone = std::max<int64_t>(k_first, (T >= F) ? T - F + 1 : 0);
-  if (flush) {
+  if (J.hasRing) s->framesDone = std::max(s->framesDone, J.nonlinear ? J.T : J.fa);
+  if (J.nonlinear) s->tensionDone = std::max<int64_t>(k_first, (J.T >= F) ? J.T - F + 1 : 0);
+  if (J.flush) {
     // soniclib.c:538-550: every complete ring buffer goes to the TSM stage at the last speed and the shim's read index
     // moves to its write index -- tension frames below it that were not computed yet never will be; sonicIntFlushStream
     // then pads 2*maxRequired zeros, which later input follows in TSM coordinates
-    if (hasRing && !direct) {
+    if (J.hasRing && !J.direct) {
       s->tensionSkip = std::max(s->tensionSkip, s->nIn / P.B);
       s->tensionDone = std::max(s->tensionDone, s->tensionSkip);
     }
     s->tsmShift += 2 * (int64_t)P.maxRequired;
   }
-  if (taps && T > fa) run_callbacks(s, fa, T, k_first);
+}
+
+// Enqueue the analysis + tension + walk launches for everything written since the last job (the eager path: this
+// handle's own launch sequence on its own HIP stream).  The caller has made sure the staging area exists and nobody
+// reads its job-table slot any more.
+static int launch_job(sonicStream s, bool flush, bool direct = false) {
+  const SpxPlanDev& P = *s->plan;
+  const int64_t C = s->channels;
+  SpxJobPlan J;
+  if (!spx_prepare_job(s, flush, direct, s->hs, nullptr, J)) return 0;
+  static_assert(2 * 128 <= SPX_STAGE_JOB && sizeof(SpxStreamDev) <= 128, "job table slot");
+  memset(s->hPinned, 0, 256);
+  memcpy(s->hPinned, &J.JA, sizeof(SpxStreamDev));
+  memcpy(s->hPinned + 128, &J.JW, sizeof(SpxStreamDev));
+  SpxStreamDev* dJobW = reinterpret_cast<SpxStreamDev*>(reinterpret_cast<unsigned char*>(s->dJob) + 128);
+  if (hipMemcpyAsync(s->dJob, s->hPinned, 256, hipMemcpyHostToDevice, s->hs) != hipSuccess) return 0;
+  (void)hipEventRecord(s->evStaged, s->hs);
+  SpxTapsDev td = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  const int64_t fo = J.JA.frame_off;
+  if (J.taps) {  // tap rows are indexed frame_off + k: give the kernels bases that make that land in the sliding buffers
+    td.tension = s->tTension.base() - fo; td.speed = s->tSpeed.base() - fo;
+    td.features = s->tFeatures.base() - fo * SPX_FEATURE_COUNT;
+    td.spectrogram = s->tSpec.base() - fo * P.N; td.normalized = s->tNorm.base() - fo * P.W;
+  }
+  if (J.tiles > 0) spx_launch_analysis(P, s->dJob, 1, J.tiles, s->dIn.p, s->dRec.p, td, nullptr, nullptr, s->hs);
+  if (J.nonlinear) spx_launch_tension(P, s->dJob, 1, s->dState, s->dRec.p, s->dScr.p, td, nullptr, nullptr, s->hs);
+  spx_launch_walk(P, dJobW, 1, (int)C, J.tsmIn->p, s->dOut.p, s->dNOut, s->dState, s->dScr.p, nullptr, J.speedupKernel, s->hs);
+  if (s->rateMode)
+    spx_launch_rate(s->dRate, s->dState, s->dNOut, s->dOut.base(), s->dFinal.base(),
+                    (s->dFinal.origin + s->dFinal.cap) / C, (int)C, J.oldR, J.newR, s->rate, s->rate == 1.0f ? 1 : 0,
+                    flush ? 1 : 0, s->hs);
+  if (hipGetLastError() != hipSuccess) { g_api_err = "kernel launch failed"; s->failed = true; return 0; }
+  const int64_t k_first = std::max(s->tensionDone, s->tensionSkip);
+  spx_finish_job(s, J);
+  if (J.taps && J.T > J.fa) run_callbacks(s, J.fa, J.T, k_first);
   return 1;
 }
 
@@ -582,7 +519,7 @@ static bool enter_mixed(sonicStream s) {
 
 // The reference stores whatever float it is given; most values outside the documented ranges have no defined behaviour
 // there (a speed <= 0 makes the TSM stage's step counts negative).  Here the next write / flush refuses them.
-static bool settings_ok(sonicStream s) {
+bool spx_settings_ok(sonicStream s) {
   if (!(s->globalSpeed > 0.0f) || !std::isfinite(s->globalSpeed) || !(s->tsmSpeed > 0.0f) || !std::isfinite(s->tsmSpeed)) {
     g_api_err = "sonicSetSpeed: speed must be finite and > 0";
     return false;
@@ -597,10 +534,13 @@ static bool settings_ok(sonicStream s) {
 }
 
 static int write_shorts(sonicStream s, const short* in, int sampleCount, bool direct = false) {
-  if (s->failed || !settings_ok(s)) return 0;
+  if (s->failed || !spx_settings_ok(s)) return 0;
   (void)hipSetDevice(s->device);
-  if (s->rate != 1.0f && !s->rateMode && !enter_rate_mode(s)) return 0;
   const int want = (s->nonlinearFactor != 0.0f && !direct) ? 1 : 0;  // soniclib.c:397: decided anew on every write; sonicInt* bypasses
+  // the coalesced path serves plain streams; anything that needs a launch sequence of its own leaves it for good
+  if (s->pooled && (direct || s->rate != 1.0f || any_callback(s) || (s->mode >= 0 && s->mode != want)) && !spx_pool_leave(s))
+    return 0;
+  if (s->rate != 1.0f && !s->rateMode && !enter_rate_mode(s)) return 0;
   if (want == 1 && !spx_internal_analysis_fits(*s->plan)) {
     g_api_err = "sample rate too high for the nonlinear path (the analysis tile does not fit one CU's LDS); linear mode only";
     return 0;
@@ -608,6 +548,7 @@ static int write_shorts(sonicStream s, const short* in, int sampleCount, bool di
   if (s->mode < 0) s->mode = want;
   if (want == 1 && s->bufferSize == 0) s->bufferSize = s->plan->B;  // sonicAllocateBuffers, soniclib.c:195
   if (!in || sampleCount <= 0) return 1;
+  if (s->pooled) return spx_pool_write(s, in, sampleCount);
   if (s->mode != want) {  // the other mode from now on: the ring sequence and the TSM input part ways
     if (!s->mixed && !enter_mixed(s)) return 0;
     s->mode = want;
@@ -667,6 +608,7 @@ int sonicWriteFloatToStream(sonicStream s, const float* in, int sampleCount) { r
 // libsonic's sonicGetSpeed: what the TSM stage runs at right now -- the last setter's value, or in nonlinear mode the
 // speed of the last tension frame handed over (soniclib.c:354)
 float sonicIntGetSpeed(sonicStream s) {
+  settle(s);
   if (s->speedSet || !s->started) return s->tsmSpeed;
   if (!sync_stream(s)) return s->tsmSpeed;
   return s->curSpeedKnown;
@@ -678,6 +620,7 @@ int sonicSamplesAvailable(sonicStream s) {
 }
 
 int sonicReadShortFromStream(sonicStream s, short* out, int bufferSize) {
+  if (s->pooled) return spx_pool_read(s, out, bufferSize);
   if (!sync_stream(s)) return 0;
   int64_t n = (s->rateMode ? s->finKnown : s->outKnown) - s->outRead;
   if (n <= 0) return 0;
@@ -705,7 +648,7 @@ int sonicReadFloatFromStream(sonicStream s, float* out, int bufferSize) {
 // stage alone: a write bypasses the shim's ring whatever the factor, a flush leaves waiting ring buffers where they are. ----
 sonicStream sonicIntCreateStream(int sampleRate, int numChannels) { return sonicCreateStream(sampleRate, numChannels); }
 void sonicIntDestroyStream(sonicStream s) { sonicDestroyStream(s); }
-void sonicIntSetSpeed(sonicStream s, float speed) { s->tsmSpeed = speed; s->speedSet = true; }  // the TSM stage alone (the shim's global speed stays)
+void sonicIntSetSpeed(sonicStream s, float speed) { settle(s); s->tsmSpeed = speed; s->speedSet = true; }  // the TSM stage alone (the shim's global speed stays)
 void sonicIntSetRate(sonicStream s, float rate) { sonicSetRate(s, rate); }
 int sonicIntWriteShortToStream(sonicStream s, const short* in, int n) {
   return write_shorts(s, in, n, true);
@@ -720,9 +663,12 @@ void sonicIntSetUserData(sonicStream s, void* p) { s->userData = p; }
 void* sonicIntGetUserData(sonicStream s) { return s->userData; }
 
 int sonicFlushStream(sonicStream s) {
-  if (s->failed || !settings_ok(s)) return 0;
+  if (s->failed || !spx_settings_ok(s)) return 0;
   (void)hipSetDevice(s->device);
   if (s->mode < 0) s->mode = (s->nonlinearFactor != 0.0f) ? 1 : 0;
+  if (s->pooled && (s->rate != 1.0f || any_callback(s) || (s->mode == 1 && s->nonlinearFactor == 0.0f)) && !spx_pool_leave(s))
+    return 0;
+  if (s->pooled) return spx_pool_flush(s);
   // the flush itself does not look at the factor (soniclib.c:529-552): pending ring buffers go to the TSM stage at its
   // last speed.  With the factor at 0 by now there is no nonlinear job to do that in: the stream becomes a mixed one,
   // whose flushes append the pending buffers to the TSM input
@@ -732,8 +678,9 @@ int sonicFlushStream(sonicStream s) {
   return launch_job(s, true);    // the stream stays usable: a later write continues behind the flush's padding
 }
 int sonicIntFlushStream(sonicStream s) {
-  if (s->failed || !settings_ok(s)) return 0;
+  if (s->failed || !spx_settings_ok(s)) return 0;
   (void)hipSetDevice(s->device);
+  if (s->pooled && !spx_pool_leave(s)) return 0;
   if (s->mode < 0) s->mode = 0;
   if (s->mode == 1 && !s->mixed && !enter_mixed(s)) return 0;  // the TSM input goes its own way from here (buffers stay in the ring)
   if (s->rate != 1.0f && !s->rateMode && !enter_rate_mode(s)) return 0;

@@ -1,0 +1,553 @@
+// Coalesced execution of the drop-in streaming API (include/sonic2.h): many sonicStream handles, ONE launch sequence.
+//
+// The reference serves one handle per call, synchronously on the CPU (soniclib.c:391-452 -> :246-373).  A GPU pays a
+// fixed price per launch sequence (a host-to-device copy, three kernels, a synchronisation: ~150 us), so a server that
+// feeds hundreds of handles in turn would spend all of it on overheads if every write ran alone.  Here a write (or a
+// flush) on a plain handle -- no monitoring callbacks, no rate stage, one mode -- only copies the samples into a pinned
+// host area and puts the handle on its device's waiting list.  The first call that needs a RESULT on a waiting handle
+// (sonicReadShortFromStream, sonicSamplesAvailable, a setter, a second flush ...) runs everything that waits:
+//
+//   stage kernel   job tables + every staged write, read straight out of pinned host memory, scattered into the
+//                  handles' device-resident input sequences; state records gathered into one array
+//   analysis / tension / walk   the batch kernels over N-stream job tables (spx_launch_*), one sequence per
+//                  (sample rate, kernel variant) group
+//   gather kernel  state records back to their handles; the new output frames of every handle and its state record
+//                  written straight into pinned host memory
+//
+// and one synchronisation.  Reads are host copies after that.  The jobs are the ones the eager path would have run
+// (spx_prepare_job / spx_finish_job, sonic2_api.hip), on the same kernels; several writes of one handle that wait
+// together become one job, which the kernels' event model treats like the reference treats consecutive writes.  Per-handle
+// results equal the reference's call for call (tests/test_gpu_pool.py: interleaved handles against the oracle shim).
+//
+// Device memory: a handle keeps its own sliding input / output allocations (sonic2_stream.h); the kernels of a pooled
+// launch get NULL base pointers and per-stream offsets that are the allocations' absolute element addresses.  The
+// per-frame arrays (records, scratch) are indexed by the kernels through ONE offset per stream, so for pooled handles
+// they live in a pool-wide frame arena: slot f = {rec[f], scr[4f..4f+3]}; a handle owns a power-of-two range of slots.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
+
+#include "sonic2_stream.h"
+
+static std::atomic<int> g_coalesce{-1};   // -1: not decided yet (environment), 0 off, 1 on
+
+struct PinBuf {   // growable pinned host area
+  unsigned char* p = nullptr;
+  size_t cap = 0;
+  bool reserve(size_t need, size_t keep) {
+    if (need <= cap) return true;
+    size_t n = cap ? cap : (1u << 20);
+    while (n < need) n *= 2;
+    unsigned char* np = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&np), n, hipHostMallocDefault) != hipSuccess) return false;
+    if (p && keep) memcpy(np, p, keep);
+    if (p) (void)hipHostFree(p);
+    p = np;
+    cap = n;
+    return true;
+  }
+};
+
+struct PoolCopy {      // one piece of a staged write
+  int16_t* dst;        // device
+  uint32_t src_off;    // bytes into the pinned input area, 16-byte aligned
+  uint32_t n;          // int16 values
+};
+struct PoolDesc {      // per waiting handle, read by the stage and gather kernels from pinned memory
+  SpxStreamState* home;     // the handle's own state record (device)
+  const int16_t* out_base;  // dOut.base(): indexed with absolute element numbers
+  int64_t out_from;         // frames already known to the host
+  int64_t out_cap;          // absolute frame capacity of the output window (SpxStreamDev::out_cap)
+  int64_t res_off;          // this handle's slice of the pinned output area, in int16 values
+  int64_t res_cap;          // ... and its size in frames
+  int32_t channels;
+  int32_t pad;
+};
+struct PoolResult { SpxStreamState st; int64_t n; };
+
+struct SpxPool {
+  std::mutex mu;
+  int device = 0;
+  hipStream_t hs = nullptr;
+  // frame arena
+  SpxFrameRec* aRec = nullptr;
+  float* aScr = nullptr;
+  int64_t aCap = 0, aBump = 0;
+  std::vector<int64_t> freeList[48];   // by log2(slots)
+  std::vector<sonicStream> members;    // handles that own arena slots
+  // waiting work
+  std::vector<sonicStream> waiting;
+  size_t waitingSegs = 0;
+  PinBuf hIn, hTab, hRes;
+  size_t hInUsed = 0;
+  unsigned char* dWs = nullptr;
+  size_t dWsCap = 0;
+  unsigned long long runs = 0, jobs = 0;   // statistics (speedyHipPoolStats)
+};
+
+static SpxPool* g_pools[64];
+static std::mutex g_pools_mu;
+
+SpxPool* spx_pool_for_device(int device) {
+  int on = g_coalesce.load();
+  if (on < 0) {
+    on = getenv("SPX_NO_POOL") ? 0 : 1;
+    g_coalesce.store(on);
+  }
+  if (!on || device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> g(g_pools_mu);
+  if (!g_pools[device]) {
+    SpxPool* p = new SpxPool();
+    p->device = device;
+    if (hipStreamCreateWithFlags(&p->hs, hipStreamNonBlocking) != hipSuccess) { delete p; return nullptr; }
+    g_pools[device] = p;
+  }
+  return g_pools[device];
+}
+static SpxPool* pool_of(sonicStream s) { return g_pools[s->device]; }
+
+void spx_pool_adopt(SpxPool* pool, sonicStream s) {
+  (void)pool;
+  s->pooled = true;
+}
+const SpxFrameRec* spx_pool_arena_rec(SpxPool* pool) { return pool->aRec; }
+
+// ---------------- frame arena ----------------
+static int log2ceil(int64_t v) { int l = 0; while (((int64_t)1 << l) < v) l++; return l; }
+
+static bool arena_grow(SpxPool* P, int64_t min_cap) {
+  static const int64_t first = [] { const char* e = getenv("SPX_POOL_FRAMES"); return e ? atoll(e) : (int64_t)1 << 20; }();
+  int64_t ncap = P->aCap ? 2 * P->aCap : first;
+  while (ncap < min_cap) ncap *= 2;
+  SpxFrameRec* nr = nullptr;
+  float* ns = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&nr), sizeof(SpxFrameRec) * (size_t)ncap) != hipSuccess) return false;
+  if (hipMalloc(reinterpret_cast<void**>(&ns), sizeof(float) * 4 * (size_t)ncap) != hipSuccess) { (void)hipFree(nr); return false; }
+  if (P->aRec) {   // everything moves; the handles' pointers follow (offsets relative to the arena base do not change)
+    (void)hipMemcpyAsync(nr, P->aRec, sizeof(SpxFrameRec) * (size_t)P->aBump, hipMemcpyDeviceToDevice, P->hs);
+    (void)hipMemcpyAsync(ns, P->aScr, sizeof(float) * 4 * (size_t)P->aBump, hipMemcpyDeviceToDevice, P->hs);
+    (void)hipStreamSynchronize(P->hs);
+    (void)hipFree(P->aRec);
+    (void)hipFree(P->aScr);
+  }
+  P->aRec = nr; P->aScr = ns; P->aCap = ncap;
+  for (sonicStream m : P->members)
+    if (m->arenaStart >= 0) { m->dRec.p = P->aRec + m->arenaStart; m->dScr.p = P->aScr + 4 * m->arenaStart; }
+  return true;
+}
+static int64_t arena_alloc(SpxPool* P, int64_t slots) {   // slots: a power of two
+  const int l = log2ceil(slots);
+  if (!P->freeList[l].empty()) { const int64_t s = P->freeList[l].back(); P->freeList[l].pop_back(); return s; }
+  if (P->aBump + slots > P->aCap && !arena_grow(P, P->aBump + slots)) return -1;
+  const int64_t s = P->aBump;
+  P->aBump += slots;
+  return s;
+}
+static void arena_free(SpxPool* P, int64_t start, int64_t slots) {
+  if (start >= 0 && slots > 0) P->freeList[log2ceil(slots)].push_back(start);
+}
+
+bool spx_pool_slide_frames(SpxPool* P, sonicStream s, int64_t keep, int64_t hi, int64_t filled, hipStream_t hs) {
+  int64_t ncap = 256;
+  while (ncap < 2 * (hi - keep)) ncap *= 2;
+  if (s->arenaStart < 0) P->members.push_back(s);
+  const int64_t nstart = arena_alloc(P, ncap);   // (may move the arena: old pointers are refreshed by arena_grow)
+  if (nstart < 0) { spx_api_error("frame arena allocation failed"); return false; }
+  if (s->arenaStart >= 0 && filled > keep && keep >= s->dRec.origin) {
+    const int64_t n = std::min(filled, s->dRec.origin + s->dRec.cap) - keep;
+    const int64_t from = s->arenaStart + (keep - s->dRec.origin);
+    // (stream order: whoever used or will use either range is on this stream too)
+    if (hipMemcpyAsync(P->aRec + nstart, P->aRec + from, sizeof(SpxFrameRec) * (size_t)n, hipMemcpyDeviceToDevice, hs) != hipSuccess ||
+        hipMemcpyAsync(P->aScr + 4 * nstart, P->aScr + 4 * from, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToDevice, hs) != hipSuccess)
+      return false;
+  }
+  arena_free(P, s->arenaStart, s->arenaCap);
+  s->arenaStart = nstart; s->arenaCap = ncap;
+  s->dRec.p = P->aRec + nstart; s->dRec.origin = keep; s->dRec.cap = ncap;
+  s->dScr.p = P->aScr + 4 * nstart; s->dScr.origin = 4 * keep; s->dScr.cap = 4 * ncap;
+  return true;
+}
+static void arena_release(SpxPool* P, sonicStream s) {
+  if (s->arenaStart < 0) return;
+  arena_free(P, s->arenaStart, s->arenaCap);
+  s->arenaStart = -1; s->arenaCap = 0;
+  s->dRec.p = nullptr; s->dRec.cap = 0; s->dScr.p = nullptr; s->dScr.cap = 0;
+  for (size_t i = 0; i < P->members.size(); i++)
+    if (P->members[i] == s) { P->members[i] = P->members.back(); P->members.pop_back(); break; }
+}
+
+// ---------------- kernels ----------------
+// Job tables into the workspace, the handles' state records into the launch's state array, every staged write from the
+// pinned input area (read over the host link, 16 bytes per lane) into its handle's input sequence.
+__global__ void __launch_bounds__(256)
+spx_pool_stage_kernel(const unsigned* __restrict__ tab_src, unsigned* __restrict__ tab_dst, unsigned n_words,
+                      const PoolDesc* __restrict__ desc, SpxStreamState* __restrict__ states, unsigned n,
+                      const PoolCopy* __restrict__ copies, unsigned n_copies, const unsigned char* __restrict__ hin) {
+  const unsigned gt = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+  for (unsigned i = gt; i < n_words; i += stride) tab_dst[i] = tab_src[i];
+  constexpr unsigned SW = sizeof(SpxStreamState) / 4;
+  for (unsigned i = gt; i < n * SW; i += stride) {
+    const unsigned h = i / SW, w = i - h * SW;
+    reinterpret_cast<unsigned*>(states + h)[w] = reinterpret_cast<const unsigned*>(desc[h].home)[w];
+  }
+  if (blockIdx.x < n_copies) {
+    const PoolCopy c = copies[blockIdx.x];
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(hin + c.src_off);
+    for (unsigned k = threadIdx.x * 8; k < c.n; k += 256 * 8) {
+      const uint4 v = src[k >> 3];   // (the area is padded: a read past the write's end stays inside it)
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+      int16_t* d = c.dst + k;
+      const unsigned m = c.n - k;
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if ((unsigned)j < m) d[j] = (int16_t)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+    }
+  }
+}
+
+// State records back home and to the host; the frames each handle produced beyond `out_from` to the pinned output area.
+__global__ void __launch_bounds__(256)
+spx_pool_gather_kernel(const PoolDesc* __restrict__ desc, const SpxStreamState* __restrict__ states,
+                       const int64_t* __restrict__ nout, PoolResult* __restrict__ res, int16_t* __restrict__ hout) {
+  const unsigned i = blockIdx.x;
+  const PoolDesc D = desc[i];
+  const int64_t k = nout[i];
+  if (blockIdx.y == 0) {
+    constexpr unsigned SW = sizeof(SpxStreamState) / 4;
+    if (threadIdx.x < SW) {
+      const unsigned v = reinterpret_cast<const unsigned*>(states + i)[threadIdx.x];
+      reinterpret_cast<unsigned*>(D.home)[threadIdx.x] = v;
+      reinterpret_cast<unsigned*>(&res[i].st)[threadIdx.x] = v;
+    }
+    if (threadIdx.x == 0) res[i].n = k;
+  }
+  // a negative count flags an overflowed stream (the frames that fitted are there); INT64_MIN a lost producer
+  int64_t produced = (k == INT64_MIN) ? D.out_from : (k < 0 ? -k : k);
+  if (produced > D.out_cap) produced = D.out_cap;
+  int64_t fresh = produced - D.out_from;
+  if (fresh > D.res_cap) fresh = D.res_cap;
+  const int64_t elems = fresh * D.channels;
+  const int16_t* __restrict__ src = D.out_base + D.out_from * D.channels;
+  int16_t* __restrict__ dst = hout + D.res_off;
+  for (int64_t e = ((int64_t)blockIdx.y * 256 + threadIdx.x) * 4; e < elems; e += (int64_t)gridDim.y * 1024) {
+    unsigned short v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = (e + j < elems) ? (unsigned short)src[e + j] : (unsigned short)0;
+    uint2 o;
+    o.x = (unsigned)v[0] | ((unsigned)v[1] << 16);
+    o.y = (unsigned)v[2] | ((unsigned)v[3] << 16);
+    *reinterpret_cast<uint2*>(dst + e) = o;   // res_off is a multiple of 8 values; the slice is padded to one
+  }
+}
+
+// ---------------- running what waits ----------------
+static bool place_input(SpxPool* P, sonicStream s, std::vector<PoolCopy>& copies) {
+  if (s->segs.empty()) return true;
+  const SpxPlanDev& PL = *s->plan;
+  const int64_t C = s->channels;
+  SlideBuf<int16_t>& dst = s->dIn;
+  // oldest frame still needed: what the TSM stage has buffered (its window refill aligns down by 8 frames) and the
+  // analysis halo (frame framesDone-1 starts at (framesDone-1)*B)
+  int64_t keepFrom = s->tsmBase - s->tsmShift - 16;
+  if (s->mode == 1) keepFrom = std::min(keepFrom, (s->framesDone - 1) * (int64_t)PL.B - 16);
+  if (!s->started) keepFrom = std::min(keepFrom, dst.origin / C);
+  if (keepFrom < 0) keepFrom = 0;
+  dst.filled = s->devIn * C;
+  if (!dst.ensure(keepFrom * C, s->nIn * C + 64, P->hs, 1 << 16)) return false;
+  for (const auto& g : s->segs) {
+    const int64_t total = g.frames * C;
+    for (int64_t k = 0; k < total; k += 16384) {
+      PoolCopy c;
+      c.dst = dst.base() + g.pos * C + k;
+      c.src_off = (uint32_t)(g.src_off + 2 * (size_t)k);
+      c.n = (uint32_t)std::min<int64_t>(16384, total - k);
+      copies.push_back(c);
+    }
+  }
+  return true;
+}
+
+static void drop_waiting(SpxPool* P) {
+  for (sonicStream s : P->waiting) { s->poolPending = false; s->pendingFlush = false; s->segs.clear(); }
+  P->waiting.clear();
+  P->waitingSegs = 0;
+  P->hInUsed = 0;
+}
+
+// Everything that waits, one launch sequence per (plan, kernel variant) group, one synchronisation.  Pool mutex held.
+static bool pool_run(SpxPool* P) {
+  if (P->waiting.empty()) return true;
+  (void)hipSetDevice(P->device);
+  struct Item { sonicStream s; SpxJobPlan J; };
+  std::vector<Item> items;
+  items.reserve(P->waiting.size());
+  std::vector<PoolCopy> copies;
+  for (sonicStream s : P->waiting) {
+    Item it;
+    it.s = s;
+    if (s->failed || !place_input(P, s, copies) || !spx_prepare_job(s, s->pendingFlush, false, P->hs, P, it.J)) {
+      s->failed = true;
+      continue;
+    }
+    items.push_back(it);
+  }
+  const size_t n = items.size();
+  if (n == 0) { drop_waiting(P); return true; }
+  // groups: same plan (sample rate, hysteresis mode), same walk kernel family
+  std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) {
+    if (a.s->plan != b.s->plan) return a.s->plan < b.s->plan;
+    return (int)a.J.speedupKernel < (int)b.J.speedupKernel;
+  });
+  struct Group { size_t i0, i1; int tiles; int maxC; };
+  std::vector<Group> groups;
+  for (size_t i = 0; i < n;) {
+    size_t j = i;
+    Group g = {i, i, 0, 1};
+    while (j < n && items[j].s->plan == items[i].s->plan && items[j].J.speedupKernel == items[i].J.speedupKernel) {
+      items[j].J.JA.first_tile = g.tiles;
+      g.tiles += items[j].J.tiles;
+      g.maxC = std::max(g.maxC, items[j].s->channels);
+      j++;
+    }
+    g.i1 = j;
+    groups.push_back(g);
+    i = j;
+  }
+  // ---- pinned tables: jobsA[n] | jobsW[n] | desc[n] | copies[m]; pinned results: PoolResult[n] | output slices ----
+  const size_t b_jobs = sizeof(SpxStreamDev) * n;
+  const size_t o_desc = 2 * b_jobs, o_copies = o_desc + sizeof(PoolDesc) * n;
+  const size_t b_tab = o_copies + sizeof(PoolCopy) * copies.size();
+  if (!P->hTab.reserve(b_tab + 64, 0)) { spx_api_error("pinned table allocation failed"); return false; }
+  size_t res_elems = 0;
+  int64_t max_slice = 0;
+  std::vector<int64_t> res_off(n), res_cap(n);
+  for (size_t i = 0; i < n; i++) {
+    sonicStream s = items[i].s;
+    res_cap[i] = std::max<int64_t>(0, items[i].J.need - s->outKnown);
+    res_off[i] = (int64_t)res_elems;
+    const int64_t e = res_cap[i] * s->channels;
+    max_slice = std::max(max_slice, e);
+    res_elems += (size_t)((e + 7) & ~(int64_t)7);
+  }
+  const size_t o_out = (sizeof(PoolResult) * n + 63) & ~(size_t)63;
+  if (!P->hRes.reserve(o_out + res_elems * sizeof(int16_t) + 64, 0)) { spx_api_error("pinned result allocation failed"); return false; }
+  // device workspace: jobsA[n] | jobsW[n] | states[n] | nout[n]
+  const size_t w_states = (2 * b_jobs + 63) & ~(size_t)63, w_nout = w_states + ((sizeof(SpxStreamState) * n + 63) & ~(size_t)63);
+  const size_t w_total = w_nout + sizeof(int64_t) * n;
+  if (w_total > P->dWsCap) {
+    if (P->dWs) (void)hipFree(P->dWs);   // (nothing of this pool is in flight between runs)
+    P->dWs = nullptr;
+    size_t cap = P->dWsCap ? P->dWsCap : 65536;
+    while (cap < w_total) cap *= 2;
+    if (hipMalloc(reinterpret_cast<void**>(&P->dWs), cap) != hipSuccess) { P->dWsCap = 0; spx_api_error("pool workspace allocation failed"); return false; }
+    P->dWsCap = cap;
+  }
+  SpxStreamDev* hA = reinterpret_cast<SpxStreamDev*>(P->hTab.p);
+  SpxStreamDev* hW = hA + n;
+  PoolDesc* hD = reinterpret_cast<PoolDesc*>(P->hTab.p + o_desc);
+  PoolCopy* hC = reinterpret_cast<PoolCopy*>(P->hTab.p + o_copies);
+  for (size_t i = 0; i < n; i++) {
+    sonicStream s = items[i].s;
+    hA[i] = items[i].J.JA;
+    hW[i] = items[i].J.JW;
+    hW[i].first_tile = hA[i].first_tile;
+    PoolDesc& D = hD[i];
+    D.home = s->dState;
+    D.out_base = s->dOut.base();
+    D.out_from = s->outKnown;
+    D.out_cap = items[i].J.JA.out_cap;
+    D.res_off = res_off[i];
+    D.res_cap = res_cap[i];
+    D.channels = s->channels;
+    D.pad = 0;
+  }
+  if (!copies.empty()) memcpy(hC, copies.data(), sizeof(PoolCopy) * copies.size());
+  SpxStreamDev* dA = reinterpret_cast<SpxStreamDev*>(P->dWs);
+  SpxStreamDev* dW = dA + n;
+  SpxStreamState* dStates = reinterpret_cast<SpxStreamState*>(P->dWs + w_states);
+  int64_t* dNout = reinterpret_cast<int64_t*>(P->dWs + w_nout);
+  PoolResult* hR = reinterpret_cast<PoolResult*>(P->hRes.p);
+  int16_t* hOut = reinterpret_cast<int16_t*>(P->hRes.p + o_out);
+
+  const unsigned n_words = (unsigned)(2 * b_jobs / 4);
+  const unsigned grid = std::max<unsigned>(std::max<unsigned>((unsigned)copies.size(), (n_words + 255) / 256), 1u);
+  hipLaunchKernelGGL(spx_pool_stage_kernel, dim3(grid), dim3(256), 0, P->hs, reinterpret_cast<const unsigned*>(hA),
+                     reinterpret_cast<unsigned*>(dA), n_words, hD, dStates, (unsigned)n, hC, (unsigned)copies.size(), P->hIn.p);
+  const SpxTapsDev no_taps = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  for (const Group& g : groups) {
+    const SpxPlanDev& PL = *items[g.i0].s->plan;
+    const int ng = (int)(g.i1 - g.i0);
+    if (g.tiles > 0) spx_launch_analysis(PL, dA + g.i0, ng, g.tiles, nullptr, P->aRec, no_taps, nullptr, nullptr, P->hs);
+    bool any_nl = false;
+    for (size_t i = g.i0; i < g.i1; i++) any_nl = any_nl || items[i].J.nonlinear;
+    if (any_nl) spx_launch_tension(PL, dA + g.i0, ng, dStates + g.i0, P->aRec, P->aScr, no_taps, nullptr, nullptr, P->hs);
+    spx_launch_walk(PL, dW + g.i0, ng, g.maxC, nullptr, nullptr, dNout + g.i0, dStates + g.i0, P->aScr, nullptr,
+                    items[g.i0].J.speedupKernel, P->hs);
+  }
+  const unsigned gy = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, (max_slice + 8191) / 8192));
+  hipLaunchKernelGGL(spx_pool_gather_kernel, dim3((unsigned)n, gy), dim3(256), 0, P->hs, hD, dStates, dNout, hR, hOut);
+  const hipError_t le = hipGetLastError();
+  const hipError_t se = hipStreamSynchronize(P->hs);
+  if (le != hipSuccess || se != hipSuccess) {
+    spx_api_error(std::string("coalesced launch failed: ") + hipGetErrorString(le != hipSuccess ? le : se));
+    for (auto& it : items) it.s->failed = true;
+    drop_waiting(P);
+    return false;
+  }
+  for (size_t i = 0; i < n; i++) {
+    sonicStream s = items[i].s;
+    spx_finish_job(s, items[i].J);
+    int64_t k = hR[i].n;
+    if (k == SPX_NOUT_LOST_PRODUCER) {
+      spx_api_error("a producer kernel never delivered its frames (device-side poll limit reached)");
+      s->failed = true;
+      k = s->outKnown;
+    } else if (k < 0) {
+      spx_api_error("output capacity exceeded on the device");
+      s->failed = true;
+      k = -k;
+    }
+    int64_t fresh = std::min(std::min(k, items[i].J.JA.out_cap) - s->outKnown, res_cap[i]);
+    if (fresh > 0) {
+      const int16_t* src = hOut + res_off[i];
+      s->hostOut.insert(s->hostOut.end(), src, src + fresh * s->channels);
+    }
+    s->outKnown = k;
+    s->outBound = k;
+    s->tsmBase = hR[i].st.w.base;
+    s->curSpeedKnown = hR[i].st.curSpeed;
+    s->dirty = false;
+    s->writesSinceSync = 0;
+    s->devIn = s->nIn;
+  }
+  P->runs++;
+  P->jobs += n;
+  drop_waiting(P);
+  return true;
+}
+
+static void enlist(SpxPool* P, sonicStream s) {
+  if (!s->poolPending) { s->poolPending = true; P->waiting.push_back(s); }
+}
+
+int spx_pool_write(sonicStream s, const short* in, int sampleCount) {
+  SpxPool* P = pool_of(s);
+  std::lock_guard<std::mutex> g(P->mu);
+  if (s->failed) return 0;
+  if (s->pendingFlush && !pool_run(P)) return 0;   // a write behind a staged flush is the next job
+  if (s->nIn + sampleCount + s->tsmShift >= (1ll << 30)) {
+    spx_api_error("stream longer than 2^30 frames is not supported");
+    return 0;
+  }
+  const size_t bytes = sizeof(short) * (size_t)sampleCount * s->channels;
+  const size_t off = (P->hInUsed + 15) & ~(size_t)15;
+  if (!P->hIn.reserve(off + bytes + 32, P->hInUsed)) { spx_api_error("pinned staging allocation failed"); return 0; }
+  memcpy(P->hIn.p + off, in, bytes);   // the caller's buffer is free again when this call returns
+  P->hInUsed = off + bytes;
+  s->segs.push_back({s->nIn, off, (int64_t)sampleCount});
+  s->nIn += sampleCount;
+  P->waitingSegs++;
+  enlist(P, s);
+  // bounded staging: a caller that only ever writes still makes progress (and the device buffers keep sliding)
+  static const size_t limit = [] { const char* e = getenv("SPX_POOL_STAGE_BYTES"); return e ? (size_t)atoll(e) : (size_t)8 << 20; }();
+  if (P->hInUsed > limit || P->waitingSegs > 8192) return pool_run(P) && !s->failed ? 1 : 0;
+  return 1;
+}
+
+int spx_pool_flush(sonicStream s) {
+  SpxPool* P = pool_of(s);
+  std::lock_guard<std::mutex> g(P->mu);
+  if (s->failed) return 0;
+  if (s->pendingFlush && !pool_run(P)) return 0;
+  s->pendingFlush = true;
+  enlist(P, s);
+  return 1;
+}
+
+bool spx_pool_sync(sonicStream s) {
+  SpxPool* P = pool_of(s);
+  std::lock_guard<std::mutex> g(P->mu);
+  if (!s->poolPending) return true;
+  return pool_run(P);
+}
+
+int spx_pool_read(sonicStream s, short* out, int bufferSize) {
+  SpxPool* P = pool_of(s);
+  std::lock_guard<std::mutex> g(P->mu);
+  if (s->poolPending && !pool_run(P)) return 0;
+  int64_t n = s->outKnown - s->outRead;
+  if (n <= 0 || bufferSize <= 0) return 0;
+  if (n > bufferSize) n = bufferSize;
+  const size_t cnt = (size_t)n * s->channels;
+  memcpy(out, s->hostOut.data() + s->hostHead, cnt * sizeof(short));
+  s->hostHead += cnt;
+  s->outRead += n;
+  if (s->hostHead == s->hostOut.size()) { s->hostOut.clear(); s->hostHead = 0; }
+  else if (s->hostHead > (1u << 16) && s->hostHead > s->hostOut.size() / 2) {
+    s->hostOut.erase(s->hostOut.begin(), s->hostOut.begin() + (ptrdiff_t)s->hostHead);
+    s->hostHead = 0;
+  }
+  return (int)n;
+}
+
+// The stream gets a launch sequence of its own from here on (sonic2_api.hip): what waits is run, the frame records move
+// from the arena into allocations of the handle, the host-side copy of the unread output is dropped (the device still
+// has those frames: a pooled handle's output window starts at its read position like an eager one's).
+bool spx_pool_leave(sonicStream s) {
+  SpxPool* P = pool_of(s);
+  std::lock_guard<std::mutex> g(P->mu);
+  (void)hipSetDevice(P->device);
+  if (s->poolPending && !pool_run(P)) return false;
+  if (s->arenaStart >= 0) {
+    SpxFrameRec* nr = nullptr;
+    float* ns = nullptr;
+    const int64_t cap = s->arenaCap;
+    if (hipMallocAsync(reinterpret_cast<void**>(&nr), sizeof(SpxFrameRec) * (size_t)cap, P->hs) != hipSuccess ||
+        hipMallocAsync(reinterpret_cast<void**>(&ns), sizeof(float) * 4 * (size_t)cap, P->hs) != hipSuccess ||
+        hipMemcpyAsync(nr, s->dRec.p, sizeof(SpxFrameRec) * (size_t)cap, hipMemcpyDeviceToDevice, P->hs) != hipSuccess ||
+        hipMemcpyAsync(ns, s->dScr.p, sizeof(float) * 4 * (size_t)cap, hipMemcpyDeviceToDevice, P->hs) != hipSuccess ||
+        hipStreamSynchronize(P->hs) != hipSuccess) {
+      spx_api_error("leaving the coalesced path failed (device allocation)");
+      s->failed = true;
+      return false;
+    }
+    const int64_t origin = s->dRec.origin;
+    arena_release(P, s);
+    s->dRec.p = nr; s->dRec.origin = origin; s->dRec.cap = cap;
+    s->dScr.p = ns; s->dScr.origin = 4 * origin; s->dScr.cap = 4 * cap;
+  }
+  s->hostOut.clear(); s->hostOut.shrink_to_fit(); s->hostHead = 0;
+  s->pooled = false;
+  return !s->failed;
+}
+
+void spx_pool_forget(sonicStream s) {
+  SpxPool* P = pool_of(s);
+  std::lock_guard<std::mutex> g(P->mu);
+  if (s->poolPending) {
+    for (size_t i = 0; i < P->waiting.size(); i++)
+      if (P->waiting[i] == s) { P->waiting.erase(P->waiting.begin() + (ptrdiff_t)i); break; }
+    P->waitingSegs -= std::min(P->waitingSegs, s->segs.size());
+    s->poolPending = false;
+    if (P->waiting.empty()) { P->hInUsed = 0; P->waitingSegs = 0; }
+  }
+  arena_release(P, s);
+  s->pooled = false;
+}
+
+extern "C" {
+// Coalesced execution of plain handles (default on; SPX_NO_POOL=1 in the environment switches it off): applies to handles
+// created afterwards.
+void speedyHipSetCoalescing(int on) { g_coalesce.store(on ? 1 : 0); }
+// Launch sequences run and jobs served by the current device's pool so far (jobs / runs = handles per launch sequence).
+void speedyHipPoolStats(unsigned long long* runs, unsigned long long* jobs) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  SpxPool* P = (dev >= 0 && dev < 64) ? g_pools[dev] : nullptr;
+  if (runs) *runs = P ? P->runs : 0;
+  if (jobs) *jobs = P ? P->jobs : 0;
+}
+}

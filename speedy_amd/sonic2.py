@@ -8,10 +8,16 @@ from ._lib import FEATURES_FN, TENSION_FN, c_float_p, c_short_p, lib
 
 
 class SonicStream:
-    def __init__(self, sample_rate, channels, match_matlab=False):
+    def __init__(self, sample_rate, channels, match_matlab=False, coalesce=None):
+        """coalesce: None = the library's default (on), False = this handle runs its own launch sequence per write."""
         self.L = lib()
-        self.L.speedyHipSetMatchMatlab(int(bool(match_matlab)))
-        self.h = self.L.sonicCreateStream(int(sample_rate), int(channels))
+        if coalesce is not None:
+            self.L.speedyHipSetCoalescing(int(bool(coalesce)))
+        try:
+            self.h = self.L.speedyHipCreateSonicStream(int(sample_rate), int(channels), int(bool(match_matlab)))
+        finally:
+            if coalesce is not None:
+                self.L.speedyHipSetCoalescing(1)
         if not self.h:
             raise RuntimeError("sonicCreateStream: " + self.L.speedyHipLastError().decode())
         self.channels = channels
@@ -64,6 +70,9 @@ class SonicStream:
     def flush(self):
         return self.L.sonicFlushStream(self.h)
 
+    def available(self):
+        return self.L.sonicSamplesAvailable(self.h)
+
     # the TSM stage alone (sonicInt*, sonic_test.cc:735-750): no ring, no analysis, whatever the nonlinear factor
     def int_write_short(self, x):
         x = np.ascontiguousarray(x, np.int16)
@@ -103,11 +112,19 @@ class SonicStream:
         self.L.sonicNormalizedSpectrogramCallback(self.h, cb)
 
 
+def pool_stats():
+    """(launch sequences run, stream jobs served) by the current device's pool."""
+    L = lib()
+    r, j = C.c_ulonglong(0), C.c_ulonglong(0)
+    L.speedyHipPoolStats(C.byref(r), C.byref(j))
+    return r.value, j.value
+
+
 def time_compress(x, sample_rate, channels, speed, nonlinear=0.0, feedback=None, chunk=1000, match_matlab=False,
-                  taps=None):
+                  taps=None, coalesce=None):
     """The write/read/flush/drain loop of compress_sound (speedy_wave.cc:199-231) and TimeCompressVector
     (sonic_test.cc:364-403).  Returns the concatenated int16 output."""
-    s = SonicStream(sample_rate, channels, match_matlab)
+    s = SonicStream(sample_rate, channels, match_matlab, coalesce)
     s.set_speed(speed)
     s.enable_nonlinear(nonlinear)
     if feedback is not None:

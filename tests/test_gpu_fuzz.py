@@ -172,6 +172,124 @@ def _dump_failing_case(request):
             pickle.dump({"tag": tag, "x": x, "ops": list(log)}, f)
 
 
+def _life_cycle_case(orc, rng, seed, i, ops, trace, coalesce=None, callbacks=None):
+    """One random stream life (a generator: it yields after every call sequence step, so that several lives can be
+    interleaved on one device -- the coalesced path then runs their staged work together)."""
+    from speedy_amd.sonic2 import SonicStream
+    L = orc.lib()
+    rate = int(rng.choice([8000, 16000, 16000, 22050, 22050, 44100]))
+    ch = int(rng.choice([1, 1, 1, 2, 3]))
+    kind = KINDS[int(rng.integers(0, len(KINDS)))]
+    n = int(rng.integers(rate // 10, int(2.5 * rate)))
+    if i == 5:                                    # one long stream per seed: the device buffers slide several times
+        n = int(rng.integers(6 * rate, 25 * rate))
+    nl = float(rng.choice([0.0, 1.0, 1.0, 0.6]))
+    speed = float(np.round(rng.choice([rng.uniform(0.4, 0.95), rng.uniform(1.05, 5.0), 2.0, 3.5]), 5))
+    fb = float(rng.choice([0.0, 0.0, 0.1]))
+    mm = bool(rng.integers(0, 2))
+    small = bool(rng.integers(0, 2)) and i != 5
+    with_cb = bool(rng.integers(0, 2))
+    if callbacks is not None:
+        with_cb = callbacks
+    x = _signal(kind, n, rate, ch, rng)
+    tag = (seed, i, rate, ch, kind, n, speed, nl, fb, mm, small)
+    h = L.orc_sonicCreateStream(rate, ch, int(mm))
+    s = SonicStream(rate, ch, mm, coalesce)
+    ref_cb, got_cb = [], []
+    if with_cb:                                   # tension and speed callbacks: same times, same values, same order
+        keep = [orc.TENSION_FN(lambda _s, t, v: ref_cb.append(("t", t, np.float32(v)))),
+                orc.TENSION_FN(lambda _s, t, v: ref_cb.append(("s", t, np.float32(v))))]
+        L.orc_sonicTensionCallback(h, keep[0]); L.orc_sonicSpeedCallback(h, keep[1])
+        s.on_tension(lambda t, v: got_cb.append(("t", t, np.float32(v))))
+        s.on_speed(lambda t, v: got_cb.append(("s", t, np.float32(v))))
+    L.orc_sonicSetSpeed(h, speed); s.set_speed(speed)
+    L.orc_sonicEnableNonlinearSpeedup(h, nl); s.enable_nonlinear(nl)
+    L.orc_sonicSetDurationFeedbackStrength(h, fb); s.set_feedback(fb)
+    buf = np.zeros(8192 * ch, np.int16)
+    pos, log, cur_nl = 0, [], nl
+    _case_log[:] = [tag, x, log]
+    if trace:
+        print("CASE", tag, flush=True)
+    while pos < n:
+        if trace and log:
+            print(" ", log[-1], flush=True)
+        op = rng.random()
+        if op < 0.06 and "flush" in ops:
+            log.append("flush")
+            L.orc_sonicFlushStream(h)
+            assert s.flush() == 1, tag
+        elif 0.06 <= op < 0.10 and "speed" in ops:
+            v = float(np.round(rng.choice([rng.uniform(0.4, 0.95), rng.uniform(1.05, 5.0), 1.0]), 5))
+            log.append(("speed", v))
+            L.orc_sonicSetSpeed(h, v); s.set_speed(v)
+        elif 0.10 <= op < 0.14 and "rate" in ops:
+            v = float(rng.choice([0.5, 0.8, 1.0, 1.0, 1.25, 2.0]))
+            log.append(("rate", v))
+            L.orc_sonicSetRate(h, v); s.set_rate(v)
+        elif 0.14 <= op < 0.17 and cur_nl != 0.0 and "nl" in ops:
+            v = float(rng.choice([0.3, 0.7, 1.0]))
+            cur_nl = v
+            log.append(("nl", v))
+            L.orc_sonicEnableNonlinearSpeedup(h, v); s.enable_nonlinear(v)
+        elif 0.22 <= op < 0.26 and "direct" in ops:   # sonicInt*: the TSM stage alone, whatever the stream is doing
+            u = rng.random()
+            if u < 0.6:
+                w = int(rng.integers(1, 1500))
+                seg = np.ascontiguousarray(x[pos * ch:(pos + w) * ch])
+                pos += w
+                log.append(("iw", seg.size // ch))
+                assert L.orc_sonicIntWriteShortToStream(h, orc.sptr(seg), seg.size // ch) == 1
+                assert s.int_write_short(seg) == 1, tag + (s.L.speedyHipLastError(),)
+            elif u < 0.8:
+                log.append("iflush")
+                L.orc_sonicIntFlushStream(h)
+                assert s.int_flush() == 1, tag + (s.L.speedyHipLastError(),)
+            else:
+                v = float(np.round(rng.choice([rng.uniform(0.4, 0.95), rng.uniform(1.05, 4.0)]), 5))
+                log.append(("ispeed", v))
+                L.orc_sonicIntSetSpeed(h, v); s.int_set_speed(v)
+        elif 0.19 <= op < 0.22 and "mode" in ops:   # linear <-> nonlinear inside one stream (soniclib.c:397-399)
+            v = 0.0 if cur_nl != 0.0 else float(rng.choice([0.5, 1.0]))
+            cur_nl = v
+            log.append(("mode", v))
+            L.orc_sonicEnableNonlinearSpeedup(h, v); s.enable_nonlinear(v)
+        elif 0.17 <= op < 0.19 and "fb" in ops:
+            v = float(rng.choice([0.0, 0.1, 0.3]))
+            log.append(("fb", v))
+            L.orc_sonicSetDurationFeedbackStrength(h, v); s.set_feedback(v)
+        else:
+            w = int(rng.integers(1, 400)) if (small or rng.random() < 0.3) else int(rng.integers(400, 4000))
+            seg = np.ascontiguousarray(x[pos * ch:(pos + w) * ch])
+            pos += w
+            log.append(("w", seg.size // ch))
+            assert L.orc_sonicWriteShortToStream(h, orc.sptr(seg), seg.size // ch) == 1
+            assert s.write_short(seg) == 1, tag + (s.L.speedyHipLastError(),)
+            assert got_cb == ref_cb, tag + ("callbacks", pos, log[-12:])
+        if trace:   # debugging: the frames readable after every call, not only the ones a read happens to ask for
+            a, b = L.orc_sonicIntSamplesAvailable(h), s.L.sonicSamplesAvailable(s.h)
+            assert a == b, tag + ("available", a, b, pos, log[-6:])
+        if rng.random() < 0.1:   # the TSM stage's current speed (libsonic's sonicGetSpeed): last setter or last tension frame
+            a, b = L.orc_sonicIntGetSpeed(h), s.L.sonicIntGetSpeed(s.h)
+            assert np.float32(a) == np.float32(b), tag + ("speed now", a, b, pos, log[-6:])
+        if rng.random() < 0.7:
+            r = int(rng.integers(1, 8193))
+            log.append(("r", r))
+            k = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), r)
+            got = s.read_short(r)
+            assert got.size == k * ch and np.array_equal(got, buf[:k * ch]), tag + ("read", pos, log[-12:])
+        yield
+    L.orc_sonicFlushStream(h)
+    assert s.flush() == 1, tag + (s.L.speedyHipLastError(),)
+    while True:
+        k = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), 8192)
+        got = s.read_short(8192)
+        assert got.size == k * ch and np.array_equal(got, buf[:k * ch]), tag + ("drain", s.L.speedyHipLastError(), log[-12:])
+        if k == 0:
+            break
+    L.orc_sonicDestroyStream(h)
+    s.close()
+
+
 @pytest.mark.parametrize("seed", list(range(31, 39)) + list(range(3000, 3000 + SOAK)))
 def test_life_cycle_fuzz(orc, seed):
     """Random call sequences through the streaming API: writes from one frame to a few thousand (many shorter than an
@@ -179,120 +297,44 @@ def test_life_cycle_fuzz(orc, seed):
     nothing written), and between writes new values for speed, rate (sonicSetRate), nonlinear factor -- including
     switches between 0 and non-zero, which make the reference interleave ring buffers and direct writes -- and
     feedback strength.  After every call the frames delivered must equal the oracle shim's."""
-    from speedy_amd.sonic2 import SonicStream
-    L = orc.lib()
     rng = np.random.default_rng(seed)
     ops = os.environ.get("SPX_LC_OPS", "flush,speed,rate,nl,fb,mode,direct").split(",")   # debugging: leave op classes out
     trace = os.environ.get("SPX_LC_TRACE")                                     # debugging: print every call
     for i in range(6):
-        rate = int(rng.choice([8000, 16000, 16000, 22050, 22050, 44100]))
-        ch = int(rng.choice([1, 1, 1, 2, 3]))
-        kind = KINDS[int(rng.integers(0, len(KINDS)))]
-        n = int(rng.integers(rate // 10, int(2.5 * rate)))
-        if i == 5:                                    # one long stream per seed: the device buffers slide several times
-            n = int(rng.integers(6 * rate, 25 * rate))
-        nl = float(rng.choice([0.0, 1.0, 1.0, 0.6]))
-        speed = float(np.round(rng.choice([rng.uniform(0.4, 0.95), rng.uniform(1.05, 5.0), 2.0, 3.5]), 5))
-        fb = float(rng.choice([0.0, 0.0, 0.1]))
-        mm = bool(rng.integers(0, 2))
-        small = bool(rng.integers(0, 2)) and i != 5
-        with_cb = bool(rng.integers(0, 2))
-        x = _signal(kind, n, rate, ch, rng)
-        tag = (seed, i, rate, ch, kind, n, speed, nl, fb, mm, small)
-        h = L.orc_sonicCreateStream(rate, ch, int(mm))
-        s = SonicStream(rate, ch, mm)
-        ref_cb, got_cb = [], []
-        if with_cb:                                   # tension and speed callbacks: same times, same values, same order
-            keep = [orc.TENSION_FN(lambda _s, t, v: ref_cb.append(("t", t, np.float32(v)))),
-                    orc.TENSION_FN(lambda _s, t, v: ref_cb.append(("s", t, np.float32(v))))]
-            L.orc_sonicTensionCallback(h, keep[0]); L.orc_sonicSpeedCallback(h, keep[1])
-            s.on_tension(lambda t, v: got_cb.append(("t", t, np.float32(v))))
-            s.on_speed(lambda t, v: got_cb.append(("s", t, np.float32(v))))
-        L.orc_sonicSetSpeed(h, speed); s.set_speed(speed)
-        L.orc_sonicEnableNonlinearSpeedup(h, nl); s.enable_nonlinear(nl)
-        L.orc_sonicSetDurationFeedbackStrength(h, fb); s.set_feedback(fb)
-        buf = np.zeros(8192 * ch, np.int16)
-        pos, log, cur_nl = 0, [], nl
-        _case_log[:] = [tag, x, log]
-        if trace:
-            print("CASE", tag, flush=True)
-        while pos < n:
-            if trace and log:
-                print(" ", log[-1], flush=True)
-            op = rng.random()
-            if op < 0.06 and "flush" in ops:
-                log.append("flush")
-                L.orc_sonicFlushStream(h)
-                assert s.flush() == 1, tag
-            elif 0.06 <= op < 0.10 and "speed" in ops:
-                v = float(np.round(rng.choice([rng.uniform(0.4, 0.95), rng.uniform(1.05, 5.0), 1.0]), 5))
-                log.append(("speed", v))
-                L.orc_sonicSetSpeed(h, v); s.set_speed(v)
-            elif 0.10 <= op < 0.14 and "rate" in ops:
-                v = float(rng.choice([0.5, 0.8, 1.0, 1.0, 1.25, 2.0]))
-                log.append(("rate", v))
-                L.orc_sonicSetRate(h, v); s.set_rate(v)
-            elif 0.14 <= op < 0.17 and cur_nl != 0.0 and "nl" in ops:
-                v = float(rng.choice([0.3, 0.7, 1.0]))
-                cur_nl = v
-                log.append(("nl", v))
-                L.orc_sonicEnableNonlinearSpeedup(h, v); s.enable_nonlinear(v)
-            elif 0.22 <= op < 0.26 and "direct" in ops:   # sonicInt*: the TSM stage alone, whatever the stream is doing
-                u = rng.random()
-                if u < 0.6:
-                    w = int(rng.integers(1, 1500))
-                    seg = np.ascontiguousarray(x[pos * ch:(pos + w) * ch])
-                    pos += w
-                    log.append(("iw", seg.size // ch))
-                    assert L.orc_sonicIntWriteShortToStream(h, orc.sptr(seg), seg.size // ch) == 1
-                    assert s.int_write_short(seg) == 1, tag + (s.L.speedyHipLastError(),)
-                elif u < 0.8:
-                    log.append("iflush")
-                    L.orc_sonicIntFlushStream(h)
-                    assert s.int_flush() == 1, tag + (s.L.speedyHipLastError(),)
-                else:
-                    v = float(np.round(rng.choice([rng.uniform(0.4, 0.95), rng.uniform(1.05, 4.0)]), 5))
-                    log.append(("ispeed", v))
-                    L.orc_sonicIntSetSpeed(h, v); s.int_set_speed(v)
-            elif 0.19 <= op < 0.22 and "mode" in ops:   # linear <-> nonlinear inside one stream (soniclib.c:397-399)
-                v = 0.0 if cur_nl != 0.0 else float(rng.choice([0.5, 1.0]))
-                cur_nl = v
-                log.append(("mode", v))
-                L.orc_sonicEnableNonlinearSpeedup(h, v); s.enable_nonlinear(v)
-            elif 0.17 <= op < 0.19 and "fb" in ops:
-                v = float(rng.choice([0.0, 0.1, 0.3]))
-                log.append(("fb", v))
-                L.orc_sonicSetDurationFeedbackStrength(h, v); s.set_feedback(v)
-            else:
-                w = int(rng.integers(1, 400)) if (small or rng.random() < 0.3) else int(rng.integers(400, 4000))
-                seg = np.ascontiguousarray(x[pos * ch:(pos + w) * ch])
-                pos += w
-                log.append(("w", seg.size // ch))
-                assert L.orc_sonicWriteShortToStream(h, orc.sptr(seg), seg.size // ch) == 1
-                assert s.write_short(seg) == 1, tag + (s.L.speedyHipLastError(),)
-                assert got_cb == ref_cb, tag + ("callbacks", pos, log[-12:])
-            if trace:   # debugging: the frames readable after every call, not only the ones a read happens to ask for
-                a, b = L.orc_sonicIntSamplesAvailable(h), s.L.sonicSamplesAvailable(s.h)
-                assert a == b, tag + ("available", a, b, pos, log[-6:])
-            if rng.random() < 0.1:   # the TSM stage's current speed (libsonic's sonicGetSpeed): last setter or last tension frame
-                a, b = L.orc_sonicIntGetSpeed(h), s.L.sonicIntGetSpeed(s.h)
-                assert np.float32(a) == np.float32(b), tag + ("speed now", a, b, pos, log[-6:])
-            if rng.random() < 0.7:
-                r = int(rng.integers(1, 8193))
-                log.append(("r", r))
-                k = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), r)
-                got = s.read_short(r)
-                assert got.size == k * ch and np.array_equal(got, buf[:k * ch]), tag + ("read", pos, log[-12:])
-        L.orc_sonicFlushStream(h)
-        assert s.flush() == 1, tag + (s.L.speedyHipLastError(),)
-        while True:
-            k = L.orc_sonicReadShortFromStream(h, orc.sptr(buf), 8192)
-            got = s.read_short(8192)
-            assert got.size == k * ch and np.array_equal(got, buf[:k * ch]), tag + ("drain", s.L.speedyHipLastError(), log[-12:])
-            if k == 0:
-                break
-        L.orc_sonicDestroyStream(h)
-        s.close()
+        for _ in _life_cycle_case(orc, rng, seed, i, ops, trace):
+            pass
+
+
+@pytest.mark.parametrize("seed", list(range(51, 55)) + list(range(5000, 5000 + SOAK // 4)))
+def test_life_cycle_fuzz_eager(orc, seed):
+    """The same lives with coalescing switched off: every handle runs its own launch sequence per write (the path handles
+    with callbacks, a rate stage or mode switches always take)."""
+    rng = np.random.default_rng(seed)
+    ops = "flush,speed,rate,nl,fb,mode,direct".split(",")
+    for i in range(4):
+        for _ in _life_cycle_case(orc, rng, seed, i, ops, None, coalesce=False):
+            pass
+
+
+@pytest.mark.parametrize("seed", list(range(61, 69)) + list(range(6000, 6000 + SOAK)))
+def test_life_cycle_fuzz_interleaved(orc, seed):
+    """Six to twelve lives at once, their calls interleaved at random: writes and flushes of plain handles wait together
+    and run as one launch sequence when any of them is asked for a result, handles drop out of the pool (callbacks, rate,
+    sonicInt*, mode switches) while others have work staged, handles are destroyed with work staged.  Every call of every
+    life still equals the oracle shim's."""
+    pick = np.random.default_rng(seed)
+    ops = "flush,speed,rate,nl,fb,mode,direct".split(",")
+    cbs = None
+    if pick.random() < 0.5:
+        ops, cbs = ["flush", "speed", "fb", "nl"], False   # half of the seeds: nothing that takes a handle out of the pool
+    k = int(pick.integers(6, 13))
+    lives = [_life_cycle_case(orc, np.random.default_rng([seed, i]), seed, i % 5, ops, None, callbacks=cbs) for i in range(k)]
+    while lives:
+        j = int(pick.integers(0, len(lives)))
+        try:
+            next(lives[j])
+        except StopIteration:
+            lives.pop(j)
 
 
 @pytest.mark.parametrize("seed", list(range(41, 44)) + list(range(4000, 4000 + SOAK // 10)))
