@@ -25,8 +25,11 @@
 extern "C" {
 #endif
 
+#ifndef SPEEDY_HIP_SONICSTREAM_DECLARED   /* (include/compat/sonic.h declares it too) */
+#define SPEEDY_HIP_SONICSTREAM_DECLARED
 struct sonicStreamStruct;
 typedef struct sonicStreamStruct* sonicStream;
+#endif
 
 sonicStream sonicCreateStream(int sampleRate, int numChannels);            /* soniclib.c:93-134  */
 void sonicDestroyStream(sonicStream stream);                               /* soniclib.c:141-167 */
@@ -75,6 +78,7 @@ int sonicIntWriteFloatToStream(sonicStream stream, const float* samples, int num
 int sonicIntReadShortFromStream(sonicStream stream, short* samples, int maxSamples);
 int sonicIntReadFloatFromStream(sonicStream stream, float* samples, int maxSamples);
 int sonicIntFlushStream(sonicStream stream);
+int sonicIntSamplesAvailable(sonicStream stream);
 void sonicIntSetUserData(sonicStream stream, void* userData);
 void* sonicIntGetUserData(sonicStream stream);
 

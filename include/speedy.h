@@ -86,6 +86,20 @@ void DeleteFirstOrderFilter(FirstOrderFilter fof);
 int speedyHipHysteresisFuture(speedyStream stream);
 int speedyHipHysteresisPast(speedyStream stream);
 
+/* The reference's compile-time constants, for callers that use them as such (speedy_test.cc:756 compares the measured
+ * latency with kTemporalHysteresisFuture).  Here the shape is chosen at RUN time -- speedyHipSetMatchMatlab /
+ * speedyHipCreateSonicStream (include/sonic2.h) -- so a caller built with -DMATCH_MATLAB must also select it once at
+ * start-up; the macros only restate which pair that build means (speedy.h:136-146). */
+#ifndef kTemporalHysteresisFuture
+#ifdef MATCH_MATLAB
+#define kTemporalHysteresisFuture 8  /* frames */
+#define kTemporalHysteresisPast 12   /* frames */
+#else
+#define kTemporalHysteresisFuture 12 /* frames */
+#define kTemporalHysteresisPast 8    /* frames */
+#endif
+#endif
+
 #ifdef __cplusplus
 }
 #endif

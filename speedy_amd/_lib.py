@@ -93,6 +93,7 @@ SYMBOLS = {
     "sonicIntReadShortFromStream": (C.c_int, [C.c_void_p, c_short_p, C.c_int]),
     "sonicIntReadFloatFromStream": (C.c_int, [C.c_void_p, c_float_p, C.c_int]),
     "sonicIntFlushStream": (C.c_int, [C.c_void_p]),
+    "sonicIntSamplesAvailable": (C.c_int, [C.c_void_p]),
     "sonicIntSetUserData": (None, [C.c_void_p, C.c_void_p]),
     "sonicIntGetUserData": (C.c_void_p, [C.c_void_p]),
     # include/speedy.h

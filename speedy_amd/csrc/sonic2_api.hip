@@ -270,7 +270,7 @@ static void run_callbacks(sonicStream s, int64_t j0, int64_t j1, int64_t k_first
 // buffers (stream-ordered on hs) and fills the two job records.  `pool`: the coalesced path -- the kernels of a pooled launch
 // get NULL base pointers, so every offset is the absolute element address of the handle's own allocation (minus the
 // sliding origin), and the frame records live in the pool's arena.
-int spx_prepare_job(sonicStream s, bool flush, bool direct, hipStream_t hs, SpxPool* pool, SpxJobPlan& J) {
+int spx_prepare_job(sonicStream s, bool flush, bool direct, hipStream_t hs, SpxPool* pool, SpxJobPlan& J, SpxDeferred* defer) {
   const SpxPlanDev& P = *s->plan;
   const int64_t C = s->channels;
   const int F = P.F, Pp = P.Pp, B = P.B;
@@ -319,7 +319,7 @@ int spx_prepare_job(sonicStream s, bool flush, bool direct, hipStream_t hs, SpxP
   s->dOut.filled = s->outBound * C;
   // rate mode: the TSM output is dead once the rate stage has taken it (one frame stays as its left neighbour's source)
   const int64_t tsmKeep = s->rateMode ? std::max<int64_t>(0, s->tsmSeenKnown - 1) : s->outRead;
-  if (!s->dOut.ensure(tsmKeep * C, need * C, hs, 1 << 16)) return 0;
+  if (!s->dOut.ensure(tsmKeep * C, need * C, hs, 1 << 16, defer)) return 0;
   int oldR = s->sampleRate, newR = s->sampleRate;
   if (s->rateMode) {
     newR = (int)(s->sampleRate / s->rate);               // the dependency's adjustRate: both halved down to 14 bits
@@ -347,7 +347,7 @@ int spx_prepare_job(sonicStream s, bool flush, bool direct, hipStream_t hs, SpxP
     if (taps)
       for (auto& m : tapm) move = move || !m.b->fits(keep * m.stride, hi * m.stride);
     if (move && pool) {
-      if (!spx_pool_slide_frames(pool, s, keep, hi, fa, hs)) return 0;
+      if (!spx_pool_slide_frames(pool, s, keep, hi, fa, defer)) return 0;
     } else if (move) {
       s->dRec.filled = fa; s->dScr.filled = 4 * fa;
       if (!s->dRec.slide_to(keep, hi, hs, 4096) || !s->dScr.slide_to(4 * keep, 4 * hi, hs, 4 * 4096)) return 0;
@@ -360,8 +360,8 @@ int spx_prepare_job(sonicStream s, bool flush, bool direct, hipStream_t hs, SpxP
   }
   SlideBuf<int16_t>& tsmIn = s->mixed ? s->dTsm : s->dIn;   // what the walk kernel reads
   J.tsmIn = &tsmIn;
-  if (!s->dIn.p && !s->dIn.ensure(0, 64 * C, hs, 1 << 16)) return 0;  // a flush before any write: the kernels still
-  if (!tsmIn.p && !tsmIn.ensure(0, 64 * C, hs, 1 << 16)) return 0;    // get real (empty, guarded) input arrays
+  if (!s->dIn.p && !s->dIn.ensure(0, 64 * C, hs, 1 << 16, defer)) return 0;  // a flush before any write: the kernels still
+  if (!tsmIn.p && !tsmIn.ensure(0, 64 * C, hs, 1 << 16, defer)) return 0;    // get real (empty, guarded) input arrays
   // ---- the jobs: absolute stream coordinates through (possibly negative) base offsets.  JA = what the analysis and
   // tension kernels see (the ring sequence), JW = what the walk kernel sees (the TSM input): the same record unless the
   // stream is mixed ----
@@ -659,8 +659,15 @@ int sonicIntWriteFloatToStream(sonicStream s, const float* in, int n) {
 int sonicIntReadShortFromStream(sonicStream s, short* out, int n) { return sonicReadShortFromStream(s, out, n); }
 int sonicIntReadFloatFromStream(sonicStream s, float* out, int n) { return sonicReadFloatFromStream(s, out, n); }
 int sonicIntFlushStream(sonicStream s);
+int sonicIntSamplesAvailable(sonicStream s) { return sonicSamplesAvailable(s); }
 void sonicIntSetUserData(sonicStream s, void* p) { s->userData = p; }
 void* sonicIntGetUserData(sonicStream s) { return s->userData; }
+// libsonic's public names for the same (include/compat/sonic.h without SONIC_INTERNAL)
+void sonicSetUserData(sonicStream s, void* p) { s->userData = p; }
+void* sonicGetUserData(sonicStream s) { return s->userData; }
+float sonicGetSpeed(sonicStream s) { return sonicIntGetSpeed(s); }
+int sonicGetSampleRate(sonicStream s) { return s->sampleRate; }
+int sonicGetNumChannels(sonicStream s) { return s->channels; }
 
 int sonicFlushStream(sonicStream s) {
   if (s->failed || !spx_settings_ok(s)) return 0;

@@ -28,6 +28,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <mutex>
 
 #include "sonic2_stream.h"
@@ -78,6 +79,7 @@ struct SpxPool {
   int64_t aCap = 0, aBump = 0;
   std::vector<int64_t> freeList[48];   // by log2(slots)
   std::vector<sonicStream> members;    // handles that own arena slots
+  std::vector<std::pair<int64_t, int64_t>> arenaLater;   // ranges to free once the run in preparation has been launched
   // waiting work
   std::vector<sonicStream> waiting;
   size_t waitingSegs = 0;
@@ -86,6 +88,9 @@ struct SpxPool {
   unsigned char* dWs = nullptr;
   size_t dWsCap = 0;
   unsigned long long runs = 0, jobs = 0;   // statistics (speedyHipPoolStats)
+  SpxDeferred* defer = nullptr;            // the run in preparation
+  std::vector<void*> blocks[48];           // device block cache by log2(bytes)
+  double t_prep = 0, t_tab = 0, t_launch = 0, t_wait = 0, t_post = 0;   // SPX_POOL_TIMES=1: host seconds per phase
 };
 
 static SpxPool* g_pools[64];
@@ -115,8 +120,29 @@ void spx_pool_adopt(SpxPool* pool, sonicStream s) {
 }
 const SpxFrameRec* spx_pool_arena_rec(SpxPool* pool) { return pool->aRec; }
 
-// ---------------- frame arena ----------------
 static int log2ceil(int64_t v) { int l = 0; while (((int64_t)1 << l) < v) l++; return l; }
+
+// ---------------- device block cache ----------------
+// Sliding buffers of pooled handles are re-allocated all the time (every few dozen writes per handle); the runtime's
+// stream-ordered allocator costs 5-10 us per call, a free list costs nothing.  Pool mutex held.
+void* spx_pool_block_alloc(SpxPool* P, size_t bytes, size_t* got) {
+  int l = log2ceil((int64_t)bytes);
+  if (l < 16) l = 16;
+  *got = (size_t)1 << l;
+  if (!P->blocks[l].empty()) { void* q = P->blocks[l].back(); P->blocks[l].pop_back(); return q; }
+  void* q = nullptr;
+  if (hipMalloc(&q, *got) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return q;
+}
+static void block_free_locked(SpxPool* P, void* p, size_t bytes) {
+  if (p) P->blocks[log2ceil((int64_t)bytes)].push_back(p);
+}
+void spx_pool_block_free(SpxPool* P, void* p, size_t bytes) {   // from outside a run (a stream that has left the pool)
+  std::lock_guard<std::mutex> g(P->mu);
+  block_free_locked(P, p, bytes);
+}
+
+// ---------------- frame arena ----------------
 
 static bool arena_grow(SpxPool* P, int64_t min_cap) {
   static const int64_t first = [] { const char* e = getenv("SPX_POOL_FRAMES"); return e ? atoll(e) : (int64_t)1 << 20; }();
@@ -133,6 +159,19 @@ static bool arena_grow(SpxPool* P, int64_t min_cap) {
     (void)hipFree(P->aRec);
     (void)hipFree(P->aScr);
   }
+  if (P->defer)   // moves already planned for the run in preparation point into the old arrays
+    for (SpxMove& mv : P->defer->moves) {
+      auto fix = [&](const void* q) -> void* {
+        const unsigned char* c = static_cast<const unsigned char*>(q);
+        const unsigned char* r0 = reinterpret_cast<const unsigned char*>(P->aRec);
+        const unsigned char* s0 = reinterpret_cast<const unsigned char*>(P->aScr);
+        if (P->aRec && c >= r0 && c < r0 + sizeof(SpxFrameRec) * (size_t)P->aCap) return reinterpret_cast<unsigned char*>(nr) + (c - r0);
+        if (P->aScr && c >= s0 && c < s0 + sizeof(float) * 4 * (size_t)P->aCap) return reinterpret_cast<unsigned char*>(ns) + (c - s0);
+        return const_cast<void*>(q);
+      };
+      mv.dst = fix(mv.dst);
+      if (mv.src) mv.src = fix(mv.src);
+    }
   P->aRec = nr; P->aScr = ns; P->aCap = ncap;
   for (sonicStream m : P->members)
     if (m->arenaStart >= 0) { m->dRec.p = P->aRec + m->arenaStart; m->dScr.p = P->aScr + 4 * m->arenaStart; }
@@ -150,8 +189,9 @@ static void arena_free(SpxPool* P, int64_t start, int64_t slots) {
   if (start >= 0 && slots > 0) P->freeList[log2ceil(slots)].push_back(start);
 }
 
-bool spx_pool_slide_frames(SpxPool* P, sonicStream s, int64_t keep, int64_t hi, int64_t filled, hipStream_t hs) {
-  int64_t ncap = 256;
+bool spx_pool_slide_frames(SpxPool* P, sonicStream s, int64_t keep, int64_t hi, int64_t filled, SpxDeferred* defer) {
+  if (s->arenaStart >= 0 && keep >= s->dRec.origin) keep -= (keep - s->dRec.origin) & 1;   // moves copy 16-byte units (two records)
+  int64_t ncap = 1024;
   while (ncap < 2 * (hi - keep)) ncap *= 2;
   if (s->arenaStart < 0) P->members.push_back(s);
   const int64_t nstart = arena_alloc(P, ncap);   // (may move the arena: old pointers are refreshed by arena_grow)
@@ -159,12 +199,12 @@ bool spx_pool_slide_frames(SpxPool* P, sonicStream s, int64_t keep, int64_t hi, 
   if (s->arenaStart >= 0 && filled > keep && keep >= s->dRec.origin) {
     const int64_t n = std::min(filled, s->dRec.origin + s->dRec.cap) - keep;
     const int64_t from = s->arenaStart + (keep - s->dRec.origin);
-    // (stream order: whoever used or will use either range is on this stream too)
-    if (hipMemcpyAsync(P->aRec + nstart, P->aRec + from, sizeof(SpxFrameRec) * (size_t)n, hipMemcpyDeviceToDevice, hs) != hipSuccess ||
-        hipMemcpyAsync(P->aScr + 4 * nstart, P->aScr + 4 * from, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToDevice, hs) != hipSuccess)
-      return false;
+    defer->moves.push_back({P->aRec + nstart, P->aRec + from, (uint64_t)(sizeof(SpxFrameRec) * (size_t)n)});
+    defer->moves.push_back({P->aScr + 4 * nstart, P->aScr + 4 * from, (uint64_t)(sizeof(float) * 4 * (size_t)n)});
   }
-  arena_free(P, s->arenaStart, s->arenaCap);
+  // the old range goes back to the free lists only after the run (another handle's move must not land in it before this
+  // handle's move has read it: all moves of a run happen in one kernel)
+  if (s->arenaStart >= 0) P->arenaLater.push_back({s->arenaStart, s->arenaCap});
   s->arenaStart = nstart; s->arenaCap = ncap;
   s->dRec.p = P->aRec + nstart; s->dRec.origin = keep; s->dRec.cap = ncap;
   s->dScr.p = P->aScr + 4 * nstart; s->dScr.origin = 4 * keep; s->dScr.cap = 4 * ncap;
@@ -185,7 +225,20 @@ static void arena_release(SpxPool* P, sonicStream s) {
 __global__ void __launch_bounds__(256)
 spx_pool_stage_kernel(const unsigned* __restrict__ tab_src, unsigned* __restrict__ tab_dst, unsigned n_words,
                       const PoolDesc* __restrict__ desc, SpxStreamState* __restrict__ states, unsigned n,
-                      const PoolCopy* __restrict__ copies, unsigned n_copies, const unsigned char* __restrict__ hin) {
+                      const PoolCopy* __restrict__ copies, unsigned n_copies, const unsigned char* __restrict__ hin,
+                      const SpxMove* __restrict__ moves, unsigned n_moves) {
+  if (blockIdx.x >= n_copies && blockIdx.x < n_copies + n_moves) {   // a buffer move (or a zero fill), 16 bytes per lane
+    const SpxMove m = moves[blockIdx.x - n_copies];
+    uint4* __restrict__ d = static_cast<uint4*>(m.dst);
+    const uint4* __restrict__ q = static_cast<const uint4*>(m.src);
+    const unsigned n16 = (unsigned)(m.bytes >> 4), tail = (unsigned)(m.bytes & 15) >> 1;   // exact: nothing behind the range is touched
+    for (unsigned k = threadIdx.x; k < n16; k += 256) d[k] = q ? q[k] : make_uint4(0u, 0u, 0u, 0u);
+    if (threadIdx.x < tail) {
+      unsigned short* dt = reinterpret_cast<unsigned short*>(d + n16);
+      const unsigned short* qt = reinterpret_cast<const unsigned short*>(q + n16);
+      dt[threadIdx.x] = q ? qt[threadIdx.x] : (unsigned short)0;
+    }
+  }
   const unsigned gt = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
   for (unsigned i = gt; i < n_words; i += stride) tab_dst[i] = tab_src[i];
   constexpr unsigned SW = sizeof(SpxStreamState) / 4;
@@ -244,7 +297,7 @@ spx_pool_gather_kernel(const PoolDesc* __restrict__ desc, const SpxStreamState* 
 }
 
 // ---------------- running what waits ----------------
-static bool place_input(SpxPool* P, sonicStream s, std::vector<PoolCopy>& copies) {
+static bool place_input(SpxPool* P, sonicStream s, std::vector<PoolCopy>& copies, SpxDeferred* defer) {
   if (s->segs.empty()) return true;
   const SpxPlanDev& PL = *s->plan;
   const int64_t C = s->channels;
@@ -256,7 +309,7 @@ static bool place_input(SpxPool* P, sonicStream s, std::vector<PoolCopy>& copies
   if (!s->started) keepFrom = std::min(keepFrom, dst.origin / C);
   if (keepFrom < 0) keepFrom = 0;
   dst.filled = s->devIn * C;
-  if (!dst.ensure(keepFrom * C, s->nIn * C + 64, P->hs, 1 << 16)) return false;
+  if (!dst.ensure(keepFrom * C, s->nIn * C + 64, P->hs, 1 << 17, defer)) return false;
   for (const auto& g : s->segs) {
     const int64_t total = g.frames * C;
     for (int64_t k = 0; k < total; k += 16384) {
@@ -285,17 +338,39 @@ static bool pool_run(SpxPool* P) {
   std::vector<Item> items;
   items.reserve(P->waiting.size());
   std::vector<PoolCopy> copies;
+  SpxDeferred defer;
+  defer.pool = P;
+  P->defer = &defer;
+  const auto tp0 = std::chrono::steady_clock::now();
   for (sonicStream s : P->waiting) {
     Item it;
     it.s = s;
-    if (s->failed || !place_input(P, s, copies) || !spx_prepare_job(s, s->pendingFlush, false, P->hs, P, it.J)) {
+    if (s->failed || !place_input(P, s, copies, &defer) || !spx_prepare_job(s, s->pendingFlush, false, P->hs, P, it.J, &defer)) {
       s->failed = true;
       continue;
     }
     items.push_back(it);
   }
+  P->defer = nullptr;
+  // whatever happens below, the replaced allocations are released behind everything enqueued so far and the replaced
+  // arena ranges return to the free lists
+  struct Releaser {
+    SpxPool* P; SpxDeferred* d;
+    ~Releaser() {
+      for (auto& q : d->frees) block_free_locked(P, q.first, q.second);
+      for (auto& r : P->arenaLater) arena_free(P, r.first, r.second);
+      P->arenaLater.clear();
+    }
+  } releaser{P, &defer};
   const size_t n = items.size();
   if (n == 0) { drop_waiting(P); return true; }
+  // moves in pieces of 64 KB, one workgroup each
+  std::vector<SpxMove> moves;
+  for (const SpxMove& m : defer.moves)
+    for (uint64_t k = 0; k < m.bytes; k += 65536)
+      moves.push_back({static_cast<unsigned char*>(m.dst) + k, m.src ? static_cast<const unsigned char*>(m.src) + k : nullptr,
+                       std::min<uint64_t>(65536, m.bytes - k)});
+  const auto tp1 = std::chrono::steady_clock::now();
   // groups: same plan (sample rate, hysteresis mode), same walk kernel family
   std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) {
     if (a.s->plan != b.s->plan) return a.s->plan < b.s->plan;
@@ -319,7 +394,8 @@ static bool pool_run(SpxPool* P) {
   // ---- pinned tables: jobsA[n] | jobsW[n] | desc[n] | copies[m]; pinned results: PoolResult[n] | output slices ----
   const size_t b_jobs = sizeof(SpxStreamDev) * n;
   const size_t o_desc = 2 * b_jobs, o_copies = o_desc + sizeof(PoolDesc) * n;
-  const size_t b_tab = o_copies + sizeof(PoolCopy) * copies.size();
+  const size_t o_moves = (o_copies + sizeof(PoolCopy) * copies.size() + 15) & ~(size_t)15;
+  const size_t b_tab = o_moves + sizeof(SpxMove) * moves.size();
   if (!P->hTab.reserve(b_tab + 64, 0)) { spx_api_error("pinned table allocation failed"); return false; }
   size_t res_elems = 0;
   int64_t max_slice = 0;
@@ -365,6 +441,8 @@ static bool pool_run(SpxPool* P) {
     D.pad = 0;
   }
   if (!copies.empty()) memcpy(hC, copies.data(), sizeof(PoolCopy) * copies.size());
+  SpxMove* hM = reinterpret_cast<SpxMove*>(P->hTab.p + o_moves);
+  if (!moves.empty()) memcpy(hM, moves.data(), sizeof(SpxMove) * moves.size());
   SpxStreamDev* dA = reinterpret_cast<SpxStreamDev*>(P->dWs);
   SpxStreamDev* dW = dA + n;
   SpxStreamState* dStates = reinterpret_cast<SpxStreamState*>(P->dWs + w_states);
@@ -373,9 +451,11 @@ static bool pool_run(SpxPool* P) {
   int16_t* hOut = reinterpret_cast<int16_t*>(P->hRes.p + o_out);
 
   const unsigned n_words = (unsigned)(2 * b_jobs / 4);
-  const unsigned grid = std::max<unsigned>(std::max<unsigned>((unsigned)copies.size(), (n_words + 255) / 256), 1u);
+  const unsigned grid = std::max<unsigned>(std::max<unsigned>((unsigned)(copies.size() + moves.size()), (n_words + 255) / 256), 1u);
+  const auto tp2 = std::chrono::steady_clock::now();
   hipLaunchKernelGGL(spx_pool_stage_kernel, dim3(grid), dim3(256), 0, P->hs, reinterpret_cast<const unsigned*>(hA),
-                     reinterpret_cast<unsigned*>(dA), n_words, hD, dStates, (unsigned)n, hC, (unsigned)copies.size(), P->hIn.p);
+                     reinterpret_cast<unsigned*>(dA), n_words, hD, dStates, (unsigned)n, hC, (unsigned)copies.size(), P->hIn.p,
+                     hM, (unsigned)moves.size());
   const SpxTapsDev no_taps = {nullptr, nullptr, nullptr, nullptr, nullptr};
   for (const Group& g : groups) {
     const SpxPlanDev& PL = *items[g.i0].s->plan;
@@ -390,7 +470,9 @@ static bool pool_run(SpxPool* P) {
   const unsigned gy = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, (max_slice + 8191) / 8192));
   hipLaunchKernelGGL(spx_pool_gather_kernel, dim3((unsigned)n, gy), dim3(256), 0, P->hs, hD, dStates, dNout, hR, hOut);
   const hipError_t le = hipGetLastError();
+  const auto tp3 = std::chrono::steady_clock::now();
   const hipError_t se = hipStreamSynchronize(P->hs);
+  const auto tp4 = std::chrono::steady_clock::now();
   if (le != hipSuccess || se != hipSuccess) {
     spx_api_error(std::string("coalesced launch failed: ") + hipGetErrorString(le != hipSuccess ? le : se));
     for (auto& it : items) it.s->failed = true;
@@ -426,6 +508,9 @@ static bool pool_run(SpxPool* P) {
   P->runs++;
   P->jobs += n;
   drop_waiting(P);
+  const auto tp5 = std::chrono::steady_clock::now();
+  auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  P->t_prep += sec(tp0, tp1); P->t_tab += sec(tp1, tp2); P->t_launch += sec(tp2, tp3); P->t_wait += sec(tp3, tp4); P->t_post += sec(tp4, tp5);
   return true;
 }
 
@@ -535,6 +620,8 @@ void spx_pool_forget(sonicStream s) {
     if (P->waiting.empty()) { P->hInUsed = 0; P->waitingSegs = 0; }
   }
   arena_release(P, s);
+  for (SlideBuf<int16_t>* b : {&s->dIn, &s->dOut})   // (nothing of a pooled handle is in flight between runs)
+    if (b->block) { block_free_locked(P, b->p - b->guard, b->block); b->p = nullptr; b->cap = 0; b->block = 0; }
   s->pooled = false;
 }
 
@@ -549,5 +636,9 @@ void speedyHipPoolStats(unsigned long long* runs, unsigned long long* jobs) {
   SpxPool* P = (dev >= 0 && dev < 64) ? g_pools[dev] : nullptr;
   if (runs) *runs = P ? P->runs : 0;
   if (jobs) *jobs = P ? P->jobs : 0;
+  if (P && getenv("SPX_POOL_TIMES") && P->runs)
+    fprintf(stderr, "[spx pool] %llu runs, host us per run: prepare %.1f, tables %.1f, launches %.1f, wait %.1f, post %.1f\n", P->runs,
+            1e6 * P->t_prep / P->runs, 1e6 * P->t_tab / P->runs, 1e6 * P->t_launch / P->runs, 1e6 * P->t_wait / P->runs,
+            1e6 * P->t_post / P->runs);
 }
 }

@@ -11,12 +11,27 @@
 #include "../../include/sonic2.h"
 #include "spx_internal.h"
 
+// Deferred device work of a coalesced run (sonic2_pool.hip): buffer moves are not issued as stream operations of their
+// own but collected and carried out by the run's stage kernel; the old allocations are freed after that kernel.
+struct SpxMove { void* dst; const void* src; uint64_t bytes; };   // dst / src 16-byte aligned, bytes even; src == nullptr: zero fill
+struct SpxPool;
+// device blocks of a pool's cache (sonic2_pool.hip): power-of-two sizes, never handed back to the runtime while the pool lives
+void* spx_pool_block_alloc(SpxPool* pool, size_t bytes, size_t* got);
+void spx_pool_block_free(SpxPool* pool, void* p, size_t bytes);
+struct SpxDeferred {
+  SpxPool* pool = nullptr;
+  std::vector<SpxMove> moves;
+  std::vector<std::pair<void*, size_t>> frees;   // blocks that return to the pool's cache after the stage kernel
+};
+
 // A device array holding elements [origin, origin + cap) of a conceptually unbounded sequence.  ensure(lo, hi) makes
 // [lo, hi) addressable and keeps what is already valid from lo on ([lo, filled)); it slides -- a stream-ordered copy
 // into a fresh allocation, the old one freed in stream order -- when hi does not fit or when more than half the
 // allocation is dead prefix.  base() is the pointer that, indexed with ABSOLUTE element numbers, lands in the allocation.
 // `guard` elements in front of p[0] belong to the allocation too (zeroed, never meaningful): a reader that aligns its
 // first position down may touch them.
+// With a SpxDeferred (coalesced runs) nothing is issued: the block comes from the pool's cache, the copy and the guard's
+// zero fill are planned as moves of the run's stage kernel, the old block returns to the cache after it.
 template <class T>
 struct SlideBuf {
   T* p = nullptr;
@@ -24,42 +39,65 @@ struct SlideBuf {
   int64_t cap = 0;     // elements
   int64_t filled = 0;  // absolute end of valid data (set by the owner before ensure)
   int64_t guard = 0;   // addressable elements in front of p[0]
+  size_t block = 0;    // != 0: the allocation is a block of that size from `owner`'s cache (not the runtime's stream-ordered pool)
+  SpxPool* owner = nullptr;
   // does [lo, hi) fit as things are (and is the dead prefix still small)?
   bool fits(int64_t lo, int64_t hi) const {
     return p && lo >= origin && hi <= origin + cap && lo - origin <= cap / 2;
   }
+  void drop_old(hipStream_t st, SpxDeferred* defer) {
+    if (!p) return;
+    if (block && defer) defer->frees.push_back({p - guard, block});
+    else if (block) { (void)hipStreamSynchronize(st); spx_pool_block_free(owner, p - guard, block); }   // (a stream that left its pool: rare)
+    else (void)hipFreeAsync(p - guard, st);
+  }
   // move the window so that it starts at lo and holds at least [lo, hi), keeping [lo, filled)
-  bool slide_to(int64_t lo, int64_t hi, hipStream_t st, int64_t min_cap) {
-    const int64_t ncap = std::max<int64_t>(min_cap, 2 * (hi - lo));
+  bool slide_to(int64_t lo, int64_t hi, hipStream_t st, int64_t min_cap, SpxDeferred* defer = nullptr) {
+    constexpr int64_t A = 16 / (int64_t)sizeof(T) > 0 ? 16 / (int64_t)sizeof(T) : 1;   // elements per 16 bytes
+    if (defer && p && lo >= origin) lo -= (lo - origin) % A;   // deferred moves copy 16-byte units: keep source and destination aligned
+    int64_t ncap = std::max<int64_t>(min_cap, 2 * (hi - lo));
+    ncap = (ncap + A - 1) / A * A;
     T* np = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void**>(&np), (size_t)(ncap + guard) * sizeof(T), st) != hipSuccess) return false;
+    size_t nblock = 0;
+    if (defer) {
+      np = static_cast<T*>(spx_pool_block_alloc(defer->pool, (size_t)(ncap + guard) * sizeof(T) + 16, &nblock));
+      if (!np) return false;
+      ncap = (int64_t)((nblock - 16) / sizeof(T)) - guard;   // the whole block is usable
+      ncap -= ncap % A;
+    } else if (hipMallocAsync(reinterpret_cast<void**>(&np), (size_t)(ncap + guard) * sizeof(T) + 16, st) != hipSuccess) {
+      return false;
+    }
     if (guard) {
-      (void)hipMemsetAsync(np, 0, (size_t)guard * sizeof(T), st);
+      if (defer) defer->moves.push_back({np, nullptr, (uint64_t)(((size_t)guard * sizeof(T) + 15) & ~(size_t)15)});
+      else (void)hipMemsetAsync(np, 0, (size_t)guard * sizeof(T), st);
       np += guard;
     }
     if (p && filled > lo && lo >= origin) {
-      if (hipMemcpyAsync(np, p + (lo - origin), (size_t)(std::min(filled, origin + cap) - lo) * sizeof(T),
-                         hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return false;
+      const size_t bytes = (size_t)(std::min(filled, origin + cap) - lo) * sizeof(T);
+      if (defer) defer->moves.push_back({np, p + (lo - origin), (uint64_t)bytes});   // exact: what lies behind is somebody else's to write
+      else if (hipMemcpyAsync(np, p + (lo - origin), bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
     }
-    if (p) (void)hipFreeAsync(p - guard, st);
+    drop_old(st, defer);
     p = np;
     origin = lo;
     cap = ncap;
+    block = nblock;
+    owner = defer ? defer->pool : nullptr;
     return true;
   }
-  bool ensure(int64_t lo, int64_t hi, hipStream_t st, int64_t min_cap = 4096) {
+  bool ensure(int64_t lo, int64_t hi, hipStream_t st, int64_t min_cap = 4096, SpxDeferred* defer = nullptr) {
     if (p && lo < origin) lo = origin;  // what was dropped stays dropped
     if (lo < 0) lo = 0;
     if (hi < lo) hi = lo;
     if (fits(lo, hi)) return true;
-    return slide_to(lo, hi, st, min_cap);
+    return slide_to(lo, hi, st, min_cap, defer);
   }
   T* base() const { return p - origin; }  // only ever dereferenced at indices >= origin
   void release(hipStream_t st) {
-    if (p) (void)hipFreeAsync(p - guard, st);
+    drop_old(st, nullptr);
     p = nullptr;
     cap = 0;
+    block = 0;
   }
 };
 
@@ -154,10 +192,10 @@ struct SpxJobPlan {
   int tiles = 0;             // analysis tiles of this job (plan tile size)
   SlideBuf<int16_t>* tsmIn = nullptr;
 };
-struct SpxPool;
 // pool == nullptr: offsets relative to the handle's own allocations; else absolute (kernels get null base pointers) and
 // frame records in the pool's arena
-int spx_prepare_job(sonicStream s, bool flush, bool direct, hipStream_t hs, SpxPool* pool, SpxJobPlan& J);
+int spx_prepare_job(sonicStream s, bool flush, bool direct, hipStream_t hs, SpxPool* pool, SpxJobPlan& J,
+                    SpxDeferred* defer = nullptr);
 void spx_finish_job(sonicStream s, const SpxJobPlan& J);
 void spx_api_error(const std::string& msg);
 bool spx_settings_ok(sonicStream s);
@@ -172,6 +210,6 @@ bool spx_pool_leave(sonicStream s);                    // hand the stream to the
 void spx_pool_forget(sonicStream s);                   // at destruction: off the lists, arena slots returned
 int spx_pool_read(sonicStream s, short* out, int bufferSize);
 // frame-arena slide of a pooled handle's records: make [keep, hi) addressable, keeping [keep, filled)
-bool spx_pool_slide_frames(SpxPool* pool, sonicStream s, int64_t keep, int64_t hi, int64_t filled, hipStream_t hs);
+bool spx_pool_slide_frames(SpxPool* pool, sonicStream s, int64_t keep, int64_t hi, int64_t filled, SpxDeferred* defer);
 const SpxFrameRec* spx_pool_arena_rec(SpxPool* pool);
 
