@@ -32,14 +32,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
 def make_streams(n_streams, n, rank):
-    """Distinct speech-like streams: 32 generated bases, the rest are rotations by a stream-specific offset."""
-    from speedy_amd.synth import speech_like
-    bases = [speech_like(n, RATE, seed=1000 * rank + i) for i in range(min(32, n_streams))]
-    out = []
-    for i in range(n_streams):
-        b = bases[i % len(bases)]
-        out.append(np.roll(b, (i // len(bases)) * 7919) if i >= len(bases) else b)
-    return out
+    """Distinct speech-like streams, one seed per stream: seed = 1234 + global stream index, global index =
+    rank * streams per GPU + i -- the streams of an N-rank run are the first 256 N of one global sequence, so partitions
+    can be compared stream by stream (tools/check_scale.py)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from speedy_amd.synth import speech_like   # its generator is seeded with 1234 + seed
+    with ThreadPoolExecutor(max(1, min(8, usable_cpus()[0]))) as ex:
+        return list(ex.map(lambda i: speech_like(n, RATE, seed=rank * n_streams + i), range(n_streams)))
 
 
 def cpu_model():
@@ -109,6 +108,33 @@ def cpu_baseline(streams, gpu_outputs, budget_s=12.0):
             "sample": "%d streams (the %d bench streams%s, %d s each), one stream per task on %d POSIX threads, "
                       "oracle built -O3 -march=native -ffp-contract=off (oracle/orc_bench.c)"
                       % (k, len(streams), ", cycled" if k > len(streams) else "", SECONDS, cores)}
+
+
+def api_many_handles(streams=256, seconds=10.0):
+    """The same configuration through the reference's own API (include/sonic2.h): 256 live sonicStream handles on ONE host
+    thread, every round writes 1000 frames to each handle and then reads from each (speedy_wave.cc:199-220 per handle).
+    A C program (tools/stream_bench.c) in a child process; host-to-device and device-to-host transfers included."""
+    exe = os.path.join(ROOT, "speedy_amd", "lib", "stream_bench")
+    try:
+        if not os.path.exists(exe):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "speedy_amd", "csrc"), "streambench"])
+        best = None
+        for _ in range(3):   # a run is ~30 ms long: the fastest of three
+            out = subprocess.run([exe, str(streams), str(seconds), "1000", str(SPEED), "1", "rounds", str(RATE)],
+                                 capture_output=True, text=True, timeout=300)
+            if out.returncode != 0:
+                return {"error": out.stderr.strip()[-300:]}
+            r = json.loads(out.stdout.strip().splitlines()[-1])
+            if best is None or r["msamples_per_s"] > best["msamples_per_s"]:
+                best = r
+        return {"value": best["msamples_per_s"], "unit": "Msamples/s", "streams": streams, "chunk_frames": 1000,
+                "x_realtime_per_stream": best["x_realtime_per_stream"], "us_per_round": best["us_per_round"],
+                "handles_per_launch_sequence": best["handles_per_sequence"],
+                "note": "sonicWriteShortToStream x %d handles, then sonicReadShortFromStream x %d handles, per round; one host "
+                        "thread; staged writes of all handles run as one launch sequence (sonic2_pool.hip); synthetic "
+                        "speech-like input generated in C" % (streams, streams)}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
 
 
 def spawn_ranks(args):
@@ -211,6 +237,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the many-handle run of the drop-in API (tools/stream_bench.c)")
     ap.add_argument("--chunks", type=int, default=int(os.environ.get("SPX_CHUNKS", "1")),
                     help="time chunks per stream inside one spx_batch_run (analysis of chunk c+1 overlaps the walk of c)")
     ap.add_argument("--crc-out", default=None, help="write this rank's per-stream output CRC-32s to CRC_OUT.rank<r>.json "
@@ -234,20 +261,36 @@ def main():
     dist = None
     red_dev = "cuda"
     backend = args.backend
+    rank_info, handshake_ms = None, None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl" and world > ndev:
-            backend = "gloo"   # several ranks on one GPU (functional check only): RCCL needs one device per rank
+            # RCCL needs one device per rank.  No silent downgrade: a scaling run on a node that shows fewer GPUs than ranks
+            # is a mis-provisioned run, not a slower one (several ranks sharing a GPU: ask for it with --backend gloo)
+            sys.exit("bench.py: WORLD_SIZE=%d but only %d GPU(s) visible; RCCL (--backend nccl) needs one device per rank. "
+                     "Use --backend gloo for a functional check with ranks sharing a GPU." % (world, ndev))
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
             red_dev = "cpu"
+        if world > ndev:
+            # ranks share a GPU: the batch engine's concurrent mode counts the polling workgroups of ONE process
+            # (spx_engine.hip SpxDevGuard); the engine also detects this itself through a per-device lock file
+            os.environ["SPX_SHARED_GPU"] = "1"
         # work-partition handshake: every rank announces its shard (stream count, input frames)
         from speedy_amd.dist import handshake
+        t_h = time.perf_counter()
         layout = handshake(dist, STREAMS_PER_GPU, STREAMS_PER_GPU * RATE * SECONDS, device=red_dev)
+        if red_dev == "cuda":
+            torch.cuda.synchronize()
+        handshake_ms = (time.perf_counter() - t_h) * 1e3
         assert layout.shape == (world, 2) and int(layout[:, 0].sum()) == world * STREAMS_PER_GPU
+        info = {"rank": rank, "local_rank": local_rank, "device_id": dev_index, "device": torch.cuda.get_device_name(dev_index),
+                "host": socket.gethostname(), "pid": os.getpid()}
+        rank_info = [None] * world
+        dist.all_gather_object(rank_info, info)
 
     from speedy_amd.batch import Batch, Plan
     n = RATE * SECONDS
@@ -313,7 +356,9 @@ def main():
         ms_analyze = sa.value / max(1, nc.value)
         ms_walk = sw.value / max(1, nc.value)
         algo_bytes = 2 * 1 * (n_in + n_out)  # int16 read once + int16 written once, per launch
-        dom, dom_ms = ("spx_walk_kernel", ms_walk) if ms_walk >= ms_analyze else ("spx_analysis_kernel", ms_analyze)
+        # the kernels that served the batch, by the names a profiler prints (template arguments included)
+        k_analysis, k_tension, k_walk = L.spx_batch_kernel_names(plan.h, STREAMS_PER_GPU, 1, 1).decode().split(";")
+        dom, dom_ms = (k_walk, ms_walk) if ms_walk >= ms_analyze else (k_analysis, ms_analyze)
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
         traffic_note = None
@@ -328,6 +373,10 @@ def main():
         line = {
             "metric": "Msamples/s processed (16 kHz mono, 3.5x nonlinear)",
             "value": total_in / dt / 1e6, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "value_definition": "input sample frames of all ranks x steps / MAX-over-ranks wall time of the timed steps, inputs "
+                                "resident in HBM when the timed region starts (the bench contract's definition); SURVEY 8(d)'s "
+                                "first-write-to-last-drained-read rate is `pcie_inclusive`, the drop-in API's rate with 256 "
+                                "live sonicStream handles is `api_256_handles`",
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16 samples; f64 DFT, f32 features, int32 AMDF/OLA",
             "data": "synthetic",
@@ -338,25 +387,29 @@ def main():
                        "launcher": "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else
                                    ("bench.py --gpus (self-spawned ranks)" if world > 1 else "single process"),
                        "backend": (backend if world > 1 else None),
+                       "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 and backend == "nccl" else None),
+                       "n_ranks_seen": (int(layout.shape[0]) if world > 1 else 1),
+                       "handshake_ms": handshake_ms,
+                       "ranks": rank_info if rank_info is not None else
+                                [{"rank": 0, "device_id": dev_index, "device": torch.cuda.get_device_name(dev_index)}],
+                       "stream_seeds": "1234 + global stream index (rank * %d + i), all distinct" % STREAMS_PER_GPU,
                        "realtime_factor_per_stream": SECONDS / (ms_step * 1e-3),
                        "out_samples_per_gpu": n_out, "pipeline_chunks": args.chunks,
-                       "kernel_launches_per_step": {"spx_analysis_kernel": args.chunks,
-                                                    "spx_tension_kernel": args.chunks,
-                                                    "spx_walk_kernel": args.chunks}},
+                       "kernel_launches_per_step": {k_analysis: args.chunks, k_tension: args.chunks, k_walk: args.chunks}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "kernel_ms_per_step": {"spx_analysis_kernel": ms_analyze, "spx_tension_kernel": ms_tension,
-                                                "spx_walk_kernel": ms_walk},
-                         "kernel_avg_launch_ms": {"spx_analysis_kernel": ms_analyze / args.chunks,
-                                                  "spx_tension_kernel": ms_tension / args.chunks,
-                                                  "spx_walk_kernel": ms_walk / args.chunks},
+                         "kernel_ms_per_step": {k_analysis: ms_analyze, k_tension: ms_tension, k_walk: ms_walk},
+                         "kernel_avg_launch_ms": {k_analysis: ms_analyze / args.chunks, k_tension: ms_tension / args.chunks,
+                                                  k_walk: ms_walk / args.chunks},
                          "limiter": "latency, not HBM: 256 per-stream chains of ~1300 dependent pitch steps, one "
                                     "workgroup per CU (DESIGN.md 5.3, 6); `bound` names the roofline the contract asks "
                                     "to be priced against"},
         }
         if pcie is not None:
             line["pcie_inclusive"] = pcie
+        if not args.no_api and world == 1:
+            line["api_256_handles"] = api_many_handles()
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (bench contract)
             line["cpu_baseline"] = cpu_baseline(streams, outs)
         print(json.dumps(line), flush=True)

@@ -111,6 +111,9 @@ void spx_set_pipeline_chunks(int chunks);
  * handed over through device-scope flags as they become ready.  Results are identical with it on or off. */
 void spx_set_concurrent(int on);
 int spx_timing_collect(double* sum_ms_analyze, double* sum_ms_walk, int* n_calls);
+/* "analysis;tension;walk": the kernels (template arguments included, as a profiler prints them) that serve a batch of
+ * n_streams streams with at most max_channels channels; speedup_only = every job has speed > 1. */
+const char* spx_batch_kernel_names(spx_plan_t plan, int n_streams, int max_channels, int speedup_only);
 /* Sum over the same calls of the frame-rate (tension) kernel's time, as of the last spx_timing_collect. */
 double spx_timing_last_tension_ms(void);
 

@@ -51,6 +51,7 @@ SYMBOLS = {
     "spx_set_concurrent": (None, [C.c_int]),
     "spx_timing_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "spx_timing_last_tension_ms": (C.c_double, []),
+    "spx_batch_kernel_names": (C.c_char_p, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "spx_device_alloc": (C.c_void_p, [C.c_size_t]),
     "spx_device_free": (None, [C.c_void_p]),
     "spx_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

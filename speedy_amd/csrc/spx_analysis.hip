@@ -77,6 +77,7 @@ static size_t analysis_lds_bytes(const SpxPlanDev& P, bool ct) {  // for the til
 }
 // what spx_launch_analysis (int16 input) will ask for: the engine's co-residency arithmetic uses this
 size_t spx_analysis_lds_bytes(const SpxPlanDev& P) { return analysis_lds_bytes(P, plan_ct_window(P) != 0); }
+int spx_analysis_ct_window(const SpxPlanDev& P) { return plan_ct_window(P); }   // which instantiation serves the plan (0 = plan-driven)
 
 __device__ __forceinline__ void wave_sync() {
   // LDS traffic of one wave is serviced in issue order; only the compiler must not reorder across this.

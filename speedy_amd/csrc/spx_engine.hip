@@ -115,6 +115,54 @@ struct SpxDevGuard {
 };
 static SpxDevGuard g_guard[64];
 
+// Allocated VGPRs of a kernel (hipFuncGetAttributes, rounded up to the granule of 8), cached per function: the query is not
+// free and the engine asks on every call.  Several plans may ask from several threads at once.
+int spx_kernel_vgprs(const void* fn) {
+  static std::mutex mu;
+  static std::map<const void*, int> cache;
+  std::lock_guard<std::mutex> g(mu);
+  auto it = cache.find(fn);
+  if (it != cache.end()) return it->second;
+  hipFuncAttributes a;
+  int regs = 128;
+  if (hipFuncGetAttributes(&a, fn) == hipSuccess) regs = (a.numRegs + 7) & ~7;
+  (void)hipGetLastError();
+  cache[fn] = regs;
+  return regs;
+}
+
+// Cross-process half of SpxDevGuard: the concurrent mode's deadlock-freedom bound counts the polling workgroups of ONE
+// call, and SpxDevGuard enforces "one such call at a time" inside a process only.  Two processes sharing a GPU (several
+// ranks on one device) could both keep polling workgroups resident and close every CU to both analysis kernels.  So the
+// first process that wants the mode on a device takes an exclusive advisory lock on a per-device file and keeps it for
+// its lifetime; a process that finds the lock taken (or cannot create the file, or is told SPX_SHARED_GPU=1) runs its
+// kernels in sequence on that device -- same results.
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+static bool device_is_ours(int dev) {
+  static std::mutex mu;
+  static int state[64];   // 0 unknown, 1 ours, -1 shared
+  if (dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> g(mu);
+  if (state[dev]) return state[dev] > 0;
+  state[dev] = -1;
+  if (getenv("SPX_SHARED_GPU")) return false;
+  char bus[64] = "dev";
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof(bus), "ordinal%d", dev); }
+  for (char* c = bus; *c; c++) if (*c == ':' || *c == '/') *c = '_';
+  const char* dir = getenv("SPX_LOCK_DIR");
+  if (!dir) dir = "/tmp";
+  char path[256];
+  snprintf(path, sizeof(path), "%s/spx_concurrent_%s.lock", dir, bus);
+  int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+  if (fd < 0) fd = open(path, O_RDONLY | O_CLOEXEC);   // somebody else's file: an advisory lock needs no write access
+  if (fd < 0) return false;
+  if (flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); return false; }
+  state[dev] = 1;   // (the descriptor stays open: the lock lives as long as the process)
+  return true;
+}
+
 // Upper bound on the frames a stream can produce from n_in input frames (flush padding included here).
 // speed >= 1: the stage never emits more than it consumes (the nonlinear speed stays >= 1, speedy.c:772).
 // speed < 1: one pitch step at speed s emits at most 2/s frames per frame consumed -- for s < 0.5 it emits
@@ -515,6 +563,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     T.calls++;
   }
   bool want_concurrent = g_concurrent.load() && !env_serial && co_resident && do_a && do_w;
+  if (want_concurrent && !device_is_ours(plan->device)) want_concurrent = false;   // another process works on this GPU
   hipStream_t st = static_cast<hipStream_t>(hs);
   // another concurrent-mode call still in flight on this device, on a different stream?  Then this one runs its kernels
   // in sequence (SpxDevGuard above); the guard stays locked until this call has left its own event behind.
@@ -699,6 +748,22 @@ int spx_batch_analyze(spx_plan_t plan, const spx_stream_job* jobs, int n, const 
 int spx_batch_walk(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                    int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs) {
   return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, false, true);
+}
+
+// Names of the kernels a batch of this shape is served by, as a profiler prints them (without "void" and the argument
+// list): "analysis;tension;walk".  bench.py keys its roofline object and profiles/pmc_traffic.json with them.
+const char* spx_batch_kernel_names(spx_plan_t plan, int n_streams, int max_channels, int speedup_only) {
+  static thread_local char buf[256];
+  const SpxPlanDev& d = plan->dev;
+  const SpxWalkConfig c = spx_walk_config(d, n_streams, max_channels < 1 ? 1 : max_channels, speedup_only != 0);
+  char walk[96];
+  if (c.fast_kernel)
+    snprintf(walk, sizeof(walk), "spx_walk_fast_kernel<%d, %d, %d, 0, %d>", c.nwm, c.nwc >= 4 ? 4 : (c.nwc >= 2 ? 2 : (c.nwc >= 1 ? 1 : 0)),
+             (c.wcap == 4096 && (d.rate == 16000 || d.rate == 22050)) ? d.rate : 0, max_channels > 1 ? 1 : 0);
+  else
+    snprintf(walk, sizeof(walk), "spx_walk_kernel<%d, %d>", c.nw, c.mode);
+  snprintf(buf, sizeof(buf), "spx_analysis_kernel<%d, %d>;spx_tension_kernel;%s", d.tile_frames, spx_analysis_ct_window(d), walk);
+  return buf;
 }
 
 void spx_set_timing(int enabled) { g_timing = enabled != 0; }

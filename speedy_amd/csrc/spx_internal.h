@@ -154,6 +154,7 @@ void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_str
                      const int16_t* in, int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
                      const int* speed_ready, bool speedup_only, hipStream_t st);
 size_t spx_analysis_lds_bytes(const SpxPlanDev& P);
+int spx_analysis_ct_window(const SpxPlanDev& P);
 // The DFT of the spec run on the host (same operation order as the kernel): used to build the Rader tables.
 void spx_host_dft(int n, const int* radix, int nstages, const double* tw, const double* in, double* out);
 size_t spx_walk_lds_bytes(const SpxPlanDev& P, int max_channels, bool speedup_only);
@@ -179,17 +180,7 @@ size_t spx_tension_lds_bytes();
 // VGPRs per lane the hardware allocates to a wave of the kernel that would be launched (hipFuncGetAttributes, rounded up
 // to the allocation granule of 8): the engine's co-residency rule needs them
 // (helper: allocated VGPRs of a kernel, cached per function -- the query is not free and the engine asks on every call)
-static inline int spx_kernel_vgprs(const void* fn) {
-  struct Slot { const void* fn; int regs; };
-  static Slot cache[32];
-  static int n_cached = 0;
-  for (int i = 0; i < n_cached; i++) if (cache[i].fn == fn) return cache[i].regs;   // benign race: same value rewritten
-  hipFuncAttributes a;
-  int regs = 128;
-  if (hipFuncGetAttributes(&a, fn) == hipSuccess) regs = (a.numRegs + 7) & ~7;
-  if (n_cached < 32) { cache[n_cached].fn = fn; cache[n_cached].regs = regs; n_cached++; }
-  return regs;
-}
+int spx_kernel_vgprs(const void* fn);   // spx_engine.hip (one cache, behind a mutex)
 int spx_tension_vgprs();
 int spx_analysis_vgprs(const SpxPlanDev& P);
 int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only);

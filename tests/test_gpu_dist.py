@@ -20,12 +20,14 @@ def test_bench_two_ranks_same_bytes_as_solo(tmp_path):
     from speedy_amd.batch import Batch, Plan
     crc = str(tmp_path / "crc")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-pcie", "--no-cpu-baseline", "--crc-out", crc]
+           "--no-pcie", "--no-cpu-baseline", "--no-api", "--crc-out", crc, "--backend", "gloo"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["n_ranks_seen"] == 2 and line["config"]["backend"] == "gloo" and line["config"]["handshake_ms"] > 0
+    assert [r["rank"] for r in line["config"]["ranks"]] == [0, 1] and all("device" in r for r in line["config"]["ranks"])
     assert line["config"]["streams_per_gpu"] == bench.STREAMS_PER_GPU
     n = bench.RATE * bench.SECONDS
     plan = Plan(bench.RATE, False)
@@ -53,3 +55,27 @@ def test_rccl_collectives_of_the_n_rank_path_with_one_rank():
                        timeout=300, env=env)
     assert r.returncode == 0 and "rccl sanity ok" in r.stdout, (r.stdout[-1000:], r.stderr[-1000:])
     assert "[[256, 40960000]]" in r.stdout
+
+
+def test_no_silent_downgrade_of_the_backend():
+    """More ranks than GPUs with the RCCL backend is a mis-provisioned scaling run: bench.py refuses it (non-zero exit, a
+    message) instead of quietly switching to gloo."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer GPUs than ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-pcie", "--no-cpu-baseline", "--no-api"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert "one device per rank" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_check_scale_partitions_agree():
+    """tools/check_scale.py (the per-stream CRC comparison of 1 / 2 / 4 / 8-rank partitions) on what a 1-GPU box can run:
+    1 and 2 ranks, the two ranks sharing the GPU over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_scale.py"), "--gpus", "1,2", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["ok"] and out["streams_checked"] == 512 and out["runs"]["2"]["n_ranks_seen"] == 2

@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 src = os.path.join(ROOT, "gpurun_out")
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
@@ -36,8 +36,16 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = {}
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
-        key = next((k for k, pat in (("spx_analysis_kernel", "spx_analysis_kernel"), ("spx_tension_kernel", "spx_tension_kernel"),
-                                     ("spx_walk_kernel", "spx_walk")) if pat in name), None)  # spx_walk_kernel / spx_walk_fast_kernel
+        # the kernel's own name with its template arguments, as spx_batch_kernel_names() spells it: no "void", no argument list
+        key = name[5:] if name.startswith("void ") else name
+        depth = 0
+        for pos, c in enumerate(key):
+            depth += (c == "<") - (c == ">")
+            if c == "(" and depth == 0:
+                key = key[:pos]
+                break
+        if not key.startswith(("spx_analysis_kernel", "spx_tension_kernel", "spx_walk")):
+            key = None
         if key and row["Counter_Name"] == counter:
             acc.setdefault(key, []).append(float(row["Counter_Value"]))
     for key, vals in acc.items():
