@@ -37,6 +37,9 @@ def make_streams(n_streams, n, rank):
     can be compared stream by stream (tools/check_scale.py)."""
     from concurrent.futures import ThreadPoolExecutor
     from speedy_amd.synth import speech_like   # its generator is seeded with 1234 + seed
+    if os.environ.get("SPX_BENCH_R02_STREAMS"):   # A/B against round-2 numbers only: that round's 32 bases + rotations
+        bases = [speech_like(n, RATE, seed=1000 * rank + i) for i in range(min(32, n_streams))]
+        return [np.roll(bases[i % 32], (i // 32) * 7919) if i >= 32 else bases[i] for i in range(n_streams)]
     with ThreadPoolExecutor(max(1, min(8, usable_cpus()[0]))) as ex:
         return list(ex.map(lambda i: speech_like(n, RATE, seed=rank * n_streams + i), range(n_streams)))
 
@@ -135,6 +138,18 @@ def api_many_handles(streams=256, seconds=10.0):
                         "speech-like input generated in C" % (streams, streams)}
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)[:300]}
+
+
+def config4_shard(rank, reps=10):
+    """One GPU's shard of BASELINE configs[4]: 256 streams x 10 s, 16 kHz / 22.05 kHz, mono / stereo, 1.5x / 3.5x, all in ONE
+    spx_batch_run_mixed call per step, inputs resident in HBM.  Returns (seconds per step, input frames per step)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_config4 as c4
+    from speedy_amd.batch import Plan
+    streams = c4.shard_streams(256, seed0=4000 + 256 * rank)
+    plans = [Plan(r, False) for r in c4.RATES]
+    b = c4.mixed_batch(plans, streams)
+    return c4.time_steps(b.run, reps=reps), sum(10 * c4.cfg(i)[0] for i in range(256))
 
 
 def spawn_ranks(args):
@@ -237,6 +252,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true")
+    ap.add_argument("--no-config4", action="store_true", help="skip the configs[4] shard (256 mixed-rate streams in one call)")
     ap.add_argument("--no-api", action="store_true", help="skip the many-handle run of the drop-in API (tools/stream_bench.c)")
     ap.add_argument("--chunks", type=int, default=int(os.environ.get("SPX_CHUNKS", "1")),
                     help="time chunks per stream inside one spx_batch_run (analysis of chunk c+1 overlaps the walk of c)")
@@ -350,6 +366,17 @@ def main():
                         "of the produced int16 output; double-buffered on three HIP streams (H2D of batch k+1 and D2H "
                         "of batch k-1 overlap the step of batch k)"}
 
+    # BASELINE configs[4], one GPU's shard per rank (256 mixed-rate streams in one call), MAX over ranks
+    c4 = None
+    if not args.no_config4:
+        barrier()
+        dt4, frames4 = config4_shard(rank)
+        dt4 = max_over_ranks(dt4)
+        c4 = {"value": frames4 * world / dt4 / 1e6, "unit": "Msamples/s", "ms_per_step": dt4 * 1e3, "streams_per_gpu": 256,
+              "note": "BASELINE configs[4], every rank its shard of 256 streams x 10 s (stream i: 16 kHz if i even else 22.05 kHz; "
+                      "mono if (i/2) even else stereo; speed 1.5 if (i/4) even else 3.5; nonlinear 1), ONE spx_batch_run_mixed "
+                      "call per step, inputs resident in HBM, MAX over ranks; input sample frames of all ranks / that time"}
+
     if rank == 0:
         total_in = n_in * world * args.steps
         ms_step = dt / args.steps * 1e3
@@ -408,6 +435,8 @@ def main():
         }
         if pcie is not None:
             line["pcie_inclusive"] = pcie
+        if c4 is not None:
+            line["config4_shard"] = c4
         if not args.no_api and world == 1:
             line["api_256_handles"] = api_many_handles()
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (bench contract)

@@ -97,6 +97,17 @@ int spx_batch_walk(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, c
                    int16_t* out, int64_t* n_out, void* workspace, size_t workspace_bytes,
                    const spx_taps* taps, void* hip_stream);
 
+/* One call for a batch whose streams differ in SAMPLE RATE (the reference fixes the rate per handle, soniclib.c:93 /
+ * speedy.c:213-214, so any mix can be alive at once; BASELINE configs[4] mixes 16 kHz and 22.05 kHz).  plans[k] serves the
+ * jobs with plan_index[i] == k (all plans on the current device, at most 8); in / out / n_out as in spx_batch_run, n_out
+ * indexed like jobs.  All groups are launched together -- the walk workgroups of every group are resident at the same
+ * time -- forked from and joined to hip_stream.  Results per stream are those of spx_batch_run on its own plan. */
+size_t spx_batch_workspace_bytes_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs,
+                                       const int* plan_index, int n_streams);
+int spx_batch_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index,
+                        int n_streams, const int16_t* in, int16_t* out, int64_t* n_out, void* workspace,
+                        size_t workspace_bytes, void* hip_stream);
+
 /* Timing hooks for bench.py: while enabled, every spx_batch_run records HIP events on hip_stream around
  * each of its kernels (no host synchronisation is added to the call).  spx_timing_collect waits for the
  * recorded events, returns the summed kernel milliseconds (over all launches of each kernel) and the number of

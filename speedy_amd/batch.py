@@ -154,6 +154,69 @@ class Batch:
         return r
 
 
+class MixedBatch:
+    """Streams of DIFFERENT sample rates in one call (spx_batch_run_mixed): stream i is served by plans[plan_index[i]].
+    Inputs and outputs are packed like Batch's; results() returns the outputs in the order the streams were given."""
+
+    def __init__(self, plans, plan_index, lengths, channels, speed, nonlinear=1.0, feedback=0.0, device="cuda"):
+        n = len(lengths)
+        self.plans, self.n = list(plans), n
+        self.L = plans[0].L
+        self.plan_index = (C.c_int * n)(*[int(v) for v in plan_index])
+        self.hplans = (C.c_void_p * len(plans))(*[p.h for p in plans])
+        ch = np.broadcast_to(np.asarray(channels, np.int32), (n,)).copy()
+        sp = np.broadcast_to(np.asarray(speed, np.float32), (n,)).copy()
+        nlv = np.broadcast_to(np.asarray(nonlinear, np.float32), (n,)).copy()
+        fb = np.broadcast_to(np.asarray(feedback, np.float32), (n,)).copy()
+        self.lengths, self.channels = np.asarray(lengths, np.int64), ch
+        self.jobs = (StreamJob * n)()
+        in_off = out_off = 0
+        self.in_offs, self.out_offs = [], []
+        for i in range(n):
+            cap = plans[int(plan_index[i])].out_capacity(int(self.lengths[i]), float(sp[i]), float(nlv[i]))
+            j = self.jobs[i]
+            j.in_off, j.n_in, j.out_off, j.out_cap = in_off, int(self.lengths[i]), out_off, cap
+            j.channels, j.speed, j.nonlinear, j.feedback = int(ch[i]), float(sp[i]), float(nlv[i]), float(fb[i])
+            self.in_offs.append(in_off)
+            self.out_offs.append(out_off)
+            in_off += int(self.lengths[i]) * int(ch[i])
+            out_off += cap * int(ch[i])
+        dev = torch.device(device)
+        self.device = dev
+        self.total_frames_in = int(self.lengths.sum())
+        self.d_in = torch.zeros(max(1, in_off) + 64, dtype=torch.int16, device=dev)
+        self.d_out = torch.zeros(max(1, out_off), dtype=torch.int16, device=dev)
+        self.d_nout = torch.zeros(n, dtype=torch.int64, device=dev)
+        wsb = self.L.spx_batch_workspace_bytes_mixed(self.hplans, len(plans), self.jobs, self.plan_index, n)
+        if wsb == 0:
+            raise RuntimeError("spx_batch_workspace_bytes_mixed: " + self.L.spx_last_error().decode())
+        self.d_ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
+
+    def upload(self, streams):
+        host = np.zeros(self.d_in.numel(), np.int16)
+        for i, x in enumerate(streams):
+            x = np.ascontiguousarray(x, np.int16).ravel()
+            assert x.size == int(self.lengths[i]) * int(self.channels[i])
+            host[self.in_offs[i]:self.in_offs[i] + x.size] = x
+        self.d_in.copy_(torch.from_numpy(host))
+
+    def run(self, stream=None):
+        hs = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        rc = self.L.spx_batch_run_mixed(self.hplans, len(self.plans), self.jobs, self.plan_index, self.n, self.d_in.data_ptr(),
+                                        self.d_out.data_ptr(), self.d_nout.data_ptr(), self.d_ws.data_ptr(),
+                                        self.d_ws.numel(), hs)
+        if rc != 0:
+            raise RuntimeError("spx_batch_run_mixed: " + self.L.spx_last_error().decode())
+
+    def results(self):
+        torch.cuda.synchronize(self.device)
+        nout = self.d_nout.cpu().numpy()
+        if (nout < 0).any():
+            raise RuntimeError("output capacity exceeded / lost producer for streams %s" % np.nonzero(nout < 0)[0][:8])
+        out = self.d_out.cpu().numpy()
+        return [out[self.out_offs[i]:self.out_offs[i] + int(nout[i]) * int(self.channels[i])].copy() for i in range(self.n)]
+
+
 def compress_batch(streams, sample_rate, channels, speed, nonlinear=1.0, feedback=0.0, match_matlab=False,
                    taps=False, spectrogram_taps=False):
     """One-call convenience: returns (list of outputs, Batch)."""

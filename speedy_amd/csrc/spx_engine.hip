@@ -87,6 +87,11 @@ struct spx_plan {
   hipEvent_t ev_tension = nullptr;
   hipEvent_t ev_start = nullptr;
   hipEvent_t ev_chunk[SPX_MAX_CHUNKS] = {};
+  // spx_batch_run_mixed: this plan's group runs on `mix`; the first plan of a call also lends the fork event and a staging slot
+  hipStream_t mix = nullptr;
+  hipEvent_t ev_join = nullptr, ev_fork = nullptr;
+  std::mutex mix_mu;
+  SpxStage mix_stage;
 };
 
 // Timing: one set of four HIP events per timed call, recorded on the launch stream and resolved lazily by
@@ -313,6 +318,11 @@ void spx_plan_destroy(spx_plan_t plan) {
   if (!plan) return;
   if (plan->side) { (void)hipStreamSynchronize(plan->side); (void)hipStreamDestroy(plan->side); }
   if (plan->side2) { (void)hipStreamSynchronize(plan->side2); (void)hipStreamDestroy(plan->side2); }
+  if (plan->mix) { (void)hipStreamSynchronize(plan->mix); (void)hipStreamDestroy(plan->mix); }
+  if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
+  if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+  if (plan->mix_stage.done) { (void)hipEventSynchronize(plan->mix_stage.done); (void)hipEventDestroy(plan->mix_stage.done); }
+  if (plan->mix_stage.p) (void)hipHostFree(plan->mix_stage.p);
   if (plan->ev_tension) (void)hipEventDestroy(plan->ev_tension);
   if (plan->ev_start) (void)hipEventDestroy(plan->ev_start);
   for (auto& e : plan->ev_chunk) if (e) (void)hipEventDestroy(e);
@@ -470,9 +480,12 @@ static hipEvent_t take_event() {
   return e;
 }
 
+// `force`: the call is one group of a mixed-rate batch (spx_batch_run_mixed): the launch mode was decided for all groups
+// together, and the device guard is held by the caller.
+struct SpxForce { int concurrent; bool idle_start; };
 static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                     int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs, bool do_a,
-                    bool do_w) {
+                    bool do_w, const SpxForce* force = nullptr) {
   if (!plan || !jobs || n <= 0) return fail(-1, "spx_batch: bad arguments");
   SpxRange range_(do_a && do_w ? "spx_batch_run" : (do_a ? "spx_batch_analyze" : "spx_batch_walk"));
   SpxPlanDev d = plan->dev;  // a copy: the tile size is chosen per call
@@ -540,7 +553,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     }
   }
   int trial_slot = -1;  // 0 / 1: this call is the timed trial of the sequential / concurrent mode
-  if (co_resident && doubtful && do_a && do_w && g_concurrent.load() && !env_serial) {
+  if (co_resident && doubtful && do_a && do_w && g_concurrent.load() && !env_serial && !force) {
     spx_plan::Trial& T = plan->trial;
     const long long key = ((long long)n << 40) ^ ((long long)L.total_frames << 8) ^ (maxC << 1) ^ (speedup_only ? 1 : 0);
     static const int force = getenv("SPX_TRIAL_FORCE") ? atoi(getenv("SPX_TRIAL_FORCE")) : -1;  // tuning: 0 / 1 = no trial
@@ -564,13 +577,14 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   }
   bool want_concurrent = g_concurrent.load() && !env_serial && co_resident && do_a && do_w;
   if (want_concurrent && !device_is_ours(plan->device)) want_concurrent = false;   // another process works on this GPU
+  if (force) want_concurrent = force->concurrent != 0 && do_a && do_w;
   hipStream_t st = static_cast<hipStream_t>(hs);
   // another concurrent-mode call still in flight on this device, on a different stream?  Then this one runs its kernels
   // in sequence (SpxDevGuard above); the guard stays locked until this call has left its own event behind.
   SpxDevGuard& guard = g_guard[(plan->device >= 0 && plan->device < 64) ? plan->device : 0];
   std::unique_lock<std::mutex> guard_lock(guard.mu, std::defer_lock);
-  bool idle_start = false;
-  if (want_concurrent) {
+  bool idle_start = force ? force->idle_start : false;
+  if (want_concurrent && !force) {
     guard_lock.lock();
     const hipError_t q = guard.valid ? hipEventQuery(guard.last) : hipSuccess;
     idle_start = (q == hipSuccess);   // the previous concurrent-mode call (if any) has drained
@@ -720,7 +734,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       HIPCHK(hipStreamWaitEvent(st, plan->ev_tension, 0));
     }
   }
-  if (concurrent) {
+  if (concurrent && !force) {
     // leave this call's completion behind for the next concurrent-mode call on the device (guard still locked)
     if (!guard.last) HIPCHK(hipEventCreateWithFlags(&guard.last, hipEventDisableTiming));
     HIPCHK(hipEventRecord(guard.last, st));
@@ -748,6 +762,170 @@ int spx_batch_analyze(spx_plan_t plan, const spx_stream_job* jobs, int n, const 
 int spx_batch_walk(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                    int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs) {
   return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, false, true);
+}
+
+// ---- one call for a batch whose streams differ in sample rate (BASELINE configs[4]: 16 kHz and 22.05 kHz, mono and
+// stereo, two speeds in one shard).  The reference fixes the rate per handle (soniclib.c:93, speedy.c:213-214), so any mix
+// can be alive at once; here the tables and the kernel instantiations are per rate (a plan), so the batch is cut into one
+// group per plan and ALL groups are launched together: every group on a HIP stream of its own (its walk kernel there, its
+// analysis and tension kernels on the plan's side streams), forked from and joined to the caller's stream -- the walk
+// workgroups of all groups are resident at the same time, one stream per CU as in a homogeneous batch.  The launch mode
+// (concurrent: walk kernels polling for speeds beside the analysis kernels; or in sequence) is decided once for all
+// groups together: the co-residency bound of run_impl counts the polling workgroups of all of them. ----
+__global__ void spx_scatter_nout_kernel(const int64_t* __restrict__ src, const int* __restrict__ idx, int n, int64_t* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[idx[i]] = src[i];
+}
+struct MixedLayout { std::vector<size_t> ws_off, ws_bytes; size_t off_nout, off_idx, total; };
+static MixedLayout mixed_layout(const spx_plan_t* plans, int n_plans, const std::vector<std::vector<spx_stream_job>>& gj, int n) {
+  MixedLayout M;
+  size_t o = 0;
+  for (int g = 0; g < n_plans; g++) {
+    const size_t b = gj[g].empty() ? 0 : layout_for(plans[g]->dev, gj[g].data(), (int)gj[g].size()).total;
+    M.ws_off.push_back(o); M.ws_bytes.push_back(b);
+    o += (b + 255) & ~(size_t)255;
+  }
+  M.off_nout = o; o += ((sizeof(int64_t) * (size_t)n + 255) & ~(size_t)255);
+  M.off_idx = o;  o += ((sizeof(int) * (size_t)n + 255) & ~(size_t)255);
+  M.total = o;
+  return M;
+}
+static int mixed_groups(int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
+                        std::vector<std::vector<spx_stream_job>>& gj, std::vector<std::vector<int>>& gi) {
+  gj.assign(n_plans, {}); gi.assign(n_plans, {});
+  for (int i = 0; i < n; i++) {
+    const int g = plan_index ? plan_index[i] : 0;
+    if (g < 0 || g >= n_plans) return fail(-1, "spx_batch_run_mixed: plan_index out of range");
+    gj[g].push_back(jobs[i]); gi[g].push_back(i);
+  }
+  return 0;
+}
+size_t spx_batch_workspace_bytes_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index,
+                                       int n_streams) {
+  std::vector<std::vector<spx_stream_job>> gj;
+  std::vector<std::vector<int>> gi;
+  if (!plans || n_plans < 1 || !jobs || n_streams < 1 || mixed_groups(n_plans, jobs, plan_index, n_streams, gj, gi)) return 0;
+  return mixed_layout(plans, n_plans, gj, n_streams).total;
+}
+int spx_batch_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
+                        const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, void* hs) {
+  if (!plans || n_plans < 1 || n_plans > 8 || !jobs || n <= 0) return fail(-1, "spx_batch_run_mixed: bad arguments");
+  SpxRange range_("spx_batch_run_mixed");
+  std::vector<std::vector<spx_stream_job>> gj;
+  std::vector<std::vector<int>> gi;
+  int rc = mixed_groups(n_plans, jobs, plan_index, n, gj, gi);
+  if (rc) return rc;
+  const MixedLayout M = mixed_layout(plans, n_plans, gj, n);
+  if (!ws || ws_bytes < M.total) return fail(-1, "spx_batch_run_mixed: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(hs);
+  spx_plan* lead = plans[0];
+  for (int g = 0; g < n_plans; g++) if (plans[g]->device != lead->device) return fail(-1, "spx_batch_run_mixed: plans of different devices");
+  // ---- the launch mode, for all groups together (the rules of run_impl, summed / maximised over the groups) ----
+  size_t cons_lds = 0, cons_waves = 0, max_ps_lds = 0, max_an_lds = 0;
+  int max_walk_regs = 0, max_an_regs = 0, groups = 0;
+  bool fits_one = true;
+  for (int g = 0; g < n_plans; g++) {
+    if (gj[g].empty()) continue;
+    groups++;
+    const SpxPlanDev& d = plans[g]->dev;
+    int maxC = 1; bool speedup_only = true, any_nl = false;
+    for (const auto& j : gj[g]) {
+      maxC = std::max(maxC, (int)j.channels);
+      if (!(j.speed > 1.0f && j.nonlinear >= 0.0f && j.nonlinear <= 1.0f)) speedup_only = false;
+      any_nl = any_nl || j.nonlinear != 0.0f;
+    }
+    const int ng = (int)gj[g].size();
+    const SpxWalkConfig wc = spx_walk_config(d, ng, maxC, speedup_only);
+    if (wc.lds > 160 * 1024) return fail(-1, "spx_batch_run_mixed: too many channels for the walk kernel's LDS window");
+    const size_t ps = wc.lds + spx_tension_lds_bytes();
+    cons_lds += (size_t)ng * ps; cons_waves += (size_t)ng * (wc.waves + 4);
+    max_ps_lds = std::max(max_ps_lds, ps);
+    if (any_nl) {
+      max_an_lds = std::max(max_an_lds, spx_analysis_lds_bytes(d));
+      max_an_regs = std::max(max_an_regs, spx_analysis_vgprs(d));
+    }
+    max_walk_regs = std::max(max_walk_regs, ((wc.waves + 3) / 4) * spx_walk_vgprs(d, ng, maxC, speedup_only));
+  }
+  bool concurrent = false;
+  const size_t lds_per_cu = lead->lds_per_cu;
+  if (max_an_lds > 0 && max_an_lds < lds_per_cu && n <= lead->cu_count) {
+    const size_t closed = cons_lds / (lds_per_cu - max_an_lds + 1) + cons_waves / 29;
+    concurrent = closed < (size_t)lead->cu_count;
+    // ... and worth it only while an analysis workgroup still finds room beside a stream's own workgroups (one suffices here:
+    // a group brings half a batch's frames or less, so its analysis finishes well ahead of its walk even at half speed)
+    const size_t lds_usable = lds_per_cu > 6144 ? lds_per_cu - 6144 : lds_per_cu;
+    if (max_ps_lds + max_an_lds > lds_usable) concurrent = false;
+    fits_one = max_walk_regs + spx_tension_vgprs() + max_an_regs <= 512;
+    if (!fits_one) concurrent = false;
+  }
+  static const bool env_serial = getenv("SPX_SERIAL") != nullptr;
+  static const int env_mixed = getenv("SPX_MIXED_MODE") ? atoi(getenv("SPX_MIXED_MODE")) : -1;   // tuning: 0 sequence, 1 concurrent
+  if (!g_concurrent.load() || env_serial || groups == 0) concurrent = false;
+  if (env_mixed >= 0 && max_an_lds > 0) concurrent = env_mixed == 1;
+  if (concurrent && !device_is_ours(lead->device)) concurrent = false;
+  // ---- the device guard, once for the whole call ----
+  SpxDevGuard& guard = g_guard[(lead->device >= 0 && lead->device < 64) ? lead->device : 0];
+  std::unique_lock<std::mutex> guard_lock(guard.mu, std::defer_lock);
+  SpxForce force = {0, false};
+  if (concurrent) {
+    guard_lock.lock();
+    const hipError_t q = guard.valid ? hipEventQuery(guard.last) : hipSuccess;
+    force.idle_start = (q == hipSuccess);
+    if (guard.valid && guard.last_stream != st && q == hipErrorNotReady) concurrent = false;
+    (void)hipGetLastError();
+    if (!concurrent) guard_lock.unlock();
+  }
+  force.concurrent = concurrent ? 1 : 0;
+  // ---- fork: every group on its plan's own stream ----
+  std::lock_guard<std::mutex> lead_lock(lead->mix_mu);
+  if (!lead->ev_fork) HIPCHK(hipEventCreateWithFlags(&lead->ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(lead->ev_fork, st));
+  unsigned char* w = static_cast<unsigned char*>(ws);
+  int64_t* d_nout = reinterpret_cast<int64_t*>(w + M.off_nout);
+  int* d_idx = reinterpret_cast<int*>(w + M.off_idx);
+  // job -> group-order index table: one small pinned staging slot of the lead plan, copied by the stream
+  std::vector<int> order;
+  order.reserve((size_t)n);
+  for (int g = 0; g < n_plans; g++) order.insert(order.end(), gi[g].begin(), gi[g].end());
+  {
+    SpxStage& G = lead->mix_stage;
+    if (G.done) HIPCHK(hipEventSynchronize(G.done));
+    else HIPCHK(hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
+    if (G.cap < sizeof(int) * (size_t)n) {
+      if (G.p) (void)hipHostFree(G.p);
+      G.p = nullptr; G.cap = 0;
+      HIPCHK(hipHostMalloc(&G.p, sizeof(int) * (size_t)n * 2 + 1024, hipHostMallocDefault));
+      G.cap = sizeof(int) * (size_t)n * 2 + 1024;
+    }
+    memcpy(G.p, order.data(), sizeof(int) * (size_t)n);
+    HIPCHK(hipMemcpyAsync(d_idx, G.p, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(G.done, st));
+  }
+  size_t pos = 0;
+  for (int g = 0; g < n_plans; g++) {
+    if (gj[g].empty()) continue;
+    spx_plan* p = plans[g];
+    if (!p->mix) {
+      HIPCHK(hipStreamCreateWithFlags(&p->mix, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    }
+    HIPCHK(hipStreamWaitEvent(p->mix, lead->ev_fork, 0));
+    rc = run_impl(p, gj[g].data(), (int)gj[g].size(), in, out, d_nout + pos, w + M.ws_off[g], M.ws_bytes[g], nullptr, p->mix, true,
+                  true, &force);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(p->ev_join, p->mix));
+    HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
+    pos += gj[g].size();
+  }
+  hipLaunchKernelGGL(spx_scatter_nout_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_nout, d_idx, n, n_out);
+  if (concurrent) {
+    if (!guard.last) HIPCHK(hipEventCreateWithFlags(&guard.last, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(guard.last, st));
+    guard.last_stream = st;
+    guard.valid = true;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 // Names of the kernels a batch of this shape is served by, as a profiler prints them (without "void" and the argument

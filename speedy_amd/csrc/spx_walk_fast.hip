@@ -54,8 +54,10 @@
 #endif
 enum { FCMD_STEP = 1, FCMD_COPY = 2, FCMD_REFILL = 3, FCMD_POLL = 4, FCMD_EXIT = 5 };
 #define FCMD_INTS 64  // ints per command slot: field k is written by lane k of the publishing wave
-#define FCG 2         // at most this many coarse groups per lane (22.05 kHz: 303 groups on 256 lanes)
-#define FRG 2         // at most this many ragged refine tasks per lane (22.05 kHz: 420 tasks on 256 lanes)
+// at most this many coarse groups / ragged refine tasks per lane (22.05 kHz: 303 groups and 441 tasks over the search lanes):
+// constants of the instantiation -- fewer search waves, more tasks per lane
+static __host__ __device__ constexpr int fcg_of(int nwm) { return nwm == 1 ? 5 : (nwm == 2 ? 3 : 2); }
+static __host__ __device__ constexpr int frg_of(int nwm) { return nwm == 1 ? 7 : (nwm == 2 ? 4 : 2); }
 
 // Diagnostic build only (-DSPX_STAMPS): per-phase shader-cycle sums of workgroup 0, wave 0.  Never in the product.
 #ifdef SPX_STAMPS
@@ -354,6 +356,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
                      int16_t* __restrict__ out_base, int64_t* __restrict__ n_out, SpxStreamState* __restrict__ states,
                      const float* scratch_base, const int* speed_ready, int wcap) {
   constexpr int NT = 64 * (NWM + NWC);
+  constexpr int FCG = fcg_of(NWM), FRG = frg_of(NWM);
   constexpr bool SP = SPEC != 0 && NWC == NWM;
   constexpr bool MCH = MC != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1000,7 +1003,7 @@ bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm) {
   const int chM = (65536 + nch - 1) / nch;
   for (int c0 = 0; c0 <= P.maxPeriod / 2 + 1; c0++)
     if (((c0 * chM) >> 16) != c0 / nch) return false;
-  return total <= FCG * 64 * nwm && ragged <= FRG * 64 * nwm;
+  return total <= fcg_of(nwm) * 64 * nwm && ragged <= frg_of(nwm) * 64 * nwm;
 }
 
 // numRegs of the instantiation spx_launch_walk_fast picks for (nwm, nwc) at this plan's rate
@@ -1012,6 +1015,7 @@ int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int max
 #define SPX_FN_R(M, C) (maxC > 1 ? SPX_FN_RM(M, C, 1) : SPX_FN_RM(M, C, 0))
   if (nwm == 8) fn = SPX_FN_R(8, 4);
   else if (nwm == 2) fn = nwc >= 1 ? SPX_FN_R(2, 1) : SPX_FN_R(2, 0);
+  else if (nwm == 1) fn = SPX_FN_R(1, 0);
   else fn = nwc >= 4 ? SPX_FN_R(4, 4) : nwc >= 2 ? SPX_FN_R(4, 2) : nwc >= 1 ? SPX_FN_R(4, 1) : SPX_FN_R(4, 0);
 #undef SPX_FN_R
 #undef SPX_FN_RM
@@ -1061,6 +1065,8 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
 #endif
   if (nwm == 8) {
     SPX_LAUNCH_FAST(8, 4);
+  } else if (nwm == 1) {
+    SPX_LAUNCH_FAST(1, 0);   // throughput mode: one wave per stream, no output waves, many streams per CU
   } else if (nwm == 2) {
     if (nwc >= 1) SPX_LAUNCH_FAST(2, 1);
     else SPX_LAUNCH_FAST(2, 0);

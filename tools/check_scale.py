@@ -31,7 +31,7 @@ def main():
         for n in counts:
             crc = os.path.join(tmp, "crc%d" % n)
             cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", str(a.steps), "--warmup", "1",
-                   "--no-pcie", "--no-cpu-baseline", "--no-api", "--crc-out", crc, "--backend", a.backend]
+                   "--no-pcie", "--no-cpu-baseline", "--no-api", "--no-config4", "--crc-out", crc, "--backend", a.backend]
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=3600, env=env)
             if r.returncode != 0:
                 sys.exit("bench.py --gpus %d failed (rc %d): %s" % (n, r.returncode, r.stderr[-1500:]))

@@ -33,7 +33,11 @@ for ns in [int(a) for a in sys.argv[1:]] or [64, 128, 256, 512, 1024, 2048]:
     sa, sw, nc = C.c_double(0), C.c_double(0), C.c_int(0)
     plan.L.spx_timing_collect(C.byref(sa), C.byref(sw), C.byref(nc))
     k = max(1, nc.value)
-    print("chunks=%d streams=%5d  %.3f ms/call  %.0f Msamples/s   (kernel sums per call: analysis %.2f ms, walk %.2f ms)"
-          % (chunks, ns, dt * 1e3, ns * n / dt / 1e6, sa.value / k, sw.value / k))
+    import zlib
+    import numpy as np
+    outs = b.results()
+    crc = zlib.crc32(np.concatenate(outs[:40]).tobytes())   # the same for every kernel variant / mode
+    print("chunks=%d streams=%5d  %.3f ms/call  %.0f Msamples/s   (kernel sums per call: analysis %.2f ms, walk %.2f ms)  crc40=%08x"
+          % (chunks, ns, dt * 1e3, ns * n / dt / 1e6, sa.value / k, sw.value / k, crc))
     del b
     torch.cuda.empty_cache()
