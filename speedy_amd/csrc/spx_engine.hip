@@ -393,7 +393,7 @@ static Layout layout_for(const SpxPlanDev& d, const spx_stream_job* jobs, int n)
   L.max_tiles = tf / TFr + n + 1;  // every stream may end with a partial tile
   L.off_order = o;   o += ((sizeof(int) * (size_t)L.max_tiles + 255) & ~(size_t)255);
   L.off_flags = o;   o += ((sizeof(int) * (size_t)L.max_tiles + 255) & ~(size_t)255);
-  L.off_ready = o;   o += ((sizeof(int) * (size_t)n + 255) & ~(size_t)255);
+  L.off_ready = o;   o += ((sizeof(int) * ((size_t)n + 1) + 255) & ~(size_t)255);   // + the count of walk workgroups that have started
   L.total = o;
   return L;
 }
@@ -455,10 +455,17 @@ static SpxTapsDev taps_of(const spx_taps* t) {
 }
 
 }  // extern "C"
-// Idle-start gate (run_impl): holds the analysis stream back for a few tens of microseconds.
-__global__ void spx_gate_kernel(unsigned spins) {
-  if (threadIdx.x == 0)
-    for (unsigned i = 0; i < spins; i++) __builtin_amdgcn_s_sleep(64);   // 64 * 64 clocks each, about 2 us
+// Idle-start gate (run_impl): holds the analysis stream back until every workgroup of the call's walk kernel has been
+// placed -- each announces itself in started[0] (= speed_ready[n_streams]) -- so the wait ends with the event it is
+// for, not after a tuned delay.  Bounded (about 0.3 ms): should the two streams share a hardware queue, the walk launch
+// sits behind this kernel and cannot start; the gate then gives up and the call is merely placed less well.
+__global__ void spx_gate_kernel(const int* started, int n_walk, unsigned max_spins) {
+  if (threadIdx.x == 0) {
+    for (unsigned i = 0; i < max_spins; i++) {
+      if (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_walk) break;
+      __builtin_amdgcn_s_sleep(8);   // 8 * 64 clocks, about 0.25 us
+    }
+  }
 }
 // Job tables (and tile order) from the plan's pinned staging slot into the workspace, hand-off flags cleared.
 __global__ void __launch_bounds__(256)
@@ -663,7 +670,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     // one small kernel reads the pinned slot over PCIe and clears the hand-off flags: a single stream operation where
     // two copies and two fills (each its own DMA packet with barriers around it) cost the concurrent mode 0.13 ms a call
     const unsigned w_sv = (unsigned)(b_sv / 4), w_or = concurrent ? (unsigned)(b_or / 4) : 0u;
-    const unsigned z_fl = concurrent ? (unsigned)tiles[0] : 0u, z_rd = concurrent ? (unsigned)n : 0u;
+    const unsigned z_fl = concurrent ? (unsigned)tiles[0] : 0u, z_rd = concurrent ? (unsigned)n + 1u : 0u;
     hipLaunchKernelGGL(spx_stage_kernel, dim3(64), dim3(256), 0, st, reinterpret_cast<const unsigned*>(hp),
                        reinterpret_cast<unsigned*>(dstreams), w_sv, reinterpret_cast<unsigned*>(d_order), w_or,
                        reinterpret_cast<unsigned*>(d_flags), z_fl, reinterpret_cast<unsigned*>(d_ready), z_rd);
@@ -703,10 +710,12 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     // right behind the staging kernel in its queue and is placed first by itself).  The walk kernel cannot simply be
     // enqueued first: HIP maps streams onto a few hardware queues, and producers queued behind a waiting consumer in a
     // shared queue never start (every consumer is enqueued after its producers, which is safe with any mapping).  So an
-    // idle start holds the analysis stream back with a gate kernel until the walk launch has had time to arrive.
+    // idle start holds the analysis stream back with a gate kernel until the walk kernel's workgroups have been placed
+    // (they count themselves in; spx_gate_kernel).
     static const bool no_gate = getenv("SPX_NO_GATE") != nullptr;  // A/B only
-    static const unsigned gate_spins = [] { const char* e = getenv("SPX_GATE_SPINS"); return e ? (unsigned)atoi(e) : 16u; }();
-    if (concurrent && do_w && idle_start && !no_gate) hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, sa, gate_spins);
+    static const unsigned gate_spins = [] { const char* e = getenv("SPX_GATE_SPINS"); return e ? (unsigned)atoi(e) : 1200u; }();
+    if (concurrent && do_w && idle_start && !no_gate)
+      hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, sa, d_ready + n, n, gate_spins);
     if (do_a && tiles[c] > 0) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, sa); }
@@ -851,11 +860,13 @@ int spx_batch_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_j
   if (max_an_lds > 0 && max_an_lds < lds_per_cu && n <= lead->cu_count) {
     const size_t closed = cons_lds / (lds_per_cu - max_an_lds + 1) + cons_waves / 29;
     concurrent = closed < (size_t)lead->cu_count;
-    // ... and worth it only while an analysis workgroup still finds room beside a stream's own workgroups (one suffices here:
-    // a group brings half a batch's frames or less, so its analysis finishes well ahead of its walk even at half speed)
+    // ... and worth it only while the analysis keeps its throughput beside the consumers: two analysis workgroups beside a
+    // stream's own on a CU, two analysis waves beside them on a SIMD (run_impl's rule).  Measured on the configs[4] shard
+    // (multi-channel walk kernel, 120 registers; 22.05 kHz analysis, 168): with ONE analysis wave per SIMD the analysis runs at
+    // a third of its speed and everything waits for it -- 5.4 ms per step concurrent against 3.8 in sequence.
     const size_t lds_usable = lds_per_cu > 6144 ? lds_per_cu - 6144 : lds_per_cu;
-    if (max_ps_lds + max_an_lds > lds_usable) concurrent = false;
-    fits_one = max_walk_regs + spx_tension_vgprs() + max_an_regs <= 512;
+    if (max_ps_lds + 2 * max_an_lds > lds_usable) concurrent = false;
+    fits_one = max_walk_regs + spx_tension_vgprs() + 2 * max_an_regs <= 512;
     if (!fits_one) concurrent = false;
   }
   static const bool env_serial = getenv("SPX_SERIAL") != nullptr;

@@ -802,6 +802,9 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   // speeds are final (agent-scope release there; one relaxed poll + agent-scope acquire here, Guideline 16); the walk
   // takes whatever is ready, and only waits when it has caught up -- after the first frames it never does.
   const int K_total = (nl != 0.0f && Ttot >= F) ? Ttot - F + 1 : 0;   // soniclib.c:317
+  // concurrent mode: this workgroup has been placed (the engine's idle-start gate counts the arrivals, spx_engine.hip)
+  if (speed_ready != nullptr && tid == 0)
+    __hip_atomic_fetch_add(const_cast<int*>(speed_ready) + gridDim.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (;;) {
     int K = K_total;
     if (speed_ready != nullptr && K_total > 0) {

@@ -865,6 +865,9 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   // Concurrent launches: that kernel runs beside this one and publishes the number of tension frames whose speeds are
   // final (agent-scope release there; one relaxed poll + agent-scope acquire here, cdna_hip_programming.md G16).
   const int K_total = (!linear && Ttot >= F) ? Ttot - F + 1 : 0;  // soniclib.c:317
+  // concurrent mode: this workgroup has been placed (the engine's idle-start gate counts the arrivals, spx_engine.hip)
+  if (speed_ready != nullptr && tid == 0)
+    __hip_atomic_fetch_add(const_cast<int*>(speed_ready) + gridDim.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (;;) {
     int K = K_total;
     if (speed_ready != nullptr && K_total > 0) {

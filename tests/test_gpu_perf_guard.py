@@ -1,0 +1,52 @@
+"""GPU: the headline kernel's run time is watched.  The walk kernel of the bench batch (BASELINE configs[3]: 256 streams x
+10 s, the bench's own streams) must stay within 5 % of the committed reference (profiles/perf_reference.json, written by
+`python tools/perf_reference.py` after a deliberate change) -- in round 2 a change of the link order alone cost 26 %
+unnoticed.  Skipped with a message when the box is too noisy to tell (two measurements more than 3 % apart)."""
+import ctypes as C
+import json
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def measure_walk_ms(steps=12, warm=4):
+    import torch
+    import bench
+    from speedy_amd.batch import Batch, Plan
+    n = bench.RATE * bench.SECONDS
+    plan = Plan(bench.RATE, False)
+    b = Batch(plan, [n] * bench.STREAMS_PER_GPU, 1, bench.SPEED, 1.0, 0.0)
+    b.upload(bench.make_streams(bench.STREAMS_PER_GPU, n, 0))
+    L = plan.L
+    out = []
+    for _ in range(2):
+        for _ in range(warm):
+            b.run()
+        torch.cuda.synchronize()
+        L.spx_set_timing(1)
+        for _ in range(steps):
+            b.run()
+        torch.cuda.synchronize()
+        L.spx_set_timing(0)
+        sa, sw, nc = C.c_double(0), C.c_double(0), C.c_int(0)
+        L.spx_timing_collect(C.byref(sa), C.byref(sw), C.byref(nc))
+        out.append(sw.value / max(1, nc.value))
+    names = L.spx_batch_kernel_names(plan.h, bench.STREAMS_PER_GPU, 1, 1).decode().split(";")
+    return out, names[2]
+
+
+def test_walk_kernel_within_5_percent_of_reference():
+    ref = json.load(open(os.path.join(ROOT, "profiles", "perf_reference.json")))
+    (a, b), kernel = measure_walk_ms()
+    if abs(a - b) > 0.03 * min(a, b):
+        pytest.skip("noisy box: two measurements of the walk kernel %.3f / %.3f ms" % (a, b))
+    got = min(a, b)
+    assert kernel == ref["kernel"], (kernel, ref["kernel"])
+    assert got <= 1.05 * ref["walk_ms_per_step"], \
+        "walk kernel %.3f ms per step, reference %.3f (profiles/perf_reference.json): a regression of %.1f %%" % (
+            got, ref["walk_ms_per_step"], 100.0 * (got / ref["walk_ms_per_step"] - 1.0))
+    if got < 0.93 * ref["walk_ms_per_step"]:
+        print("walk kernel %.3f ms against a reference of %.3f: refresh profiles/perf_reference.json" % (got, ref["walk_ms_per_step"]))
