@@ -605,7 +605,9 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // the walk of chunk c through ordinary stream ordering (measured at 512 / 1024 streams x 10 s: 5.32 -> 4.76 ms and
   // 9.94 -> 9.28 ms per call; no difference at 2048).
   int nch = (do_a && do_w) ? g_chunks.load() : 1;
-  if (do_a && do_w && !g_chunks_set.load() && !want_concurrent && n > cu_count) nch = 4;
+  // (two time chunks once the walk is in its throughput form, more than 2.25 streams per CU: 2048 streams 9.7 -> 9.6 ms;
+  // below that the chains are the run time and the kernels run back to back: 512 streams 3.63 against 3.99 chunked)
+  if (do_a && do_w && !g_chunks_set.load() && !want_concurrent && (long)n * 4 > (long)cu_count * 9) nch = 2;
   if (nch < 1) nch = 1;
   if (nch > SPX_MAX_CHUNKS) nch = SPX_MAX_CHUNKS;
   std::vector<SpxStreamDev> sv;

@@ -942,12 +942,24 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   // 3.67 / 3.19 / 2.91 (walk kernel alone), 512: 5.40 / 4.78 / 5.63, 1024: 10.3 / 9.3 / 10.5, 2048: 19.7 / 17.7 / -.
   c.nw = (n_streams <= 256) ? 8 : 4;
   if (T.nw > 0) c.nw = T.nw;
-  // spx_walk_fast_kernel: search waves + output waves, window frames
-  c.nwm = 4;
-  // output waves: 4 while a stream has a CU to itself; none in large batches (2048 streams x 10 s: walk 11.8 -> 9.1 ms per call,
-  // the output work rides on the search waves and four workgroups of four waves share a CU)
-  c.nwc = (n_streams <= 256) ? 4 : 0;
-  c.wcap = 4096;
+  // spx_walk_fast_kernel: search waves + output waves, window frames.  Three regimes (MI355X, 16 kHz mono x 10 s, ms per call;
+  // profiles/r03/r03l_tp_variants.txt):
+  //   up to ~2.25 streams per CU: 4 search + 4 output waves, 4096-frame window -- a stream's chain is the run time, the
+  //     output work is off it (512 streams: 3.63 against 3.89 without output waves)
+  //   beyond: THROUGHPUT form -- 2 search waves, no output waves, 1536-frame window: 15 KB of LDS and two waves per stream,
+  //     eight streams per CU at four waves per SIMD; the chains hide each other's latencies and the control flow is
+  //     executed twice per stream, not four times (1024 streams: 5.5 against 6.3; 2048: 9.6 against 12.4; 4096: 19.0)
+  static const int cus = [] {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      return prop.multiProcessorCount;
+    (void)hipGetLastError();
+    return 256;
+  }();
+  const bool throughput = (long)n_streams * 4 > (long)cus * 9;
+  c.nwm = throughput ? 2 : 4;
+  c.nwc = throughput ? 0 : 4;
+  c.wcap = throughput ? 1536 : 4096;
   if (T.nwm > 0) c.nwm = T.nwm;
   if (T.nwc >= 0) c.nwc = T.nwc;
   if (T.wcap > 0) c.wcap = T.wcap;

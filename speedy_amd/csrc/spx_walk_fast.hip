@@ -52,6 +52,10 @@
 #ifndef SPX_CT_WCAP
 #define SPX_CT_WCAP 4096  // window frames of the rate-specialised kernels
 #endif
+#ifndef SPX_CT_WCAP_TP
+#define SPX_CT_WCAP_TP 1536  // ... of their throughput instantiations (two search waves, no output waves, eight streams per CU)
+#endif
+#define SPX_CT_WCAP_OF(NWMV, NWCV) (((NWCV) == 0 && (NWMV) <= 2) ? SPX_CT_WCAP_TP : SPX_CT_WCAP)
 enum { FCMD_STEP = 1, FCMD_COPY = 2, FCMD_REFILL = 3, FCMD_POLL = 4, FCMD_EXIT = 5 };
 #define FCMD_INTS 64  // ints per command slot: field k is written by lane k of the publishing wave
 // at most this many coarse groups / ragged refine tasks per lane (22.05 kHz: 303 groups and 441 tasks over the search lanes):
@@ -351,7 +355,10 @@ __device__ __forceinline__ int pair_addr(int base, int d2, int e) { return base 
 // comment at the output waves' loop.  Needs as many output waves as search waves (the same dealing of the refine tasks).
 // MC: 0 = mono streams only (the instantiation of the bench), 1 = any channel count up to 8 per stream.
 template <int NWM, int NWC, int RATE, int SPEC, int MC>
-__global__ void __launch_bounds__(64 * (NWM + NWC)) __attribute__((amdgpu_waves_per_eu((RATE == 16000 && NWC > 0) ? 5 : 4, (RATE == 16000 && NWC > 0) ? 5 : 8)))
+#ifndef SPX_TP_WAVES
+#define SPX_TP_WAVES 4   // minimum waves per SIMD the throughput instantiations (NWC == 0) are compiled for
+#endif
+__global__ void __launch_bounds__(64 * (NWM + NWC)) __attribute__((amdgpu_waves_per_eu((RATE == 16000 && NWC > 0) ? 5 : (NWC == 0 ? SPX_TP_WAVES : 4), (RATE == 16000 && NWC > 0) ? 5 : 8)))
 spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const int16_t* __restrict__ in_base,
                      int16_t* __restrict__ out_base, int64_t* __restrict__ n_out, SpxStreamState* __restrict__ states,
                      const float* scratch_base, const int* speed_ready, int wcap) {
@@ -368,7 +375,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   const int minP = CT ? RATE / 400 : P.minPeriod, maxP = CT ? RATE / 65 : P.maxPeriod;
   const int maxRequired = 2 * maxP;
   const int B = CT ? (int)(RATE / 100.0) : P.B;
-  if (CT) wcap = SPX_CT_WCAP;
+  if (CT) wcap = SPX_CT_WCAP_OF(NWM, NWC);
   const FastLds LY = fast_lds_layout_i(maxP, skip, wcap);
 
   FastOut X;
@@ -493,6 +500,14 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       case 1: d = sad_rect<1>(ap, bp, apx, bpx, app, bpp, d); break;
       case 2: d = sad_rect<2>(ap, bp, apx, bpx, app, bpp, d); break;
       default: d = sad_rect<3>(ap, bp, apx, bpx, app, bpp, d); break;
+    }
+    if constexpr (NWM == 1) {
+      // one chunk per lag (64 lanes, 33 .. 41 lags): it takes every left-over pair of the rectangle, not just the first
+#pragma unroll
+      for (int e = 1; e < 3; e++) {
+        const unsigned* bq = (e < rho) ? bp + pOff + e : app + e;
+        d = __builtin_amdgcn_sad_u16(app[e], *bq, d);
+      }
     }
     atomicAdd(&sums[myT], tOk ? d : 0u);
     FSTAMP(13);
@@ -1002,7 +1017,8 @@ bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm) {
   for (int t = 0; t < 8 * skip + 1; t++) ragged += (t + 2) >> 1;
   // the refine search's common rectangle: at least one chunk per lag, and the multiply-shift division by NCH exact
   const int nlag = 8 * skip + 1, nch = (64 * nwm) / nlag;
-  if (nch < 1) return false;
+  if (nwm < 2) return false;   // one search wave: instantiated for experiments (SPX_WALK_NWM=1 is refused here), results not yet right
+  if (nch < 3) return false;   // up to three left-over pairs of the rectangle, one per chunk
   const int chM = (65536 + nch - 1) / nch;
   for (int c0 = 0; c0 <= P.maxPeriod / 2 + 1; c0++)
     if (((c0 * chM) >> 16) != c0 / nch) return false;
@@ -1012,8 +1028,8 @@ bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm) {
 // numRegs of the instantiation spx_launch_walk_fast picks for (nwm, nwc) at this plan's rate
 int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC) {
   const void* fn = nullptr;
-#define SPX_FN_RM(M, C, MCV) (P.rate == 16000 && wcap == SPX_CT_WCAP ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 16000, 0, MCV>) \
-                        : P.rate == 22050 && wcap == SPX_CT_WCAP ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 22050, 0, MCV>) \
+#define SPX_FN_RM(M, C, MCV) (P.rate == 16000 && wcap == SPX_CT_WCAP_OF(M, C) ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 16000, 0, MCV>) \
+                        : P.rate == 22050 && wcap == SPX_CT_WCAP_OF(M, C) ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 22050, 0, MCV>) \
                         : reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 0, 0, MCV>))
 #define SPX_FN_R(M, C) (maxC > 1 ? SPX_FN_RM(M, C, 1) : SPX_FN_RM(M, C, 0))
   if (nwm == 8) fn = SPX_FN_R(8, 4);
@@ -1039,8 +1055,8 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
   // the two rates of the BASELINE configs get their own specialisation (with the default 4096-frame window)
 #define SPX_LAUNCH_FAST(M, C)                                              \
   do {                                                                     \
-    if (P.rate == 16000 && wcap == SPX_CT_WCAP) SPX_LAUNCH_FAST_R(M, C, 16000);   \
-    else if (P.rate == 22050 && wcap == SPX_CT_WCAP) SPX_LAUNCH_FAST_R(M, C, 22050); \
+    if (P.rate == 16000 && wcap == SPX_CT_WCAP_OF(M, C)) SPX_LAUNCH_FAST_R(M, C, 16000);   \
+    else if (P.rate == 22050 && wcap == SPX_CT_WCAP_OF(M, C)) SPX_LAUNCH_FAST_R(M, C, 22050); \
     else SPX_LAUNCH_FAST_R(M, C, 0);                                       \
   } while (0)
 #ifdef SPX_STAMPS

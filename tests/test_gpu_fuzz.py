@@ -337,15 +337,22 @@ def test_life_cycle_fuzz_interleaved(orc, seed):
             lives.pop(j)
 
 
+@pytest.mark.parametrize("seed", list(range(71, 74)) + list(range(7000, 7000 + SOAK // 10)))
+def test_throughput_batch_fuzz(orc, seed):
+    """Batches of 577 .. 1 100 streams: the walk kernel's throughput form (two search waves, no output waves, 1536-frame
+    window, eight streams per CU) and two pipelined time chunks -- every stream against the oracle."""
+    test_big_batch_fuzz(orc, seed, lo=577, hi=1101)
+
+
 @pytest.mark.parametrize("seed", list(range(41, 44)) + list(range(4000, 4000 + SOAK // 10)))
-def test_big_batch_fuzz(orc, seed):
+def test_big_batch_fuzz(orc, seed, lo=257, hi=601):
     """Batches of 257 .. 600 streams (the large-batch path: speed-up kernels without output waves, pipelined time
     chunks, the sequential fallback) with per-stream channels, lengths 0 .. 1.5 s, speeds including exactly 1 and just
     above it, nonlinear factors 0 / 0.5 / 1, feedback, and the taps -- every stream against the oracle."""
     from speedy_amd.batch import compress_batch
     rng = np.random.default_rng(seed)
     rate = int(rng.choice([8000, 11025, 16000, 16000, 22050, 22050, 44100]))
-    k = int(rng.integers(257, 601))
+    k = int(rng.integers(lo, hi))
     slow = bool(rng.integers(0, 4) == 0)              # one batch in four contains slow-down jobs (general kernel)
     multi = bool(rng.integers(0, 2))
     with_taps = bool(rng.integers(0, 2))
