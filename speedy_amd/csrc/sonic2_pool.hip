@@ -465,7 +465,7 @@ static bool pool_run(SpxPool* P) {
     for (size_t i = g.i0; i < g.i1; i++) any_nl = any_nl || items[i].J.nonlinear;
     if (any_nl) spx_launch_tension(PL, dA + g.i0, ng, dStates + g.i0, P->aRec, P->aScr, no_taps, nullptr, nullptr, P->hs);
     spx_launch_walk(PL, dW + g.i0, ng, g.maxC, nullptr, nullptr, dNout + g.i0, dStates + g.i0, P->aScr, nullptr,
-                    items[g.i0].J.speedupKernel, P->hs);
+                    items[g.i0].J.speedupKernel, P->hs, /*short_jobs=*/true);
   }
   const unsigned gy = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, (max_slice + 8191) / 8192));
   hipLaunchKernelGGL(spx_pool_gather_kernel, dim3((unsigned)n, gy), dim3(256), 0, P->hs, hD, dStates, dNout, hR, hOut);

@@ -543,7 +543,10 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   if (spx_analysis_lds_bytes(d) < lds_per_cu) {
     const size_t lds_closing = lds_per_cu - spx_analysis_lds_bytes(d) + 1;
     const size_t closed = ((size_t)n * per_stream_lds) / lds_closing + ((size_t)n * per_stream_waves) / 29;
-    co_resident = closed < (size_t)cu_count;
+    // ... and the mode is built for ONE stream per CU (the analysis keeps two workgroups' worth of room on every CU): with
+    // the throughput-form walk kernel the bound alone would admit 640 streams, whose polling workgroups then leave the
+    // analysis a fifth of the machine (10.9 ms per call against 4.5 in sequence)
+    co_resident = closed < (size_t)cu_count && n <= cu_count;
     // ... and only worth it when the analysis keeps its throughput beside the consumers: a stream's workgroups and
     // still two analysis workgroups on a CU (measured at 22.05 kHz, where only one fits: 4.1 ms back to back, 5.2 ms concurrent)
     if (per_stream_lds + 2 * spx_analysis_lds_bytes(d) > lds_usable) co_resident = false;
@@ -605,9 +608,9 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // the walk of chunk c through ordinary stream ordering (measured at 512 / 1024 streams x 10 s: 5.32 -> 4.76 ms and
   // 9.94 -> 9.28 ms per call; no difference at 2048).
   int nch = (do_a && do_w) ? g_chunks.load() : 1;
-  // (two time chunks once the walk is in its throughput form, more than 2.25 streams per CU: 2048 streams 9.7 -> 9.6 ms;
+  // (two time chunks once the walk is in its throughput form, more than two streams per CU: 2048 streams 9.7 -> 9.6 ms;
   // below that the chains are the run time and the kernels run back to back: 512 streams 3.63 against 3.99 chunked)
-  if (do_a && do_w && !g_chunks_set.load() && !want_concurrent && (long)n * 4 > (long)cu_count * 9) nch = 2;
+  if (do_a && do_w && !g_chunks_set.load() && !want_concurrent && n > 2 * cu_count) nch = 2;
   if (nch < 1) nch = 1;
   if (nch > SPX_MAX_CHUNKS) nch = SPX_MAX_CHUNKS;
   std::vector<SpxStreamDev> sv;

@@ -152,7 +152,7 @@ void spx_launch_tension(const SpxPlanDev& P, const SpxStreamDev* streams, int n_
 // so the time-scale stage only ever sees speeds >= 1: selects the walk kernel specialised for that.
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int max_channels,
                      const int16_t* in, int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
-                     const int* speed_ready, bool speedup_only, hipStream_t st);
+                     const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs = false);
 size_t spx_analysis_lds_bytes(const SpxPlanDev& P);
 int spx_analysis_ct_window(const SpxPlanDev& P);
 // The DFT of the spec run on the host (same operation order as the kernel): used to build the Rader tables.
@@ -167,7 +167,8 @@ struct SpxWalkConfig {
   int waves;         // waves per stream of the kernel that will run
   size_t lds;        // its LDS bytes per stream
 };
-SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only);
+// short_jobs: the streams bring a few pitch steps each (coalesced sonic2.h writes): latency form whatever their number
+SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only, bool short_jobs = false);
 // spx_walk_fast.hip
 size_t spx_walk_fast_lds_bytes(const SpxPlanDev& P, int wcap);
 bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm);

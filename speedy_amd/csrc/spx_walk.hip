@@ -932,7 +932,7 @@ static int walk_mode(const SpxPlanDev& P, int maxC, bool speedup_only) {
 
 // Kernel variant, waves per stream and LDS per stream for a batch: the one place the launcher and the engine's
 // co-residency arithmetic both ask.
-SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only) {
+SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool short_jobs) {
   if (maxC < 1) maxC = 1;
   const WalkTuning& T = walk_tuning();
   SpxWalkConfig c;
@@ -944,7 +944,7 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   if (T.nw > 0) c.nw = T.nw;
   // spx_walk_fast_kernel: search waves + output waves, window frames.  Three regimes (MI355X, 16 kHz mono x 10 s, ms per call;
   // profiles/r03/r03l_tp_variants.txt):
-  //   up to ~2.25 streams per CU: 4 search + 4 output waves, 4096-frame window -- a stream's chain is the run time, the
+  //   up to two streams per CU: 4 search + 4 output waves, 4096-frame window -- a stream's chain is the run time, the
   //     output work is off it (512 streams: 3.63 against 3.89 without output waves)
   //   beyond: THROUGHPUT form -- 2 search waves, no output waves, 1536-frame window: 15 KB of LDS and two waves per stream,
   //     eight streams per CU at four waves per SIMD; the chains hide each other's latencies and the control flow is
@@ -956,9 +956,14 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
     (void)hipGetLastError();
     return 256;
   }();
-  const bool throughput = (long)n_streams * 4 > (long)cus * 9;
+  //   (the register file holds five waves of the 4 + 4 form per SIMD, i.e. TWO such workgroups per CU: a third waits for a
+  //   slot -- 576 streams 5.8 ms -- so the throughput form starts right above two streams per CU)
+  //   short jobs (coalesced sonic2.h writes: a few pitch steps per stream and launch): nothing to amortise a 2-wave step's
+  //   longer latency over; 4 search waves, output waves while a stream has a CU to itself (1024 handles x 1000 frames:
+  //   511 us per round against 714 in the throughput form)
+  const bool throughput = !short_jobs && n_streams > 2 * cus;
   c.nwm = throughput ? 2 : 4;
-  c.nwc = throughput ? 0 : 4;
+  c.nwc = throughput ? 0 : ((short_jobs && n_streams > cus) ? 0 : 4);
   c.wcap = throughput ? 1536 : 4096;
   if (T.nwm > 0) c.nwm = T.nwm;
   if (T.nwc >= 0) c.nwc = T.nwc;
@@ -1005,10 +1010,10 @@ size_t spx_walk_lds_bytes(const SpxPlanDev& P, int maxC, bool speedup_only) {
 
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int maxC, const int16_t* in,
                      int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
-                     const int* speed_ready, bool speedup_only, hipStream_t st) {
+                     const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs) {
   if (n_streams <= 0) return;
   if (maxC < 1) maxC = 1;
-  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC, speedup_only);
+  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC, speedup_only, short_jobs);
   if (cfg.fast_kernel) {
     spx_launch_walk_fast(P, streams, n_streams, in, out, n_out, states, scratch, speed_ready, cfg.nwm, cfg.nwc, cfg.wcap,
                          maxC, st);
