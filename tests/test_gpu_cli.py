@@ -134,3 +134,17 @@ def test_c_batch_example(orc, tmp_path, name, speed, nl, copies, split):
     assert r.returncode == 0, r.stderr
     ref = orc.compress_sound(x, rate, ch, speed, nl, 0.0, False, chunk=1000 if nl else x.size // ch, taps=False)["out"]
     assert np.array_equal(np.fromfile(out, dtype="<i2"), ref)
+
+
+@pytest.mark.parametrize("seed,handles", [(1, 24), (2, 40), (3, 16)])
+def test_c_api_fuzz_two_execution_paths_agree(seed, handles):
+    """tools/api_fuzz.c, a plain C99 program over include/sonic2.h: a random schedule of writes (short and float), reads,
+    flushes, setters, callbacks switched on mid-stream, sonicInt* calls and destroy / re-create over many handles, run once
+    with coalesced execution and once with every handle on its own launch sequences -- every handle delivers the same bytes
+    at every read.  (The same program runs under ASan + UBSan: tools/asan_host.sh.)"""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "speedy_amd", "csrc"), "apifuzz"])
+    r = subprocess.run([os.path.join(ROOT, "speedy_amd", "lib", "api_fuzz"), str(seed), str(handles), "2500"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    assert "0 handles differ" in r.stdout
