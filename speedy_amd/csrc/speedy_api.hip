@@ -46,31 +46,52 @@ struct speedyStreamStruct {
   std::vector<float> hSpec, hSpecAt, hNorm, hFeat, hTmp;
 };
 
-static bool grow(speedyStream s, int64_t need_hi) {
-  // make frames [max(0, T - SPD_KEEP), need_hi) addressable; everything slides together (one frame_off in the kernels)
+// Oldest frame the device keeps: the reference remembers 21 spectra and 42 hysteresis values (speedy.c:95-97), i.e. a
+// tension older than current_time - 21 cannot be computed there either.  Here the window is SPD_KEEP + Pp + F frames behind
+// the NEWEST frame, whatever has or has not been asked for: a caller that only adds frames (or lags with
+// speedyComputeTension) no longer keeps every row alive -- tensions older than the window are refused instead.
+static int64_t oldest_kept(speedyStream s) {
   const SpxPlanDev& P = *s->plan;
-  const int64_t lo = std::max<int64_t>(0, std::min(s->T, s->tensionDone) - SPD_KEEP - P.Pp - P.F);
+  return std::max<int64_t>(0, s->T - SPD_KEEP - P.Pp - P.F - 8);
+}
+static bool grow(speedyStream s, int64_t need_hi) {
+  // make frames [oldest_kept, need_hi) addressable; everything slides together (one frame_off in the kernels)
+  const SpxPlanDev& P = *s->plan;
+  const int64_t lo = std::max(oldest_kept(s), s->origin);
   if (s->dFrames && need_hi <= s->origin + s->cap && lo - s->origin <= s->cap / 2) return true;
   const int64_t ncap = std::max<int64_t>(256, 2 * (need_hi - lo));
-  const int64_t keep_lo = std::max(lo, s->origin), keep_hi = std::max(s->T + 1, s->hookHi);  // rows that hold data (+1: normalised row T)
-  auto move = [&](auto*& p, int64_t stride) -> bool {
-    using E = std::remove_reference_t<decltype(*p)>;
-    E* np = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void**>(&np), (size_t)ncap * stride * sizeof(E), s->hs) != hipSuccess) return false;
-    (void)hipMemsetAsync(np, 0, (size_t)ncap * stride * sizeof(E), s->hs);
-    if (p && keep_hi > keep_lo) {
+  const int64_t keep_lo = lo, keep_hi = std::max(s->T + 1, s->hookHi);  // rows that hold data (+1: normalised row T)
+  // all new arrays first; the stream's pointers, origin and cap change only when every allocation has succeeded
+  struct Arr { void** p; size_t elem; int64_t stride; void* np; };
+  Arr arrs[8] = {{reinterpret_cast<void**>(&s->dFrames), sizeof(float), P.W, nullptr},
+                 {reinterpret_cast<void**>(&s->dRec), sizeof(SpxFrameRec), 1, nullptr},
+                 {reinterpret_cast<void**>(&s->dScr), sizeof(float), 4, nullptr},
+                 {reinterpret_cast<void**>(&s->tTension), sizeof(float), 1, nullptr},
+                 {reinterpret_cast<void**>(&s->tSpeed), sizeof(float), 1, nullptr},
+                 {reinterpret_cast<void**>(&s->tFeatures), sizeof(float), SPX_FEATURE_COUNT, nullptr},
+                 {reinterpret_cast<void**>(&s->tSpec), sizeof(float), P.N, nullptr},
+                 {reinterpret_cast<void**>(&s->tNorm), sizeof(float), P.W, nullptr}};
+  for (Arr& a : arrs) {
+    if (hipMallocAsync(&a.np, (size_t)ncap * a.stride * a.elem, s->hs) != hipSuccess) {
+      (void)hipGetLastError();
+      for (Arr& b : arrs) if (b.np) (void)hipFreeAsync(b.np, s->hs);
+      return false;   // nothing has moved: the stream is as it was
+    }
+  }
+  for (Arr& a : arrs) {
+    unsigned char* np = static_cast<unsigned char*>(a.np);
+    unsigned char* op = static_cast<unsigned char*>(*a.p);
+    const size_t row = (size_t)a.stride * a.elem;
+    (void)hipMemsetAsync(np, 0, (size_t)ncap * row, s->hs);
+    if (op && keep_hi > keep_lo) {
       const int64_t n = std::min(keep_hi, s->origin + s->cap) - keep_lo;
       if (n > 0)
-        (void)hipMemcpyAsync(np + (keep_lo - lo) * stride, p + (keep_lo - s->origin) * stride, (size_t)n * stride * sizeof(E),
+        (void)hipMemcpyAsync(np + (size_t)(keep_lo - lo) * row, op + (size_t)(keep_lo - s->origin) * row, (size_t)n * row,
                              hipMemcpyDeviceToDevice, s->hs);
     }
-    if (p) (void)hipFreeAsync(p, s->hs);
-    p = np;
-    return true;
-  };
-  if (!move(s->dFrames, P.W) || !move(s->dRec, 1) || !move(s->dScr, 4) || !move(s->tTension, 1) || !move(s->tSpeed, 1) ||
-      !move(s->tFeatures, SPX_FEATURE_COUNT) || !move(s->tSpec, P.N) || !move(s->tNorm, P.W))
-    return false;
+    if (op) (void)hipFreeAsync(op, s->hs);
+    *a.p = a.np;
+  }
   s->origin = lo;
   s->cap = ncap;
   return true;
@@ -320,6 +341,13 @@ int speedyComputeTension(speedyStream s, int64_t at_time, float* tension) {
     spx_internal_set_api_error("speedyComputeTension: tensions must be asked for in increasing time order, each once");
     return 0;
   }
+  // the tension of time t reads frames t - t0 - Pp - 1 .. t - t0 + F; older than the kept window = older than what the
+  // reference's 21-entry spectrum ring still holds (speedy.c:97,476-487)
+  const int64_t lowest = std::max(oldest_kept(s), s->origin);
+  if (lowest > 0 && at_time - s->plan->Pp - 2 < lowest) {
+    spx_internal_set_api_error("speedyComputeTension: that time is older than the history the stream keeps");
+    return 0;
+  }
   if (!launch(s, false, at_time, at_time + 1)) return 0;
   float v = 0.0f;
   if (hipMemcpyAsync(&v, s->tTension + (at_time - s->origin), sizeof(float), hipMemcpyDeviceToHost, s->hs) != hipSuccess ||
@@ -480,6 +508,11 @@ void speedyPreemphasisFilter(speedyStream s, float* input, int length) {        
   hipLaunchKernelGGL(hk_preemph_kernel, dim3(1), dim3(64), 0, s->hs, d, length, s->preemph_prev);
   (void)hipMemcpyAsync(input, d, sizeof(float) * length, hipMemcpyDeviceToHost, s->hs);
   (void)hipFreeAsync(d, s->hs);
+  // ONE pre-emphasis state, as in the reference (speedy.c:416-425): speedyAddData's analysis takes its carry from the last
+  // sample of the previous frame's row, so that is where the hook leaves it (the row's own spectrum is long computed)
+  if (s->T > 0 && s->dFrames && s->T - 1 >= s->origin)
+    (void)hipMemcpyAsync(s->dFrames + (s->T - 1 - s->origin) * s->plan->W + (s->plan->W - 1), &last_raw, sizeof(float),
+                         hipMemcpyHostToDevice, s->hs);
   (void)hipStreamSynchronize(s->hs);
   s->preemph_prev = last_raw;
 }

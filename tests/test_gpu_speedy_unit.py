@@ -330,3 +330,29 @@ def test_hook_spectral_difference(orc):
         amp = np.float32(amp * np.float32(0.9))
     assert abs(last) < 1e-6
     g.close()
+
+
+def test_history_is_bounded_when_tensions_lag(orc):
+    """A caller that only adds frames (or lags far behind with speedyComputeTension) does not make the stream keep every
+    row: device memory stays flat over 20 000 frames, a tension far behind the newest frame is refused with a message (the
+    reference's 21-entry spectrum ring no longer holds it either, speedy.c:97), recent ones still come out right."""
+    import ctypes as C
+    import torch
+    from speedy_amd._lib import c_float_p, lib
+    L = lib()
+    L.speedyHipSetMatchMatlab(0)
+    s = L.speedyCreateStream(16000)
+    W = L.speedyInputFrameSize(s)
+    rng = np.random.default_rng(3)
+    frame = (rng.standard_normal(W) * 0.1).astype(np.float32)
+    for t in range(600):
+        L.speedyAddData(s, frame.ctypes.data_as(c_float_p), t)
+    free0 = torch.cuda.mem_get_info()[0]
+    for t in range(600, 20000):
+        L.speedyAddData(s, np.roll(frame, t).ctypes.data_as(c_float_p), t)
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, (free0, free1)
+    v = C.c_float(0)
+    assert L.speedyComputeTension(s, 100, C.byref(v)) == 0 and b"older than the history" in L.speedyHipLastError()
+    assert L.speedyComputeTension(s, 19999 - 12, C.byref(v)) == 1 and np.isfinite(v.value)
+    L.speedyDestroyStream(s)
