@@ -38,7 +38,9 @@ extern "C" void spx_debug_astamps(unsigned long long* out, int reset) {
 
 // Two tile sizes are compiled: SPX_TF frames (default) and SPX_TF_SMALL, which the engine picks when the smaller LDS
 // footprint is what lets two analysis workgroups sit beside a stream's walk and tension workgroups (concurrent mode).
+#ifndef SPX_TF_SMALL
 #define SPX_TF_SMALL 8
+#endif
 int spx_analysis_tile_frames() { return SPX_TF; }
 int spx_analysis_small_tile_frames() { return SPX_TF_SMALL; }
 
