@@ -535,11 +535,11 @@ bool spx_settings_ok(sonicStream s) {
 
 static int write_shorts(sonicStream s, const short* in, int sampleCount, bool direct = false) {
   if (s->failed || !spx_settings_ok(s)) return 0;
-  (void)hipSetDevice(s->device);
   const int want = (s->nonlinearFactor != 0.0f && !direct) ? 1 : 0;  // soniclib.c:397: decided anew on every write; sonicInt* bypasses
   // the coalesced path serves plain streams; anything that needs a launch sequence of its own leaves it for good
   if (s->pooled && (direct || s->rate != 1.0f || any_callback(s) || (s->mode >= 0 && s->mode != want)) && !spx_pool_leave(s))
     return 0;
+  if (!s->pooled) (void)hipSetDevice(s->device);   // (a staged write makes no runtime call at all; the pool sets the device when it runs)
   if (s->rate != 1.0f && !s->rateMode && !enter_rate_mode(s)) return 0;
   if (want == 1 && !spx_internal_analysis_fits(*s->plan)) {
     g_api_err = "sample rate too high for the nonlinear path (the analysis tile does not fit one CU's LDS); linear mode only";

@@ -89,6 +89,11 @@ struct SpxPool {
   size_t dWsCap = 0;
   unsigned long long runs = 0, jobs = 0;   // statistics (speedyHipPoolStats)
   SpxDeferred* defer = nullptr;            // the run in preparation
+  struct Item { sonicStream s; SpxJobPlan J; };
+  std::vector<Item> items;                 // the run's tables (capacity kept from run to run)
+  std::vector<PoolCopy> copies;
+  std::vector<SpxMove> moves;
+  std::vector<int64_t> res_off, res_cap;
   std::vector<void*> blocks[48];           // device block cache by log2(bytes)
   double t_prep = 0, t_tab = 0, t_launch = 0, t_wait = 0, t_post = 0;   // SPX_POOL_TIMES=1: host seconds per phase
 };
@@ -334,22 +339,25 @@ static void drop_waiting(SpxPool* P) {
 static bool pool_run(SpxPool* P) {
   if (P->waiting.empty()) return true;
   (void)hipSetDevice(P->device);
-  struct Item { sonicStream s; SpxJobPlan J; };
-  std::vector<Item> items;
+  typedef SpxPool::Item Item;
+  // (the run's tables live in the pool and keep their capacity: no allocation on the hot path)
+  std::vector<Item>& items = P->items;
+  std::vector<PoolCopy>& copies = P->copies;
+  items.clear();
+  copies.clear();
   items.reserve(P->waiting.size());
-  std::vector<PoolCopy> copies;
   SpxDeferred defer;
   defer.pool = P;
   P->defer = &defer;
   const auto tp0 = std::chrono::steady_clock::now();
   for (sonicStream s : P->waiting) {
-    Item it;
+    items.emplace_back();
+    Item& it = items.back();   // prepared in place
     it.s = s;
     if (s->failed || !place_input(P, s, copies, &defer) || !spx_prepare_job(s, s->pendingFlush, false, P->hs, P, it.J, &defer)) {
       s->failed = true;
-      continue;
+      items.pop_back();
     }
-    items.push_back(it);
   }
   P->defer = nullptr;
   // whatever happens below, the replaced allocations are released behind everything enqueued so far and the replaced
@@ -365,17 +373,19 @@ static bool pool_run(SpxPool* P) {
   const size_t n = items.size();
   if (n == 0) { drop_waiting(P); return true; }
   // moves in pieces of 64 KB, one workgroup each
-  std::vector<SpxMove> moves;
+  std::vector<SpxMove>& moves = P->moves;
+  moves.clear();
   for (const SpxMove& m : defer.moves)
     for (uint64_t k = 0; k < m.bytes; k += 65536)
       moves.push_back({static_cast<unsigned char*>(m.dst) + k, m.src ? static_cast<const unsigned char*>(m.src) + k : nullptr,
                        std::min<uint64_t>(65536, m.bytes - k)});
   const auto tp1 = std::chrono::steady_clock::now();
   // groups: same plan (sample rate, hysteresis mode), same walk kernel family
-  std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) {
+  auto before = [](const Item& a, const Item& b) {
     if (a.s->plan != b.s->plan) return a.s->plan < b.s->plan;
     return (int)a.J.speedupKernel < (int)b.J.speedupKernel;
-  });
+  };
+  if (!std::is_sorted(items.begin(), items.end(), before)) std::stable_sort(items.begin(), items.end(), before);   // (one kind of handle: nothing to do)
   struct Group { size_t i0, i1; int tiles; int maxC; };
   std::vector<Group> groups;
   for (size_t i = 0; i < n;) {
@@ -399,7 +409,10 @@ static bool pool_run(SpxPool* P) {
   if (!P->hTab.reserve(b_tab + 64, 0)) { spx_api_error("pinned table allocation failed"); return false; }
   size_t res_elems = 0;
   int64_t max_slice = 0;
-  std::vector<int64_t> res_off(n), res_cap(n);
+  std::vector<int64_t>& res_off = P->res_off;
+  std::vector<int64_t>& res_cap = P->res_cap;
+  res_off.resize(n);
+  res_cap.resize(n);
   for (size_t i = 0; i < n; i++) {
     sonicStream s = items[i].s;
     res_cap[i] = std::max<int64_t>(0, items[i].J.need - s->outKnown);
@@ -471,7 +484,18 @@ static bool pool_run(SpxPool* P) {
   hipLaunchKernelGGL(spx_pool_gather_kernel, dim3((unsigned)n, gy), dim3(256), 0, P->hs, hD, dStates, dNout, hR, hOut);
   const hipError_t le = hipGetLastError();
   const auto tp3 = std::chrono::steady_clock::now();
-  const hipError_t se = hipStreamSynchronize(P->hs);
+  // The run is a few tens of microseconds of GPU work: waiting for it in the runtime's blocking way costs about as much
+  // again in wake-up latency.  Poll the stream for a while (SPX_POOL_SPIN_US, default 2000 us), then block.
+  static const long spin_us = [] { const char* e = getenv("SPX_POOL_SPIN_US"); return e ? atol(e) : 2000L; }();
+  hipError_t se = hipErrorNotReady;
+  if (spin_us > 0) {
+    const auto t_spin = std::chrono::steady_clock::now();
+    while ((se = hipStreamQuery(P->hs)) == hipErrorNotReady) {
+      if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_spin).count() > (double)spin_us) break;
+    }
+    if (se == hipErrorNotReady) (void)hipGetLastError();
+  }
+  if (se == hipErrorNotReady) se = hipStreamSynchronize(P->hs);
   const auto tp4 = std::chrono::steady_clock::now();
   if (le != hipSuccess || se != hipSuccess) {
     spx_api_error(std::string("coalesced launch failed: ") + hipGetErrorString(le != hipSuccess ? le : se));
