@@ -46,9 +46,6 @@
 #ifndef SPX_PAD_PL
 #define SPX_PAD_PL 0
 #endif
-#ifndef SPX_SPEC_DELAY
-#define SPX_SPEC_DELAY 0
-#endif
 #ifndef SPX_CT_WCAP
 #define SPX_CT_WCAP 4096  // window frames of the rate-specialised kernels
 #endif
@@ -108,7 +105,7 @@ static __host__ __device__ inline FastLds fast_lds_layout_i(int maxPeriod, int s
   L.off_wait = o; o += 16;
   L.off_sumC = o; o += 2 * 64 * 4;
   L.off_sumR = o; o += 2 * 64 * 4;
-  L.off_sumS = o; o += 2 * 64 * 4;   // speculative refine sums (SPEC kernels)
+  L.off_sumS = o; o += 2 * 64 * 4;   // spare (was: speculative refine sums; kept so that no LDS offset moves)
   L.off_inv = o; o += ((maxPeriod + 2) * 8 + 15) & ~15;
   const int mb = ((wcap + 8) * 2 + 15) & ~15;
   L.off_mono = o; o += mb + SPX_PAD_MONO;
@@ -406,10 +403,9 @@ __device__ __forceinline__ int pair_addr(int base, int d2, int e) { return base 
 // At most 96 VGPRs: in concurrent mode a SIMD holds two waves of this kernel (a search and an output wave), one of the
 // tension kernel (56 registers) and analysis waves of 128 -- with 96 here two of those fit in the 512-register file,
 // with the 97 the compiler would take by itself only one (and the analysis then runs at a third of its speed: measured).
-// SPEC: the output waves run the refine search of every step SPECULATIVELY, for the window the previous step's coarse
-// winner predicts, while the search waves are still busy with the coarse search; when the prediction holds (the coarse
-// winner repeats in 30-60 % of steps on speech) the step skips its refine phase -- half of its time.  See the protocol
-// comment at the output waves' loop.  Needs as many output waves as search waves (the same dealing of the refine tasks).
+// SPEC: always 0.  (Round 2 tried speculative refine searches on the output waves -- the previous step's coarse winner
+// predicts this step's refine window in 30-60 % of steps -- bit-exact and SLOWER, 2.44 against 2.06 ms: DESIGN.md 5.3; the
+// protocol lived here behind this parameter until round 3 and is in the history, commit dd0437d and before.)
 // MC: 0 = mono streams only (the instantiation of the bench), 1 = any channel count up to 8 per stream.
 template <int NWM, int NWC, int RATE, int SPEC, int MC>
 #ifndef SPX_TP_WAVES
@@ -421,7 +417,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
                      const float* scratch_base, const int* speed_ready, int wcap) {
   constexpr int NT = 64 * (NWM + NWC);
   constexpr int FCG = fcg_of(NWM), FRG = frg_of(NWM);
-  constexpr bool SP = SPEC != 0 && NWC == NWM;
+  static_assert(SPEC == 0, "the speculative-refine protocol was removed in round 3");
   constexpr bool MCH = MC != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -444,21 +440,31 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   X.offA0 = LY.off_mono;
   unsigned* sumC = reinterpret_cast<unsigned*>(lds + LY.off_sumC);
   unsigned* sumR = reinterpret_cast<unsigned*>(lds + LY.off_sumR);
-  unsigned* sumS = reinterpret_cast<unsigned*>(lds + LY.off_sumS);
   int* cmd = reinterpret_cast<int*>(lds + LY.off_cmd);
   int* sWait = reinterpret_cast<int*>(lds + LY.off_wait);  // [0] polled count, [1] search-wave arrivals, [2] speculation done
   {
     double* invw = reinterpret_cast<double*>(lds + LY.off_inv);
     for (int t = tid; t <= maxP; t += NT) invw[t] = t > 0 ? 65536.0 / (double)t : 0.0;
-    for (int t = tid; t < 128; t += NT) { sumC[t] = 0; sumR[t] = 0; sumS[t] = 0; }
+    for (int t = tid; t < 128; t += NT) { sumC[t] = 0; sumR[t] = 0; }
     if (tid < 4) sWait[tid] = 0;
     for (int t = tid; t < 2 * FCMD_INTS; t += NT) cmd[t] = 0;
   }
   __syncthreads();
+#ifndef SPX_WALK_PAD
+#define SPX_WALK_PAD 2
+#endif
+#if SPX_WALK_PAD > 0
+  // Code placement: the step loop's speed depends on where it lies relative to the 64-byte instruction fetch lines (round 3:
+  // removing ONE 8-byte prologue instruction, the loop's ISA unchanged, cost 2 %).  SPX_WALK_PAD s_nop's here, executed once,
+  // shift everything behind them by four bytes each.  Swept 0 .. 64 bytes (tools/walk_pad_sweep.sh,
+  // profiles/r03/r03x_walk_pad.txt): the walk kernel of the bench batch reads 2.29 .. 2.36 ms, periodic in 64 bytes; 8 bytes
+  // is the best.  Re-run the sweep after any change to this kernel.
+  asm volatile(".rept %0\n\ts_nop 0\n\t.endr" ::"n"(SPX_WALK_PAD));
+#endif
   const int dA = LY.off_monoB - 2 - LY.off_mono;         // see pair_addr
 
   // ---- refine search: the dealing of its tasks to lanes (constants of the lane).  `sid` = index of the thread among
-  // the 64 * NWM threads that run the refine SADs: the search waves, and (SPEC) the output waves with the same dealing ----
+  // the 64 * NWM threads that run the refine SADs ----
   const int sid = (wave >= NWM) ? tid - 64 * NWM : tid;
   int nRG;  // ragged refine tasks per lane (uniform)
   {
@@ -505,8 +511,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   const int chM = (65536 + NCH - 1) / NCH;  // g / NCH == (g * chM) >> 16 for every group count (checked by spx_walk_fast_supports)
   FSTAMP_VARS
   // The SAD phase of a refine search at window offset o over the lags lo..hi: the ragged tasks and the rectangle of the
-  // calling lane, added into sums[lag - lo].  Search waves (every step whose window was not predicted) and, SPEC,
-  // output waves (the predicted window of every step) run the same code on the same dealing.
+  // calling lane, added into sums[lag - lo].
   auto refine_sads = [&](int o, int lo, int hi, unsigned* sums) __attribute__((always_inline)) {
     const int c0 = lo >> 1;  // pairs every lag of this search has
     const int par = lo & 1;
@@ -580,57 +585,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
 
   if (wave >= NWM) {
     // ------------------------------ output waves: obey commands until FCMD_EXIT ------------------------------
-    if constexpr (SP) {
-      // SPEC protocol.  The search waves publish a command into one of two LDS slots (alternating; field 13 = its
-      // sequence number, written by the same store as the rest) and carry on; the output waves POLL for it instead of
-      // sleeping in a barrier, so they can start at once:
-      //   STEP    speculative refine SADs for the predicted window (fields 10..12) into sumS[parity], arrival counter
-      //           sWait[2] += 1 per wave (behind the sums: a wave's LDS operations are served in order); then the
-      //           previous step's cross-fade; then the step's ONE workgroup barrier.  The search waves meanwhile meet
-      //           among themselves on sWait[1] after the coarse SADs, select, and either find the prediction right --
-      //           wait for sWait[2], barrier, read sumS -- or run the refine SADs themselves, barrier, read sumR.
-      //   others  the barrier that follows the command, then as without SPEC.
-      // A slot is rewritten two commands later, i.e. behind a barrier the output waves joined after reading it.
-      int seq = 0, nspec = 0;
-      pos_t wb = -1, lim = (pos_t)(S.n_in + S.tsm_shift);  // window base / input limit as the commands have announced them
-      for (;;) {
-        const int* c = cmd + (seq & 1) * FCMD_INTS;
-        seq++;
-        while (lds_probe(c + 13) != seq) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-        const int type = uni(c[0]);
-        const int xf_n = uni(c[1]), xf_down = uni(c[2]), xf_period = uni(c[3]), xf_out = uni(c[4]);
-        if (type == FCMD_STEP) {
-          const int so = uni(c[10]), slo = uni(c[11]), shi = uni(c[12]);
-          if (slo >= 0) {
-            const int sg = nspec & 1;
-            nspec++;
-            if (wave == NWM) sumS[(1 - sg) * 64 + lane] = 0;  // the buffer of the speculation before: everyone is past it
-#if SPX_SPEC_DELAY > 0
-            __builtin_amdgcn_s_sleep(SPX_SPEC_DELAY);  // let the search waves' coarse loads through first (LDS is shared)
-#endif
-            refine_sads(so, slo, shi, sumS + sg * 64);
-            if (lane == 0) atomicAdd(reinterpret_cast<unsigned*>(sWait) + 2, 1u);
-          }
-          fast_outputs<64 * NWC, MCH>(X, tid - 64 * NWM, xf_n, xf_down, xf_period, xf_out, 0, 0, 0, lim, wb);
-          fast_sync();
-          continue;
-        }
-        fast_sync();  // the barrier that follows every other command
-        const int cp_n = uni(c[5]), cp_src = uni(c[6]), cp_out = uni(c[7]);
-        const pos_t limit = uni(c[8]), nb = uni(c[9]);
-        lim = limit;
-        fast_outputs<64 * NWC, MCH>(X, tid - 64 * NWM, xf_n, xf_down, xf_period, xf_out, cp_n, cp_src, cp_out, limit, wb);
-        if (type == FCMD_REFILL) {
-          fast_refill<NT, MCH>(X, LY, skip, nb, limit);
-          wb = nb;
-        } else if (type == FCMD_POLL) {
-          fast_sync();            // the polled count is in LDS
-        } else if (type == FCMD_EXIT) {
-          break;
-        }
-      }
-    } else if constexpr (NWC > 0) {
+    if constexpr (NWC > 0) {
       int seq = 0;
       pos_t wb = -1, lim = (pos_t)(S.n_in + S.tsm_shift);  // window base / input limit as the commands have announced them
       for (;;) {
@@ -694,9 +649,6 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   pos_t wbase = -1;              // window covers [wbase, wbase + wcap); -1 = invalid
   int tg = 0;                    // which of the two lag-sum buffers this step adds into (both clear at kernel start)
   int seq = 0;                   // commands published
-  int spO = 0, spLo = -1, spHi = -1;  // SPEC: the refine window handed to the output waves with the step command (set just before)
-  int qPrev = -1;                // SPEC: the previous step's coarse winner = the prediction
-  int stepNo = 0;                // SPEC: steps so far; every step but a stream's first carries a speculation
   int xf_n = 0, xf_down = 0, xf_period = 0;  // cross-fade decided but not yet handed to the output waves
   pos_t xf_out = 0;
 
@@ -758,12 +710,6 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
           rec_ = fast_writelane((int)limit, 8, rec_);                                                      \
           rec_ = fast_writelane((int)(NB), 9, rec_);                                                       \
         }                                                                                                              \
-        if constexpr (SP) {                                                                                            \
-          rec_ = fast_writelane(spO, 10, rec_);                                                            \
-          rec_ = fast_writelane(spLo, 11, rec_);                                                           \
-          rec_ = fast_writelane(spHi, 12, rec_);                                                           \
-          rec_ = fast_writelane(seq + 1, 13, rec_);   /* what the output waves poll for */                 \
-        }                                                                                                              \
         cmd[(seq & 1) * FCMD_INTS + lane] = rec_;                                                                      \
       }                                                                                                                \
       seq++;                                                                                                           \
@@ -788,16 +734,6 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     }
     FSTAMP(2);
     const int o = (int)(pos - wbase);
-    if constexpr (SP) {
-      spO = o;
-      spLo = -1;
-      if (qPrev >= 0 && SPEC != 2) {  // SPEC == 2 (diagnostic): the protocol without speculation
-        const int pp = (minC + qPrev) * skip;
-        spLo = pp - (skip << 2); spHi = pp + (skip << 2);
-        if (spLo < minP) spLo = minP;
-        if (spHi > maxP) spHi = maxP;
-      }
-    }
     FAST_PUBLISH(FCMD_STEP, 0, 0, 0, 0);  // the previous step's cross-fade rides on this step's command
     // ---- coarse search on the decimated signal: each lane its constant group(s) of pair slots ----
     int bestC;
@@ -825,16 +761,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         }
       }
       FSTAMP(3);
-      if constexpr (SP) {
-        // the output waves are busy speculating: the search waves meet among themselves on an LDS counter (a wave's LDS
-        // operations are served in order, so its arrival lands after its lag sums)
-        stepNo++;
-        if (lane == 0) atomicAdd(reinterpret_cast<unsigned*>(sWait) + 1, 1u);
-        const int target = NWM * stepNo;
-        while (lds_probe(sWait + 1) - target < 0) {}
-      } else {
-        fast_sync();
-      }
+      fast_sync();
       FSTAMP(4);
       if (wave == 0) sumC[(1 - tg) * 64 + lane] = 0;  // the buffer the previous step used: everyone is past it
       const unsigned dsum = sumC[tg * 64 + lane];
@@ -852,13 +779,8 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     const double scale = invTab[valid ? p : lo];
     unsigned dsum;
     int nLane, remLane;
-    bool hit = false;
-    if constexpr (SP) {
-      hit = qPrev == bestC && SPEC == 1;  // (SPEC == 3, diagnostic: speculate, never use it)  same coarse winner as the previous step: the output waves have this search's sums
-      qPrev = bestC;
-    }
     {
-      if (!hit) refine_sads(o, lo, hi, sumR + tg * 64);
+      refine_sads(o, lo, hi, sumR + tg * 64);
       // what the step will do for each candidate period: exact IEEE divisions, off the chain; lane 63 = previous period
       {
         const int pc = (lane == 63) ? prevPeriod : p;
@@ -867,17 +789,10 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         remLane = ge2 ? 0 : (int)(fp * twom / sm1);
       }
       FSTAMP(6);
-      if constexpr (SP) {
-        if (hit) {  // every output wave has added its share (arrival counter behind its sums, in order)
-          const int target = NWC * (stepNo - 1);  // speculations published so far (all steps but the first)
-          while (lds_probe(sWait + 2) - target < 0) {}
-        }
-      }
       fast_sync();  // the step's one workgroup barrier: refine sums complete, the output waves done with the command
       FSTAMP(7);
       if (wave == 0) sumR[(1 - tg) * 64 + lane] = 0;
-      if (hit) dsum = sumS[(stepNo & 1) * 64 + lane];  // speculation number stepNo - 1 (from 1) -> buffer (stepNo - 2) & 1
-      else dsum = sumR[tg * 64 + lane];
+      dsum = sumR[tg * 64 + lane];
     }
     tg ^= 1;
     unsigned kmin;
@@ -1119,25 +1034,6 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
 #ifdef SPX_STAMPS
   SPX_LAUNCH_FAST(4, 4);
   return;
-#endif
-#ifdef SPX_WITH_SPEC
-  // Speculative refine searches on the output waves (template parameter SPEC; bit-exact, all parity and fuzz tests pass) --
-  // MEASURED SLOWER and therefore not built by default (make CXXFLAGS=-DSPX_WITH_SPEC to try): walk 2.44 ms against
-  // 2.06; the polling protocol alone costs 6 % (2.18 ms, SPX_WALK_SPEC=2), the speculative SADs another 25 % even when
-  // their result is never used (2.70 ms, SPX_WALK_SPEC=3) -- the second refine search per step competes with the chain
-  // for the CU's one LDS pipe (SQ counters: more than half of its busy cycles are bank conflicts already) -- and a 45 %
-  // hit rate wins back only part of it.  Skipping every refine phase outright (an upper bound, wrong results) runs
-  // in 0.94 ms, so the idea is right about where the time is; it needs a cheaper second search.  DESIGN.md 5.3.
-  static const bool no_spec = getenv("SPX_WALK_NOSPEC") != nullptr;
-  static const int spec_diag = getenv("SPX_WALK_SPEC") ? atoi(getenv("SPX_WALK_SPEC")) : 1;
-  if (nwm == 4 && nwc >= 4 && !no_spec) {
-    if (P.rate == 16000 && wcap == SPX_CT_WCAP && spec_diag == 2) SPX_LAUNCH_FAST_RS(4, 4, 16000, 2);
-    else if (P.rate == 16000 && wcap == SPX_CT_WCAP && spec_diag == 3) SPX_LAUNCH_FAST_RS(4, 4, 16000, 3);
-    else if (P.rate == 16000 && wcap == SPX_CT_WCAP) SPX_LAUNCH_FAST_RS(4, 4, 16000, 1);
-    else if (P.rate == 22050 && wcap == SPX_CT_WCAP) SPX_LAUNCH_FAST_RS(4, 4, 22050, 1);
-    else SPX_LAUNCH_FAST_RS(4, 4, 0, 1);
-    return;
-  }
 #endif
   if (nwm == 8) {
     SPX_LAUNCH_FAST(8, 4);
