@@ -41,18 +41,24 @@ extern "C" void spx_debug_astamps(unsigned long long* out, int reset) {
 #ifndef SPX_TF_SMALL
 #define SPX_TF_SMALL 8
 #endif
+// ... and SPX_TF_TINY, with fewer than four waves doing transforms (SpxPlanDev::dft_waves), for the window sizes of sample
+// rates above about 61 kHz, whose fp64 work areas and log-term rows would not fit one CU's LDS otherwise (plan-driven
+// instantiation only).
+#define SPX_TF_TINY 4
 int spx_analysis_tile_frames() { return SPX_TF; }
 int spx_analysis_small_tile_frames() { return SPX_TF_SMALL; }
+int spx_analysis_tiny_tile_frames() { return SPX_TF_TINY; }
 
 #define SPX_CB 24  // W = 240 kernel: |log ratio| terms are handed from the waves that compute them to the wave that sums
                    // them in blocks of SPX_CB bins (two blocks in flight); row stride SPX_CB + 1 doubles (LDS banks)
-static __host__ __device__ inline size_t work_bytes(int W, int tf, bool ct = false) {
+static __host__ __device__ inline size_t work_bytes(int W, int tf, bool ct = false, int dft_waves = 4) {
+  if (dft_waves < 1 || dft_waves > 4) dft_waves = 4;
   if (ct) {
     size_t a = (size_t)4 * 2 * W * sizeof(double);             // 4 waves x W complex, stages in place
     size_t b = (size_t)2 * tf * (SPX_CB + 1) * sizeof(double); // aliased: two blocks of log terms
     return (a > b ? a : b);
   }
-  size_t a = (size_t)4 * 2 * 2 * W * sizeof(double);         // 4 waves x ping-pong x W complex
+  size_t a = (size_t)dft_waves * 2 * 2 * W * sizeof(double);   // transforming waves x ping-pong x W complex
   size_t b = (size_t)tf * (W + 1) * sizeof(double);          // aliased: log terms
   return (a > b ? a : b);
 }
@@ -75,7 +81,7 @@ static size_t analysis_lds_bytes(const SpxPlanDev& P, bool ct) {  // for the til
   size_t stage = (stage_samples(P, tf) * sizeof(short) + 15) & ~(size_t)15;
   // tuning only (fewer workgroups per CU); part of the size so that the co-residency rule sees it; read once per process
   static const size_t pad = [] { const char* e = getenv("SPX_ANALYSIS_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
-  return work_bytes(P.W, tf, ct) + ((mags + 15) & ~(size_t)15) + ((small + 15) & ~(size_t)15) + stage + pad;
+  return work_bytes(P.W, tf, ct, P.dft_waves) + ((mags + 15) & ~(size_t)15) + ((small + 15) & ~(size_t)15) + stage + pad;
 }
 // what spx_launch_analysis (int16 input) will ask for: the engine's co-residency arithmetic uses this
 size_t spx_analysis_lds_bytes(const SpxPlanDev& P) { return analysis_lds_bytes(P, plan_ct_window(P) != 0); }
@@ -276,7 +282,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   const int16_t* __restrict__ in = in_base + S.in_off;
 
   double* work = reinterpret_cast<double*>(lds);
-  const size_t wb = work_bytes(W, TF, WCT != 0);
+  const size_t wb = work_bytes(W, TF, WCT != 0, (WCT != 0) ? 4 : P.dft_waves);
   float* mags = reinterpret_cast<float*>(lds + wb);
   const size_t mags_b = (((size_t)(TF + 1) * (W + 1) * sizeof(float)) + 15) & ~(size_t)15;
   float* fE = reinterpret_cast<float*>(lds + wb + mags_b);
@@ -639,7 +645,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       ASTAMP(2);
     }
   } else
-  for (int s = wave; s <= TF; s += 4) {
+  for (int s = wave, ndw = (P.dft_waves >= 1 && P.dft_waves <= 4) ? P.dft_waves : 4; s <= TF && wave < ndw; s += ndw) {
     const int j = j0 - 1 + s;
     float* mrow = mags + (size_t)s * MS;
     if (j < 0 || j >= j1) {  // outside the stream (or the tile's tail): zero spectrum
@@ -892,7 +898,9 @@ void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n
 #define SPX_LAUNCH_ANALYSIS(TFV, WV)                                                                                   \
   hipLaunchKernelGGL((spx_analysis_kernel<TFV, WV>), dim3(n_tiles), dim3(SPX_BLOCK), lds, st, P, streams, n_streams, in, \
                      rec, taps, tile_order, tile_flags, (const float*)nullptr, 0)
-  if (P.tile_frames == SPX_TF_SMALL) {
+  if (P.tile_frames == SPX_TF_TINY) {
+    SPX_LAUNCH_ANALYSIS(SPX_TF_TINY, 0);
+  } else if (P.tile_frames == SPX_TF_SMALL) {
     if (ctw == 240) SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 240); else if (ctw == 330) SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 330);
     else SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 0);
   } else {
@@ -906,7 +914,8 @@ int spx_analysis_vgprs(const SpxPlanDev& P) {
   const int ctw = plan_ct_window(P);
   const bool small = P.tile_frames == SPX_TF_SMALL;
   const void* fn;
-  if (small) fn = ctw == 240 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_SMALL, 240>)
+  if (P.tile_frames == SPX_TF_TINY) fn = reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_TINY, 0>);
+  else if (small) fn = ctw == 240 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_SMALL, 240>)
                 : ctw == 330 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_SMALL, 330>)
                              : reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_SMALL, 0>);
   else fn = ctw == 240 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF, 240>)
@@ -919,9 +928,12 @@ void spx_launch_analysis_frames(const SpxPlanDev& P, const SpxStreamDev* streams
                                 bool preemph, SpxFrameRec* rec, SpxTapsDev taps, hipStream_t st) {
   if (n_tiles <= 0) return;
   SpxPlanDev Q = P;
-  if (Q.tile_frames != SPX_TF_SMALL) Q.tile_frames = SPX_TF;   // (the plan's tile is the small one above about 49 kHz)
+  if (Q.tile_frames != SPX_TF_SMALL && Q.tile_frames != SPX_TF_TINY) Q.tile_frames = SPX_TF;   // (smaller tiles above about 49 / 61 kHz)
   const size_t lds = analysis_lds_bytes(Q, false);  // the plan-driven instantiation
-  if (Q.tile_frames == SPX_TF_SMALL)
+  if (Q.tile_frames == SPX_TF_TINY)
+    hipLaunchKernelGGL((spx_analysis_kernel<SPX_TF_TINY, 0>), dim3(n_tiles), dim3(SPX_BLOCK), lds, st, Q, streams, 1,
+                       (const int16_t*)nullptr, rec, taps, (const int*)nullptr, (int*)nullptr, frames, preemph ? 1 : 2);
+  else if (Q.tile_frames == SPX_TF_SMALL)
     hipLaunchKernelGGL((spx_analysis_kernel<SPX_TF_SMALL, 0>), dim3(n_tiles), dim3(SPX_BLOCK), lds, st, Q, streams, 1,
                        (const int16_t*)nullptr, rec, taps, (const int*)nullptr, (int*)nullptr, frames, preemph ? 1 : 2);
   else

@@ -225,11 +225,20 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
     fail(-1, "spx_plan_create: too many DFT stages");
     return nullptr;
   }
+  // The analysis tile must fit one CU's LDS: 16 frames and four transforming waves up to about 49 kHz, 8 frames up to about
+  // 61 kHz; above that (round 3) fewer waves transform -- their fp64 work areas are what grows -- and the tile shrinks to 4
+  // frames (its rows of log terms grow too): 2 waves up to about 100 kHz, 1 wave up to the 128 kHz the walk kernel takes.
+  d.dft_waves = 4;
   d.tile_frames = spx_analysis_tile_frames();
-  if (spx_analysis_lds_bytes(d) > 160 * 1024)    // one CU's LDS: above about 49 kHz the plan's tile is the 8-frame one
-    d.tile_frames = spx_analysis_small_tile_frames();
-  // ... and above about 61 kHz not even that fits (four waves' DFT work areas): the plan then serves linear jobs only
-  // (the TSM stage alone, spx_internal_analysis_fits); a nonlinear job on it is refused
+  const int cand[5][2] = {{spx_analysis_tile_frames(), 4}, {spx_analysis_small_tile_frames(), 4}, {spx_analysis_small_tile_frames(), 2},
+                          {spx_analysis_tiny_tile_frames(), 2}, {spx_analysis_tiny_tile_frames(), 1}};
+  for (int c = 0; c < 5; c++) {
+    d.tile_frames = cand[c][0];
+    d.dft_waves = cand[c][1];
+    if (spx_analysis_lds_bytes(d) <= 160 * 1024) break;
+  }
+  // (a window too large even for that leaves the plan to linear jobs -- the TSM stage alone, spx_internal_analysis_fits --
+  // and a nonlinear job on it is refused; no rate below 128 kHz is)
   d.minPeriod = sample_rate / 400;
   d.maxPeriod = sample_rate / 65;
   d.maxRequired = 2 * d.maxPeriod;
@@ -389,7 +398,7 @@ static Layout layout_for(const SpxPlanDev& d, const spx_stream_job* jobs, int n)
   L.off_states = o;  o += ((sizeof(SpxStreamState) * (size_t)n + 255) & ~(size_t)255);
   L.off_rec = o;     o += ((sizeof(SpxFrameRec) * (size_t)(tf + 1) + 255) & ~(size_t)255);
   L.off_scratch = o; o += ((sizeof(float) * 4 * (size_t)(tf + 1) + 255) & ~(size_t)255);
-  const int TFr = spx_analysis_small_tile_frames();  // the smaller of the two tile sizes: an upper bound on tiles
+  const int TFr = std::min(spx_analysis_small_tile_frames(), d.tile_frames > 0 ? d.tile_frames : spx_analysis_small_tile_frames());  // the smallest tile a call may take: an upper bound on tiles
   L.max_tiles = tf / TFr + n + 1;  // every stream may end with a partial tile
   L.off_order = o;   o += ((sizeof(int) * (size_t)L.max_tiles + 255) & ~(size_t)255);
   L.off_flags = o;   o += ((sizeof(int) * (size_t)L.max_tiles + 255) & ~(size_t)255);
@@ -533,13 +542,13 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // workgroups has no room for the walk workgroup, which then only starts when the analysis drains -- measured at
   // 22.05 kHz, where the small tile fits with 2 KB to spare and the call got slower, not faster)
   const size_t lds_usable = lds_per_cu > 6144 ? lds_per_cu - 6144 : lds_per_cu;
-  if (per_stream_lds + 2 * spx_analysis_lds_bytes(d) > lds_usable && do_a && do_w) {
+  if (per_stream_lds + 2 * spx_analysis_lds_bytes(d) > lds_usable && do_a && do_w && d.tile_frames == spx_analysis_tile_frames()) {
     SpxPlanDev d8 = d;
     d8.tile_frames = spx_analysis_small_tile_frames();
     if (per_stream_lds + 2 * spx_analysis_lds_bytes(d8) <= lds_usable) d.tile_frames = d8.tile_frames;
   }
   static const bool env_small_tile = getenv("SPX_TILE_SMALL") != nullptr;  // tuning: the 8-frame tile whenever concurrent
-  if (env_small_tile && do_a && do_w) d.tile_frames = spx_analysis_small_tile_frames();
+  if (env_small_tile && do_a && do_w && d.tile_frames == spx_analysis_tile_frames()) d.tile_frames = spx_analysis_small_tile_frames();
   if (spx_analysis_lds_bytes(d) < lds_per_cu) {
     const size_t lds_closing = lds_per_cu - spx_analysis_lds_bytes(d) + 1;
     const size_t closed = ((size_t)n * per_stream_lds) / lds_closing + ((size_t)n * per_stream_waves) / 29;

@@ -20,6 +20,7 @@ struct SpxPlanDev {
   int radix[SPX_MAX_STAGES];
   int minPeriod, maxPeriod, maxRequired, skip;  // libsonic limits
   int tile_frames;  // frames per analysis tile (spx_analysis_tile_frames)
+  int dft_waves;    // waves of an analysis workgroup that transform frames (4; fewer for the windows of the highest sample rates)
   float alpha;            // (float)exp(-1.0/100)             (speedy.c:67,287)
   float one_minus_alpha;  // (1 - alpha) evaluated in float   (speedy.c:74)
   const double* tw;    // [W]  (cos, -sin)(2 pi t / W)
@@ -191,6 +192,7 @@ void spx_launch_speed_from_tension(SpxStreamState* state, float tension, float R
                                    hipStream_t st);
 int spx_analysis_tile_frames();
 int spx_analysis_small_tile_frames();
+int spx_analysis_tiny_tile_frames();
 
 // Shared, cached plan per (sample rate, hysteresis mode); owned by the library for the process lifetime.
 struct spx_plan;

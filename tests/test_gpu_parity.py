@@ -487,11 +487,12 @@ def test_many_channels(orc, rate, ch):
         assert np.array_equal(outs[0], ref["out"]), (rate, ch, speed, nl)
 
 
-@pytest.mark.parametrize("rate", [1000, 3999, 4001, 7919, 12345, 24000, 37800, 50000, 60000])
+@pytest.mark.parametrize("rate", [1000, 3999, 4001, 7919, 12345, 24000, 37800, 50000, 60000, 62000, 88200, 96000, 127999])
 def test_unusual_sample_rates(orc, rate):
     """Rates nobody tunes for: below the 4 kHz decimation threshold (skip = 1), prime window lengths (generic and Rader
-    DFT stages), and the range above 49 kHz where the plan falls back to the 8-frame analysis tile.  Mono and stereo,
-    linear and nonlinear, taps included."""
+    DFT stages), the range above 49 kHz where the plan falls back to the 8-frame analysis tile, and (round 3) the range
+    above 61 kHz -- the reference takes any rate, speedy.c:213 -- where two waves, then one, transform 4-frame tiles.
+    Mono and stereo, linear and nonlinear, taps included."""
     from speedy_amd.batch import compress_batch
     from speedy_amd.synth import speech_like
     for ch in (1, 2):
@@ -507,28 +508,21 @@ def test_unusual_sample_rates(orc, rate):
 
 
 def test_sample_rates_outside_the_supported_range_fail_loudly(orc):
-    """Below 1 kHz and from 128 kHz on there is no plan.  Between about 61 kHz and 128 kHz the analysis tile does not fit
-    one CU's LDS: the plan serves linear jobs (the TSM stage alone) -- bit-exact -- and refuses nonlinear ones."""
-    from speedy_amd.batch import Plan, compress_batch
-    from speedy_amd.sonic2 import SonicStream
+    """Below 1 kHz and from 128 kHz on there is no plan (the walk kernels hold at most 256 lags per search).  Everything
+    in between runs in both modes, through the streaming API too (96 kHz here: the one-stream analysis tile of four frames)."""
+    from speedy_amd.batch import Plan
+    from speedy_amd.sonic2 import time_compress
     from speedy_amd.synth import speech_like
     for rate in (999, 128000):
         with pytest.raises(RuntimeError):
             Plan(rate, False)
-    for rate in (62000, 96000):
-        x = speech_like(rate // 2, rate, seed=3)
-        for speed in (2.0, 0.7):
-            ref = orc.compress_sound(x, rate, 1, speed, 0.0, 0.0, False, chunk=x.size, taps=False)["out"]
-            outs, _ = compress_batch([x], rate, 1, speed, 0.0, 0.0, False)
-            assert np.array_equal(outs[0], ref), (rate, speed)
-        with pytest.raises(RuntimeError):
-            compress_batch([x], rate, 1, 2.0, 1.0, 0.0, False)
-        s = SonicStream(rate, 1, False)
-        s.set_speed(2.0)
-        assert s.write_short(x[:5000]) == 1                       # linear
-        s.enable_nonlinear(1.0)
-        assert s.write_short(x[5000:9000]) == 0 and b"sample rate too high" in s.L.speedyHipLastError()
-        s.close()
+    rate = 96000
+    x = speech_like(rate // 2, rate, seed=3)
+    for speed, nl in ((2.0, 1.0), (2.0, 0.0)):
+        ref = orc.compress_sound(x, rate, 1, speed, nl, 0.0, False, chunk=1000 if nl else x.size, taps=False)["out"]
+        for coalesce in (True, False):
+            got = time_compress(x, rate, 1, speed, nl, feedback=0.0, chunk=3000, coalesce=coalesce)
+            assert np.array_equal(got, ref), (speed, nl, coalesce)
 
 
 @pytest.mark.parametrize("rate,n_streams,multi,slow", [(16000, 700, False, False), (22050, 400, True, False),
