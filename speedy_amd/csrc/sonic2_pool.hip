@@ -198,9 +198,9 @@ bool spx_pool_slide_frames(SpxPool* P, sonicStream s, int64_t keep, int64_t hi, 
   if (s->arenaStart >= 0 && keep >= s->dRec.origin) keep -= (keep - s->dRec.origin) & 1;   // moves copy 16-byte units (two records)
   int64_t ncap = 1024;
   while (ncap < 2 * (hi - keep)) ncap *= 2;
-  if (s->arenaStart < 0) P->members.push_back(s);
   const int64_t nstart = arena_alloc(P, ncap);   // (may move the arena: old pointers are refreshed by arena_grow)
   if (nstart < 0) { spx_api_error("frame arena allocation failed"); return false; }
+  if (s->arenaStart < 0) P->members.push_back(s);
   if (s->arenaStart >= 0 && filled > keep && keep >= s->dRec.origin) {
     const int64_t n = std::min(filled, s->dRec.origin + s->dRec.cap) - keep;
     const int64_t from = s->arenaStart + (keep - s->dRec.origin);
@@ -406,7 +406,13 @@ static bool pool_run(SpxPool* P) {
   const size_t o_desc = 2 * b_jobs, o_copies = o_desc + sizeof(PoolDesc) * n;
   const size_t o_moves = (o_copies + sizeof(PoolCopy) * copies.size() + 15) & ~(size_t)15;
   const size_t b_tab = o_moves + sizeof(SpxMove) * moves.size();
-  if (!P->hTab.reserve(b_tab + 64, 0)) { spx_api_error("pinned table allocation failed"); return false; }
+  auto give_up = [&](const char* why) {   // nothing was launched: the waiting handles cannot be served
+    spx_api_error(why);
+    for (auto& it : items) it.s->failed = true;
+    drop_waiting(P);
+    return false;
+  };
+  if (!P->hTab.reserve(b_tab + 64, 0)) return give_up("pinned table allocation failed");
   size_t res_elems = 0;
   int64_t max_slice = 0;
   std::vector<int64_t>& res_off = P->res_off;
@@ -422,7 +428,7 @@ static bool pool_run(SpxPool* P) {
     res_elems += (size_t)((e + 7) & ~(int64_t)7);
   }
   const size_t o_out = (sizeof(PoolResult) * n + 63) & ~(size_t)63;
-  if (!P->hRes.reserve(o_out + res_elems * sizeof(int16_t) + 64, 0)) { spx_api_error("pinned result allocation failed"); return false; }
+  if (!P->hRes.reserve(o_out + res_elems * sizeof(int16_t) + 64, 0)) return give_up("pinned result allocation failed");
   // device workspace: jobsA[n] | jobsW[n] | states[n] | nout[n]
   const size_t w_states = (2 * b_jobs + 63) & ~(size_t)63, w_nout = w_states + ((sizeof(SpxStreamState) * n + 63) & ~(size_t)63);
   const size_t w_total = w_nout + sizeof(int64_t) * n;
@@ -431,7 +437,7 @@ static bool pool_run(SpxPool* P) {
     P->dWs = nullptr;
     size_t cap = P->dWsCap ? P->dWsCap : 65536;
     while (cap < w_total) cap *= 2;
-    if (hipMalloc(reinterpret_cast<void**>(&P->dWs), cap) != hipSuccess) { P->dWsCap = 0; spx_api_error("pool workspace allocation failed"); return false; }
+    if (hipMalloc(reinterpret_cast<void**>(&P->dWs), cap) != hipSuccess) { P->dWs = nullptr; P->dWsCap = 0; (void)hipGetLastError(); return give_up("pool workspace allocation failed"); }
     P->dWsCap = cap;
   }
   SpxStreamDev* hA = reinterpret_cast<SpxStreamDev*>(P->hTab.p);
