@@ -136,8 +136,11 @@ def test_c_batch_example(orc, tmp_path, name, speed, nl, copies, split):
     assert np.array_equal(np.fromfile(out, dtype="<i2"), ref)
 
 
-@pytest.mark.parametrize("seed,handles", [(1, 24), (2, 40), (3, 16)])
-def test_c_api_fuzz_two_execution_paths_agree(seed, handles):
+@pytest.mark.parametrize("seed,handles,env", [(1, 24, {}), (2, 40, {}), (3, 16, {}),
+                                              # a frame arena that must grow several times, a staging area that forces runs
+                                              (4, 48, {"SPX_POOL_FRAMES": "1024"}),
+                                              (5, 32, {"SPX_POOL_FRAMES": "1024", "SPX_POOL_STAGE_BYTES": "30000"})])
+def test_c_api_fuzz_two_execution_paths_agree(seed, handles, env):
     """tools/api_fuzz.c, a plain C99 program over include/sonic2.h: a random schedule of writes (short and float), reads,
     flushes, setters, callbacks switched on mid-stream, sonicInt* calls and destroy / re-create over many handles, run once
     with coalesced execution and once with every handle on its own launch sequences -- every handle delivers the same bytes
@@ -145,6 +148,6 @@ def test_c_api_fuzz_two_execution_paths_agree(seed, handles):
     import subprocess
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "speedy_amd", "csrc"), "apifuzz"])
     r = subprocess.run([os.path.join(ROOT, "speedy_amd", "lib", "api_fuzz"), str(seed), str(handles), "2500"], capture_output=True,
-                       text=True, timeout=900)
+                       text=True, timeout=900, env=dict(os.environ, **env))
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
     assert "0 handles differ" in r.stdout
