@@ -34,8 +34,9 @@ def child(sel):
     from speedy_amd.synth import speech_like
     rate, n, nstreams = 16000, 160000, int(os.environ.get("NSTREAMS", "256"))
     plan = Plan(rate, False)
-    base = [speech_like(n, rate, seed=i) for i in range(8)]
-    b = Batch(plan, [n] * nstreams, 1, 3.5, 1.0, 0.0)
+    base = [speech_like(n, rate, seed=i, channels=int(os.environ.get("CHANNELS", "1"))) for i in range(8)]
+    ch = int(os.environ.get("CHANNELS", "1"))
+    b = Batch(plan, [n] * nstreams, ch, 3.5, 1.0, 0.0)
     b.upload([base[i % 8] for i in range(nstreams)])
     b.run()
     torch.cuda.synchronize()
