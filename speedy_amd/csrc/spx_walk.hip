@@ -971,8 +971,7 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   const int need = P.maxRequired + 2 * P.skip + 2;
   if (c.wcap < 2 * need) c.wcap = 2 * need;
   c.wcap = (c.wcap + 7) & ~7;
-  if (c.nwm != 1 && c.nwm != 2 && c.nwm != 4 && c.nwm != 8) c.nwm = 4;
-  if (c.nwm == 1) c.nwc = 0;
+  if (c.nwm != 2 && c.nwm != 4 && c.nwm != 8) c.nwm = 4;
   while (c.fast_kernel && !spx_walk_fast_supports(P, c.nwm)) {  // the coarse triangle must fit the search lanes
     if (c.nwm < 4) c.nwm = 4; else if (c.nwm < 8) c.nwm = 8; else c.fast_kernel = false;
   }

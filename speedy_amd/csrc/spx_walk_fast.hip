@@ -57,8 +57,8 @@ enum { FCMD_STEP = 1, FCMD_COPY = 2, FCMD_REFILL = 3, FCMD_POLL = 4, FCMD_EXIT =
 #define FCMD_INTS 64  // ints per command slot: field k is written by lane k of the publishing wave
 // at most this many coarse groups / ragged refine tasks per lane (22.05 kHz: 303 groups and 441 tasks over the search lanes):
 // constants of the instantiation -- fewer search waves, more tasks per lane
-static __host__ __device__ constexpr int fcg_of(int nwm) { return nwm == 1 ? 5 : (nwm == 2 ? 3 : 2); }
-static __host__ __device__ constexpr int frg_of(int nwm) { return nwm == 1 ? 7 : (nwm == 2 ? 4 : 2); }
+static __host__ __device__ constexpr int fcg_of(int nwm) { return nwm == 2 ? 3 : 2; }
+static __host__ __device__ constexpr int frg_of(int nwm) { return nwm == 2 ? 4 : 2; }
 
 // Diagnostic build only (-DSPX_STAMPS): per-phase shader-cycle sums of workgroup 0, wave 0.  Never in the product.
 #ifdef SPX_STAMPS
@@ -563,14 +563,6 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       case 2: d = sad_rect<2>(ap, bp, apx, bpx, app, bpp, d); break;
       default: d = sad_rect<3>(ap, bp, apx, bpx, app, bpp, d); break;
     }
-    if constexpr (NWM == 1) {
-      // one chunk per lag (64 lanes, 33 .. 41 lags): it takes every left-over pair of the rectangle, not just the first
-#pragma unroll
-      for (int e = 1; e < 3; e++) {
-        const unsigned* bq = (e < rho) ? bp + pOff + e : app + e;
-        d = __builtin_amdgcn_sad_u16(app[e], *bq, d);
-      }
-    }
     atomicAdd(&sums[myT], tOk ? d : 0u);
     FSTAMP(13);
 #pragma unroll
@@ -989,7 +981,7 @@ bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm) {
   for (int t = 0; t < 8 * skip + 1; t++) ragged += (t + 2) >> 1;
   // the refine search's common rectangle: at least one chunk per lag, and the multiply-shift division by NCH exact
   const int nlag = 8 * skip + 1, nch = (64 * nwm) / nlag;
-  if (nwm < 2) return false;   // one search wave: instantiated for experiments (SPX_WALK_NWM=1 is refused here), results not yet right
+  if (nwm < 2) return false;   // (one search wave per stream was tried in round 3: no faster than two; not instantiated)
   if (nch < 3) return false;   // up to three left-over pairs of the rectangle, one per chunk
   const int chM = (65536 + nch - 1) / nch;
   for (int c0 = 0; c0 <= P.maxPeriod / 2 + 1; c0++)
@@ -1006,7 +998,6 @@ int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int max
 #define SPX_FN_R(M, C) (maxC > 1 ? SPX_FN_RM(M, C, 1) : SPX_FN_RM(M, C, 0))
   if (nwm == 8) fn = SPX_FN_R(8, 4);
   else if (nwm == 2) fn = nwc >= 1 ? SPX_FN_R(2, 1) : SPX_FN_R(2, 0);
-  else if (nwm == 1) fn = SPX_FN_R(1, 0);
   else fn = nwc >= 4 ? SPX_FN_R(4, 4) : nwc >= 2 ? SPX_FN_R(4, 2) : nwc >= 1 ? SPX_FN_R(4, 1) : SPX_FN_R(4, 0);
 #undef SPX_FN_R
 #undef SPX_FN_RM
@@ -1037,8 +1028,6 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
 #endif
   if (nwm == 8) {
     SPX_LAUNCH_FAST(8, 4);
-  } else if (nwm == 1) {
-    SPX_LAUNCH_FAST(1, 0);   // throughput mode: one wave per stream, no output waves, many streams per CU
   } else if (nwm == 2) {
     if (nwc >= 1) SPX_LAUNCH_FAST(2, 1);
     else SPX_LAUNCH_FAST(2, 0);
