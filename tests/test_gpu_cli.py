@@ -151,3 +151,41 @@ def test_c_api_fuzz_two_execution_paths_agree(seed, handles, env):
                        text=True, timeout=900, env=dict(os.environ, **env))
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
     assert "0 handles differ" in r.stdout
+
+
+@pytest.mark.parametrize("speed,nonlinear,match", [(3.5, 1.0, False), (2.0, 0.0, False), (3.0, 0.0, True)])
+def test_reference_cli_binary_runs_on_this_library(orc, tmp_path, speed, nonlinear, match):
+    """oracle/_ref/speedy_wave_ref is the REFERENCE's own speedy_wave.cc -- compiled where it lies in the build container,
+    unmodified, against include/compat + its own headers (oracle/Makefile `_ref`) -- linked with libspeedy_hip.so.  Run on
+    tapestry.wav as the reference's header comment runs it (speedy_wave.cc:50-66); the WAV it writes must hold exactly the
+    oracle's samples, and the tension and speed files its callbacks write the oracle's values.  --match_nonlinear is the
+    two-pass use (speedy_wave.cc:424-427): a nonlinear pass without callbacks or output (this library's coalesced path),
+    whose achieved speed-up then drives a linear pass.  Skipped where the binary was not built."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "speedy_wave_ref")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/speedy_wave_ref not built (needs /root/reference at build time)")
+    from util import read_wav
+    x, rate, ch = read_wav("tapestry.wav")
+    out = tmp_path / "out.wav"
+    ten, spd = tmp_path / "tension.txt", tmp_path / "speed.txt"
+    cmd = [exe, "--input", os.path.join(ROOT, "tests", "golden", "tapestry.wav"), "--output", str(out), "--speed", str(speed),
+           "--nonlinear", str(nonlinear), "--tension_file", str(ten), "--speed_file", str(spd)]
+    if match:
+        cmd.append("--match_nonlinear")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    if match:
+        first = orc.compress_sound(x, rate, ch, speed, 1.0, 0.0, False, chunk=1000, taps=False)
+        assert "output %d frames with nonlinear=1." % first["out"].size in r.stdout, r.stdout[-600:]
+        speed = float(x.size) / first["out"].size        # speedy_wave.cc:240-241, in double
+    ref = orc.compress_sound(x, rate, ch, speed, nonlinear, 0.0, False, chunk=1000, taps=(nonlinear != 0))   # the CLI's defaults
+    raw = open(out, "rb").read()
+    got = np.frombuffer(raw[44:], np.int16)
+    assert got.size == ref["out"].size and np.array_equal(got, ref["out"]), (got.size, ref["out"].size)
+    assert "Compress_sound read %d frames, and output %d frames" % (x.size, ref["out"].size) in r.stdout
+    if nonlinear:
+        t = np.array([float(v) for v in open(ten).read().split()], np.float32)
+        s_ = np.array([float(v) for v in open(spd).read().split()], np.float32)
+        assert t.size == ref["tension"].size and t.size > 250
+        assert np.allclose(t, ref["tension"], rtol=1e-5, atol=1e-6)         # "%g" keeps 6 significant digits
+        assert np.allclose(s_, ref["speed"], rtol=1e-5, atol=1e-6)
