@@ -42,6 +42,15 @@
 // read alternately from a signal and from its shifted copy, so the copies' bank offset decides the conflicts.
 #ifndef SPX_PAD_MONO
 #define SPX_PAD_MONO 48  // 16 kHz: the refine rectangle's reads become conflict-free (model: 211 -> 145 LDS cycles per step; walk -0.6 %)
+// Branch hints for the step loop: the compiler lays the expected side out as the fall-through (a taken branch costs a wave
+// ~20 cycles, tools/ubench/issue_costs.hip).  -DSPX_NO_HINTS builds the loop as the compiler would place it by itself.
+#ifdef SPX_NO_HINTS
+#define SPX_LIKELY(x) (x)
+#define SPX_UNLIKELY(x) (x)
+#else
+#define SPX_LIKELY(x) __builtin_expect(!!(x), 1)
+#define SPX_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#endif
 #endif
 #ifndef SPX_PAD_PL
 #define SPX_PAD_PL 0
@@ -553,7 +562,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     const unsigned* app = ap + pOff;
     const unsigned* bpp = (myC < rho) ? bp + pOff : app;
     unsigned d = 0u;
-    while (NGL > 3) {  // long periods at the higher rates only
+    while (SPX_UNLIKELY(NGL > 3)) {  // long periods at the higher rates only
       d = sad_flight_n<4, false>(ap, bp, 0, d);
       ap += 16; bp += 16; NGL -= 4;
     }
@@ -612,6 +621,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   const int Ttot = S.n_frames, F = P.F;
   const float Rg = S.speed, nl = S.nonlinear;
   const bool linear = nl == 0.0f;
+  const bool hotStream = Rg >= 2.0f;  // most of its events run at speed >= 2: see the hot loop
   const bool do_flush = (S.flags & SPX_F_FLUSH) != 0;
   const int minC = minP / skip, nC = maxP / skip - minC + 1;
   const bool needResolve = (long)maxP * maxP >= 65536;
@@ -717,7 +727,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   auto find_period = [&](pos_t pos, bool ge2, float sm1, float twom, int& n_ret, int& rem_ret)
                          __attribute__((always_inline)) -> int {
     FSTAMP(1);
-    if (!(wbase >= 0 && pos >= wbase && pos + need <= wbase + LY.wcap)) {
+    if (SPX_UNLIKELY(!(wbase >= 0 && pos >= wbase && pos + need <= wbase + LY.wcap))) {
       const pos_t nb = pos & ~7;
       FAST_PUBLISH(FCMD_REFILL, 0, 0, 0, nb);
       if (NWC > 0) fast_sync();
@@ -816,7 +826,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     pos_t pos = base;
     bool failed = false;
     do {
-      if (remaining > 0) {
+      if (SPX_UNLIKELY(remaining > 0)) {
         int n = remaining;
         if (n > maxRequired) n = maxRequired;
         if (out_n + n > X.out_cap) overflow = 1;
@@ -830,13 +840,22 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         const int period = find_period(pos, ge2, sm1, twom, n, rem);
         if (!ge2) remaining = rem;
         if (out_n + n > X.out_cap) overflow = 1;
-        if (n == 0) { failed = true; break; }
+#ifdef SPX_FAILED_BRANCH
+        if (SPX_UNLIKELY(n == 0)) { failed = true; break; }
         xf_n = n; xf_down = (int)(pos - wbase); xf_period = period; xf_out = out_n;
         out_n += n;
         pos += period + n;
+#else
+        // a failed step (n == 0) is no branch of its own: it hands over no cross-fade (xf_n = 0), leaves pos where it is and ends
+        // the loop through its condition
+        failed = n == 0;
+        xf_n = n; xf_down = (int)(pos - wbase); xf_period = period; xf_out = out_n;
+        out_n += n;
+        pos += failed ? 0 : period + n;
+#endif
         FSTAMP(10);
       }
-    } while (pos + maxRequired <= availE);
+    } while (!failed && pos + maxRequired <= availE);
     if (!failed) base = pos;
   };
 
@@ -919,7 +938,43 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       const int perEvent = flushBlk ? 2 * maxRequired : B;
       const pos_t availLane = (linear && !flushBlk) ? n_tsm : availBlk + (lane + 1) * perEvent;  // frames handed over after event `lane`
       int i = 0;
-      while (i < nIn) {
+#ifndef SPX_NO_HOT_LOOP
+      for (;;) {
+        // The hot loop: events at speed >= 2 with nothing left to copy through -- nearly every event of a stream that is sped
+        // up by 2 or more -- run here, in a loop of their own whose only loop-carried state is what such a step changes;
+        // anything else (a pass-through at unity speed, 1 < speed < 2, frames still to be copied) leaves it for ONE pass of
+        // the general code below.  Same arithmetic: run_event with ge2 a constant.
+        if (hotStream) {
+          for (;;) {
+            const unsigned long long runnable = __builtin_amdgcn_ballot_w64(
+                lane >= i && lane < nIn && (unityLane || availLane - base >= maxRequired));
+            if (SPX_UNLIKELY(runnable == 0)) break;
+            const int e = __builtin_ctzll(runnable);
+            const float speed = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, spv), e));
+            if (SPX_UNLIKELY(((unityMask >> e) & 1) != 0 || !(speed >= 2.0f) || remaining > 0)) break;
+            i = e;
+            const pos_t availE = (linear && !flushBlk) ? n_tsm : availBlk + (i + 1) * perEvent;
+            FSTAMP(0);
+            const float sm1 = speed - 1.0f;
+            pos_t pos = base;
+            bool failed;
+            do {
+              int n, rem;
+              const int period = find_period(pos, true, sm1, 0.0f, n, rem);
+              if (out_n + n > X.out_cap) overflow = 1;
+              failed = n == 0;
+              xf_n = n; xf_down = (int)(pos - wbase); xf_period = period; xf_out = out_n;
+              out_n += n;
+              pos += failed ? 0 : period + n;
+              FSTAMP(10);
+            } while (!failed && pos + maxRequired <= availE);
+            if (!failed) base = pos;
+            FSTAMP(11);
+            i++;
+          }
+        }
+        // the general code: one event
+        if (i >= nIn) break;
         const unsigned long long runnable = __builtin_amdgcn_ballot_w64(
             lane >= i && lane < nIn && (unityLane || availLane - base >= maxRequired));
         if (runnable == 0) break;
@@ -942,6 +997,31 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         FSTAMP(11);
         i++;
       }
+#else
+      while (i < nIn) {
+        const unsigned long long runnable = __builtin_amdgcn_ballot_w64(
+            lane >= i && lane < nIn && (unityLane || availLane - base >= maxRequired));
+        if (SPX_UNLIKELY(runnable == 0)) break;
+        i = __builtin_ctzll(runnable);
+        const pos_t availE = (linear && !flushBlk) ? n_tsm : availBlk + (i + 1) * perEvent;
+        FSTAMP(0);
+        if (SPX_UNLIKELY((unityMask >> i) & 1)) {
+          const pos_t n = availE - base;
+          if (n > 0) {
+            if (out_n + n > X.out_cap) overflow = 1;
+            FAST_PUBLISH(FCMD_COPY, n, base, out_n, 0);
+            if (NWC > 0) fast_sync();
+            out_n += n;
+          }
+          base = availE;
+        } else {
+          const float speed = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, spv), i));
+          run_event(speed, availE);
+        }
+        FSTAMP(11);
+        i++;
+      }
+#endif
       avail = (linear && !flushBlk) ? n_tsm : availBlk + nIn * perEvent;
       if (flushBlk) {
         if (out_n > expected) out_n = expected;

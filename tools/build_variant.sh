@@ -1,0 +1,15 @@
+#!/bin/bash
+# Build container: a variant of the library with extra compiler flags for the hot code object only, as
+# speedy_amd/lib/ab/libspeedy_hip_<NAME>.so (A/B on the GPU box: SPEEDY_HIP_LIB=... python bench.py, tools/ab_variants.sh).
+#   bash tools/build_variant.sh NAME "-DSPX_WALK_PAD=3 -DFOO"      (several can run in parallel)
+set -e
+NAME=$1; EXTRA=$2
+cd "$(dirname "$0")/../speedy_amd/csrc"
+mkdir -p ../lib/ab ../lib/obj
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function"
+/opt/rocm/bin/hipcc $FLAGS $EXTRA -c spx_hot.hip -o ../lib/obj/spx_hot_$NAME.o
+OBJ=""
+for o in spx_walk spx_engine sonic2_api speedy_api spx_rate sonic2_pool wave_compat; do OBJ="$OBJ ../lib/obj/$o.o"; done
+/opt/rocm/bin/hipcc $FLAGS -shared -o ../lib/ab/libspeedy_hip_$NAME.so ../lib/obj/spx_hot_$NAME.o $OBJ
+rm -f ../lib/obj/spx_hot_$NAME.o
+echo "built speedy_amd/lib/ab/libspeedy_hip_$NAME.so"
