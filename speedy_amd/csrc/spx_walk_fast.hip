@@ -31,6 +31,7 @@
 //   * as in spx_walk.hip: LDS sliding window of biased u16 samples kept twice (shifted by one) so that any lag reads
 //     aligned pairs for v_sad_u16, decimated planes built at refill time, partial sums met with ds_add_u32, LDS-only
 //     barriers (output stores are never waited for).
+#include <type_traits>
 #include <stdlib.h>
 
 #include "spx_walk_common.h"
@@ -562,6 +563,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     const unsigned* app = ap + pOff;
     const unsigned* bpp = (myC < rho) ? bp + pOff : app;
     unsigned d = 0u;
+#ifdef SPX_RECT_OLD
     while (SPX_UNLIKELY(NGL > 3)) {  // long periods at the higher rates only
       d = sad_flight_n<4, false>(ap, bp, 0, d);
       ap += 16; bp += 16; NGL -= 4;
@@ -572,6 +574,27 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       case 2: d = sad_rect<2>(ap, bp, apx, bpx, app, bpp, d); break;
       default: d = sad_rect<3>(ap, bp, apx, bpx, app, bpp, d); break;
     }
+#else
+    // the left-over group and pair are the same code whatever the group count: their loads go first, the dispatch on the
+    // group count holds whole groups only, their SADs come last (one flight of loads all the same: nothing waits in between)
+    unsigned xa[4], xb[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { xa[k] = apx[k]; xb[k] = bpx[k]; }
+    const unsigned pa = *app, pb = *bpp;
+    while (SPX_UNLIKELY(NGL > 3)) {  // long periods at the higher rates only
+      d = sad_flight_n<4, false>(ap, bp, 0, d);
+      ap += 16; bp += 16; NGL -= 4;
+    }
+    switch (NGL) {
+      case 1: d = sad_flight_n<1, false>(ap, bp, 0, d); break;
+      case 2: d = sad_flight_n<2, false>(ap, bp, 0, d); break;
+      case 3: d = sad_flight_n<3, false>(ap, bp, 0, d); break;
+      default: break;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) d = __builtin_amdgcn_sad_u16(xa[k], xb[k], d);
+    d = __builtin_amdgcn_sad_u16(pa, pb, d);
+#endif
     atomicAdd(&sums[myT], tOk ? d : 0u);
     FSTAMP(13);
 #pragma unroll
@@ -724,8 +747,27 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
 
   // findPitchPeriod at absolute position pos; every search wave computes the same result.  Also returns what the step
   // then does: n frames of cross-fade and, for 1 < speed < 2, `rem` frames copied through afterwards.
-  auto find_period = [&](pos_t pos, bool ge2, float sm1, float twom, int& n_ret, int& rem_ret)
+  // The operands of the coarse search at window offset o (each lane its constant groups of pair slots): loads only.
+  auto coarse_loads = [&](int o, unsigned (&a)[FCG][4], unsigned (&b)[FCG][4]) __attribute__((always_inline)) {
+    const int oD = (o * skipM) >> 16;
+    const int r = o - oD * skip;
+    const int plr = LY.off_pl + r * LY.plStrideB;
+#pragma unroll
+    for (int g = 0; g < FCG; g++) {
+      if (g < nGC) {
+        const unsigned* ap = reinterpret_cast<const unsigned*>(lds + pair_addr(plr, dPl, oD + cOffA[g]));
+        const unsigned* bp = reinterpret_cast<const unsigned*>(lds + pair_addr(plr, dPl, oD + cOffB[g]));
+#pragma unroll
+        for (int k = 0; k < 4; k++) { a[g][k] = ap[k]; b[g][k] = bp[k]; }
+      }
+    }
+  };
+  // (Round 3 tried issuing the NEXT step's coarse loads from the end of a step, in front of the bookkeeping between two steps:
+  // 3 % slower at every code placement, profiles/r03/r03y_pf_pads.txt -- the round trip was not what the chain waited for.)
+
+  auto find_period = [&](pos_t pos, bool ge2, float sm1, float twom, int& n_ret, int& rem_ret, auto hot)
                          __attribute__((always_inline)) -> int {
+    (void)hot;  // std::true_type from the hot loop: its copy of this code has ge2 a constant
     FSTAMP(1);
     if (SPX_UNLIKELY(!(wbase >= 0 && pos >= wbase && pos + need <= wbase + LY.wcap))) {
       const pos_t nb = pos & ~7;
@@ -736,23 +778,12 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     }
     FSTAMP(2);
     const int o = (int)(pos - wbase);
-    FAST_PUBLISH(FCMD_STEP, 0, 0, 0, 0);  // the previous step's cross-fade rides on this step's command
     // ---- coarse search on the decimated signal: each lane its constant group(s) of pair slots ----
     int bestC;
     {
-      const int oD = (o * skipM) >> 16;
-      const int r = o - oD * skip;
-      const int plr = LY.off_pl + r * LY.plStrideB;
       unsigned a[FCG][4], b[FCG][4];
-#pragma unroll
-      for (int g = 0; g < FCG; g++) {
-        if (g < nGC) {
-          const unsigned* ap = reinterpret_cast<const unsigned*>(lds + pair_addr(plr, dPl, oD + cOffA[g]));
-          const unsigned* bp = reinterpret_cast<const unsigned*>(lds + pair_addr(plr, dPl, oD + cOffB[g]));
-#pragma unroll
-          for (int k = 0; k < 4; k++) { a[g][k] = ap[k]; b[g][k] = bp[k]; }
-        }
-      }
+      coarse_loads(o, a, b);
+      FAST_PUBLISH(FCMD_STEP, 0, 0, 0, 0);  // the previous step's cross-fade rides on this step's command; behind the loads
 #pragma unroll
       for (int g = 0; g < FCG; g++) {
         if (g < nGC) {
@@ -790,6 +821,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         nLane = ge2 ? (int)(fp / sm1) : pc;
         remLane = ge2 ? 0 : (int)(fp * twom / sm1);
       }
+      asm volatile("" ::"v"(nLane), "v"(remLane));  // here, while the sums are on their way -- not behind the barrier
       FSTAMP(6);
       fast_sync();  // the step's one workgroup barrier: refine sums complete, the output waves done with the command
       FSTAMP(7);
@@ -837,7 +869,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         pos += n;
       } else {
         int n, rem;
-        const int period = find_period(pos, ge2, sm1, twom, n, rem);
+        const int period = find_period(pos, ge2, sm1, twom, n, rem, std::false_type());
         if (!ge2) remaining = rem;
         if (out_n + n > X.out_cap) overflow = 1;
 #ifdef SPX_FAILED_BRANCH
@@ -960,7 +992,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
             bool failed;
             do {
               int n, rem;
-              const int period = find_period(pos, true, sm1, 0.0f, n, rem);
+              const int period = find_period(pos, true, sm1, 0.0f, n, rem, std::true_type());
               if (out_n + n > X.out_cap) overflow = 1;
               failed = n == 0;
               xf_n = n; xf_down = (int)(pos - wbase); xf_period = period; xf_out = out_n;
