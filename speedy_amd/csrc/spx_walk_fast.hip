@@ -218,9 +218,67 @@ __device__ __forceinline__ void fast_outputs(const FastOut& X, int t0, int xf_n,
 // plane r (r < skip) holds S[m*skip + r], S[i] = truncated mean of window samples i .. i+skip-1, so the decimated
 // search signal of a step at window offset o is plane (o % skip) from element o / skip on, contiguous.  All NT threads
 // of the workgroup; three LDS barriers.
+// The refill of a MONO window at skip 4 (16 kHz) whose frames are all real input, 16-byte aligned in HBM: every thread
+// takes eight window frames (and the eight behind them) as two 16-byte loads and writes, from registers, its share of all
+// four images -- the window and its shifted copy as one ds_write_b128 each, the decimated planes (element m of plane r =
+// trunc((x[4m+r] + .. + x[4m+r+3]) / 4), m = 2t, 2t+1 and, for the shifted copies, 2t+1, 2t+2) as eight ds_write_b32 --
+// in ONE pass between two barriers.  (The general code below: sixteen 2-byte LDS writes per thread, a barrier, then the
+// planes from fourteen 2-byte LDS reads and sixteen 2-byte writes per thread: 5 700 cycles per refill, 5 % of a 16 kHz
+// chain; the walk kernel of the bench batch 2.10 -> 2.06 ms with this one, profiles/r03/r03z_refill.txt.)  Same LDS contents wherever a search may read; entries the general code leaves unwritten
+// (planes r > 0 of the last element) get their true values.
+template <int NT>
+__device__ __forceinline__ void fast_refill_mono4(const FastOut& X, const FastLds& LY, pos_t nb) {
+  const int wcap = LY.wcap;
+  const int16_t* __restrict__ src = X.in + nb;
+  const int plStrideB = LY.plStrideB;
+  for (int t = threadIdx.x; 8 * t < wcap; t += NT) {
+    const uint4 q0 = *reinterpret_cast<const uint4*>(src + 8 * t);
+    const uint4 q1 = *reinterpret_cast<const uint4*>(src + 8 * t + 8);
+    const unsigned w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    // the window (u16 biased by 32768: the sign bits flipped) and its copy shifted by one frame
+    uint4 m0, m1;
+    m0.x = w[0] ^ 0x80008000u; m0.y = w[1] ^ 0x80008000u; m0.z = w[2] ^ 0x80008000u; m0.w = w[3] ^ 0x80008000u;
+    m1.x = __builtin_amdgcn_alignbit(w[1], w[0], 16) ^ 0x80008000u;
+    m1.y = __builtin_amdgcn_alignbit(w[2], w[1], 16) ^ 0x80008000u;
+    m1.z = __builtin_amdgcn_alignbit(w[3], w[2], 16) ^ 0x80008000u;
+    m1.w = __builtin_amdgcn_alignbit(w[4], w[3], 16) ^ 0x80008000u;
+    *reinterpret_cast<uint4*>(X.lds + LY.off_mono + 16 * t) = m0;
+    *reinterpret_cast<uint4*>(X.lds + LY.off_monoB + 16 * t) = m1;
+    // frames 8t .. 8t+14 as ints, the twelve sums of four consecutive ones
+    int x[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { x[2 * i] = (int)(short)(w[i] & 0xffffu); x[2 * i + 1] = (int)w[i] >> 16; }
+    int P[12];
+    P[0] = x[0] + x[1] + x[2] + x[3];
+#pragma unroll
+    for (int i = 1; i < 12; i++) P[i] = P[i - 1] + x[i + 3] - x[i - 1];
+    unsigned u[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      const int v = P[i];
+      const int mag = v < 0 ? -v : v;
+      const int qm = mag >> 2;                       // = mulhi(mag, 2^30): the truncating division by skip = 4
+      u[i] = (unsigned)((v < 0 ? -qm : qm) + 32768) & 0xffffu;
+    }
+    // plane r: elements m = 2t (P[r]), 2t+1 (P[4+r]), 2t+2 (P[8+r]); the shifted copy holds element m at index m - 1
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      *reinterpret_cast<unsigned*>(X.lds + LY.off_pl + r * plStrideB + 4 * t) = u[r] | (u[4 + r] << 16);
+      *reinterpret_cast<unsigned*>(X.lds + LY.off_plB + r * plStrideB + 4 * t) = u[4 + r] | (u[8 + r] << 16);
+    }
+  }
+  fast_sync();
+}
+
 template <int NT, bool MC>
 __device__ __forceinline__ void fast_refill(const FastOut& X, const FastLds& LY, int skip, pos_t nb, pos_t limit) {
   fast_sync();  // everyone is done reading the old window
+#ifndef SPX_NO_FAST_REFILL
+  if ((!MC || X.C == 1) && skip == 4 && limit - nb >= LY.wcap + 16 && ((size_t)(X.in + nb) & 15) == 0) {
+    fast_refill_mono4<NT>(X, LY, nb);
+    return;
+  }
+#endif
   const int wcap = LY.wcap;
   const int C = MC ? X.C : 1;
   unsigned short* monoH = reinterpret_cast<unsigned short*>(X.lds + LY.off_mono);
@@ -770,11 +828,13 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     (void)hot;  // std::true_type from the hot loop: its copy of this code has ge2 a constant
     FSTAMP(1);
     if (SPX_UNLIKELY(!(wbase >= 0 && pos >= wbase && pos + need <= wbase + LY.wcap))) {
+      FSTAMP(16);
       const pos_t nb = pos & ~7;
       FAST_PUBLISH(FCMD_REFILL, 0, 0, 0, nb);
       if (NWC > 0) fast_sync();
       fast_refill<NT, MCH>(X, LY, skip, nb, limit);
       wbase = nb;
+      FSTAMP(15);
     }
     FSTAMP(2);
     const int o = (int)(pos - wbase);

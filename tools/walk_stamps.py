@@ -21,10 +21,10 @@ if KIND == "fast":
              6: "refine: candidate n / rem divisions", 7: "barrier B wait", 8: "refine sums read + select",
              9: "previous-period rule", 10: "n, state update", 11: "after the steps of an event",
              12: "refine: setup + ragged loads issued", 13: "refine: common share summed + added",
-             14: "refine: ragged tasks summed + added"}
+             14: "refine: ragged tasks summed + added", 15: "window refill (whole)", 16: "window check before a refill"}
 FN = "spx_debug_fstamps" if KIND == "fast" else "spx_debug_stamps"
 PREFIX = "libspeedy_hip_fstamps_%d.so" if KIND == "fast" else "libspeedy_hip_stamps_%d.so"
-NSEL = 15 if KIND == "fast" else 15
+NSEL = 17 if KIND == "fast" else 15
 
 
 def child(sel):
@@ -56,7 +56,7 @@ if len(sys.argv) > 1:
     sys.exit(0)
 
 rows = []
-for sel in range(NSEL):
+for sel in [int(v) for v in os.environ["STAMP_SELS"].split()] if os.environ.get("STAMP_SELS") else range(NSEL):
     env = dict(os.environ, SPX_SERIAL="1",
                SPEEDY_HIP_LIB=os.path.join(ROOT, "speedy_amd", "lib", "stamps", PREFIX % sel))
     out = subprocess.run([sys.executable, os.path.abspath(__file__), str(sel)], env=env, capture_output=True, text=True)
