@@ -218,53 +218,77 @@ __device__ __forceinline__ void fast_outputs(const FastOut& X, int t0, int xf_n,
 // plane r (r < skip) holds S[m*skip + r], S[i] = truncated mean of window samples i .. i+skip-1, so the decimated
 // search signal of a step at window offset o is plane (o % skip) from element o / skip on, contiguous.  All NT threads
 // of the workgroup; three LDS barriers.
-// The refill of a MONO window at skip 4 (16 kHz) whose frames are all real input, 16-byte aligned in HBM: every thread
-// takes eight window frames (and the eight behind them) as two 16-byte loads and writes, from registers, its share of all
-// four images -- the window and its shifted copy as one ds_write_b128 each, the decimated planes (element m of plane r =
-// trunc((x[4m+r] + .. + x[4m+r+3]) / 4), m = 2t, 2t+1 and, for the shifted copies, 2t+1, 2t+2) as eight ds_write_b32 --
-// in ONE pass between two barriers.  (The general code below: sixteen 2-byte LDS writes per thread, a barrier, then the
-// planes from fourteen 2-byte LDS reads and sixteen 2-byte writes per thread: 5 700 cycles per refill, 5 % of a 16 kHz
-// chain; the walk kernel of the bench batch 2.10 -> 2.06 ms with this one, profiles/r03/r03z_refill.txt.)  Same LDS contents wherever a search may read; entries the general code leaves unwritten
-// (planes r > 0 of the last element) get their true values.
-template <int NT>
-__device__ __forceinline__ void fast_refill_mono4(const FastOut& X, const FastLds& LY, pos_t nb) {
+// The refill of a mono or stereo window at skip 4 or 5 (16 / 22.05 kHz) whose frames are all real input, 4-byte aligned in
+// HBM, in ONE pass between two barriers: thread t takes the 2*skip window frames from 2*skip*t on and the 2*skip - 1 behind
+// them as dword loads (all in flight at once) and writes, from registers, its share of all four images -- the window and its
+// copy shifted by one frame (skip pairs each: one ds_write_b128 each at skip 4), and elements m = 2t, 2t+1 (shifted copies:
+// 2t+1, 2t+2) of every decimated plane as one ds_write_b32 each.  The arithmetic of the general code below (window = the
+// frame, stereo: trunc((L + R) / 2); plane element = trunc(sum of skip*C raw samples / (skip*C))), and the same LDS contents
+// wherever a search may read; the few entries past the window that the general code leaves unwritten get their true values.
+// (General code, mono: sixteen 2-byte LDS writes per thread, a barrier, then the planes from fourteen 2-byte LDS reads and
+// sixteen 2-byte writes per thread -- 5 700 cycles per refill, 5 % of a 16 kHz chain; the walk kernel of the bench batch
+// 2.10 -> 2.06 ms with this pass, profiles/r03/r03z_refill.txt.)
+template <int NT, int SKIP, bool STEREO>
+__device__ __forceinline__ void fast_refill_onepass(const FastOut& X, const FastLds& LY, pos_t nb) {
+  constexpr int NF = 4 * SKIP - 1;                    // frames a thread needs
+  constexpr int ND = STEREO ? NF : (NF + 1) / 2;      // dwords holding them
+  constexpr int DIV = SKIP * (STEREO ? 2 : 1);
+  constexpr unsigned M = (unsigned)((0x100000000ull + DIV - 1) / DIV);
   const int wcap = LY.wcap;
-  const int16_t* __restrict__ src = X.in + nb;
+  const unsigned* __restrict__ src = reinterpret_cast<const unsigned*>(X.in + (size_t)nb * (STEREO ? 2 : 1));
   const int plStrideB = LY.plStrideB;
-  for (int t = threadIdx.x; 8 * t < wcap; t += NT) {
-    const uint4 q0 = *reinterpret_cast<const uint4*>(src + 8 * t);
-    const uint4 q1 = *reinterpret_cast<const uint4*>(src + 8 * t + 8);
-    const unsigned w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-    // the window (u16 biased by 32768: the sign bits flipped) and its copy shifted by one frame
-    uint4 m0, m1;
-    m0.x = w[0] ^ 0x80008000u; m0.y = w[1] ^ 0x80008000u; m0.z = w[2] ^ 0x80008000u; m0.w = w[3] ^ 0x80008000u;
-    m1.x = __builtin_amdgcn_alignbit(w[1], w[0], 16) ^ 0x80008000u;
-    m1.y = __builtin_amdgcn_alignbit(w[2], w[1], 16) ^ 0x80008000u;
-    m1.z = __builtin_amdgcn_alignbit(w[3], w[2], 16) ^ 0x80008000u;
-    m1.w = __builtin_amdgcn_alignbit(w[4], w[3], 16) ^ 0x80008000u;
-    *reinterpret_cast<uint4*>(X.lds + LY.off_mono + 16 * t) = m0;
-    *reinterpret_cast<uint4*>(X.lds + LY.off_monoB + 16 * t) = m1;
-    // frames 8t .. 8t+14 as ints, the twelve sums of four consecutive ones
-    int x[16];
+  for (int t = threadIdx.x; 2 * SKIP * t < wcap; t += NT) {
+    unsigned w[ND];
 #pragma unroll
-    for (int i = 0; i < 8; i++) { x[2 * i] = (int)(short)(w[i] & 0xffffu); x[2 * i + 1] = (int)w[i] >> 16; }
-    int P[12];
-    P[0] = x[0] + x[1] + x[2] + x[3];
+    for (int i = 0; i < ND; i++) w[i] = src[(STEREO ? 2 * SKIP : SKIP) * t + i];
+    int fs[NF];      // raw channel sums per frame
 #pragma unroll
-    for (int i = 1; i < 12; i++) P[i] = P[i - 1] + x[i + 3] - x[i - 1];
-    unsigned u[12];
+    for (int i = 0; i < NF; i++) {
+      if (STEREO) fs[i] = (int)(short)(w[i] & 0xffffu) + ((int)w[i] >> 16);
+      else fs[i] = (i & 1) ? ((int)w[i >> 1] >> 16) : (int)(short)(w[i >> 1] & 0xffffu);
+    }
+    // the window (u16 biased by 32768) and its copy shifted by one frame: SKIP pairs each
+    unsigned m0[SKIP], m1[SKIP];
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
+    for (int k = 0; k < SKIP; k++) {
+      if (STEREO) {
+        const unsigned a = (unsigned)(fs[2 * k] / 2 + 32768) & 0xffffu, b = (unsigned)(fs[2 * k + 1] / 2 + 32768) & 0xffffu,
+                       c = (unsigned)(fs[2 * k + 2] / 2 + 32768) & 0xffffu;
+        m0[k] = a | (b << 16);
+        m1[k] = b | (c << 16);
+      } else {
+        m0[k] = w[k] ^ 0x80008000u;
+        m1[k] = __builtin_amdgcn_alignbit(w[k + 1], w[k], 16) ^ 0x80008000u;
+      }
+    }
+    unsigned* d0 = reinterpret_cast<unsigned*>(X.lds + LY.off_mono + 4 * SKIP * t);
+    unsigned* d1 = reinterpret_cast<unsigned*>(X.lds + LY.off_monoB + 4 * SKIP * t);
+    if (SKIP == 4) {
+      *reinterpret_cast<uint4*>(d0) = make_uint4(m0[0], m0[1], m0[2], m0[3]);
+      *reinterpret_cast<uint4*>(d1) = make_uint4(m1[0], m1[1], m1[2], m1[3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < SKIP; k++) { d0[k] = m0[k]; d1[k] = m1[k]; }
+    }
+    // the 3*SKIP sums of SKIP consecutive frames: element m = 2t + a of plane r is P[a*SKIP + r]
+    int P[3 * SKIP];
+    P[0] = 0;
+#pragma unroll
+    for (int j = 0; j < SKIP; j++) P[0] += fs[j];
+#pragma unroll
+    for (int i = 1; i < 3 * SKIP; i++) P[i] = P[i - 1] + fs[i + SKIP - 1] - fs[i - 1];
+    unsigned u[3 * SKIP];
+#pragma unroll
+    for (int i = 0; i < 3 * SKIP; i++) {
       const int v = P[i];
-      const int mag = v < 0 ? -v : v;
-      const int qm = mag >> 2;                       // = mulhi(mag, 2^30): the truncating division by skip = 4
+      const unsigned mag = (unsigned)(v < 0 ? -v : v);
+      const int qm = (int)__umulhi(mag, M);              // the truncating division by skip * C (exact: |v| < 2^21)
       u[i] = (unsigned)((v < 0 ? -qm : qm) + 32768) & 0xffffu;
     }
-    // plane r: elements m = 2t (P[r]), 2t+1 (P[4+r]), 2t+2 (P[8+r]); the shifted copy holds element m at index m - 1
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      *reinterpret_cast<unsigned*>(X.lds + LY.off_pl + r * plStrideB + 4 * t) = u[r] | (u[4 + r] << 16);
-      *reinterpret_cast<unsigned*>(X.lds + LY.off_plB + r * plStrideB + 4 * t) = u[4 + r] | (u[8 + r] << 16);
+    for (int r = 0; r < SKIP; r++) {
+      *reinterpret_cast<unsigned*>(X.lds + LY.off_pl + r * plStrideB + 4 * t) = u[r] | (u[SKIP + r] << 16);
+      *reinterpret_cast<unsigned*>(X.lds + LY.off_plB + r * plStrideB + 4 * t) = u[SKIP + r] | (u[2 * SKIP + r] << 16);
     }
   }
   fast_sync();
@@ -274,9 +298,13 @@ template <int NT, bool MC>
 __device__ __forceinline__ void fast_refill(const FastOut& X, const FastLds& LY, int skip, pos_t nb, pos_t limit) {
   fast_sync();  // everyone is done reading the old window
 #ifndef SPX_NO_FAST_REFILL
-  if ((!MC || X.C == 1) && skip == 4 && limit - nb >= LY.wcap + 16 && ((size_t)(X.in + nb) & 15) == 0) {
-    fast_refill_mono4<NT>(X, LY, nb);
-    return;
+  {
+    const int C = MC ? X.C : 1;
+    if (C <= 2 && (skip == 4 || skip == 5) && limit - nb >= LY.wcap + 4 * skip && ((size_t)(X.in + (size_t)nb * C) & 3) == 0) {
+      if (C == 1) { if (skip == 4) fast_refill_onepass<NT, 4, false>(X, LY, nb); else fast_refill_onepass<NT, 5, false>(X, LY, nb); }
+      else if constexpr (MC) { if (skip == 4) fast_refill_onepass<NT, 4, true>(X, LY, nb); else fast_refill_onepass<NT, 5, true>(X, LY, nb); }
+      return;
+    }
   }
 #endif
   const int wcap = LY.wcap;
