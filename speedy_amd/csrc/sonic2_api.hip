@@ -453,7 +453,8 @@ static int launch_job(sonicStream s, bool flush, bool direct = false) {
   }
   if (J.tiles > 0) spx_launch_analysis(P, s->dJob, 1, J.tiles, s->dIn.p, s->dRec.p, td, nullptr, nullptr, s->hs);
   if (J.nonlinear) spx_launch_tension(P, s->dJob, 1, s->dState, s->dRec.p, s->dScr.p, td, nullptr, nullptr, s->hs);
-  spx_launch_walk(P, dJobW, 1, (int)C, J.tsmIn->p, s->dOut.p, s->dNOut, s->dState, s->dScr.p, nullptr, J.speedupKernel, s->hs);
+  spx_launch_walk(P, dJobW, 1, (int)C, J.tsmIn->p, s->dOut.p, s->dNOut, s->dState, s->dScr.p, nullptr, J.speedupKernel, s->hs,
+                  /*short_jobs: one write, a few pitch steps -- the usual window, not the long one*/ true);
   if (s->rateMode)
     spx_launch_rate(s->dRate, s->dState, s->dNOut, s->dOut.base(), s->dFinal.base(),
                     (s->dFinal.origin + s->dFinal.cap) / C, (int)C, J.oldR, J.newR, s->rate, s->rate == 1.0f ? 1 : 0,

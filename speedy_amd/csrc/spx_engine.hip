@@ -961,8 +961,12 @@ const char* spx_batch_kernel_names(spx_plan_t plan, int n_streams, int max_chann
   const SpxWalkConfig c = spx_walk_config(d, n_streams, max_channels < 1 ? 1 : max_channels, speedup_only != 0);
   char walk[96];
   if (c.fast_kernel)
-    snprintf(walk, sizeof(walk), "spx_walk_fast_kernel<%d, %d, %d, 0, %d>", c.nwm, c.nwc >= 4 ? 4 : (c.nwc >= 2 ? 2 : (c.nwc >= 1 ? 1 : 0)),
-             (c.wcap == 4096 && (d.rate == 16000 || d.rate == 22050)) ? d.rate : 0, max_channels > 1 ? 1 : 0);
+    {
+      const bool ct_rate = d.rate == 16000 || d.rate == 22050;
+      const bool lng = ct_rate && c.nwm == 4 && c.nwc >= 4 && c.wcap == 8192;   // spx_launch_walk_fast's long-window instantiations
+      snprintf(walk, sizeof(walk), "spx_walk_fast_kernel<%d, %d, %d, %d, %d>", c.nwm, c.nwc >= 4 ? 4 : (c.nwc >= 2 ? 2 : (c.nwc >= 1 ? 1 : 0)),
+               (ct_rate && (lng || c.wcap == ((c.nwc == 0 && c.nwm <= 2) ? 1536 : 4096))) ? d.rate : 0, lng ? 1 : 0, max_channels > 1 ? 1 : 0);
+    }
   else
     snprintf(walk, sizeof(walk), "spx_walk_kernel<%d, %d>", c.nw, c.mode);
   snprintf(buf, sizeof(buf), "spx_analysis_kernel<%d, %d>;spx_tension_kernel;%s", d.tile_frames, spx_analysis_ct_window(d), walk);

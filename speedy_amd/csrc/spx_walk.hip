@@ -965,6 +965,10 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   c.nwm = throughput ? 2 : 4;
   c.nwc = throughput ? 0 : ((short_jobs && n_streams > cus) ? 0 : 4);
   c.wcap = throughput ? 1536 : 4096;
+  // long jobs with at most two streams per CU on the rate-specialised kernels with output waves: the 8192-frame window (half
+  // as many refills; spx_walk_fast.hip, SPEC = 1)
+  if (!throughput && !short_jobs && c.fast_kernel && c.nwm == 4 && c.nwc == 4 && (P.rate == 16000 || P.rate == 22050) && T.nwm <= 0 &&
+      T.nwc < 0) c.wcap = 8192;
   if (T.nwm > 0) c.nwm = T.nwm;
   if (T.nwc >= 0) c.nwc = T.nwc;
   if (T.wcap > 0) c.wcap = T.wcap;

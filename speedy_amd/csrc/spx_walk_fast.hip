@@ -62,6 +62,9 @@
 #ifndef SPX_CT_WCAP_TP
 #define SPX_CT_WCAP_TP 1536  // ... of their throughput instantiations (two search waves, no output waves, eight streams per CU)
 #endif
+#ifndef SPX_CT_WCAP_LONG
+#define SPX_CT_WCAP_LONG 8192  // ... of their long-window instantiations (SPEC = 1; spx_walk_config picks the window)
+#endif
 #define SPX_CT_WCAP_OF(NWMV, NWCV) (((NWCV) == 0 && (NWMV) <= 2) ? SPX_CT_WCAP_TP : SPX_CT_WCAP)
 enum { FCMD_STEP = 1, FCMD_COPY = 2, FCMD_REFILL = 3, FCMD_POLL = 4, FCMD_EXIT = 5 };
 #define FCMD_INTS 64  // ints per command slot: field k is written by lane k of the publishing wave
@@ -499,7 +502,11 @@ __device__ __forceinline__ int pair_addr(int base, int d2, int e) { return base 
 // At most 96 VGPRs: in concurrent mode a SIMD holds two waves of this kernel (a search and an output wave), one of the
 // tension kernel (56 registers) and analysis waves of 128 -- with 96 here two of those fit in the 512-register file,
 // with the 97 the compiler would take by itself only one (and the analysis then runs at a third of its speed: measured).
-// SPEC: always 0.  (Round 2 tried speculative refine searches on the output waves -- the previous step's coarse winner
+// SPEC: 0 = the usual window (SPX_CT_WCAP_OF), 1 = the LONG window of SPX_CT_WCAP_LONG frames for long jobs that have a CU
+// to themselves or share it with one other stream (rate-specialised instantiations with output waves only): half as many
+// refills, 68 KB of LDS instead of 36 -- two analysis workgroups still fit beside it at 16 kHz.  Walk kernel of the bench
+// batch 2.058 -> 2.035 ms (profiles/r03/r03ab_w8k.txt).
+// (The parameter's name is history: round 2 tried speculative refine searches on the output waves -- the previous step's coarse winner
 // predicts this step's refine window in 30-60 % of steps -- bit-exact and SLOWER, 2.44 against 2.06 ms: DESIGN.md 5.3; the
 // protocol lived here behind this parameter until round 3 and is in the history, commit dd0437d and before.)
 // MC: 0 = mono streams only (the instantiation of the bench), 1 = any channel count up to 8 per stream.
@@ -513,7 +520,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
                      const float* scratch_base, const int* speed_ready, int wcap) {
   constexpr int NT = 64 * (NWM + NWC);
   constexpr int FCG = fcg_of(NWM), FRG = frg_of(NWM);
-  static_assert(SPEC == 0, "the speculative-refine protocol was removed in round 3");
+  static_assert(SPEC == 0 || (SPEC == 1 && RATE != 0 && NWC > 0), "SPEC = 1: the long window of the rate-specialised kernels with output waves");
   constexpr bool MCH = MC != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -524,7 +531,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   const int minP = CT ? RATE / 400 : P.minPeriod, maxP = CT ? RATE / 65 : P.maxPeriod;
   const int maxRequired = 2 * maxP;
   const int B = CT ? (int)(RATE / 100.0) : P.B;
-  if (CT) wcap = SPX_CT_WCAP_OF(NWM, NWC);
+  if (CT) wcap = SPEC == 1 ? SPX_CT_WCAP_LONG : SPX_CT_WCAP_OF(NWM, NWC);
   const FastLds LY = fast_lds_layout_i(maxP, skip, wcap);
 
   FastOut X;
@@ -1198,7 +1205,10 @@ int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int max
                         : P.rate == 22050 && wcap == SPX_CT_WCAP_OF(M, C) ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 22050, 0, MCV>) \
                         : reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 0, 0, MCV>))
 #define SPX_FN_R(M, C) (maxC > 1 ? SPX_FN_RM(M, C, 1) : SPX_FN_RM(M, C, 0))
-  if (nwm == 8) fn = SPX_FN_R(8, 4);
+  if (nwm == 4 && nwc >= 4 && wcap == SPX_CT_WCAP_LONG && (P.rate == 16000 || P.rate == 22050))
+    fn = P.rate == 16000 ? (maxC > 1 ? reinterpret_cast<const void*>(spx_walk_fast_kernel<4, 4, 16000, 1, 1>) : reinterpret_cast<const void*>(spx_walk_fast_kernel<4, 4, 16000, 1, 0>))
+                         : (maxC > 1 ? reinterpret_cast<const void*>(spx_walk_fast_kernel<4, 4, 22050, 1, 1>) : reinterpret_cast<const void*>(spx_walk_fast_kernel<4, 4, 22050, 1, 0>));
+  else if (nwm == 8) fn = SPX_FN_R(8, 4);
   else if (nwm == 2) fn = nwc >= 1 ? SPX_FN_R(2, 1) : SPX_FN_R(2, 0);
   else fn = nwc >= 4 ? SPX_FN_R(4, 4) : nwc >= 2 ? SPX_FN_R(4, 2) : nwc >= 1 ? SPX_FN_R(4, 1) : SPX_FN_R(4, 0);
 #undef SPX_FN_R
@@ -1228,7 +1238,9 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
   SPX_LAUNCH_FAST(4, 4);
   return;
 #endif
-  if (nwm == 8) {
+  if (nwm == 4 && nwc >= 4 && wcap == SPX_CT_WCAP_LONG && (P.rate == 16000 || P.rate == 22050)) {
+    if (P.rate == 16000) SPX_LAUNCH_FAST_RS(4, 4, 16000, 1); else SPX_LAUNCH_FAST_RS(4, 4, 22050, 1);
+  } else if (nwm == 8) {
     SPX_LAUNCH_FAST(8, 4);
   } else if (nwm == 2) {
     if (nwc >= 1) SPX_LAUNCH_FAST(2, 1);
