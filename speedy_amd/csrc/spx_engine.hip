@@ -1,4 +1,5 @@
 // C-ABI of the batch engine (include/speedy_hip.h): plan tables, workspace layout, kernel launches.
+#include <algorithm>
 #include <math.h>
 #include <cmath>
 #include <stdio.h>
@@ -89,7 +90,7 @@ struct spx_plan {
   hipEvent_t ev_chunk[SPX_MAX_CHUNKS] = {};
   // spx_batch_run_mixed: this plan's group runs on `mix`; the first plan of a call also lends the fork event and a staging slot
   hipStream_t mix = nullptr;
-  hipEvent_t ev_join = nullptr, ev_fork = nullptr;
+  hipEvent_t ev_join = nullptr, ev_fork = nullptr, ev_an = nullptr;
   std::mutex mix_mu;
   SpxStage mix_stage;
 };
@@ -329,6 +330,7 @@ void spx_plan_destroy(spx_plan_t plan) {
   if (plan->side2) { (void)hipStreamSynchronize(plan->side2); (void)hipStreamDestroy(plan->side2); }
   if (plan->mix) { (void)hipStreamSynchronize(plan->mix); (void)hipStreamDestroy(plan->mix); }
   if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
+  if (plan->ev_an) (void)hipEventDestroy(plan->ev_an);
   if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
   if (plan->mix_stage.done) { (void)hipEventSynchronize(plan->mix_stage.done); (void)hipEventDestroy(plan->mix_stage.done); }
   if (plan->mix_stage.p) (void)hipHostFree(plan->mix_stage.p);
@@ -498,7 +500,8 @@ static hipEvent_t take_event() {
 
 // `force`: the call is one group of a mixed-rate batch (spx_batch_run_mixed): the launch mode was decided for all groups
 // together, and the device guard is held by the caller.
-struct SpxForce { int concurrent; bool idle_start; };
+struct SpxForce { int concurrent; bool idle_start; int total_streams; hipEvent_t after_analysis; };
+// total_streams: of all groups of the mixed call; after_analysis: recorded behind the group's analysis launch (or null)
 static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                     int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs, bool do_a,
                     bool do_w, const SpxForce* force = nullptr) {
@@ -713,8 +716,16 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, st); }
       static const bool diag_nowait = getenv("SPX_DIAG_NOWAIT") != nullptr;  // DIAGNOSTIC ONLY: the walk reads the speeds
       // the previous identical call left in the scratch array instead of waiting for this call's (timing experiments)
+      // Kernels in sequence, and every stream of the call (of all groups of a mixed call) can have a CU to itself: ask for
+      // more than half a CU's LDS per walk workgroup, so that they DO get one each.  Walk kernels of several groups launched
+      // side by side, or a walk kernel placed while another group's analysis fills the CUs, otherwise land two to a CU here
+      // and there, and those chains end the call: the configs[4] shard 3.30 -> 3.04 ms per step (profiles/r03/r03ad_config4_lds_min.txt).
+      // (The concurrent mode needs that LDS for the analysis workgroups beside the walk; its idle-start gate does this job.)
+      static const bool no_excl = getenv("SPX_NO_EXCLUSIVE_CU") != nullptr;   // A/B
+      const int total = force ? force->total_streams : n;
+      const size_t lds_min = (!concurrent && !no_excl && nch == 1 && total <= cu_count) ? lds_per_cu / 2 + 1024 : 0;
       spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, (concurrent && !diag_nowait) ? d_ready : nullptr,
-                      speedup_only, st);
+                      speedup_only, st, false, lds_min);
       if (timed) { (void)hipEventRecord(e1, st); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({e0, e1, 1}); } }
     };
     // Concurrent mode on an IDLE device (the first call after a synchronisation): kernels start as their launches arrive,
@@ -737,6 +748,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
                           concurrent ? d_flags : nullptr, sa);
       if (timed) { (void)hipEventRecord(e1, sa); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({e0, e1, 0}); } }
     }
+    if (force && force->after_analysis && c == nch - 1) HIPCHK(hipEventRecord(force->after_analysis, sa));
     if (sa != st) HIPCHK(hipEventRecord(plan->ev_chunk[c], sa));
     if (sa != st && !concurrent) HIPCHK(hipStreamWaitEvent(st, plan->ev_chunk[c], 0));
     if (do_w) {
@@ -891,7 +903,7 @@ int spx_batch_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_j
   // ---- the device guard, once for the whole call ----
   SpxDevGuard& guard = g_guard[(lead->device >= 0 && lead->device < 64) ? lead->device : 0];
   std::unique_lock<std::mutex> guard_lock(guard.mu, std::defer_lock);
-  SpxForce force = {0, false};
+  SpxForce force = {0, false, n, nullptr};
   if (concurrent) {
     guard_lock.lock();
     const hipError_t q = guard.valid ? hipEventQuery(guard.last) : hipSuccess;
@@ -926,21 +938,38 @@ int spx_batch_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_j
     HIPCHK(hipMemcpyAsync(d_idx, G.p, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(G.done, st));
   }
-  size_t pos = 0;
-  for (int g = 0; g < n_plans; g++) {
-    if (gj[g].empty()) continue;
+  std::vector<size_t> gpos(n_plans, 0);
+  { size_t pos = 0; for (int g = 0; g < n_plans; g++) { gpos[g] = pos; pos += gj[g].size(); } }
+  // Kernels in sequence: the groups' analysis kernels one after the other, the cheapest first (lowest rate: fewest frames
+  // and the shortest transform), instead of all at once.  Shared, every analysis ends late and every walk kernel starts
+  // late; shortest first, the first group's walk starts early and the last analysis -- alone on what the running walk
+  // kernels leave -- ends no later than it did shared (configs[4] shard: 16 kHz analysis done at 0.31 instead of 0.50 ms,
+  // 22.05 kHz at 0.87 instead of 0.92; the call ends with the later group's walk kernel).
+  std::vector<int> ord;
+  for (int g = 0; g < n_plans; g++) if (!gj[g].empty()) ord.push_back(g);
+  static const bool no_sjf = getenv("SPX_MIXED_NO_ORDER") != nullptr;   // A/B
+  const bool chain_analyses = !concurrent && !no_sjf && ord.size() > 1;
+  if (chain_analyses) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return plans[a]->dev.rate < plans[b]->dev.rate; });
+  hipEvent_t prev_an = nullptr;
+  for (int g : ord) {
     spx_plan* p = plans[g];
     if (!p->mix) {
       HIPCHK(hipStreamCreateWithFlags(&p->mix, hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
     }
+    if (!p->ev_an) HIPCHK(hipEventCreateWithFlags(&p->ev_an, hipEventDisableTiming));
     HIPCHK(hipStreamWaitEvent(p->mix, lead->ev_fork, 0));
-    rc = run_impl(p, gj[g].data(), (int)gj[g].size(), in, out, d_nout + pos, w + M.ws_off[g], M.ws_bytes[g], nullptr, p->mix, true,
-                  true, &force);
+    SpxForce f = force;
+    if (chain_analyses) {
+      if (prev_an) HIPCHK(hipStreamWaitEvent(p->mix, prev_an, 0));
+      f.after_analysis = p->ev_an;
+      prev_an = p->ev_an;
+    }
+    rc = run_impl(p, gj[g].data(), (int)gj[g].size(), in, out, d_nout + gpos[g], w + M.ws_off[g], M.ws_bytes[g], nullptr, p->mix,
+                  true, true, &f);
     if (rc) return rc;
     HIPCHK(hipEventRecord(p->ev_join, p->mix));
     HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
-    pos += gj[g].size();
   }
   hipLaunchKernelGGL(spx_scatter_nout_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_nout, d_idx, n, n_out);
   if (concurrent) {

@@ -153,7 +153,7 @@ void spx_launch_tension(const SpxPlanDev& P, const SpxStreamDev* streams, int n_
 // so the time-scale stage only ever sees speeds >= 1: selects the walk kernel specialised for that.
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int max_channels,
                      const int16_t* in, int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
-                     const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs = false);
+                     const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs = false, size_t lds_min = 0);
 size_t spx_analysis_lds_bytes(const SpxPlanDev& P);
 int spx_analysis_ct_window(const SpxPlanDev& P);
 // The DFT of the spec run on the host (same operation order as the kernel): used to build the Rader tables.
@@ -175,7 +175,7 @@ size_t spx_walk_fast_lds_bytes(const SpxPlanDev& P, int wcap);
 bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm);
 void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, const int16_t* in,
                           int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
-                          const int* speed_ready, int nwm, int nwc, int wcap, int max_channels, hipStream_t st);
+                          const int* speed_ready, int nwm, int nwc, int wcap, int max_channels, hipStream_t st, size_t lds_min = 0);
 // n_out value of a stream whose producer kernel never delivered (concurrent mode poll limit): not an overflow
 #define SPX_NOUT_LOST_PRODUCER INT64_MIN
 size_t spx_tension_lds_bytes();

@@ -1013,13 +1013,13 @@ size_t spx_walk_lds_bytes(const SpxPlanDev& P, int maxC, bool speedup_only) {
 
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int maxC, const int16_t* in,
                      int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
-                     const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs) {
+                     const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs, size_t lds_min) {
   if (n_streams <= 0) return;
   if (maxC < 1) maxC = 1;
   const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC, speedup_only, short_jobs);
   if (cfg.fast_kernel) {
     spx_launch_walk_fast(P, streams, n_streams, in, out, n_out, states, scratch, speed_ready, cfg.nwm, cfg.nwc, cfg.wcap,
-                         maxC, st);
+                         maxC, st, lds_min);
     return;
   }
   const int fast = cfg.mode;

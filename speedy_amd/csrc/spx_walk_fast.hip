@@ -1218,11 +1218,14 @@ int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int max
 
 void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, const int16_t* in,
                           int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
-                          const int* speed_ready, int nwm, int nwc, int wcap, int maxC, hipStream_t st) {
+                          const int* speed_ready, int nwm, int nwc, int wcap, int maxC, hipStream_t st, size_t lds_min) {
   if (n_streams <= 0) return;
   const FastLds LY = fast_lds_layout(P, wcap);
+  // lds_min: the caller wants these workgroups ONE to a CU (it asks for more than half a CU's LDS): walk kernels of several
+  // groups launched side by side otherwise land two to a CU here and there, and those chains end the call (spx_engine.hip)
+  const size_t lds_req = (size_t)LY.total > lds_min ? (size_t)LY.total : lds_min;
 #define SPX_LAUNCH_FAST_RSM(M, C, R, SPECV, MCV)                                                                               \
-  hipLaunchKernelGGL((spx_walk_fast_kernel<M, C, R, SPECV, MCV>), dim3(n_streams), dim3(64 * (M + C)), LY.total, st, P, streams, \
+  hipLaunchKernelGGL((spx_walk_fast_kernel<M, C, R, SPECV, MCV>), dim3(n_streams), dim3(64 * (M + C)), lds_req, st, P, streams, \
                      in, out, n_out, states, scratch, speed_ready, wcap)
 #define SPX_LAUNCH_FAST_RS(M, C, R, SPECV)                                                                                \
   do { if (maxC > 1) SPX_LAUNCH_FAST_RSM(M, C, R, SPECV, 1); else SPX_LAUNCH_FAST_RSM(M, C, R, SPECV, 0); } while (0)
