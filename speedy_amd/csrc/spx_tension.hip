@@ -36,6 +36,23 @@ __device__ __forceinline__ float iir_wave(const float* sA, float* sB, int n, flo
   for (int b0 = 0; b0 < n; b0 += 64) {
     const int m = n - b0 < 64 ? n - b0 : 64;
     const float ax = a * ((lane < m) ? sA[b0 + lane] : 0.0f);
+#ifndef SPX_TENSION_OLD_CHAIN
+    if (m == 64) {
+      // A full block: the chain runs on lane 0 alone -- per element one v_readlane (it ignores EXEC), the two dependent
+      // operations and one LDS store at a constant offset; no per-element bound check, no lane masks.  (Before: ten
+      // instructions per element, among them two v_readlane of a spilled lane mask: 63 of the kernel's 113 us per 1 000 frames.)
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 64; j++) {
+          const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ax), j));
+          y = s + b * y;
+          sB[b0 + j] = y;
+        }
+      }
+      y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, y)));
+      continue;
+    }
+#endif
     float out = 0.0f;
 #pragma unroll
     for (int j = 0; j < 64; j++) {
@@ -231,11 +248,19 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
               const int m = n - b0 < 64 ? n - b0 : 64;
               const float req = (tid < m) ? sA[b0 + tid] : 1.0f;
               const float q = fd / req;
+              if (m == 64) {   // a full block: no per-element bound check
 #pragma unroll
-              for (int j = 0; j < 64; j++) {
-                if (j < m) {  // uniform
+                for (int j = 0; j < 64; j++) {
                   cur_dur += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q), j));
                   des_dur += cstep;
+                }
+              } else {
+#pragma unroll
+                for (int j = 0; j < 64; j++) {
+                  if (j < m) {  // uniform
+                    cur_dur += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q), j));
+                    des_dur += cstep;
+                  }
                 }
               }
               if (tid < m) sB[b0 + tid] = req * nl + Rg * (1 - nl);                      // soniclib.c:344-345
