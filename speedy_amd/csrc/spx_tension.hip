@@ -53,6 +53,21 @@ __device__ __forceinline__ float iir_wave(const float* sA, float* sB, int n, flo
       continue;
     }
 #endif
+#ifndef SPX_TENSION_OLD_CHAIN
+    // a partial block (the last one; every block of a concurrent-mode chunk or of a streamed write): the same on lane 0,
+    // with the bound check per element
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 64; j++) {
+        if (j < m) {  // uniform
+          const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ax), j));
+          y = s + b * y;
+          sB[b0 + j] = y;
+        }
+      }
+    }
+    y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, y)));
+#else
     float out = 0.0f;
 #pragma unroll
     for (int j = 0; j < 64; j++) {
@@ -63,6 +78,7 @@ __device__ __forceinline__ float iir_wave(const float* sA, float* sB, int n, flo
       }
     }
     if (lane < m) sB[b0 + lane] = out;
+#endif
   }
   return y;
 }
