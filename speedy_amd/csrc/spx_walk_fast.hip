@@ -560,8 +560,9 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   // Code placement: the step loop's speed depends on where it lies relative to the 64-byte instruction fetch lines (round 3:
   // removing ONE 8-byte prologue instruction, the loop's ISA unchanged, cost 2 %).  SPX_WALK_PAD s_nop's here, executed once,
   // shift everything behind them by four bytes each.  Swept 0 .. 64 bytes (tools/walk_pad_sweep.sh,
-  // profiles/r03/r03x_walk_pad.txt): the walk kernel of the bench batch reads 2.29 .. 2.36 ms, periodic in 64 bytes; 8 bytes
-  // is the best.  Re-run the sweep after any change to this kernel.
+  // profiles/r03/r03x_walk_pad.txt): the walk kernel of the bench batch read 2.29 .. 2.36 ms, periodic in 64 bytes; 8 bytes
+  // was the best.  With the step loop of the round's second half the sweep reads 2.032 .. 2.056 ms (r03af_walk_pad.txt): 8
+  // bytes is within 0.2 % of the best and stays.  Re-run the sweep after any change to this kernel.
   asm volatile(".rept %0\n\ts_nop 0\n\t.endr" ::"n"(SPX_WALK_PAD));
 #endif
   const int dA = LY.off_monoB - 2 - LY.off_mono;         // see pair_addr
