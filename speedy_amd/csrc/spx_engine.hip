@@ -326,8 +326,9 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
 
 void spx_plan_destroy(spx_plan_t plan) {
   if (!plan) return;
-  if (plan->side) { (void)hipStreamSynchronize(plan->side); (void)hipStreamDestroy(plan->side); }
-  if (plan->side2) { (void)hipStreamSynchronize(plan->side2); (void)hipStreamDestroy(plan->side2); }
+  // (side / side2 belong to the device, not to the plan: dev_side_streams)
+  if (plan->side) (void)hipStreamSynchronize(plan->side);
+  if (plan->side2) (void)hipStreamSynchronize(plan->side2);
   if (plan->mix) { (void)hipStreamSynchronize(plan->mix); (void)hipStreamDestroy(plan->mix); }
   if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
   if (plan->ev_an) (void)hipEventDestroy(plan->ev_an);
@@ -500,6 +501,25 @@ static hipEvent_t take_event() {
 
 // `force`: the call is one group of a mixed-rate batch (spx_batch_run_mixed): the launch mode was decided for all groups
 // together, and the device guard is held by the caller.
+// The two side streams of the concurrent mode (analysis, tension) and of the time-chunk pipeline are per DEVICE, created once:
+// HIP maps streams onto a few hardware queues in creation order, and a queue runs its kernels in order -- with side streams
+// per plan, the second plan of a process got a tension stream that shared the caller stream's queue, its walk kernel waited
+// behind its own tension kernel, and the call ran analysis and walk one after the other (3.5 instead of 2.4 ms per 256 x 10 s
+// at 22.05 kHz, profiles/r03/r03aj_lean_22k.txt).  Only one concurrent-mode call is in flight per device anyway (SpxDevGuard);
+// calls that pipeline time chunks from several host threads share the analysis stream.
+static int dev_side_streams(int dev, hipStream_t* side, hipStream_t* side2) {
+  static std::mutex mu;
+  static hipStream_t s1[64], s2[64];
+  const int d = (dev >= 0 && dev < 64) ? dev : 0;
+  std::lock_guard<std::mutex> g(mu);
+  if (!s1[d]) {
+    if (hipStreamCreateWithFlags(&s1[d], hipStreamNonBlocking) != hipSuccess) { s1[d] = nullptr; return -1; }
+    if (hipStreamCreateWithFlags(&s2[d], hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(s1[d]); s1[d] = nullptr; s2[d] = nullptr; return -1; }
+  }
+  *side = s1[d]; *side2 = s2[d];
+  return 0;
+}
+
 struct SpxForce { int concurrent; bool idle_start; int total_streams; hipEvent_t after_analysis; };
 // total_streams: of all groups of the mixed call; after_analysis: recorded behind the group's analysis launch (or null)
 static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
@@ -532,9 +552,28 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   std::lock_guard<std::mutex> plan_lock(plan->mu);
   const int cu_count = plan->cu_count;
   const size_t lds_per_cu = plan->lds_per_cu;
-  const SpxWalkConfig wcfg = spx_walk_config(d, n, maxC, speedup_only);
+  SpxWalkConfig wcfg = spx_walk_config(d, n, maxC, speedup_only);
   if (wcfg.lds > 160 * 1024)   // one CU's LDS; the window holds every channel of maxRequired + 64 frames at least
     return fail(-1, "spx_batch: too many channels for the walk kernel's LDS window");
+  // The LEAN walk form for the concurrent mode (round 3): where a stream's walk workgroup in its usual form (4 search + 4
+  // output waves: TWO walk waves per SIMD) leaves no room for two analysis waves or workgroups beside it, but the form
+  // without output waves does -- 22.05 kHz mono: 2 x 112 + 56 + 2 x 168 registers does not fit a SIMD's 512, 120 + 56 + 2 x 168
+  // does -- the walk gives up its output waves (its search waves then cross-fade and copy themselves, from the LDS window: a
+  // few percent of the chain) and the call keeps the concurrent mode (mono only: a multi-channel stream's cross-fades read
+  // the input from HBM, which the chain cannot wait for).
+  bool lean_walk = false;
+  static const bool no_lean = getenv("SPX_NO_LEAN_WALK") != nullptr;   // A/B
+  if (do_a && do_w && maxC == 1 && n <= plan->cu_count && wcfg.fast_kernel && wcfg.nwc > 0 && !no_lean && !force) {
+    const SpxWalkConfig lc = spx_walk_config(d, n, maxC, speedup_only, false, true);
+    if (lc.fast_kernel && lc.nwc == 0) {
+      const size_t lds_u = plan->lds_per_cu > 6144 ? plan->lds_per_cu - 6144 : plan->lds_per_cu;
+      auto fits = [&](const SpxWalkConfig& c, bool lean) {
+        return c.lds + spx_tension_lds_bytes() + 2 * spx_analysis_lds_bytes(d) <= lds_u &&
+               ((c.waves + 3) / 4) * spx_walk_vgprs(d, n, maxC, speedup_only, lean) + spx_tension_vgprs() + 2 * spx_analysis_vgprs(d) <= 512;
+      };
+      if (!fits(wcfg, false) && fits(lc, true)) { lean_walk = true; wcfg = lc; }
+    }
+  }
   const size_t per_stream_lds = wcfg.lds + spx_tension_lds_bytes();
   const size_t per_stream_waves = (size_t)wcfg.waves + 4;  // walk (spx_launch_walk's choice) + tension
   bool co_resident = false, doubtful = false;
@@ -567,7 +606,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     // = 504.  22.05 kHz: 2 x 112 + 56 + 2 x 168 does not fit -- one analysis wave per SIMD stretched the analysis from
     // 1.0 to 2.5-3.2 ms and the walk waited: 3.0-4.6 ms per call against 2.3-3.2 in sequence.)
     if (co_resident) {
-      const int walk_regs = ((wcfg.waves + 3) / 4) * spx_walk_vgprs(d, n, maxC, speedup_only);
+      const int walk_regs = ((wcfg.waves + 3) / 4) * spx_walk_vgprs(d, n, maxC, speedup_only, lean_walk);
       if (walk_regs + spx_tension_vgprs() + 2 * spx_analysis_vgprs(d) > 512) {
         if (walk_regs + spx_tension_vgprs() + spx_analysis_vgprs(d) > 512) co_resident = false;  // not even one
         else doubtful = true;  // one analysis wave per SIMD: decided by trial (spx_plan::Trial)
@@ -643,8 +682,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   hipStream_t sa = st;  // stream the analysis launches go to
   if (nch > 1 || concurrent) {
     if (!plan->side) {
-      HIPCHK(hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking));
-      HIPCHK(hipStreamCreateWithFlags(&plan->side2, hipStreamNonBlocking));
+      if (dev_side_streams(plan->device, &plan->side, &plan->side2)) return fail(-1, "spx_batch: no side streams");
       HIPCHK(hipEventCreateWithFlags(&plan->ev_start, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&plan->ev_tension, hipEventDisableTiming));
       for (auto& e : plan->ev_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -725,7 +763,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       const int total = force ? force->total_streams : n;
       const size_t lds_min = (!concurrent && !no_excl && nch == 1 && total <= cu_count) ? lds_per_cu / 2 + 1024 : 0;
       spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, (concurrent && !diag_nowait) ? d_ready : nullptr,
-                      speedup_only, st, false, lds_min);
+                      speedup_only, st, false, lds_min, lean_walk && concurrent);
       if (timed) { (void)hipEventRecord(e1, st); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({e0, e1, 1}); } }
     };
     // Concurrent mode on an IDLE device (the first call after a synchronisation): kernels start as their launches arrive,

@@ -153,7 +153,8 @@ void spx_launch_tension(const SpxPlanDev& P, const SpxStreamDev* streams, int n_
 // so the time-scale stage only ever sees speeds >= 1: selects the walk kernel specialised for that.
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int max_channels,
                      const int16_t* in, int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
-                     const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs = false, size_t lds_min = 0);
+                     const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs = false, size_t lds_min = 0,
+                     bool lean = false);
 size_t spx_analysis_lds_bytes(const SpxPlanDev& P);
 int spx_analysis_ct_window(const SpxPlanDev& P);
 // The DFT of the spec run on the host (same operation order as the kernel): used to build the Rader tables.
@@ -169,7 +170,10 @@ struct SpxWalkConfig {
   size_t lds;        // its LDS bytes per stream
 };
 // short_jobs: the streams bring a few pitch steps each (coalesced sonic2.h writes): latency form whatever their number
-SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only, bool short_jobs = false);
+// lean: no output waves (and the usual window) although the streams have a CU each -- the search waves do the output work:
+// one walk wave per SIMD instead of two, which is what lets two analysis waves of 168 registers sit beside it (22.05 kHz)
+SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only, bool short_jobs = false,
+                              bool lean = false);
 // spx_walk_fast.hip
 size_t spx_walk_fast_lds_bytes(const SpxPlanDev& P, int wcap);
 bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm);
@@ -185,7 +189,7 @@ size_t spx_tension_lds_bytes();
 int spx_kernel_vgprs(const void* fn);   // spx_engine.hip (one cache, behind a mutex)
 int spx_tension_vgprs();
 int spx_analysis_vgprs(const SpxPlanDev& P);
-int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only);
+int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only, bool lean = false);
 // speedyComputeSpeedFromTension (speedy.c:768-788) on the stream's state record: *speed_out = requested speed, the
 // duration sums of the record advance.
 void spx_launch_speed_from_tension(SpxStreamState* state, float tension, float Rg, float feedback, float* speed_out,

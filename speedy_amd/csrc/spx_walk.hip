@@ -932,7 +932,7 @@ static int walk_mode(const SpxPlanDev& P, int maxC, bool speedup_only) {
 
 // Kernel variant, waves per stream and LDS per stream for a batch: the one place the launcher and the engine's
 // co-residency arithmetic both ask.
-SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool short_jobs) {
+SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool short_jobs, bool lean) {
   if (maxC < 1) maxC = 1;
   const WalkTuning& T = walk_tuning();
   SpxWalkConfig c;
@@ -969,6 +969,7 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   // as many refills; spx_walk_fast.hip, SPEC = 1)
   if (!throughput && !short_jobs && c.fast_kernel && c.nwm == 4 && c.nwc == 4 && (P.rate == 16000 || P.rate == 22050) && T.nwm <= 0 &&
       T.nwc < 0) c.wcap = 8192;
+  if (lean && !throughput) { c.nwc = 0; c.wcap = 4096; }
   if (T.nwm > 0) c.nwm = T.nwm;
   if (T.nwc >= 0) c.nwc = T.nwc;
   if (T.wcap > 0) c.wcap = T.wcap;
@@ -990,8 +991,8 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   return c;
 }
 int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC);
-int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only) {
-  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC < 1 ? 1 : maxC, speedup_only);
+int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool lean) {
+  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC < 1 ? 1 : maxC, speedup_only, false, lean);
   if (cfg.fast_kernel) return spx_walk_fast_vgprs(P, cfg.nwm, cfg.nwc, cfg.wcap, maxC);
   const void* fn;
 #define SPX_FN_W(NWV) (cfg.mode == 1 ? reinterpret_cast<const void*>(spx_walk_kernel<NWV, 1>)   \
@@ -1013,10 +1014,10 @@ size_t spx_walk_lds_bytes(const SpxPlanDev& P, int maxC, bool speedup_only) {
 
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int maxC, const int16_t* in,
                      int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
-                     const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs, size_t lds_min) {
+                     const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs, size_t lds_min, bool lean) {
   if (n_streams <= 0) return;
   if (maxC < 1) maxC = 1;
-  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC, speedup_only, short_jobs);
+  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC, speedup_only, short_jobs, lean);
   if (cfg.fast_kernel) {
     spx_launch_walk_fast(P, streams, n_streams, in, out, n_out, states, scratch, speed_ready, cfg.nwm, cfg.nwc, cfg.wcap,
                          maxC, st, lds_min);
