@@ -42,7 +42,8 @@
 // LDS bank placement of the shifted copies relative to the originals (bytes added between the two): lanes of adjacent lags
 // read alternately from a signal and from its shifted copy, so the copies' bank offset decides the conflicts.
 #ifndef SPX_PAD_MONO
-#define SPX_PAD_MONO 48  // 16 kHz: the refine rectangle's reads become conflict-free (model: 211 -> 145 LDS cycles per step; walk -0.6 %)
+#define SPX_PAD_MONO 48  // 16 kHz: the refine rectangle's reads become conflict-free (tools/lds_conflict_model.py: 267 -> 202 LDS cycles per step)
+#endif
 // Branch hints for the step loop: the compiler lays the expected side out as the fall-through (a taken branch costs a wave
 // ~20 cycles, tools/ubench/issue_costs.hip).  -DSPX_NO_HINTS builds the loop as the compiler would place it by itself.
 #ifdef SPX_NO_HINTS
@@ -51,7 +52,6 @@
 #else
 #define SPX_LIKELY(x) __builtin_expect(!!(x), 1)
 #define SPX_UNLIKELY(x) __builtin_expect(!!(x), 0)
-#endif
 #endif
 #ifndef SPX_PAD_PL
 #define SPX_PAD_PL 0
@@ -970,19 +970,12 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         const int period = find_period(pos, ge2, sm1, twom, n, rem, std::false_type());
         if (!ge2) remaining = rem;
         if (out_n + n > X.out_cap) overflow = 1;
-#ifdef SPX_FAILED_BRANCH
-        if (SPX_UNLIKELY(n == 0)) { failed = true; break; }
-        xf_n = n; xf_down = (int)(pos - wbase); xf_period = period; xf_out = out_n;
-        out_n += n;
-        pos += period + n;
-#else
         // a failed step (n == 0) is no branch of its own: it hands over no cross-fade (xf_n = 0), leaves pos where it is and ends
         // the loop through its condition
         failed = n == 0;
         xf_n = n; xf_down = (int)(pos - wbase); xf_period = period; xf_out = out_n;
         out_n += n;
         pos += failed ? 0 : period + n;
-#endif
         FSTAMP(10);
       }
     } while (!failed && pos + maxRequired <= availE);
@@ -1068,7 +1061,6 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       const int perEvent = flushBlk ? 2 * maxRequired : B;
       const pos_t availLane = (linear && !flushBlk) ? n_tsm : availBlk + (lane + 1) * perEvent;  // frames handed over after event `lane`
       int i = 0;
-#ifndef SPX_NO_HOT_LOOP
       for (;;) {
         // The hot loop: events at speed >= 2 with nothing left to copy through -- nearly every event of a stream that is sped
         // up by 2 or more -- run here, in a loop of their own whose only loop-carried state is what such a step changes;
@@ -1127,31 +1119,6 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         FSTAMP(11);
         i++;
       }
-#else
-      while (i < nIn) {
-        const unsigned long long runnable = __builtin_amdgcn_ballot_w64(
-            lane >= i && lane < nIn && (unityLane || availLane - base >= maxRequired));
-        if (SPX_UNLIKELY(runnable == 0)) break;
-        i = __builtin_ctzll(runnable);
-        const pos_t availE = (linear && !flushBlk) ? n_tsm : availBlk + (i + 1) * perEvent;
-        FSTAMP(0);
-        if (SPX_UNLIKELY((unityMask >> i) & 1)) {
-          const pos_t n = availE - base;
-          if (n > 0) {
-            if (out_n + n > X.out_cap) overflow = 1;
-            FAST_PUBLISH(FCMD_COPY, n, base, out_n, 0);
-            if (NWC > 0) fast_sync();
-            out_n += n;
-          }
-          base = availE;
-        } else {
-          const float speed = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, spv), i));
-          run_event(speed, availE);
-        }
-        FSTAMP(11);
-        i++;
-      }
-#endif
       avail = (linear && !flushBlk) ? n_tsm : availBlk + nIn * perEvent;
       if (flushBlk) {
         if (out_n > expected) out_n = expected;
