@@ -50,6 +50,13 @@ __global__ void __launch_bounds__(1024) k(unsigned long long* out, int ns, int* 
                        "=&v"(*(unsigned long long*)&a4), "=&v"(*(unsigned long long*)&a5), "=&v"(*(unsigned long long*)&a6), "=&v"(*(unsigned long long*)&a7)
                      : "v"(addr));
         v += a0 + a7;
+      } else if (TEST == 15) {  // 8 independent 8-byte LDS reads in flight (the same bytes as test 6), then wait
+        unsigned long long a0, a1, a2, a3, a4, a5, a6, a7;
+        asm volatile(REP8("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:8\n\tds_read_b64 %2, %8 offset:16\n\tds_read_b64 %3, %8 offset:24\n\t"
+                          "ds_read_b64 %4, %8 offset:32\n\tds_read_b64 %5, %8 offset:40\n\tds_read_b64 %6, %8 offset:48\n\tds_read_b64 %7, %8 offset:56\n\ts_waitcnt lgkmcnt(0)\n\t")
+                     : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6), "=&v"(a7)
+                     : "v"(addr * 2));
+        v += (int)(a0 + a7);
       } else if (TEST == 7) {  // ds_add + wait
         asm volatile(REP64("ds_add_u32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\t") : : "v"(addr), "v"(v) : "memory");
       } else if (TEST == 9) {  // taken branches
@@ -113,6 +120,7 @@ int main(int argc, char** argv) {
     RUN(4, "v_readlane -> s_add -> v_add (dependent triple)", 64.0);
     RUN(5, "ds_read_b32 -> wait -> v_and (dependent)", 64.0);
     RUN(6, "8x ds_read2_b32 in flight + wait (per group)", 8.0);
+    RUN(15, "8x ds_read_b64 in flight + wait (per group)", 8.0);
     RUN(7, "ds_add_u32 + wait", 64.0);
     RUN(8, "s_barrier (all waves)", 64.0);
     RUN(9, "taken s_branch + skipped s_nop", 64.0);
