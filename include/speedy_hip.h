@@ -125,6 +125,13 @@ int spx_timing_collect(double* sum_ms_analyze, double* sum_ms_walk, int* n_calls
 /* "analysis;tension;walk": the kernels (template arguments included, as a profiler prints them) that serve a batch of
  * n_streams streams with at most max_channels channels; speedup_only = every job has speed > 1. */
 const char* spx_batch_kernel_names(spx_plan_t plan, int n_streams, int max_channels, int speedup_only);
+/* Diagnostics: the form of the walk kernel launched last in this process, 16 * search waves + output waves (68 = the usual
+ * 4 + 4, 64 = the lean form of the concurrent mode at 22.05 kHz mono, 32 = the throughput form), 0 = the general kernel. */
+int spx_debug_last_walk_form(void);
+/* Diagnostics: allocated VGPRs (hipFuncGetAttributes, rounded up to the granule of 8) of the kernels whose register budgets
+ * decide the concurrent mode.  which: 0 tension, 1 walk 16 kHz mono (4 + 4 waves, long window), 2 walk 22.05 kHz mono lean
+ * (4 + 0), 3 analysis 16 kHz, 4 analysis 22.05 kHz, 5 walk 16 kHz multi-channel (4 + 4).  -1 for an unknown index. */
+int spx_debug_kernel_vgprs(int which);
 /* Sum over the same calls of the frame-rate (tension) kernel's time, as of the last spx_timing_collect. */
 double spx_timing_last_tension_ms(void);
 

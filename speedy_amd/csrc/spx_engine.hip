@@ -676,6 +676,10 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   SpxTapsDev td = taps_of(taps);
   const bool timed = g_timing.load() && do_a && do_w;
   const bool concurrent = want_concurrent && nch == 1 && tiles[0] > 0;
+  static const bool dbg_mode = getenv("SPX_DEBUG_MODE") != nullptr;   // one line per call: what was decided and why
+  if (dbg_mode)
+    fprintf(stderr, "[spx mode] rate %d n %d maxC %d: co_resident %d doubtful %d lean %d want_concurrent %d chunks %d tiles %d -> %s\n", d.rate, n,
+            maxC, (int)co_resident, (int)doubtful, (int)lean_walk, (int)want_concurrent, nch, tiles[0], concurrent ? "concurrent" : "sequence");
   int* d_order = reinterpret_cast<int*>(w + L.off_order);
   int* d_flags = reinterpret_cast<int*>(w + L.off_flags);
   int* d_ready = reinterpret_cast<int*>(w + L.off_ready);
@@ -1038,6 +1042,20 @@ const char* spx_batch_kernel_names(spx_plan_t plan, int n_streams, int max_chann
     snprintf(walk, sizeof(walk), "spx_walk_kernel<%d, %d>", c.nw, c.mode);
   snprintf(buf, sizeof(buf), "spx_analysis_kernel<%d, %d>;spx_tension_kernel;%s", d.tile_frames, spx_analysis_ct_window(d), walk);
   return buf;
+}
+
+int spx_debug_kernel_vgprs(int which) {
+  if (which == 0) return spx_tension_vgprs();
+  const int rate = (which == 2 || which == 4) ? 22050 : 16000;
+  const SpxPlanDev* P = spx_internal_shared_plan(rate, 0);
+  if (!P) return -1;
+  switch (which) {
+    case 1: return spx_walk_vgprs(*P, 256, 1, true, false);
+    case 2: return spx_walk_vgprs(*P, 256, 1, true, true);
+    case 3: case 4: return spx_analysis_vgprs(*P);
+    case 5: return spx_walk_vgprs(*P, 256, 2, true, false);
+    default: return -1;
+  }
 }
 
 void spx_set_timing(int enabled) { g_timing = enabled != 0; }

@@ -83,6 +83,10 @@ __device__ __forceinline__ float iir_wave(const float* sA, float* sB, int n, flo
   return y;
 }
 
+// REGISTER BUDGET: at most 48 VGPRs.  In the concurrent mode a SIMD holds one wave of this kernel beside the walk and the
+// analysis waves, and at 22.05 kHz mono the sum is tight to the register: lean walk 128 + 48 + 2 x 168 (analysis) = 512
+// (spx_engine.hip).  A version of pass 2 that staged its inputs in LDS (6 us faster per 1 000 frames) took 49, was
+// allocated 56, and silently cost that mode; tests/test_gpu_parity.py::test_register_budgets_of_the_concurrent_mode watches it.
 __global__ void __launch_bounds__(SPX_TENSION_THREADS)
 spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxStreamState* __restrict__ states,
                    const SpxFrameRec* __restrict__ rec_base, float* __restrict__ scratch_base, SpxTapsDev taps,
@@ -181,48 +185,34 @@ spx_tension_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, SpxSt
       }
       Z.lp = lp;
       // ---- pass 2: hysteresis and emphasis-weighted difference, one lane per tension frame ----
-      // The F + P + 1 compressed energies a frame looks at are staged in LDS per block of tension frames (sA is free between
-      // passes 1 and 3): before, every lane read them from HBM in a loop of runtime length, one dependent round trip after the
-      // other -- most of what was left of this kernel's time once the recurrences ran on lane 0.
-      constexpr int CH2 = SPX_CH - 32;   // tension frames per block: CH2 + F + P + 1 <= SPX_CH (F + P = 20)
-      __syncthreads();
-      for (int c0 = K0; c0 < K; c0 += CH2) {
-        const int n = min(CH2, K - c0);
-        const int j0 = c0 - Pp - t0;     // frame staged at sA[0]: hysteresis slot c0 - P
-        const int m = n + Pp + F;        // slots c0 - P .. c0 + n - 1 + F
-        for (int i = tid; i < m; i += NT) {
-          const int j = j0 + i;
-          sA[i] = (j >= 0) ? scr[4 * j + 0] : 0.0f;   // slots before the first frame are the zero init
+      for (int k = K0 + tid; k < K; k += NT) {
+        float future_max = 0.0f, past_max = 0.0f;
+        for (int i = 0; i <= F; i++) {
+          const int tau = k + i;  // hysteresis slot `tau` holds frame tau - t0; earlier slots are the zero init
+          float v = (tau >= t0) ? scr[4 * (tau - t0) + 0] : 0.0f;
+          v *= P.taperF[i];
+          if (v > future_max) future_max = v;
         }
-        __syncthreads();
-        for (int k = c0 + tid; k < c0 + n; k += NT) {
-          const float* cw = sA + (k - c0 + Pp);   // cw[d] = slot k + d
-          float future_max = 0.0f, past_max = 0.0f;
-          for (int i = 0; i <= F; i++) {
-            float v = cw[i];
-            v *= P.taperF[i];
-            if (v > future_max) future_max = v;
-          }
-          for (int i = 0; i <= Pp; i++) {
-            float v = cw[-i];
-            v *= P.taperP[i];
-            if (v > past_max) past_max = v;
-          }
-          const float hyst = (float)((double)(past_max + future_max) / 2.0);  // speedy.c:609
-          const float e_cur = (k < t0) ? 0.0f : rec[k - t0].energy;          // history slot k holds frame k - t0
-          const bool low = e_cur <= lowthr || k == first_k;                  // the very first call is skipped (speedy.c:692)
-          const float lsd = low ? 0.0f : rec[k - t0].lsd;
-          const float ewld = low ? 0.0f : lsd * hyst;                          // speedy.c:720
-          scr[4 * k + 1] = hyst;
-          scr[4 * k + 2] = ewld;
-          if (tfeat) {
-            float* f = tfeat + (size_t)k * SPX_FEATURE_COUNT;
-            f[0] = e_cur; f[4] = hyst; f[5] = low ? 1.0f : 0.0f; f[6] = lsd; f[7] = ewld;
-            f[13] = (float)k; f[14] = lowthr;
-          }
+        for (int i = 0; i <= Pp; i++) {
+          const int tau = k - i;
+          float v = (tau >= t0) ? scr[4 * (tau - t0) + 0] : 0.0f;
+          v *= P.taperP[i];
+          if (v > past_max) past_max = v;
         }
-        __syncthreads();
+        const float hyst = (float)((double)(past_max + future_max) / 2.0);  // speedy.c:609
+        const float e_cur = (k < t0) ? 0.0f : rec[k - t0].energy;          // history slot k holds frame k - t0
+        const bool low = e_cur <= lowthr || k == first_k;                  // the very first call is skipped (speedy.c:692)
+        const float lsd = low ? 0.0f : rec[k - t0].lsd;
+        const float ewld = low ? 0.0f : lsd * hyst;                          // speedy.c:720
+        scr[4 * k + 1] = hyst;
+        scr[4 * k + 2] = ewld;
+        if (tfeat) {
+          float* f = tfeat + (size_t)k * SPX_FEATURE_COUNT;
+          f[0] = e_cur; f[4] = hyst; f[5] = low ? 1.0f : 0.0f; f[6] = lsd; f[7] = ewld;
+          f[13] = (float)k; f[14] = lowthr;
+        }
       }
+      __syncthreads();
       // ---- pass 3: difference low-pass (sequential) -> relative difference -> tension -> raw speed ----
       float lpf = Z.lpf;
       for (int c0 = K0; c0 < K; c0 += SPX_CH) {

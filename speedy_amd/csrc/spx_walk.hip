@@ -22,6 +22,7 @@
 //     the few lanes within 2^-16 of the extremum on the scalar unit (ties -> smallest lag, as a sequential
 //     scan would);  every wave does this redundantly, so no broadcast barrier is needed.
 // All sample arithmetic is integer; results are bit-exact against oracle/orc_sonic.c.
+#include <atomic>
 #include <stdlib.h>
 
 #include "spx_internal.h"
@@ -1012,12 +1013,16 @@ size_t spx_walk_lds_bytes(const SpxPlanDev& P, int maxC, bool speedup_only) {
   return spx_walk_config(P, 256, maxC, speedup_only).lds;
 }
 
+static std::atomic<int> g_last_walk_form{0};
+extern "C" int spx_debug_last_walk_form(void) { return g_last_walk_form.load(std::memory_order_relaxed); }
+
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int maxC, const int16_t* in,
                      int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
                      const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs, size_t lds_min, bool lean) {
   if (n_streams <= 0) return;
   if (maxC < 1) maxC = 1;
   const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC, speedup_only, short_jobs, lean);
+  g_last_walk_form.store(cfg.fast_kernel ? 16 * cfg.nwm + cfg.nwc : 0, std::memory_order_relaxed);
   if (cfg.fast_kernel) {
     spx_launch_walk_fast(P, streams, n_streams, in, out, n_out, states, scratch, speed_ready, cfg.nwm, cfg.nwc, cfg.wcap,
                          maxC, st, lds_min);

@@ -5,6 +5,8 @@ Bars (north_star / task rules): int16 output and sample indexing bit-exact; floa
 speed within 1e-4 (TOL below) -- and in fact bit-identical, because the kernels follow the oracle's
 operation order (DESIGN.md "Why the floats are bit-exact"); that stronger property is asserted too.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -586,3 +588,47 @@ def test_output_capacity_too_small_is_reported_and_contained(orc, ch, speed, nl,
     offs = offs.cpu().numpy()
     assert offs[victim + 1] - offs[victim] == cap * ch
     assert np.array_equal(packed.cpu().numpy()[offs[victim]:offs[victim + 1]], refs[victim][:cap * ch])
+
+
+def test_walk_form_follows_the_co_residency_arithmetic(orc):
+    """Which form of the walk kernel a batch gets (spx_engine.hip): 16 kHz mono keeps its 4 search + 4 output
+    waves in the concurrent mode; 22.05 kHz mono gives up the output waves there (the lean form: 120 + 56 + 2 x 168 registers
+    fit a SIMD, 2 x 112 + 56 + 2 x 168 do not) -- and still matches the oracle; 22.05 kHz stereo keeps them (its cross-fades
+    read the input from HBM) and runs in sequence."""
+    import torch
+    from speedy_amd.batch import Batch, Plan
+    from speedy_amd.synth import speech_like
+    L = Plan(16000, False).L
+    forms = {}
+    for rate, ch in ((16000, 1), (22050, 1), (22050, 2)):
+        n = rate * 2
+        plan = Plan(rate, False)
+        xs = [speech_like(n, rate, seed=900 + i, channels=ch) for i in range(6)]
+        b = Batch(plan, [n] * 6, ch, 3.5, 1.0, 0.0)
+        b.upload(xs)
+        b.run()
+        outs = b.results()
+        forms[(rate, ch)] = L.spx_debug_last_walk_form()
+        for x, got in zip(xs, outs):
+            ref = orc.compress_sound(x, rate, ch, 3.5, 1.0, 0.0, False, chunk=n, taps=False)["out"]
+            assert np.array_equal(got, ref)
+    if os.environ.get("SPX_NO_LEAN_WALK") or os.environ.get("SPX_SERIAL") or os.environ.get("SPX_SHARED_GPU"):
+        pytest.skip("a tuning variable overrides the launch mode: forms %r" % forms)
+    assert forms[(16000, 1)] == 16 * 4 + 4, forms
+    assert forms[(22050, 1)] == 16 * 4 + 0, forms
+    assert forms[(22050, 2)] == 16 * 4 + 4, forms
+
+
+def test_register_budgets_of_the_concurrent_mode():
+    """The concurrent mode needs two analysis waves beside a stream's walk and tension waves on a SIMD's 512 registers
+    (DESIGN.md 2).  Both cases that matter are tight: 16 kHz mono 2 x 96 + tension + 2 x 128, and 22.05 kHz mono with the lean
+    walk form 128 + 48 + 2 x 168 = 512 exactly -- one register more in the tension kernel (allocated in eights) silently
+    sends 22.05 kHz batches back to running their kernels in sequence (it happened in round 3)."""
+    from speedy_amd._lib import lib
+    L = lib()
+    v = {k: L.spx_debug_kernel_vgprs(i) for i, k in enumerate(["tension", "walk16", "lean22", "analysis16", "analysis22", "walk16mc"])}
+    assert all(x > 0 for x in v.values()), v
+    assert v["tension"] <= 48, v
+    assert 2 * v["walk16"] + v["tension"] + 2 * v["analysis16"] <= 512, v
+    assert v["lean22"] + v["tension"] + 2 * v["analysis22"] <= 512, v
+    assert 2 * v["walk16mc"] + v["tension"] + 2 * v["analysis16"] <= 512, v
