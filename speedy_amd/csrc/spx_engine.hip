@@ -557,7 +557,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     return fail(-1, "spx_batch: too many channels for the walk kernel's LDS window");
   // The LEAN walk form for the concurrent mode (round 3): where a stream's walk workgroup in its usual form (4 search + 4
   // output waves: TWO walk waves per SIMD) leaves no room for two analysis waves or workgroups beside it, but the form
-  // without output waves does -- 22.05 kHz mono: 2 x 112 + 56 + 2 x 168 registers does not fit a SIMD's 512, 120 + 56 + 2 x 168
+  // without output waves does -- 22.05 kHz mono: 2 x 112 + 48 + 2 x 168 registers does not fit a SIMD's 512, 128 + 48 + 2 x 168
   // does -- the walk gives up its output waves (its search waves then cross-fade and copy themselves, from the LDS window: a
   // few percent of the chain) and the call keeps the concurrent mode (mono only: a multi-channel stream's cross-fades read
   // the input from HBM, which the chain cannot wait for).

@@ -592,8 +592,8 @@ def test_output_capacity_too_small_is_reported_and_contained(orc, ch, speed, nl,
 
 def test_walk_form_follows_the_co_residency_arithmetic(orc):
     """Which form of the walk kernel a batch gets (spx_engine.hip): 16 kHz mono keeps its 4 search + 4 output
-    waves in the concurrent mode; 22.05 kHz mono gives up the output waves there (the lean form: 120 + 56 + 2 x 168 registers
-    fit a SIMD, 2 x 112 + 56 + 2 x 168 do not) -- and still matches the oracle; 22.05 kHz stereo keeps them (its cross-fades
+    waves in the concurrent mode; 22.05 kHz mono gives up the output waves there (the lean form: 128 + 48 + 2 x 168 registers
+    fit a SIMD, 2 x 112 + 48 + 2 x 168 do not) -- and still matches the oracle; 22.05 kHz stereo keeps them (its cross-fades
     read the input from HBM) and runs in sequence."""
     import torch
     from speedy_amd.batch import Batch, Plan
