@@ -11,12 +11,13 @@ for r in $(seq $REPS); do
     label=${v%%|*}; envs=${v#*|}
     for m in ${AB_MODES:-serial conc}; do
       if [ $m = serial ]; then S="SPX_SERIAL=1"; else S="SPX_NOOP=1"; fi
-      line=$(env $S $envs timeout 300 python3 bench.py --no-cpu-baseline --no-pcie 2>/dev/null | tail -1)
+      line=$(env $S $envs timeout 300 python3 bench.py --no-cpu-baseline --no-pcie --no-api --no-config4 2>/dev/null | tail -1)
       echo "$line" | python3 -c "
 import json,sys
 try:
     d=json.loads(sys.stdin.readline()); k=d['roofline']['kernel_ms_per_step']
-    print('%-8s %-6s ms/step=%.3f walk=%.3f analysis=%.3f tension=%.3f' % ('$label', '$m', d['ms_per_step'], k['spx_walk_kernel'], k['spx_analysis_kernel'], k['spx_tension_kernel']))
+    g=lambda w: [v for n, v in k.items() if w in n][0]   # keys are the real kernel names since round 3
+    print('%-8s %-6s ms/step=%.3f walk=%.3f analysis=%.3f tension=%.3f' % ('$label', '$m', d['ms_per_step'], g('walk'), g('analysis'), g('tension')))
 except Exception as e:
     print('$label $m FAILED', e)
 " | tee -a "$OUT/${TAG}_ab.txt"
