@@ -13,7 +13,7 @@ wcap = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
 rate, skip = 16000, 4
 minP, maxP = rate // 400, rate // 65
 minC, nC = minP // skip, maxP // skip - minP // skip + 1
-NWM = 4
+NWM = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 FCMD_INTS = 64
 # layout (fast_lds_layout_i)
 o = 0
