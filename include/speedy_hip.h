@@ -132,6 +132,9 @@ int spx_debug_last_walk_form(void);
  * decide the concurrent mode.  which: 0 tension, 1 walk 16 kHz mono (4 + 4 waves, long window), 2 walk 22.05 kHz mono lean
  * (4 + 0), 3 analysis 16 kHz, 4 analysis 22.05 kHz, 5 walk 16 kHz multi-channel (4 + 4).  -1 for an unknown index. */
 int spx_debug_kernel_vgprs(int which);
+/* Diagnostics: 1 if the last spx_batch_run / analyze+walk call of this process took the concurrent three-kernel mode, 0 if it
+ * launched its kernels in sequence (another process holds the device's concurrent-mode lock, a tuning variable, the batch shape). */
+int spx_debug_last_call_concurrent(void);
 /* Sum over the same calls of the frame-rate (tension) kernel's time, as of the last spx_timing_collect. */
 double spx_timing_last_tension_ms(void);
 

@@ -57,6 +57,7 @@ SYMBOLS = {
     "spx_batch_kernel_names": (C.c_char_p, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "spx_debug_last_walk_form": (C.c_int, []),
     "spx_debug_kernel_vgprs": (C.c_int, [C.c_int]),
+    "spx_debug_last_call_concurrent": (C.c_int, []),
     "spx_device_alloc": (C.c_void_p, [C.c_size_t]),
     "spx_device_free": (None, [C.c_void_p]),
     "spx_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

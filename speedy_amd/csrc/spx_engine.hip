@@ -100,6 +100,7 @@ struct spx_plan {
 // Process-wide switches are atomics; the event lists behind spx_timing_collect are guarded by g_tmu.  spx_batch_run may be
 // called from several host threads (one plan per thread, or one plan shared: launches on a plan are serialised by its mutex).
 static std::atomic<bool> g_timing{false};
+static std::atomic<int> g_last_concurrent{0};   // spx_debug_last_call_concurrent
 static std::atomic<int> g_concurrent{1};  // spx_set_concurrent: analysis and walk kernels on two streams, tile-flag hand-off
 static std::atomic<bool> g_chunks_set{false};  // the caller chose a chunk count (spx_set_pipeline_chunks)
 static std::atomic<int> g_chunks{1};  // spx_set_pipeline_chunks (measured on MI355X, 256 x 10 s: 1 -> 5.09 ms, 2 -> 5.25, 4 -> 5.54 per step)
@@ -676,6 +677,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   SpxTapsDev td = taps_of(taps);
   const bool timed = g_timing.load() && do_a && do_w;
   const bool concurrent = want_concurrent && nch == 1 && tiles[0] > 0;
+  if (do_a && do_w) g_last_concurrent.store(concurrent ? 1 : 0, std::memory_order_relaxed);
   static const bool dbg_mode = getenv("SPX_DEBUG_MODE") != nullptr;   // one line per call: what was decided and why
   if (dbg_mode)
     fprintf(stderr, "[spx mode] rate %d n %d maxC %d: co_resident %d doubtful %d lean %d want_concurrent %d chunks %d tiles %d -> %s\n", d.rate, n,
@@ -1044,6 +1046,7 @@ const char* spx_batch_kernel_names(spx_plan_t plan, int n_streams, int max_chann
   return buf;
 }
 
+int spx_debug_last_call_concurrent(void) { return g_last_concurrent.load(std::memory_order_relaxed); }
 int spx_debug_kernel_vgprs(int which) {
   if (which == 0) return spx_tension_vgprs();
   const int rate = (which == 2 || which == 4) ? 22050 : 16000;

@@ -609,6 +609,8 @@ def test_walk_form_follows_the_co_residency_arithmetic(orc):
         b.run()
         outs = b.results()
         forms[(rate, ch)] = L.spx_debug_last_walk_form()
+        if (rate, ch) == (16000, 1) and not L.spx_debug_last_call_concurrent():
+            pytest.skip("the concurrent mode is not available to this process (another process holds the device's lock?)")
         for x, got in zip(xs, outs):
             ref = orc.compress_sound(x, rate, ch, 3.5, 1.0, 0.0, False, chunk=n, taps=False)["out"]
             assert np.array_equal(got, ref)
