@@ -10,6 +10,17 @@ collectives are the work-partition handshake and the barrier / MAX-reduce of the
 by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or directly: `python bench.py --gpus N`
 starts the N rank processes itself, before anything touches the GPU.
 
+Beside `value` the line carries (every figure ONE timed window of consecutive steps, no best-of-N anywhere):
+  roofline            HBM (the contract's), plus `latency` (walk kernel: cycles per dependent pitch step against the modelled floor)
+                      and `valu_fp64` (analysis kernel alone: fp64 operations of the DFT spec per second against the vector peak)
+  large_batch         2 048 streams x 10 s in ONE call: the throughput regime, HBM fraction
+  pcie_inclusive      pinned host -> HBM -> step -> gather -> host, double-buffered
+  config4_shard       one GPU's 256-stream shard of BASELINE configs[4] (weak: every rank its shard)
+  config4_full        ALL of configs[4]: the fixed batch of --total-streams (2 048) mixed streams, rank r of N takes block r
+                      (STRONG scaling; N = 1 runs all of it in one call)
+  api_256_handles     the drop-in API with 256 live sonicStream handles on one host thread
+  cpu_baseline        the CPU port on the host cores, with the output CRCs of the GPU legs checked against it
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -29,6 +40,7 @@ sys.path.insert(0, ROOT)
 
 RATE, SECONDS, STREAMS_PER_GPU, SPEED = 16000, 10, 256, 3.5
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TFLOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # fp64 vector operations/s without FMA: 39.3 (see `peak_source` in the line)
 
 
 def make_streams(n_streams, n, rank):
@@ -77,11 +89,13 @@ def usable_cpus():
     return n, quota
 
 
-def cpu_baseline(streams, gpu_outputs, budget_s=12.0):
+def cpu_baseline(streams, gpu_outputs, budget_s=12.0, c4_checks=None):
     """The CPU oracle (kind "port": C restatement of the reference path; the reference itself is unbuildable here,
     DESIGN.md "Oracle") on the host cores of this machine: oracle/orc_bench.c -- POSIX threads, one stream per task,
     the speedy_wave.cc write-1000/read loop per stream -- built here with -O3 -march=native -ffp-contract=off.
-    A bounded sample of the SAME streams; the output CRC of each sampled stream is compared with the GPU's."""
+    A bounded sample of the SAME streams; the output CRC of each sampled stream is compared with the GPU's.
+    c4_checks: {name: (streams, global ids, gpu crcs)} of the configs[4] legs -- a sample of every kind of every shard is run
+    through the port as well and its CRCs compared (the checker's only other use in this file)."""
     subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "liborc_bench.so"])
     L = C.CDLL(os.path.join(ROOT, "oracle", "liborc_bench.so"))
     L.orc_bench_run.restype = C.c_double
@@ -90,11 +104,12 @@ def cpu_baseline(streams, gpu_outputs, budget_s=12.0):
     cores, quota = usable_cpus()
     n = streams[0].size
 
-    def run(sample, threads):
+    def run(sample, threads, rate=RATE, ch=1, speed=SPEED):
         buf = np.ascontiguousarray(np.concatenate(sample), np.int16)
         frames = (C.c_long * len(sample))()
         crcs = (C.c_uint32 * len(sample))()
-        dt = L.orc_bench_run(buf.ctypes.data, n, len(sample), RATE, 1, SPEED, 1.0, 0.0, 0, 1000, threads, frames, crcs)
+        dt = L.orc_bench_run(buf.ctypes.data, sample[0].size // ch, len(sample), rate, ch, speed, 1.0, 0.0, 0, 1000, threads,
+                             frames, crcs)
         return dt, list(crcs)
 
     one, _ = run(streams[:1], 1)                       # single-thread rate, also sizes the sample
@@ -103,53 +118,85 @@ def cpu_baseline(streams, gpu_outputs, budget_s=12.0):
     dt, crcs = run(sample, cores)
     mismatched = sum(1 for i, c in enumerate(crcs)
                      if c != zlib.crc32(np.ascontiguousarray(gpu_outputs[i % len(streams)]).tobytes()))
-    return {"value": k * n / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "cpu_model": cpu_model(), "host_hw_threads": os.cpu_count(), "cgroup_cpu_quota": quota,
-            "single_thread_msamples_s": n / one / 1e6,
-            "thread_scaling": (k * n / dt) / (n / one),
-            "output_crc_mismatches_vs_gpu": mismatched,
-            "sample": "%d streams (the %d bench streams%s, %d s each), one stream per task on %d POSIX threads, "
-                      "oracle built -O3 -march=native -ffp-contract=off (oracle/orc_bench.c)"
-                      % (k, len(streams), ", cycled" if k > len(streams) else "", SECONDS, cores)}
+    res = {"value": k * n / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+           "cpu_model": cpu_model(), "host_hw_threads": os.cpu_count(), "cgroup_cpu_quota": quota,
+           "single_thread_msamples_s": n / one / 1e6,
+           "thread_scaling": (k * n / dt) / (n / one),
+           "output_crc_mismatches_vs_gpu": mismatched,
+           "sample": "%d streams (the %d bench streams%s, %d s each), one stream per task on %d POSIX threads, "
+                     "oracle built -O3 -march=native -ffp-contract=off (oracle/orc_bench.c)"
+                     % (k, len(streams), ", cycled" if k > len(streams) else "", SECONDS, cores)}
+    if c4_checks:
+        from speedy_amd import config4 as C4
+        chk = {}
+        for name, (c4_streams, ids, gpu_crcs) in c4_checks.items():
+            # per kind (rate, channels, speed): the first stream of that kind in every block of 256 (every GPU's shard), at most 16
+            bad = total = 0
+            for kind in range(8):
+                pick = [j for j, i in enumerate(ids) if C4.kind(i) == kind and (i % 256) < 8][:16]
+                if not pick:
+                    continue
+                rate, ch, speed = C4.cfg(ids[pick[0]])
+                _, cr = run([c4_streams[j] for j in pick], min(cores, len(pick)), rate, ch, speed)
+                bad += sum(1 for j, c in zip(pick, cr) if c != gpu_crcs[j])
+                total += len(pick)
+            chk[name] = {"streams_checked": total, "output_crc_mismatches_vs_gpu": bad}
+        res["config4_crc_check"] = chk
+    return res
 
 
-def api_many_handles(streams=256, seconds=10.0):
+def api_many_handles(streams=256, seconds=40.0):
     """The same configuration through the reference's own API (include/sonic2.h): 256 live sonicStream handles on ONE host
     thread, every round writes 1000 frames to each handle and then reads from each (speedy_wave.cc:199-220 per handle).
-    A C program (tools/stream_bench.c) in a child process; host-to-device and device-to-host transfers included."""
+    A C program (tools/stream_bench.c) in a child process; host-to-device and device-to-host transfers included.  ONE run
+    (one timed window of seconds * 16 rounds), like every other figure of the line."""
     exe = os.path.join(ROOT, "speedy_amd", "lib", "stream_bench")
     try:
         if not os.path.exists(exe):
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "speedy_amd", "csrc"), "streambench"])
-        best = None
-        for _ in range(3):   # a run is ~30 ms long: the fastest of three
-            out = subprocess.run([exe, str(streams), str(seconds), "1000", str(SPEED), "1", "rounds", str(RATE)],
-                                 capture_output=True, text=True, timeout=300)
-            if out.returncode != 0:
-                return {"error": out.stderr.strip()[-300:]}
-            r = json.loads(out.stdout.strip().splitlines()[-1])
-            if best is None or r["msamples_per_s"] > best["msamples_per_s"]:
-                best = r
+        out = subprocess.run([exe, str(streams), str(seconds), "1000", str(SPEED), "1", "rounds", str(RATE)],
+                             capture_output=True, text=True, timeout=600)
+        if out.returncode != 0:
+            return {"error": out.stderr.strip()[-300:]}
+        best = json.loads(out.stdout.strip().splitlines()[-1])
         return {"value": best["msamples_per_s"], "unit": "Msamples/s", "streams": streams, "chunk_frames": 1000,
                 "x_realtime_per_stream": best["x_realtime_per_stream"], "us_per_round": best["us_per_round"],
-                "handles_per_launch_sequence": best["handles_per_sequence"],
+                "handles_per_launch_sequence": best["handles_per_sequence"], "seconds_per_handle": seconds,
                 "note": "sonicWriteShortToStream x %d handles, then sonicReadShortFromStream x %d handles, per round; one host "
                         "thread; staged writes of all handles run as one launch sequence (sonic2_pool.hip); synthetic "
-                        "speech-like input generated in C" % (streams, streams)}
+                        "speech-like input generated in C; one run" % (streams, streams)}
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)[:300]}
 
 
-def config4_shard(rank, reps=10):
-    """One GPU's shard of BASELINE configs[4]: 256 streams x 10 s, 16 kHz / 22.05 kHz, mono / stereo, 1.5x / 3.5x, all in ONE
-    spx_batch_run_mixed call per step, inputs resident in HBM.  Returns (seconds per step, input frames per step)."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import bench_config4 as c4
+def time_window(run, reps, warm):
+    """ONE timed window of `reps` consecutive steps after `warm` untimed ones (each followed by a synchronisation: the
+    engine's launch-mode trial of a batch shape needs three completed calls).  Seconds per step."""
+    import torch
+    for _ in range(warm):
+        run()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def config4_leg(ids, reps, warm=4):
+    """The global configs[4] streams `ids` in ONE spx_batch_run_mixed call per step, inputs resident in HBM.
+    Returns dict(seconds per step, input frames, streams, crcs, algorithmic bytes, kernel names)."""
+    from speedy_amd import config4 as C4
     from speedy_amd.batch import Plan
-    streams = c4.shard_streams(256, seed0=4000 + 256 * rank)
-    plans = [Plan(r, False) for r in c4.RATES]
-    b = c4.mixed_batch(plans, streams)
-    return c4.time_steps(b.run, reps=reps), sum(10 * c4.cfg(i)[0] for i in range(256))
+    streams = C4.make_streams(ids, threads=max(1, min(16, usable_cpus()[0])))
+    plans = [Plan(r, False) for r in C4.RATES]
+    b = C4.mixed_batch(plans, ids, streams)
+    dt = time_window(b.run, reps, warm)
+    counts = b.counts()
+    crcs = b.crcs()
+    steps = b.step_counts()
+    return {"dt": dt, "frames": C4.input_frames(ids), "streams": streams, "crcs": crcs,
+            "algo_bytes": C4.algorithmic_bytes(ids, counts), "steps": steps, "out_frames": int(counts.sum())}
 
 
 def spawn_ranks(args):
@@ -245,6 +292,36 @@ def pcie_pipeline(plan, streams, n, reps, warm=2):
     return dt, totals[-1]
 
 
+def standalone_analysis_ms(plan, batch, reps=10, warm=3):
+    """The analysis kernel ALONE on the batch (spx_batch_analyze on the current stream: nothing beside it), HIP events around
+    one window of `reps` launches.  Milliseconds per launch."""
+    import torch
+    L = plan.L
+    hs = torch.cuda.current_stream().cuda_stream
+
+    def launch():
+        rc = L.spx_batch_analyze(plan.h, batch.jobs, batch.n, batch.d_in.data_ptr(), batch.d_ws.data_ptr(), batch.d_ws.numel(), None, hs)
+        if rc != 0:
+            raise RuntimeError("spx_batch_analyze: " + L.spx_last_error().decode())
+    for _ in range(warm):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def load_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -252,12 +329,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true")
-    ap.add_argument("--no-config4", action="store_true", help="skip the configs[4] shard (256 mixed-rate streams in one call)")
+    ap.add_argument("--no-config4", action="store_true", help="skip both configs[4] legs (the 256-stream shard and the full batch)")
+    ap.add_argument("--no-config4-full", action="store_true", help="skip the full configs[4] batch (strong scaling leg)")
+    ap.add_argument("--total-streams", type=int, default=2048,
+                    help="configs[4] as a whole: the fixed batch of this many mixed streams, N ranks take 1/N each (strong "
+                         "scaling; N = 1 runs all of it in one call); reported as config4_full")
+    ap.add_argument("--no-large-batch", action="store_true", help="skip the 2 048-stream call of the headline kind")
     ap.add_argument("--no-api", action="store_true", help="skip the many-handle run of the drop-in API (tools/stream_bench.c)")
     ap.add_argument("--chunks", type=int, default=int(os.environ.get("SPX_CHUNKS", "1")),
                     help="time chunks per stream inside one spx_batch_run (analysis of chunk c+1 overlaps the walk of c)")
     ap.add_argument("--crc-out", default=None, help="write this rank's per-stream output CRC-32s to CRC_OUT.rank<r>.json "
-                    "(tests: N-rank runs must produce the same bytes per stream as solo runs)")
+                    "(tests: N-rank runs must produce the same bytes per stream as solo runs); the configs[4] legs' CRCs "
+                    "go to CRC_OUT.c4.rank<r>.json keyed by global stream index")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for "
                     "a functional check of the N > 1 path when several ranks share one GPU)")
     args = ap.parse_args()
@@ -330,6 +413,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def sum_over_ranks(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
     for _ in range(args.warmup):
         b.run()
     barrier()
@@ -347,35 +437,93 @@ def main():
     n_in = n * STREAMS_PER_GPU
     outs = b.results()
     n_out = int(sum(o.size for o in outs))
+    chain_steps = b.step_counts()         # pitch searches per stream: the length of every stream's dependent chain
     if args.crc_out:
         with open("%s.rank%d.json" % (args.crc_out, rank), "w") as f:
             json.dump([zlib.crc32(np.ascontiguousarray(o).tobytes()) for o in outs], f)
+
+    # the analysis kernel alone (its fp64 vector roofline), rank 0's device
+    ms_analysis_alone = standalone_analysis_ms(plan, b) if rank == 0 else None
+
+    # the throughput regime: 2 048 streams of the headline kind in ONE call (the 256 bench streams, eight times), rank 0's device
+    large = None
+    if not args.no_large_batch and rank == 0:
+        nl = 8 * STREAMS_PER_GPU
+        bl = Batch(plan, [n] * nl, 1, SPEED, 1.0, 0.0)
+        bl.d_in[: n * nl].copy_(b.d_in[: n * STREAMS_PER_GPU].repeat(8))
+        dtl = time_window(bl.run, reps=5, warm=3)
+        nout_l = bl.d_nout.cpu().numpy()
+        assert (nout_l > 0).all()
+        algo_l = 2 * (n * nl + int(nout_l.sum()))
+        ka, kt, kw = L.spx_batch_kernel_names(plan.h, nl, 1, 1).decode().split(";")
+        large = {"streams": nl, "ms_per_step": dtl * 1e3, "value": n * nl / dtl / 1e6, "unit": "Msamples/s",
+                 "hbm": {"achieved": algo_l / dtl / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo_l / dtl / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_step": algo_l, "of": "the whole call (analysis, tension and walk kernels of two pipelined time chunks)"},
+                 "kernels": {"analysis": ka, "tension": kt, "walk": kw},
+                 "note": "BASELINE configs[3]'s kind at eight times its batch: %d x %d s, 16 kHz mono, 3.5x nonlinear, ONE spx_batch_run "
+                         "per step (the 256 bench streams, eight times); the walk kernel in its throughput form" % (nl, SECONDS)}
+        del bl
+        torch.cuda.empty_cache()
 
     # PCIe-inclusive steady state on every rank, MAX over ranks (reported beside `value`, which by the bench contract is
     # the rate with inputs already resident in HBM)
     pcie = None
     if not args.no_pcie:
         barrier()
-        # three passes, the fastest counts: a pass is only ~25 ms long and shares the box's PCIe and host with whatever else runs
-        dt1, total = min(pcie_pipeline(plan, streams, n, reps=max(4, min(args.steps, 10))) for _ in range(3))
+        dt1, total = pcie_pipeline(plan, streams, n, reps=max(10, args.steps))
         assert total == n_out, (total, n_out)
         dt1 = max_over_ranks(dt1)
         pcie = {"value": n_in * world / dt1 / 1e6, "unit": "Msamples/s", "ms_per_step": dt1 * 1e3,
                 "vs_resident_step": dt1 / (dt / args.steps),
                 "note": "every rank, MAX over ranks: pinned host int16 input -> HBM, the step, device-side gather, one D2H "
                         "of the produced int16 output; double-buffered on three HIP streams (H2D of batch k+1 and D2H "
-                        "of batch k-1 overlap the step of batch k)"}
+                        "of batch k-1 overlap the step of batch k); one window of %d batches" % max(10, args.steps)}
 
-    # BASELINE configs[4], one GPU's shard per rank (256 mixed-rate streams in one call), MAX over ranks
-    c4 = None
+    # BASELINE configs[4].  (1) WEAK: every rank one GPU's shard of 256 mixed streams (global streams 256 r .. 256 r + 255) in
+    # one call.  (2) STRONG: the fixed batch of --total-streams streams, rank r of N its contiguous block, one call per rank.
+    c4 = c4f = None
+    c4_checks = {}
+    c4_crc_dump = {}
     if not args.no_config4:
+        from speedy_amd import config4 as C4
         barrier()
-        dt4, frames4 = config4_shard(rank)
-        dt4 = max_over_ranks(dt4)
-        c4 = {"value": frames4 * world / dt4 / 1e6, "unit": "Msamples/s", "ms_per_step": dt4 * 1e3, "streams_per_gpu": 256,
-              "note": "BASELINE configs[4], every rank its shard of 256 streams x 10 s (stream i: 16 kHz if i even else 22.05 kHz; "
-                      "mono if (i/2) even else stereo; speed 1.5 if (i/4) even else 3.5; nonlinear 1), ONE spx_batch_run_mixed "
-                      "call per step, inputs resident in HBM, MAX over ranks; input sample frames of all ranks / that time"}
+        ids = list(range(256 * rank, 256 * (rank + 1)))
+        leg = config4_leg(ids, reps=10)
+        dt4 = max_over_ranks(leg["dt"])
+        frames4 = sum_over_ranks(leg["frames"])
+        c4 = {"value": frames4 / dt4 / 1e6, "unit": "Msamples/s", "ms_per_step": dt4 * 1e3, "streams_per_gpu": 256,
+              "hbm_frac": sum_over_ranks(leg["algo_bytes"]) / dt4 / 1e9 / (HBM_PEAK_GBS * world),
+              "chain_steps_max": int(leg["steps"].max()),
+              "note": "BASELINE configs[4], WEAK: every rank its shard of 256 streams x 10 s (global stream i: 16 kHz if i even else "
+                      "22.05 kHz; mono if (i/2) even else stereo; speed 1.5 if (i/4) even else 3.5; nonlinear 1; 2 048 distinct signals, "
+                      "seed 4000 + i), ONE spx_batch_run_mixed call per step, inputs resident in HBM, MAX over ranks; input sample "
+                      "frames of all ranks / that time"}
+        c4_checks["config4_shard"] = (leg["streams"], ids, leg["crcs"])
+        c4_crc_dump.update({str(i): c for i, c in zip(ids, leg["crcs"])})
+        if not args.no_config4_full:
+            total = args.total_streams
+            barrier()
+            ids_f = C4.rank_ids(rank, world, total)
+            if ids_f == ids:       # (N = 8: a rank's block of the full batch IS its shard)
+                legf = leg
+            else:
+                del leg
+                legf = config4_leg(ids_f, reps=6, warm=4)
+            dtf = max_over_ranks(legf["dt"])
+            frames_f = sum_over_ranks(legf["frames"])
+            c4f = {"value": frames_f / dtf / 1e6, "unit": "Msamples/s", "ms_per_step": dtf * 1e3, "total_streams": total,
+                   "streams_per_gpu": len(ids_f), "scaling": "strong",
+                   "hbm_frac": sum_over_ranks(legf["algo_bytes"]) / dtf / 1e9 / (HBM_PEAK_GBS * world),
+                   "note": "BASELINE configs[4] as a whole, STRONG scaling: the fixed batch of %d mixed streams x 10 s (same global "
+                           "sequence as config4_shard), rank r of N takes the contiguous block r (stream i -> GPU i / (%d / N)), ONE "
+                           "spx_batch_run_mixed call per rank and step, inputs resident in HBM, MAX over ranks; N = 1 runs the whole "
+                           "batch in one call (two groups of %d streams: throughput-form walk kernels, pipelined time chunks)"
+                           % (total, total, total // 2)}
+            c4_checks["config4_full"] = (legf["streams"], ids_f, legf["crcs"])
+            c4_crc_dump.update({str(i): c for i, c in zip(ids_f, legf["crcs"])})
+        if args.crc_out:
+            with open("%s.c4.rank%d.json" % (args.crc_out, rank), "w") as f:
+                json.dump(c4_crc_dump, f)
 
     if rank == 0:
         total_in = n_in * world * args.steps
@@ -389,21 +537,49 @@ def main():
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
         traffic_note = None
-        pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pj):
-            try:
-                pt = json.load(open(pj))
-                traffic = pt.get(dom, {}).get("hbm_bytes_per_launch")
-                traffic_note = pt.get("_note")
-            except Exception:
-                traffic = None
+        pt = load_json("pmc_traffic.json")
+        if pt:
+            traffic = pt.get(dom, {}).get("hbm_bytes_per_launch")
+            traffic_note = pt.get("_note")
+        # ---- the two rooflines that actually bound the path (SURVEY 8d "report all three") ----
+        clock_mhz = float(getattr(torch.cuda.get_device_properties(dev_index), "clock_rate", 2400000)) / 1e3   # nominal shader clock (2 400 MHz)
+        lm = load_json("latency_model.json")
+        fm = load_json("flop_model.json")
+        smax, smean = int(chain_steps.max()), float(chain_steps.mean())
+        latency = None
+        if lm and smax > 0 and ms_walk > 0:
+            cyc = ms_walk * 1e-3 * clock_mhz * 1e6 / smax
+            latency = {"bound": "latency of the per-stream chain of dependent pitch steps (one stream per CU)", "kernel": k_walk,
+                       "steps_per_stream": {"max": smax, "mean": smean, "min": int(chain_steps.min()),
+                                            "source": "counted by the walk kernel itself (spx_batch_read_steps)"},
+                       "clock_mhz": clock_mhz,
+                       "achieved_cycles_per_step": cyc, "model_floor_cycles_per_step": lm["floor_cycles_per_step"],
+                       "frac": lm["floor_cycles_per_step"] / cyc,
+                       "definition": "achieved = walk kernel ms x nominal clock / steps of the LONGEST chain (the kernel ends with its "
+                                     "slowest stream; its first ~85 us wait for speeds are inside); floor = tools/latency_model.py "
+                                     "(profiles/latency_model.json: dependent latencies of one step priced with "
+                                     "tools/ubench/issue_costs.hip); frac = floor / achieved"}
+        valu = None
+        if fm and ms_analysis_alone:
+            frames = int(sum(b.frames))
+            flop = fm[str(RATE)]["flop_per_frame"]
+            tf = flop * frames / (ms_analysis_alone * 1e-3) / 1e12
+            peak = FP64_VALU_PEAK_TFLOPS
+            valu = {"bound": "fp64 vector ALU", "kernel": k_analysis, "flop_per_frame": flop, "frames_per_launch": frames,
+                    "standalone_ms": ms_analysis_alone, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                    "peak_source": "MI355X fp64 vector rate WITHOUT fused multiply-add: 256 CUs x 4 SIMDs x 16 fp64 lanes/clk x 2.4 GHz "
+                                   "= 39.3 T operations/s (half of the 78.6 TFLOP/s FMA figure, itself half of the guide's 157.3 fp32); "
+                                   "the path cannot contract to FMA: its rounding points are the reference's (-ffp-contract=off)",
+                    "definition": "fp64 operations of the DFT spec per frame (tools/flop_count.py, profiles/flop_model.json) x frames / "
+                                  "the analysis kernel ALONE (spx_batch_analyze, one window of 10 launches, HIP events)"}
         line = {
             "metric": "Msamples/s processed (16 kHz mono, 3.5x nonlinear)",
             "value": total_in / dt / 1e6, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "value_definition": "input sample frames of all ranks x steps / MAX-over-ranks wall time of the timed steps, inputs "
                                 "resident in HBM when the timed region starts (the bench contract's definition); SURVEY 8(d)'s "
                                 "first-write-to-last-drained-read rate is `pcie_inclusive`, the drop-in API's rate with 256 "
-                                "live sonicStream handles is `api_256_handles`",
+                                "live sonicStream handles is `api_256_handles`.  ONE rule for every figure in this line: a single "
+                                "timed window of consecutive steps after untimed warm-up steps -- no best-of-N anywhere",
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16 samples; f64 DFT, f32 features, int32 AMDF/OLA",
             "data": "synthetic",
@@ -431,16 +607,26 @@ def main():
                                                   k_walk: ms_walk / args.chunks},
                          "limiter": "latency, not HBM: 256 per-stream chains of ~1300 dependent pitch steps, one "
                                     "workgroup per CU (DESIGN.md 5.3, 6); `bound` names the roofline the contract asks "
-                                    "to be priced against"},
+                                    "to be priced against; `latency` and `valu_fp64` are the rooflines that bound the two "
+                                    "big kernels, `large_batch.hbm` the HBM fraction where the path is throughput-bound",
+                         "latency": latency, "valu_fp64": valu},
         }
+        if large is not None:
+            line["large_batch"] = large
         if pcie is not None:
             line["pcie_inclusive"] = pcie
         if c4 is not None:
             line["config4_shard"] = c4
+        if c4f is not None:
+            line["config4_full"] = c4f
         if not args.no_api and world == 1:
             line["api_256_handles"] = api_many_handles()
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (bench contract)
-            line["cpu_baseline"] = cpu_baseline(streams, outs)
+            line["cpu_baseline"] = cpu_baseline(streams, outs, c4_checks=c4_checks)
+            for name, r in line["cpu_baseline"].get("config4_crc_check", {}).items():
+                if name in line:
+                    line[name]["output_crc_mismatches_vs_cpu_port"] = r["output_crc_mismatches_vs_gpu"]
+                    line[name]["streams_checked_against_cpu_port"] = r["streams_checked"]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -96,6 +96,11 @@ sonicStream speedyHipCreateSonicStream(int sampleRate, int numChannels, int matc
  * call; a server that writes to all its streams and then reads from all of them pays one launch sequence per round
  * instead of one per stream.  Streams of one device may be used from different threads (the pool is locked). */
 void speedyHipSetCoalescing(int on);
+int speedyHipGetCoalescing(void);
+/* sonicCreateStream with the hysteresis shape AND the execution path chosen for this handle alone: coalesce = -1 the
+ * process-wide default above, 0 = the handle runs its own launch sequence per write, 1 = coalesced.  Nothing process-wide
+ * is read or written for an explicit 0 / 1, so handles of both kinds can be created from several threads at once. */
+sonicStream speedyHipCreateSonicStreamEx(int sampleRate, int numChannels, int matchMatlab, int coalesce);
 /* Launch sequences run / stream jobs served by the current device's pool so far. */
 void speedyHipPoolStats(unsigned long long* runs, unsigned long long* jobs);
 /* Frames currently readable without blocking on new input. */

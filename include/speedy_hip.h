@@ -108,6 +108,14 @@ int spx_batch_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_j
                         int n_streams, const int16_t* in, int16_t* out, int64_t* n_out, void* workspace,
                         size_t workspace_bytes, void* hip_stream);
 
+/* The same with the debug taps.  Row order: streams grouped by plan index ascending, job order inside a group; row r of a
+ * stream lives at index tap_off[s] + r with tap_off[s] = the analysis-frame counts (spx_plan_frames on the stream's own plan,
+ * 0 for a linear job) of every stream in front of it in THAT order.  spectrogram / normalized rows are as wide as the
+ * stream's own plan makes them (N, W): their element offsets are the sums of frames x width of the streams in front. */
+int spx_batch_run_mixed_taps(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index,
+                             int n_streams, const int16_t* in, int16_t* out, int64_t* n_out, void* workspace,
+                             size_t workspace_bytes, const spx_taps* taps, void* hip_stream);
+
 /* Timing hooks for bench.py: while enabled, every spx_batch_run records HIP events on hip_stream around
  * each of its kernels (no host synchronisation is added to the call).  spx_timing_collect waits for the
  * recorded events, returns the summed kernel milliseconds (over all launches of each kernel) and the number of
@@ -137,6 +145,14 @@ int spx_debug_kernel_vgprs(int which);
 int spx_debug_last_call_concurrent(void);
 /* Sum over the same calls of the frame-rate (tension) kernel's time, as of the last spx_timing_collect. */
 double spx_timing_last_tension_ms(void);
+
+/* Diagnostics: the number of pitch searches (libsonic's findPitchPeriod calls) each stream's walk ran in the batch's last
+ * call -- the length of the stream's chain of dependent steps, which is what bounds a call with one stream per CU.
+ *   workspace  DEVICE  the workspace that call ran with;  steps  HOST  int32[n_streams].  Waits for hip_stream first. */
+int spx_batch_read_steps(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, const void* workspace,
+                         int32_t* steps, void* hip_stream);
+int spx_batch_read_steps_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index,
+                               int n_streams, const void* workspace, int32_t* steps, void* hip_stream);
 
 /* ---- plain device-memory helpers (so that C/C++ hosts need no HIP headers) ---- */
 void* spx_device_alloc(size_t bytes);

@@ -217,3 +217,37 @@ def compress_sound(x, sample_rate, channels, speed, nonlinear=1.0, feedback=0.0,
     k = nt.value
     return dict(out=out[: n * channels].copy(), tension=ten[:k].copy(), speed=spd[:k].copy(),
                 features=fea[:k].copy())
+
+
+_BENCH = None
+
+
+def bench_lib():
+    """oracle/liborc_bench.so: the same sources plus the POSIX-thread runner (oracle/orc_bench.c), built for this machine."""
+    global _BENCH
+    if _BENCH is None:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liborc_bench.so"])
+        L = C.CDLL(os.path.join(_HERE, "liborc_bench.so"))
+        L.orc_bench_run.restype = C.c_double
+        L.orc_bench_run.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _BENCH = L
+    return _BENCH
+
+
+def crc_streams(streams, sample_rate, channels, speed, nonlinear=1.0, feedback=0.0, match_matlab=False, chunk=1000,
+                threads=None):
+    """The speedy_wave.cc loop of compress_sound over equally long streams of one kind on `threads` POSIX threads (one
+    stream per task): returns (wall seconds, frames produced per stream, CRC-32 of each stream's int16 output bytes)."""
+    L = bench_lib()
+    n = np.asarray(streams[0]).size // channels
+    assert all(np.asarray(x).size == n * channels for x in streams)
+    buf = np.ascontiguousarray(np.concatenate([np.asarray(x, np.int16).ravel() for x in streams]), np.int16)
+    frames = (C.c_long * len(streams))()
+    crcs = (C.c_uint32 * len(streams))()
+    if threads is None:
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        threads = max(1, min(threads, 16, len(streams)))
+    dt = L.orc_bench_run(buf.ctypes.data, n, len(streams), int(sample_rate), int(channels), float(speed), float(nonlinear),
+                         float(feedback), int(bool(match_matlab)), int(chunk), int(threads), frames, crcs)
+    return dt, list(frames), list(crcs)

@@ -45,6 +45,11 @@ SYMBOLS = {
     "spx_batch_workspace_bytes_mixed": (C.c_size_t, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(StreamJob), C.POINTER(C.c_int), C.c_int]),
     "spx_batch_run_mixed": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(StreamJob), C.POINTER(C.c_int), C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "spx_batch_run_mixed_taps": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(StreamJob), C.POINTER(C.c_int), C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Taps), C.c_void_p]),
+    "spx_batch_read_steps": (C.c_int, [C.c_void_p, C.POINTER(StreamJob), C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "spx_batch_read_steps_mixed": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(StreamJob), C.POINTER(C.c_int), C.c_int,
+                                             C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "spx_batch_analyze": (C.c_int, [C.c_void_p, C.POINTER(StreamJob), C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_size_t, C.POINTER(Taps), C.c_void_p]),
     "spx_batch_walk": (C.c_int, [C.c_void_p, C.POINTER(StreamJob), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -143,6 +148,8 @@ SYMBOLS = {
     "speedyHipSetMatchMatlab": (None, [C.c_int]),
     "speedyHipCreateSonicStream": (C.c_void_p, [C.c_int, C.c_int, C.c_int]),
     "speedyHipSetCoalescing": (None, [C.c_int]),
+    "speedyHipGetCoalescing": (C.c_int, []),
+    "speedyHipCreateSonicStreamEx": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "speedyHipPoolStats": (None, [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "sonicSamplesAvailable": (C.c_int, [C.c_void_p]),
     "speedyHipLastError": (C.c_char_p, []),

@@ -109,6 +109,16 @@ class Batch:
         if rc != 0:
             raise RuntimeError("spx_batch_run: " + self.plan.L.spx_last_error().decode())
 
+    def step_counts(self):
+        """Pitch searches per stream of the last run (the length of each stream's dependent chain); synchronises."""
+        steps = (C.c_int32 * self.n)()
+        rc = self.plan.L.spx_batch_read_steps(self.plan.h, self.jobs, self.n, self.d_ws.data_ptr(), steps,
+                                              torch.cuda.current_stream(self.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError("spx_batch_read_steps: " + self.plan.L.spx_last_error().decode())
+        torch.cuda.synchronize(self.device)
+        return np.frombuffer(steps, np.int32).copy()
+
     def results(self):
         """Synchronise and return per-stream int16 outputs (host numpy)."""
         torch.cuda.synchronize(self.device)
@@ -158,11 +168,12 @@ class MixedBatch:
     """Streams of DIFFERENT sample rates in one call (spx_batch_run_mixed): stream i is served by plans[plan_index[i]].
     Inputs and outputs are packed like Batch's; results() returns the outputs in the order the streams were given."""
 
-    def __init__(self, plans, plan_index, lengths, channels, speed, nonlinear=1.0, feedback=0.0, device="cuda"):
+    def __init__(self, plans, plan_index, lengths, channels, speed, nonlinear=1.0, feedback=0.0, device="cuda", taps=False):
         n = len(lengths)
         self.plans, self.n = list(plans), n
         self.L = plans[0].L
-        self.plan_index = (C.c_int * n)(*[int(v) for v in plan_index])
+        self.pidx = [int(v) for v in plan_index]
+        self.plan_index = (C.c_int * n)(*self.pidx)
         self.hplans = (C.c_void_p * len(plans))(*[p.h for p in plans])
         ch = np.broadcast_to(np.asarray(channels, np.int32), (n,)).copy()
         sp = np.broadcast_to(np.asarray(speed, np.float32), (n,)).copy()
@@ -171,14 +182,16 @@ class MixedBatch:
         self.lengths, self.channels = np.asarray(lengths, np.int64), ch
         self.jobs = (StreamJob * n)()
         in_off = out_off = 0
-        self.in_offs, self.out_offs = [], []
+        self.in_offs, self.out_offs, self.frames = [], [], []
         for i in range(n):
-            cap = plans[int(plan_index[i])].out_capacity(int(self.lengths[i]), float(sp[i]), float(nlv[i]))
+            pl = plans[self.pidx[i]]
+            cap = pl.out_capacity(int(self.lengths[i]), float(sp[i]), float(nlv[i]))
             j = self.jobs[i]
             j.in_off, j.n_in, j.out_off, j.out_cap = in_off, int(self.lengths[i]), out_off, cap
             j.channels, j.speed, j.nonlinear, j.feedback = int(ch[i]), float(sp[i]), float(nlv[i]), float(fb[i])
             self.in_offs.append(in_off)
             self.out_offs.append(out_off)
+            self.frames.append(pl.frames(int(self.lengths[i])) if nlv[i] != 0 else 0)
             in_off += int(self.lengths[i]) * int(ch[i])
             out_off += cap * int(ch[i])
         dev = torch.device(device)
@@ -191,6 +204,21 @@ class MixedBatch:
         if wsb == 0:
             raise RuntimeError("spx_batch_workspace_bytes_mixed: " + self.L.spx_last_error().decode())
         self.d_ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
+        self.taps = None
+        if taps:
+            # tap rows: streams grouped by plan index, job order inside a group (include/speedy_hip.h)
+            self.tap_off = [0] * n
+            rows = 0
+            for g in range(len(plans)):
+                for i in range(n):
+                    if self.pidx[i] == g:
+                        self.tap_off[i] = rows
+                        rows += self.frames[i]
+            T1 = max(1, rows)
+            self.t_tension = torch.zeros(T1, dtype=torch.float32, device=dev)
+            self.t_speed = torch.zeros(T1, dtype=torch.float32, device=dev)
+            self.t_features = torch.zeros(T1 * 15, dtype=torch.float32, device=dev)
+            self.taps = Taps(self.t_tension.data_ptr(), self.t_speed.data_ptr(), self.t_features.data_ptr(), None, None)
 
     def upload(self, streams):
         host = np.zeros(self.d_in.numel(), np.int16)
@@ -202,19 +230,49 @@ class MixedBatch:
 
     def run(self, stream=None):
         hs = (stream or torch.cuda.current_stream(self.device)).cuda_stream
-        rc = self.L.spx_batch_run_mixed(self.hplans, len(self.plans), self.jobs, self.plan_index, self.n, self.d_in.data_ptr(),
-                                        self.d_out.data_ptr(), self.d_nout.data_ptr(), self.d_ws.data_ptr(),
-                                        self.d_ws.numel(), hs)
+        rc = self.L.spx_batch_run_mixed_taps(self.hplans, len(self.plans), self.jobs, self.plan_index, self.n,
+                                             self.d_in.data_ptr(), self.d_out.data_ptr(), self.d_nout.data_ptr(),
+                                             self.d_ws.data_ptr(), self.d_ws.numel(),
+                                             C.byref(self.taps) if self.taps is not None else None, hs)
         if rc != 0:
             raise RuntimeError("spx_batch_run_mixed: " + self.L.spx_last_error().decode())
 
-    def results(self):
+    def step_counts(self):
+        steps = (C.c_int32 * self.n)()
+        torch.cuda.synchronize(self.device)
+        rc = self.L.spx_batch_read_steps_mixed(self.hplans, len(self.plans), self.jobs, self.plan_index, self.n,
+                                               self.d_ws.data_ptr(), steps, torch.cuda.current_stream(self.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError("spx_batch_read_steps_mixed: " + self.L.spx_last_error().decode())
+        return np.frombuffer(steps, np.int32).copy()
+
+    def counts(self):
+        """Synchronise; produced frames per stream (raises on overflow / a lost producer)."""
         torch.cuda.synchronize(self.device)
         nout = self.d_nout.cpu().numpy()
         if (nout < 0).any():
             raise RuntimeError("output capacity exceeded / lost producer for streams %s" % np.nonzero(nout < 0)[0][:8])
+        return nout
+
+    def results(self):
+        nout = self.counts()
         out = self.d_out.cpu().numpy()
         return [out[self.out_offs[i]:self.out_offs[i] + int(nout[i]) * int(self.channels[i])].copy() for i in range(self.n)]
+
+    def crcs(self):
+        """CRC-32 of every stream's output bytes (what tools/check_scale.py and bench.py compare)."""
+        import zlib
+        nout = self.counts()
+        out = self.d_out.cpu().numpy()
+        return [zlib.crc32(out[self.out_offs[i]:self.out_offs[i] + int(nout[i]) * int(self.channels[i])].tobytes())
+                for i in range(self.n)]
+
+    def tap_arrays(self, i):
+        torch.cuda.synchronize(self.device)
+        fo, T = self.tap_off[i], self.frames[i]
+        K = max(0, T - self.plans[self.pidx[i]].F + 1)
+        return dict(tension=self.t_tension[fo:fo + K].cpu().numpy(), speed=self.t_speed[fo:fo + K].cpu().numpy(),
+                    features=self.t_features[fo * 15:(fo + K) * 15].cpu().numpy().reshape(K, 15))
 
 
 def compress_batch(streams, sample_rate, channels, speed, nonlinear=1.0, feedback=0.0, match_matlab=False,

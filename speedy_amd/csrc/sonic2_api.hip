@@ -77,11 +77,17 @@ extern "C" {
 const char* speedyHipLastError(void) { return g_api_err.c_str(); }
 void speedyHipSetMatchMatlab(int on) { g_match_matlab = on ? 1 : 0; }
 
-sonicStream speedyHipCreateSonicStream(int sampleRate, int numChannels, int matchMatlab);
+sonicStream speedyHipCreateSonicStreamEx(int sampleRate, int numChannels, int matchMatlab, int coalesce);
 sonicStream sonicCreateStream(int sampleRate, int numChannels) {
-  return speedyHipCreateSonicStream(sampleRate, numChannels, g_match_matlab.load());
+  return speedyHipCreateSonicStreamEx(sampleRate, numChannels, g_match_matlab.load(), -1);
 }
 sonicStream speedyHipCreateSonicStream(int sampleRate, int numChannels, int matchMatlab) {
+  return speedyHipCreateSonicStreamEx(sampleRate, numChannels, matchMatlab, -1);
+}
+// coalesce: -1 = the process-wide default (speedyHipSetCoalescing / SPX_NO_POOL), 0 = this handle runs its own launch
+// sequence per write, 1 = this handle is coalesced whatever the default says.  The choice is the handle's: nothing
+// process-wide is written here.
+sonicStream speedyHipCreateSonicStreamEx(int sampleRate, int numChannels, int matchMatlab, int coalesce) {
   if (numChannels < 1) { g_api_err = "sonicCreateStream: numChannels < 1"; return nullptr; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
@@ -115,7 +121,7 @@ sonicStream speedyHipCreateSonicStream(int sampleRate, int numChannels, int matc
   s->dState = reinterpret_cast<SpxStreamState*>(s->dSmall + 256);
   s->dNOut = reinterpret_cast<int64_t*>(s->dSmall + 256 + sizeof(SpxStreamState));  // directly behind the state
   s->dRate = reinterpret_cast<SpxRateState*>(s->dSmall + 256 + sizeof(SpxStreamState) + sizeof(int64_t));
-  if (SpxPool* pool = spx_pool_for_device(s->device)) spx_pool_adopt(pool, s);
+  if (SpxPool* pool = spx_pool_for_device(s->device, coalesce)) spx_pool_adopt(pool, s);
   return s;
 }
 
@@ -179,25 +185,22 @@ static bool sync_stream(sonicStream s) {
   const size_t hbytes = s->rateMode ? sizeof(h) : sizeof(SpxStreamState) + sizeof(int64_t);
   if (hipMemcpyAsync(&h, s->dState, hbytes, hipMemcpyDeviceToHost, s->hs) != hipSuccess ||
       hipStreamSynchronize(s->hs) != hipSuccess) {
-    g_api_err = std::string("stream synchronisation failed: ") + hipGetErrorString(hipGetLastError());
-    s->failed = true;
+    spx_stream_fail(s, std::string("stream synchronisation failed: ") + hipGetErrorString(hipGetLastError()));
     return false;
   }
   int64_t n = h.n;
   if (n == SPX_NOUT_LOST_PRODUCER) {
-    g_api_err = "a producer kernel never delivered its frames (device-side poll limit reached)";
-    s->failed = true;
+    spx_stream_fail(s, "a producer kernel never delivered its frames (device-side poll limit reached)");
     n = s->outKnown;
   } else if (n < 0) {
-    g_api_err = "output capacity exceeded on the device";
-    s->failed = true;
+    spx_stream_fail(s, "output capacity exceeded on the device");
     n = -n;
   }
   s->outKnown = n;
   s->outBound = n;
   if (s->rateMode) {
-    if (h.r.overflow == 2 && !s->failed) { g_api_err = "a producer kernel never delivered its frames (device-side poll limit reached)"; s->failed = true; }
-    else if (h.r.overflow && !s->failed) { g_api_err = "output capacity exceeded on the device (rate stage)"; s->failed = true; }
+    if (h.r.overflow == 2 && !s->failed) spx_stream_fail(s, "a producer kernel never delivered its frames (device-side poll limit reached)");
+    else if (h.r.overflow && !s->failed) spx_stream_fail(s, "output capacity exceeded on the device (rate stage)");
     s->finKnown = h.r.final_n;
     s->finBound = h.r.final_n;
     s->tsmSeenKnown = h.r.tsm_seen;
@@ -459,7 +462,7 @@ static int launch_job(sonicStream s, bool flush, bool direct = false) {
     spx_launch_rate(s->dRate, s->dState, s->dNOut, s->dOut.base(), s->dFinal.base(),
                     (s->dFinal.origin + s->dFinal.cap) / C, (int)C, J.oldR, J.newR, s->rate, s->rate == 1.0f ? 1 : 0,
                     flush ? 1 : 0, s->hs);
-  if (hipGetLastError() != hipSuccess) { g_api_err = "kernel launch failed"; s->failed = true; return 0; }
+  if (hipGetLastError() != hipSuccess) { spx_stream_fail(s, "kernel launch failed"); return 0; }
   const int64_t k_first = std::max(s->tensionDone, s->tensionSkip);
   spx_finish_job(s, J);
   if (J.taps && J.T > J.fa) run_callbacks(s, J.fa, J.T, k_first);
@@ -535,7 +538,7 @@ bool spx_settings_ok(sonicStream s) {
 }
 
 static int write_shorts(sonicStream s, const short* in, int sampleCount, bool direct = false) {
-  if (s->failed || !spx_settings_ok(s)) return 0;
+  if (spx_stream_failed(s) || !spx_settings_ok(s)) return 0;
   const int want = (s->nonlinearFactor != 0.0f && !direct) ? 1 : 0;  // soniclib.c:397: decided anew on every write; sonicInt* bypasses
   // the coalesced path serves plain streams; anything that needs a launch sequence of its own leaves it for good
   if (s->pooled && (direct || s->rate != 1.0f || any_callback(s) || (s->mode >= 0 && s->mode != want)) && !spx_pool_leave(s))
@@ -671,7 +674,7 @@ int sonicGetSampleRate(sonicStream s) { return s->sampleRate; }
 int sonicGetNumChannels(sonicStream s) { return s->channels; }
 
 int sonicFlushStream(sonicStream s) {
-  if (s->failed || !spx_settings_ok(s)) return 0;
+  if (spx_stream_failed(s) || !spx_settings_ok(s)) return 0;
   (void)hipSetDevice(s->device);
   if (s->mode < 0) s->mode = (s->nonlinearFactor != 0.0f) ? 1 : 0;
   if (s->pooled && (s->rate != 1.0f || any_callback(s) || (s->mode == 1 && s->nonlinearFactor == 0.0f)) && !spx_pool_leave(s))
@@ -686,7 +689,7 @@ int sonicFlushStream(sonicStream s) {
   return launch_job(s, true);    // the stream stays usable: a later write continues behind the flush's padding
 }
 int sonicIntFlushStream(sonicStream s) {
-  if (s->failed || !spx_settings_ok(s)) return 0;
+  if (spx_stream_failed(s) || !spx_settings_ok(s)) return 0;
   (void)hipSetDevice(s->device);
   if (s->pooled && !spx_pool_leave(s)) return 0;
   if (s->mode < 0) s->mode = 0;

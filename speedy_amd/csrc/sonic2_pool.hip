@@ -101,12 +101,18 @@ struct SpxPool {
 static SpxPool* g_pools[64];
 static std::mutex g_pools_mu;
 
-SpxPool* spx_pool_for_device(int device) {
+static int coalesce_default() {
   int on = g_coalesce.load();
   if (on < 0) {
     on = getenv("SPX_NO_POOL") ? 0 : 1;
-    g_coalesce.store(on);
+    int expected = -1;
+    g_coalesce.compare_exchange_strong(expected, on);   // (a speedyHipSetCoalescing call that raced us wins)
+    on = g_coalesce.load();
   }
+  return on;
+}
+SpxPool* spx_pool_for_device(int device, int coalesce) {
+  const int on = coalesce < 0 ? coalesce_default() : (coalesce ? 1 : 0);
   if (!on || device < 0 || device >= 64) return nullptr;
   std::lock_guard<std::mutex> g(g_pools_mu);
   if (!g_pools[device]) {
@@ -150,7 +156,7 @@ void spx_pool_block_free(SpxPool* P, void* p, size_t bytes) {   // from outside 
 // ---------------- frame arena ----------------
 
 static bool arena_grow(SpxPool* P, int64_t min_cap) {
-  static const int64_t first = [] { const char* e = getenv("SPX_POOL_FRAMES"); return e ? atoll(e) : (int64_t)1 << 20; }();
+  static const int64_t first = [] { const char* e = getenv("SPX_POOL_FRAMES"); return std::max<int64_t>(1024, e ? atoll(e) : (int64_t)1 << 20); }();
   int64_t ncap = P->aCap ? 2 * P->aCap : first;
   while (ncap < min_cap) ncap *= 2;
   SpxFrameRec* nr = nullptr;
@@ -355,7 +361,7 @@ static bool pool_run(SpxPool* P) {
     Item& it = items.back();   // prepared in place
     it.s = s;
     if (s->failed || !place_input(P, s, copies, &defer) || !spx_prepare_job(s, s->pendingFlush, false, P->hs, P, it.J, &defer)) {
-      s->failed = true;
+      if (!s->failed) spx_stream_fail(s, "preparing the staged work failed (device allocation)");
       items.pop_back();
     }
   }
@@ -407,8 +413,7 @@ static bool pool_run(SpxPool* P) {
   const size_t o_moves = (o_copies + sizeof(PoolCopy) * copies.size() + 15) & ~(size_t)15;
   const size_t b_tab = o_moves + sizeof(SpxMove) * moves.size();
   auto give_up = [&](const char* why) {   // nothing was launched: the waiting handles cannot be served
-    spx_api_error(why);
-    for (auto& it : items) it.s->failed = true;
+    for (auto& it : items) spx_stream_fail(it.s, why);
     drop_waiting(P);
     return false;
   };
@@ -504,8 +509,8 @@ static bool pool_run(SpxPool* P) {
   if (se == hipErrorNotReady) se = hipStreamSynchronize(P->hs);
   const auto tp4 = std::chrono::steady_clock::now();
   if (le != hipSuccess || se != hipSuccess) {
-    spx_api_error(std::string("coalesced launch failed: ") + hipGetErrorString(le != hipSuccess ? le : se));
-    for (auto& it : items) it.s->failed = true;
+    const std::string why = std::string("coalesced launch failed: ") + hipGetErrorString(le != hipSuccess ? le : se);
+    for (auto& it : items) spx_stream_fail(it.s, why);
     drop_waiting(P);
     return false;
   }
@@ -514,21 +519,25 @@ static bool pool_run(SpxPool* P) {
     spx_finish_job(s, items[i].J);
     int64_t k = hR[i].n;
     if (k == SPX_NOUT_LOST_PRODUCER) {
-      spx_api_error("a producer kernel never delivered its frames (device-side poll limit reached)");
-      s->failed = true;
+      spx_stream_fail(s, "a producer kernel never delivered its frames (device-side poll limit reached)");
       k = s->outKnown;
     } else if (k < 0) {
-      spx_api_error("output capacity exceeded on the device");
-      s->failed = true;
+      spx_stream_fail(s, "output capacity exceeded on the device");
       k = -k;
     }
-    int64_t fresh = std::min(std::min(k, items[i].J.JA.out_cap) - s->outKnown, res_cap[i]);
+    // what the gather kernel delivered: the frames beyond outKnown that fitted the output window AND the handle's slice of
+    // the pinned result area (sized from the host-side bound J.need).  The host's count follows what it actually holds: a
+    // device that produced more than the bound is an error of this handle, never a read past hostOut.
+    const int64_t avail = std::min(k, items[i].J.JA.out_cap) - s->outKnown;
+    const int64_t fresh = std::max<int64_t>(0, std::min(avail, res_cap[i]));
+    if (avail > res_cap[i] && !s->failed)
+      spx_stream_fail(s, "the device produced more frames than the host-side bound of the job (coalesced result slice)");
     if (fresh > 0) {
       const int16_t* src = hOut + res_off[i];
       s->hostOut.insert(s->hostOut.end(), src, src + fresh * s->channels);
     }
-    s->outKnown = k;
-    s->outBound = k;
+    s->outKnown += fresh;
+    s->outBound = s->outKnown;
     s->tsmBase = hR[i].st.w.base;
     s->curSpeedKnown = hR[i].st.curSpeed;
     s->dirty = false;
@@ -551,8 +560,8 @@ static void enlist(SpxPool* P, sonicStream s) {
 int spx_pool_write(sonicStream s, const short* in, int sampleCount) {
   SpxPool* P = pool_of(s);
   std::lock_guard<std::mutex> g(P->mu);
-  if (s->failed) return 0;
-  if (s->pendingFlush && !pool_run(P)) return 0;   // a write behind a staged flush is the next job
+  if (spx_stream_failed(s)) return 0;
+  if (s->pendingFlush && (!pool_run(P) || spx_stream_failed(s))) return 0;   // a write behind a staged flush is the next job
   if (s->nIn + sampleCount + s->tsmShift >= (1ll << 30)) {
     spx_api_error("stream longer than 2^30 frames is not supported");
     return 0;
@@ -568,15 +577,15 @@ int spx_pool_write(sonicStream s, const short* in, int sampleCount) {
   enlist(P, s);
   // bounded staging: a caller that only ever writes still makes progress (and the device buffers keep sliding)
   static const size_t limit = [] { const char* e = getenv("SPX_POOL_STAGE_BYTES"); return e ? (size_t)atoll(e) : (size_t)8 << 20; }();
-  if (P->hInUsed > limit || P->waitingSegs > 8192) return pool_run(P) && !s->failed ? 1 : 0;
+  if (P->hInUsed > limit || P->waitingSegs > 8192) return pool_run(P) && !spx_stream_failed(s) ? 1 : 0;
   return 1;
 }
 
 int spx_pool_flush(sonicStream s) {
   SpxPool* P = pool_of(s);
   std::lock_guard<std::mutex> g(P->mu);
-  if (s->failed) return 0;
-  if (s->pendingFlush && !pool_run(P)) return 0;
+  if (spx_stream_failed(s)) return 0;
+  if (s->pendingFlush && (!pool_run(P) || spx_stream_failed(s))) return 0;
   s->pendingFlush = true;
   enlist(P, s);
   return 1;
@@ -593,9 +602,13 @@ int spx_pool_read(sonicStream s, short* out, int bufferSize) {
   SpxPool* P = pool_of(s);
   std::lock_guard<std::mutex> g(P->mu);
   if (s->poolPending && !pool_run(P)) return 0;
+  (void)spx_stream_failed(s);   // (what the host holds is still delivered; the reason is this thread's last error)
   int64_t n = s->outKnown - s->outRead;
   if (n <= 0 || bufferSize <= 0) return 0;
   if (n > bufferSize) n = bufferSize;
+  const int64_t held = (int64_t)((s->hostOut.size() - std::min(s->hostHead, s->hostOut.size())) / (size_t)s->channels);
+  if (n > held) n = held;   // (a failed handle's counts may be ahead of what the host holds)
+  if (n <= 0) return 0;
   const size_t cnt = (size_t)n * s->channels;
   memcpy(out, s->hostOut.data() + s->hostHead, cnt * sizeof(short));
   s->hostHead += cnt;
@@ -625,8 +638,7 @@ bool spx_pool_leave(sonicStream s) {
         hipMemcpyAsync(nr, s->dRec.p, sizeof(SpxFrameRec) * (size_t)cap, hipMemcpyDeviceToDevice, P->hs) != hipSuccess ||
         hipMemcpyAsync(ns, s->dScr.p, sizeof(float) * 4 * (size_t)cap, hipMemcpyDeviceToDevice, P->hs) != hipSuccess ||
         hipStreamSynchronize(P->hs) != hipSuccess) {
-      spx_api_error("leaving the coalesced path failed (device allocation)");
-      s->failed = true;
+      spx_stream_fail(s, "leaving the coalesced path failed (device allocation)");
       return false;
     }
     const int64_t origin = s->dRec.origin;
@@ -659,6 +671,7 @@ extern "C" {
 // Coalesced execution of plain handles (default on; SPX_NO_POOL=1 in the environment switches it off): applies to handles
 // created afterwards.
 void speedyHipSetCoalescing(int on) { g_coalesce.store(on ? 1 : 0); }
+int speedyHipGetCoalescing(void) { return coalesce_default(); }
 // Launch sequences run and jobs served by the current device's pool so far (jobs / runs = handles per launch sequence).
 void speedyHipPoolStats(unsigned long long* runs, unsigned long long* jobs) {
   int dev = 0;

@@ -162,6 +162,7 @@ struct sonicStreamStruct {  // speedyConnectionStruct + the parts of libsonic's 
   bool dirty = false;       // launches in flight since the last synchronisation
   bool started = false;     // a job has been launched (state record valid)
   std::atomic<bool> failed{false};
+  std::string errText;         // why (written once, before `failed` is set: spx_stream_fail); surfaced by the handle's next call
   void* userData = nullptr;    // sonicIntSetUserData (soniclib.c:98,106)
 
   // ---- coalesced execution (sonic2_pool.hip).  A handle starts in its device's pool and stays there while nothing it
@@ -198,10 +199,22 @@ int spx_prepare_job(sonicStream s, bool flush, bool direct, hipStream_t hs, SpxP
                     SpxDeferred* defer = nullptr);
 void spx_finish_job(sonicStream s, const SpxJobPlan& J);
 void spx_api_error(const std::string& msg);
+// A handle fails for good: the reason is kept IN the handle -- a coalesced run may be triggered by another thread's call, and
+// speedyHipLastError() is per thread -- and repeated as the calling thread's last error.
+inline void spx_stream_fail(sonicStream s, const std::string& msg) {
+  if (!s->failed.load(std::memory_order_acquire)) { s->errText = msg; s->failed.store(true, std::memory_order_release); }
+  spx_api_error(msg);
+}
+// true (and the handle's reason becomes this thread's last error) when the handle has failed
+inline bool spx_stream_failed(sonicStream s) {
+  if (!s->failed.load(std::memory_order_acquire)) return false;
+  if (!s->errText.empty()) spx_api_error(s->errText);
+  return true;
+}
 bool spx_settings_ok(sonicStream s);
 
 // ---- sonic2_pool.hip ----
-SpxPool* spx_pool_for_device(int device);              // nullptr when coalescing is switched off
+SpxPool* spx_pool_for_device(int device, int coalesce = -1);   // nullptr when coalescing is off (coalesce: -1 the process default, 0 / 1 this handle's own choice)
 void spx_pool_adopt(SpxPool* pool, sonicStream s);     // at creation
 int spx_pool_write(sonicStream s, const short* in, int sampleCount);   // stage a write
 int spx_pool_flush(sonicStream s);                                     // stage a flush

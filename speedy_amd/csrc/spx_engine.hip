@@ -150,23 +150,38 @@ int spx_kernel_vgprs(const void* fn) {
 static bool device_is_ours(int dev) {
   static std::mutex mu;
   static int state[64];   // 0 unknown, 1 ours, -1 shared
+  static int lock_fd[64];
+  static pid_t owner = 0;
   if (dev < 0 || dev >= 64) return false;
   std::lock_guard<std::mutex> g(mu);
+  if (owner != getpid()) {
+    // first call, or a fork()ed child: the child shares the parent's open file description and with it the parent's lock --
+    // both would believe the device is theirs.  The child drops the inherited descriptors (the parent keeps the lock) and
+    // asks again for itself.
+    for (int d = 0; d < 64; d++) { if (owner && state[d] > 0 && lock_fd[d] > 0) close(lock_fd[d]); state[d] = 0; lock_fd[d] = -1; }
+    owner = getpid();
+  }
   if (state[dev]) return state[dev] > 0;
   state[dev] = -1;
   if (getenv("SPX_SHARED_GPU")) return false;
   char bus[64] = "dev";
   if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof(bus), "ordinal%d", dev); }
   for (char* c = bus; *c; c++) if (*c == ':' || *c == '/') *c = '_';
+  // The lock must be seen by every process that can use the device, so it lives in a shared directory (SPX_LOCK_DIR, else
+  // /tmp).  O_NOFOLLOW: a symbolic link planted under the name is refused, never followed; the file is created 0644 and never
+  // written -- another user's file is opened read-only (an advisory lock needs no write access).  Anyone who can open the
+  // file can hold the lock and thereby send other processes to the sequential launch order: that costs them speed, never
+  // results (SPX_DEBUG_MODE=1 prints the mode of every call).
   const char* dir = getenv("SPX_LOCK_DIR");
   if (!dir) dir = "/tmp";
   char path[256];
   snprintf(path, sizeof(path), "%s/spx_concurrent_%s.lock", dir, bus);
-  int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-  if (fd < 0) fd = open(path, O_RDONLY | O_CLOEXEC);   // somebody else's file: an advisory lock needs no write access
+  int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0644);
+  if (fd < 0) fd = open(path, O_RDONLY | O_CLOEXEC | O_NOFOLLOW);
   if (fd < 0) return false;
   if (flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); return false; }
   state[dev] = 1;   // (the descriptor stays open: the lock lives as long as the process)
+  lock_fd[dev] = fd;
   return true;
 }
 
@@ -888,6 +903,11 @@ size_t spx_batch_workspace_bytes_mixed(const spx_plan_t* plans, int n_plans, con
 }
 int spx_batch_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
                         const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, void* hs) {
+  return spx_batch_run_mixed_taps(plans, n_plans, jobs, plan_index, n, in, out, n_out, ws, ws_bytes, nullptr, hs);
+}
+int spx_batch_run_mixed_taps(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
+                             const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps,
+                             void* hs) {
   if (!plans || n_plans < 1 || n_plans > 8 || !jobs || n <= 0) return fail(-1, "spx_batch_run_mixed: bad arguments");
   SpxRange range_("spx_batch_run_mixed");
   std::vector<std::vector<spx_stream_job>> gj;
@@ -984,6 +1004,22 @@ int spx_batch_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_j
   }
   std::vector<size_t> gpos(n_plans, 0);
   { size_t pos = 0; for (int g = 0; g < n_plans; g++) { gpos[g] = pos; pos += gj[g].size(); } }
+  // taps: the rows of group g follow those of groups 0 .. g-1 (plan order, whatever order the groups are launched in); the
+  // row widths of the two spectrum taps are the group's own N and W
+  std::vector<spx_taps> gtaps(n_plans);
+  if (taps) {
+    size_t rows = 0, o_spec = 0, o_norm = 0;
+    for (int g = 0; g < n_plans; g++) {
+      spx_taps& t = gtaps[g];
+      t.tension = taps->tension ? taps->tension + rows : nullptr;
+      t.speed = taps->speed ? taps->speed + rows : nullptr;
+      t.features = taps->features ? taps->features + rows * SPX_FEATURE_COUNT : nullptr;
+      t.spectrogram = taps->spectrogram ? taps->spectrogram + o_spec : nullptr;
+      t.normalized = taps->normalized ? taps->normalized + o_norm : nullptr;
+      const size_t fr = gj[g].empty() ? 0 : (size_t)layout_for(plans[g]->dev, gj[g].data(), (int)gj[g].size()).total_frames;
+      rows += fr; o_spec += fr * (size_t)plans[g]->dev.N; o_norm += fr * (size_t)plans[g]->dev.W;
+    }
+  }
   // Kernels in sequence: the groups' analysis kernels one after the other, the cheapest first (lowest rate: fewest frames
   // and the shortest transform), instead of all at once.  Shared, every analysis ends late and every walk kernel starts
   // late; shortest first, the first group's walk starts early and the last analysis -- alone on what the running walk
@@ -1009,11 +1045,17 @@ int spx_batch_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_j
       f.after_analysis = p->ev_an;
       prev_an = p->ev_an;
     }
-    rc = run_impl(p, gj[g].data(), (int)gj[g].size(), in, out, d_nout + gpos[g], w + M.ws_off[g], M.ws_bytes[g], nullptr, p->mix,
+    rc = run_impl(p, gj[g].data(), (int)gj[g].size(), in, out, d_nout + gpos[g], w + M.ws_off[g], M.ws_bytes[g], taps ? &gtaps[g] : nullptr, p->mix,
                   true, true, &f);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(p->ev_join, p->mix));
-    HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
+    // (also when the group failed: whatever it -- and the groups before it -- enqueued on their streams still reads the
+    // caller's buffers, so the caller's stream waits for it before the error is returned)
+    const std::string err = rc ? g_err : std::string();
+    if (hipEventRecord(p->ev_join, p->mix) != hipSuccess || hipStreamWaitEvent(st, p->ev_join, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(p->mix);   // no event: make sure by waiting here
+      if (!rc) return fail(-2, "spx_batch_run_mixed: joining a group's stream failed");
+    }
+    if (rc) return fail(rc, err);
   }
   hipLaunchKernelGGL(spx_scatter_nout_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_nout, d_idx, n, n_out);
   if (concurrent) {
@@ -1023,6 +1065,39 @@ int spx_batch_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_j
     guard.valid = true;
   }
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Pitch searches per stream of the batch's last run (SpxWalkState::steps): the length of every stream's dependent chain.
+// Waits for hip_stream, then copies the state records out of the workspace.
+static int read_steps(const SpxPlanDev& d, const spx_stream_job* jobs, int n, const void* ws, int32_t* steps, hipStream_t st) {
+  const Layout L = layout_for(d, jobs, n);
+  std::vector<SpxStreamState> h((size_t)n);
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipMemcpy(h.data(), static_cast<const unsigned char*>(ws) + L.off_states, sizeof(SpxStreamState) * (size_t)n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) steps[i] = h[i].w.steps;
+  return 0;
+}
+int spx_batch_read_steps(spx_plan_t plan, const spx_stream_job* jobs, int n, const void* ws, int32_t* steps, void* hs) {
+  if (!plan || !jobs || n <= 0 || !ws || !steps) return fail(-1, "spx_batch_read_steps: bad arguments");
+  return read_steps(plan->dev, jobs, n, ws, steps, static_cast<hipStream_t>(hs));
+}
+int spx_batch_read_steps_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
+                               const void* ws, int32_t* steps, void* hs) {
+  if (!plans || n_plans < 1 || n_plans > 8 || !jobs || n <= 0 || !ws || !steps) return fail(-1, "spx_batch_read_steps_mixed: bad arguments");
+  std::vector<std::vector<spx_stream_job>> gj;
+  std::vector<std::vector<int>> gi;
+  int rc = mixed_groups(n_plans, jobs, plan_index, n, gj, gi);
+  if (rc) return rc;
+  const MixedLayout M = mixed_layout(plans, n_plans, gj, n);
+  for (int g = 0; g < n_plans; g++) {
+    if (gj[g].empty()) continue;
+    std::vector<int32_t> sg(gj[g].size());
+    rc = read_steps(plans[g]->dev, gj[g].data(), (int)gj[g].size(), static_cast<const unsigned char*>(ws) + M.ws_off[g], sg.data(),
+                    static_cast<hipStream_t>(hs));
+    if (rc) return rc;
+    for (size_t k = 0; k < sg.size(); k++) steps[gi[g][k]] = sg[k];
+  }
   return 0;
 }
 

@@ -394,6 +394,7 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
   const int maxC = direct ? P.maxPeriod : P.maxPeriod / skip;
   const int tg = st.prevPeriod_toggle & 1;
   st.prevPeriod_toggle ^= 1;
+  st.steps++;
   Sel S1 = {0u, 0u, 0, 0};
   if (!FAST && (direct || skip == 1)) {  // this search is the final one: it also needs the worst lag
     search_split<NW, true, FAST>(direct ? M0 : D0, direct ? M1 : D1, direct ? o : 0, minC, maxC - minC + 1,
@@ -750,7 +751,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   SpxStreamState Z;
   if (S.flags & SPX_F_INIT) {
     Z.w.base = 0; Z.w.out_n = 0; Z.w.avail = 0; Z.w.remaining = 0; Z.w.prevPeriod = 0; Z.w.prevMinDiff = 0;
-    Z.w.overflow = 0; Z.w.prevPeriod_toggle = 0; Z.w.pad_ = 0;
+    Z.w.overflow = 0; Z.w.prevPeriod_toggle = 0; Z.w.steps = 0;
     Z.curSpeed = Rg;    // sonicSetSpeed -> sonicIntSetSpeed, soniclib.c:182
     Z.handed = 0;
   } else {
@@ -793,7 +794,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   WalkState st;
   st.base = uni((pos_t)Z.w.base); st.out_n = uni((pos_t)Z.w.out_n); st.avail = uni((pos_t)Z.w.avail);
   st.remaining = uni(Z.w.remaining); st.prevPeriod = uni(Z.w.prevPeriod); st.prevMinDiff = uni(Z.w.prevMinDiff);
-  st.overflow = uni(Z.w.overflow); st.prevPeriod_toggle = uni(Z.w.prevPeriod_toggle);
+  st.overflow = uni(Z.w.overflow); st.prevPeriod_toggle = uni(Z.w.prevPeriod_toggle); st.steps = 0;
   float curSpeed = unif(Z.curSpeed);
   pos_t avail = st.avail;
   pos_t handed = (nl != 0.0f) ? ((S.flags & SPX_F_HANDED_IN) ? S.handed_in : Z.handed) : 0;
@@ -893,7 +894,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   if (tid == 0) {
     Z.w.base = st.base; Z.w.out_n = st.out_n; Z.w.avail = avail; Z.w.remaining = st.remaining;
     Z.w.prevPeriod = st.prevPeriod; Z.w.prevMinDiff = st.prevMinDiff; Z.w.overflow = st.overflow;
-    Z.w.prevPeriod_toggle = st.prevPeriod_toggle; Z.w.pad_ = 0;
+    Z.w.prevPeriod_toggle = st.prevPeriod_toggle; Z.w.steps = st.steps;
     states[blockIdx.x].w = Z.w;  // field-wise: the tension kernel may be writing its own fields of this record
     states[blockIdx.x].curSpeed = curSpeed;
     if (nl != 0.0f) states[blockIdx.x].handed = (int)handed;
@@ -950,12 +951,18 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   //   beyond: THROUGHPUT form -- 2 search waves, no output waves, 1536-frame window: 15 KB of LDS and two waves per stream,
   //     eight streams per CU at four waves per SIMD; the chains hide each other's latencies and the control flow is
   //     executed twice per stream, not four times (1024 streams: 5.5 against 6.3; 2048: 9.6 against 12.4; 4096: 19.0)
-  static const int cus = [] {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      return prop.multiProcessorCount;
+  // (per device: a process may hold plans on several GPUs; the count is cached, the query is not free)
+  const int cus = [] {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    hipDeviceProp_t prop;
+    v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     (void)hipGetLastError();
-    return 256;
+    cache[dev].store(v, std::memory_order_relaxed);
+    return v;
   }();
   //   (the register file holds five waves of the 4 + 4 form per SIMD, i.e. TWO such workgroups per CU: a third waits for a
   //   slot -- 576 streams 5.8 ms -- so the throughput form starts right above two streams per CU)

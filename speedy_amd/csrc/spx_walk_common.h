@@ -9,6 +9,7 @@ typedef int pos_t;
 struct WalkState {
   pos_t base, out_n, avail;
   int remaining, prevPeriod, prevMinDiff, overflow, prevPeriod_toggle;
+  int steps;   // pitch searches of this job (diagnostic: SpxWalkState::steps)
 };
 
 // Values that are the same in every lane but that the compiler cannot prove uniform (they come from LDS or from

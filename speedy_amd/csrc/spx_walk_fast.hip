@@ -711,6 +711,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     // ------------------------------ output waves: obey commands until FCMD_EXIT ------------------------------
     if constexpr (NWC > 0) {
       int seq = 0;
+      int nsteps = 0;  // step commands seen = pitch searches of this job: counted HERE, off the chain (SpxWalkState::steps)
       pos_t wb = -1, lim = (pos_t)(S.n_in + S.tsm_shift);  // window base / input limit as the commands have announced them
       for (;;) {
         fast_sync();  // the barrier that follows every published command
@@ -724,6 +725,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         fast_outputs<64 * NWC, MCH>(X, tid - 64 * NWM, xf_n, xf_down, xf_period, xf_out, type == FCMD_STEP ? 0 : cp_n, cp_src,
                                cp_out, lim, wb);
         if (type == FCMD_STEP) {
+          nsteps++;
           fast_sync();            // the step's second barrier (refine sums complete)
         } else if (type == FCMD_REFILL) {
           fast_refill<NT, MCH>(X, LY, skip, nb, lim);
@@ -733,6 +735,8 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         } else if (type == FCMD_POLL) {
           fast_sync();            // the polled count is in LDS
         } else if (type == FCMD_EXIT) {
+          // (the search waves write the rest of the record, field by field, at about the same time)
+          if (tid == 64 * NWM) states[blockIdx.x].w.steps = nsteps;
           break;
         }
       }
@@ -776,6 +780,8 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   pos_t wbase = -1;              // window covers [wbase, wbase + wcap); -1 = invalid
   int tg = 0;                    // which of the two lag-sum buffers this step adds into (both clear at kernel start)
   int seq = 0;                   // commands published
+  int nsteps = 0;                // pitch searches of this job (counted here only when there are no output waves)
+  (void)nsteps;
   int xf_n = 0, xf_down = 0, xf_period = 0;  // cross-fade decided but not yet handed to the output waves
   pos_t xf_out = 0;
 
@@ -870,6 +876,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   auto find_period = [&](pos_t pos, bool ge2, float sm1, float twom, int& n_ret, int& rem_ret, auto hot)
                          __attribute__((always_inline)) -> int {
     (void)hot;  // std::true_type from the hot loop: its copy of this code has ge2 a constant
+    if constexpr (NWC == 0) nsteps++;   // (with output waves THEY count the step commands, off the chain)
     FSTAMP(1);
     if (SPX_UNLIKELY(!(wbase >= 0 && pos >= wbase && pos + need <= wbase + LY.wcap))) {
       FSTAMP(16);
@@ -1186,8 +1193,12 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     SpxWalkState W;
     W.base = base; W.out_n = out_n; W.avail = avail; W.remaining = remaining;
     W.prevPeriod = prevPeriod; W.prevMinDiff = prevMinDiff; W.overflow = overflow;
-    W.prevPeriod_toggle = 0; W.pad_ = 0;
-    states[blockIdx.x].w = W;  // field-wise: the tension kernel may be writing its own fields of this record
+    W.prevPeriod_toggle = 0;
+    // field-wise: the tension kernel may be writing its own fields of this record (and, with output waves, `steps` is theirs)
+    SpxWalkState& D = states[blockIdx.x].w;
+    D.base = W.base; D.out_n = W.out_n; D.avail = W.avail; D.remaining = W.remaining; D.prevPeriod = W.prevPeriod;
+    D.prevMinDiff = W.prevMinDiff; D.overflow = W.overflow; D.prevPeriod_toggle = 0;
+    if constexpr (NWC == 0) D.steps = nsteps;
     states[blockIdx.x].curSpeed = tailSpeed;
     if (!linear) states[blockIdx.x].handed = (int)handed;
     // a truncated output is reported as a negative count; a lost producer as INT64_MIN (SPX_NOUT_LOST_PRODUCER)

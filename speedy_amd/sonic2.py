@@ -9,15 +9,11 @@ from ._lib import FEATURES_FN, TENSION_FN, c_float_p, c_short_p, lib
 
 class SonicStream:
     def __init__(self, sample_rate, channels, match_matlab=False, coalesce=None):
-        """coalesce: None = the library's default (on), False = this handle runs its own launch sequence per write."""
+        """coalesce: None = the process-wide default (speedyHipSetCoalescing / SPX_NO_POOL), False = this handle runs its
+        own launch sequence per write, True = coalesced.  The choice is per handle; no process-wide switch is touched."""
         self.L = lib()
-        if coalesce is not None:
-            self.L.speedyHipSetCoalescing(int(bool(coalesce)))
-        try:
-            self.h = self.L.speedyHipCreateSonicStream(int(sample_rate), int(channels), int(bool(match_matlab)))
-        finally:
-            if coalesce is not None:
-                self.L.speedyHipSetCoalescing(1)
+        self.h = self.L.speedyHipCreateSonicStreamEx(int(sample_rate), int(channels), int(bool(match_matlab)),
+                                                     -1 if coalesce is None else int(bool(coalesce)))
         if not self.h:
             raise RuntimeError("sonicCreateStream: " + self.L.speedyHipLastError().decode())
         self.channels = channels

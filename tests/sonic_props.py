@@ -210,3 +210,233 @@ def check_chirp_speedup(make_stream):
     s3 = linear_slope(np.arange(n - 1000 - n * 3 // 4), teager[n * 3 // 4: n - 1000])
     assert abs(s1 - s3) <= s1 * 0.05, (s1, s2, s3)
     assert abs(s2 - s1 / 2) <= s1 * 0.01, (s1, s2, s3)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Round 4: the reference-held constraints on the TSM stage that were not restated before.
+# `make_stream(rate, channels)` returns an object with set_speed / enable_nonlinear / write_short / read_short /
+# flush (and write_float / read_float for the float test): the oracle shim or the HIP library's sonic2.h.
+# ---------------------------------------------------------------------------------------------------------
+K_PITCH = np.float32(237)   # sonic_test.cc:255
+
+
+def create_sinusoid_test(rate, channels, matching, seconds):
+    """CreateSinusoidTest, sonic_test.cc:257-275: int16(32000 * sin(i * 2 pi / (float(rate) / 237))), the other channels
+    the same sample times `matching` (1 = diotic, 0 = silent)."""
+    total = int(np.float32(seconds) * rate)
+    per = float(np.float32(rate) / K_PITCH)
+    i = np.arange(total, dtype=np.float64)
+    first = np.trunc(32000 * np.sin(i * 2 * math.pi / per)).astype(np.int16)   # C cast: truncation toward zero
+    if channels == 1:
+        return first
+    out = np.zeros((total, channels), np.int16)
+    out[:, 0] = first
+    out[:, 1:] = (first * matching)[:, None]
+    return out.reshape(-1)
+
+
+def create_sinusoid_float_test(rate, channels, matching):
+    """CreateSinusoidFloatTest, sonic_test.cc:282-297: one second of 0.99 * sin(...), float."""
+    per = float(np.float32(rate / K_PITCH))
+    i = np.arange(rate, dtype=np.float64)
+    first = (np.float32(0.99) * np.sin(i * 2 * math.pi / per)).astype(np.float32)
+    if channels == 1:
+        return first
+    out = np.zeros((rate, channels), np.float32)
+    out[:, 0] = first
+    out[:, 1:] = (first * matching)[:, None]
+    return out.reshape(-1)
+
+
+def teager_variance_ref(data, total=None):
+    """TeagerVariance, sonic_test.cc:142-156, operation for operation: the Teager term in double, then float; online
+    mean / M2 in float with the division by the int n; variance = M2 / (total - 3)."""
+    d = np.asarray(data, np.float64)
+    total = d.size if total is None else int(total)
+    teager = (1.0 * d[1:total - 1] * d[1:total - 1] - 1.0 * d[0:total - 2] * d[2:total]).astype(np.float32)
+    mean = np.float32(0)
+    m2 = np.float32(0)
+    for n, v in enumerate(teager, start=1):
+        delta = np.float32(v - mean)
+        mean = np.float32(mean + np.float32(delta / np.float32(n)))
+        delta2 = np.float32(v - mean)
+        m2 = np.float32(m2 + np.float32(delta * delta2))
+    return float(mean), float(np.float32(m2 / np.float32(total - 3)))
+
+
+def time_compress_vector(make_stream, x, rate, channels, speed, nonlinear, chunk=128):
+    """TimeCompressVector, sonic_test.cc:364-403: set speed and factor, write 128 / read 128, flush, drain."""
+    s = make_stream(rate, channels)
+    s.set_speed(speed)
+    s.enable_nonlinear(nonlinear)
+    x = np.ascontiguousarray(x, np.int16)
+    n = x.size // channels
+    out = []
+    for t in range(0, n, chunk):
+        assert s.write_short(x[t * channels:(t + chunk) * channels])
+        out.append(np.array(s.read_short(chunk), np.int16))
+    assert s.flush()
+    while True:
+        got = s.read_short(chunk)
+        if got.size == 0:
+            break
+        out.append(np.array(got, np.int16))
+    if hasattr(s, "close"):
+        s.close()
+    return np.concatenate(out)
+
+
+def time_compress_float_vector(make_stream, x, rate, channels, speed, nonlinear, chunk=128):
+    """TimeCompressFloatVector, sonic_test.cc:408-445 (sonicWriteFloatToStream / sonicReadFloatFromStream)."""
+    s = make_stream(rate, channels)
+    s.set_speed(speed)
+    s.enable_nonlinear(nonlinear)
+    x = np.ascontiguousarray(x, np.float32)
+    n = x.size // channels
+    out = []
+    for t in range(0, n, chunk):
+        assert s.write_float(x[t * channels:(t + chunk) * channels])
+        out.append(np.array(s.read_float(chunk), np.float32))
+    assert s.flush()
+    while True:
+        got = s.read_float(chunk)
+        if got.size == 0:
+            break
+        out.append(np.array(got, np.float32))
+    if hasattr(s, "close"):
+        s.close()
+    return np.concatenate(out)
+
+
+# TestWithVaryingSpeed, sonic_test.cc:965-1039: the ten SpeedSpecs with the upstream authors' own annotations.
+VARYING_SPEED_SPECS = [
+    (1.0, 1.0, "pass"), (1.5, 1.5, "pass"), (2.5, 2.5, "pass"), (3.0, 3.0, "pass"),
+    (1.25, 1.75, "fail"), (2.25, 3.5, "fail"), (1.5, 3.0, "fail"),
+    (0.75, 0.75, "pass"), (0.75, 1.5, "pass"),   # "Passes?!?" upstream
+    (0.75, 3.0, "fail"),
+]
+# output periods minus expected periods of each case, measured on oracle/orc_sonic.c (round 4; the round-3 review measured
+# the same pattern independently): the FINGERPRINT of the libsonic revision's per-write speed semantics.  |delta| <= 6 is
+# the reference's own assertion; the failing cases are failing cases upstream too ("TODO ... Fix code so that all these
+# tests pass").
+VARYING_SPEED_DELTAS = [0.0, -1.006, -0.007, -1.884, 98.965, 94.427, 183.409, -0.013, 0.978, 551.224]
+
+
+def varying_speed_delta(make_stream, speed1, speed2):
+    """One TestWithVaryingSpeed case: returns output_period_count - expected_period_count (floats as in the C++)."""
+    rate, chunk = 22050, 128
+    x = create_sinusoid_test(rate, 1, 1, 10.0)
+    s = make_stream(rate, 1)
+    s.enable_nonlinear(0)
+    n_out = 0
+    expected = np.float32(0)
+    frame = 0
+    for t in range(0, x.size, chunk):
+        cnt = min(chunk, x.size - t)
+        speed = np.float32(speed1 if frame % 2 else speed2)
+        frame += 1
+        s.set_speed(float(speed))
+        assert s.write_short(x[t:t + cnt])
+        expected = np.float32(expected + np.float32(np.float32(cnt) / speed))
+        n_out += np.asarray(s.read_short(chunk)).size
+    assert s.flush()
+    while True:
+        k = np.asarray(s.read_short(chunk)).size
+        if k == 0:
+            break
+        n_out += k
+    if hasattr(s, "close"):
+        s.close()
+    per = np.float32(np.float32(rate) / K_PITCH)       # kSampleRate / kPitch: int / float -> float
+    return float(np.float32(np.float32(n_out) / per) - np.float32(expected / per))
+
+
+def check_varying_speed(make_stream, deltas=None):
+    """All ten cases: the reference's tolerance (6 periods) holds exactly where upstream says the test passes and is
+    missed exactly where upstream says it fails; with `deltas` (a fingerprint measured on the oracle) every case also
+    lands within half a period of it.  Returns the measured deltas."""
+    got = []
+    for i, (s1, s2, verdict) in enumerate(VARYING_SPEED_SPECS):
+        d = varying_speed_delta(make_stream, s1, s2)
+        got.append(d)
+        assert (abs(d) <= 6) == (verdict == "pass"), (i, s1, s2, d, verdict)
+        if deltas is not None:
+            assert abs(d - deltas[i]) <= 0.5, (i, s1, s2, d, deltas[i])
+    return got
+
+
+def check_stereo_sinusoid(make_stream):
+    """TestStereoSinusoid, sonic_test.cc:759-862: mono, diotic and dichotic 237 Hz sinusoids at 3x through the full
+    nonlinear path (factor 1e-5): lengths within 1 %, each audible channel's Teager mean and variance within 1 % of the
+    mono result, left and right variance of the diotic pair within 1e-4, and the silent channel EXACTLY silent."""
+    speed, rate, nl = 3.0, 22050, 1e-5
+    mono_in = create_sinusoid_test(rate, 1, 1, 1.0)
+    assert mono_in.size == rate
+    mono = time_compress_vector(make_stream, mono_in, rate, 1, speed, nl)
+    assert abs(mono.size - mono_in.size / speed) <= mono.size * 0.01
+    m_mean, m_var = teager_variance_ref(mono, mono.size - 300)
+    st_in = create_sinusoid_test(rate, 2, 1, 1.0)
+    assert st_in.size == 2 * rate
+    st = time_compress_vector(make_stream, st_in, rate, 2, speed, nl)
+    assert abs(st.size - st_in.size / speed) <= st_in.size * 0.01
+    left, right = st[0::2], st[1::2]
+    assert abs(left.size - st_in.size / speed / 2) <= st_in.size * 0.01
+    l_mean, l_var = teager_variance_ref(left, left.size - 300)
+    assert abs(m_mean - l_mean) <= m_mean * 0.01 and abs(m_var - l_var) <= m_var * 0.01
+    r_mean, r_var = teager_variance_ref(right, right.size - 300)
+    assert abs(m_mean - r_mean) <= m_mean * 0.01 and abs(m_var - r_var) <= m_var * 0.01
+    assert abs(l_var - r_var) <= l_var * 0.0001
+    di_in = create_sinusoid_test(rate, 2, 0, 1.0)
+    di = time_compress_vector(make_stream, di_in, rate, 2, speed, nl)
+    assert abs(di.size - di_in.size / speed) <= di_in.size * 0.01
+    dl, dr = di[0::2], di[1::2]
+    assert dl.size > 0 and dr.size > 0
+    dl_mean, dl_var = teager_variance_ref(dl, dl.size - 300)
+    assert abs(m_mean - dl_mean) <= m_mean * 0.01 and abs(m_var - dl_var) <= m_var * 0.01
+    dr_mean, dr_var = teager_variance_ref(dr, dr.size - 300)
+    assert dr_mean == 0.0 and dr_var == 0.0        # EXPECT_EQ: the silent channel stays exactly 0
+    assert not dr.any()
+    assert dl_var > dr_var
+
+
+def check_float_sinusoids(make_stream):
+    """TestWithFloatSinusoids, sonic_test.cc:597-637: the float API on a 0.99-amplitude sinusoid, 3x, factor 1e-5:
+    length within 3 %, Teager mean within 1 %, sigma / mean below 1 % for input and output."""
+    speed, rate, nl = 3.0, 22050, 1e-5
+    x = create_sinusoid_float_test(rate, 1, 1)
+    y = time_compress_float_vector(make_stream, x, rate, 1, speed, nl)
+    expected = x.size / speed
+    assert abs(y.size - expected) <= 0.03 * expected, (y.size, expected)
+    i_mean, i_var = teager_variance_ref(x)
+    c_mean, c_var = teager_variance_ref(y, y.size - 300)
+    assert abs(i_mean - c_mean) <= 0.01 * i_mean, (i_mean, c_mean)
+    assert math.sqrt(i_var) / i_mean < 0.01
+    assert math.sqrt(c_var) / c_mean < 0.01, (c_var, c_mean)
+
+
+def check_real_speech_normalized(make_speedy, cround):
+    """TestRealSpeechNormalized, speedy_test.cc:598-651 (the unit-level API on tapestry.wav with the test's own
+    `output_time = 0` quirk at :628): tension min < -0.4, max > 0.75, |mean| < max / 6, and the speeds
+    speedyComputeSpeedFromTension derives at Rg = 2.1 average within Rg / 10 of Rg."""
+    data, rate, ch = read_wav("tapestry.wav")
+    assert data.size == 50381 and ch == 1
+    x = data.astype(np.float32)
+    s = make_speedy(rate)
+    step = np.float32(rate / np.float32(100))
+    W = s.frame_size
+    frame_count = int((x.size - W) / step + 1)
+    tension, out_t = [], 0
+    for t in range(frame_count):
+        start = cround(np.float32(t) * step)
+        s.add_data(x[start:start + W], t)
+        ok, v = s.compute_tension(out_t)
+        if ok:
+            tension.append(v)
+            out_t = 0
+    tension = np.asarray(tension, np.float32)
+    assert tension.min() < -0.4 and tension.max() > 0.75
+    assert abs(float(tension.astype(np.float64).mean())) <= float(tension.max()) / 6.0
+    rg = 2.1
+    speed = np.asarray([s.speed_from_tension(float(t), rg, 0.0) for t in tension], np.float32)
+    assert abs(float(speed.astype(np.float64).mean()) - rg) <= rg / 10.0
+    return tension, speed

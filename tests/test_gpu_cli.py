@@ -155,15 +155,15 @@ def test_c_api_fuzz_two_execution_paths_agree(seed, handles, env):
 
 @pytest.mark.parametrize("speed,nonlinear,match", [(3.5, 1.0, False), (2.0, 0.0, False), (3.0, 0.0, True)])
 def test_reference_cli_binary_runs_on_this_library(orc, tmp_path, speed, nonlinear, match):
-    """oracle/_ref/speedy_wave_ref is the REFERENCE's own speedy_wave.cc -- compiled where it lies in the build container,
-    unmodified, against include/compat + its own headers (oracle/Makefile `_ref`) -- linked with libspeedy_hip.so.  Run on
+    """tests/_refcli/speedy_wave_ref is the REFERENCE's own speedy_wave.cc -- compiled where it lies in the build container,
+    unmodified, against include/compat + its own headers (tests/Makefile `refcli`) -- linked with libspeedy_hip.so.  Run on
     tapestry.wav as the reference's header comment runs it (speedy_wave.cc:50-66); the WAV it writes must hold exactly the
     oracle's samples, and the tension and speed files its callbacks write the oracle's values.  --match_nonlinear is the
     two-pass use (speedy_wave.cc:424-427): a nonlinear pass without callbacks or output (this library's coalesced path),
     whose achieved speed-up then drives a linear pass.  Skipped where the binary was not built."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "speedy_wave_ref")
+    exe = os.path.join(ROOT, "tests", "_refcli", "speedy_wave_ref")
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/speedy_wave_ref not built (needs /root/reference at build time)")
+        pytest.skip("tests/_refcli/speedy_wave_ref not built (needs /root/reference at build time)")
     from util import read_wav
     x, rate, ch = read_wav("tapestry.wav")
     out = tmp_path / "out.wav"

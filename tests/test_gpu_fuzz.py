@@ -383,3 +383,62 @@ def test_big_batch_fuzz(orc, seed, lo=257, hi=601):
             taps = b.tap_arrays(i)
             for key in ("tension", "speed", "features"):
                 assert np.array_equal(taps[key], ref[key]), tag + (key,)
+
+
+@pytest.mark.parametrize("seed", list(range(81, 87)) + list(range(8000, 8000 + SOAK // 10)))
+def test_mixed_rate_batch_fuzz(orc, seed):
+    """spx_batch_run_mixed, the call BASELINE configs[4] rides on: 2 .. 4 plans -- always one rate whose streams run on the
+    general walk kernel or the plan-driven analysis (8 kHz, 44.1 kHz ...), hysteresis shape per plan -- 3 .. 900 streams dealt
+    to them at random (a plan may get none), ragged lengths including 0, linear / nonlinear / slow-down jobs, per-stream
+    channels and feedback, the taps in half of the cases -- every stream against the oracle."""
+    from speedy_amd.batch import MixedBatch, Plan
+    rng = np.random.default_rng(seed)
+    n_plans = int(rng.integers(2, 5))
+    rates = [int(rng.choice([8000, 11025, 32000, 44100, 48000]))]
+    while len(rates) < n_plans:
+        rates.append(int(rng.choice([16000, 22050, 16000, 22050, 8000, 44100, 24000])))
+    order = rng.permutation(n_plans)
+    rates = [rates[j] for j in order]
+    mms = [bool(rng.integers(0, 2)) for _ in rates]
+    plans = [Plan(r, m) for r, m in zip(rates, mms)]
+    k = int(rng.choice([rng.integers(3, 40), rng.integers(40, 300), rng.integers(300, 901)]))
+    empty = int(rng.integers(0, n_plans)) if rng.random() < 0.3 else -1          # a plan without streams
+    slow = bool(rng.integers(0, 3) == 0)
+    multi = bool(rng.integers(0, 2))
+    with_taps = bool(rng.integers(0, 2))
+    long_ones = max(1, 3000 // k)              # seconds of audio per stream shrink as the batch grows
+    pidx, chs, speeds, nls, fbs, xs, lens = [], [], [], [], [], [], []
+    for i in range(k):
+        g = int(rng.integers(0, n_plans))
+        if g == empty:
+            g = (g + 1) % n_plans
+        rate = rates[g]
+        ch = int(rng.choice([1, 1, 2, 3])) if multi else 1
+        u = rng.random()
+        n = 0 if u < 0.04 else (int(rng.integers(1, 300)) if u < 0.10 else int(rng.integers(300, int(min(1.5, 0.3 * long_ones + 0.2) * rate))))
+        u = rng.random()
+        if u < 0.05:
+            sp_ = 1.0
+        elif slow and u < 0.3:
+            sp_ = float(np.round(rng.uniform(0.4, 0.95), 3))
+        else:
+            sp_ = float(np.round(rng.uniform(1.05, 5.0), 3))
+        pidx.append(g); chs.append(ch); speeds.append(sp_); lens.append(n)
+        nls.append(float(rng.choice([0.0, 1.0, 1.0, 0.5]))); fbs.append(float(rng.choice([0.0, 0.0, 0.1])))
+        xs.append(_signal(KINDS[int(rng.integers(0, len(KINDS)))], n, rate, ch, rng))
+    b = MixedBatch(plans, pidx, lens, chs, speeds, nls, fbs, taps=with_taps)
+    b.upload(xs)
+    b.run()
+    outs = b.results()
+    for i in range(k):
+        rate, mm = rates[pidx[i]], mms[pidx[i]]
+        ref = orc.compress_sound(xs[i], rate, chs[i], speeds[i], nls[i], fbs[i], mm,
+                                 chunk=1000 if nls[i] != 0 else max(lens[i], 1), taps=with_taps)
+        tag = (seed, i, k, rates, pidx[i], chs[i], lens[i], speeds[i], nls[i], fbs[i], mm)
+        assert np.array_equal(outs[i], ref["out"]), tag
+        if with_taps and nls[i] != 0:
+            taps = b.tap_arrays(i)
+            for key in ("tension", "speed", "features"):
+                assert np.array_equal(taps[key], ref[key]), tag + (key,)
+    for p in plans:
+        p.close()

@@ -171,8 +171,9 @@ def test_full_size_round_trip_properties():
 
 
 def test_bench_streams_match_oracle(orc):
-    """The bench workload's own inputs (bench.make_streams: 32 generated bases + rotations, 256 x 10 s): a sample of
-    bases AND rotated copies against the oracle, so the number bench.py reports is for bytes the oracle agrees with."""
+    """The bench workload's own inputs (bench.make_streams: 256 distinct streams x 10 s, seed = 1234 + global stream index):
+    a sample of them against the oracle, so the number bench.py reports is for bytes the oracle agrees with (bench.py itself
+    compares the CRC of every sampled stream of its cpu_baseline leg with the GPU's)."""
     import bench
     from speedy_amd.batch import Batch, Plan
     n = bench.RATE * bench.SECONDS
@@ -240,6 +241,45 @@ def test_config4_one_gpu_shard_full_size(orc):
         assert np.array_equal(whole[i], ref), (i, kind)
         checked[kind] = checked.get(kind, 0) + 1
     assert len(checked) == 8 and all(v >= 8 for v in checked.values()), checked
+
+
+def test_config4_whole_batch_on_one_gpu(orc):
+    """ALL of BASELINE configs[4] on one GPU: the 2 048 mixed streams x 10 s (rate by i%2, channels by (i/2)%2,
+    speed by (i/4)%2; 2 048 distinct signals, seed = 4000 + global index) run two ways -- ONE 2 048-stream
+    spx_batch_run_mixed call (what N = 1 of the strong-scaling curve runs: two groups of 1 024 streams, the walk kernel's
+    throughput form, pipelined time chunks) and the eight 256-stream calls the eight ranks of the 8-GPU layout make (one
+    stream per CU, 4 + 4 waves) -- per-stream CRCs equal between the two, and equal to the oracle's on 8 streams of each of
+    the 8 kinds IN EVERY SHARD (512 oracle runs on the host's threads)."""
+    from speedy_amd import config4 as C4
+    from speedy_amd.batch import Plan
+    ids = list(range(C4.TOTAL_STREAMS))
+    streams = C4.make_streams(ids)
+    assert len({x.tobytes()[:4096] for x in streams}) == len(streams)        # distinct signals
+    plans = [Plan(r, False) for r in C4.RATES]
+    b = C4.mixed_batch(plans, ids, streams)
+    b.run()
+    whole = b.crcs()
+    b.run()                       # again (warm): the same bytes
+    assert b.crcs() == whole
+    counts = b.counts()
+    del b
+    for r in range(8):
+        sl = slice(256 * r, 256 * (r + 1))
+        bs = C4.mixed_batch(plans, ids[sl], streams[sl])
+        bs.run()
+        assert bs.crcs() == whole[sl], r
+        assert list(bs.counts()) == list(counts[sl]), r
+        del bs
+    checked = 0
+    for k in range(8):            # one oracle pass per kind: 8 streams from every shard
+        rate, ch, speed = C4.cfg(k)
+        pick = [256 * r + k + 8 * j for r in range(8) for j in range(8)]
+        assert all(C4.cfg(i) == (rate, ch, speed) for i in pick)
+        _, frames, crcs = orc.crc_streams([streams[i] for i in pick], rate, ch, speed, 1.0, 0.0, False)
+        for i, f, c in zip(pick, frames, crcs):
+            assert counts[i] == f and whole[i] == c, (i, rate, ch, speed, int(counts[i]), f)
+            checked += 1
+    assert checked == 512
 
 
 @pytest.mark.parametrize("chunks", [2, 5])

@@ -178,6 +178,32 @@ def test_chirp_and_dtw_properties_through_the_hip_api(orc):
     sp.check_speech_dtw(comp, _spectrogram(orc))
 
 
+def test_remaining_reference_constraints_through_the_hip_api(orc):
+    """Round 4: sonic_test.cc:965-1039 (varying speed, all ten cases with the upstream pass / fail pattern and the oracle's
+    fingerprint), :759-862 (stereo sinusoids; the silent channel stays exactly 0), :597-637 (float API) through
+    include/sonic2.h of the HIP library -- coalesced and eager handles -- and the outputs of the first two equal to the
+    oracle's, sample for sample."""
+    from speedy_amd.sonic2 import SonicStream
+    from test_oracle_sonic_properties import _OrcStream
+    for coalesce in (None, False):
+        mk = lambda rate, ch: SonicStream(rate, ch, True, coalesce)  # noqa: E731
+        sp.check_stereo_sinusoid(mk)
+        sp.check_float_sinusoids(mk)
+    mk = lambda rate, ch: SonicStream(rate, ch, True)  # noqa: E731
+    got = sp.check_varying_speed(mk, sp.VARYING_SPEED_DELTAS)
+    ref = [sp.varying_speed_delta(lambda rate, ch: _OrcStream(orc, rate, ch), s1, s2) for s1, s2, _ in sp.VARYING_SPEED_SPECS]
+    assert got == ref, (got, ref)      # the same output lengths as the oracle, case for case
+    for ch, matching in ((1, 1), (2, 1), (2, 0)):
+        x = sp.create_sinusoid_test(22050, ch, matching, 1.0)
+        a = sp.time_compress_vector(mk, x, 22050, ch, 3.0, 1e-5)
+        b = sp.time_compress_vector(lambda rate, c: _OrcStream(orc, rate, c), x, 22050, ch, 3.0, 1e-5)
+        assert np.array_equal(a, b), (ch, matching)
+    xf = sp.create_sinusoid_float_test(22050, 1, 1)
+    a = sp.time_compress_float_vector(mk, xf, 22050, 1, 3.0, 1e-5)
+    b = sp.time_compress_float_vector(lambda rate, c: _OrcStream(orc, rate, c), xf, 22050, 1, 3.0, 1e-5)
+    assert np.array_equal(a, b)
+
+
 def test_negative_speed_input_does_not_crash():
     """speedy_test.cc:1059-1076: 24 kHz file, speed 0.25, nonlinear, one big write."""
     from speedy_amd.sonic2 import SonicStream

@@ -66,6 +66,18 @@ def test_tension_known_answer_and_oracle_equality(orc, mm):
     g.close()
 
 
+def test_real_speech_normalized(orc):
+    """speedy_test.cc:598-651 on the HIP library's unit-level API; tensions and speeds bit-equal to the oracle's."""
+    import sonic_props as sp
+
+    class _O(orc.Speedy):
+        def speed_from_tension(self, t, rg, fb):
+            return self.L.orc_speedyComputeSpeedFromTension(float(t), float(rg), float(fb), self.h)
+    tg, sg = sp.check_real_speech_normalized(lambda rate: _hip(rate, True), cround)
+    to, so = sp.check_real_speech_normalized(lambda rate: _O(rate, True), cround)
+    assert np.array_equal(tg, to) and np.array_equal(sg, so)
+
+
 def test_speed_from_tension_and_feedback(orc):
     """speedy.c:768-788 through the device state record: same speeds as the oracle for a tension sequence, with feedback."""
     g, o = _hip(16000), orc.Speedy(16000, True)

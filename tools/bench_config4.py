@@ -12,24 +12,20 @@ import torch  # noqa: E402
 from speedy_amd.batch import Batch, MixedBatch, Plan  # noqa: E402
 from speedy_amd.synth import speech_like  # noqa: E402
 
-RATES = (16000, 22050)
+from speedy_amd import config4 as C4  # noqa: E402
+
+RATES = C4.RATES
+cfg = C4.cfg
 
 
-def cfg(i):
-    return (16000 if i % 2 == 0 else 22050, 1 if (i // 2) % 2 == 0 else 2, 1.5 if (i // 4) % 2 == 0 else 3.5)
+def shard_streams(n=256, seed0=4000, first=0):
+    """Distinct signals of the global streams first .. first + n - 1 (seed = 4000 + global index, speedy_amd/config4.py)."""
+    assert seed0 == C4.SEED0
+    return C4.make_streams(range(first, first + n))
 
 
-def shard_streams(n=256, seed0=4000):
-    """Distinct signals: seed = seed0 + stream index."""
-    return [speech_like(10 * cfg(i)[0], cfg(i)[0], seed=seed0 + i, channels=cfg(i)[1]) for i in range(n)]
-
-
-def mixed_batch(plans, streams):
-    n = len(streams)
-    b = MixedBatch(plans, [RATES.index(cfg(i)[0]) for i in range(n)], [10 * cfg(i)[0] for i in range(n)],
-                   [cfg(i)[1] for i in range(n)], [cfg(i)[2] for i in range(n)], 1.0, 0.0)
-    b.upload(streams)
-    return b
+def mixed_batch(plans, streams, first=0):
+    return C4.mixed_batch(plans, list(range(first, first + len(streams))), streams)
 
 
 def time_steps(run, reps=10, warm=4):
