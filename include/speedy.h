@@ -12,7 +12,10 @@
  * Call pattern (as in the reference's tests and shim): speedyAddData with at_time = t0, t0+1, t0+2, ... (t0 = 0 or 1),
  * speedyComputeTension with increasing at_time, each at most once; times may be left out (the shim does after a flush,
  * soniclib.c:538-550) and are then never computed -- as in the reference, the first call that succeeds is the one treated
- * as a low-energy frame (speedy.c:293,691).  Anything else returns 0 / is ignored with a message in speedyHipLastError().
+ * as a low-energy frame (speedy.c:293,691).  A time asked again, out of order, or 20 or more frames behind the newest
+ * frame is answered as the reference answers it: from what its 21-entry spectrum ring and 42-entry hysteresis ring hold at
+ * that moment (speedy.c:198-200,484-487,594-608 -- its own tests do this, speedy_test.cc:564,628).  Anything else returns 0 /
+ * is ignored with a message in speedyHipLastError().
  *
  * The reference's test hooks between stages (speedy.h:102-133) are provided too, see below: with the stages fused on the
  * device there is no host-visible hand-off to hook, so each is a small kernel of its own on the shared device state. */

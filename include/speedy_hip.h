@@ -146,8 +146,7 @@ int spx_debug_last_call_concurrent(void);
 /* Sum over the same calls of the frame-rate (tension) kernel's time, as of the last spx_timing_collect. */
 double spx_timing_last_tension_ms(void);
 
-/* Diagnostics: the number of pitch searches (libsonic's findPitchPeriod calls) each stream's walk ran in the batch's last
- * call -- the length of the stream's chain of dependent steps, which is what bounds a call with one stream per CU.
+/* Diagnostics: the number of pitch searches (libsonic's findPitchPeriod calls) each stream's walk has run since the stream started (a batch job starts it) -- the length of the stream's chain of dependent steps, which is what bounds a call with one stream per CU.
  *   workspace  DEVICE  the workspace that call ran with;  steps  HOST  int32[n_streams].  Waits for hip_stream first. */
 int spx_batch_read_steps(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, const void* workspace,
                          int32_t* steps, void* hip_stream);

@@ -44,6 +44,8 @@ struct speedyStreamStruct {
   float preemph_prev = 0.0f;  // speedyPreemphasisFilter: the last raw sample it (or speedyAddData) has seen (speedy.c:416-425)
   float* dHook = nullptr;     // [0] scalar result of a hook kernel; [8 ..) a frame's worth of scratch floats
   std::vector<float> hSpec, hSpecAt, hNorm, hFeat, hTmp;
+  bool aliased = false;       // the last speedyComputeTension answered a stale / repeated time (hAlFeat / hAlNorm hold its rows)
+  std::vector<float> hAlFeat, hAlNorm;
 };
 
 // Oldest frame the device keeps: the reference remembers 21 spectra and 42 hysteresis values (speedy.c:95-97), i.e. a
@@ -174,7 +176,10 @@ __global__ void hk_preemph_kernel(float* x, int n, float prev) {
 __device__ inline float hk_slot(const SpxPlanDev& P, const float* scr, int64_t origin, int64_t cap, int64_t time0, int64_t hi,
                                 int64_t tau) {
   const int64_t ring = 2 * (int64_t)(P.F + P.Pp + 1);
+  // the ring slot of time tau holds the LATEST time written that shares it: a time not written yet reads what was written
+  // one ring length (or several) earlier, a time overwritten since reads the newer value (speedy.c:617: index = time mod ring)
   if (tau > hi) tau -= ring * ((tau - hi + ring - 1) / ring);
+  else tau += ring * ((hi - tau) / ring);
   const int64_t j = tau - time0;
   return (j >= origin && j < origin + cap && j >= 0) ? scr[4 * (j - origin) + 0] : 0.0f;
 }
@@ -213,7 +218,7 @@ __global__ void hk_local_energy_kernel(SpxPlanDev P, SpxStreamState* st, float e
 // speedyComputeSpectralDifference (speedy.c:664-729) for the two spectra given: features row k, normalised spectra
 __global__ void hk_spectral_difference_kernel(SpxPlanDev P, SpxStreamState* st, const float* cur, const float* last,
                                               const float* scr, int64_t origin, int64_t cap, int64_t time0, int64_t hi, int64_t k,
-                                              float* feat, float* norm_row, float* norm_last) {
+                                              float* feat, float* norm_row, float* norm_last, int any_order, float* tension_out) {
   if (threadIdx.x != 0) return;
   const int W = P.W;   // = fft_size / 2
   const float hyst = hk_hysteresis(P, scr, origin, cap, time0, hi, k);
@@ -226,8 +231,10 @@ __global__ void hk_spectral_difference_kernel(SpxPlanDev P, SpxStreamState* st, 
   for (int i = 0; i < W; i++) { norm_row[i] = cur[i] * inv; norm_last[i] = last[i] * inv2; }
   const float lowthr = (float)(0.04 * (double)1.41421f);               // speedy.c:682
   int first_k = st->tension_first;
-  if (first_k < 0) { first_k = (int)k; st->tension_first = first_k; }  // the very first call is skipped (speedy.c:293,691)
-  const bool low = e <= lowthr || (int)k == first_k;
+  const bool first_call = first_k < 0;
+  if (first_call) { first_k = (int)k; st->tension_first = first_k; }  // the very first call is skipped (speedy.c:293,691)
+  // any_order: a time asked again (or out of order) -- only the FIRST call ever is the skipped one, whatever its time
+  const bool low = e <= lowthr || (any_order ? first_call : (int)k == first_k);
   float lsd = 0.0f, ewld = 0.0f, rel = 0.0f, sc = 0.0f;
   if (!low) {
     const float thr = (float)((double)mx / 100.0);                     // speedy.c:709
@@ -249,6 +256,12 @@ __global__ void hk_spectral_difference_kernel(SpxPlanDev P, SpxStreamState* st, 
   }
   feat[0] = e; feat[4] = hyst; feat[5] = low ? 1.0f : 0.0f; feat[6] = lsd; feat[7] = ewld; feat[8] = lpf; feat[9] = rel;
   feat[10] = sc; feat[13] = (float)k; feat[14] = lowthr;
+  if (tension_out) {
+    const float a = 0.5f, b = 0.25f, M_E_ = 0.7f, M_S = 1.0f;
+    const float tension = a * (hyst - M_E_) + b * (sc - M_S);          // speedy.c:761
+    feat[11] = tension;
+    *tension_out = tension;
+  }
 }
 
 extern "C" {
@@ -274,7 +287,7 @@ speedyStream speedyCreateStream(int sample_rate) {
       hipMalloc(reinterpret_cast<void**>(&s->dSmall), 1024) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&s->dScratchFrame), sizeof(float) * 2 * P.W) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&s->dScratchSpec), sizeof(float) * 2 * P.N) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&s->dHook), sizeof(float) * (8 + 3 * (size_t)P.N)) != hipSuccess) {
+      hipMalloc(reinterpret_cast<void**>(&s->dHook), sizeof(float) * (64 + 6 * (size_t)P.N)) != hipSuccess) {
     spx_internal_set_api_error("speedyCreateStream: device allocation failed");
     speedyDestroyStream(s);
     return nullptr;
@@ -284,6 +297,7 @@ speedyStream speedyCreateStream(int sample_rate) {
   s->dSpeed = reinterpret_cast<float*>(s->dSmall + 512);
   s->hSpec.assign(P.N, 0.0f); s->hSpecAt.assign(P.N, 0.0f); s->hNorm.assign(P.N, 0.0f);
   s->hFeat.assign(SPX_FEATURE_COUNT, 0.0f); s->hTmp.assign(2 * P.N, 0.0f);
+  s->hAlFeat.assign(SPX_FEATURE_COUNT, 0.0f); s->hAlNorm.assign(P.N, 0.0f);
   return s;
 }
 
@@ -334,26 +348,69 @@ void speedyAddDataShort(speedyStream s, const int16_t input[], int64_t at_time) 
   speedyAddData(s, f.data(), at_time);
 }
 
+// A time the reference's rings no longer hold as such -- 20 or more frames behind the newest (its spectrum ring has 21
+// entries, speedy.c:97,476-487) -- or a time asked again / out of order: the reference answers from whatever its rings hold
+// NOW (speedy.c:198-200,484-487,594-608: every index is the time modulo the ring length), i.e. from the latest frames that
+// share the slots.  Its own tests do that (speedy_test.cc:564,628: `output_time = 0` after every success).  Same here: the
+// two spectra are the rows of the latest frames in slots at_time and at_time - 1 (zeros when never written, speedy.c:242-248),
+// the hysteresis reads the latest value of every slot (hk_slot), and the per-call state (difference filter, "the first call
+// is the skipped one") advances in call order -- one lane of hk_spectral_difference_kernel, the arithmetic of the fused path.
+static int tension_any_time(speedyStream s, int64_t at_time, float* tension) {
+  const SpxPlanDev& P = *s->plan;
+  if (!grow(s, s->T + 2)) { spx_internal_set_api_error("speedy: device allocation failed"); return 0; }
+  if (!s->started && !launch(s, false, s->tensionDone, s->tensionDone)) return 0;   // (the state record exists after the first launch)
+  const int64_t ring = P.F + P.Pp + 1, ct = s->current_time, t0 = s->time0 < 0 ? 0 : s->time0;
+  float* zero = s->dHook + 64 + 4 * (size_t)P.N;        // [N] zeros
+  float* feat = s->dHook + 8;                            // [15]
+  float* nrow = s->dHook + 64;                           // [N] normalised row of this call
+  float* nlast = s->dHook + 64 + 2 * (size_t)P.N;
+  (void)hipMemsetAsync(zero, 0, sizeof(float) * P.N, s->hs);
+  (void)hipMemsetAsync(feat, 0, sizeof(float) * 16, s->hs);
+  auto row_of = [&](int64_t tau) -> const float* {
+    // latest time <= ct that shares tau's slot
+    int64_t m = ((tau % ring) + ring) % ring, c = ((ct % ring) + ring) % ring;
+    int64_t latest = ct - ((c - m + ring) % ring);
+    const int64_t j = latest - t0;
+    if (j < 0 || j >= s->T || j < s->origin) return zero;   // never written (the kept window always covers one ring length)
+    return s->tSpec + (j - s->origin) * P.N;
+  };
+  const float* cur = row_of(at_time);
+  const float* last = row_of(at_time - 1);
+  hipLaunchKernelGGL(hk_spectral_difference_kernel, dim3(1), dim3(64), 0, s->hs, P, s->dState, cur, last, s->dScr, s->origin, s->cap,
+                     t0, ct, at_time, feat, nrow, nlast, 1, s->dHook);
+  float v = 0.0f;
+  if (hipMemcpyAsync(&v, s->dHook, sizeof(float), hipMemcpyDeviceToHost, s->hs) != hipSuccess ||
+      hipMemcpyAsync(s->hAlFeat.data(), feat, sizeof(float) * SPX_FEATURE_COUNT, hipMemcpyDeviceToHost, s->hs) != hipSuccess ||
+      hipMemcpyAsync(s->hAlNorm.data(), nrow, sizeof(float) * P.W, hipMemcpyDeviceToHost, s->hs) != hipSuccess ||
+      hipStreamSynchronize(s->hs) != hipSuccess)
+    return 0;
+  // the values speedyComputeLocalEnergy left at the last speedyAddData (features 1-3, 12: speedy.c:517-522)
+  if (s->T > 0 && s->T - 1 >= s->origin) {
+    const int64_t k = s->T - 1 + (s->time0 == 0 ? 0 : 1) - P.F;
+    if (k >= s->origin && k >= 0) {
+      float f[SPX_FEATURE_COUNT];
+      (void)hipMemcpy(f, s->tFeatures + (k - s->origin) * SPX_FEATURE_COUNT, sizeof(f), hipMemcpyDeviceToHost);
+      s->hAlFeat[1] = f[1]; s->hAlFeat[2] = f[2]; s->hAlFeat[3] = f[3];
+    }
+    s->hAlFeat[12] = (float)ct;
+  }
+  s->aliased = true;
+  *tension = v;
+  return 1;
+}
+
 int speedyComputeTension(speedyStream s, int64_t at_time, float* tension) {
   (void)hipSetDevice(s->device);
   if (s->T == 0 || !(at_time + s->plan->F <= s->current_time)) return 0;  // speedy.c:756
-  if (at_time < s->tensionDone) {
-    spx_internal_set_api_error("speedyComputeTension: tensions must be asked for in increasing time order, each once");
-    return 0;
-  }
-  // the tension of time t reads frames t - t0 - Pp - 1 .. t - t0 + F; older than the kept window = older than what the
-  // reference's 21-entry spectrum ring still holds (speedy.c:97,476-487)
-  const int64_t lowest = std::max(oldest_kept(s), s->origin);
-  if (lowest > 0 && at_time - s->plan->Pp - 2 < lowest) {
-    spx_internal_set_api_error("speedyComputeTension: that time is older than the history the stream keeps");
-    return 0;
-  }
+  // in time order, and recent enough that the reference's rings still hold this time's own frames: the fused kernels
+  if (at_time < s->tensionDone || s->current_time - at_time >= s->plan->F + s->plan->Pp) return tension_any_time(s, at_time, tension);
   if (!launch(s, false, at_time, at_time + 1)) return 0;
   float v = 0.0f;
   if (hipMemcpyAsync(&v, s->tTension + (at_time - s->origin), sizeof(float), hipMemcpyDeviceToHost, s->hs) != hipSuccess ||
       hipStreamSynchronize(s->hs) != hipSuccess)
     return 0;
   s->tensionDone = at_time + 1;
+  s->aliased = false;
   *tension = v;
   return 1;
 }
@@ -411,9 +468,11 @@ float* speedyGetSpectrogramAtTime(speedyStream s, int64_t at_time) {
   return fetch_row(s, s->tSpec, j, s->plan->N, s->hSpecAt, s->plan->N);
 }
 float* speedyGetNormalizedSpectrogram(speedyStream s) {
+  if (s->aliased) return s->hAlNorm.data();
   return fetch_row(s, s->tNorm, s->tensionDone - 1, s->plan->W, s->hNorm, s->plan->N);
 }
 float* speedyGetInternalState(speedyStream s) {
+  if (s->aliased) return s->hAlFeat.data();
   return fetch_row(s, s->tFeatures, s->tensionDone - 1, SPX_FEATURE_COUNT, s->hFeat, SPX_FEATURE_COUNT);
 }
 float speedyGetEnergyCompressed(speedyStream s) {
@@ -573,8 +632,9 @@ void speedyComputeSpectralDifference(speedyStream s, const float* spectrogram, c
   (void)hipMemcpyAsync(dc + P.N, last_spectrogram, sizeof(float) * P.W, hipMemcpyHostToDevice, s->hs);
   hipLaunchKernelGGL(hk_spectral_difference_kernel, dim3(1), dim3(64), 0, s->hs, P, s->dState, dc, dc + P.N, s->dScr, s->origin,
                      s->cap, hook_time0(s), hook_hi(s), k, s->tFeatures + (k - s->origin) * SPX_FEATURE_COUNT,
-                     s->tNorm + (k - s->origin) * P.W, dc + 2 * P.N);
+                     s->tNorm + (k - s->origin) * P.W, dc + 2 * P.N, 0, nullptr);
   (void)hipStreamSynchronize(s->hs);
+  s->aliased = false;
   if (s->tensionDone < k + 1) s->tensionDone = k + 1;   // speedyGetInternalState / speedyGetSpeechChanges now show this row
 }
 

@@ -1030,29 +1030,43 @@ int spx_batch_run_mixed_taps(const spx_plan_t* plans, int n_plans, const spx_str
   static const bool no_sjf = getenv("SPX_MIXED_NO_ORDER") != nullptr;   // A/B
   const bool chain_analyses = !concurrent && !no_sjf && ord.size() > 1;
   if (chain_analyses) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return plans[a]->dev.rate < plans[b]->dev.rate; });
+  // Which stream a group runs on.  Kernels in sequence (every mix measured so far): the first group on the CALLER's stream,
+  // the second on the device's second side stream (idle in this mode), further groups on their plans' own streams -- so the
+  // usual two-rate call keeps this library at its three streams per device whatever else the process has created.  HIP maps
+  // streams onto a few hardware queues, a queue runs its kernels in order, and two groups whose streams share a queue run one
+  // after the other: with a stream per plan, the configs[4] shard took 4.95 instead of 3.0 ms in every process that had run
+  // a concurrent-mode call before (its two side streams had taken queues; profiles/r04/r04c_c4_prefix.txt).
+  hipStream_t dev_s1 = nullptr, dev_s2 = nullptr;
+  if (!concurrent && ord.size() > 1 && dev_side_streams(lead->device, &dev_s1, &dev_s2)) return fail(-1, "spx_batch_run_mixed: no side streams");
   hipEvent_t prev_an = nullptr;
+  int launch_idx = 0;
   for (int g : ord) {
     spx_plan* p = plans[g];
-    if (!p->mix) {
-      HIPCHK(hipStreamCreateWithFlags(&p->mix, hipStreamNonBlocking));
-      HIPCHK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    hipStream_t gs = nullptr;
+    if (!concurrent && launch_idx == 0) gs = st;
+    else if (!concurrent && launch_idx == 1) gs = dev_s2;
+    else {
+      if (!p->mix) HIPCHK(hipStreamCreateWithFlags(&p->mix, hipStreamNonBlocking));
+      gs = p->mix;
     }
+    launch_idx++;
+    if (!p->ev_join) HIPCHK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
     if (!p->ev_an) HIPCHK(hipEventCreateWithFlags(&p->ev_an, hipEventDisableTiming));
-    HIPCHK(hipStreamWaitEvent(p->mix, lead->ev_fork, 0));
+    if (gs != st) HIPCHK(hipStreamWaitEvent(gs, lead->ev_fork, 0));
     SpxForce f = force;
     if (chain_analyses) {
-      if (prev_an) HIPCHK(hipStreamWaitEvent(p->mix, prev_an, 0));
+      if (prev_an) HIPCHK(hipStreamWaitEvent(gs, prev_an, 0));
       f.after_analysis = p->ev_an;
       prev_an = p->ev_an;
     }
-    rc = run_impl(p, gj[g].data(), (int)gj[g].size(), in, out, d_nout + gpos[g], w + M.ws_off[g], M.ws_bytes[g], taps ? &gtaps[g] : nullptr, p->mix,
+    rc = run_impl(p, gj[g].data(), (int)gj[g].size(), in, out, d_nout + gpos[g], w + M.ws_off[g], M.ws_bytes[g], taps ? &gtaps[g] : nullptr, gs,
                   true, true, &f);
     // (also when the group failed: whatever it -- and the groups before it -- enqueued on their streams still reads the
     // caller's buffers, so the caller's stream waits for it before the error is returned)
     const std::string err = rc ? g_err : std::string();
-    if (hipEventRecord(p->ev_join, p->mix) != hipSuccess || hipStreamWaitEvent(st, p->ev_join, 0) != hipSuccess) {
+    if (gs != st && (hipEventRecord(p->ev_join, gs) != hipSuccess || hipStreamWaitEvent(st, p->ev_join, 0) != hipSuccess)) {
       (void)hipGetLastError();
-      (void)hipStreamSynchronize(p->mix);   // no event: make sure by waiting here
+      (void)hipStreamSynchronize(gs);   // no event: make sure by waiting here
       if (!rc) return fail(-2, "spx_batch_run_mixed: joining a group's stream failed");
     }
     if (rc) return fail(rc, err);

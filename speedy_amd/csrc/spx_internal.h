@@ -85,8 +85,8 @@ struct SpxWalkState {
   int prevPeriod, prevMinDiff;
   int overflow;
   int prevPeriod_toggle;  // which of the two LDS lag-sum buffers the next pitch step uses (walk kernel internal)
-  int steps;       // pitch searches (findPitchPeriod calls) the LAST job of the stream ran: the length of its dependent chain
-                   // (diagnostic -- bench.py's latency roofline divides the walk kernel's time by it; -1: not counted)
+  int steps;       // pitch searches (findPitchPeriod calls) since the stream started: the length of its chain of dependent
+                   // steps (diagnostic -- bench.py's latency roofline divides the walk kernel's time by it)
 };
 // Everything a stream carries from one job to the next.
 struct SpxStreamState {

@@ -894,7 +894,7 @@ spx_walk_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const in
   if (tid == 0) {
     Z.w.base = st.base; Z.w.out_n = st.out_n; Z.w.avail = avail; Z.w.remaining = st.remaining;
     Z.w.prevPeriod = st.prevPeriod; Z.w.prevMinDiff = st.prevMinDiff; Z.w.overflow = st.overflow;
-    Z.w.prevPeriod_toggle = st.prevPeriod_toggle; Z.w.steps = st.steps;
+    Z.w.prevPeriod_toggle = st.prevPeriod_toggle; Z.w.steps += st.steps;   // (Z.w.steps: 0 on a fresh stream, else what earlier jobs ran)
     states[blockIdx.x].w = Z.w;  // field-wise: the tension kernel may be writing its own fields of this record
     states[blockIdx.x].curSpeed = curSpeed;
     if (nl != 0.0f) states[blockIdx.x].handed = (int)handed;

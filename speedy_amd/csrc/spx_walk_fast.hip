@@ -736,7 +736,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
           fast_sync();            // the polled count is in LDS
         } else if (type == FCMD_EXIT) {
           // (the search waves write the rest of the record, field by field, at about the same time)
-          if (tid == 64 * NWM) states[blockIdx.x].w.steps = nsteps;
+          if (tid == 64 * NWM) states[blockIdx.x].w.steps = ((S.flags & SPX_F_INIT) ? 0 : states[blockIdx.x].w.steps) + nsteps;
           break;
         }
       }
@@ -1198,7 +1198,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     SpxWalkState& D = states[blockIdx.x].w;
     D.base = W.base; D.out_n = W.out_n; D.avail = W.avail; D.remaining = W.remaining; D.prevPeriod = W.prevPeriod;
     D.prevMinDiff = W.prevMinDiff; D.overflow = W.overflow; D.prevPeriod_toggle = 0;
-    if constexpr (NWC == 0) D.steps = nsteps;
+    if constexpr (NWC == 0) D.steps = ((S.flags & SPX_F_INIT) ? 0 : D.steps) + nsteps;
     states[blockIdx.x].curSpeed = tailSpeed;
     if (!linear) states[blockIdx.x].handed = (int)handed;
     // a truncated output is reported as a negative count; a lost producer as INT64_MIN (SPX_NOUT_LOST_PRODUCER)

@@ -243,6 +243,37 @@ def test_config4_one_gpu_shard_full_size(orc):
     assert len(checked) == 8 and all(v >= 8 for v in checked.values()), checked
 
 
+def test_step_counts_equal_the_oracles(orc):
+    """The walk kernels count their pitch searches (SpxWalkState::steps, the denominator of bench.py's latency roofline):
+    the same number libsonic's findPitchPeriod runs in the oracle, on every kernel form -- 4 + 4 waves (one stream per CU),
+    the throughput form (more than two streams per CU), multi-channel, the general kernel (slow-down)."""
+    from speedy_amd.batch import Batch, Plan
+    from speedy_amd.synth import speech_like
+    L = orc.lib()
+
+    def oracle_steps(x, rate, ch, speed, nl):
+        h = L.orc_sonicCreateStream(rate, ch, 0)
+        L.orc_sonicSetSpeed(h, speed); L.orc_sonicEnableNonlinearSpeedup(h, nl); L.orc_sonicSetDurationFeedbackStrength(h, 0.0)
+        x = np.ascontiguousarray(x, np.int16)
+        n = x.size // ch
+        for pos in range(0, n, 1000):
+            seg = np.ascontiguousarray(x[pos * ch:(pos + 1000) * ch])
+            L.orc_sonicWriteShortToStream(h, orc.sptr(seg), seg.size // ch)
+        L.orc_sonicFlushStream(h)
+        k = int(L.orc_sonicIntStepCount(h))
+        L.orc_sonicDestroyStream(h)
+        return k
+    for rate, ch, speed, nl, count in ((16000, 1, 3.5, 1.0, 12), (16000, 1, 3.5, 1.0, 600), (22050, 2, 1.5, 1.0, 9),
+                                       (16000, 1, 0.6, 0.0, 5), (44100, 1, 2.0, 1.0, 4)):
+        base = [speech_like(rate * 2, rate, seed=900 + i, channels=ch) for i in range(6)]
+        b = Batch(Plan(rate, False), [rate * 2] * count, ch, speed, nl, 0.0)
+        b.upload([base[i % 6] for i in range(count)])
+        b.run()
+        steps = b.step_counts()
+        ref = [oracle_steps(x, rate, ch, speed, nl) for x in base]
+        assert list(steps) == [ref[i % 6] for i in range(count)], (rate, ch, speed, nl, count, list(steps[:6]), ref)
+
+
 def test_config4_whole_batch_on_one_gpu(orc):
     """ALL of BASELINE configs[4] on one GPU: the 2 048 mixed streams x 10 s (rate by i%2, channels by (i/2)%2,
     speed by (i/4)%2; 2 048 distinct signals, seed = 4000 + global index) run two ways -- ONE 2 048-stream

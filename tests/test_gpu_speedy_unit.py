@@ -346,25 +346,36 @@ def test_hook_spectral_difference(orc):
 
 def test_history_is_bounded_when_tensions_lag(orc):
     """A caller that only adds frames (or lags far behind with speedyComputeTension) does not make the stream keep every
-    row: device memory stays flat over 20 000 frames, a tension far behind the newest frame is refused with a message (the
-    reference's 21-entry spectrum ring no longer holds it either, speedy.c:97), recent ones still come out right."""
+    row: device memory stays flat over 20 000 frames.  A tension far behind the newest frame is answered as the reference
+    answers it -- from whatever its 21-entry spectrum ring and 42-entry hysteresis ring hold NOW (speedy.c:198-200,484-487,
+    594-608; round 4: the same value as the oracle's, bit for bit) -- and recent ones still come out right."""
     import ctypes as C
     import torch
     from speedy_amd._lib import c_float_p, lib
     L = lib()
     L.speedyHipSetMatchMatlab(0)
     s = L.speedyCreateStream(16000)
+    o = orc.Speedy(16000, False)
     W = L.speedyInputFrameSize(s)
     rng = np.random.default_rng(3)
     frame = (rng.standard_normal(W) * 0.1).astype(np.float32)
     for t in range(600):
         L.speedyAddData(s, frame.ctypes.data_as(c_float_p), t)
+        o.add_data(frame, t)
     free0 = torch.cuda.mem_get_info()[0]
     for t in range(600, 20000):
-        L.speedyAddData(s, np.roll(frame, t).ctypes.data_as(c_float_p), t)
+        x = np.roll(frame, t)
+        L.speedyAddData(s, x.ctypes.data_as(c_float_p), t)
+        o.add_data(x, t)
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 8 << 20, (free0, free1)
     v = C.c_float(0)
-    assert L.speedyComputeTension(s, 100, C.byref(v)) == 0 and b"older than the history" in L.speedyHipLastError()
-    assert L.speedyComputeTension(s, 19999 - 12, C.byref(v)) == 1 and np.isfinite(v.value)
+    for t in (100, 19999 - 12, 7, 19999 - 12, 19999 - 30):      # stale, recent, stale, the same again, between the two rings
+        ok, ref = o.compute_tension(t)
+        assert L.speedyComputeTension(s, t, C.byref(v)) == int(ok) == 1
+        assert np.float32(v.value) == np.float32(ref), (t, v.value, ref)
+        got = np.ctypeslib.as_array(L.speedyGetInternalState(s), shape=(15,)).copy()
+        want = o.features()
+        for i in (0, 4, 5, 6, 7, 8, 9, 10, 11, 13, 14):
+            assert got[i] == want[i], (t, i, got[i], want[i])
     L.speedyDestroyStream(s)
