@@ -599,6 +599,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       const int T = k * 64 * NWM + sid;
       const int nlMax = 8 * skip + 1;
       int first = 0, ft = -1, fr = 0, half = 0;
+#ifdef SPX_RAGGED_LAG_MAJOR
       for (int t = 0; t < nlMax; t++) {
         const int full = (t + par) >> 1;             // whole pairs beyond lo >> 1
         const int cnt = full + ((t + par) & 1);      // + the lone sample of an odd lag (lo + t odd <=> t + par odd)
@@ -608,6 +609,23 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         }
         first += cnt;
       }
+#else
+      // Round 4: PAIR-major order -- pair r of every lag that has one, then pair r + 1 ... -- so that neighbouring lanes hold
+      // DIFFERENT lags.  A lane ends its task with a ds_add_u32 into its lag's sum, and lanes of a wave that add into one word
+      // are served one after the other: in lag-major order up to 17 neighbouring lanes shared a lag (and every idle lane of the
+      // second round added its zero into the sum of lag 0): ~330 LDS cycles of atomics per step, right in front of the step's
+      // second barrier, against ~30 in this order (tools/lds_conflict_model.py) -- the bank conflicts the round-3 counters showed
+      // and the model of the reads could not explain.  Lag t has pair r iff r < ceil((t + par) / 2), i.e. t >= 2 r + 1 - par.
+      for (int r = 0; 2 * r + 1 - par < nlMax; r++) {
+        const int tmin = (2 * r + 1 - par) > 0 ? (2 * r + 1 - par) : 0;
+        const int cnt = nlMax - tmin;                // lags that have a pair (or the lone sample) number r
+        if (ft < 0 && T < first + cnt) {
+          ft = tmin + (T - first); fr = r;
+          half = (r < ((ft + par) >> 1)) ? 0 : 1;   // beyond the lag's whole pairs: the lone sample of an odd lag
+        }
+        first += cnt;
+      }
+#endif
       const int w = (ft < 0) ? 0 : ((ft & 0xff) | ((fr & 0xff) << 8) | (half << 16) | (1 << 17));
       if (par == 0) rP0[k] = w; else rP1[k] = w;
     }
@@ -619,6 +637,10 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   const int myT = sid % NLAG, myC = sid / NLAG;
   const bool myOn = myC < NCH;
   const int chM = (65536 + NCH - 1) / NCH;  // g / NCH == (g * chM) >> 16 for every group count (checked by spx_walk_fast_supports)
+  // the lane's constant parts of its rectangle operand addresses (round 4, see the coarse dealing below for the algebra):
+  // byte address = (uniform part of the step) + (constant of the lane) [+ one uniform-selected term for the `b` parity]
+  const int rC16 = 16 * myC, rC4 = 4 * myC;
+  const int rB0 = 2 * myT + ((myT & 1) ? dA : 0), rFlip = (myT & 1) ? -dA : dA;
   FSTAMP_VARS
   // The SAD phase of a refine search at window offset o over the lags lo..hi: the ragged tasks and the rectangle of the
   // calling lane, added into sums[lag - lo].
@@ -632,12 +654,17 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     unsigned rm[FRG];
 #pragma unroll
     for (int k = 0; k < FRG; k++) {
-      if (k >= nRG) { rt[k] = 0; rm[k] = 0u; ra[k] = 0u; rb[k] = 0u; continue; }
+      if (k >= nRG) { rt[k] = 0; rm[k] = 0u; ra[k] = 0u; rb[k] = 0u; continue; }   // (no atomic is issued for k >= nRG)
       const int w = par ? rP1[k] : rP0[k];
       rt[k] = w & 0xff;
       const int rr = (w >> 8) & 0xff;
       rm[k] = (w & (1 << 17)) ? ((w & (1 << 16)) ? 0xffffu : 0xffffffffu) : 0u;
+#ifdef SPX_RAGGED_LAG_MAJOR
       if (!(w & (1 << 17)) || rt[k] >= nl) { rt[k] = 0; rm[k] = 0u; }   // no task, or a lag the clamped search does not have
+#else
+      // no task, or a lag the clamped search does not have
+      if (!(w & (1 << 17)) || rt[k] >= nl) { rt[k] = 0; rm[k] = 0u; }   // (rm == 0 marks the lane idle for the add below)
+#endif
       const int ea = o + 2 * (c0 + rr);
       ra[k] = *reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea));
       rb[k] = *reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea + lo + rt[k]));
@@ -652,6 +679,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     const int LG = G - NCH * NGL;
     asm volatile("" : "+s"(NGL));  // opaque: keeps the branch conditions below scalar compares of this value
     const bool tOk = myOn && myT < nl;
+#ifdef SPX_RECT_ADDR_R03
     const int pT = lo + myT;
     const int ea = o + 8 * myC * NGL;  // first sample of the lane's groups (same parity as o)
     const unsigned* ap = reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea));
@@ -662,6 +690,26 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     const unsigned* bpx = (myC < LG) ? bp + xOff : apx;
     const unsigned* app = ap + pOff;
     const unsigned* bpp = (myC < rho) ? bp + pOff : app;
+#else
+    // The lane's groups start at sample ea = o + 8 myC NGL (same parity as o), its `b` operand at ea + lo + myT; its left-over
+    // group is group NCH NGL + myC and its left-over pair is pair 4 G + myC of the rectangle.  As byte addresses:
+    //   a      = [M + 2 o + (o & 1) dA]  + 16 myC NGL
+    //   b      = [M + 2 (o + lo)]        + 16 myC NGL + 2 myT + (parity of o + lo + myT ? dA : 0)
+    //   a left-over group = a's uniform part + 16 NCH NGL + 16 myC      (the 16 myC NGL cancel),   pair: + 16 G + 4 myC
+    // -- uniform parts on the scalar unit, lane constants in registers since kernel start, one multiplication.
+    const int aU = LY.off_mono + 2 * o + (o & 1) * dA;
+    const int bU = LY.off_mono + 2 * (o + lo);
+    const int aL = (int)__umul24((unsigned)rC16, (unsigned)NGL);
+    const int bSel = rB0 + ((o + lo) & 1) * rFlip;
+    const int XU = 16 * NCH * NGL, GU = 16 * G;
+    const unsigned* ap = reinterpret_cast<const unsigned*>(lds + (aU + aL));
+    const unsigned* bp = reinterpret_cast<const unsigned*>(lds + (bU + aL + bSel));
+    const int apxO = aU + XU + rC16, appO = aU + GU + rC4;
+    const unsigned* apx = reinterpret_cast<const unsigned*>(lds + apxO);
+    const unsigned* bpx = reinterpret_cast<const unsigned*>(lds + ((myC < LG) ? bU + XU + rC16 + bSel : apxO));
+    const unsigned* app = reinterpret_cast<const unsigned*>(lds + appO);
+    const unsigned* bpp = reinterpret_cast<const unsigned*>(lds + ((myC < rho) ? bU + GU + rC4 + bSel : appO));
+#endif
     unsigned d = 0u;
 #ifdef SPX_RECT_OLD
     while (SPX_UNLIKELY(NGL > 3)) {  // long periods at the higher rates only
@@ -695,13 +743,23 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     for (int k = 0; k < 4; k++) d = __builtin_amdgcn_sad_u16(xa[k], xb[k], d);
     d = __builtin_amdgcn_sad_u16(pa, pb, d);
 #endif
+#ifdef SPX_RAGGED_LAG_MAJOR
     atomicAdd(&sums[myT], tOk ? d : 0u);
+#else
+    atomicAdd(&sums[tOk ? myT : 128 + lane], tOk ? d : 0u);
+#endif
     FSTAMP(13);
 #pragma unroll
     for (int k = 0; k < FRG; k++) {
       if (k < nRG) {
         const unsigned dr = __builtin_amdgcn_sad_u16(ra[k] & rm[k], rb[k] & rm[k], 0u);
+#ifdef SPX_RAGGED_LAG_MAJOR
         atomicAdd(&sums[rt[k]], dr);
+#else
+        // an idle lane's zero goes to a word of its own in the spare block behind the two sum buffers (sums + 128 + lane stays
+        // inside it from either buffer), not into a sum other lanes add into: same-address atomics of a wave are served in turn
+        atomicAdd(&sums[rm[k] ? rt[k] : 128 + lane], dr);
+#endif
       }
     }
     FSTAMP(14);
@@ -789,7 +847,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   // groups contain T; a group is four consecutive pair slots of that lag (slot j = samples 2j, 2j+1; an odd lag's last
   // slot holds one sample).  cOffA / cOffB: element offsets of the two operands from the step's decimated position;
   // cMask: per-slot byte masks (all / low half / none); cLag: lag index (= lane of the sum it adds into). ----
-  int cOffA[FCG], cOffB[FCG], cLag[FCG];
+  int cOffA[FCG], cOffB[FCG], cLag[FCG], cByteB[FCG], cFlipB[FCG];
   unsigned cMask[FCG][4];
   int nGC;  // groups per lane (uniform)
   {
@@ -799,7 +857,14 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     if (nGC > FCG) nGC = FCG;  // spx_walk_config keeps such plans off this kernel
 #pragma unroll
     for (int g = 0; g < FCG; g++) {
+#ifndef SPX_COARSE_BLOCK
+      // (round 4) consecutive groups -- the groups of one lag -- on DIFFERENT waves: a wave's ds_add_u32 then finds at most two
+      // or three of its lanes on one sum instead of up to eight neighbours (model: 47 -> 20 LDS cycles of atomics per step in
+      // front of the first barrier, for 12 more cycles of bank conflicts in the operand reads behind it)
+      const int T = g * 64 * NWM + lane * NWM + wave;
+#else
       const int T = g * 64 * NWM + tid;
+#endif
       int first = 0, found = 0, fq = 0, ff = 0;
       for (int q = 0; q < nC; q++) {
         const int p = minC + q;
@@ -811,12 +876,20 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       cOffA[g] = 8 * gi;
       cOffB[g] = p + 8 * gi;
       cLag[g] = found ? fq : 0;
+      if (!found) { cOffA[g] = 0; cOffB[g] = 0; }
+      // Round 4: the operand addresses as (wave-uniform part of the step) + (constant of the lane).  pair_addr(base, d, e) =
+      // base + 2 e + (e & 1) d; the step's decimated position oD is uniform, so the parity of e = oD + offset is the uniform
+      // parity of oD XOR the lane's constant parity of its offset:  address = base + 2 oD + [2 off + (off odd ? d : 0)] +
+      // (oD & 1) * (off odd ? -d : d).  A step then forms its two addresses with one v_add and one v_mad instead of the dozen
+      // VALU instructions of two generic pair_addr evaluations -- and every instruction a search wave issues is on the chain.
+      cOffA[g] = 2 * cOffA[g];                                                   // (the `a` offset is even: its parity is oD's)
+      cByteB[g] = 2 * cOffB[g] + ((cOffB[g] & 1) ? dPl : 0);
+      cFlipB[g] = (cOffB[g] & 1) ? -dPl : dPl;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int j = 4 * gi + k;
         cMask[g][k] = !found ? 0u : (j < (p >> 1) ? 0xffffffffu : ((j == (p >> 1) && (p & 1)) ? 0xffffu : 0u));
       }
-      if (!found) { cOffA[g] = 0; cOffB[g] = 0; }
     }
   }
   const double scaleC = 65536.0 / (double)(minC + lane);
@@ -860,11 +933,14 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     const int oD = (o * skipM) >> 16;
     const int r = o - oD * skip;
     const int plr = LY.off_pl + r * LY.plStrideB;
+    const int parD = oD & 1;
+    const int baseU = plr + 2 * oD;            // uniform
+    const int aU = baseU + parD * dPl;         // uniform
 #pragma unroll
     for (int g = 0; g < FCG; g++) {
       if (g < nGC) {
-        const unsigned* ap = reinterpret_cast<const unsigned*>(lds + pair_addr(plr, dPl, oD + cOffA[g]));
-        const unsigned* bp = reinterpret_cast<const unsigned*>(lds + pair_addr(plr, dPl, oD + cOffB[g]));
+        const unsigned* ap = reinterpret_cast<const unsigned*>(lds + (aU + cOffA[g]));
+        const unsigned* bp = reinterpret_cast<const unsigned*>(lds + (baseU + cByteB[g] + parD * cFlipB[g]));
 #pragma unroll
         for (int k = 0; k < 4; k++) { a[g][k] = ap[k]; b[g][k] = bp[k]; }
       }

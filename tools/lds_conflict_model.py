@@ -14,6 +14,7 @@ rate, skip = 16000, 4
 minP, maxP = rate // 400, rate // 65
 minC, nC = minP // skip, maxP // skip - minP // skip + 1
 NWM = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+DEAL = sys.argv[5] if len(sys.argv) > 5 else "spread"   # coarse dealing: "block" = task = thread (round 3), "spread" = consecutive tasks on different waves (round 4)
 FCMD_INTS = 64
 # layout (fast_lds_layout_i)
 o = 0
@@ -80,7 +81,7 @@ def coarse(oo):
         for g in range(FCG):
             A, B, L = [], [], []
             for lane in range(64):
-                T = g * 64 * NWM + w * 64 + lane
+                T = g * 64 * NWM + ((lane * NWM + w) if DEAL == "spread" else (w * 64 + lane))
                 if T < len(tasks):
                     q, gi = tasks[T]
                     A.append(pair_addr(plr, dPl, oD + 8 * gi)); B.append(pair_addr(plr, dPl, oD + minC + q + 8 * gi)); L.append(off_sumC + 4 * q)
@@ -141,3 +142,47 @@ for _ in range(N):
 print("pad_mono %d pad_pl %d wcap %d: LDS cycles per step (model, reads only; ragged tasks and sum reads not modelled)" % (pad_mono, pad_pl, wcap))
 print("  coarse loads   %6.1f (conflict-free %5.1f)   coarse atomics %5.1f (conflict-free 8)" % (cs / N, ci / N, ca / N))
 print("  refine rect    %6.1f (conflict-free %5.1f)   refine atomics %5.1f (conflict-free 8)" % (rs / N, ri / N, ra / N))
+
+
+# ---- ragged refine tasks (round 4): their two ds_add_u32 per lane ----
+def ragged_tasks(par, order):
+    tasks = []
+    nl = 8 * skip + 1
+    if order == "t":          # lag-major (round 3): the tasks of one lag on neighbouring lanes
+        for t in range(nl):
+            full = (t + par) >> 1
+            for r in range(full + ((t + par) & 1)):
+                tasks.append(t)
+    else:                     # pair-major: neighbouring lanes hold different lags
+        rmax = (nl + par) // 2 + 1
+        for r in range(rmax):
+            for t in range(nl):
+                full = (t + par) >> 1
+                if r < full + ((t + par) & 1):
+                    tasks.append(t)
+    return tasks
+
+
+def ragged_atomics(order, idle):
+    tot = 0
+    for par in (0, 1):
+        tasks = ragged_tasks(par, order)
+        rounds = (len(tasks) + 64 * NWM - 1) // (64 * NWM)
+        for k in range(rounds):
+            for w in range(NWM):
+                L = []
+                for lane in range(64):
+                    T = k * 64 * NWM + 64 * w + lane
+                    if T < len(tasks):
+                        L.append(off_sumR + 4 * tasks[T])
+                    else:
+                        L.append(off_sumR if idle == "lag0" else off_sumR + 512 + 4 * lane)
+                tot += atomic_cycles(L)
+    return tot / 2.0, len(ragged_tasks(0, order)), len(ragged_tasks(1, order))
+
+
+for order in ("t", "r"):
+    for idle in ("lag0", "own"):
+        c, n0, n1 = ragged_atomics(order, idle)
+        print("  ragged atomics, tasks in %s-major order, idle lanes add to %s: %5.1f LDS cycles per step (%d / %d tasks)" % (
+            order, "sums[0]" if idle == "lag0" else "a word of their own", c, n0, n1))
