@@ -875,7 +875,10 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       const int p = minC + fq, gi = T - ff;
       cOffA[g] = 8 * gi;
       cOffB[g] = p + 8 * gi;
-      cLag[g] = found ? fq : 0;
+      // (a lane without a group adds its zero into a word of its own in the spare block behind the sum buffers -- index 256 +
+      // lane from either coarse buffer -- not into the sum of lag 0: same-address atomics of a wave are served one after the
+      // other, and with two search waves or at 22.05 kHz a third of the lanes of a round have no group)
+      cLag[g] = found ? fq : 256 + lane;
       if (!found) { cOffA[g] = 0; cOffB[g] = 0; }
       // Round 4: the operand addresses as (wave-uniform part of the step) + (constant of the lane).  pair_addr(base, d, e) =
       // base + 2 e + (e & 1) d; the step's decimated position oD is uniform, so the parity of e = oD + offset is the uniform
@@ -977,7 +980,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
           unsigned d = 0;
 #pragma unroll
           for (int k = 0; k < 4; k++) d = __builtin_amdgcn_sad_u16(a[g][k] & cMask[g][k], b[g][k] & cMask[g][k], d);
-          atomicAdd(&sumC[tg * 64 + cLag[g]], d);  // idle lanes add 0 to lag 0
+          atomicAdd(&sumC[tg * 64 + cLag[g]], d);  // (idle lanes: a word of their own, see the dealing)
         }
       }
       FSTAMP(3);
