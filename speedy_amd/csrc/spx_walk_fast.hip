@@ -73,6 +73,15 @@
 #endif
 #define SPX_CT_WCAP_OF(NWMV, NWCV) (((NWCV) == 0 && (NWMV) <= 2) ? SPX_CT_WCAP_TP : SPX_CT_WCAP)
 enum { FCMD_STEP = 1, FCMD_COPY = 2, FCMD_REFILL = 3, FCMD_POLL = 4, FCMD_EXIT = 5 };
+// Diagnostic builds only (-DSPX_PROBE_SITE=k, tools/slack_probe.sh): about 100 cycles of s_nop at ONE place of the step.  What
+// the walk kernel's time grows by tells whether that place is on the chain (all of it shows) or in the shadow of a wait (none
+// does) -- in-kernel time stamps cannot tell since the waits went: reading s_memtime drains the LDS counter and serialises
+// exactly the overlap that is to be measured.  Never in the product.
+#ifdef SPX_PROBE_SITE
+#define SPX_PROBE(k) do { if ((k) == SPX_PROBE_SITE) asm volatile(".rept 7\n\ts_nop 15\n\t.endr" ::: "memory"); } while (0)
+#else
+#define SPX_PROBE(k)
+#endif
 #define FCMD_INTS 64  // ints per command slot: field k is written by lane k of the publishing wave
 // at most this many coarse groups / ragged refine tasks per lane (22.05 kHz: 303 groups and 441 tasks over the search lanes):
 // constants of the instantiation -- fewer search waves, more tasks per lane
@@ -670,6 +679,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       rb[k] = *reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea + lo + rt[k]));
     }
     FSTAMP(12);
+    SPX_PROBE(6);   // behind the ragged loads, in front of the rectangle set-up
     // common share: the c0 pairs every lag of the search has form a rectangle of lags x pairs, cut into groups of four
     // pairs and dealt to ALL search lanes: lane = (lag myT, chunk myC) takes NGL = (c0 / 4) / NCH consecutive groups --
     // the same count for every lane, so no masks -- plus, for the first chunks, one of the left-over groups and one of
@@ -968,11 +978,13 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     }
     FSTAMP(2);
     const int o = (int)(pos - wbase);
+    SPX_PROBE(1);   // in front of the coarse operand addresses
     // ---- coarse search on the decimated signal: each lane its constant group(s) of pair slots ----
     int bestC;
     {
       unsigned a[FCG][4], b[FCG][4];
       coarse_loads(o, a, b);
+      SPX_PROBE(2);   // behind the coarse loads (their shadow)
       FAST_PUBLISH(FCMD_STEP, 0, 0, 0, 0);  // the previous step's cross-fade rides on this step's command; behind the loads
 #pragma unroll
       for (int g = 0; g < FCG; g++) {
@@ -984,14 +996,17 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         }
       }
       FSTAMP(3);
+      SPX_PROBE(3);   // behind the coarse atomics, in front of the first barrier
       fast_sync();
       FSTAMP(4);
+      SPX_PROBE(4);   // behind the first barrier, in front of the coarse select
       if (wave == 0) sumC[(1 - tg) * 64 + lane] = 0;  // the buffer the previous step used: everyone is past it
       const unsigned dsum = sumC[tg * 64 + lane];
       unsigned kmin;
       bestC = fast_select(dsum, scaleC, validC, false, minC, kmin);
     }
     FSTAMP(5);
+    SPX_PROBE(5);   // behind the coarse select, in front of the refine set-up
     // ---- refine at full rate around the coarse winner ----
     int period = (minC + bestC) * skip;
     int lo = period - (skip << 2), hi = period + (skip << 2);
@@ -1013,8 +1028,10 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       }
       asm volatile("" ::"v"(nLane), "v"(remLane));  // here, while the sums are on their way -- not behind the barrier
       FSTAMP(6);
+      SPX_PROBE(7);   // behind the refine atomics and the candidate divisions, in front of the second barrier
       fast_sync();  // the step's one workgroup barrier: refine sums complete, the output waves done with the command
       FSTAMP(7);
+      SPX_PROBE(8);   // behind the second barrier, in front of the refine select
       if (wave == 0) sumR[(1 - tg) * 64 + lane] = 0;
       dsum = sumR[tg * 64 + lane];
     }
@@ -1024,6 +1041,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     period = lo + best;
     const int minDiff = (int)(kmin >> 16);  // floor(diff / lag) of the winner
     FSTAMP(8);
+    SPX_PROBE(9);   // behind the refine select (decision, bookkeeping)
     // Previous-period rule (libsonic prevPeriodBetter, preferNewPeriod = 1).  Only "maxDiff > 3*minDiff" is ever asked
     // of the worst lag, and max_p floor(d_p/p) = floor(max_p d_p/p), so the test is "some lag has d_p >= (3*minDiff+1)*p".
     int ret = period, sel = best;
@@ -1170,6 +1188,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
             i = e;
             const pos_t availE = (linear && !flushBlk) ? n_tsm : availBlk + (i + 1) * perEvent;
             FSTAMP(0);
+            SPX_PROBE(10);  // once per EVENT of the hot loop (not per step)
             const float sm1 = speed - 1.0f;
             pos_t pos = base;
             bool failed;
