@@ -20,7 +20,7 @@ def test_bench_two_ranks_same_bytes_as_solo(tmp_path):
     from speedy_amd.batch import Batch, Plan
     crc = str(tmp_path / "crc")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-pcie", "--no-cpu-baseline", "--no-api", "--no-config4", "--crc-out", crc, "--backend", "gloo"]
+           "--no-pcie", "--no-cpu-baseline", "--no-api", "--no-config4", "--no-large-batch", "--crc-out", crc, "--backend", "gloo"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -65,7 +65,7 @@ def test_no_silent_downgrade_of_the_backend():
         pytest.skip("needs a box with fewer GPUs than ranks")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-                        "--no-pcie", "--no-cpu-baseline", "--no-api", "--no-config4"], capture_output=True, text=True, timeout=600, env=env)
+                        "--no-pcie", "--no-cpu-baseline", "--no-api", "--no-config4", "--no-large-batch"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode != 0
     assert "one device per rank" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
@@ -79,3 +79,15 @@ def test_check_scale_partitions_agree():
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["ok"] and out["streams_checked"] == 512 and out["runs"]["2"]["n_ranks_seen"] == 2
+
+
+def test_config4_strong_scaling_partitions_agree():
+    """BASELINE configs[4] as a fixed batch (bench.py --total-streams, the strong-scaling leg `config4_full`) on what a 1-GPU box
+    can run: 512 mixed streams as ONE rank's single call and as two ranks' 256-stream calls (the ranks share the GPU, gloo) --
+    every global stream the same output CRC in both runs, the weak leg's shards included."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_scale.py"), "--gpus", "1,2", "--backend", "gloo",
+                        "--config4", "--total-streams", "512"], capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["ok"] and out["config4_streams_checked"] == 512 and out["runs"]["2"]["n_ranks_seen"] == 2
