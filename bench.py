@@ -336,6 +336,8 @@ def main():
                          "scaling; N = 1 runs all of it in one call); reported as config4_full")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the 2 048-stream call of the headline kind")
     ap.add_argument("--no-api", action="store_true", help="skip the many-handle run of the drop-in API (tools/stream_bench.c)")
+    ap.add_argument("--serial", action="store_true", help="spx_set_concurrent(0): the three kernels of a step back to back on one "
+                    "stream (what the per-kernel PMC passes behind roofline.traffic need: one kernel in flight at a time)")
     ap.add_argument("--chunks", type=int, default=int(os.environ.get("SPX_CHUNKS", "1")),
                     help="time chunks per stream inside one spx_batch_run (analysis of chunk c+1 overlaps the walk of c)")
     ap.add_argument("--crc-out", default=None, help="write this rank's per-stream output CRC-32s to CRC_OUT.rank<r>.json "
@@ -399,6 +401,8 @@ def main():
     b.upload(streams)
     L = plan.L
     L.spx_set_pipeline_chunks(args.chunks)
+    if args.serial:
+        L.spx_set_concurrent(0)
 
     def barrier():
         torch.cuda.synchronize()

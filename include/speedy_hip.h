@@ -140,6 +140,12 @@ int spx_debug_last_walk_form(void);
  * decide the concurrent mode.  which: 0 tension, 1 walk 16 kHz mono (4 + 4 waves, long window), 2 walk 22.05 kHz mono lean
  * (4 + 0), 3 analysis 16 kHz, 4 analysis 22.05 kHz, 5 walk 16 kHz multi-channel (4 + 4).  -1 for an unknown index. */
 int spx_debug_kernel_vgprs(int which);
+/* Diagnostics: the walk kernel a batch of this shape would be served by -- out[0] allocated VGPRs, out[1] scratch bytes per lane
+ * (spilled registers), out[2] LDS bytes per workgroup, out[3] its form (as spx_debug_last_walk_form), out[4] waves per workgroup --
+ * and the analysis kernel of a sample rate (out[0 .. 2] alike).  tests/test_gpu_parity.py pins these per (rate, channels, batch
+ * size): the engine's choice of launch mode is arithmetic over them. */
+int spx_debug_walk_info(int sample_rate, int channels, int n_streams, int speedup_only, int short_jobs, int lean, int* out5);
+int spx_debug_analysis_info(int sample_rate, int* out3);
 /* Diagnostics: 1 if the last spx_batch_run / analyze+walk call of this process took the concurrent three-kernel mode, 0 if it
  * launched its kernels in sequence (another process holds the device's concurrent-mode lock, a tuning variable, the batch shape). */
 int spx_debug_last_call_concurrent(void);

@@ -63,6 +63,8 @@ SYMBOLS = {
     "spx_debug_last_walk_form": (C.c_int, []),
     "spx_debug_kernel_vgprs": (C.c_int, [C.c_int]),
     "spx_debug_last_call_concurrent": (C.c_int, []),
+    "spx_debug_walk_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "spx_debug_analysis_info": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "spx_device_alloc": (C.c_void_p, [C.c_size_t]),
     "spx_device_free": (None, [C.c_void_p]),
     "spx_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

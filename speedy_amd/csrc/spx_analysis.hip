@@ -65,7 +65,7 @@ static __host__ __device__ inline size_t work_bytes(int W, int tf, bool ct = fal
 // 16 kHz (W = 240 = 4*4*3*5) and 22.05 kHz (W = 330 = 2*3*5*11) have their own instantiations of the kernel; every
 // other window size takes the plan-driven one.  Returns the compiled-in window size, or 0.
 static inline int plan_ct_window(const SpxPlanDev& P) {
-  static const bool generic_only = getenv("SPX_ANALYSIS_GENERIC") != nullptr;  // A/B and tests of the plan-driven path
+  static const bool generic_only = spx_tuning_env("SPX_ANALYSIS_GENERIC") != nullptr;  // A/B and tests of the plan-driven path
   if (generic_only || P.rader || P.nstages != 4) return 0;
   if (P.W == 240 && P.radix[0] == 4 && P.radix[1] == 4 && P.radix[2] == 3 && P.radix[3] == 5) return 240;
   if (P.W == 330 && P.radix[0] == 2 && P.radix[1] == 3 && P.radix[2] == 5 && P.radix[3] == 11) return 330;
@@ -80,7 +80,7 @@ static size_t analysis_lds_bytes(const SpxPlanDev& P, bool ct) {  // for the til
   size_t small = (size_t)3 * (tf + 1) * sizeof(float);
   size_t stage = (stage_samples(P, tf) * sizeof(short) + 15) & ~(size_t)15;
   // tuning only (fewer workgroups per CU); part of the size so that the co-residency rule sees it; read once per process
-  static const size_t pad = [] { const char* e = getenv("SPX_ANALYSIS_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
+  static const size_t pad = [] { const char* e = spx_tuning_env("SPX_ANALYSIS_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
   return work_bytes(P.W, tf, ct, P.dft_waves) + ((mags + 15) & ~(size_t)15) + ((small + 15) & ~(size_t)15) + stage + pad;
 }
 // what spx_launch_analysis (int16 input) will ask for: the engine's co-residency arithmetic uses this
@@ -938,7 +938,7 @@ void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n
 #undef SPX_LAUNCH_ANALYSIS
 }
 
-int spx_analysis_vgprs(const SpxPlanDev& P) {
+int spx_analysis_vgprs(const SpxPlanDev& P, int* scratch_bytes) {
   const int ctw = plan_ct_window(P);
   const bool small = P.tile_frames == SPX_TF_SMALL;
   const void* fn;
@@ -949,7 +949,7 @@ int spx_analysis_vgprs(const SpxPlanDev& P) {
   else fn = ctw == 240 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF, 240>)
           : ctw == 330 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF, 330>)
                        : reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF, 0>);
-  return spx_kernel_vgprs(fn);
+  return spx_kernel_vgprs(fn, scratch_bytes);
 }
 
 void spx_launch_analysis_frames(const SpxPlanDev& P, const SpxStreamDev* streams, int n_tiles, const float* frames,

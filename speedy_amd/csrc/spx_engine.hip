@@ -124,18 +124,20 @@ static SpxDevGuard g_guard[64];
 
 // Allocated VGPRs of a kernel (hipFuncGetAttributes, rounded up to the granule of 8), cached per function: the query is not
 // free and the engine asks on every call.  Several plans may ask from several threads at once.
-int spx_kernel_vgprs(const void* fn) {
+int spx_kernel_vgprs(const void* fn, int* scratch_bytes) {
   static std::mutex mu;
-  static std::map<const void*, int> cache;
+  static std::map<const void*, std::pair<int, int>> cache;
   std::lock_guard<std::mutex> g(mu);
   auto it = cache.find(fn);
-  if (it != cache.end()) return it->second;
-  hipFuncAttributes a;
-  int regs = 128;
-  if (hipFuncGetAttributes(&a, fn) == hipSuccess) regs = (a.numRegs + 7) & ~7;
-  (void)hipGetLastError();
-  cache[fn] = regs;
-  return regs;
+  if (it == cache.end()) {
+    hipFuncAttributes a;
+    int regs = 128, scratch = -1;
+    if (hipFuncGetAttributes(&a, fn) == hipSuccess) { regs = (a.numRegs + 7) & ~7; scratch = (int)a.localSizeBytes; }
+    (void)hipGetLastError();
+    it = cache.emplace(fn, std::make_pair(regs, scratch)).first;
+  }
+  if (scratch_bytes) *scratch_bytes = it->second.second;
+  return it->second.first;
 }
 
 // Cross-process half of SpxDevGuard: the concurrent mode's deadlock-freedom bound counts the polling workgroups of ONE
@@ -556,7 +558,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // flag per tile; the tension kernel (second side stream) turns ready tiles into per-frame speeds and publishes their
   // count; the walk kernel starts at once on the caller's stream and runs every event whose speed is there.  Same
   // arithmetic, same results; only the serialisation of the kernels goes.
-  static const bool env_serial = getenv("SPX_SERIAL") != nullptr;  // tuning: kernels back to back on one stream
+  static const bool env_serial = spx_tuning_env("SPX_SERIAL") != nullptr;  // tuning: kernels back to back on one stream
   // The three kernels hand frames over through flags that consumers poll.  Polling workgroups hold their CU resources
   // while they wait, so the mode is only safe if the analysis kernel -- which waits for nothing -- can always place a
   // workgroup somewhere: then it runs to completion whatever happens, and everything downstream follows.  A CU is
@@ -578,7 +580,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // few percent of the chain) and the call keeps the concurrent mode (mono only: a multi-channel stream's cross-fades read
   // the input from HBM, which the chain cannot wait for).
   bool lean_walk = false;
-  static const bool no_lean = getenv("SPX_NO_LEAN_WALK") != nullptr;   // A/B
+  static const bool no_lean = spx_tuning_env("SPX_NO_LEAN_WALK") != nullptr;   // A/B
   if (do_a && do_w && maxC == 1 && n <= plan->cu_count && wcfg.fast_kernel && wcfg.nwc > 0 && !no_lean && !force) {
     const SpxWalkConfig lc = spx_walk_config(d, n, maxC, speedup_only, false, true);
     if (lc.fast_kernel && lc.nwc == 0) {
@@ -605,7 +607,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     d8.tile_frames = spx_analysis_small_tile_frames();
     if (per_stream_lds + 2 * spx_analysis_lds_bytes(d8) <= lds_usable) d.tile_frames = d8.tile_frames;
   }
-  static const bool env_small_tile = getenv("SPX_TILE_SMALL") != nullptr;  // tuning: the 8-frame tile whenever concurrent
+  static const bool env_small_tile = spx_tuning_env("SPX_TILE_SMALL") != nullptr;  // tuning: the 8-frame tile whenever concurrent
   if (env_small_tile && do_a && do_w && d.tile_frames == spx_analysis_tile_frames()) d.tile_frames = spx_analysis_small_tile_frames();
   if (spx_analysis_lds_bytes(d) < lds_per_cu) {
     const size_t lds_closing = lds_per_cu - spx_analysis_lds_bytes(d) + 1;
@@ -633,7 +635,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   if (co_resident && doubtful && do_a && do_w && g_concurrent.load() && !env_serial && !force) {
     spx_plan::Trial& T = plan->trial;
     const long long key = ((long long)n << 40) ^ ((long long)L.total_frames << 8) ^ (maxC << 1) ^ (speedup_only ? 1 : 0);
-    static const int force = getenv("SPX_TRIAL_FORCE") ? atoi(getenv("SPX_TRIAL_FORCE")) : -1;  // tuning: 0 / 1 = no trial
+    static const int force = spx_tuning_env("SPX_TRIAL_FORCE") ? atoi(spx_tuning_env("SPX_TRIAL_FORCE")) : -1;  // tuning: 0 / 1 = no trial
     if (T.key != key) { T.key = key; T.calls = 0; T.choice = force; }
     if (T.choice < 0 && T.calls >= 3 && hipEventQuery(T.ev[1]) == hipSuccess && hipEventQuery(T.ev[3]) == hipSuccess) {
       float ms_seq = 0, ms_con = 0;
@@ -773,14 +775,14 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     auto launch_walk = [&]() {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, st); }
-      static const bool diag_nowait = getenv("SPX_DIAG_NOWAIT") != nullptr;  // DIAGNOSTIC ONLY: the walk reads the speeds
+      static const bool diag_nowait = spx_tuning_env("SPX_DIAG_NOWAIT") != nullptr;  // DIAGNOSTIC ONLY: the walk reads the speeds
       // the previous identical call left in the scratch array instead of waiting for this call's (timing experiments)
       // Kernels in sequence, and every stream of the call (of all groups of a mixed call) can have a CU to itself: ask for
       // more than half a CU's LDS per walk workgroup, so that they DO get one each.  Walk kernels of several groups launched
       // side by side, or a walk kernel placed while another group's analysis fills the CUs, otherwise land two to a CU here
       // and there, and those chains end the call: the configs[4] shard 3.30 -> 3.04 ms per step (profiles/r03/r03ad_config4_lds_min.txt).
       // (The concurrent mode needs that LDS for the analysis workgroups beside the walk; its idle-start gate does this job.)
-      static const bool no_excl = getenv("SPX_NO_EXCLUSIVE_CU") != nullptr;   // A/B
+      static const bool no_excl = spx_tuning_env("SPX_NO_EXCLUSIVE_CU") != nullptr;   // A/B
       const int total = force ? force->total_streams : n;
       const size_t lds_min = (!concurrent && !no_excl && nch == 1 && total <= cu_count) ? lds_per_cu / 2 + 1024 : 0;
       spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, (concurrent && !diag_nowait) ? d_ready : nullptr,
@@ -796,8 +798,8 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     // shared queue never start (every consumer is enqueued after its producers, which is safe with any mapping).  So an
     // idle start holds the analysis stream back with a gate kernel until the walk kernel's workgroups have been placed
     // (they count themselves in; spx_gate_kernel).
-    static const bool no_gate = getenv("SPX_NO_GATE") != nullptr;  // A/B only
-    static const unsigned gate_spins = [] { const char* e = getenv("SPX_GATE_SPINS"); return e ? (unsigned)atoi(e) : 1200u; }();
+    static const bool no_gate = spx_tuning_env("SPX_NO_GATE") != nullptr;  // A/B only
+    static const unsigned gate_spins = [] { const char* e = spx_tuning_env("SPX_GATE_SPINS"); return e ? (unsigned)atoi(e) : 1200u; }();
     if (concurrent && do_w && idle_start && !no_gate)
       hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, sa, d_ready + n, n, gate_spins);
     if (do_a && tiles[c] > 0) {
@@ -959,8 +961,8 @@ int spx_batch_run_mixed_taps(const spx_plan_t* plans, int n_plans, const spx_str
     fits_one = max_walk_regs + spx_tension_vgprs() + 2 * max_an_regs <= 512;
     if (!fits_one) concurrent = false;
   }
-  static const bool env_serial = getenv("SPX_SERIAL") != nullptr;
-  static const int env_mixed = getenv("SPX_MIXED_MODE") ? atoi(getenv("SPX_MIXED_MODE")) : -1;   // tuning: 0 sequence, 1 concurrent
+  static const bool env_serial = spx_tuning_env("SPX_SERIAL") != nullptr;
+  static const int env_mixed = spx_tuning_env("SPX_MIXED_MODE") ? atoi(spx_tuning_env("SPX_MIXED_MODE")) : -1;   // tuning: 0 sequence, 1 concurrent
   if (!g_concurrent.load() || env_serial || groups == 0) concurrent = false;
   if (env_mixed >= 0 && max_an_lds > 0) concurrent = env_mixed == 1;
   if (concurrent && !device_is_ours(lead->device)) concurrent = false;
@@ -1027,7 +1029,7 @@ int spx_batch_run_mixed_taps(const spx_plan_t* plans, int n_plans, const spx_str
   // 22.05 kHz at 0.87 instead of 0.92; the call ends with the later group's walk kernel).
   std::vector<int> ord;
   for (int g = 0; g < n_plans; g++) if (!gj[g].empty()) ord.push_back(g);
-  static const bool no_sjf = getenv("SPX_MIXED_NO_ORDER") != nullptr;   // A/B
+  static const bool no_sjf = spx_tuning_env("SPX_MIXED_NO_ORDER") != nullptr;   // A/B
   const bool chain_analyses = !concurrent && !no_sjf && ord.size() > 1;
   if (chain_analyses) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return plans[a]->dev.rate < plans[b]->dev.rate; });
   // Which stream a group runs on.  Kernels in sequence (every mix measured so far): the first group on the CALLER's stream,
@@ -1148,6 +1150,32 @@ int spx_debug_kernel_vgprs(int which) {
     case 5: return spx_walk_vgprs(*P, 256, 2, true, false);
     default: return -1;
   }
+}
+
+// Diagnostics: what spx_launch_walk would launch for a batch of this shape, and what that kernel costs -- out[0] allocated
+// VGPRs (rounded up to the granule of 8), out[1] scratch bytes per lane (spilled registers), out[2] LDS bytes per workgroup,
+// out[3] the form (16 * search waves + output waves; 0 = the general kernel), out[4] waves per workgroup.
+int spx_debug_walk_info(int sample_rate, int channels, int n_streams, int speedup_only, int short_jobs, int lean, int* out) {
+  const SpxPlanDev* P = spx_internal_shared_plan(sample_rate, 0);
+  if (!P || !out) return -1;
+  const SpxWalkConfig c = spx_walk_config(*P, n_streams, channels < 1 ? 1 : channels, speedup_only != 0, short_jobs != 0, lean != 0);
+  int scratch = -1;
+  out[0] = spx_walk_kernel_regs(*P, n_streams, channels, speedup_only != 0, short_jobs != 0, lean != 0, &scratch);
+  out[1] = scratch;
+  out[2] = (int)c.lds;
+  out[3] = c.fast_kernel ? 16 * c.nwm + c.nwc : 0;
+  out[4] = c.waves;
+  return 0;
+}
+// ... and the same for the analysis kernel of a rate (out[0] VGPRs, out[1] scratch bytes, out[2] LDS bytes) and the tension kernel
+int spx_debug_analysis_info(int sample_rate, int* out) {
+  const SpxPlanDev* P = spx_internal_shared_plan(sample_rate, 0);
+  if (!P || !out) return -1;
+  int scratch = -1;
+  out[0] = spx_analysis_vgprs(*P, &scratch);
+  out[1] = scratch;
+  out[2] = (int)spx_analysis_lds_bytes(*P);
+  return 0;
 }
 
 void spx_set_timing(int enabled) { g_timing = enabled != 0; }

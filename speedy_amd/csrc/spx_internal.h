@@ -3,6 +3,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
+// A/B switches of the developers' tools (tools/ab_lib.sh, tools/scale_sweep.sh ...) exist only in builds with -DSPX_TUNING
+// (`make -C speedy_amd/csrc tuning` -> speedy_amd/lib/ab/libspeedy_hip_tuning.so).  The shipped library reads the documented
+// environment variables only (INTEGRATION.md "Environment"): SPX_NO_POOL, SPX_POOL_*, SPX_SHARED_GPU, SPX_LOCK_DIR,
+// SPX_DEBUG_MODE, SPX_DEBUG_TRIAL.
+#ifdef SPX_TUNING
+static inline const char* spx_tuning_env(const char* name) { return getenv(name); }
+#else
+static inline const char* spx_tuning_env(const char*) { return nullptr; }
+#endif
+
 #define SPX_MAX_STAGES 16
 #define SPX_WAVE 64
 #define SPX_BLOCK 256
@@ -187,10 +199,12 @@ size_t spx_tension_lds_bytes();
 // VGPRs per lane the hardware allocates to a wave of the kernel that would be launched (hipFuncGetAttributes, rounded up
 // to the allocation granule of 8): the engine's co-residency rule needs them
 // (helper: allocated VGPRs of a kernel, cached per function -- the query is not free and the engine asks on every call)
-int spx_kernel_vgprs(const void* fn);   // spx_engine.hip (one cache, behind a mutex)
+int spx_kernel_vgprs(const void* fn, int* scratch_bytes = nullptr);   // spx_engine.hip (one cache, behind a mutex)
 int spx_tension_vgprs();
-int spx_analysis_vgprs(const SpxPlanDev& P);
+int spx_analysis_vgprs(const SpxPlanDev& P, int* scratch_bytes = nullptr);
 int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only, bool lean = false);
+int spx_walk_kernel_regs(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only, bool short_jobs, bool lean,
+                         int* scratch_bytes);
 // speedyComputeSpeedFromTension (speedy.c:768-788) on the stream's state record: *speed_out = requested speed, the
 // duration sums of the record advance.
 void spx_launch_speed_from_tension(SpxStreamState* state, float tension, float Rg, float feedback, float* speed_out,

@@ -910,9 +910,9 @@ struct WalkTuning {
 static const WalkTuning& walk_tuning() {
   static const WalkTuning T = [] {
     WalkTuning t;
-    auto geti = [](const char* k) { const char* e = getenv(k); return e ? atoi(e) : -1; };
-    t.generic = getenv("SPX_WALK_GENERIC") != nullptr;   // force the general kernel
-    t.old_fast = getenv("SPX_WALK_OLD") != nullptr;      // mono speed-up batches on spx_walk_kernel<NW, 1> (A/B only)
+    auto geti = [](const char* k) { const char* e = spx_tuning_env(k); return e ? atoi(e) : -1; };
+    t.generic = spx_tuning_env("SPX_WALK_GENERIC") != nullptr;   // force the general kernel
+    t.old_fast = spx_tuning_env("SPX_WALK_OLD") != nullptr;      // mono speed-up batches on spx_walk_kernel<NW, 1> (A/B only)
     t.nw = geti("SPX_WALK_NW");
     t.nwm = geti("SPX_WALK_NWM");
     t.nwc = geti("SPX_WALK_NWC");
@@ -985,11 +985,16 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   if (c.wcap < 2 * need) c.wcap = 2 * need;
   c.wcap = (c.wcap + 7) & ~7;
   if (c.nwm != 2 && c.nwm != 4 && c.nwm != 8) c.nwm = 4;
+#ifndef SPX_TUNING
+  c.nwc = c.nwc >= 4 ? 4 : 0;          // the shipped library's forms (spx_walk_fast.hip SPX_FAST_FORMS)
+  if (c.nwm == 2) c.nwc = 0;
+#endif
   while (c.fast_kernel && !spx_walk_fast_supports(P, c.nwm)) {  // the coarse triangle must fit the search lanes
     if (c.nwm < 4) c.nwm = 4; else if (c.nwm < 8) c.nwm = 8; else c.fast_kernel = false;
   }
   if (c.fast_kernel) {
     c.mode = 1;
+    if (c.nwm == 8) c.nwc = 4;           // the eight-search-wave form always has its four output waves
     c.waves = c.nwm + c.nwc;
     c.lds = spx_walk_fast_lds_bytes(P, c.wcap);
   } else {
@@ -998,10 +1003,10 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   }
   return c;
 }
-int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC);
-int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool lean) {
-  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC < 1 ? 1 : maxC, speedup_only, false, lean);
-  if (cfg.fast_kernel) return spx_walk_fast_vgprs(P, cfg.nwm, cfg.nwc, cfg.wcap, maxC);
+int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC, int* scratch_bytes = nullptr);
+int spx_walk_kernel_regs(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool short_jobs, bool lean, int* scratch_bytes) {
+  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC < 1 ? 1 : maxC, speedup_only, short_jobs, lean);
+  if (cfg.fast_kernel) return spx_walk_fast_vgprs(P, cfg.nwm, cfg.nwc, cfg.wcap, maxC, scratch_bytes);
   const void* fn;
 #define SPX_FN_W(NWV) (cfg.mode == 1 ? reinterpret_cast<const void*>(spx_walk_kernel<NWV, 1>)   \
                        : cfg.mode == 2 ? reinterpret_cast<const void*>(spx_walk_kernel<NWV, 2>) \
@@ -1014,7 +1019,10 @@ int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_on
     default: fn = SPX_FN_W(4); break;
   }
 #undef SPX_FN_W
-  return spx_kernel_vgprs(fn);
+  return spx_kernel_vgprs(fn, scratch_bytes);
+}
+int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool lean) {
+  return spx_walk_kernel_regs(P, n_streams, maxC, speedup_only, false, lean, nullptr);
 }
 size_t spx_walk_lds_bytes(const SpxPlanDev& P, int maxC, bool speedup_only) {
   return spx_walk_config(P, 256, maxC, speedup_only).lds;

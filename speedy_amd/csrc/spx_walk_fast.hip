@@ -1326,7 +1326,7 @@ bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm) {
 }
 
 // numRegs of the instantiation spx_launch_walk_fast picks for (nwm, nwc) at this plan's rate
-int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC) {
+int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC, int* scratch_bytes) {
   const void* fn = nullptr;
 #define SPX_FN_RM(M, C, MCV) (P.rate == 16000 && wcap == SPX_CT_WCAP_OF(M, C) ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 16000, 0, MCV>) \
                         : P.rate == 22050 && wcap == SPX_CT_WCAP_OF(M, C) ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 22050, 0, MCV>) \
@@ -1335,12 +1335,19 @@ int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int max
   if (nwm == 4 && nwc >= 4 && wcap == SPX_CT_WCAP_LONG && (P.rate == 16000 || P.rate == 22050))
     fn = P.rate == 16000 ? (maxC > 1 ? reinterpret_cast<const void*>(spx_walk_fast_kernel<4, 4, 16000, 1, 1>) : reinterpret_cast<const void*>(spx_walk_fast_kernel<4, 4, 16000, 1, 0>))
                          : (maxC > 1 ? reinterpret_cast<const void*>(spx_walk_fast_kernel<4, 4, 22050, 1, 1>) : reinterpret_cast<const void*>(spx_walk_fast_kernel<4, 4, 22050, 1, 0>));
+#ifdef SPX_TUNING
   else if (nwm == 8) fn = SPX_FN_R(8, 4);
   else if (nwm == 2) fn = nwc >= 1 ? SPX_FN_R(2, 1) : SPX_FN_R(2, 0);
   else fn = nwc >= 4 ? SPX_FN_R(4, 4) : nwc >= 2 ? SPX_FN_R(4, 2) : nwc >= 1 ? SPX_FN_R(4, 1) : SPX_FN_R(4, 0);
+#else
+  // the shipped library carries the forms spx_walk_config selects by itself (SPX_FAST_FORMS below)
+  else if (nwm == 8) fn = maxC > 1 ? reinterpret_cast<const void*>(spx_walk_fast_kernel<8, 4, 0, 0, 1>) : reinterpret_cast<const void*>(spx_walk_fast_kernel<8, 4, 0, 0, 0>);
+  else if (nwm == 2) fn = SPX_FN_R(2, 0);
+  else fn = nwc >= 4 ? SPX_FN_R(4, 4) : SPX_FN_R(4, 0);
+#endif
 #undef SPX_FN_R
 #undef SPX_FN_RM
-  return spx_kernel_vgprs(fn);
+  return spx_kernel_vgprs(fn, scratch_bytes);
 }
 
 void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, const int16_t* in,
@@ -1368,8 +1375,15 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
   SPX_LAUNCH_FAST(4, 4);
   return;
 #endif
+  // SPX_FAST_FORMS -- the forms the SHIPPED library carries are the ones spx_walk_config selects by itself: 4 + 4 waves (one or two
+  // streams per CU; with the long window at the two BASELINE rates), 4 + 0 (lean form, short jobs beyond one stream per CU),
+  // 2 + 0 (throughput form), each rate-specialised for 16 / 22.05 kHz and generic, mono-only and multi-channel; 8 + 4 generic
+  // for the rates whose ragged refine tasks do not fit four search waves (24 .. 32 kHz).  The other combinations (1 or 2
+  // output waves, two search waves with an output wave, eight search waves at a BASELINE rate) were A/B points of rounds 2
+  // and 3; they exist in builds with -DSPX_TUNING, where SPX_WALK_NWM / NWC select them (`make tuning`).  52 -> 24 kernels.
   if (nwm == 4 && nwc >= 4 && wcap == SPX_CT_WCAP_LONG && (P.rate == 16000 || P.rate == 22050)) {
     if (P.rate == 16000) SPX_LAUNCH_FAST_RS(4, 4, 16000, 1); else SPX_LAUNCH_FAST_RS(4, 4, 22050, 1);
+#ifdef SPX_TUNING
   } else if (nwm == 8) {
     SPX_LAUNCH_FAST(8, 4);
   } else if (nwm == 2) {
@@ -1381,6 +1395,16 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
     else if (nwc >= 1) SPX_LAUNCH_FAST(4, 1);
     else SPX_LAUNCH_FAST(4, 0);
   }
+#else
+  } else if (nwm == 8) {
+    SPX_LAUNCH_FAST_R(8, 4, 0);
+  } else if (nwm == 2) {
+    SPX_LAUNCH_FAST(2, 0);
+  } else {
+    if (nwc >= 4) SPX_LAUNCH_FAST(4, 4);
+    else SPX_LAUNCH_FAST(4, 0);
+  }
+#endif
 #undef SPX_LAUNCH_FAST
 #undef SPX_LAUNCH_FAST_RS
 #undef SPX_LAUNCH_FAST_RSM

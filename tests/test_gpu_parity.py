@@ -705,3 +705,47 @@ def test_register_budgets_of_the_concurrent_mode():
     assert 2 * v["walk16"] + v["tension"] + 2 * v["analysis16"] <= 512, v
     assert v["lean22"] + v["tension"] + 2 * v["analysis22"] <= 512, v
     assert 2 * v["walk16mc"] + v["tension"] + 2 * v["analysis16"] <= 512, v
+
+
+def test_kernel_resources_of_every_form_the_engine_selects():
+    """Round 4: the register allocation, the spilled bytes and the form of the walk kernel for EVERY batch shape spx_walk_config
+    can pick at the rates of the BASELINE configs (and one rate of each other kernel family), and of the analysis kernels --
+    pinned.  The engine's choice between the concurrent and the sequential launch order is arithmetic over these numbers
+    (DESIGN.md 2), a SIMD's 512 registers leave no slack, and a change that costs a kernel a register or makes it spill has so
+    far only ever been noticed by accident.  Allocated VGPRs and scratch bytes may go DOWN without touching this table."""
+    import ctypes as C
+    from speedy_amd._lib import lib
+    L = lib()
+    # (rate, channels, streams, short_jobs, lean) -> (form, allocated VGPRs <=, scratch bytes <=)
+    table = {
+        (16000, 1, 256, 0, 0): (16 * 4 + 4, 96, 52),      # spx_walk_fast_kernel<4, 4, 16000, 1, 0>: the bench's
+        (16000, 2, 256, 0, 0): (16 * 4 + 4, 96, 112),     # <4, 4, 16000, 1, 1>
+        (22050, 1, 256, 0, 0): (16 * 4 + 4, 120, 0),      # <4, 4, 22050, 1, 0>
+        (22050, 1, 256, 0, 1): (16 * 4 + 0, 128, 0),      # <4, 0, 22050, 0, 0>: the lean form of the concurrent mode
+        (22050, 2, 256, 0, 0): (16 * 4 + 4, 128, 28),     # <4, 4, 22050, 1, 1>
+        (16000, 1, 2048, 0, 0): (16 * 2 + 0, 128, 24),    # <2, 0, 16000, 0, 0>: the throughput form
+        (16000, 2, 2048, 0, 0): (16 * 2 + 0, 128, 108),
+        (22050, 1, 2048, 0, 0): (16 * 2 + 0, 128, 80),
+        (22050, 2, 2048, 0, 0): (16 * 2 + 0, 128, 152),
+        (16000, 1, 1024, 1, 0): (16 * 4 + 0, 128, 0),     # <4, 0, 16000, 0, 0>: short (coalesced sonic2.h) jobs beyond one stream per CU
+        (8000, 1, 256, 0, 0): (16 * 4 + 4, 128, 20),      # <4, 4, 0, 0, 0>: the plan-driven instantiation
+        (24000, 1, 256, 0, 0): (16 * 8 + 4, 128, 20),     # <8, 4, 0, 0, 0>: rates whose ragged tasks need eight search waves
+        (44100, 1, 256, 0, 0): (0, 112, 0),               # spx_walk_kernel<8, 0>: the general kernel
+    }
+    out = (C.c_int * 5)()
+    for (rate, ch, n, short, lean), (form, vg, sc) in table.items():
+        assert L.spx_debug_walk_info(rate, ch, n, 1, short, lean, out) == 0
+        got = list(out)
+        assert got[3] == form, ((rate, ch, n, short, lean), got)
+        assert 0 < got[0] <= vg and 0 <= got[1] <= sc, ((rate, ch, n, short, lean), got, (vg, sc))
+    a = (C.c_int * 3)()
+    for rate, vg in ((16000, 128), (22050, 168), (44100, 120)):
+        assert L.spx_debug_analysis_info(rate, a) == 0
+        assert 0 < a[0] <= vg and a[1] == 0, (rate, list(a))
+    # the budgets of the concurrent mode, from the same source
+    L.spx_debug_walk_info(16000, 1, 256, 1, 0, 0, out); w16 = out[0]
+    L.spx_debug_walk_info(22050, 1, 256, 1, 0, 1, out); lean22 = out[0]
+    L.spx_debug_analysis_info(16000, a); a16 = a[0]
+    L.spx_debug_analysis_info(22050, a); a22 = a[0]
+    ten = L.spx_debug_kernel_vgprs(0)
+    assert 2 * w16 + ten + 2 * a16 <= 512 and lean22 + ten + 2 * a22 <= 512, (w16, lean22, a16, a22, ten)

@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU box: A/B of library builds / tuning variables on the bench workload, interleaved so that drift cancels.
+# (tuning variables need the tuning build: make -C speedy_amd/csrc tuning; SPEEDY_HIP_LIB=$PWD/speedy_amd/lib/ab/libspeedy_hip_tuning.so)
 #   bash tools/ab_lib.sh TAG REPS "label|ENV=.. ENV=.." "label2|..." ...
 # e.g. bash tools/ab_lib.sh r02x 2 "new|" "base|SPEEDY_HIP_LIB=$PWD/speedy_amd/lib/ab/libspeedy_hip_base.so"
 TAG=${1:-ab}; REPS=${2:-2}; shift; shift
@@ -10,8 +11,8 @@ for r in $(seq $REPS); do
   for v in "$@"; do
     label=${v%%|*}; envs=${v#*|}
     for m in ${AB_MODES:-serial conc}; do
-      if [ $m = serial ]; then S="SPX_SERIAL=1"; else S="SPX_NOOP=1"; fi
-      line=$(env $S $envs timeout 300 python3 bench.py --no-cpu-baseline --no-pcie --no-api --no-config4 2>/dev/null | tail -1)
+      if [ $m = serial ]; then S="--serial"; else S=""; fi
+      line=$(env SPX_NOOP=1 $envs timeout 300 python3 bench.py $S --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch 2>/dev/null | tail -1)
       echo "$line" | python3 -c "
 import json,sys
 try:

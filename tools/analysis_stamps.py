@@ -1,12 +1,11 @@
 """Diagnostic only: cycle shares of the analysis kernel's phases (wave 0 of workgroup 7) from a -DSPX_STAMPS build
-(speedy_amd/lib/stamps/libspeedy_hip_astamps.so), kernels run one at a time (SPX_SERIAL=1)."""
+(speedy_amd/lib/stamps/libspeedy_hip_astamps.so), kernels run one at a time (spx_set_concurrent(0))."""
 import ctypes as C
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("SPEEDY_HIP_LIB", os.path.join(ROOT, "speedy_amd", "lib", "stamps", "libspeedy_hip_astamps.so"))
-os.environ["SPX_SERIAL"] = "1"
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from speedy_amd.batch import Batch, Plan  # noqa: E402
@@ -18,6 +17,7 @@ NAMES = ["phase 1: stage 1 (pre-emphasis, window, first radix)", "phase 1: remai
 rate = int(sys.argv[1]) if len(sys.argv) > 1 else 16000
 n = 10 * rate
 plan = Plan(rate, False)
+plan.L.spx_set_concurrent(0)
 base = [speech_like(n, rate, seed=i) for i in range(8)]
 b = Batch(plan, [n] * 256, 1, 3.5, 1.0, 0.0)
 b.upload([base[i % 8] for i in range(256)])

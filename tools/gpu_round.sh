@@ -17,10 +17,8 @@ timeout 600 python3 bench.py --gpus 2 --backend gloo --no-cpu-baseline --no-api 
 cat "$OUT/${TAG}_bench_2rank_1gpu.json"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_stats" -o stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch \
   > "$OUT/${TAG}_stats.log" 2>&1
-export SPX_SERIAL=1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c -d "$OUT/${TAG}_pmc_$c" -o pmc --output-format csv -- python3 bench.py --steps 3 --warmup 1 \
+  timeout 600 rocprofv3 --kernel-trace --pmc $c -d "$OUT/${TAG}_pmc_$c" -o pmc --output-format csv -- python3 bench.py --serial --steps 3 --warmup 1 \
     --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch > "$OUT/${TAG}_pmc_$c.log" 2>&1
 done
-unset SPX_SERIAL
 ls "$OUT" | grep "${TAG}" | head -40

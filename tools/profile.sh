@@ -13,7 +13,7 @@ python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_stats" -o stats --output-format csv -- python3 bench.py --no-cpu-baseline \
   > "$OUT/${TAG}_stats.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d "$OUT/${TAG}_pmc_$c" -o pmc --output-format csv -- python3 bench.py --steps 3 --warmup 1 \
+  rocprofv3 --kernel-trace --pmc $c -d "$OUT/${TAG}_pmc_$c" -o pmc --output-format csv -- python3 bench.py --serial --steps 3 --warmup 1 \
     --no-cpu-baseline > "$OUT/${TAG}_pmc_$c.log" 2>&1
 done
 ls -R "$OUT" | grep -i "${TAG}" | head -40

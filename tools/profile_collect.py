@@ -56,8 +56,9 @@ for key, t in traffic.items():
     t["correction"] = ("FETCH_SIZE doubled (gfx950 reports half the bytes of a coalesced streaming read, "
                        "MI355X_MICROARCH.md HBM section); WRITE_SIZE used as is.")
     t["source"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py "
-                   "--steps 3 --warmup 1 --no-cpu-baseline --no-pcie, SPX_SERIAL=1 (one kernel in flight at a time); "
+                   "--serial --steps 3 --warmup 1 --no-cpu-baseline --no-pcie (one kernel in flight at a time); "
                    "profiles/%s/%s_pmc_*.csv" % (rnd, tag))
 if traffic:
+    traffic["_note"] = ("HBM bytes per launch from rocprofv3 PMC passes in serial mode (bench.py --serial); tools/profile_collect.py %s %s" % (tag, rnd))
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print("collected into", dst, "kernels:", sorted(traffic))

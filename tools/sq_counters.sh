@@ -4,13 +4,13 @@ TAG=${1:-sq}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 OUT=$PWD/gpurun_out
-export SPX_SERIAL=1   # kernels one after the other: counters per kernel are not blurred by sharing
+# --serial: kernels one after the other, so that the counters per kernel are not blurred by sharing
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
-  -d "$OUT/${TAG}_sq1" -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch > "$OUT/${TAG}_sq1.log" 2>&1
+  -d "$OUT/${TAG}_sq1" -o pmc --output-format csv -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch > "$OUT/${TAG}_sq1.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_IFETCH SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS \
-  -d "$OUT/${TAG}_sq2" -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch > "$OUT/${TAG}_sq2.log" 2>&1
+  -d "$OUT/${TAG}_sq2" -o pmc --output-format csv -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch > "$OUT/${TAG}_sq2.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_INST_CYCLES_SALU SQ_INSTS_SENDMSG \
-  -d "$OUT/${TAG}_sq3" -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch > "$OUT/${TAG}_sq3.log" 2>&1
+  -d "$OUT/${TAG}_sq3" -o pmc --output-format csv -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch > "$OUT/${TAG}_sq3.log" 2>&1
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, json, os, sys
 out, tag = sys.argv[1], sys.argv[2]
@@ -29,7 +29,7 @@ for f in glob.glob(os.path.join(out, tag + "_sq*", "**", "*counter_collection.cs
         if key.startswith(("spx_analysis_kernel", "spx_tension_kernel", "spx_walk")):
             acc.setdefault(key, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 res = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
-json.dump({"note": "rocprofv3 --kernel-trace --pmc (three passes of SQ counters), SPX_SERIAL=1 bench.py --steps 2 --warmup 1; "
+json.dump({"note": "rocprofv3 --kernel-trace --pmc (three passes of SQ counters), bench.py --serial --steps 2 --warmup 1; "
                    "averages per launch; 256 streams x 10 s", "counters": res},
           open(os.path.join(out, tag + "_sq_counters.json"), "w"), indent=1)
 for k, d in res.items():

@@ -1,7 +1,7 @@
 """Diagnostic only: per-phase shader-cycle shares of the walk kernel (workgroup 0 = stream 0), from the
 `make -C speedy_amd/csrc stamps` builds -- one library per stamped region so that the single accumulator does not
-disturb the kernel's register allocation.  Usage on the GPU box:  python tools/walk_stamps.py   (SPX_SERIAL=1 is
-set for the children so that the walk kernel is measured alone)."""
+disturb the kernel's register allocation.  Usage on the GPU box:  python tools/walk_stamps.py   (the children call
+spx_set_concurrent(0) so that the walk kernel is measured alone)."""
 import ctypes as C
 import os
 import subprocess
@@ -34,6 +34,7 @@ def child(sel):
     from speedy_amd.synth import speech_like
     rate, n, nstreams = 16000, 160000, int(os.environ.get("NSTREAMS", "256"))
     plan = Plan(rate, False)
+    plan.L.spx_set_concurrent(0)
     base = [speech_like(n, rate, seed=i, channels=int(os.environ.get("CHANNELS", "1"))) for i in range(8)]
     ch = int(os.environ.get("CHANNELS", "1"))
     b = Batch(plan, [n] * nstreams, ch, 3.5, 1.0, 0.0)
@@ -57,7 +58,7 @@ if len(sys.argv) > 1:
 
 rows = []
 for sel in [int(v) for v in os.environ["STAMP_SELS"].split()] if os.environ.get("STAMP_SELS") else range(NSEL):
-    env = dict(os.environ, SPX_SERIAL="1",
+    env = dict(os.environ,
                SPEEDY_HIP_LIB=os.path.join(ROOT, "speedy_amd", "lib", "stamps", PREFIX % sel))
     out = subprocess.run([sys.executable, os.path.abspath(__file__), str(sel)], env=env, capture_output=True, text=True)
     for line in out.stdout.splitlines():
