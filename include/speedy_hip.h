@@ -146,6 +146,10 @@ int spx_debug_kernel_vgprs(int which);
  * size): the engine's choice of launch mode is arithmetic over them. */
 int spx_debug_walk_info(int sample_rate, int channels, int n_streams, int speedup_only, int short_jobs, int lean, int* out5);
 int spx_debug_analysis_info(int sample_rate, int* out3);
+/* Diagnostics: the walk kernel's five-instruction division for the candidate step lengths against the IEEE quotient, for
+ * `denominators` random speeds (speed - 1 log-uniform in [2^exp_lo, 2^exp_hi)) x every count 1 .. 4096 x both numerator forms;
+ * returns the number of mismatches (0 is the only acceptable answer), -1 on a runtime error. */
+long long spx_debug_fdiv_check(unsigned seed, unsigned denominators, int exp_lo, int exp_hi);
 /* Diagnostics: 1 if the last spx_batch_run / analyze+walk call of this process took the concurrent three-kernel mode, 0 if it
  * launched its kernels in sequence (another process holds the device's concurrent-mode lock, a tuning variable, the batch shape). */
 int spx_debug_last_call_concurrent(void);

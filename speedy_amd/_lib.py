@@ -63,6 +63,7 @@ SYMBOLS = {
     "spx_debug_last_walk_form": (C.c_int, []),
     "spx_debug_kernel_vgprs": (C.c_int, [C.c_int]),
     "spx_debug_last_call_concurrent": (C.c_int, []),
+    "spx_debug_fdiv_check": (C.c_longlong, [C.c_uint, C.c_uint, C.c_int, C.c_int]),
     "spx_debug_walk_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "spx_debug_analysis_info": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "spx_device_alloc": (C.c_void_p, [C.c_size_t]),
@@ -174,6 +175,8 @@ def lib():
     import torch  # noqa: F401  (loads libamdhip64 with the soname the library links against)
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
+        if os.environ.get("SPEEDY_HIP_LIB") and not hasattr(L, name):
+            continue           # a developer's A/B build of an older tree (tools/build_variant.sh) may lack newer diagnostics
         fn = getattr(L, name)  # AttributeError = the header and the library disagree
         fn.restype = res
         fn.argtypes = args

@@ -400,7 +400,9 @@ int spx_prepare_job(sonicStream s, bool flush, bool direct, hipStream_t hs, SpxP
     if (flush && !direct) JW.nonlinear = (s->nonlinearFactor != 0.0f) ? s->nonlinearFactor : 1.0f;  // the ring path; no tension event is pending
   }
   // once a stream has run at a speed <= 1 its carried speed may be below 1: stay on the general kernel from then on
-  if (!(JA.speed > 1.0f && JW.speed > 1.0f && JA.nonlinear >= 0.0f && JA.nonlinear <= 1.0f)) s->speedupOnly = false;
+  if (!(JA.speed > 1.0f && JW.speed > 1.0f && JA.speed < SPX_FAST_MAX_SPEED && JW.speed < SPX_FAST_MAX_SPEED && JA.nonlinear >= 0.0f &&
+        JA.nonlinear <= 1.0f))
+    s->speedupOnly = false;
   // SPX_F_NO_TRUNC and the mixed-stream flags are the general walk kernel's (the speed-up kernels are tuned to their
   // register budget)
   J.speedupKernel = s->speedupOnly && !s->rateMode && !s->mixed;

@@ -552,7 +552,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   bool speedup_only = true;  // every job speeds up: the walk kernel specialised for speeds >= 1 applies
   for (int i = 0; i < n; i++) {
     if (jobs[i].channels > maxC) maxC = jobs[i].channels;
-    if (!(jobs[i].speed > 1.0f && jobs[i].nonlinear >= 0.0f && jobs[i].nonlinear <= 1.0f)) speedup_only = false;
+    if (!(jobs[i].speed > 1.0f && jobs[i].speed < SPX_FAST_MAX_SPEED && jobs[i].nonlinear >= 0.0f && jobs[i].nonlinear <= 1.0f)) speedup_only = false;
   }
   // Concurrent mode: the analysis kernel goes to a side stream in "earliest frames first" tile order and publishes a
   // flag per tile; the tension kernel (second side stream) turns ready tiles into per-frame speeds and publishes their
@@ -932,7 +932,7 @@ int spx_batch_run_mixed_taps(const spx_plan_t* plans, int n_plans, const spx_str
     int maxC = 1; bool speedup_only = true, any_nl = false;
     for (const auto& j : gj[g]) {
       maxC = std::max(maxC, (int)j.channels);
-      if (!(j.speed > 1.0f && j.nonlinear >= 0.0f && j.nonlinear <= 1.0f)) speedup_only = false;
+      if (!(j.speed > 1.0f && j.speed < SPX_FAST_MAX_SPEED && j.nonlinear >= 0.0f && j.nonlinear <= 1.0f)) speedup_only = false;
       any_nl = any_nl || j.nonlinear != 0.0f;
     }
     const int ng = (int)gj[g].size();

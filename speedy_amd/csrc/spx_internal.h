@@ -15,6 +15,11 @@ static inline const char* spx_tuning_env(const char* name) { return getenv(name)
 static inline const char* spx_tuning_env(const char*) { return nullptr; }
 #endif
 
+// Speeds the speed-up walk kernel (spx_walk_fast.hip) serves: its division for the step lengths is the IEEE sequence without
+// the scaling half, exact for speed - 1 in [2^-60, 2^80) (fast_div).  Anything beyond (a speed of 1e18 turns every step into a
+// failed one anyway) runs on the general kernel.
+#define SPX_FAST_MAX_SPEED 1.0e18f
+
 #define SPX_MAX_STAGES 16
 #define SPX_WAVE 64
 #define SPX_BLOCK 256

@@ -512,6 +512,61 @@ __device__ __forceinline__ int fast_writelane_impl(int v, int old, T) { return o
 // element: base + 2e for even e, (base of the shifted copy - 2) + 2e for odd e;  d2 = shiftedBase - 2 - base
 __device__ __forceinline__ int pair_addr(int base, int d2, int e) { return base + 2 * e + (e & 1) * d2; }
 
+// n / d for the candidate step lengths of a pitch step, WITHOUT the scaling and fix-up halves of the IEEE division sequence.
+// The compiler's expansion of a float division is: v_div_scale x 2, v_rcp, two fma for the reciprocal, a multiplication, two
+// rounds of (residual, correction) and v_div_fmas / v_div_fixup -- twelve instructions per step on the chain.  For the operands
+// that occur here -- n a sample count up to a few thousand (or that times 2 - speed), d = speed - 1 between 1e-5 and 1e18
+// (SPX_FAST_MAX_SPEED), nowhere near the exponent range's ends -- v_div_scale returns its operands unchanged, v_div_fmas is a
+// plain fma and v_div_fixup returns the quotient as it is: what remains is the SAME arithmetic, and the reciprocal half of it
+// depends on the event's speed only.  fast_rcp_refined once per event, fast_div per step: five instructions (walk kernel of the
+// bench batch 1.687 -> 1.671 ms).  Bit-identical to the IEEE quotient for d in [2^-60, 2^80)
+// (tests/test_gpu_parity.py::test_fast_division_equals_the_ieee_quotient, through spx_debug_fdiv_check below).
+__device__ __forceinline__ float fast_rcp_refined(float d) {
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+  return __builtin_fmaf(e0, r0, r0);
+}
+__device__ __forceinline__ float fast_div(float n, float d, float r) {
+  float q = n * r;
+  float e = __builtin_fmaf(-d, q, n);
+  q = __builtin_fmaf(e, r, q);
+  e = __builtin_fmaf(-d, q, n);
+  return __builtin_fmaf(e, r, q);
+}
+__global__ void spx_fdiv_check_kernel(unsigned seed, unsigned trials, int exp_lo, int exp_hi, unsigned* mismatches) {
+  // thread = one denominator per trial; every count 1 .. 4096 against it, both numerator forms of a step
+  unsigned x = seed * 2654435761u + (blockIdx.x * blockDim.x + threadIdx.x) * 40503u + 12345u;
+  unsigned bad = 0;
+  for (unsigned t = 0; t < trials; t++) {
+    x = x * 1664525u + 1013904223u;
+    // speed - 1: a random float in [2^exp_lo, 2^exp_hi), log-uniform exponent, random mantissa
+    const unsigned ex = (unsigned)(127 + exp_lo) + (x >> 24) % (unsigned)(exp_hi - exp_lo);
+    const float d = __builtin_bit_cast(float, (ex << 23) | (x & 0x7fffffu));
+    const float twom = 1.0f - d;      // 2 - speed
+    const float r = fast_rcp_refined(d);
+    for (int n = 1; n <= 4096; n++) {
+      const float fn = (float)n;
+      bad += (fn / d != fast_div(fn, d, r));
+      const float m = fn * twom;
+      bad += (m / d != fast_div(m, d, r));
+    }
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+extern "C" long long spx_debug_fdiv_check(unsigned seed, unsigned denominators, int exp_lo, int exp_hi) {
+  if (exp_lo < -126 || exp_hi > 127 || exp_hi <= exp_lo) return -1;
+  unsigned* d = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(unsigned)) != hipSuccess) return -1;
+  (void)hipMemset(d, 0, sizeof(unsigned));
+  const unsigned threads = 256, blocks = 1024;
+  const unsigned trials = (denominators + threads * blocks - 1) / (threads * blocks);
+  hipLaunchKernelGGL(spx_fdiv_check_kernel, dim3(blocks), dim3(threads), 0, nullptr, seed, trials, exp_lo, exp_hi, d);
+  unsigned h = 0;
+  const hipError_t e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  return e == hipSuccess ? (long long)h : -1;
+}
+
 // RATE != 0: the kernel is compiled for that sample rate and a 4096-frame window -- every LDS offset, period limit and
 // divisor an immediate, which frees some thirty scalar registers in the step loop; RATE == 0 takes them from the plan.
 // At most 96 VGPRs: in concurrent mode a SIMD holds two waves of this kernel (a search and an output wave), one of the
@@ -790,8 +845,10 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         const int cp_n = uni(c[5]), cp_src = uni(c[6]), cp_out = uni(c[7]);
         const pos_t nb = uni(c[9]);
         if (type != FCMD_STEP) lim = uni(c[8]);  // a step command carries fields 0..4 only
+#ifndef SPX_EXP_NO_OUTPUT   // (diagnostic builds: the output waves only take part in the barriers -- WRONG audio, same chain)
         fast_outputs<64 * NWC, MCH>(X, tid - 64 * NWM, xf_n, xf_down, xf_period, xf_out, type == FCMD_STEP ? 0 : cp_n, cp_src,
                                cp_out, lim, wb);
+#endif
         if (type == FCMD_STEP) {
           nsteps++;
           fast_sync();            // the step's second barrier (refine sums complete)
@@ -962,7 +1019,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   // (Round 3 tried issuing the NEXT step's coarse loads from the end of a step, in front of the bookkeeping between two steps:
   // 3 % slower at every code placement, profiles/r03/r03y_pf_pads.txt -- the round trip was not what the chain waited for.)
 
-  auto find_period = [&](pos_t pos, bool ge2, float sm1, float twom, int& n_ret, int& rem_ret, auto hot)
+  auto find_period = [&](pos_t pos, bool ge2, float sm1, float twom, float rinv, int& n_ret, int& rem_ret, auto hot)
                          __attribute__((always_inline)) -> int {
     (void)hot;  // std::true_type from the hot loop: its copy of this code has ge2 a constant
     if constexpr (NWC == 0) nsteps++;   // (with output waves THEY count the step commands, off the chain)
@@ -1023,8 +1080,14 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       {
         const int pc = (lane == 63) ? prevPeriod : p;
         const float fp = (float)pc;
+#ifdef SPX_IEEE_DIV
+        (void)rinv;
         nLane = ge2 ? (int)(fp / sm1) : pc;
         remLane = ge2 ? 0 : (int)(fp * twom / sm1);
+#else
+        nLane = ge2 ? (int)fast_div(fp, sm1, rinv) : pc;
+        remLane = ge2 ? 0 : (int)fast_div(fp * twom, sm1, rinv);
+#endif
       }
       asm volatile("" ::"v"(nLane), "v"(remLane));  // here, while the sums are on their way -- not behind the barrier
       FSTAMP(6);
@@ -1064,6 +1127,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   auto run_event = [&](float speed, pos_t availE) __attribute__((always_inline)) {
     const bool ge2 = speed >= 2.0f;
     const float sm1 = speed - 1.0f, twom = 2.0f - speed;
+    const float rinv = fast_rcp_refined(sm1);
     pos_t pos = base;
     bool failed = false;
     do {
@@ -1078,7 +1142,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         pos += n;
       } else {
         int n, rem;
-        const int period = find_period(pos, ge2, sm1, twom, n, rem, std::false_type());
+        const int period = find_period(pos, ge2, sm1, twom, rinv, n, rem, std::false_type());
         if (!ge2) remaining = rem;
         if (out_n + n > X.out_cap) overflow = 1;
         // a failed step (n == 0) is no branch of its own: it hands over no cross-fade (xf_n = 0), leaves pos where it is and ends
@@ -1190,11 +1254,12 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
             FSTAMP(0);
             SPX_PROBE(10);  // once per EVENT of the hot loop (not per step)
             const float sm1 = speed - 1.0f;
+            const float rinv = fast_rcp_refined(sm1);
             pos_t pos = base;
             bool failed;
             do {
               int n, rem;
-              const int period = find_period(pos, true, sm1, 0.0f, n, rem, std::true_type());
+              const int period = find_period(pos, true, sm1, 0.0f, rinv, n, rem, std::true_type());
               if (out_n + n > X.out_cap) overflow = 1;
               failed = n == 0;
               xf_n = n; xf_down = (int)(pos - wbase); xf_period = period; xf_out = out_n;
@@ -1222,6 +1287,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
             i = e;
             const pos_t availE = (linear && !flushBlk) ? n_tsm : availBlk + (i + 1) * perEvent;
             const float sm1 = speed - 1.0f, twom = 2.0f - speed;
+            const float rinv = fast_rcp_refined(sm1);
             pos_t pos = base;
             bool failed = false;
             do {
@@ -1236,7 +1302,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
                 pos += n;
               } else {
                 int n, rem;
-                const int period = find_period(pos, false, sm1, twom, n, rem, std::true_type());
+                const int period = find_period(pos, false, sm1, twom, rinv, n, rem, std::true_type());
                 remaining = rem;
                 if (out_n + n > X.out_cap) overflow = 1;
                 failed = n == 0;

@@ -718,18 +718,18 @@ def test_kernel_resources_of_every_form_the_engine_selects():
     L = lib()
     # (rate, channels, streams, short_jobs, lean) -> (form, allocated VGPRs <=, scratch bytes <=)
     table = {
-        (16000, 1, 256, 0, 0): (16 * 4 + 4, 96, 52),      # spx_walk_fast_kernel<4, 4, 16000, 1, 0>: the bench's
-        (16000, 2, 256, 0, 0): (16 * 4 + 4, 96, 112),     # <4, 4, 16000, 1, 1>
+        (16000, 1, 256, 0, 0): (16 * 4 + 4, 96, 60),      # spx_walk_fast_kernel<4, 4, 16000, 1, 0>: the bench's
+        (16000, 2, 256, 0, 0): (16 * 4 + 4, 96, 136),     # <4, 4, 16000, 1, 1>
         (22050, 1, 256, 0, 0): (16 * 4 + 4, 120, 0),      # <4, 4, 22050, 1, 0>
-        (22050, 1, 256, 0, 1): (16 * 4 + 0, 128, 0),      # <4, 0, 22050, 0, 0>: the lean form of the concurrent mode
+        (22050, 1, 256, 0, 1): (16 * 4 + 0, 128, 12),      # <4, 0, 22050, 0, 0>: the lean form of the concurrent mode
         (22050, 2, 256, 0, 0): (16 * 4 + 4, 128, 28),     # <4, 4, 22050, 1, 1>
-        (16000, 1, 2048, 0, 0): (16 * 2 + 0, 128, 24),    # <2, 0, 16000, 0, 0>: the throughput form
+        (16000, 1, 2048, 0, 0): (16 * 2 + 0, 128, 28),    # <2, 0, 16000, 0, 0>: the throughput form
         (16000, 2, 2048, 0, 0): (16 * 2 + 0, 128, 108),
         (22050, 1, 2048, 0, 0): (16 * 2 + 0, 128, 80),
         (22050, 2, 2048, 0, 0): (16 * 2 + 0, 128, 152),
         (16000, 1, 1024, 1, 0): (16 * 4 + 0, 128, 0),     # <4, 0, 16000, 0, 0>: short (coalesced sonic2.h) jobs beyond one stream per CU
-        (8000, 1, 256, 0, 0): (16 * 4 + 4, 128, 20),      # <4, 4, 0, 0, 0>: the plan-driven instantiation
-        (24000, 1, 256, 0, 0): (16 * 8 + 4, 128, 20),     # <8, 4, 0, 0, 0>: rates whose ragged tasks need eight search waves
+        (8000, 1, 256, 0, 0): (16 * 4 + 4, 128, 28),      # <4, 4, 0, 0, 0>: the plan-driven instantiation
+        (24000, 1, 256, 0, 0): (16 * 8 + 4, 128, 28),     # <8, 4, 0, 0, 0>: rates whose ragged tasks need eight search waves
         (44100, 1, 256, 0, 0): (0, 112, 0),               # spx_walk_kernel<8, 0>: the general kernel
     }
     out = (C.c_int * 5)()
@@ -749,3 +749,21 @@ def test_kernel_resources_of_every_form_the_engine_selects():
     L.spx_debug_analysis_info(22050, a); a22 = a[0]
     ten = L.spx_debug_kernel_vgprs(0)
     assert 2 * w16 + ten + 2 * a16 <= 512 and lean22 + ten + 2 * a22 <= 512, (w16, lean22, a16, a22, ten)
+
+
+def test_fast_division_equals_the_ieee_quotient():
+    """The walk kernel forms the candidate step lengths n = (int)(period / (speed - 1)) with a per-event reciprocal and two
+    correction rounds -- the IEEE division sequence without its scaling and fix-up halves, which are no-ops for these operands
+    (spx_walk_fast.hip fast_div).  Bit-equality with the `/` operator over 4 M random speeds x every count up to 4096 x both
+    numerator forms of a step (3.4e10 divisions)."""
+    from speedy_amd._lib import lib
+    assert lib().spx_debug_fdiv_check(20261003, 1 << 22, -17, 8) == 0      # speeds 1.00001 .. 257: everything a test uses
+    assert lib().spx_debug_fdiv_check(7, 1 << 20, -60, 80) == 0             # ... and the whole range the sequence is exact on
+    # (speeds of 1e18 and more -- SPX_FAST_MAX_SPEED, far inside it -- run on the general kernel, which divides the IEEE way)
+    from speedy_amd.batch import compress_batch
+    from speedy_amd.synth import speech_like
+    from oracle import pyorc
+    x = speech_like(16000, 16000, seed=77)
+    for speed in (9.9e17, 3.0e18, 1.0e30):
+        outs, _ = compress_batch([x], 16000, 1, speed, 0.0, 0.0, False)
+        assert np.array_equal(outs[0], pyorc.compress_sound(x, 16000, 1, speed, 0.0, 0.0, False, chunk=x.size, taps=False)["out"]), speed
