@@ -49,13 +49,17 @@ int spx_analysis_tile_frames() { return SPX_TF; }
 int spx_analysis_small_tile_frames() { return SPX_TF_SMALL; }
 int spx_analysis_tiny_tile_frames() { return SPX_TF_TINY; }
 
-#define SPX_CB 24  // W = 240 kernel: |log ratio| terms are handed from the waves that compute them to the wave that sums
-                   // them in blocks of SPX_CB bins (two blocks in flight); row stride SPX_CB + 1 doubles (LDS banks)
+#define SPX_CB 24  // compiled-in windows: |log ratio| terms are handed from the waves that compute them to the wave that sums
+                   // them in blocks of bins (two blocks in flight); row stride + 1 double (LDS banks).  SPX_CB bins per block
+                   // for the 16-frame tile, twice that for the 8-frame tile: two terms per lane of waves 1..3 either way.
+// row stride of the magnitudes in LDS (floats): 16-byte rows, so that the energy chain reads four bins per instruction
+static __host__ __device__ constexpr int spx_mag_stride(int W) { return (W + 4) & ~3; }
+static __host__ __device__ constexpr int spx_cb(int tf) { return tf <= 8 ? 2 * SPX_CB : SPX_CB; }
 static __host__ __device__ inline size_t work_bytes(int W, int tf, bool ct = false, int dft_waves = 4) {
   if (dft_waves < 1 || dft_waves > 4) dft_waves = 4;
   if (ct) {
     size_t a = (size_t)4 * 2 * W * sizeof(double);             // 4 waves x W complex, stages in place
-    size_t b = (size_t)2 * tf * (SPX_CB + 1) * sizeof(double); // aliased: two blocks of log terms
+    size_t b = (size_t)2 * tf * (spx_cb(tf) + 1) * sizeof(double); // aliased: two blocks of log terms
     return (a > b ? a : b);
   }
   size_t a = (size_t)dft_waves * 2 * 2 * W * sizeof(double);   // transforming waves x ping-pong x W complex
@@ -66,17 +70,36 @@ static __host__ __device__ inline size_t work_bytes(int W, int tf, bool ct = fal
 // other window size takes the plan-driven one.  Returns the compiled-in window size, or 0.
 static inline int plan_ct_window(const SpxPlanDev& P) {
   static const bool generic_only = spx_tuning_env("SPX_ANALYSIS_GENERIC") != nullptr;  // A/B and tests of the plan-driven path
-  if (generic_only || P.rader || P.nstages != 4) return 0;
-  if (P.W == 240 && P.radix[0] == 4 && P.radix[1] == 4 && P.radix[2] == 3 && P.radix[3] == 5) return 240;
-  if (P.W == 330 && P.radix[0] == 2 && P.radix[1] == 3 && P.radix[2] == 5 && P.radix[3] == 11) return 330;
+  if (generic_only) return 0;
+  auto is = [](const int* r, int n, std::initializer_list<int> want) {
+    if (n != (int)want.size()) return false;
+    int k = 0;
+    for (int w : want) if (r[k++] != w) return false;
+    return true;
+  };
+  if (!P.rader && P.W == 240 && is(P.radix, P.nstages, {4, 4, 3, 5})) return 240;
+  if (!P.rader && P.W == 330 && is(P.radix, P.nstages, {2, 3, 5, 11})) return 330;
+  // round 4: 48 kHz (W = 720) and 44.1 kHz (W = 661, Rader over M = 660), built for the 8-frame tile only (two workgroups
+  // per CU: their transform buffers are what fills the LDS)
+  if (P.tile_frames == SPX_TF_SMALL && P.dft_waves == 4) {
+    if (!P.rader && P.W == 720 && is(P.radix, P.nstages, {4, 4, 3, 3, 5})) return 720;
+    if (P.rader && P.W == 661 && is(P.radixM, P.nstagesM, {4, 3, 5, 11})) return 661;
+  }
   return 0;
+}
+int spx_analysis_prefers_small_tile(const SpxPlanDev& P) {  // plan creation: window sizes whose compiled-in kernel exists for that tile only
+  SpxPlanDev Q = P;
+  Q.tile_frames = SPX_TF_SMALL;
+  Q.dft_waves = 4;
+  const int w = plan_ct_window(Q);
+  return w == 720 || w == 661;
 }
 static __host__ __device__ inline size_t stage_samples(const SpxPlanDev& P, int tf) {
   return (size_t)(tf + 1) * P.B + (P.W - P.B) + 8;  // mono samples of frames j0-1 .. j0+TF-1
 }
 static size_t analysis_lds_bytes(const SpxPlanDev& P, bool ct) {  // for the tile size the plan copy carries (P.tile_frames)
   const int tf = P.tile_frames > 0 ? P.tile_frames : SPX_TF;
-  size_t mags = (size_t)(tf + 1) * (P.W + 1) * sizeof(float);
+  size_t mags = (size_t)(tf + 1) * spx_mag_stride(P.W) * sizeof(float);
   size_t small = (size_t)3 * (tf + 1) * sizeof(float);
   size_t stage = (stage_samples(P, tf) * sizeof(short) + 15) & ~(size_t)15;
   // tuning only (fewer workgroups per CU); part of the size so that the co-residency rule sees it; read once per process
@@ -254,9 +277,151 @@ __device__ __forceinline__ void st(double* buf, int idx, cplx v) {
   *reinterpret_cast<double2*>(buf + 2 * idx) = make_double2(v.r, v.i);
 }
 
+// ---------------- compiled-in transforms of further window sizes (round 4: W = 720 at 48 kHz, the M = 660 plan of
+// Rader's algorithm at 44.1 kHz) ----------------
+// The same butterflies and twiddle products as dft_stage, in the same order; a stage works IN PLACE on one buffer per
+// wave: all the points a lane's butterflies take are loaded into registers before the stage's first store (a wave's
+// LDS operations are served in issue order), indices are constants of the lane, and the last stage (every twiddle 1)
+// stores its results as they are.
+template <int R>
+__device__ __forceinline__ void ct_bfly(const cplx (&a)[R], cplx (&o)[R]) {
+  static_assert(R == 2 || R == 3 || R == 4 || R == 5, "fixed-formula radices");
+  if constexpr (R == 2) {
+    o[0] = {a[0].r + a[1].r, a[0].i + a[1].i};
+    o[1] = {a[0].r - a[1].r, a[0].i - a[1].i};
+  } else if constexpr (R == 3) {
+    const cplx t1 = {a[1].r + a[2].r, a[1].i + a[2].i};
+    const cplx t2 = {a[0].r - 0.5 * t1.r, a[0].i - 0.5 * t1.i};
+    const cplx t3 = {S3_1 * (a[1].r - a[2].r), S3_1 * (a[1].i - a[2].i)};
+    o[0] = {a[0].r + t1.r, a[0].i + t1.i};
+    o[1] = {t2.r + t3.i, t2.i - t3.r};
+    o[2] = {t2.r - t3.i, t2.i + t3.r};
+  } else if constexpr (R == 4) {
+    const cplx t0 = {a[0].r + a[2].r, a[0].i + a[2].i}, t1 = {a[0].r - a[2].r, a[0].i - a[2].i};
+    const cplx t2 = {a[1].r + a[3].r, a[1].i + a[3].i}, t3 = {a[1].r - a[3].r, a[1].i - a[3].i};
+    o[0] = {t0.r + t2.r, t0.i + t2.i};
+    o[2] = {t0.r - t2.r, t0.i - t2.i};
+    o[1] = {t1.r + t3.i, t1.i - t3.r};
+    o[3] = {t1.r - t3.i, t1.i + t3.r};
+  } else {
+    const cplx t1 = {a[1].r + a[4].r, a[1].i + a[4].i}, t2 = {a[2].r + a[3].r, a[2].i + a[3].i};
+    const cplx t3 = {a[1].r - a[4].r, a[1].i - a[4].i}, t4 = {a[2].r - a[3].r, a[2].i - a[3].i};
+    o[0] = {(a[0].r + t1.r) + t2.r, (a[0].i + t1.i) + t2.i};
+    const cplx m1 = {(a[0].r + C5_1 * t1.r) + C5_2 * t2.r, (a[0].i + C5_1 * t1.i) + C5_2 * t2.i};
+    const cplx m2 = {(a[0].r + C5_2 * t1.r) + C5_1 * t2.r, (a[0].i + C5_2 * t1.i) + C5_1 * t2.i};
+    const cplx n1 = {S5_1 * t3.r + S5_2 * t4.r, S5_1 * t3.i + S5_2 * t4.i};
+    const cplx n2 = {S5_2 * t3.r - S5_1 * t4.r, S5_2 * t3.i - S5_1 * t4.i};
+    o[1] = {m1.r + n1.i, m1.i - n1.r};
+    o[4] = {m1.r - n1.i, m1.i + n1.r};
+    o[2] = {m2.r + n2.i, m2.i - n2.r};
+    o[3] = {m2.r - n2.i, m2.i + n2.r};
+  }
+}
+
+// One stage of radix R (S = product of the earlier radices) of an NPTS-point transform, in place.  load(u, i) hands
+// over input i of the lane's u-th butterfly (point lane + 64 u + i NPTS/R): the buffer itself, or what the first stage
+// of a transform is fed from.
+template <int NPTS, int R, int S, class Load>
+__device__ __forceinline__ void ct_stage(double* buf, const double2* __restrict__ twp, const int lane, Load load) {
+  constexpr int SPAN = NPTS / R, NP = (SPAN + 63) / 64;
+  constexpr bool LAST = (S * R == NPTS);
+  cplx a[NP][R];
+#pragma unroll
+  for (int u = 0; u < NP; u++) {
+#pragma unroll
+    for (int i = 0; i < R; i++) a[u][i] = load(u, i);
+  }
+  wave_sync();  // compiler: no store of this stage above its loads
+#pragma unroll
+  for (int u = 0; u < NP; u++) {
+    const int b = lane + 64 * u;
+    if (b < SPAN) {
+      cplx o[R];
+      ct_bfly<R>(a[u], o);
+      const int p = b / S, q = b - p * S;
+      const int base = q + S * R * p, tp = S * p;
+      st(buf, base, o[0]);
+#pragma unroll
+      for (int j = 1; j < R; j++) st(buf, base + j * S, LAST ? o[j] : cmul_tw(o[j], twp[j * tp]));
+    }
+  }
+  wave_sync();
+}
+// the usual source of a stage: the buffer (lanes beyond the last butterfly of a partial pass read point 0's group)
+template <int NPTS, int R>
+struct ct_from_buf {
+  const double* buf;
+  int lane;
+  __device__ __forceinline__ cplx operator()(int u, int i) const {
+    constexpr int SPAN = NPTS / R;
+    const int b = (lane + 64 * u < SPAN) ? lane + 64 * u : 0;
+    return ld(buf, b + i * SPAN);
+  }
+};
+
+// Last stage of an NPTS-point transform, odd prime radix R = 2H+1 by conjugate-symmetric pairs (DESIGN.md "DFT spec"),
+// one lane per butterfly reading its R points and writing the same R; wc/ws = (cos, -sin)(2 pi k / R), k = 1..R-1.
+template <int NPTS, int R>
+__device__ __forceinline__ void ct_stage_prime_last(double* buf, const int lane, const double (&wc)[R - 1], const double (&ws)[R - 1]) {
+  constexpr int SPAN = NPTS / R, H = (R - 1) / 2;
+  static_assert(SPAN <= 64, "one pass");
+  if (lane < SPAN) {
+    cplx a[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) a[i] = ld(buf, lane + SPAN * i);
+    cplx uu[H], vv[H];
+    cplx B0 = a[0];
+#pragma unroll
+    for (int i = 1; i <= H; i++) {
+      uu[i - 1] = {a[i].r + a[R - i].r, a[i].i + a[R - i].i};
+      vv[i - 1] = {a[i].r - a[R - i].r, a[i].i - a[R - i].i};
+      B0.r = B0.r + uu[i - 1].r; B0.i = B0.i + uu[i - 1].i;
+    }
+    st(buf, lane, B0);
+#pragma unroll
+    for (int jj = 1; jj <= H; jj++) {
+      cplx Pj = a[0], Qj = {0.0, 0.0};
+#pragma unroll
+      for (int i = 1; i <= H; i++) {
+        const double wx = wc[(i * jj) % R - 1], wy = ws[(i * jj) % R - 1];
+        Pj.r = Pj.r + wx * uu[i - 1].r; Pj.i = Pj.i + wx * uu[i - 1].i;
+        if (i == 1) { Qj.r = wy * vv[0].r; Qj.i = wy * vv[0].i; }
+        else { Qj.r = Qj.r + wy * vv[i - 1].r; Qj.i = Qj.i + wy * vv[i - 1].i; }
+      }
+      st(buf, lane + SPAN * jj, cplx{Pj.r - Qj.i, Pj.i + Qj.r});
+      st(buf, lane + SPAN * (R - jj), cplx{Pj.r + Qj.i, Pj.i - Qj.r});
+    }
+  }
+  wave_sync();
+}
+
+// a table pointer as this frame's own: keeps the compiler from hoisting the lane's loads from it out of the loop over the
+// tile's frames (they are the same for every frame, and live in registers where that pays; where it does not, the
+// kernel would spill)
+template <class T>
+__device__ __forceinline__ const T* per_frame(const T* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+__device__ __forceinline__ double uniform_f64(double v) {  // a wave-uniform double, pinned to scalar registers
+  return __longlong_as_double(((long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(v) >> 32)) << 32) |
+                              (unsigned)__builtin_amdgcn_readfirstlane((int)__double_as_longlong(v)));
+}
+
+// packed point n of frame j: z[n] = v[2n] + i v[2n+1], v = pre-emphasised samples times the window (speedy.c:416-425,
+// :442); fr = the frame's first mono sample in the staged span, w0 / w1 = window[2n], window[2n+1]
+__device__ __forceinline__ cplx packed_point(const short* fr, int n, int j, int prev0, float w0, float w1) {
+  const int i0 = 2 * n;
+  const int m0 = fr[i0], m1 = fr[i0 + 1];
+  const int mp0 = (i0 > 0) ? (int)fr[i0 - 1] : ((j > 0) ? (int)fr[prev0] : 0);
+  const float x0 = (float)(m0 / 32768.0), x1 = (float)(m1 / 32768.0), xp0 = (float)(mp0 / 32768.0);
+  const float y0 = (float)(1.0 * (double)x0 - 0.97 * (double)xp0), y1 = (float)(1.0 * (double)x1 - 0.97 * (double)x0);
+  return {(double)(y0 * w0), (double)(y1 * w1)};
+}
+
 // WCT != 0: the kernel is compiled for that window size (16 kHz: W = 240 = 4*4*3*5) -- see the phase-1 comment.
 template <int TF, int WCT>
-__global__ void __launch_bounds__(SPX_BLOCK)
+__global__ void __launch_bounds__(SPX_BLOCK, WCT == 240 ? 4 : WCT == 330 ? 3 : (WCT == 661 || WCT == 720) ? 2 : 1)  // (.., waves per SIMD the register count must allow: the concurrent mode's budgets)
 spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int n_streams,
                     const int16_t* __restrict__ in_base, SpxFrameRec* __restrict__ rec, SpxTapsDev taps,
                     const int* __restrict__ tile_order, int* tile_flags, const float* __restrict__ frames,
@@ -284,11 +449,11 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   double* work = reinterpret_cast<double*>(lds);
   const size_t wb = work_bytes(W, TF, WCT != 0, (WCT != 0) ? 4 : P.dft_waves);
   float* mags = reinterpret_cast<float*>(lds + wb);
-  const size_t mags_b = (((size_t)(TF + 1) * (W + 1) * sizeof(float)) + 15) & ~(size_t)15;
+  const size_t mags_b = (((size_t)(TF + 1) * spx_mag_stride(W) * sizeof(float)) + 15) & ~(size_t)15;
   float* fE = reinterpret_cast<float*>(lds + wb + mags_b);
   float* fThr = fE + (TF + 1);
   float* fInv = fThr + (TF + 1);
-  const int MS = W + 1;  // mags row stride (floats)
+  const int MS = spx_mag_stride(W);  // mags row stride (floats)
 
   const size_t small_b = (((size_t)3 * (TF + 1) * sizeof(float)) + 15) & ~(size_t)15;
   const double* ltw = P.tw;    // twiddles stay in global memory (L1-resident, 16 B per lane per use)
@@ -644,6 +809,176 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       wave_sync();
       ASTAMP(2);
     }
+  } else if constexpr (WCT == 720) {
+    // W = 720 = 4*4*3*3*5 (48 kHz): the stages of ct_stage, the first fed straight from the staged samples (its upper two
+    // inputs are the zero padding), window values in registers.
+    const double2* twp = reinterpret_cast<const double2*>(P.tw);
+    const double2* tw2p = reinterpret_cast<const double2*>(P.tw2);
+    float wn[3][2][2];
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int n = ((lane + 64 * u < 180) ? lane + 64 * u : 0) + 180 * i;
+        wn[u][i][0] = P.window[2 * n]; wn[u][i][1] = P.window[2 * n + 1];
+      }
+    }
+    for (int s = wave; s <= TF; s += 4) {
+      const int j = j0 - 1 + s;
+      float* mrow = mags + (size_t)s * MS;
+      if (j < 0 || j >= j1) {  // outside the stream (or the tile's tail): zero spectrum
+        for (int k = lane; k < 720; k += SPX_WAVE) mrow[k] = 0.0f;
+        continue;
+      }
+      const short* fr = smono + (size_t)(j - jfirst) * B;  // this frame's 720 mono samples
+      const int prev0 = (720 - B) - 1;
+      ct_stage<720, 4, 1>(bufA, twp, lane, [&](int u, int i) -> cplx {
+        if (i >= 2) return cplx{0.0, 0.0};
+        const int n = ((lane + 64 * u < 180) ? lane + 64 * u : 0) + 180 * i;
+        return packed_point(fr, n, j, prev0, wn[u][i][0], wn[u][i][1]);
+      });
+      ASTAMP(0);
+      ct_stage<720, 4, 4>(bufA, twp, lane, ct_from_buf<720, 4>{bufA, lane});
+      ct_stage<720, 3, 16>(bufA, twp, lane, ct_from_buf<720, 3>{bufA, lane});
+      ct_stage<720, 3, 48>(bufA, twp, lane, ct_from_buf<720, 3>{bufA, lane});
+      ct_stage<720, 5, 144>(bufA, twp, lane, ct_from_buf<720, 5>{bufA, lane});
+      ASTAMP(1);
+      // untangle the packed transform:  X[k] = E[k] + e^{-2 pi i k/N} O[k]
+      float* spec_out = taps.spectrogram ? taps.spectrogram + (size_t)(S.frame_off + j) * 1440 : nullptr;
+#pragma unroll 4
+      for (int u = 0; u < 12; u++) {
+        const int k = lane + 64 * u;
+        if (k < 720) {
+          const int k2 = (k == 0) ? 0 : 720 - k;
+          const cplx a = ld(bufA, k), c = ld(bufA, k2);
+          const double b_r = c.r, b_i = -c.i;
+          const double er = 0.5 * (a.r + b_r), ei = 0.5 * (a.i + b_i);
+          const double dr = a.r - b_r, di = a.i - b_i;
+          const double o_r = 0.5 * di, o_i = -0.5 * dr;
+          const double2 w = tw2p[k];
+          const double xr = er + (w.x * o_r - w.y * o_i);
+          const double xi = ei + (w.x * o_i + w.y * o_r);
+          const float mag = (float)__builtin_sqrt(xr * xr + xi * xi);
+          mrow[k] = mag;
+          if (spec_out) {
+            spec_out[k] = mag;
+            if (k > 0) spec_out[1440 - k] = mag;
+            else spec_out[720] = (float)__builtin_fabs(a.r - a.i);
+          }
+        }
+      }
+      wave_sync();
+      ASTAMP(2);
+    }
+  } else if constexpr (WCT == 661) {
+    // W = 661, prime (44.1 kHz): Rader's algorithm (DESIGN.md "DFT spec") over the compiled-in M = 660 = 4*3*5*11 plan.
+    // a[p] = z[g^p] is gathered straight from the staged samples by the first stage of the first transform (indices in
+    // registers), conj(A .* F(b)) is formed by the loads of the second transform's first stage, and the
+    // untangle pass gathers Z[k] = z[0] + c[q(k)] through the discrete-logarithm table instead of a scatter pass.
+    constexpr int M = 660;
+    const double2* twMp = reinterpret_cast<const double2*>(P.twM);
+    const double2* bfp = reinterpret_cast<const double2*>(P.bfft);
+    const double2* tw2p = reinterpret_cast<const double2*>(P.tw2);
+    int pn[3][4];
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int pt = ((lane + 64 * u < 165) ? lane + 64 * u : 0) + 165 * i;
+        const int n = P.perm[pt];          // 1 .. 660; points above 330 are the zero padding
+        pn[u][i] = (n <= 330) ? n : -1;
+      }
+    }
+    double wc[10], ws[10];
+#pragma unroll
+    for (int k = 1; k <= 10; k++) {
+      const double2 w = twMp[k * 60];
+      wc[k - 1] = uniform_f64(w.x);
+      ws[k - 1] = uniform_f64(w.y);
+    }
+    unsigned qq[11];  // q(k) | q(661 - k) << 16 for the lane's bins k = lane + 64 u
+#pragma unroll
+    for (int u = 0; u < 11; u++) {
+      const int k = lane + 64 * u;
+      const int ka = (k >= 1 && k < 661) ? k : 1;
+      qq[u] = (unsigned)P.qlog[ka] | ((unsigned)P.qlog[661 - ka] << 16);
+    }
+    const float w00 = P.window[0], w01 = P.window[1];
+    const double inv = 1.0 / (double)M;
+    for (int s = wave; s <= TF; s += 4) {
+      const int j = j0 - 1 + s;
+      float* mrow = mags + (size_t)s * MS;
+      if (j < 0 || j >= j1) {  // outside the stream (or the tile's tail): zero spectrum
+        for (int k = lane; k < 661; k += SPX_WAVE) mrow[k] = 0.0f;
+        continue;
+      }
+      const short* fr = smono + (size_t)(j - jfirst) * B;  // this frame's 661 mono samples
+      const int prev0 = (661 - B) - 1;
+      const cplx x0 = packed_point(fr, 0, j, prev0, w00, w01);
+      int ln = lane;  // the lane index as this frame's own: the stages' addresses are computed per frame, not kept in ~150 registers
+      asm volatile("" : "+v"(ln));
+      const float* winq = per_frame(P.window);
+      const double2* bfq = per_frame(bfp);
+      const double2* tw2q = per_frame(tw2p);
+      const double2* twMq = per_frame(twMp);
+      ct_stage<M, 4, 1>(bufA, twMp, ln, [&](int u, int i) -> cplx {
+        const int n = pn[u][i];
+        if (n < 0) return cplx{0.0, 0.0};
+        // sample 661 is padding: its window value is 0 and the product must be +0 like the plan-driven path's
+        cplx z = packed_point(fr, n, j, prev0, winq[2 * n], (n < 330) ? winq[2 * n + 1] : 0.0f);
+        if (n == 330) z.i = 0.0;
+        return z;
+      });
+      ASTAMP(0);
+      ct_stage<M, 3, 4>(bufA, twMq, ln, ct_from_buf<M, 3>{bufA, ln});
+      ct_stage<M, 5, 12>(bufA, twMq, ln, ct_from_buf<M, 5>{bufA, ln});
+      ct_stage_prime_last<M, 11>(bufA, ln, wc, ws);
+      const cplx A0 = ld(bufA, 0);
+      ct_stage<M, 4, 1>(bufA, twMp, ln, [&](int u, int i) -> cplx {
+        const int k = ((ln + 64 * u < 165) ? ln + 64 * u : 0) + 165 * i;
+        const cplx a = ld(bufA, k);
+        const double2 b = bfq[k];
+        const double cr = a.r * b.x - a.i * b.y;
+        const double ci = a.r * b.y + a.i * b.x;
+        return cplx{cr, -ci};
+      });
+      ct_stage<M, 3, 4>(bufA, twMq, ln, ct_from_buf<M, 3>{bufA, ln});
+      ct_stage<M, 5, 12>(bufA, twMq, ln, ct_from_buf<M, 5>{bufA, ln});
+      ct_stage_prime_last<M, 11>(bufA, ln, wc, ws);
+      ASTAMP(1);
+      // untangle the packed transform:  X[k] = E[k] + e^{-2 pi i k/N} O[k], Z[0] = z[0] + A[0], Z[k] = z[0] + conj(F[q(k)]) / M
+      float* spec_out = taps.spectrogram ? taps.spectrogram + (size_t)(S.frame_off + j) * 1322 : nullptr;
+      const cplx Z0 = {x0.r + A0.r, x0.i + A0.i};
+#pragma unroll
+      for (int u = 0; u < 11; u++) {
+        const int k = lane + 64 * u;
+        if (k < 661) {
+          cplx a = Z0, c = Z0;
+          if (k > 0) {
+            const cplx f1 = ld(bufA, (int)(qq[u] & 0xffffu)), f2 = ld(bufA, (int)(qq[u] >> 16));
+            const double c1r = f1.r * inv, c1i = -f1.i * inv, c2r = f2.r * inv, c2i = -f2.i * inv;
+            a = {x0.r + c1r, x0.i + c1i};
+            c = {x0.r + c2r, x0.i + c2i};
+          }
+          const double b_r = c.r, b_i = -c.i;
+          const double er = 0.5 * (a.r + b_r), ei = 0.5 * (a.i + b_i);
+          const double dr = a.r - b_r, di = a.i - b_i;
+          const double o_r = 0.5 * di, o_i = -0.5 * dr;
+          const double2 w = tw2q[k];
+          const double xr = er + (w.x * o_r - w.y * o_i);
+          const double xi = ei + (w.x * o_i + w.y * o_r);
+          const float mag = (float)__builtin_sqrt(xr * xr + xi * xi);
+          mrow[k] = mag;
+          if (spec_out) {
+            spec_out[k] = mag;
+            if (k > 0) spec_out[1322 - k] = mag;
+            else spec_out[661] = (float)__builtin_fabs(a.r - a.i);
+          }
+        }
+      }
+      wave_sync();
+      ASTAMP(2);
+    }
   } else
   for (int s = wave, ndw = (P.dft_waves >= 1 && P.dft_waves <= 4) ? P.dft_waves : 4; s <= TF && wave < ndw; s += ndw) {
     const int j = j0 - 1 + s;
@@ -769,45 +1104,59 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   ASTAMP(4);
 
   // ---------------- phase 2: per-slot energy (float, index order), max, inverse norm ----------------
-  if (tid <= TF) {
-    const float* mrow = mags + (size_t)tid * MS;
-    float e = 0.0f, mx = 0.0f;
-    // the float sum's order is the reference's (speedy.c:513-516): one dependent add per bin.  Only TF + 1 lanes work here
-    // and the other waves wait, so the chain's latency is the tile's: the loads run eight bins ahead of the adds (as the
-    // loop was written, every bin paid an LDS round trip: 43 cycles per bin, a sixth of a tile's time).
-    {
-      float cur[8], nxt[8];
-      int i = 1;
-      if (i + 8 <= W) {
+  // Wave 0, one lane per slot: the float sum in the reference's order (speedy.c:513-516), one dependent add per bin -- a
+  // chain the whole tile waits for, so it carries nothing else: four bins per LDS read (16-byte rows), sixteen bins' reads
+  // in flight ahead of the adds, the squares as packed multiplications, and the row maxima (speedy.c:709; a maximum does
+  // not depend on the order) by the other three waves meanwhile.  (Rounds 1-3: load, multiply, add, maximum and a register
+  // copy per bin on the chain's wave: 23-40 cycles per bin, 10-27 % of a tile's time.)
+  if (wave > 0) {
+    for (int s = wave - 1; s <= TF; s += 3) {
+      const float* mrow = mags + (size_t)s * MS;
+      float mx = 0.0f;
+      for (int i = 1 + lane; i < W; i += SPX_WAVE) mx = fmaxf(mx, mrow[i]);
 #pragma unroll
-        for (int u = 0; u < 8; u++) cur[u] = mrow[i + u];
-      }
-      for (; i + 8 <= W; i += 8) {
-        const bool more = i + 16 <= W;   // uniform
-        if (more) {
-#pragma unroll
-          for (int u = 0; u < 8; u++) nxt[u] = mrow[i + 8 + u];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const float v = cur[u];
-          e += v * v;
-          mx = fmaxf(mx, v);
-        }
-        if (more) {
-#pragma unroll
-          for (int u = 0; u < 8; u++) cur[u] = nxt[u];
-        }
-      }
-      for (; i < W; i++) {
-        const float v = mrow[i];
-        e += v * v;
-        mx = fmaxf(mx, v);
-      }
+      for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+      if (lane == 0) fThr[s] = (float)((double)mx / 100.0);                      // speedy.c:709
     }
+  } else if (tid <= TF) {
+    const float4* r4 = reinterpret_cast<const float4*>(mags + (size_t)tid * MS);
+    float e = 0.0f;
+    __builtin_amdgcn_s_setprio(3);
+    auto acc8 = [&](const float4& p, const float4& q) {
+      const float4 pp = {p.x * p.x, p.y * p.y, p.z * p.z, p.w * p.w}, qq = {q.x * q.x, q.y * q.y, q.z * q.z, q.w * q.w};
+      e += pp.x; e += pp.y; e += pp.z; e += pp.w;
+      e += qq.x; e += qq.y; e += qq.z; e += qq.w;
+    };
+    {
+      const float4 h = r4[0];   // bins 0 (not part of the sum) .. 3
+      if (1 < W) e += h.y * h.y;
+      if (2 < W) e += h.z * h.z;
+      if (3 < W) e += h.w * h.w;
+    }
+    // (reads run up to 32 bytes past a row's end: the next row, or the arrays behind the magnitudes)
+    int i = 4;
+    float4 a0 = r4[1], a1 = r4[2];
+#pragma unroll 1
+    for (; i + 16 <= W; i += 16) {
+      const float4 b0 = r4[(i >> 2) + 2], b1 = r4[(i >> 2) + 3];
+      acc8(a0, a1);
+      a0 = r4[(i >> 2) + 4]; a1 = r4[(i >> 2) + 5];
+      acc8(b0, b1);
+    }
+    if (i + 8 <= W) {
+      acc8(a0, a1);
+      i += 8;
+      a0 = r4[i >> 2]; a1 = r4[(i >> 2) + 1];
+    }
+    {
+      const float t[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (i + u < W) e += t[u] * t[u];
+    }
+    __builtin_amdgcn_s_setprio(0);
     const float eps = 2.2204e-16f;
     fE[tid] = e;
-    fThr[tid] = (float)((double)mx / 100.0);                                   // speedy.c:709
     fInv[tid] = (float)(1.0 / (__builtin_sqrt((double)e) + (double)eps));      // speedy.c:642
   }
   __syncthreads();
@@ -859,28 +1208,75 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
     // ---------------- phases 3 + 4, pipelined: waves 1..3 compute the terms of a block of SPX_CB bins (all frames)
     // while wave 0 -- one lane per frame, bin order, the float accumulation of speedy.c:715 -- sums the previous block.
     // Two blocks in flight in the (now free) transform buffers; one workgroup barrier per block. ----------------
-    constexpr int CBS = SPX_CB + 1;
+    constexpr int CB = spx_cb(TF);
+    constexpr int CBS = CB + 1;
+    static_assert(TF * CB == 2 * (SPX_BLOCK - SPX_WAVE), "two terms per lane of waves 1..3 and block");
     double* tblk = work;  // [2][TF][CBS]
-    constexpr int NBLK = (WCT - 1 + SPX_CB - 1) / SPX_CB;
+    constexpr int NBLK = (WCT - 1 + CB - 1) / CB;
     float lsd = 0.0f;
     for (int k = 0; k <= NBLK; k++) {
       if (wave > 0) {
         if (k < NBLK) {
           double* tb = tblk + (size_t)(k & 1) * TF * CBS;
-          for (int it = tid - SPX_WAVE; it < nfr * SPX_CB; it += SPX_BLOCK - SPX_WAVE) {
-            const int f = it / SPX_CB, c = it - f * SPX_CB;
-            const int i = 1 + k * SPX_CB + c;
-            if (i < WCT) tb[f * CBS + c] = log_term(f, i);
+          // the lane's two terms, their straight-line halves first (spx_log.h) so that the two interleave
+          int fi[2], ci[2];
+          bool ok[2], gate[2];
+          float xr[2];
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            const int it = tid - SPX_WAVE + t * (SPX_BLOCK - SPX_WAVE);
+            fi[t] = it / CB;
+            ci[t] = it - fi[t] * CB;
+            const int i = 1 + k * CB + ci[t];
+            ok[t] = fi[t] < nfr;                                               // (bins past the window: a term of 0, see the chain)
+            const bool in = ok[t] && i < WCT;
+            const int fl = in ? fi[t] : 0, il = in ? i : 1;
+            const float cur = mags[(size_t)(fl + 1) * MS + il], last = mags[(size_t)fl * MS + il];
+            const float thr = fThr[fl + 1];
+            gate[t] = in && cur > thr && last > thr;                           // speedy.c:705-717
+            const float eps = 2.2204e-16f;
+            const float nc = cur * fInv[fl + 1], nl = last * fInv[fl];
+            const float ratio = (nc + eps) / (nl + eps);
+            xr[t] = gate[t] ? ratio : 2.0f;
           }
+          const spx_log_parts p0 = spx_log_main((double)xr[0]), p1 = spx_log_main((double)xr[1]);
+          const double t0 = gate[0] ? __builtin_fabs(spx_log_finish(p0, (double)xr[0])) : 0.0;
+          const double t1 = gate[1] ? __builtin_fabs(spx_log_finish(p1, (double)xr[1])) : 0.0;
+          if (ok[0]) tb[fi[0] * CBS + ci[0]] = t0;
+          if (ok[1]) tb[fi[1] * CBS + ci[1]] = t1;
         }
       } else if (k > 0 && tid < nfr) {
         const double* tb = tblk + (size_t)((k - 1) & 1) * TF * CBS + tid * CBS;
-        const int i0 = 1 + (k - 1) * SPX_CB;
-#pragma unroll 8
-        for (int c = 0; c < SPX_CB; c++)
-          if (i0 + c < WCT) lsd = (float)((double)lsd + tb[c]);                // speedy.c:715 (float +=)
+        const int i0 = 1 + (k - 1) * CB;
+        // the order-bound chain (three dependent conversions / additions per term) is what a tile waits for: its wave goes
+        // first whenever it can issue (the SIMD is shared with other workgroups' transform and log waves)
+        __builtin_amdgcn_s_setprio(3);
+        // eight terms' loads in flight, then their eight chain steps: a term's LDS round trip is not on the chain.  The last
+        // block's bins past the window hold 0 -- (float)((double)lsd + 0.0) is lsd -- so no step is conditional.
+        (void)i0;
+        static_assert(CB % 8 == 0, "batches of eight");
+        double tv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) tv[u] = tb[u];
+#pragma unroll
+        for (int c = 0; c < CB; c += 8) {
+          double nx[8];
+          if (c + 8 < CB) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) nx[u] = tb[c + 8 + u];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) lsd = (float)((double)lsd + tv[u]);        // speedy.c:715 (float +=)
+          if (c + 8 < CB) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) tv[u] = nx[u];
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
       }
+      ASTAMP(6);   // wave 0: its chain; (7): the wait for the waves that compute the next block's terms
       __syncthreads();
+      ASTAMP(7);
     }
     if (tid < nfr) write_rec(tid, lsd);
   } else {
@@ -898,7 +1294,15 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   if (tid < nfr) {
     const double* trow = terms + (size_t)tid * (W + 1);
     float lsd = 0.0f;
-    for (int i = 1; i < W; i++) lsd = (float)((double)lsd + trow[i]);          // speedy.c:715 (float +=)
+    int i = 1;
+    for (; i + 8 <= W; i += 8) {   // eight loads in flight per eight chain steps
+      double tv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) tv[u] = trow[i + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) lsd = (float)((double)lsd + tv[u]);          // speedy.c:715 (float +=)
+    }
+    for (; i < W; i++) lsd = (float)((double)lsd + trow[i]);
     write_rec(tid, lsd);
   }
   }
@@ -930,6 +1334,7 @@ void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n
     SPX_LAUNCH_ANALYSIS(SPX_TF_TINY, 0);
   } else if (P.tile_frames == SPX_TF_SMALL) {
     if (ctw == 240) SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 240); else if (ctw == 330) SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 330);
+    else if (ctw == 720) SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 720); else if (ctw == 661) SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 661);
     else SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 0);
   } else {
     if (ctw == 240) SPX_LAUNCH_ANALYSIS(SPX_TF, 240); else if (ctw == 330) SPX_LAUNCH_ANALYSIS(SPX_TF, 330);
@@ -945,6 +1350,8 @@ int spx_analysis_vgprs(const SpxPlanDev& P, int* scratch_bytes) {
   if (P.tile_frames == SPX_TF_TINY) fn = reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_TINY, 0>);
   else if (small) fn = ctw == 240 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_SMALL, 240>)
                 : ctw == 330 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_SMALL, 330>)
+                : ctw == 720 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_SMALL, 720>)
+                : ctw == 661 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_SMALL, 661>)
                              : reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_SMALL, 0>);
   else fn = ctw == 240 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF, 240>)
           : ctw == 330 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF, 330>)

@@ -244,18 +244,6 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
     fail(-1, "spx_plan_create: too many DFT stages");
     return nullptr;
   }
-  // The analysis tile must fit one CU's LDS: 16 frames and four transforming waves up to about 49 kHz, 8 frames up to about
-  // 61 kHz; above that (round 3) fewer waves transform -- their fp64 work areas are what grows -- and the tile shrinks to 4
-  // frames (its rows of log terms grow too): 2 waves up to about 100 kHz, 1 wave up to the 128 kHz the walk kernel takes.
-  d.dft_waves = 4;
-  d.tile_frames = spx_analysis_tile_frames();
-  const int cand[5][2] = {{spx_analysis_tile_frames(), 4}, {spx_analysis_small_tile_frames(), 4}, {spx_analysis_small_tile_frames(), 2},
-                          {spx_analysis_tiny_tile_frames(), 2}, {spx_analysis_tiny_tile_frames(), 1}};
-  for (int c = 0; c < 5; c++) {
-    d.tile_frames = cand[c][0];
-    d.dft_waves = cand[c][1];
-    if (spx_analysis_lds_bytes(d) <= 160 * 1024) break;
-  }
   // (a window too large even for that leaves the plan to linear jobs -- the TSM stage alone, spx_internal_analysis_fits --
   // and a nonlinear job on it is refused; no rate below 128 kHz is)
   d.minPeriod = sample_rate / 400;
@@ -279,11 +267,28 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
     d.rader = 1;
     d.nstagesM = factor_radices(M, d.radixM);
   }
+  // The analysis tile must fit one CU's LDS: 16 frames and four transforming waves up to about 49 kHz, 8 frames up to about
+  // 61 kHz; above that (round 3) fewer waves transform -- their fp64 work areas are what grows -- and the tile shrinks to 4
+  // frames (its rows of log terms grow too): 2 waves up to about 100 kHz, 1 wave up to the 128 kHz the walk kernel takes.
+  d.dft_waves = 4;
+  d.tile_frames = spx_analysis_tile_frames();
+  const int cand[5][2] = {{spx_analysis_tile_frames(), 4}, {spx_analysis_small_tile_frames(), 4}, {spx_analysis_small_tile_frames(), 2},
+                          {spx_analysis_tiny_tile_frames(), 2}, {spx_analysis_tiny_tile_frames(), 1}};
+  for (int c = 0; c < 5; c++) {
+    d.tile_frames = cand[c][0];
+    d.dft_waves = cand[c][1];
+    if (spx_analysis_lds_bytes(d) <= 160 * 1024) break;
+  }
+  if (spx_analysis_prefers_small_tile(d)) {  // 44.1 / 48 kHz: the compiled-in kernels, two 8-frame workgroups per CU
+    d.tile_frames = spx_analysis_small_tile_frames();
+    d.dft_waves = 4;
+  }
   const size_t n_tw = 2 * (size_t)W, n_win = (size_t)W, n_tf = d.F + 1, n_tp = d.Pp + 1;
   const size_t n_rd = rader ? 2 * (size_t)M : 0;  // doubles in each of twM and bfft
   const size_t n_ri = rader ? (size_t)M : 0;      // ints in each of perm and iperm
+  const size_t n_ql = rader ? (size_t)W : 0;      // ints in qlog
   const size_t bytes = sizeof(double) * (2 * n_tw + 2 * n_rd) + sizeof(float) * (n_win + n_tf + n_tp + 8) +
-                       sizeof(int) * 2 * n_ri;
+                       sizeof(int) * (2 * n_ri + n_ql);
   std::vector<unsigned char> host(bytes, 0);
   double* tw = reinterpret_cast<double*>(host.data());
   double* tw2 = tw + n_tw;
@@ -294,6 +299,7 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
   float* tp = tf + n_tf;
   int* perm = reinterpret_cast<int*>(tp + n_tp + 8);
   int* iperm = perm + n_ri;
+  int* qlog = iperm + n_ri;
   for (int t = 0; t < W; t++) {
     tw[2 * t] = cos(2.0 * M_PI * t / W);
     tw[2 * t + 1] = -sin(2.0 * M_PI * t / W);
@@ -316,6 +322,7 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
     long v = 1;
     for (int k = 0; k < M; k++) { perm[k] = (int)v; v = (v * g) % W; }
     for (int q = 0; q < M; q++) iperm[q] = perm[(M - q) % M];  // g^-q = g^(M-q)
+    for (int q = 0; q < M; q++) qlog[iperm[q]] = q;
     std::vector<double> b(2 * (size_t)M);
     for (int q = 0; q < M; q++) { b[2 * q] = tw[2 * iperm[q]]; b[2 * q + 1] = tw[2 * iperm[q] + 1]; }
     spx_host_dft(M, d.radixM, d.nstagesM, twM, b.data(), bfft);
@@ -339,6 +346,7 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
   d.taperP = d.taperF + n_tf;
   d.perm = reinterpret_cast<const int*>(d.taperP + n_tp + 8);
   d.iperm = d.perm + n_ri;
+  d.qlog = d.iperm + n_ri;
   return p;
 }
 

@@ -54,6 +54,7 @@ struct SpxPlanDev {
   const double* bfft;  // [M]  M-point transform of b[q] = tw[iperm[q]]
   const int* perm;     // [M]  perm[p]  = g^p  mod W, g the smallest primitive root
   const int* iperm;    // [M]  iperm[q] = g^-q mod W
+  const int* qlog;     // [W]  qlog[k] = the q with g^-q = k (k = 1 .. M; entry 0 unused)
 };
 
 // Per-stream job in device memory.  A job covers "everything new since the last call": batch jobs start
@@ -217,6 +218,7 @@ void spx_launch_speed_from_tension(SpxStreamState* state, float tension, float R
 int spx_analysis_tile_frames();
 int spx_analysis_small_tile_frames();
 int spx_analysis_tiny_tile_frames();
+int spx_analysis_prefers_small_tile(const SpxPlanDev& P);
 
 // Shared, cached plan per (sample rate, hysteresis mode); owned by the library for the process lifetime.
 struct spx_plan;
