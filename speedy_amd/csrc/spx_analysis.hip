@@ -1133,25 +1133,23 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       if (2 < W) e += h.z * h.z;
       if (3 < W) e += h.w * h.w;
     }
-    // (reads run up to 32 bytes past a row's end: the next row, or the arrays behind the magnitudes)
+    // sixteen bins per round, the next round's four reads issued before this round's adds (they run up to 64 bytes past
+    // a row's end: the next row, or the arrays behind the magnitudes)
     int i = 4;
-    float4 a0 = r4[1], a1 = r4[2];
+    float4 c0 = r4[1], c1 = r4[2], c2 = r4[3], c3 = r4[4];
 #pragma unroll 1
     for (; i + 16 <= W; i += 16) {
-      const float4 b0 = r4[(i >> 2) + 2], b1 = r4[(i >> 2) + 3];
-      acc8(a0, a1);
-      a0 = r4[(i >> 2) + 4]; a1 = r4[(i >> 2) + 5];
-      acc8(b0, b1);
-    }
-    if (i + 8 <= W) {
-      acc8(a0, a1);
-      i += 8;
-      a0 = r4[i >> 2]; a1 = r4[(i >> 2) + 1];
+      const float4 n0 = r4[(i >> 2) + 4], n1 = r4[(i >> 2) + 5], n2 = r4[(i >> 2) + 6], n3 = r4[(i >> 2) + 7];
+      __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks some of the reads below the adds and the chain
+                                           // pays their round trip every round)
+      acc8(c0, c1);
+      acc8(c2, c3);
+      c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     }
     {
-      const float t[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const float t[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
 #pragma unroll
-      for (int u = 0; u < 8; u++)
+      for (int u = 0; u < 16; u++)
         if (i + u < W) e += t[u] * t[u];
     }
     __builtin_amdgcn_s_setprio(0);

@@ -1,5 +1,6 @@
 // Walk kernel for the common case -- mono streams that only ever speed up (every job speed > 1, 0 <= nonlinear <= 1),
-// rates below 32 kHz (at most 64 lags in either pitch search): BASELINE configs[1..3] and the mono half of configs[4].
+// rates below 64 kHz (at most 64 lags in the coarse pitch search, 121 in the refine search -- more than 63 of those in the
+// eight-search-wave form only): BASELINE configs[1..3] and configs[4].
 // Same stage as spx_walk.hip (a10 AMDF pitch search, a11 skip + cross-fade, FIFO bookkeeping, flush; driven by the
 // shim's event sequence soniclib.c:354,369,538-551), same results bit for bit.  What differs is how a pitch step is laid
 // on the hardware: a stream is a chain of ~130 dependent pitch steps per second of audio, at 256 streams per GPU (one
@@ -86,7 +87,7 @@ enum { FCMD_STEP = 1, FCMD_COPY = 2, FCMD_REFILL = 3, FCMD_POLL = 4, FCMD_EXIT =
 // at most this many coarse groups / ragged refine tasks per lane (22.05 kHz: 303 groups and 441 tasks over the search lanes):
 // constants of the instantiation -- fewer search waves, more tasks per lane
 static __host__ __device__ constexpr int fcg_of(int nwm) { return nwm == 2 ? 3 : 2; }
-static __host__ __device__ constexpr int frg_of(int nwm) { return nwm == 2 ? 4 : 2; }
+static __host__ __device__ constexpr int frg_of(int nwm) { return nwm == 2 ? 4 : nwm == 8 ? 5 : 2; }   // (8 search waves: up to 121 refine lags)
 
 // Diagnostic build only (-DSPX_STAMPS): per-phase shader-cycle sums of workgroup 0, wave 0.  Never in the product.
 #ifdef SPX_STAMPS
@@ -124,6 +125,7 @@ extern "C" void spx_debug_fstamps(unsigned long long* out, int reset) {
 // LDS layout (bytes), shared by host and device
 struct FastLds {
   int off_cmd, off_wait, off_sumC, off_sumR, off_sumS, off_inv, off_mono, off_monoB, off_pl, off_plB, plStrideB, total, wcap;
+  int off_sumW;   // refine searches of more than 64 lags (rates from 32 kHz: 8 skip + 1 lags): two buffers of 128 sums + spare words
 };
 static __host__ __device__ inline FastLds fast_lds_layout_i(int maxPeriod, int skip_, int wcap) {
   FastLds L;
@@ -144,6 +146,8 @@ static __host__ __device__ inline FastLds fast_lds_layout_i(int maxPeriod, int s
   const int plb = (plStride * skip * 2 + 15) & ~15;
   L.off_pl = o; o += plb + SPX_PAD_PL;
   L.off_plB = o; o += plb;
+  L.off_sumW = o;
+  if (skip >= 6) o += 512 * 4;   // (the rates the eight-search-wave form serves) behind everything else: no other offset moves
   L.total = o;
   return L;
 }
@@ -502,6 +506,36 @@ __device__ __forceinline__ int fast_select(unsigned dsum, double scale, bool val
   return idx;
 }
 
+// The same over two lags per lane (lags lane and 64 + lane; refine searches of more than 64 lags).  Returns the lag index.
+__device__ __forceinline__ int fast_select2(unsigned dsum, unsigned dsum2, double scale, double scale2, bool valid, bool valid2,
+                                            bool needResolve, int p0, unsigned& kmin) {
+  const double q = __builtin_fma((double)dsum, scale, 0x1p-12), q2 = __builtin_fma((double)dsum2, scale2, 0x1p-12);
+  const unsigned key = valid ? (unsigned)q : 0xffffffffu, key2 = valid2 ? (unsigned)q2 : 0xffffffffu;
+  kmin = wave_min_u32(key < key2 ? key : key2);
+  unsigned long long m = __builtin_amdgcn_ballot_w64(key == kmin), m2 = __builtin_amdgcn_ballot_w64(key2 == kmin);
+  int idx = m ? __builtin_ctzll(m) : 64 + __builtin_ctzll(m2);
+  if (m) m &= m - 1; else m2 &= m2 - 1;
+  if (needResolve && (m | m2)) {  // exact scan of the ties, in lag order
+    unsigned bd = idx < 64 ? (unsigned)__builtin_amdgcn_readlane((int)dsum, idx) : (unsigned)__builtin_amdgcn_readlane((int)dsum2, idx - 64);
+    int bp = p0 + idx;
+    while (m) {
+      const int i = __builtin_ctzll(m);
+      m &= m - 1;
+      const unsigned di = (unsigned)__builtin_amdgcn_readlane((int)dsum, i);
+      const int pi = p0 + i;
+      if ((unsigned long long)di * (unsigned)bp < (unsigned long long)bd * (unsigned)pi) { bd = di; bp = pi; idx = i; }
+    }
+    while (m2) {
+      const int i = __builtin_ctzll(m2);
+      m2 &= m2 - 1;
+      const unsigned di = (unsigned)__builtin_amdgcn_readlane((int)dsum2, i);
+      const int pi = p0 + 64 + i;
+      if ((unsigned long long)di * (unsigned)bp < (unsigned long long)bd * (unsigned)pi) { bd = di; bp = pi; idx = 64 + i; }
+    }
+  }
+  return idx;
+}
+
 // lane `LANE` of `old` replaced by the wave-uniform value v (v_writelane_b32: no EXEC change)
 template <typename T>
 __device__ __forceinline__ int fast_writelane_impl(int v, int old, T) { return old; }
@@ -584,7 +618,7 @@ template <int NWM, int NWC, int RATE, int SPEC, int MC>
 #ifndef SPX_TP_WAVES
 #define SPX_TP_WAVES 4   // minimum waves per SIMD the throughput instantiations (NWC == 0) are compiled for
 #endif
-__global__ void __launch_bounds__(64 * (NWM + NWC)) __attribute__((amdgpu_waves_per_eu((RATE == 16000 && NWC > 0) ? 5 : (NWC == 0 ? SPX_TP_WAVES : 4), (RATE == 16000 && NWC > 0) ? 5 : 8)))
+__global__ void __launch_bounds__(64 * (NWM + NWC)) __attribute__((amdgpu_waves_per_eu((RATE == 16000 && NWC > 0) ? 5 : (NWC == 0 ? SPX_TP_WAVES : (NWM == 8 ? 3 : 4)), (RATE == 16000 && NWC > 0) ? 5 : 8)))
 spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const int16_t* __restrict__ in_base,
                      int16_t* __restrict__ out_base, int64_t* __restrict__ n_out, SpxStreamState* __restrict__ states,
                      const float* scratch_base, const int* speed_ready, int wcap) {
@@ -592,6 +626,11 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   constexpr int FCG = fcg_of(NWM), FRG = frg_of(NWM);
   static_assert(SPEC == 0 || (SPEC == 1 && RATE != 0 && NWC > 0), "SPEC = 1: the long window of the rate-specialised kernels with output waves");
   constexpr bool MCH = MC != 0;
+  // WIDE: refine searches of up to 121 lags (8 skip + 1; 44.1 kHz: 89, 48 kHz: 97) -- two lags per lane in the refine select,
+  // sum buffers of 128 words.  The eight-search-wave form only (its rectangle has the lanes for that many lags).
+  constexpr bool WIDE = NWM == 8;
+  constexpr int RS = WIDE ? 128 : 64;        // words per refine sum buffer
+  constexpr int RIDLE = WIDE ? 256 : 128;    // sums[RIDLE + lane]: an idle lane's own word behind the two buffers
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uni(tid >> 6);  // wave-uniform, and the compiler must know it: everything keyed on it stays scalar
@@ -612,13 +651,14 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   X.out_cap = (pos_t)(S.out_cap > 0x7fffffff ? 0x7fffffff : S.out_cap);
   X.offA0 = LY.off_mono;
   unsigned* sumC = reinterpret_cast<unsigned*>(lds + LY.off_sumC);
-  unsigned* sumR = reinterpret_cast<unsigned*>(lds + LY.off_sumR);
+  unsigned* sumR = reinterpret_cast<unsigned*>(lds + (WIDE ? LY.off_sumW : LY.off_sumR));
   int* cmd = reinterpret_cast<int*>(lds + LY.off_cmd);
   int* sWait = reinterpret_cast<int*>(lds + LY.off_wait);  // [0] polled count, [1] search-wave arrivals, [2] speculation done
   {
     double* invw = reinterpret_cast<double*>(lds + LY.off_inv);
     for (int t = tid; t <= maxP; t += NT) invw[t] = t > 0 ? 65536.0 / (double)t : 0.0;
     for (int t = tid; t < 128; t += NT) { sumC[t] = 0; sumR[t] = 0; }
+    if constexpr (WIDE) { for (int t = 128 + tid; t < 512; t += NT) sumR[t] = 0; }
     if (tid < 4) sWait[tid] = 0;
     for (int t = tid; t < 2 * FCMD_INTS; t += NT) cmd[t] = 0;
   }
@@ -811,7 +851,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
 #ifdef SPX_RAGGED_LAG_MAJOR
     atomicAdd(&sums[myT], tOk ? d : 0u);
 #else
-    atomicAdd(&sums[tOk ? myT : 128 + lane], tOk ? d : 0u);
+    atomicAdd(&sums[tOk ? myT : RIDLE + lane], tOk ? d : 0u);
 #endif
     FSTAMP(13);
 #pragma unroll
@@ -823,7 +863,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
 #else
         // an idle lane's zero goes to a word of its own in the spare block behind the two sum buffers (sums + 128 + lane stays
         // inside it from either buffer), not into a sum other lanes add into: same-address atomics of a wave are served in turn
-        atomicAdd(&sums[rm[k] ? rt[k] : 128 + lane], dr);
+        atomicAdd(&sums[rm[k] ? rt[k] : RIDLE + lane], dr);
 #endif
       }
     }
@@ -1072,13 +1112,17 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     const bool valid = lane <= hi - lo;
     const int p = lo + lane;
     const double scale = invTab[valid ? p : lo];
-    unsigned dsum;
-    int nLane, remLane;
+    // WIDE: the lane's second lag, 64 + lane (registers `...2`; the previous period's slot is lane 63 of THAT set)
+    const bool valid2 = WIDE && lane + 64 <= hi - lo;
+    const int p2 = lo + 64 + lane;
+    const double scale2 = WIDE ? invTab[valid2 ? p2 : lo] : 0.0;
+    unsigned dsum, dsum2 = 0u;
+    int nLane, remLane, nLane2 = 0, remLane2 = 0;
     {
-      refine_sads(o, lo, hi, sumR + tg * 64);
+      refine_sads(o, lo, hi, sumR + tg * RS);
       // what the step will do for each candidate period: exact IEEE divisions, off the chain; lane 63 = previous period
       {
-        const int pc = (lane == 63) ? prevPeriod : p;
+        const int pc = (!WIDE && lane == 63) ? prevPeriod : p;
         const float fp = (float)pc;
 #ifdef SPX_IEEE_DIV
         (void)rinv;
@@ -1088,19 +1132,37 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         nLane = ge2 ? (int)fast_div(fp, sm1, rinv) : pc;
         remLane = ge2 ? 0 : (int)fast_div(fp * twom, sm1, rinv);
 #endif
+        if constexpr (WIDE) {
+          const int pc2 = (lane == 63) ? prevPeriod : p2;
+          const float fp2 = (float)pc2;
+#ifdef SPX_IEEE_DIV
+          nLane2 = ge2 ? (int)(fp2 / sm1) : pc2;
+          remLane2 = ge2 ? 0 : (int)(fp2 * twom / sm1);
+#else
+          nLane2 = ge2 ? (int)fast_div(fp2, sm1, rinv) : pc2;
+          remLane2 = ge2 ? 0 : (int)fast_div(fp2 * twom, sm1, rinv);
+#endif
+        }
       }
       asm volatile("" ::"v"(nLane), "v"(remLane));  // here, while the sums are on their way -- not behind the barrier
+      if constexpr (WIDE) asm volatile("" ::"v"(nLane2), "v"(remLane2));
       FSTAMP(6);
       SPX_PROBE(7);   // behind the refine atomics and the candidate divisions, in front of the second barrier
       fast_sync();  // the step's one workgroup barrier: refine sums complete, the output waves done with the command
       FSTAMP(7);
       SPX_PROBE(8);   // behind the second barrier, in front of the refine select
-      if (wave == 0) sumR[(1 - tg) * 64 + lane] = 0;
-      dsum = sumR[tg * 64 + lane];
+      if (wave == 0) {
+        sumR[(1 - tg) * RS + lane] = 0;
+        if constexpr (WIDE) sumR[(1 - tg) * RS + 64 + lane] = 0;
+      }
+      dsum = sumR[tg * RS + lane];
+      if constexpr (WIDE) dsum2 = sumR[tg * RS + 64 + lane];
     }
     tg ^= 1;
     unsigned kmin;
-    const int best = fast_select(dsum, scale, valid, needResolve, lo, kmin);
+    int best;
+    if constexpr (WIDE) best = fast_select2(dsum, dsum2, scale, scale2, valid, valid2, needResolve, lo, kmin);
+    else best = fast_select(dsum, scale, valid, needResolve, lo, kmin);
     period = lo + best;
     const int minDiff = (int)(kmin >> 16);  // floor(diff / lag) of the winner
     FSTAMP(8);
@@ -1111,12 +1173,20 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     // (unlikely: the rule's body out of line, the common case falls through -- walk kernel 2.035 -> 2.02 ms, r03aw_micro.txt)
     if (SPX_UNLIKELY(minDiff != 0 && prevPeriod != 0 && minDiff * 2 > prevMinDiff * 3)) {
       const unsigned need3 = 3u * (unsigned)minDiff + 1u;
-      if (__builtin_amdgcn_ballot_w64(valid && dsum >= need3 * (unsigned)p) == 0) { ret = prevPeriod; sel = 63; }
+      if (__builtin_amdgcn_ballot_w64((valid && dsum >= need3 * (unsigned)p) || (valid2 && dsum2 >= need3 * (unsigned)p2)) == 0) {
+        ret = prevPeriod;
+        sel = WIDE ? 127 : 63;
+      }
     }
     prevMinDiff = minDiff;
     prevPeriod = period;
-    n_ret = __builtin_amdgcn_readlane(nLane, sel);
-    rem_ret = __builtin_amdgcn_readlane(remLane, sel);
+    if (WIDE && sel >= 64) {
+      n_ret = __builtin_amdgcn_readlane(nLane2, sel - 64);
+      rem_ret = __builtin_amdgcn_readlane(remLane2, sel - 64);
+    } else {
+      n_ret = __builtin_amdgcn_readlane(nLane, sel);
+      rem_ret = __builtin_amdgcn_readlane(remLane, sel);
+    }
     FSTAMP(9);
     return ret;
   };
@@ -1383,6 +1453,8 @@ bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm) {
   for (int t = 0; t < 8 * skip + 1; t++) ragged += (t + 2) >> 1;
   // the refine search's common rectangle: at least one chunk per lag, and the multiply-shift division by NCH exact
   const int nlag = 8 * skip + 1, nch = (64 * nwm) / nlag;
+  if (nlag > (nwm == 8 ? 121 : 63)) return false;   // one lag per lane of the refine select (two in the eight-wave form); lane 63 / 127 = the previous period
+  if (nwm == 8 && skip < 6) return false;            // (that form's sum buffers exist in the layout from skip 6 on)
   if (nwm < 2) return false;   // (one search wave per stream was tried in round 3: no faster than two; not instantiated)
   if (nch < 3) return false;   // up to three left-over pairs of the rectangle, one per chunk
   const int chM = (65536 + nch - 1) / nch;

@@ -729,8 +729,10 @@ def test_kernel_resources_of_every_form_the_engine_selects():
         (22050, 2, 2048, 0, 0): (16 * 2 + 0, 128, 152),
         (16000, 1, 1024, 1, 0): (16 * 4 + 0, 128, 0),     # <4, 0, 16000, 0, 0>: short (coalesced sonic2.h) jobs beyond one stream per CU
         (8000, 1, 256, 0, 0): (16 * 4 + 4, 128, 28),      # <4, 4, 0, 0, 0>: the plan-driven instantiation
-        (24000, 1, 256, 0, 0): (16 * 8 + 4, 128, 28),     # <8, 4, 0, 0, 0>: rates whose ragged tasks need eight search waves
-        (44100, 1, 256, 0, 0): (0, 112, 0),               # spx_walk_kernel<8, 0>: the general kernel
+        (24000, 1, 256, 0, 0): (16 * 8 + 4, 168, 0),      # <8, 4, 0, 0, 0>: rates whose ragged tasks need eight search waves (three waves per SIMD: 168)
+        (44100, 1, 256, 0, 0): (16 * 8 + 4, 168, 0),      # ... and, since round 4, the rates with more than 64 refine lags
+        (48000, 2, 256, 0, 0): (16 * 8 + 4, 168, 0),      # <8, 4, 0, 0, 1>
+        (96000, 1, 256, 0, 0): (0, 128, 0),               # spx_walk_kernel<8, 0>: the general kernel
     }
     out = (C.c_int * 5)()
     for (rate, ch, n, short, lean), (form, vg, sc) in table.items():
