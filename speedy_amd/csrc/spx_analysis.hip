@@ -903,7 +903,6 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       const int ka = (k >= 1 && k < 661) ? k : 1;
       qq[u] = (unsigned)P.qlog[ka] | ((unsigned)P.qlog[661 - ka] << 16);
     }
-    const float w00 = P.window[0], w01 = P.window[1];
     const double inv = 1.0 / (double)M;
     for (int s = wave; s <= TF; s += 4) {
       const int j = j0 - 1 + s;
@@ -914,20 +913,34 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       }
       const short* fr = smono + (size_t)(j - jfirst) * B;  // this frame's 661 mono samples
       const int prev0 = (661 - B) - 1;
-      const cplx x0 = packed_point(fr, 0, j, prev0, w00, w01);
-      int ln = lane;  // the lane index as this frame's own: the stages' addresses are computed per frame, not kept in ~150 registers
-      asm volatile("" : "+v"(ln));
+      // the frame's 661 pre-emphasised, windowed samples as floats into the head of the wave's buffer (one lane per sample,
+      // every read in order), so that the gather below is one 8-byte read per point.  (Gathering the samples and the window
+      // values themselves -- three 16-bit LDS reads and two scattered global loads per point -- was a fifth of the kernel.)
+      float* vf = reinterpret_cast<float*>(bufA);
       const float* winq = per_frame(P.window);
+#pragma unroll
+      for (int u = 0; u < 11; u++) {
+        const int i = lane + 64 * u;
+        if (i < 661) {
+          const int m = fr[i];
+          const int mp = (i > 0) ? (int)fr[i - 1] : ((j > 0) ? (int)fr[prev0] : 0);
+          const float x = (float)(m / 32768.0), xp = (float)(mp / 32768.0);
+          const float y = (float)(1.0 * (double)x - 0.97 * (double)xp);      // speedy.c:422
+          vf[i] = y * winq[i];                                               // speedy.c:442 / :462
+        }
+      }
+      if (lane == 0) vf[661] = 0.0f;   // the imaginary half of point 330 is padding
+      wave_sync();
       const double2* bfq = per_frame(bfp);
       const double2* tw2q = per_frame(tw2p);
       const double2* twMq = per_frame(twMp);
+      int ln = lane;  // the lane index as this frame's own: the stages' addresses are computed per frame, not kept in ~150 registers
+      asm volatile("" : "+v"(ln));
+      const cplx x0 = [&] { const float2 v = *reinterpret_cast<const float2*>(vf); return cplx{(double)v.x, (double)v.y}; }();
       ct_stage<M, 4, 1>(bufA, twMp, ln, [&](int u, int i) -> cplx {
         const int n = pn[u][i];
-        if (n < 0) return cplx{0.0, 0.0};
-        // sample 661 is padding: its window value is 0 and the product must be +0 like the plan-driven path's
-        cplx z = packed_point(fr, n, j, prev0, winq[2 * n], (n < 330) ? winq[2 * n + 1] : 0.0f);
-        if (n == 330) z.i = 0.0;
-        return z;
+        const float2 v = *reinterpret_cast<const float2*>(vf + 2 * (n < 0 ? 0 : n));
+        return (n < 0) ? cplx{0.0, 0.0} : cplx{(double)v.x, (double)v.y};
       });
       ASTAMP(0);
       ct_stage<M, 3, 4>(bufA, twMq, ln, ct_from_buf<M, 3>{bufA, ln});

@@ -978,6 +978,9 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   // as many refills; spx_walk_fast.hip, SPEC = 1)
   if (!throughput && !short_jobs && c.fast_kernel && c.nwm == 4 && c.nwc == 4 && (P.rate == 16000 || P.rate == 22050) && T.nwm <= 0 &&
       T.nwc < 0) c.wcap = 8192;
+  // rates from 24 kHz (the eight-search-wave form): a step needs up to 2 x maxRequired frames of window, so the 4096-frame window
+  // is refilled every ~2 700 frames at 44.1 kHz -- 160 times per 10 s stream; twice the window, a third of the refills
+  if (!throughput && !short_jobs && c.fast_kernel && P.skip >= 6 && T.wcap <= 0) c.wcap = 8192;
   if (lean && !throughput) { c.nwc = 0; c.wcap = 4096; }
   if (T.nwm > 0) c.nwm = T.nwm;
   if (T.nwc >= 0) c.nwc = T.nwc;

@@ -82,6 +82,37 @@ def test_batch_fuzz(orc, seed):
                 assert np.array_equal(taps[key], ref[key]), tag + (key,)
 
 
+@pytest.mark.parametrize("seed", list(range(21, 25)) + list(range(2000, 2000 + SOAK)))
+def test_batch_fuzz_rates_above_32_khz(orc, seed):
+    """Round 4: the speed-up kernels at 24 ... 63 kHz -- the eight-search-wave form of the walk kernel with two lags per lane in
+    its refine select (up to 121 lags; 44.1 kHz: 89, 48 kHz: 97), the compiled-in analysis kernels of 44.1 and 48 kHz, and the
+    channel counts either side of skip x channels = 56, where the engine goes back to the general walk kernel.  Speed-up jobs
+    of up to three seconds, several streams per call (the batch shape decides the form), every stream against the oracle."""
+    from speedy_amd.batch import compress_batch
+    rng = np.random.default_rng(seed)
+    for i in range(6):
+        rate = int(rng.choice([24000, 32000, 44100, 44100, 48000, 48000, 60000, 63999]))
+        ch = int(rng.choice([1, 1, 2, 4, 5]))
+        speed = float(np.round(rng.choice([rng.uniform(1.05, 1.99), rng.uniform(2.0, 6.0), 2.0, rng.uniform(25.0, 90.0)]), 6))
+        nl = float(rng.choice([0.0, 1.0, 1.0, 0.5]))
+        fb = float(rng.choice([0.0, 0.1]))
+        mm = bool(rng.integers(0, 2))
+        xs = []
+        for k in range(int(rng.integers(1, 4))):
+            n = int(rng.integers(0, int(3.0 * rate)))
+            xs.append(_signal(KINDS[(i + k) % len(KINDS)], n, rate, ch, rng))
+        outs, b = compress_batch(xs, rate, ch, speed, nl, fb, mm, taps=(nl != 0))
+        for k, x in enumerate(xs):
+            n = x.size // ch
+            ref = orc.compress_sound(x, rate, ch, speed, nl, fb, mm, chunk=1000 if nl != 0 else max(n, 1))
+            tag = (seed, i, k, rate, ch, n, speed, nl, fb, mm)
+            assert np.array_equal(outs[k], ref["out"]), tag
+            if nl != 0:
+                taps = b.tap_arrays(k)
+                for key in ("tension", "speed", "features"):
+                    assert np.array_equal(taps[key], ref[key]), tag + (key,)
+
+
 @pytest.mark.parametrize("seed", list(range(11, 15)) + list(range(1000, 1000 + SOAK)))
 def test_streaming_fuzz(orc, seed):
     """Same idea through sonicWriteShortToStream / sonicReadShortFromStream with random write and read sizes: the
