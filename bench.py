@@ -14,6 +14,7 @@ Beside `value` the line carries (every figure ONE timed window of consecutive st
   roofline            HBM (the contract's), plus `latency` (walk kernel: cycles per dependent pitch step against the modelled floor)
                       and `valu_fp64` (analysis kernel alone: fp64 operations of the DFT spec per second against the vector peak)
   large_batch         2 048 streams x 10 s in ONE call: the throughput regime, HBM fraction
+  other_rates         256 x 10 s at 44.1 kHz mono and at 48 kHz stereo (beyond BASELINE's rates), CRC-checked against the CPU port
   pcie_inclusive      pinned host -> HBM -> step -> gather -> host, double-buffered
   config4_shard       one GPU's 256-stream shard of BASELINE configs[4] (weak: every rank its shard)
   config4_full        ALL of configs[4]: the fixed batch of --total-streams (2 048) mixed streams, rank r of N takes block r
@@ -89,7 +90,7 @@ def usable_cpus():
     return n, quota
 
 
-def cpu_baseline(streams, gpu_outputs, budget_s=12.0, c4_checks=None):
+def cpu_baseline(streams, gpu_outputs, budget_s=12.0, c4_checks=None, rate_checks=None):
     """The CPU oracle (kind "port": C restatement of the reference path; the reference itself is unbuildable here,
     DESIGN.md "Oracle") on the host cores of this machine: oracle/orc_bench.c -- POSIX threads, one stream per task,
     the speedy_wave.cc write-1000/read loop per stream -- built here with -O3 -march=native -ffp-contract=off.
@@ -142,6 +143,13 @@ def cpu_baseline(streams, gpu_outputs, budget_s=12.0, c4_checks=None):
                 total += len(pick)
             chk[name] = {"streams_checked": total, "output_crc_mismatches_vs_gpu": bad}
         res["config4_crc_check"] = chk
+    if rate_checks:
+        # the other_rates legs: every distinct signal of each through the port, output CRCs compared
+        chk = {}
+        for name, (base, rate, ch, gpu_crcs) in rate_checks.items():
+            _, cr = run(base, min(cores, len(base)), rate, ch, SPEED)
+            chk[name] = {"streams_checked": len(base), "output_crc_mismatches_vs_gpu": sum(1 for a, c in zip(cr, gpu_crcs) if a != c)}
+        res["other_rates_crc_check"] = chk
     return res
 
 
@@ -197,6 +205,31 @@ def config4_leg(ids, reps, warm=4):
     steps = b.step_counts()
     return {"dt": dt, "frames": C4.input_frames(ids), "streams": streams, "crcs": crcs,
             "algo_bytes": C4.algorithmic_bytes(ids, counts), "steps": steps, "out_frames": int(counts.sum())}
+
+
+def other_rate_leg(rate, ch, reps=5, warm=4, distinct=8):
+    """Widening beyond BASELINE's rates (round 4): 256 streams x 10 s at `rate`, `ch` channels, the headline's speed and
+    nonlinear factor, ONE spx_batch_run per step, inputs resident in HBM.  `distinct` different signals (seed 7000 + i), cycled
+    over the 256 streams; their output CRCs go to the CPU port for checking (cpu_baseline)."""
+    import torch
+    from speedy_amd.batch import Batch, Plan
+    from speedy_amd.synth import speech_like
+    n = SECONDS * rate
+    plan = Plan(rate, False)
+    base = [speech_like(n, rate, seed=7000 + i, channels=ch) for i in range(distinct)]
+    b = Batch(plan, [n] * STREAMS_PER_GPU, ch, SPEED, 1.0, 0.0)
+    b.upload([base[i % distinct] for i in range(STREAMS_PER_GPU)])
+    dt = time_window(b.run, reps, warm)
+    outs = b.results()
+    crcs = [zlib.crc32(np.ascontiguousarray(outs[i]).tobytes()) for i in range(distinct)]
+    ka, kt, kw = plan.L.spx_batch_kernel_names(plan.h, STREAMS_PER_GPU, ch, 1).decode().split(";")
+    n_out = int(sum(o.size for o in outs)) // ch
+    res = {"rate": rate, "channels": ch, "ms_per_step": dt * 1e3, "value": n * STREAMS_PER_GPU / dt / 1e6, "unit": "Msamples/s",
+           "hbm_frac": 2 * ch * (n * STREAMS_PER_GPU + n_out) / dt / 1e9 / HBM_PEAK_GBS,
+           "kernels": {"analysis": ka, "tension": kt, "walk": kw}}
+    del b
+    torch.cuda.empty_cache()
+    return res, (base, rate, ch, crcs)
 
 
 def spawn_ranks(args):
@@ -335,6 +368,7 @@ def main():
                     help="configs[4] as a whole: the fixed batch of this many mixed streams, N ranks take 1/N each (strong "
                          "scaling; N = 1 runs all of it in one call); reported as config4_full")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the 2 048-stream call of the headline kind")
+    ap.add_argument("--no-other-rates", action="store_true", help="skip the 44.1 kHz mono / 48 kHz stereo calls (widening row; N = 1 only)")
     ap.add_argument("--no-api", action="store_true", help="skip the many-handle run of the drop-in API (tools/stream_bench.c)")
     ap.add_argument("--serial", action="store_true", help="spx_set_concurrent(0): the three kernels of a step back to back on one "
                     "stream (what the per-kernel PMC passes behind roofline.traffic need: one kernel in flight at a time)")
@@ -468,6 +502,15 @@ def main():
                          "per step (the 256 bench streams, eight times); the walk kernel in its throughput form" % (nl, SECONDS)}
         del bl
         torch.cuda.empty_cache()
+
+    # widening row: the speed-up kernels at 44.1 kHz mono and 48 kHz stereo (rank 0, N = 1 only)
+    other = None
+    rate_checks = {}
+    if not args.no_other_rates and world == 1:
+        other = {}
+        for rate_o, ch_o in ((44100, 1), (48000, 2)):
+            name = "%d_hz_%s" % (rate_o, "mono" if ch_o == 1 else "%dch" % ch_o)
+            other[name], rate_checks[name] = other_rate_leg(rate_o, ch_o)
 
     # PCIe-inclusive steady state on every rank, MAX over ranks (reported beside `value`, which by the bench contract is
     # the rate with inputs already resident in HBM)
@@ -617,6 +660,10 @@ def main():
         }
         if large is not None:
             line["large_batch"] = large
+        if other:
+            other["note"] = ("beyond BASELINE's rates: 256 streams x %d s, speed %.1f nonlinear, ONE spx_batch_run per step, inputs "
+                             "resident in HBM, input sample frames / time; 8 distinct signals per kind (seed 7000 + i)" % (SECONDS, SPEED))
+            line["other_rates"] = other
         if pcie is not None:
             line["pcie_inclusive"] = pcie
         if c4 is not None:
@@ -626,7 +673,10 @@ def main():
         if not args.no_api and world == 1:
             line["api_256_handles"] = api_many_handles()
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (bench contract)
-            line["cpu_baseline"] = cpu_baseline(streams, outs, c4_checks=c4_checks)
+            line["cpu_baseline"] = cpu_baseline(streams, outs, c4_checks=c4_checks, rate_checks=rate_checks)
+            for name, r in line["cpu_baseline"].get("other_rates_crc_check", {}).items():
+                line["other_rates"][name]["output_crc_mismatches_vs_cpu_port"] = r["output_crc_mismatches_vs_gpu"]
+                line["other_rates"][name]["streams_checked_against_cpu_port"] = r["streams_checked"]
             for name, r in line["cpu_baseline"].get("config4_crc_check", {}).items():
                 if name in line:
                     line[name]["output_crc_mismatches_vs_cpu_port"] = r["output_crc_mismatches_vs_gpu"]

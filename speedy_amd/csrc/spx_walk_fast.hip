@@ -1173,9 +1173,10 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     // (unlikely: the rule's body out of line, the common case falls through -- walk kernel 2.035 -> 2.02 ms, r03aw_micro.txt)
     if (SPX_UNLIKELY(minDiff != 0 && prevPeriod != 0 && minDiff * 2 > prevMinDiff * 3)) {
       const unsigned need3 = 3u * (unsigned)minDiff + 1u;
-      if (__builtin_amdgcn_ballot_w64((valid && dsum >= need3 * (unsigned)p) || (valid2 && dsum2 >= need3 * (unsigned)p2)) == 0) {
-        ret = prevPeriod;
-        sel = WIDE ? 127 : 63;
+      if constexpr (WIDE) {
+        if (__builtin_amdgcn_ballot_w64((valid && dsum >= need3 * (unsigned)p) || (valid2 && dsum2 >= need3 * (unsigned)p2)) == 0) { ret = prevPeriod; sel = 127; }
+      } else {
+        if (__builtin_amdgcn_ballot_w64(valid && dsum >= need3 * (unsigned)p) == 0) { ret = prevPeriod; sel = 63; }
       }
     }
     prevMinDiff = minDiff;

@@ -12,7 +12,7 @@ for r in $(seq $REPS); do
     label=${v%%|*}; envs=${v#*|}
     for m in ${AB_MODES:-serial conc}; do
       if [ $m = serial ]; then S="--serial"; else S=""; fi
-      line=$(env SPX_NOOP=1 $envs timeout 300 python3 bench.py $S --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch 2>/dev/null | tail -1)
+      line=$(env SPX_NOOP=1 $envs timeout 300 python3 bench.py $S --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch --no-other-rates 2>/dev/null | tail -1)
       echo "$line" | python3 -c "
 import json,sys
 try:

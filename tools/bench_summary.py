@@ -14,7 +14,7 @@ if r.get("latency"):
 if r.get("valu_fp64"):
     v = r["valu_fp64"]
     print("valu_fp64: analysis alone %.3f ms, %.2f TFLOP/s of %.1f, frac %.3f" % (v["standalone_ms"], v["achieved"], v["peak"], v["frac"]))
-for k in ("large_batch", "pcie_inclusive", "config4_shard", "config4_full", "api_256_handles"):
+for k in ("large_batch", "other_rates", "pcie_inclusive", "config4_shard", "config4_full", "api_256_handles"):
     v = d.get(k)
     if v:
         print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items() if a not in ("note", "kernels", "hbm")},

@@ -6,11 +6,11 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 OUT=$PWD/gpurun_out
 # --serial: kernels one after the other, so that the counters per kernel are not blurred by sharing
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
-  -d "$OUT/${TAG}_sq1" -o pmc --output-format csv -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch > "$OUT/${TAG}_sq1.log" 2>&1
+  -d "$OUT/${TAG}_sq1" -o pmc --output-format csv -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch --no-other-rates > "$OUT/${TAG}_sq1.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_IFETCH SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS \
-  -d "$OUT/${TAG}_sq2" -o pmc --output-format csv -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch > "$OUT/${TAG}_sq2.log" 2>&1
+  -d "$OUT/${TAG}_sq2" -o pmc --output-format csv -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch --no-other-rates > "$OUT/${TAG}_sq2.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_INST_CYCLES_SALU SQ_INSTS_SENDMSG \
-  -d "$OUT/${TAG}_sq3" -o pmc --output-format csv -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch > "$OUT/${TAG}_sq3.log" 2>&1
+  -d "$OUT/${TAG}_sq3" -o pmc --output-format csv -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch --no-other-rates > "$OUT/${TAG}_sq3.log" 2>&1
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, json, os, sys
 out, tag = sys.argv[1], sys.argv[2]
