@@ -85,6 +85,12 @@ static inline int plan_ct_window(const SpxPlanDev& P) {
     if (!P.rader && P.W == 720 && is(P.radix, P.nstages, {4, 4, 3, 3, 5})) return 720;
     if (P.rader && P.W == 661 && is(P.radixM, P.nstagesM, {4, 3, 5, 11})) return 661;
   }
+  // 8, 24 and 32 kHz: the same code as 48 kHz over their plans (built for the 16-frame tile; 8 kHz for both tiles)
+  if (!P.rader && P.dft_waves == 4) {
+    if (P.W == 120 && is(P.radix, P.nstages, {4, 2, 3, 5}) && (P.tile_frames == SPX_TF || P.tile_frames == SPX_TF_SMALL)) return 120;
+    if (P.W == 360 && is(P.radix, P.nstages, {4, 2, 3, 3, 5}) && P.tile_frames == SPX_TF) return 360;
+    if (P.W == 480 && is(P.radix, P.nstages, {4, 4, 2, 3, 5}) && P.tile_frames == SPX_TF) return 480;
+  }
   return 0;
 }
 int spx_analysis_prefers_small_tile(const SpxPlanDev& P) {  // plan creation: window sizes whose compiled-in kernel exists for that tile only
@@ -318,6 +324,14 @@ __device__ __forceinline__ void ct_bfly(const cplx (&a)[R], cplx (&o)[R]) {
   }
 }
 
+// The compiled-in plans (radices in the order of DESIGN.md "DFT spec": 4s, a 2, 3s, 5s).  240 and 330 have hand-written code
+// of their own below; 661 is Rader's algorithm over the 660-point plan.
+template <int W> struct ct_plan { static constexpr int n = 0; };
+template <> struct ct_plan<120> { static constexpr int n = 4; static constexpr int r[4] = {4, 2, 3, 5}; };      //  8 kHz
+template <> struct ct_plan<360> { static constexpr int n = 5; static constexpr int r[5] = {4, 2, 3, 3, 5}; };   // 24 kHz
+template <> struct ct_plan<480> { static constexpr int n = 5; static constexpr int r[5] = {4, 4, 2, 3, 5}; };   // 32 kHz
+template <> struct ct_plan<720> { static constexpr int n = 5; static constexpr int r[5] = {4, 4, 3, 3, 5}; };   // 48 kHz
+
 // One stage of radix R (S = product of the earlier radices) of an NPTS-point transform, in place.  load(u, i) hands
 // over input i of the lane's u-th butterfly (point lane + 64 u + i NPTS/R): the buffer itself, or what the first stage
 // of a transform is fed from.
@@ -358,6 +372,16 @@ struct ct_from_buf {
     return ld(buf, b + i * SPAN);
   }
 };
+
+// stages ST .. of the plan of W, each from the buffer
+template <int W, int ST, int S>
+__device__ __forceinline__ void ct_stages_from(double* buf, const double2* __restrict__ twp, const int lane) {
+  if constexpr (ST < ct_plan<W>::n) {
+    constexpr int R = ct_plan<W>::r[ST];
+    ct_stage<W, R, S>(buf, twp, lane, ct_from_buf<W, R>{buf, lane});
+    ct_stages_from<W, ST + 1, S * R>(buf, twp, lane);
+  }
+}
 
 // Last stage of an NPTS-point transform, odd prime radix R = 2H+1 by conjugate-symmetric pairs (DESIGN.md "DFT spec"),
 // one lane per butterfly reading its R points and writing the same R; wc/ws = (cos, -sin)(2 pi k / R), k = 1..R-1.
@@ -421,7 +445,7 @@ __device__ __forceinline__ cplx packed_point(const short* fr, int n, int j, int 
 
 // WCT != 0: the kernel is compiled for that window size (16 kHz: W = 240 = 4*4*3*5) -- see the phase-1 comment.
 template <int TF, int WCT>
-__global__ void __launch_bounds__(SPX_BLOCK, WCT == 240 ? 4 : WCT == 330 ? 3 : (WCT == 661 || WCT == 720) ? 2 : 1)  // (.., waves per SIMD the register count must allow: the concurrent mode's budgets)
+__global__ void __launch_bounds__(SPX_BLOCK, (WCT == 240 || WCT == 120) ? 4 : WCT == 330 ? 3 : (WCT == 661 || WCT == 720 || WCT == 480 || WCT == 360) ? 2 : 1)  // (.., waves per SIMD the register count must allow: the concurrent mode's budgets)
 spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int n_streams,
                     const int16_t* __restrict__ in_base, SpxFrameRec* __restrict__ rec, SpxTapsDev taps,
                     const int* __restrict__ tile_order, int* tile_flags, const float* __restrict__ frames,
@@ -809,47 +833,39 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       wave_sync();
       ASTAMP(2);
     }
-  } else if constexpr (WCT == 720) {
-    // W = 720 = 4*4*3*3*5 (48 kHz): the stages of ct_stage, the first fed straight from the staged samples (its upper two
-    // inputs are the zero padding), window values in registers.
+  } else if constexpr (ct_plan<WCT>::n != 0) {
+    // A window size with a compiled-in plan (8 / 24 / 32 / 48 kHz): the stages of ct_stage, the first fed straight from the
+    // staged samples (its upper inputs are the zero padding); the window values a lane needs are the same for every frame
+    // and the compiler keeps them in registers.
+    constexpr int R0 = ct_plan<WCT>::r[0], SPAN0 = WCT / R0;
+    static_assert(WCT % 2 == 0 && (R0 == 4 || R0 == 2), "packed points 0 .. W/2 - 1 are inputs 0 .. R0/2 - 1 of the first stage");
     const double2* twp = reinterpret_cast<const double2*>(P.tw);
     const double2* tw2p = reinterpret_cast<const double2*>(P.tw2);
-    float wn[3][2][2];
-#pragma unroll
-    for (int u = 0; u < 3; u++) {
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        const int n = ((lane + 64 * u < 180) ? lane + 64 * u : 0) + 180 * i;
-        wn[u][i][0] = P.window[2 * n]; wn[u][i][1] = P.window[2 * n + 1];
-      }
-    }
+    const float* win = P.window;
     for (int s = wave; s <= TF; s += 4) {
       const int j = j0 - 1 + s;
       float* mrow = mags + (size_t)s * MS;
       if (j < 0 || j >= j1) {  // outside the stream (or the tile's tail): zero spectrum
-        for (int k = lane; k < 720; k += SPX_WAVE) mrow[k] = 0.0f;
+        for (int k = lane; k < WCT; k += SPX_WAVE) mrow[k] = 0.0f;
         continue;
       }
-      const short* fr = smono + (size_t)(j - jfirst) * B;  // this frame's 720 mono samples
-      const int prev0 = (720 - B) - 1;
-      ct_stage<720, 4, 1>(bufA, twp, lane, [&](int u, int i) -> cplx {
-        if (i >= 2) return cplx{0.0, 0.0};
-        const int n = ((lane + 64 * u < 180) ? lane + 64 * u : 0) + 180 * i;
-        return packed_point(fr, n, j, prev0, wn[u][i][0], wn[u][i][1]);
+      const short* fr = smono + (size_t)(j - jfirst) * B;  // this frame's W mono samples
+      const int prev0 = (WCT - B) - 1;
+      ct_stage<WCT, R0, 1>(bufA, twp, lane, [&](int u, int i) -> cplx {
+        if (i * SPAN0 >= WCT / 2) return cplx{0.0, 0.0};
+        const int n = ((lane + 64 * u < SPAN0) ? lane + 64 * u : 0) + SPAN0 * i;
+        return packed_point(fr, n, j, prev0, win[2 * n], win[2 * n + 1]);
       });
       ASTAMP(0);
-      ct_stage<720, 4, 4>(bufA, twp, lane, ct_from_buf<720, 4>{bufA, lane});
-      ct_stage<720, 3, 16>(bufA, twp, lane, ct_from_buf<720, 3>{bufA, lane});
-      ct_stage<720, 3, 48>(bufA, twp, lane, ct_from_buf<720, 3>{bufA, lane});
-      ct_stage<720, 5, 144>(bufA, twp, lane, ct_from_buf<720, 5>{bufA, lane});
+      ct_stages_from<WCT, 1, R0>(bufA, twp, lane);
       ASTAMP(1);
       // untangle the packed transform:  X[k] = E[k] + e^{-2 pi i k/N} O[k]
-      float* spec_out = taps.spectrogram ? taps.spectrogram + (size_t)(S.frame_off + j) * 1440 : nullptr;
+      float* spec_out = taps.spectrogram ? taps.spectrogram + (size_t)(S.frame_off + j) * (2 * WCT) : nullptr;
 #pragma unroll 4
-      for (int u = 0; u < 12; u++) {
+      for (int u = 0; u < (WCT + 63) / 64; u++) {
         const int k = lane + 64 * u;
-        if (k < 720) {
-          const int k2 = (k == 0) ? 0 : 720 - k;
+        if (k < WCT) {
+          const int k2 = (k == 0) ? 0 : WCT - k;
           const cplx a = ld(bufA, k), c = ld(bufA, k2);
           const double b_r = c.r, b_i = -c.i;
           const double er = 0.5 * (a.r + b_r), ei = 0.5 * (a.i + b_i);
@@ -862,8 +878,8 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
           mrow[k] = mag;
           if (spec_out) {
             spec_out[k] = mag;
-            if (k > 0) spec_out[1440 - k] = mag;
-            else spec_out[720] = (float)__builtin_fabs(a.r - a.i);
+            if (k > 0) spec_out[2 * WCT - k] = mag;
+            else spec_out[WCT] = (float)__builtin_fabs(a.r - a.i);
           }
         }
       }
@@ -1346,9 +1362,12 @@ void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n
   } else if (P.tile_frames == SPX_TF_SMALL) {
     if (ctw == 240) SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 240); else if (ctw == 330) SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 330);
     else if (ctw == 720) SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 720); else if (ctw == 661) SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 661);
+    else if (ctw == 120) SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 120);
     else SPX_LAUNCH_ANALYSIS(SPX_TF_SMALL, 0);
   } else {
     if (ctw == 240) SPX_LAUNCH_ANALYSIS(SPX_TF, 240); else if (ctw == 330) SPX_LAUNCH_ANALYSIS(SPX_TF, 330);
+    else if (ctw == 120) SPX_LAUNCH_ANALYSIS(SPX_TF, 120); else if (ctw == 360) SPX_LAUNCH_ANALYSIS(SPX_TF, 360);
+    else if (ctw == 480) SPX_LAUNCH_ANALYSIS(SPX_TF, 480);
     else SPX_LAUNCH_ANALYSIS(SPX_TF, 0);
   }
 #undef SPX_LAUNCH_ANALYSIS
@@ -1358,15 +1377,14 @@ int spx_analysis_vgprs(const SpxPlanDev& P, int* scratch_bytes) {
   const int ctw = plan_ct_window(P);
   const bool small = P.tile_frames == SPX_TF_SMALL;
   const void* fn;
-  if (P.tile_frames == SPX_TF_TINY) fn = reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_TINY, 0>);
-  else if (small) fn = ctw == 240 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_SMALL, 240>)
-                : ctw == 330 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_SMALL, 330>)
-                : ctw == 720 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_SMALL, 720>)
-                : ctw == 661 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_SMALL, 661>)
-                             : reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF_SMALL, 0>);
-  else fn = ctw == 240 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF, 240>)
-          : ctw == 330 ? reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF, 330>)
-                       : reinterpret_cast<const void*>(spx_analysis_kernel<SPX_TF, 0>);
+#define SPX_AN_FN(TFV, WV) reinterpret_cast<const void*>(spx_analysis_kernel<TFV, WV>)
+  if (P.tile_frames == SPX_TF_TINY) fn = SPX_AN_FN(SPX_TF_TINY, 0);
+  else if (small) fn = ctw == 240 ? SPX_AN_FN(SPX_TF_SMALL, 240) : ctw == 330 ? SPX_AN_FN(SPX_TF_SMALL, 330)
+                     : ctw == 720 ? SPX_AN_FN(SPX_TF_SMALL, 720) : ctw == 661 ? SPX_AN_FN(SPX_TF_SMALL, 661)
+                     : ctw == 120 ? SPX_AN_FN(SPX_TF_SMALL, 120) : SPX_AN_FN(SPX_TF_SMALL, 0);
+  else fn = ctw == 240 ? SPX_AN_FN(SPX_TF, 240) : ctw == 330 ? SPX_AN_FN(SPX_TF, 330) : ctw == 120 ? SPX_AN_FN(SPX_TF, 120)
+          : ctw == 360 ? SPX_AN_FN(SPX_TF, 360) : ctw == 480 ? SPX_AN_FN(SPX_TF, 480) : SPX_AN_FN(SPX_TF, 0);
+#undef SPX_AN_FN
   return spx_kernel_vgprs(fn, scratch_bytes);
 }
 

@@ -741,7 +741,7 @@ def test_kernel_resources_of_every_form_the_engine_selects():
         assert got[3] == form, ((rate, ch, n, short, lean), got)
         assert 0 < got[0] <= vg and 0 <= got[1] <= sc, ((rate, ch, n, short, lean), got, (vg, sc))
     a = (C.c_int * 3)()
-    for rate, vg in ((16000, 128), (22050, 168), (44100, 256), (48000, 256), (32000, 120)):   # <= 256: two waves per SIMD
+    for rate, vg in ((16000, 128), (22050, 168), (44100, 256), (48000, 256), (32000, 160), (24000, 136), (8000, 88), (11025, 120)):   # <= 256: two waves per SIMD
         assert L.spx_debug_analysis_info(rate, a) == 0
         assert 0 < a[0] <= vg and a[1] == 0, (rate, list(a))
     # the budgets of the concurrent mode, from the same source
