@@ -703,17 +703,6 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       const int T = k * 64 * NWM + sid;
       const int nlMax = 8 * skip + 1;
       int first = 0, ft = -1, fr = 0, half = 0;
-#ifdef SPX_RAGGED_LAG_MAJOR
-      for (int t = 0; t < nlMax; t++) {
-        const int full = (t + par) >> 1;             // whole pairs beyond lo >> 1
-        const int cnt = full + ((t + par) & 1);      // + the lone sample of an odd lag (lo + t odd <=> t + par odd)
-        if (ft < 0 && T < first + cnt) {
-          ft = t; fr = T - first;
-          half = (fr < full) ? 0 : 1;
-        }
-        first += cnt;
-      }
-#else
       // Round 4: PAIR-major order -- pair r of every lag that has one, then pair r + 1 ... -- so that neighbouring lanes hold
       // DIFFERENT lags.  A lane ends its task with a ds_add_u32 into its lag's sum, and lanes of a wave that add into one word
       // are served one after the other: in lag-major order up to 17 neighbouring lanes shared a lag (and every idle lane of the
@@ -729,7 +718,6 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         }
         first += cnt;
       }
-#endif
       const int w = (ft < 0) ? 0 : ((ft & 0xff) | ((fr & 0xff) << 8) | (half << 16) | (1 << 17));
       if (par == 0) rP0[k] = w; else rP1[k] = w;
     }
@@ -763,12 +751,8 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       rt[k] = w & 0xff;
       const int rr = (w >> 8) & 0xff;
       rm[k] = (w & (1 << 17)) ? ((w & (1 << 16)) ? 0xffffu : 0xffffffffu) : 0u;
-#ifdef SPX_RAGGED_LAG_MAJOR
-      if (!(w & (1 << 17)) || rt[k] >= nl) { rt[k] = 0; rm[k] = 0u; }   // no task, or a lag the clamped search does not have
-#else
       // no task, or a lag the clamped search does not have
       if (!(w & (1 << 17)) || rt[k] >= nl) { rt[k] = 0; rm[k] = 0u; }   // (rm == 0 marks the lane idle for the add below)
-#endif
       const int ea = o + 2 * (c0 + rr);
       ra[k] = *reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea));
       rb[k] = *reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea + lo + rt[k]));
@@ -784,18 +768,6 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     const int LG = G - NCH * NGL;
     asm volatile("" : "+s"(NGL));  // opaque: keeps the branch conditions below scalar compares of this value
     const bool tOk = myOn && myT < nl;
-#ifdef SPX_RECT_ADDR_R03
-    const int pT = lo + myT;
-    const int ea = o + 8 * myC * NGL;  // first sample of the lane's groups (same parity as o)
-    const unsigned* ap = reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea));
-    const unsigned* bp = reinterpret_cast<const unsigned*>(lds + pair_addr(LY.off_mono, dA, ea + pT));
-    const int xOff = 4 * (NCH * NGL + myC - myC * NGL);   // dwords from the lane's first pair to its left-over group
-    const int pOff = 4 * G + myC - 4 * myC * NGL;         // ... and to its left-over pair
-    const unsigned* apx = ap + xOff;
-    const unsigned* bpx = (myC < LG) ? bp + xOff : apx;
-    const unsigned* app = ap + pOff;
-    const unsigned* bpp = (myC < rho) ? bp + pOff : app;
-#else
     // The lane's groups start at sample ea = o + 8 myC NGL (same parity as o), its `b` operand at ea + lo + myT; its left-over
     // group is group NCH NGL + myC and its left-over pair is pair 4 G + myC of the rectangle.  As byte addresses:
     //   a      = [M + 2 o + (o & 1) dA]  + 16 myC NGL
@@ -814,20 +786,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     const unsigned* bpx = reinterpret_cast<const unsigned*>(lds + ((myC < LG) ? bU + XU + rC16 + bSel : apxO));
     const unsigned* app = reinterpret_cast<const unsigned*>(lds + appO);
     const unsigned* bpp = reinterpret_cast<const unsigned*>(lds + ((myC < rho) ? bU + GU + rC4 + bSel : appO));
-#endif
     unsigned d = 0u;
-#ifdef SPX_RECT_OLD
-    while (SPX_UNLIKELY(NGL > 3)) {  // long periods at the higher rates only
-      d = sad_flight_n<4, false>(ap, bp, 0, d);
-      ap += 16; bp += 16; NGL -= 4;
-    }
-    switch (NGL) {
-      case 0: d = sad_rect<0>(ap, bp, apx, bpx, app, bpp, d); break;
-      case 1: d = sad_rect<1>(ap, bp, apx, bpx, app, bpp, d); break;
-      case 2: d = sad_rect<2>(ap, bp, apx, bpx, app, bpp, d); break;
-      default: d = sad_rect<3>(ap, bp, apx, bpx, app, bpp, d); break;
-    }
-#else
     // the left-over group and pair are the same code whatever the group count: their loads go first, the dispatch on the
     // group count holds whole groups only, their SADs come last (one flight of loads all the same: nothing waits in between)
     unsigned xa[4], xb[4];
@@ -847,24 +806,15 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
 #pragma unroll
     for (int k = 0; k < 4; k++) d = __builtin_amdgcn_sad_u16(xa[k], xb[k], d);
     d = __builtin_amdgcn_sad_u16(pa, pb, d);
-#endif
-#ifdef SPX_RAGGED_LAG_MAJOR
-    atomicAdd(&sums[myT], tOk ? d : 0u);
-#else
     atomicAdd(&sums[tOk ? myT : RIDLE + lane], tOk ? d : 0u);
-#endif
     FSTAMP(13);
 #pragma unroll
     for (int k = 0; k < FRG; k++) {
       if (k < nRG) {
         const unsigned dr = __builtin_amdgcn_sad_u16(ra[k] & rm[k], rb[k] & rm[k], 0u);
-#ifdef SPX_RAGGED_LAG_MAJOR
-        atomicAdd(&sums[rt[k]], dr);
-#else
         // an idle lane's zero goes to a word of its own in the spare block behind the two sum buffers (sums + 128 + lane stays
         // inside it from either buffer), not into a sum other lanes add into: same-address atomics of a wave are served in turn
         atomicAdd(&sums[rm[k] ? rt[k] : RIDLE + lane], dr);
-#endif
       }
     }
     FSTAMP(14);
@@ -964,14 +914,10 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     if (nGC > FCG) nGC = FCG;  // spx_walk_config keeps such plans off this kernel
 #pragma unroll
     for (int g = 0; g < FCG; g++) {
-#ifndef SPX_COARSE_BLOCK
       // (round 4) consecutive groups -- the groups of one lag -- on DIFFERENT waves: a wave's ds_add_u32 then finds at most two
       // or three of its lanes on one sum instead of up to eight neighbours (model: 47 -> 20 LDS cycles of atomics per step in
       // front of the first barrier, for 12 more cycles of bank conflicts in the operand reads behind it)
       const int T = g * 64 * NWM + lane * NWM + wave;
-#else
-      const int T = g * 64 * NWM + tid;
-#endif
       int first = 0, found = 0, fq = 0, ff = 0;
       for (int q = 0; q < nC; q++) {
         const int p = minC + q;
