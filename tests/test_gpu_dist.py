@@ -20,7 +20,7 @@ def test_bench_two_ranks_same_bytes_as_solo(tmp_path):
     from speedy_amd.batch import Batch, Plan
     crc = str(tmp_path / "crc")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-pcie", "--no-cpu-baseline", "--no-api", "--no-config4", "--no-large-batch --no-other-rates", "--crc-out", crc, "--backend", "gloo"]
+           "--no-pcie", "--no-cpu-baseline", "--no-api", "--no-config4", "--no-large-batch", "--no-other-rates", "--crc-out", crc, "--backend", "gloo"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -65,7 +65,7 @@ def test_no_silent_downgrade_of_the_backend():
         pytest.skip("needs a box with fewer GPUs than ranks")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-                        "--no-pcie", "--no-cpu-baseline", "--no-api", "--no-config4", "--no-large-batch --no-other-rates"], capture_output=True, text=True, timeout=600, env=env)
+                        "--no-pcie", "--no-cpu-baseline", "--no-api", "--no-config4", "--no-large-batch", "--no-other-rates"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode != 0
     assert "one device per rank" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 

@@ -35,7 +35,7 @@ def main():
         for n in counts:
             crc = os.path.join(tmp, "crc%d" % n)
             cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", str(a.steps), "--warmup", "1",
-                   "--no-pcie", "--no-cpu-baseline", "--no-api", "--no-large-batch --no-other-rates", "--crc-out", crc, "--backend", a.backend]
+                   "--no-pcie", "--no-cpu-baseline", "--no-api", "--no-large-batch", "--no-other-rates", "--crc-out", crc, "--backend", a.backend]
             cmd += ["--total-streams", str(a.total_streams)] if a.config4 else ["--no-config4"]
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=3600, env=env)
             if r.returncode != 0:
