@@ -74,6 +74,37 @@ def test_spectrogram_tap_matches_oracle(orc):
     assert abs(float((taps["normalized"][150] ** 2).sum()) - 1.0) < 4e-3  # speedy_test.cc:975-978
 
 
+@pytest.mark.parametrize("rate", [8000, 16000, 24000, 32000, 44100, 48000, 11025])
+def test_spectrogram_taps_of_every_compiled_in_window(orc, rate):
+    """The spectrogram and normalised-spectrogram taps (every bin of every frame, the mirrored upper half and bin W included)
+    at the rates that have analysis kernels of their own -- 8 / 24 / 32 / 48 kHz over compiled-in plans, 44.1 kHz by Rader's
+    algorithm over the 660-point plan, 16 kHz hand-written -- and at one that takes the plan-driven kernel (11.025 kHz);
+    stream lengths that leave a partial last tile."""
+    from speedy_amd.synth import speech_like
+    L = orc.lib()
+    for seed, n in ((3, int(0.83 * rate) + 17), (4, int(0.29 * rate))):
+        x = speech_like(n, rate, seed=seed)
+        spec_rows, norm_rows = [], []
+        h = L.orc_sonicCreateStream(rate, 1, 0)
+        nb = L.orc_sonicSpectrogramSize(h)
+        cb1 = orc.FEATURES_FN(lambda s, t, p: spec_rows.append(np.ctypeslib.as_array(p, shape=(nb,)).copy()))
+        cb2 = orc.FEATURES_FN(lambda s, t, p: norm_rows.append(np.ctypeslib.as_array(p, shape=(nb,)).copy()))
+        L.orc_sonicSpectrogramCallback(h, cb1)
+        L.orc_sonicNormalizedSpectrogramCallback(h, cb2)
+        L.orc_sonicSetSpeed(h, 2.5)
+        L.orc_sonicEnableNonlinearSpeedup(h, 1.0)
+        L.orc_sonicWriteShortToStream(h, orc.sptr(x), x.size)
+        L.orc_sonicDestroyStream(h)
+        outs, b = _batch([x], rate, 1, 2.5, 1.0, 0.0, False, spec=True)
+        taps = b.tap_arrays(0)
+        ref = np.array(spec_rows)
+        assert taps["spectrogram"].shape == ref.shape, (rate, n)
+        assert np.array_equal(taps["spectrogram"], ref), (rate, n)
+        F, W = b.plan.F, nb // 2
+        nref = np.array(norm_rows)[F:, :W]
+        assert np.array_equal(taps["normalized"][:nref.shape[0]], nref), (rate, n)
+
+
 @pytest.mark.parametrize("rate,ch,speed,nl,fb,mm", [
     (16000, 1, 3.5, 1.0, 0.0, False),
     (16000, 2, 3.5, 1.0, 0.1, False),
