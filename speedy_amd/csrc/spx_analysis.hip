@@ -85,9 +85,10 @@ static inline int plan_ct_window(const SpxPlanDev& P) {
     if (!P.rader && P.W == 720 && is(P.radix, P.nstages, {4, 4, 3, 3, 5})) return 720;
     if (P.rader && P.W == 661 && is(P.radixM, P.nstagesM, {4, 3, 5, 11})) return 661;
   }
-  // 8, 24 and 32 kHz: the same code as 48 kHz over their plans (built for the 16-frame tile; 8 kHz for both tiles)
+  // 8, 12, 24 and 32 kHz: the same code as 48 kHz over their plans (built for the 16-frame tile; 8 kHz for both tiles)
   if (!P.rader && P.dft_waves == 4) {
     if (P.W == 120 && is(P.radix, P.nstages, {4, 2, 3, 5}) && (P.tile_frames == SPX_TF || P.tile_frames == SPX_TF_SMALL)) return 120;
+    if (P.W == 180 && is(P.radix, P.nstages, {4, 3, 3, 5}) && P.tile_frames == SPX_TF) return 180;
     if (P.W == 360 && is(P.radix, P.nstages, {4, 2, 3, 3, 5}) && P.tile_frames == SPX_TF) return 360;
     if (P.W == 480 && is(P.radix, P.nstages, {4, 4, 2, 3, 5}) && P.tile_frames == SPX_TF) return 480;
   }
@@ -328,6 +329,7 @@ __device__ __forceinline__ void ct_bfly(const cplx (&a)[R], cplx (&o)[R]) {
 // of their own below; 661 is Rader's algorithm over the 660-point plan.
 template <int W> struct ct_plan { static constexpr int n = 0; };
 template <> struct ct_plan<120> { static constexpr int n = 4; static constexpr int r[4] = {4, 2, 3, 5}; };      //  8 kHz
+template <> struct ct_plan<180> { static constexpr int n = 4; static constexpr int r[4] = {4, 3, 3, 5}; };      // 12 kHz
 template <> struct ct_plan<360> { static constexpr int n = 5; static constexpr int r[5] = {4, 2, 3, 3, 5}; };   // 24 kHz
 template <> struct ct_plan<480> { static constexpr int n = 5; static constexpr int r[5] = {4, 4, 2, 3, 5}; };   // 32 kHz
 template <> struct ct_plan<720> { static constexpr int n = 5; static constexpr int r[5] = {4, 4, 3, 3, 5}; };   // 48 kHz
@@ -445,7 +447,7 @@ __device__ __forceinline__ cplx packed_point(const short* fr, int n, int j, int 
 
 // WCT != 0: the kernel is compiled for that window size (16 kHz: W = 240 = 4*4*3*5) -- see the phase-1 comment.
 template <int TF, int WCT>
-__global__ void __launch_bounds__(SPX_BLOCK, (WCT == 240 || WCT == 120) ? 4 : WCT == 330 ? 3 : (WCT == 661 || WCT == 720 || WCT == 480 || WCT == 360) ? 2 : 1)  // (.., waves per SIMD the register count must allow: the concurrent mode's budgets)
+__global__ void __launch_bounds__(SPX_BLOCK, (WCT == 240 || WCT == 120 || WCT == 180) ? 4 : WCT == 330 ? 3 : (WCT == 661 || WCT == 720 || WCT == 480 || WCT == 360) ? 2 : 1)  // (.., waves per SIMD the register count must allow: the concurrent mode's budgets)
 spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int n_streams,
                     const int16_t* __restrict__ in_base, SpxFrameRec* __restrict__ rec, SpxTapsDev taps,
                     const int* __restrict__ tile_order, int* tile_flags, const float* __restrict__ frames,
@@ -834,7 +836,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       ASTAMP(2);
     }
   } else if constexpr (ct_plan<WCT>::n != 0) {
-    // A window size with a compiled-in plan (8 / 24 / 32 / 48 kHz): the stages of ct_stage, the first fed straight from the
+    // A window size with a compiled-in plan (8 / 12 / 24 / 32 / 48 kHz): the stages of ct_stage, the first fed straight from the
     // staged samples (its upper inputs are the zero padding); the window values a lane needs are the same for every frame
     // and the compiler keeps them in registers.
     constexpr int R0 = ct_plan<WCT>::r[0], SPAN0 = WCT / R0;
@@ -1367,6 +1369,7 @@ void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n
   } else {
     if (ctw == 240) SPX_LAUNCH_ANALYSIS(SPX_TF, 240); else if (ctw == 330) SPX_LAUNCH_ANALYSIS(SPX_TF, 330);
     else if (ctw == 120) SPX_LAUNCH_ANALYSIS(SPX_TF, 120); else if (ctw == 360) SPX_LAUNCH_ANALYSIS(SPX_TF, 360);
+    else if (ctw == 180) SPX_LAUNCH_ANALYSIS(SPX_TF, 180);
     else if (ctw == 480) SPX_LAUNCH_ANALYSIS(SPX_TF, 480);
     else SPX_LAUNCH_ANALYSIS(SPX_TF, 0);
   }
@@ -1383,7 +1386,8 @@ int spx_analysis_vgprs(const SpxPlanDev& P, int* scratch_bytes) {
                      : ctw == 720 ? SPX_AN_FN(SPX_TF_SMALL, 720) : ctw == 661 ? SPX_AN_FN(SPX_TF_SMALL, 661)
                      : ctw == 120 ? SPX_AN_FN(SPX_TF_SMALL, 120) : SPX_AN_FN(SPX_TF_SMALL, 0);
   else fn = ctw == 240 ? SPX_AN_FN(SPX_TF, 240) : ctw == 330 ? SPX_AN_FN(SPX_TF, 330) : ctw == 120 ? SPX_AN_FN(SPX_TF, 120)
-          : ctw == 360 ? SPX_AN_FN(SPX_TF, 360) : ctw == 480 ? SPX_AN_FN(SPX_TF, 480) : SPX_AN_FN(SPX_TF, 0);
+          : ctw == 360 ? SPX_AN_FN(SPX_TF, 360) : ctw == 480 ? SPX_AN_FN(SPX_TF, 480) : ctw == 180 ? SPX_AN_FN(SPX_TF, 180)
+          : SPX_AN_FN(SPX_TF, 0);
 #undef SPX_AN_FN
   return spx_kernel_vgprs(fn, scratch_bytes);
 }

@@ -74,10 +74,10 @@ def test_spectrogram_tap_matches_oracle(orc):
     assert abs(float((taps["normalized"][150] ** 2).sum()) - 1.0) < 4e-3  # speedy_test.cc:975-978
 
 
-@pytest.mark.parametrize("rate", [8000, 16000, 24000, 32000, 44100, 48000, 11025])
+@pytest.mark.parametrize("rate", [8000, 12000, 16000, 24000, 32000, 44100, 48000, 11025])
 def test_spectrogram_taps_of_every_compiled_in_window(orc, rate):
     """The spectrogram and normalised-spectrogram taps (every bin of every frame, the mirrored upper half and bin W included)
-    at the rates that have analysis kernels of their own -- 8 / 24 / 32 / 48 kHz over compiled-in plans, 44.1 kHz by Rader's
+    at the rates that have analysis kernels of their own -- 8 / 12 / 24 / 32 / 48 kHz over compiled-in plans, 44.1 kHz by Rader's
     algorithm over the 660-point plan, 16 kHz hand-written -- and at one that takes the plan-driven kernel (11.025 kHz);
     stream lengths that leave a partial last tile."""
     from speedy_amd.synth import speech_like
