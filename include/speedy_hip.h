@@ -90,6 +90,19 @@ int spx_batch_run(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, co
                   int16_t* out, int64_t* n_out, void* workspace, size_t workspace_bytes,
                   const spx_taps* taps, void* hip_stream);
 
+/* spx_batch_run for a caller that issues batch after batch (round 4): consecutive calls are software-pipelined.  This call's
+ * analysis and tension kernels are enqueued on a stream of the library's and start AT ONCE -- beside the walk kernel of the
+ * previous call, which is still running on hip_stream -- and its own walk kernel follows on hip_stream with every speed ready.
+ * Same results as spx_batch_run.  The caller's side of the contract:
+ *   - `in` is complete in device memory when the call is made (the analysis does not wait for work queued on hip_stream);
+ *   - consecutive calls alternate (at least) two workspaces / out / n_out buffers; a call that hands over the previous call's
+ *     workspace again waits for that call to finish instead (correct, no overlap);
+ *   - hip_stream is the same stream call after call; when it has drained, every kernel of every call issued on it has.
+ * Batches that do not fit the shape (more streams than CUs, taps of many kinds ...) run exactly as spx_batch_run would. */
+int spx_batch_run_ahead(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, const int16_t* in,
+                        int16_t* out, int64_t* n_out, void* workspace, size_t workspace_bytes,
+                        const spx_taps* taps, void* hip_stream);
+
 /* The two stages separately (same arguments); spx_batch_run = analyze then walk. */
 int spx_batch_analyze(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, const int16_t* in,
                       void* workspace, size_t workspace_bytes, const spx_taps* taps, void* hip_stream);

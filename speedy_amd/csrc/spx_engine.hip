@@ -88,6 +88,13 @@ struct spx_plan {
   hipEvent_t ev_tension = nullptr;
   hipEvent_t ev_start = nullptr;
   hipEvent_t ev_chunk[SPX_MAX_CHUNKS] = {};
+  // spx_batch_run_ahead: the previous calls' walk kernels (ring of two), the workspace and started-counter of the last one
+  hipEvent_t ev_walk[2] = {nullptr, nullptr};
+  bool ev_walk_valid[2] = {false, false};
+  int ahead_calls = 0;
+  void* ahead_last_ws = nullptr;
+  const int* ahead_started = nullptr;
+  int ahead_n = 0;
   // spx_batch_run_mixed: this plan's group runs on `mix`; the first plan of a call also lends the fork event and a staging slot
   hipStream_t mix = nullptr;
   hipEvent_t ev_join = nullptr, ev_fork = nullptr, ev_an = nullptr;
@@ -550,7 +557,7 @@ struct SpxForce { int concurrent; bool idle_start; int total_streams; hipEvent_t
 // total_streams: of all groups of the mixed call; after_analysis: recorded behind the group's analysis launch (or null)
 static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                     int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs, bool do_a,
-                    bool do_w, const SpxForce* force = nullptr) {
+                    bool do_w, const SpxForce* force = nullptr, bool ahead_req = false) {
   if (!plan || !jobs || n <= 0) return fail(-1, "spx_batch: bad arguments");
   SpxRange range_(do_a && do_w ? "spx_batch_run" : (do_a ? "spx_batch_analyze" : "spx_batch_walk"));
   SpxPlanDev d = plan->dev;  // a copy: the tile size is chosen per call
@@ -666,6 +673,13 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   if (want_concurrent && !device_is_ours(plan->device)) want_concurrent = false;   // another process works on this GPU
   if (force) want_concurrent = force->concurrent != 0 && do_a && do_w;
   hipStream_t st = static_cast<hipStream_t>(hs);
+  // AHEAD (spx_batch_run_ahead, round 4): consecutive calls on DIFFERENT workspaces are software-pipelined -- this call's
+  // staging, analysis and tension kernels go to the side stream at once, beside the PREVIOUS call's walk kernel, which is
+  // still running on the caller's stream; its own walk kernel follows on the caller's stream with every speed ready: no
+  // consumer polls a producer (nothing to deadlock, no guard), and no walk waits for its first frames.  Same shapes as the
+  // concurrent mode (one stream per CU, two analysis workgroups beside a stream's walk and tension workgroups).
+  const bool ahead = ahead_req && want_concurrent && !doubtful && !force && trial_slot < 0 && (!g_chunks_set.load() || g_chunks.load() == 1);
+  if (ahead) want_concurrent = false;
   // another concurrent-mode call still in flight on this device, on a different stream?  Then this one runs its kernels
   // in sequence (SpxDevGuard above); the guard stays locked until this call has left its own event behind.
   SpxDevGuard& guard = g_guard[(plan->device >= 0 && plan->device < 64) ? plan->device : 0];
@@ -679,7 +693,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     (void)hipGetLastError();  // hipErrorNotReady is not an error of this call
     if (!want_concurrent) guard_lock.unlock();
   }
-  if (!want_concurrent) d.tile_frames = plan->dev.tile_frames;  // no concurrency: default tile
+  if (!want_concurrent && !ahead) d.tile_frames = plan->dev.tile_frames;  // no concurrency: default tile
   // Pipelining in time needs both stages in one call; the separate entry points run one chunk.  A batch too large for
   // the concurrent mode gets four time chunks unless the caller chose a count: the analysis of chunk c+1 then overlaps
   // the walk of chunk c through ordinary stream ordering (measured at 512 / 1024 streams x 10 s: 5.32 -> 4.76 ms and
@@ -688,6 +702,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // (two time chunks once the walk is in its throughput form, more than two streams per CU: 2048 streams 9.7 -> 9.6 ms;
   // below that the chains are the run time and the kernels run back to back: 512 streams 3.63 against 3.99 chunked)
   if (do_a && do_w && !g_chunks_set.load() && !want_concurrent && n > 2 * cu_count) nch = 2;
+  if (ahead) nch = 1;
   if (nch < 1) nch = 1;
   if (nch > SPX_MAX_CHUNKS) nch = SPX_MAX_CHUNKS;
   std::vector<SpxStreamDev> sv;
@@ -711,7 +726,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   int* d_flags = reinterpret_cast<int*>(w + L.off_flags);
   int* d_ready = reinterpret_cast<int*>(w + L.off_ready);
   hipStream_t sa = st;  // stream the analysis launches go to
-  if (nch > 1 || concurrent) {
+  if (nch > 1 || concurrent || ahead) {
     if (!plan->side) {
       if (dev_side_streams(plan->device, &plan->side, &plan->side2)) return fail(-1, "spx_batch: no side streams");
       HIPCHK(hipEventCreateWithFlags(&plan->ev_start, hipEventDisableTiming));
@@ -756,11 +771,19 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     // one small kernel reads the pinned slot over PCIe and clears the hand-off flags: a single stream operation where
     // two copies and two fills (each its own DMA packet with barriers around it) cost the concurrent mode 0.13 ms a call
     const unsigned w_sv = (unsigned)(b_sv / 4), w_or = concurrent ? (unsigned)(b_or / 4) : 0u;
-    const unsigned z_fl = concurrent ? (unsigned)tiles[0] : 0u, z_rd = concurrent ? (unsigned)n + 1u : 0u;
-    hipLaunchKernelGGL(spx_stage_kernel, dim3(64), dim3(256), 0, st, reinterpret_cast<const unsigned*>(hp),
+    const unsigned z_fl = concurrent ? (unsigned)tiles[0] : 0u, z_rd = (concurrent || ahead) ? (unsigned)n + 1u : 0u;
+    if (ahead) {
+      // this call's producers must not touch a workspace the walk kernel of an earlier call still reads: with the caller
+      // alternating two workspaces that is the call before the previous one (the older event of the ring); a caller that
+      // hands over the previous call's workspace again waits for that call instead (correct, and no overlap)
+      const int cur = plan->ahead_calls & 1;          // this call's slot of the ring = the slot of the call two back
+      if (ws == plan->ahead_last_ws && plan->ev_walk_valid[cur ^ 1]) HIPCHK(hipStreamWaitEvent(sa, plan->ev_walk[cur ^ 1], 0));
+      if (plan->ev_walk_valid[cur]) HIPCHK(hipStreamWaitEvent(sa, plan->ev_walk[cur], 0));
+    }
+    hipLaunchKernelGGL(spx_stage_kernel, dim3(64), dim3(256), 0, ahead ? sa : st, reinterpret_cast<const unsigned*>(hp),
                        reinterpret_cast<unsigned*>(dstreams), w_sv, reinterpret_cast<unsigned*>(d_order), w_or,
                        reinterpret_cast<unsigned*>(d_flags), z_fl, reinterpret_cast<unsigned*>(d_ready), z_rd);
-    HIPCHK(hipEventRecord(G.done, st));
+    HIPCHK(hipEventRecord(G.done, ahead ? sa : st));
     staged_ev = G.done;
   }
   if (trial_slot >= 0) {  // bracket this call on the caller's stream (spx_plan::Trial)
@@ -768,7 +791,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     if (!e0) HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventRecord(e0, st));
   }
-  if (sa != st) {
+  if (sa != st && !ahead) {
     // the side stream starts after everything already queued on the caller's stream (job tables, cleared flags, and
     // the previous call's walk, which still reads the frame records this call's analysis will overwrite)
     // (the staging slot's event marks exactly that point of the caller's stream: one stream operation fewer in front of
@@ -792,9 +815,11 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       // (The concurrent mode needs that LDS for the analysis workgroups beside the walk; its idle-start gate does this job.)
       static const bool no_excl = spx_tuning_env("SPX_NO_EXCLUSIVE_CU") != nullptr;   // A/B
       const int total = force ? force->total_streams : n;
-      const size_t lds_min = (!concurrent && !no_excl && nch == 1 && total <= cu_count) ? lds_per_cu / 2 + 1024 : 0;
-      spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, (concurrent && !diag_nowait) ? d_ready : nullptr,
-                      speedup_only, st, false, lds_min, lean_walk && concurrent);
+      const size_t lds_min = (!concurrent && !ahead && !no_excl && nch == 1 && total <= cu_count) ? lds_per_cu / 2 + 1024 : 0;
+      // (AHEAD: the counts are all published by the time the kernel starts -- its one poll returns at once -- and its
+      // workgroups count themselves in for the next call's gate)
+      spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, ((concurrent && !diag_nowait) || ahead) ? d_ready : nullptr,
+                      speedup_only, st, false, lds_min, lean_walk && (concurrent || ahead));
       if (timed) { (void)hipEventRecord(e1, st); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({e0, e1, 1}); } }
     };
     // Concurrent mode on an IDLE device (the first call after a synchronisation): kernels start as their launches arrive,
@@ -810,6 +835,15 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     static const unsigned gate_spins = [] { const char* e = spx_tuning_env("SPX_GATE_SPINS"); return e ? (unsigned)atoi(e) : 1200u; }();
     if (concurrent && do_w && idle_start && !no_gate)
       hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, sa, d_ready + n, n, gate_spins);
+    // AHEAD: the analysis must not fill the CUs before the PREVIOUS call's walk workgroups have been placed one per CU (its
+    // walk kernel becomes runnable at the same moment as this analysis: when the walk before it retires)
+    // (only while that call is still in flight: then its workspace, where the counter lives, is alive by the usual contract)
+    if (ahead && plan->ahead_started != nullptr && plan->ahead_n > 0 && !no_gate) {
+      const int prev = (plan->ahead_calls & 1) ^ 1;
+      const bool in_flight = plan->ev_walk_valid[prev] && hipEventQuery(plan->ev_walk[prev]) == hipErrorNotReady;
+      (void)hipGetLastError();
+      if (in_flight) hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, sa, plan->ahead_started, plan->ahead_n, gate_spins);
+    }
     if (do_a && tiles[c] > 0) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, sa); }
@@ -819,18 +853,32 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     }
     if (force && force->after_analysis && c == nch - 1) HIPCHK(hipEventRecord(force->after_analysis, sa));
     if (sa != st) HIPCHK(hipEventRecord(plan->ev_chunk[c], sa));
-    if (sa != st && !concurrent) HIPCHK(hipStreamWaitEvent(st, plan->ev_chunk[c], 0));
+    if (sa != st && !concurrent && !ahead) HIPCHK(hipStreamWaitEvent(st, plan->ev_chunk[c], 0));
     if (do_w) {
       // frame-rate stage: after the analysis on the same stream, or -- concurrent -- beside it on its own stream,
-      // consuming tile flags and publishing the count of ready speeds
-      hipStream_t stn = concurrent ? plan->side2 : st;
+      // consuming tile flags and publishing the count of ready speeds (AHEAD: behind the analysis on the side stream)
+      hipStream_t stn = concurrent ? plan->side2 : (ahead ? sa : st);
       hipEvent_t t0 = nullptr, t1 = nullptr;
       if (timed) { t0 = take_event(); t1 = take_event(); (void)hipEventRecord(t0, stn); }
       spx_launch_tension(d, dj, n, states, rec, scratch, td, concurrent ? d_flags : nullptr,
-                         concurrent ? d_ready : nullptr, stn);
+                         (concurrent || ahead) ? d_ready : nullptr, stn);
       if (timed) { (void)hipEventRecord(t1, stn); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({t0, t1, 2}); } }
       if (concurrent) HIPCHK(hipEventRecord(plan->ev_tension, stn));
+      if (ahead) {   // the walk kernel starts when every speed of the call is there
+        HIPCHK(hipEventRecord(plan->ev_tension, stn));
+        HIPCHK(hipStreamWaitEvent(st, plan->ev_tension, 0));
+      }
       launch_walk();
+      if (ahead) {
+        const int cur = plan->ahead_calls & 1;
+        if (!plan->ev_walk[cur]) HIPCHK(hipEventCreateWithFlags(&plan->ev_walk[cur], hipEventDisableTiming));
+        HIPCHK(hipEventRecord(plan->ev_walk[cur], st));
+        plan->ev_walk_valid[cur] = true;
+        plan->ahead_calls++;
+        plan->ahead_last_ws = ws;
+        plan->ahead_started = d_ready + n;
+        plan->ahead_n = n;
+      }
     }
     // the caller's stream is "done" only when the side launches have retired too
     if (concurrent) {
@@ -858,6 +906,10 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
 int spx_batch_run(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                   int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs) {
   return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true);
+}
+int spx_batch_run_ahead(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
+                        int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs) {
+  return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true, nullptr, true);
 }
 int spx_batch_analyze(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, void* ws,
                       size_t ws_bytes, const spx_taps* taps, void* hs) {
