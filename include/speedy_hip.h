@@ -163,8 +163,9 @@ int spx_debug_analysis_info(int sample_rate, int* out3);
  * `denominators` random speeds (speed - 1 log-uniform in [2^exp_lo, 2^exp_hi)) x every count 1 .. 4096 x both numerator forms;
  * returns the number of mismatches (0 is the only acceptable answer), -1 on a runtime error. */
 long long spx_debug_fdiv_check(unsigned seed, unsigned denominators, int exp_lo, int exp_hi);
-/* Diagnostics: 1 if the last spx_batch_run / analyze+walk call of this process took the concurrent three-kernel mode, 0 if it
- * launched its kernels in sequence (another process holds the device's concurrent-mode lock, a tuning variable, the batch shape). */
+/* Diagnostics: 1 if the last spx_batch_run / analyze+walk call of this process took the concurrent three-kernel mode, 2 if it was
+ * pipelined with the previous call (spx_batch_run_ahead), 0 if it launched its kernels in sequence (another process holds the
+ * device's concurrent-mode lock, a tuning variable, the batch shape). */
 int spx_debug_last_call_concurrent(void);
 /* Sum over the same calls of the frame-rate (tension) kernel's time, as of the last spx_timing_collect. */
 double spx_timing_last_tension_ms(void);

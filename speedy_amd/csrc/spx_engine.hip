@@ -88,11 +88,13 @@ struct spx_plan {
   hipEvent_t ev_tension = nullptr;
   hipEvent_t ev_start = nullptr;
   hipEvent_t ev_chunk[SPX_MAX_CHUNKS] = {};
-  // spx_batch_run_ahead: the previous calls' walk kernels (ring of two), the workspace and started-counter of the last one
+  // spx_batch_run_ahead: the walk kernels of the plan's previous two calls (ring of two events), the workspace, stream and
+  // started-counter of the last one
   hipEvent_t ev_walk[2] = {nullptr, nullptr};
   bool ev_walk_valid[2] = {false, false};
   int ahead_calls = 0;
   void* ahead_last_ws = nullptr;
+  hipStream_t ahead_last_stream = nullptr;
   const int* ahead_started = nullptr;
   int ahead_n = 0;
   // spx_batch_run_mixed: this plan's group runs on `mix`; the first plan of a call also lends the fork event and a staging slot
@@ -107,7 +109,7 @@ struct spx_plan {
 // Process-wide switches are atomics; the event lists behind spx_timing_collect are guarded by g_tmu.  spx_batch_run may be
 // called from several host threads (one plan per thread, or one plan shared: launches on a plan are serialised by its mutex).
 static std::atomic<bool> g_timing{false};
-static std::atomic<int> g_last_concurrent{0};   // spx_debug_last_call_concurrent
+static std::atomic<int> g_last_concurrent{0};   // spx_debug_last_call_concurrent (2 = pipelined with the previous call)
 static std::atomic<int> g_concurrent{1};  // spx_set_concurrent: analysis and walk kernels on two streams, tile-flag hand-off
 static std::atomic<bool> g_chunks_set{false};  // the caller chose a chunk count (spx_set_pipeline_chunks)
 static std::atomic<int> g_chunks{1};  // spx_set_pipeline_chunks (measured on MI355X, 256 x 10 s: 1 -> 5.09 ms, 2 -> 5.25, 4 -> 5.54 per step)
@@ -717,7 +719,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   SpxTapsDev td = taps_of(taps);
   const bool timed = g_timing.load() && do_a && do_w;
   const bool concurrent = want_concurrent && nch == 1 && tiles[0] > 0;
-  if (do_a && do_w) g_last_concurrent.store(concurrent ? 1 : 0, std::memory_order_relaxed);
+  if (do_a && do_w) g_last_concurrent.store(concurrent ? 1 : (ahead ? 2 : 0), std::memory_order_relaxed);
   static const bool dbg_mode = getenv("SPX_DEBUG_MODE") != nullptr;   // one line per call: what was decided and why
   if (dbg_mode)
     fprintf(stderr, "[spx mode] rate %d n %d maxC %d: co_resident %d doubtful %d lean %d want_concurrent %d chunks %d tiles %d -> %s\n", d.rate, n,
@@ -777,7 +779,9 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       // alternating two workspaces that is the call before the previous one (the older event of the ring); a caller that
       // hands over the previous call's workspace again waits for that call instead (correct, and no overlap)
       const int cur = plan->ahead_calls & 1;          // this call's slot of the ring = the slot of the call two back
-      if (ws == plan->ahead_last_ws && plan->ev_walk_valid[cur ^ 1]) HIPCHK(hipStreamWaitEvent(sa, plan->ev_walk[cur ^ 1], 0));
+      // (the previous call's too when it used this workspace, or another stream: then the ring's order says nothing)
+      if ((ws == plan->ahead_last_ws || st != plan->ahead_last_stream) && plan->ev_walk_valid[cur ^ 1])
+        HIPCHK(hipStreamWaitEvent(sa, plan->ev_walk[cur ^ 1], 0));
       if (plan->ev_walk_valid[cur]) HIPCHK(hipStreamWaitEvent(sa, plan->ev_walk[cur], 0));
     }
     hipLaunchKernelGGL(spx_stage_kernel, dim3(64), dim3(256), 0, ahead ? sa : st, reinterpret_cast<const unsigned*>(hp),
@@ -869,14 +873,17 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
         HIPCHK(hipStreamWaitEvent(st, plan->ev_tension, 0));
       }
       launch_walk();
-      if (ahead) {
+      if (c == nch - 1 && !force) {
+        // every call of the plan that walks leaves its event in the ring (a pipelined call orders its producers behind the
+        // walk kernels of the two calls before it, pipelined or not)
         const int cur = plan->ahead_calls & 1;
         if (!plan->ev_walk[cur]) HIPCHK(hipEventCreateWithFlags(&plan->ev_walk[cur], hipEventDisableTiming));
         HIPCHK(hipEventRecord(plan->ev_walk[cur], st));
         plan->ev_walk_valid[cur] = true;
         plan->ahead_calls++;
         plan->ahead_last_ws = ws;
-        plan->ahead_started = d_ready + n;
+        plan->ahead_last_stream = st;
+        plan->ahead_started = (concurrent || ahead) ? d_ready + n : nullptr;   // (only these walk kernels count themselves in)
         plan->ahead_n = n;
       }
     }

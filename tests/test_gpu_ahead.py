@@ -1,0 +1,120 @@
+"""spx_batch_run_ahead (include/speedy_hip.h): consecutive batch calls software-pipelined -- a call's analysis and tension kernels
+run beside the previous call's walk kernel.  The results must be spx_batch_run's (and the oracle's) whatever the calls overlap
+with: batches of DIFFERENT content taking turns on two and three workspaces, one workspace handed over again and again, shapes
+that do not fit the mode, other calls in between."""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _crc(outs):
+    return [zlib.crc32(np.ascontiguousarray(o).tobytes()) for o in outs]
+
+
+def _make(plan, rate, ch, n_streams, seed, seconds, speed=3.5, nl=1.0, fb=0.0, ragged=True):
+    from speedy_amd.batch import Batch
+    from speedy_amd.synth import speech_like
+    rng = np.random.default_rng(seed)
+    lens = [int(rate * seconds * (rng.uniform(0.3, 1.0) if ragged else 1.0)) for _ in range(n_streams)]
+    base = [speech_like(max(lens), rate, seed=1000 * seed + i, channels=ch) for i in range(min(n_streams, 12))]
+    streams = [base[i % len(base)][: lens[i] * ch] for i in range(n_streams)]
+    b = Batch(plan, lens, ch, speed, nl, fb)
+    b.upload(streams)
+    return b, streams
+
+
+@pytest.mark.parametrize("rate,ch,n_streams", [(16000, 1, 256), (16000, 1, 97), (22050, 1, 256), (16000, 2, 128), (48000, 2, 64)])
+def test_alternating_batches_of_different_content(orc, rate, ch, n_streams):
+    """Three batches with different signals and lengths take turns (a ring of three workspaces, then of two): every pass of
+    every batch must reproduce what spx_batch_run gives for it; a sample of the streams is checked against the oracle."""
+    import torch
+    from speedy_amd.batch import Plan
+    plan = Plan(rate, False)
+    bs = []
+    for seed in (1, 2, 3):
+        b, streams = _make(plan, rate, ch, n_streams, seed, seconds=1.5)
+        b.run()
+        want = _crc(b.results())
+        for i in (0, n_streams // 2, n_streams - 1):
+            ref = orc.compress_sound(streams[i], rate, ch, 3.5, 1.0, 0.0, False, chunk=1000)
+            assert want[i] == zlib.crc32(np.ascontiguousarray(ref["out"]).tobytes()), (seed, i)
+        b.d_out.zero_()
+        bs.append((b, want))
+    torch.cuda.synchronize()
+    for ring in (3, 2):
+        order = [k % ring for k in range(9)]
+        for k in order:
+            bs[k][0].run_ahead()
+        if (rate, ch) == (16000, 1):     # the shapes of the headline take the mode (the others decide by their co-residency arithmetic)
+            assert plan.L.spx_debug_last_call_concurrent() == 2
+        torch.cuda.synchronize()
+        for k in set(order):
+            assert _crc(bs[k][0].results()) == bs[k][1], (ring, k)
+            bs[k][0].d_out.zero_()
+
+
+def test_one_workspace_again_and_again(orc):
+    """The caller breaks the contract's advice (no second workspace): every call then waits for the previous one -- same bytes."""
+    import torch
+    from speedy_amd.batch import Plan
+    plan = Plan(16000, False)
+    b, _ = _make(plan, 16000, 1, 200, 7, seconds=1.0)
+    b.run()
+    want = _crc(b.results())
+    for _ in range(6):
+        b.run_ahead()
+    torch.cuda.synchronize()
+    assert _crc(b.results()) == want
+
+
+def test_shapes_outside_the_mode_and_calls_in_between(orc):
+    """More streams than CUs, slow-down jobs, linear jobs, a plain spx_batch_run between two pipelined calls, two plans of
+    different rates taking turns on the same HIP stream: spx_batch_run_ahead decides per call and the bytes never change."""
+    import torch
+    from speedy_amd.batch import Plan
+    p16, p22 = Plan(16000, False), Plan(22050, False)
+    cases = [(p16, 16000, 1, 600, 3.5, 1.0), (p16, 16000, 1, 64, 0.7, 1.0), (p16, 16000, 1, 64, 2.0, 0.0),
+             (p22, 22050, 2, 100, 1.5, 1.0), (p16, 16000, 1, 256, 3.5, 1.0), (p22, 22050, 1, 256, 3.5, 1.0)]
+    bs = []
+    for j, (plan, rate, ch, n, speed, nl) in enumerate(cases):
+        b, _ = _make(plan, rate, ch, n, 20 + j, seconds=0.8, speed=speed, nl=nl)
+        b.run()
+        bs.append((b, _crc(b.results())))
+        b.d_out.zero_()
+    torch.cuda.synchronize()
+    seq = [4, 5, 4, 0, 5, 1, 4, 2, 5, 3, 4, 5]
+    for t, k in enumerate(seq):
+        if t == 6:
+            bs[k][0].run()          # a plain call in between
+        else:
+            bs[k][0].run_ahead()
+    torch.cuda.synchronize()
+    for k in set(seq):
+        assert _crc(bs[k][0].results()) == bs[k][1], k
+
+
+def test_pipelined_calls_are_faster_than_plain_ones():
+    """What the mode is for (bench.py's `value` against its `unpipelined`): the bench batch, two workspaces."""
+    import time
+    import torch
+    import bench
+    from speedy_amd.batch import Batch, Plan
+    n = bench.RATE * bench.SECONDS
+    plan = Plan(bench.RATE, False)
+    streams = bench.make_streams(bench.STREAMS_PER_GPU, n, 0)
+    bs = [Batch(plan, [n] * len(streams), 1, bench.SPEED, 1.0, 0.0) for _ in range(2)]
+    for b in bs:
+        b.upload(streams)
+    plain = bench.time_window(bs[0].run, 12, 4)
+    for k in range(4):
+        bs[k % 2].run_ahead()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(12):
+        bs[k % 2].run_ahead()
+    torch.cuda.synchronize()
+    ahead = (time.perf_counter() - t0) / 12
+    assert ahead < 0.97 * plain, (ahead, plain)
