@@ -103,6 +103,13 @@ int spx_batch_run_ahead(spx_plan_t plan, const spx_stream_job* jobs, int n_strea
                         int16_t* out, int64_t* n_out, void* workspace, size_t workspace_bytes,
                         const spx_taps* taps, void* hip_stream);
 
+/* The same for input that is still on its way when the call is made (a host-to-device copy on another stream):
+ * in_ready_event is a hipEvent_t the caller has recorded behind whatever completes `in`; the call's producers wait for it
+ * (NULL: as spx_batch_run_ahead). */
+int spx_batch_run_ahead_when(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, const int16_t* in,
+                             int16_t* out, int64_t* n_out, void* workspace, size_t workspace_bytes,
+                             const spx_taps* taps, void* hip_stream, void* in_ready_event);
+
 /* The two stages separately (same arguments); spx_batch_run = analyze then walk. */
 int spx_batch_analyze(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, const int16_t* in,
                       void* workspace, size_t workspace_bytes, const spx_taps* taps, void* hip_stream);

@@ -109,13 +109,15 @@ class Batch:
         if rc != 0:
             raise RuntimeError("spx_batch_run: " + self.plan.L.spx_last_error().decode())
 
-    def run_ahead(self, stream=None):
+    def run_ahead(self, stream=None, in_ready=None):
         """spx_batch_run_ahead: like run(), software-pipelined with the previous call on the same stream (the caller alternates
-        two Batch objects; inputs are resident when the call is made)."""
+        two Batch objects).  in_ready: a recorded torch.cuda.Event behind whatever completes the input (None: the input is
+        resident when the call is made)."""
         hs = (stream or torch.cuda.current_stream(self.device)).cuda_stream
-        rc = self.plan.L.spx_batch_run_ahead(self.plan.h, self.jobs, self.n, self.d_in.data_ptr(), self.d_out.data_ptr(),
-                                             self.d_nout.data_ptr(), self.d_ws.data_ptr(), self.d_ws.numel(),
-                                             C.byref(self.taps) if self.taps is not None else None, hs)
+        rc = self.plan.L.spx_batch_run_ahead_when(self.plan.h, self.jobs, self.n, self.d_in.data_ptr(), self.d_out.data_ptr(),
+                                                  self.d_nout.data_ptr(), self.d_ws.data_ptr(), self.d_ws.numel(),
+                                                  C.byref(self.taps) if self.taps is not None else None, hs,
+                                                  in_ready.cuda_event if in_ready is not None else None)
         if rc != 0:
             raise RuntimeError("spx_batch_run_ahead: " + self.plan.L.spx_last_error().decode())
 

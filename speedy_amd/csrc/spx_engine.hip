@@ -559,7 +559,7 @@ struct SpxForce { int concurrent; bool idle_start; int total_streams; hipEvent_t
 // total_streams: of all groups of the mixed call; after_analysis: recorded behind the group's analysis launch (or null)
 static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                     int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs, bool do_a,
-                    bool do_w, const SpxForce* force = nullptr, bool ahead_req = false) {
+                    bool do_w, const SpxForce* force = nullptr, bool ahead_req = false, void* in_ready = nullptr) {
   if (!plan || !jobs || n <= 0) return fail(-1, "spx_batch: bad arguments");
   SpxRange range_(do_a && do_w ? "spx_batch_run" : (do_a ? "spx_batch_analyze" : "spx_batch_walk"));
   SpxPlanDev d = plan->dev;  // a copy: the tile size is chosen per call
@@ -783,7 +783,9 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       if ((ws == plan->ahead_last_ws || st != plan->ahead_last_stream) && plan->ev_walk_valid[cur ^ 1])
         HIPCHK(hipStreamWaitEvent(sa, plan->ev_walk[cur ^ 1], 0));
       if (plan->ev_walk_valid[cur]) HIPCHK(hipStreamWaitEvent(sa, plan->ev_walk[cur], 0));
+      if (in_ready) HIPCHK(hipStreamWaitEvent(sa, static_cast<hipEvent_t>(in_ready), 0));   // the caller's "input is there"
     }
+    if (!ahead && in_ready) HIPCHK(hipStreamWaitEvent(st, static_cast<hipEvent_t>(in_ready), 0));
     hipLaunchKernelGGL(spx_stage_kernel, dim3(64), dim3(256), 0, ahead ? sa : st, reinterpret_cast<const unsigned*>(hp),
                        reinterpret_cast<unsigned*>(dstreams), w_sv, reinterpret_cast<unsigned*>(d_order), w_or,
                        reinterpret_cast<unsigned*>(d_flags), z_fl, reinterpret_cast<unsigned*>(d_ready), z_rd);
@@ -917,6 +919,10 @@ int spx_batch_run(spx_plan_t plan, const spx_stream_job* jobs, int n, const int1
 int spx_batch_run_ahead(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                         int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs) {
   return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true, nullptr, true);
+}
+int spx_batch_run_ahead_when(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
+                             int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs, void* in_ready_event) {
+  return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true, nullptr, true, in_ready_event);
 }
 int spx_batch_analyze(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, void* ws,
                       size_t ws_bytes, const spx_taps* taps, void* hs) {

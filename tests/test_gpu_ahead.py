@@ -96,6 +96,39 @@ def test_shapes_outside_the_mode_and_calls_in_between(orc):
         assert _crc(bs[k][0].results()) == bs[k][1], k
 
 
+def test_input_that_arrives_on_another_stream(orc):
+    """spx_batch_run_ahead_when: the input of every call is still being copied (pinned host -> device, on a stream of the
+    caller's) when the call is made; the call's producers wait for the caller's event, not for the caller's stream."""
+    import torch
+    from speedy_amd.batch import Plan
+    plan = Plan(16000, False)
+    bs, want, hosts = [], [], []
+    for seed in (31, 32):
+        b, streams = _make(plan, 16000, 1, 256, seed, seconds=1.0)
+        b.run()
+        want.append(_crc(b.results()))
+        hosts.append(b.d_in.cpu().pin_memory())
+        bs.append(b)
+    s_copy = torch.cuda.Stream()
+    evs = [torch.cuda.Event() for _ in bs]
+    done = [torch.cuda.Event() for _ in bs]
+    torch.cuda.synchronize()
+    for k in range(8):
+        i = k % 2
+        with torch.cuda.stream(s_copy):
+            if k >= 2:
+                s_copy.wait_event(done[i])          # the walk of the call that last read this input has finished
+            bs[i].d_in.zero_()                      # whoever reads too early reads silence
+            bs[i].d_in.copy_(hosts[i], non_blocking=True)
+            evs[i].record(s_copy)
+        bs[i].d_out.zero_()
+        bs[i].run_ahead(in_ready=evs[i])
+        done[i].record()
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert _crc(bs[i].results()) == want[i], i
+
+
 def test_pipelined_calls_are_faster_than_plain_ones():
     """What the mode is for (bench.py's `value` against its `unpipelined`): the bench batch, two workspaces."""
     import time
