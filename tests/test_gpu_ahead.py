@@ -129,6 +129,46 @@ def test_input_that_arrives_on_another_stream(orc):
         assert _crc(bs[i].results()) == want[i], i
 
 
+def test_two_host_threads_each_with_a_plan_and_a_stream(orc):
+    """Two threads pipeline their own batches on their own plans and HIP streams; the library's side stream is the device's, so
+    their producers (and gate kernels) share it."""
+    import threading
+    import torch
+    from speedy_amd.batch import Plan
+    work, errors = [], []
+    for t, rate in enumerate((16000, 22050)):
+        plan = Plan(rate, False)
+        pair = []
+        for seed in (41 + 2 * t, 42 + 2 * t):
+            b, _ = _make(plan, rate, 1, 256, seed, seconds=1.0)
+            b.run()
+            pair.append((b, _crc(b.results())))
+            b.d_out.zero_()
+        work.append(pair)
+    torch.cuda.synchronize()
+
+    def body(pair):
+        try:
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            for k in range(10):
+                pair[k % 2][0].run_ahead(stream=s)
+            s.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=body, args=(pair,)) for pair in work]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for pair in work:
+        for b, want in pair:
+            assert _crc(b.results()) == want
+
+
 def test_pipelined_calls_are_faster_than_plain_ones():
     """What the mode is for (bench.py's `value` against its `unpipelined`): the bench batch, two workspaces."""
     import time
