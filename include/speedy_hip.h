@@ -135,6 +135,13 @@ int spx_batch_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_j
 int spx_batch_run_mixed_taps(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index,
                              int n_streams, const int16_t* in, int16_t* out, int64_t* n_out, void* workspace,
                              size_t workspace_bytes, const spx_taps* taps, void* hip_stream);
+/* spx_batch_run_mixed for a caller that issues mixed batch after mixed batch (see spx_batch_run_ahead: same contract -- `in`
+ * complete when the call is made, two workspaces / out / n_out taking turns, one hip_stream, and the same plans[0] call after
+ * call): every group's analysis and tension kernels start at once on a stream of the library's, beside the previous call's walk
+ * kernels.  Calls of more streams than the device has CUs run exactly as spx_batch_run_mixed would. */
+int spx_batch_run_mixed_ahead(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index,
+                              int n_streams, const int16_t* in, int16_t* out, int64_t* n_out, void* workspace,
+                              size_t workspace_bytes, void* hip_stream);
 
 /* Timing hooks for bench.py: while enabled, every spx_batch_run records HIP events on hip_stream around
  * each of its kernels (no host synchronisation is added to the call).  spx_timing_collect waits for the

@@ -49,6 +49,8 @@ SYMBOLS = {
     "spx_batch_workspace_bytes_mixed": (C.c_size_t, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(StreamJob), C.POINTER(C.c_int), C.c_int]),
     "spx_batch_run_mixed": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(StreamJob), C.POINTER(C.c_int), C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "spx_batch_run_mixed_ahead": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(StreamJob), C.POINTER(C.c_int), C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "spx_batch_run_mixed_taps": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(StreamJob), C.POINTER(C.c_int), C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Taps), C.c_void_p]),
     "spx_batch_read_steps": (C.c_int, [C.c_void_p, C.POINTER(StreamJob), C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),

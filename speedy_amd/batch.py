@@ -249,6 +249,17 @@ class MixedBatch:
         if rc != 0:
             raise RuntimeError("spx_batch_run_mixed: " + self.L.spx_last_error().decode())
 
+    def run_ahead(self, stream=None):
+        """spx_batch_run_mixed_ahead: like run() (no taps), software-pipelined with the previous call on the same stream (the
+        caller alternates two MixedBatch objects over the same plans; inputs are resident when the call is made)."""
+        assert self.taps is None
+        hs = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        rc = self.L.spx_batch_run_mixed_ahead(self.hplans, len(self.plans), self.jobs, self.plan_index, self.n,
+                                              self.d_in.data_ptr(), self.d_out.data_ptr(), self.d_nout.data_ptr(),
+                                              self.d_ws.data_ptr(), self.d_ws.numel(), hs)
+        if rc != 0:
+            raise RuntimeError("spx_batch_run_mixed_ahead: " + self.L.spx_last_error().decode())
+
     def step_counts(self):
         steps = (C.c_int32 * self.n)()
         torch.cuda.synchronize(self.device)

@@ -95,6 +95,7 @@ struct spx_plan {
   int ahead_calls = 0;
   void* ahead_last_ws = nullptr;
   hipStream_t ahead_last_stream = nullptr;
+  std::vector<std::pair<const int*, int>> mixed_started;   // the same for the groups of the last mixed call (lead plan)
   const int* ahead_started = nullptr;
   int ahead_n = 0;
   // spx_batch_run_mixed: this plan's group runs on `mix`; the first plan of a call also lends the fork event and a staging slot
@@ -555,7 +556,9 @@ static int dev_side_streams(int dev, hipStream_t* side, hipStream_t* side2) {
   return 0;
 }
 
-struct SpxForce { int concurrent; bool idle_start; int total_streams; hipEvent_t after_analysis; };
+struct SpxForce { int concurrent; bool idle_start; int total_streams; hipEvent_t after_analysis; hipStream_t ahead_sa; const int** started_out; };
+// ahead_sa: the group of a pipelined mixed call -- its producers go to this stream at once (spx_batch_run_mixed_ahead orders it);
+// started_out: where the group's walk workgroups count themselves in (for the next call's gate)
 // total_streams: of all groups of the mixed call; after_analysis: recorded behind the group's analysis launch (or null)
 static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                     int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs, bool do_a,
@@ -680,7 +683,9 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // still running on the caller's stream; its own walk kernel follows on the caller's stream with every speed ready: no
   // consumer polls a producer (nothing to deadlock, no guard), and no walk waits for its first frames.  Same shapes as the
   // concurrent mode (one stream per CU, two analysis workgroups beside a stream's walk and tension workgroups).
-  const bool ahead = ahead_req && want_concurrent && !doubtful && !force && trial_slot < 0 && (!g_chunks_set.load() || g_chunks.load() == 1);
+  const bool ahead_forced = force && force->ahead_sa != nullptr && do_a && do_w;   // a group of spx_batch_run_mixed_ahead
+  const bool ahead = ahead_forced ||
+                     (ahead_req && want_concurrent && !doubtful && !force && trial_slot < 0 && (!g_chunks_set.load() || g_chunks.load() == 1));
   if (ahead) want_concurrent = false;
   // another concurrent-mode call still in flight on this device, on a different stream?  Then this one runs its kernels
   // in sequence (SpxDevGuard above); the guard stays locked until this call has left its own event behind.
@@ -736,6 +741,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       for (auto& e : plan->ev_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     sa = plan->side;
+    if (ahead_forced) sa = force->ahead_sa;
   }
   // job tables (and, concurrent mode, the tile order) go through a plan-owned pinned slot: the copies are asynchronous
   // and must not read host memory that dies when this function returns
@@ -774,7 +780,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     // two copies and two fills (each its own DMA packet with barriers around it) cost the concurrent mode 0.13 ms a call
     const unsigned w_sv = (unsigned)(b_sv / 4), w_or = concurrent ? (unsigned)(b_or / 4) : 0u;
     const unsigned z_fl = concurrent ? (unsigned)tiles[0] : 0u, z_rd = (concurrent || ahead) ? (unsigned)n + 1u : 0u;
-    if (ahead) {
+    if (ahead && !force) {
       // this call's producers must not touch a workspace the walk kernel of an earlier call still reads: with the caller
       // alternating two workspaces that is the call before the previous one (the older event of the ring); a caller that
       // hands over the previous call's workspace again waits for that call instead (correct, and no overlap)
@@ -821,7 +827,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       // (The concurrent mode needs that LDS for the analysis workgroups beside the walk; its idle-start gate does this job.)
       static const bool no_excl = spx_tuning_env("SPX_NO_EXCLUSIVE_CU") != nullptr;   // A/B
       const int total = force ? force->total_streams : n;
-      const size_t lds_min = (!concurrent && !ahead && !no_excl && nch == 1 && total <= cu_count) ? lds_per_cu / 2 + 1024 : 0;
+      const size_t lds_min = (!concurrent && (!ahead || ahead_forced) && !no_excl && nch == 1 && total <= cu_count) ? lds_per_cu / 2 + 1024 : 0;
       // (AHEAD: the counts are all published by the time the kernel starts -- its one poll returns at once -- and its
       // workgroups count themselves in for the next call's gate)
       spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, ((concurrent && !diag_nowait) || ahead) ? d_ready : nullptr,
@@ -844,7 +850,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     // AHEAD: the analysis must not fill the CUs before the PREVIOUS call's walk workgroups have been placed one per CU (its
     // walk kernel becomes runnable at the same moment as this analysis: when the walk before it retires)
     // (only while that call is still in flight: then its workspace, where the counter lives, is alive by the usual contract)
-    if (ahead && plan->ahead_started != nullptr && plan->ahead_n > 0 && !no_gate) {
+    if (ahead && !force && plan->ahead_started != nullptr && plan->ahead_n > 0 && !no_gate) {
       const int prev = (plan->ahead_calls & 1) ^ 1;
       const bool in_flight = plan->ev_walk_valid[prev] && hipEventQuery(plan->ev_walk[prev]) == hipErrorNotReady;
       (void)hipGetLastError();
@@ -875,6 +881,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
         HIPCHK(hipStreamWaitEvent(st, plan->ev_tension, 0));
       }
       launch_walk();
+      if (ahead_forced && force->started_out) *force->started_out = d_ready + n;
       if (c == nch - 1 && !force) {
         // every call of the plan that walks leaves its event in the ring (a pipelined call orders its producers behind the
         // walk kernels of the two calls before it, pipelined or not)
@@ -976,13 +983,28 @@ size_t spx_batch_workspace_bytes_mixed(const spx_plan_t* plans, int n_plans, con
   if (!plans || n_plans < 1 || !jobs || n_streams < 1 || mixed_groups(n_plans, jobs, plan_index, n_streams, gj, gi)) return 0;
   return mixed_layout(plans, n_plans, gj, n_streams).total;
 }
+static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
+                      const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps,
+                      void* hs, bool ahead_req);
 int spx_batch_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
                         const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, void* hs) {
-  return spx_batch_run_mixed_taps(plans, n_plans, jobs, plan_index, n, in, out, n_out, ws, ws_bytes, nullptr, hs);
+  return mixed_impl(plans, n_plans, jobs, plan_index, n, in, out, n_out, ws, ws_bytes, nullptr, hs, false);
 }
 int spx_batch_run_mixed_taps(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
                              const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps,
                              void* hs) {
+  return mixed_impl(plans, n_plans, jobs, plan_index, n, in, out, n_out, ws, ws_bytes, taps, hs, false);
+}
+// spx_batch_run_ahead for a mixed-rate batch: consecutive calls (two workspaces taking turns, one HIP stream, the same lead
+// plan) pipelined -- every group's staging, analysis and tension kernels on the device's first side stream at once, beside the
+// previous call's walk kernels; the groups' walk kernels on their streams as in a plain call, each behind its tension kernel.
+int spx_batch_run_mixed_ahead(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
+                              const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, void* hs) {
+  return mixed_impl(plans, n_plans, jobs, plan_index, n, in, out, n_out, ws, ws_bytes, nullptr, hs, true);
+}
+static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
+                      const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps,
+                      void* hs, bool ahead_req) {
   if (!plans || n_plans < 1 || n_plans > 8 || !jobs || n <= 0) return fail(-1, "spx_batch_run_mixed: bad arguments");
   SpxRange range_("spx_batch_run_mixed");
   std::vector<std::vector<spx_stream_job>> gj;
@@ -1042,7 +1064,10 @@ int spx_batch_run_mixed_taps(const spx_plan_t* plans, int n_plans, const spx_str
   // ---- the device guard, once for the whole call ----
   SpxDevGuard& guard = g_guard[(lead->device >= 0 && lead->device < 64) ? lead->device : 0];
   std::unique_lock<std::mutex> guard_lock(guard.mu, std::defer_lock);
-  SpxForce force = {0, false, n, nullptr};
+  SpxForce force = {0, false, n, nullptr, nullptr, nullptr};
+  // pipelined with the previous call (spx_batch_run_mixed_ahead): kernels in sequence, one stream per CU at most
+  const bool ahead = ahead_req && !concurrent && g_concurrent.load() && !env_serial && groups > 0 && n <= lead->cu_count &&
+                     device_is_ours(lead->device);
   if (concurrent) {
     guard_lock.lock();
     const hipError_t q = guard.valid ? hipEventQuery(guard.last) : hipSuccess;
@@ -1112,7 +1137,23 @@ int spx_batch_run_mixed_taps(const spx_plan_t* plans, int n_plans, const spx_str
   // after the other: with a stream per plan, the configs[4] shard took 4.95 instead of 3.0 ms in every process that had run
   // a concurrent-mode call before (its two side streams had taken queues; profiles/r04/r04c_c4_prefix.txt).
   hipStream_t dev_s1 = nullptr, dev_s2 = nullptr;
-  if (!concurrent && ord.size() > 1 && dev_side_streams(lead->device, &dev_s1, &dev_s2)) return fail(-1, "spx_batch_run_mixed: no side streams");
+  if (!concurrent && (ord.size() > 1 || ahead) && dev_side_streams(lead->device, &dev_s1, &dev_s2)) return fail(-1, "spx_batch_run_mixed: no side streams");
+  std::vector<const int*> started(n_plans, nullptr);
+  if (ahead) {
+    // the producers' stream: behind the walk kernels of the lead plan's call before the previous one (the last user of this
+    // workspace when two take turns; the previous call too if it used this workspace or another stream), and -- while the
+    // previous call is still in flight -- behind gate kernels that wait until its walk workgroups have been placed
+    std::lock_guard<std::mutex> ring_lock(lead->mu);
+    const int cur = lead->ahead_calls & 1;
+    if ((ws == lead->ahead_last_ws || st != lead->ahead_last_stream) && lead->ev_walk_valid[cur ^ 1])
+      HIPCHK(hipStreamWaitEvent(dev_s1, lead->ev_walk[cur ^ 1], 0));
+    if (lead->ev_walk_valid[cur]) HIPCHK(hipStreamWaitEvent(dev_s1, lead->ev_walk[cur], 0));
+    const bool in_flight = lead->ev_walk_valid[cur ^ 1] && hipEventQuery(lead->ev_walk[cur ^ 1]) == hipErrorNotReady;
+    (void)hipGetLastError();
+    if (in_flight)
+      for (const auto& sn : lead->mixed_started)
+        if (sn.first && sn.second > 0) hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, dev_s1, sn.first, sn.second, 1200u);
+  }
   hipEvent_t prev_an = nullptr;
   int launch_idx = 0;
   for (int g : ord) {
@@ -1129,7 +1170,10 @@ int spx_batch_run_mixed_taps(const spx_plan_t* plans, int n_plans, const spx_str
     if (!p->ev_an) HIPCHK(hipEventCreateWithFlags(&p->ev_an, hipEventDisableTiming));
     if (gs != st) HIPCHK(hipStreamWaitEvent(gs, lead->ev_fork, 0));
     SpxForce f = force;
-    if (chain_analyses) {
+    if (ahead) {
+      f.ahead_sa = dev_s1;            // (the analyses follow one another on that stream by themselves, cheapest first)
+      f.started_out = &started[g];
+    } else if (chain_analyses) {
       if (prev_an) HIPCHK(hipStreamWaitEvent(gs, prev_an, 0));
       f.after_analysis = p->ev_an;
       prev_an = p->ev_an;
@@ -1147,6 +1191,23 @@ int spx_batch_run_mixed_taps(const spx_plan_t* plans, int n_plans, const spx_str
     if (rc) return fail(rc, err);
   }
   hipLaunchKernelGGL(spx_scatter_nout_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_nout, d_idx, n, n_out);
+  {
+    // every mixed call leaves its end in the lead plan's ring (a pipelined call orders its producers behind the two calls before it)
+    std::lock_guard<std::mutex> ring_lock(lead->mu);
+    const int cur = lead->ahead_calls & 1;
+    if (!lead->ev_walk[cur]) HIPCHK(hipEventCreateWithFlags(&lead->ev_walk[cur], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(lead->ev_walk[cur], st));
+    lead->ev_walk_valid[cur] = true;
+    lead->ahead_calls++;
+    lead->ahead_last_ws = ws;
+    lead->ahead_last_stream = st;
+    lead->ahead_started = nullptr;
+    lead->ahead_n = 0;
+    lead->mixed_started.clear();
+    if (ahead)
+      for (int g = 0; g < n_plans; g++)
+        if (started[g]) lead->mixed_started.emplace_back(started[g], (int)gj[g].size());
+  }
   if (concurrent) {
     if (!guard.last) HIPCHK(hipEventCreateWithFlags(&guard.last, hipEventDisableTiming));
     HIPCHK(hipEventRecord(guard.last, st));
