@@ -191,19 +191,38 @@ def time_window(run, reps, warm):
     return (time.perf_counter() - t0) / reps
 
 
-def config4_leg(ids, reps, warm=4):
+def config4_leg(ids, reps, warm=4, pipeline=True):
     """The global configs[4] streams `ids` in ONE spx_batch_run_mixed call per step, inputs resident in HBM.
     Returns dict(seconds per step, input frames, streams, crcs, algorithmic bytes, kernel names)."""
     from speedy_amd import config4 as C4
     from speedy_amd.batch import Plan
+    import torch
     streams = C4.make_streams(ids, threads=max(1, min(16, usable_cpus()[0])))
     plans = [Plan(r, False) for r in C4.RATES]
     b = C4.mixed_batch(plans, ids, streams)
-    dt = time_window(b.run, reps, warm)
+    dt_plain = time_window(b.run, reps, warm)
     counts = b.counts()
     crcs = b.crcs()
     steps = b.step_counts()
-    return {"dt": dt, "frames": C4.input_frames(ids), "streams": streams, "crcs": crcs,
+    dt = dt_plain
+    pipelined = False
+    if pipeline and len(ids) <= torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count:
+        # consecutive steps software-pipelined (spx_batch_run_mixed_ahead): two batches with the same resident input take turns
+        b2 = C4.mixed_batch(plans, ids, streams)
+        turn = [b, b2]
+        b.d_out.zero_()
+        for k in range(warm):
+            turn[k % 2].run_ahead()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(reps):
+            turn[(warm + k) % 2].run_ahead()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        assert b.crcs() == crcs and b2.crcs() == crcs, "the pipelined mixed calls changed the output"
+        pipelined = True
+        del b2
+    return {"dt": dt, "dt_plain": dt_plain, "pipelined": pipelined, "frames": C4.input_frames(ids), "streams": streams, "crcs": crcs,
             "algo_bytes": C4.algorithmic_bytes(ids, counts), "steps": steps, "out_frames": int(counts.sum())}
 
 
@@ -558,16 +577,20 @@ def main():
         from speedy_amd import config4 as C4
         barrier()
         ids = list(range(256 * rank, 256 * (rank + 1)))
-        leg = config4_leg(ids, reps=10)
+        leg = config4_leg(ids, reps=10, pipeline=not args.no_pipeline)
         dt4 = max_over_ranks(leg["dt"])
         frames4 = sum_over_ranks(leg["frames"])
         c4 = {"value": frames4 / dt4 / 1e6, "unit": "Msamples/s", "ms_per_step": dt4 * 1e3, "streams_per_gpu": 256,
               "hbm_frac": sum_over_ranks(leg["algo_bytes"]) / dt4 / 1e9 / (HBM_PEAK_GBS * world),
               "chain_steps_max": int(leg["steps"].max()),
+              "pipelined": leg["pipelined"],
+              "unpipelined_ms_per_step": max_over_ranks(leg["dt_plain"]) * 1e3,
               "note": "BASELINE configs[4], WEAK: every rank its shard of 256 streams x 10 s (global stream i: 16 kHz if i even else "
                       "22.05 kHz; mono if (i/2) even else stereo; speed 1.5 if (i/4) even else 3.5; nonlinear 1; 2 048 distinct signals, "
-                      "seed 4000 + i), ONE spx_batch_run_mixed call per step, inputs resident in HBM, MAX over ranks; input sample "
-                      "frames of all ranks / that time"}
+                      "seed 4000 + i), ONE spx_batch_run_mixed[_ahead] call per step, inputs resident in HBM, MAX over ranks; input sample "
+                      "frames of all ranks / that time.  Pipelined like `value`: two batches with the same input take turns, a step's "
+                      "analysis and tension kernels run beside the previous step's walk kernels; `unpipelined_ms_per_step` is "
+                      "spx_batch_run_mixed on one batch, call after call"}
         c4_checks["config4_shard"] = (leg["streams"], ids, leg["crcs"])
         c4_crc_dump.update({str(i): c for i, c in zip(ids, leg["crcs"])})
         if not args.no_config4_full:
@@ -578,11 +601,12 @@ def main():
                 legf = leg
             else:
                 del leg
-                legf = config4_leg(ids_f, reps=6, warm=4)
+                legf = config4_leg(ids_f, reps=6, warm=4, pipeline=not args.no_pipeline)
             dtf = max_over_ranks(legf["dt"])
             frames_f = sum_over_ranks(legf["frames"])
             c4f = {"value": frames_f / dtf / 1e6, "unit": "Msamples/s", "ms_per_step": dtf * 1e3, "total_streams": total,
-                   "streams_per_gpu": len(ids_f), "scaling": "strong",
+                   "streams_per_gpu": len(ids_f), "scaling": "strong", "pipelined": legf["pipelined"],
+                   "unpipelined_ms_per_step": max_over_ranks(legf["dt_plain"]) * 1e3,
                    "hbm_frac": sum_over_ranks(legf["algo_bytes"]) / dtf / 1e9 / (HBM_PEAK_GBS * world),
                    "note": "BASELINE configs[4] as a whole, STRONG scaling: the fixed batch of %d mixed streams x 10 s (same global "
                            "sequence as config4_shard), rank r of N takes the contiguous block r (stream i -> GPU i / (%d / N)), ONE "

@@ -191,3 +191,53 @@ def test_pipelined_calls_are_faster_than_plain_ones():
     torch.cuda.synchronize()
     ahead = (time.perf_counter() - t0) / 12
     assert ahead < 0.97 * plain, (ahead, plain)
+
+
+def test_mixed_rate_calls_pipelined(orc):
+    """spx_batch_run_mixed_ahead: three mixed-rate batches of different content (16 / 22.05 / 8 kHz, mono and stereo, two speeds,
+    ragged lengths) take turns on rings of three and two workspaces, with a plain mixed call and a call of more streams than the
+    device has CUs in between; every pass must give what spx_batch_run_mixed gives for the batch, and a sample of the streams is
+    checked against the oracle."""
+    import torch
+    from speedy_amd.batch import MixedBatch, Plan
+    from speedy_amd.synth import speech_like
+    rates = [16000, 22050, 8000]
+    plans = [Plan(r, False) for r in rates]
+
+    def make(seed, n):
+        rng = np.random.default_rng(seed)
+        pidx = [int(rng.integers(0, 3)) for _ in range(n)]
+        chs = [int(rng.choice([1, 1, 2])) for _ in range(n)]
+        speeds = [float(rng.choice([1.5, 3.5])) for _ in range(n)]
+        lens = [int(rates[pidx[i]] * rng.uniform(0.2, 0.9)) for i in range(n)]
+        xs = [speech_like(lens[i], rates[pidx[i]], seed=seed * 1000 + (i % 16), channels=chs[i]) for i in range(n)]
+        b = MixedBatch(plans, pidx, lens, chs, speeds, 1.0, 0.0)
+        b.upload(xs)
+        b.run()
+        want = b.crcs()
+        res = b.results()
+        for i in (0, n // 3, n - 1):
+            ref = orc.compress_sound(xs[i], rates[pidx[i]], chs[i], speeds[i], 1.0, 0.0, False, chunk=1000)
+            assert np.array_equal(res[i], ref["out"]), (seed, i)
+        b.d_out.zero_()
+        return b, want
+
+    bs = [make(51, 200), make(52, 256), make(53, 77)]
+    big = make(54, 700)
+    torch.cuda.synchronize()
+    for ring in (3, 2):
+        for t in range(10):
+            k = t % ring
+            if t == 4:
+                bs[k][0].run()
+            elif t == 7:
+                big[0].run_ahead()          # more streams than CUs: runs as a plain call would, between two pipelined ones
+                bs[k][0].run_ahead()
+            else:
+                bs[k][0].run_ahead()
+        torch.cuda.synchronize()
+        for k in range(ring):
+            assert bs[k][0].crcs() == bs[k][1], (ring, k)
+            bs[k][0].d_out.zero_()
+        assert big[0].crcs() == big[1]
+        big[0].d_out.zero_()
