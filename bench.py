@@ -389,6 +389,7 @@ def main():
                     help="configs[4] as a whole: the fixed batch of this many mixed streams, N ranks take 1/N each (strong "
                          "scaling; N = 1 runs all of it in one call); reported as config4_full")
     ap.add_argument("--no-pipeline", action="store_true", help="time spx_batch_run on ONE batch, call after call (no software pipelining of consecutive steps)")
+    ap.add_argument("--no-unpipelined", action="store_true", help="skip the window of plain spx_batch_run calls behind `unpipelined` (profiling runs)")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the 2 048-stream call of the headline kind")
     ap.add_argument("--no-other-rates", action="store_true", help="skip the 44.1 kHz mono / 48 kHz stereo calls (widening row; N = 1 only)")
     ap.add_argument("--no-api", action="store_true", help="skip the many-handle run of the drop-in API (tools/stream_bench.c)")
@@ -494,7 +495,8 @@ def main():
         q = turn[k % len(turn)]
         q.run_ahead() if b2 is not None else q.run()
 
-    dt_single = time_window(b.run, reps=max(5, args.steps), warm=max(3, args.warmup))   # the unpipelined figure (also warms up)
+    # the unpipelined figure (also warms up); --no-unpipelined: profiling runs, whose per-kernel averages should be the timed loop's
+    dt_single = None if args.no_unpipelined else time_window(b.run, reps=max(5, args.steps), warm=max(3, args.warmup))
     for k in range(args.warmup):
         step(k)
     barrier()
@@ -517,7 +519,8 @@ def main():
         del outs2
     n_out = int(sum(o.size for o in outs))
     chain_steps = b.step_counts()         # pitch searches per stream: the length of every stream's dependent chain
-    dt_single = max_over_ranks(dt_single)
+    if dt_single is not None:
+        dt_single = max_over_ranks(dt_single)
     if args.crc_out:
         with open("%s.rank%d.json" % (args.crc_out, rank), "w") as f:
             json.dump([zlib.crc32(np.ascontiguousarray(o).tobytes()) for o in outs], f)
@@ -680,7 +683,8 @@ def main():
                                    "batch, call after call (what rounds 1-4 reported as `value`)" if b2 is not None else
                                    "spx_batch_run on one batch, call after call (--no-pipeline)"),
             "pipelined": b2 is not None,
-            "unpipelined": {"ms_per_step": dt_single * 1e3, "value": n_in * world / dt_single / 1e6, "unit": "Msamples/s",
+            "unpipelined": None if dt_single is None else
+                           {"ms_per_step": dt_single * 1e3, "value": n_in * world / dt_single / 1e6, "unit": "Msamples/s",
                             "note": "spx_batch_run on ONE batch, call after call (its three kernels side by side, the walk "
                                     "waiting for its first speeds at the start of every call); MAX over ranks"},
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",

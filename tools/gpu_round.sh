@@ -15,7 +15,7 @@ fi
 timeout 600 python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"; cat "$OUT/${TAG}_bench.json"
 timeout 600 python3 bench.py --gpus 2 --backend gloo --no-cpu-baseline --no-api --no-config4 > "$OUT/${TAG}_bench_2rank_1gpu.json" 2> "$OUT/${TAG}_bench_2rank.err"
 cat "$OUT/${TAG}_bench_2rank_1gpu.json"
-timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_stats" -o stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch --no-other-rates \
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_stats" -o stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch --no-other-rates --no-unpipelined \
   > "$OUT/${TAG}_stats.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c -d "$OUT/${TAG}_pmc_$c" -o pmc --output-format csv -- python3 bench.py --serial --steps 3 --warmup 1 \
