@@ -375,6 +375,7 @@ void spx_plan_destroy(spx_plan_t plan) {
   if (plan->ev_start) (void)hipEventDestroy(plan->ev_start);
   for (auto& e : plan->ev_chunk) if (e) (void)hipEventDestroy(e);
   for (auto& e : plan->trial.ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : plan->ev_walk) if (e) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); }
   for (auto& g : plan->stage) {
     if (g.done) { (void)hipEventSynchronize(g.done); (void)hipEventDestroy(g.done); }
     if (g.p) (void)hipHostFree(g.p);
