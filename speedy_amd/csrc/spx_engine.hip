@@ -685,8 +685,10 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // consumer polls a producer (nothing to deadlock, no guard), and no walk waits for its first frames.  Same shapes as the
   // concurrent mode (one stream per CU, two analysis workgroups beside a stream's walk and tension workgroups).
   const bool ahead_forced = force && force->ahead_sa != nullptr && do_a && do_w;   // a group of spx_batch_run_mixed_ahead
+  static const bool ahead_any = spx_tuning_env("SPX_AHEAD_ANY") != nullptr;   // tuning: the pipelined order whatever the co-residency arithmetic says
   const bool ahead = ahead_forced ||
-                     (ahead_req && want_concurrent && !doubtful && !force && trial_slot < 0 && (!g_chunks_set.load() || g_chunks.load() == 1));
+                     (ahead_req && (want_concurrent || (ahead_any && do_a && do_w && n <= cu_count && g_concurrent.load())) && !doubtful && !force &&
+                      trial_slot < 0 && (!g_chunks_set.load() || g_chunks.load() == 1));
   if (ahead) want_concurrent = false;
   // another concurrent-mode call still in flight on this device, on a different stream?  Then this one runs its kernels
   // in sequence (SpxDevGuard above); the guard stays locked until this call has left its own event behind.
