@@ -1,5 +1,5 @@
 #!/bin/bash
-# full GPU suite + bench (+ optional tag)
+# full GPU suite + the default bench line (+ optional tag):  gpurun -- bash tools/full_gpu.sh TAG
 TAG=${1:-r04x}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
