@@ -507,6 +507,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     L.spx_set_timing(0)
+    # what the library did with the last timed call: 2 = pipelined with its predecessor, 1 = its three kernels side by side, 0 = in
+    # sequence (ranks sharing a GPU, --serial ...)
+    last_mode = int(L.spx_debug_last_call_concurrent())
     sa, sw, nc = C.c_double(0), C.c_double(0), C.c_int(0)
     L.spx_timing_collect(C.byref(sa), C.byref(sw), C.byref(nc))
     ms_tension = float(L.spx_timing_last_tension_ms()) / max(1, nc.value)
@@ -682,7 +685,9 @@ def main():
                                    "kernel; every step is the whole hot path over one batch.  `unpipelined` is spx_batch_run on one "
                                    "batch, call after call (what rounds 1-4 reported as `value`)" if b2 is not None else
                                    "spx_batch_run on one batch, call after call (--no-pipeline)"),
-            "pipelined": b2 is not None,
+            "pipelined": b2 is not None and last_mode == 2,
+            "launch_mode_of_the_timed_calls": {2: "pipelined with the previous call (spx_batch_run_ahead)", 1: "three kernels side by side",
+                                               0: "kernels in sequence"}.get(last_mode, str(last_mode)),
             "unpipelined": None if dt_single is None else
                            {"ms_per_step": dt_single * 1e3, "value": n_in * world / dt_single / 1e6, "unit": "Msamples/s",
                             "note": "spx_batch_run on ONE batch, call after call (its three kernels side by side, the walk "
