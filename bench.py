@@ -330,9 +330,10 @@ def pcie_pipeline(plan, streams, n, reps, warm=2):
             s_run.wait_event(ev_in[i])
             if k >= 2:
                 s_run.wait_event(ev_out[i])       # the output of batch k-2 has left this buffer
-            # (spx_batch_run_ahead_when with ev_in as its input event was tried here: 2.26 ms per batch at best and 3-4.5 in a third of
-            # the runs, with 4, 8 or 16 hardware queues, against a steady 2.0: the transfers' own stream operations sit between the
-            # pipelined calls)
+            # (spx_batch_run_ahead_when with ev_in as its input event was tried here: a steady 2.35 ms per batch against 2.0 -- the
+            # transfers' own stream operations sit between the pipelined calls; with the gate kernel's first, shorter bound a third of
+            # the runs read 3-4.5 ms: the previous walk kernel waits for its output buffer here, the gate gave up, and the analysis
+            # took the CUs first)
             bs[i].run(stream=s_run)
             packed[i], d_offs = bs[i].pack_outputs(stream=s_run)
             h_offs[i].copy_(d_offs, non_blocking=True)

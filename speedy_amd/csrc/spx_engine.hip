@@ -857,7 +857,10 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       const int prev = (plan->ahead_calls & 1) ^ 1;
       const bool in_flight = plan->ev_walk_valid[prev] && hipEventQuery(plan->ev_walk[prev]) == hipErrorNotReady;
       (void)hipGetLastError();
-      if (in_flight) hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, sa, plan->ahead_started, plan->ahead_n, gate_spins);
+      // (a longer bound than the idle-start gate's: the previous walk kernel may itself be waiting for something of the
+      // caller's -- an output buffer still being copied out -- and a gate that gives up early lets this call's analysis fill the
+      // CUs first, which costs the previous call half its speed; ~2 ms)
+      if (in_flight) hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, sa, plan->ahead_started, plan->ahead_n, 8000u);
     }
     if (do_a && tiles[c] > 0) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1155,7 +1158,7 @@ static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job
     (void)hipGetLastError();
     if (in_flight)
       for (const auto& sn : lead->mixed_started)
-        if (sn.first && sn.second > 0) hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, dev_s1, sn.first, sn.second, 1200u);
+        if (sn.first && sn.second > 0) hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, dev_s1, sn.first, sn.second, 8000u);
   }
   hipEvent_t prev_an = nullptr;
   int launch_idx = 0;
