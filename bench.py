@@ -283,14 +283,23 @@ def spawn_ranks(args):
     sys.exit(rc)
 
 
-def pcie_pipeline(plan, streams, n, reps, warm=2):
+def pcie_pipeline(plan, streams, n, reps, warm=3, nbuf=None, ahead=None):
     """PCIe-inclusive steady state (SURVEY.md 8d "first write to last drained read"): pinned host input -> HBM, the step,
-    a device-side gather of the produced frames, one copy to pinned host memory -- double-buffered on three HIP
-    streams, so that the H2D of batch k+1 and the D2H of batch k-1 overlap the step of batch k.
+    a device-side gather of the produced frames, one copy to pinned host memory -- `nbuf` sets of device buffers on three HIP
+    streams, so that the H2D of later batches and the D2H of earlier ones overlap the step of batch k.
+    ahead (environment SPX_BENCH_PCIE=ahead; NOT the default): consecutive steps software-pipelined by the library
+    (spx_batch_run_ahead_when with the H2D's event) on three sets of buffers.  Measured: 2.35 ms per batch with two sets (the
+    copy-in of batch k + 1 can only start when step k - 1 has finished with its buffer, so the analysis behind it comes too late
+    to run beside step k) and 2.3-3.5 with three (this loop waits on the host for step k - 1 before it issues batch k + 1)
+    against a steady 2.0-2.1 for plain calls on two sets: the default.
     Returns seconds per batch."""
     import torch
     from speedy_amd.batch import Batch
-    bs = [Batch(plan, [n] * len(streams), 1, SPEED, 1.0, 0.0) for _ in range(2)]
+    if ahead is None:
+        ahead = os.environ.get("SPX_BENCH_PCIE", "plain") == "ahead"
+    if nbuf is None:
+        nbuf = 3 if ahead else 2
+    bs = [Batch(plan, [n] * len(streams), 1, SPEED, 1.0, 0.0) for _ in range(nbuf)]
     h_in = torch.empty(bs[0].d_in.numel(), dtype=torch.int16).pin_memory()
     h_in.zero_()
     off = 0
@@ -303,12 +312,12 @@ def pcie_pipeline(plan, streams, n, reps, warm=2):
     ev_in = [torch.cuda.Event() for _ in bs]
     ev_done = [torch.cuda.Event() for _ in bs]
     ev_out = [torch.cuda.Event() for _ in bs]
-    packed = [None, None]
+    packed = [None] * nbuf
     totals = []
     t0 = 0.0
 
     def drain(k):  # output of batch k: wait for its step (long finished in steady state), then one D2H of the exact size
-        i = k % 2
+        i = k % nbuf
         ev_done[i].synchronize()
         total = int(h_offs[i][-1])
         totals.append(total)
@@ -320,21 +329,20 @@ def pcie_pipeline(plan, streams, n, reps, warm=2):
         if k == warm:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        i = k % 2
+        i = k % nbuf
         with torch.cuda.stream(s_h2d):
-            if k >= 2:
-                s_h2d.wait_event(ev_done[i])      # the step of batch k-2 has finished reading this input buffer
+            if k >= nbuf:
+                s_h2d.wait_event(ev_done[i])      # the step of batch k - nbuf has finished reading this input buffer
             bs[i].d_in.copy_(h_in, non_blocking=True)
             ev_in[i].record(s_h2d)
         with torch.cuda.stream(s_run):
-            s_run.wait_event(ev_in[i])
-            if k >= 2:
-                s_run.wait_event(ev_out[i])       # the output of batch k-2 has left this buffer
-            # (spx_batch_run_ahead_when with ev_in as its input event was tried here: a steady 2.35 ms per batch against 2.0 -- the
-            # transfers' own stream operations sit between the pipelined calls; with the gate kernel's first, shorter bound a third of
-            # the runs read 3-4.5 ms: the previous walk kernel waits for its output buffer here, the gate gave up, and the analysis
-            # took the CUs first)
-            bs[i].run(stream=s_run)
+            if k >= nbuf:
+                s_run.wait_event(ev_out[i])       # the output of batch k - nbuf has left this buffer
+            if ahead:
+                bs[i].run_ahead(stream=s_run, in_ready=ev_in[i])   # (its producers wait for the copy-in themselves)
+            else:
+                s_run.wait_event(ev_in[i])
+                bs[i].run(stream=s_run)
             packed[i], d_offs = bs[i].pack_outputs(stream=s_run)
             h_offs[i].copy_(d_offs, non_blocking=True)
             ev_done[i].record(s_run)
@@ -343,7 +351,7 @@ def pcie_pipeline(plan, streams, n, reps, warm=2):
     drain(warm + reps - 1)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    last = (warm + reps - 1) % 2      # what arrived in host memory is what the device packed (outside the timed region)
+    last = (warm + reps - 1) % nbuf   # what arrived in host memory is what the device packed (outside the timed region)
     assert torch.equal(h_out[last][:totals[-1]], packed[last][:totals[-1]].cpu()), "PCIe pipeline: host copy differs"
     return dt, totals[-1]
 
