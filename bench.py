@@ -39,6 +39,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HIP maps streams onto four hardware queues by default, and a queue runs its kernels in order.  The PCIe leg drives three
+# streams of its own beside the library's two side streams: with four queues two of the five share one, and which two depends on
+# the order of creation -- 2 of 8 runs of this file read 3.4-3.8 ms per batch there instead of 2.05 (profiles/r04/r05u_hw_queues.txt).
+# Eight queues give every stream its own; nothing else in the line moves.  (Read by the HIP runtime at its first call: set here,
+# before torch is imported; an application with copy streams of its own beside this library should do the same, INTEGRATION.md.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 RATE, SECONDS, STREAMS_PER_GPU, SPEED = 16000, 10, 256, 3.5
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # fp64 vector operations/s without FMA: 39.3 (see `peak_source` in the line)
@@ -298,7 +305,8 @@ def pcie_pipeline(plan, streams, n, reps, warm=3, nbuf=None, ahead=None):
     if ahead is None:
         ahead = os.environ.get("SPX_BENCH_PCIE", "plain") == "ahead"
     if nbuf is None:
-        nbuf = 3 if ahead else 2
+        nbuf = int(os.environ.get("SPX_BENCH_PCIE_NBUF", "4" if ahead else "2"))
+    lag = int(os.environ.get("SPX_BENCH_PCIE_LAG", "2" if ahead else "1"))   # the host drains batch k - lag after issuing batch k
     bs = [Batch(plan, [n] * len(streams), 1, SPEED, 1.0, 0.0) for _ in range(nbuf)]
     h_in = torch.empty(bs[0].d_in.numel(), dtype=torch.int16).pin_memory()
     h_in.zero_()
@@ -346,9 +354,10 @@ def pcie_pipeline(plan, streams, n, reps, warm=3, nbuf=None, ahead=None):
             packed[i], d_offs = bs[i].pack_outputs(stream=s_run)
             h_offs[i].copy_(d_offs, non_blocking=True)
             ev_done[i].record(s_run)
-        if k >= 1:
-            drain(k - 1)
-    drain(warm + reps - 1)
+        if k >= lag:
+            drain(k - lag)
+    for k in range(max(0, warm + reps - lag), warm + reps):
+        drain(k)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     last = (warm + reps - 1) % nbuf   # what arrived in host memory is what the device packed (outside the timed region)
