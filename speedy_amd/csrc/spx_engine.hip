@@ -685,8 +685,21 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // consumer polls a producer (nothing to deadlock, no guard), and no walk waits for its first frames.  Same shapes as the
   // concurrent mode (one stream per CU, two analysis workgroups beside a stream's walk and tension workgroups).
   const bool ahead_forced = force && force->ahead_sa != nullptr && do_a && do_w;   // a group of spx_batch_run_mixed_ahead
+  // ... and a batch whose kernels run in sequence (no two analysis workgroups beside a stream's own, e.g. 22.05 kHz stereo)
+  // can still be pipelined with its predecessor if ONE analysis workgroup fits beside a walk workgroup that asks for a CU of
+  // its own (LDS) and one analysis wave beside its waves (registers): the walk kernels keep their exclusive placement, the next
+  // call's analysis fills what they leave -- the order the groups of a pipelined mixed call run in
+  bool seq_ahead = false;
+  if (ahead_req && !want_concurrent && !force && do_a && do_w && n <= cu_count && g_concurrent.load() && !env_serial && trial_slot < 0 &&
+      (!g_chunks_set.load() || g_chunks.load() == 1)) {
+    SpxPlanDev dd = plan->dev;   // (the default tile: no co-residency tile games in this order)
+    const size_t walk_lds = std::max(wcfg.lds, lds_per_cu / 2 + 1024);
+    const int walk_regs = ((wcfg.waves + 3) / 4) * spx_walk_vgprs(d, n, maxC, speedup_only, false);
+    seq_ahead = walk_lds + spx_tension_lds_bytes() + spx_analysis_lds_bytes(dd) <= lds_usable &&
+                walk_regs + spx_tension_vgprs() + spx_analysis_vgprs(dd) <= 512 && !lean_walk && device_is_ours(plan->device);
+  }
   static const bool ahead_any = spx_tuning_env("SPX_AHEAD_ANY") != nullptr;   // tuning: the pipelined order whatever the co-residency arithmetic says
-  const bool ahead = ahead_forced ||
+  const bool ahead = ahead_forced || seq_ahead ||
                      (ahead_req && (want_concurrent || (ahead_any && do_a && do_w && n <= cu_count && g_concurrent.load())) && !doubtful && !force &&
                       trial_slot < 0 && (!g_chunks_set.load() || g_chunks.load() == 1));
   if (ahead) want_concurrent = false;
@@ -703,7 +716,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     (void)hipGetLastError();  // hipErrorNotReady is not an error of this call
     if (!want_concurrent) guard_lock.unlock();
   }
-  if (!want_concurrent && !ahead) d.tile_frames = plan->dev.tile_frames;  // no concurrency: default tile
+  if (!want_concurrent && (!ahead || seq_ahead)) d.tile_frames = plan->dev.tile_frames;  // no concurrency: default tile
   // Pipelining in time needs both stages in one call; the separate entry points run one chunk.  A batch too large for
   // the concurrent mode gets four time chunks unless the caller chose a count: the analysis of chunk c+1 then overlaps
   // the walk of chunk c through ordinary stream ordering (measured at 512 / 1024 streams x 10 s: 5.32 -> 4.76 ms and
@@ -830,7 +843,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       // (The concurrent mode needs that LDS for the analysis workgroups beside the walk; its idle-start gate does this job.)
       static const bool no_excl = spx_tuning_env("SPX_NO_EXCLUSIVE_CU") != nullptr;   // A/B
       const int total = force ? force->total_streams : n;
-      const size_t lds_min = (!concurrent && (!ahead || ahead_forced) && !no_excl && nch == 1 && total <= cu_count) ? lds_per_cu / 2 + 1024 : 0;
+      const size_t lds_min = (!concurrent && (!ahead || ahead_forced || seq_ahead) && !no_excl && nch == 1 && total <= cu_count) ? lds_per_cu / 2 + 1024 : 0;
       // (AHEAD: the counts are all published by the time the kernel starts -- its one poll returns at once -- and its
       // workgroups count themselves in for the next call's gate)
       spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, ((concurrent && !diag_nowait) || ahead) ? d_ready : nullptr,

@@ -38,7 +38,22 @@ for rate, ch, speed, nl in [(16000, 1, 3.5, 1.0), (16000, 1, 1.5, 1.0), (22050, 
     import ctypes as C
     sa, sw, nc = C.c_double(0), C.c_double(0), C.c_int(0)
     plan.L.spx_timing_collect(C.byref(sa), C.byref(sw), C.byref(nc))
-    print("rate=%5d ch=%d speed=%.1f nl=%.0f  %.3f ms/call  %.0f Msamples/s (frames)   analysis %.2f walk %.2f ms" %
-          (rate, ch, speed, nl, dt * 1e3, ns * n / dt / 1e6, sa.value / reps, sw.value / reps))
-    del b
+    # the same kind with consecutive calls pipelined (spx_batch_run_ahead, two batches taking turns); the library takes the mode
+    # for the shapes of its concurrent mode and runs every other call as the plain one
+    b2 = Batch(plan, [n] * ns, ch, speed, nl, 0.0)
+    b2.d_in.copy_(b.d_in)
+    turn = [b, b2]
+    for k in range(4):
+        turn[k % 2].run_ahead()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(8):
+        turn[k % 2].run_ahead()
+    torch.cuda.synchronize()
+    dta = (time.perf_counter() - t0) / 8
+    mode = plan.L.spx_debug_last_call_concurrent()
+    print("rate=%5d ch=%d speed=%.1f nl=%.0f  %.3f ms/call  %.0f Msamples/s (frames)   analysis %.2f walk %.2f ms   | calls pipelined: %.3f ms  %.0f Msamples/s%s" %
+          (rate, ch, speed, nl, dt * 1e3, ns * n / dt / 1e6, sa.value / reps, sw.value / reps, dta * 1e3, ns * n / dta / 1e6,
+           "" if mode == 2 else "  (mode not taken)"))
+    del b, b2
     torch.cuda.empty_cache()
