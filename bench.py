@@ -402,6 +402,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true")
+    ap.add_argument("--pcie-child", type=str, default=None, metavar="DEV,RANK,REPS",
+                    help="internal: run ONLY the PCIe-inclusive pipeline on device DEV with rank RANK's streams and print one JSON object")
     ap.add_argument("--no-config4", action="store_true", help="skip both configs[4] legs (the 256-stream shard and the full batch)")
     ap.add_argument("--no-config4-full", action="store_true", help="skip the full configs[4] batch (strong scaling leg)")
     ap.add_argument("--total-streams", type=int, default=2048,
@@ -422,6 +424,20 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for "
                     "a functional check of the N > 1 path when several ranks share one GPU)")
     args = ap.parse_args()
+    if args.pcie_child:
+        # The PCIe leg in a process of its own, started before the parent touches the GPU (see there).
+        import torch
+        from speedy_amd.batch import Plan
+        dev, rk, reps = (int(v) for v in args.pcie_child.split(","))
+        torch.cuda.set_device(dev)
+        n_ = RATE * SECONDS
+        plan_ = Plan(RATE, False)
+        streams_ = make_streams(STREAMS_PER_GPU, n_, rk)
+        if os.environ.get("SPX_SHARED_GPU"):
+            pass   # (ranks sharing a GPU: the engine runs its kernels in sequence, as in the parent)
+        dt_, total_ = pcie_pipeline(plan_, streams_, n_, reps=reps)
+        print(json.dumps({"dt": dt_, "total": total_}), flush=True)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)   # never returns
@@ -430,10 +446,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    ndev = torch.cuda.device_count()     # (does not initialise the GPU)
+    if ndev < 1:
+        sys.exit("bench.py needs an MI355X (the product has no CPU path)")
+    dev_index = local_rank % max(1, ndev)
+    # The PCIe-inclusive leg runs FIRST, in a child process, before this process has touched the GPU: how HIP streams fall onto
+    # hardware queues (and how those are shared between processes) depends on what else holds queues on the device, and behind
+    # the other legs -- or beside an initialised parent -- this leg read 2.3, 2.4 or 4 ms per batch where it reads 2.0 alone
+    # (profiles/r04/r05u_hw_queues.txt).  Every rank runs its own (MAX over ranks below).
+    pcie_early = None
+    if not args.no_pcie:
+        child = subprocess.run([sys.executable, os.path.abspath(__file__), "--pcie-child",
+                                "%d,%d,%d" % (dev_index, rank, max(10, args.steps))], capture_output=True, text=True, timeout=900)
+        if child.returncode != 0:
+            sys.exit("bench.py: the PCIe leg failed: " + child.stderr[-1500:])
+        res = json.loads([ln for ln in child.stdout.splitlines() if ln.startswith("{")][-1])
+        pcie_early = (res["dt"], res["total"])
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (the product has no CPU path)")
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank % max(1, ndev)
     torch.cuda.set_device(dev_index)
     dist = None
     red_dev = "cuda"
@@ -584,14 +614,15 @@ def main():
     pcie = None
     if not args.no_pcie:
         barrier()
-        dt1, total = pcie_pipeline(plan, streams, n, reps=max(10, args.steps))
+        dt1, total = pcie_early
         assert total == n_out, (total, n_out)
         dt1 = max_over_ranks(dt1)
         pcie = {"value": n_in * world / dt1 / 1e6, "unit": "Msamples/s", "ms_per_step": dt1 * 1e3,
                 "vs_resident_step": dt1 / (dt / args.steps),
                 "note": "every rank, MAX over ranks: pinned host int16 input -> HBM, the step, device-side gather, one D2H "
                         "of the produced int16 output; double-buffered on three HIP streams (H2D of batch k+1 and D2H "
-                        "of batch k-1 overlap the step of batch k); one window of %d batches" % max(10, args.steps)}
+                        "of batch k-1 overlap the step of batch k); one window of %d batches; plain spx_batch_run calls; the leg "
+                        "runs first, in a child process, before this process touches the GPU" % max(10, args.steps)}
 
     # BASELINE configs[4].  (1) WEAK: every rank one GPU's shard of 256 mixed streams (global streams 256 r .. 256 r + 255) in
     # one call.  (2) STRONG: the fixed batch of --total-streams streams, rank r of N its contiguous block, one call per rank.

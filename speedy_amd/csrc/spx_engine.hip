@@ -95,6 +95,10 @@ struct spx_plan {
   int ahead_calls = 0;
   void* ahead_last_ws = nullptr;
   hipStream_t ahead_last_stream = nullptr;
+  hipEvent_t ev_call[2] = {nullptr, nullptr};   // the caller's stream as it stood when the last two pipelined calls were made
+  const void* ahead_last_out = nullptr;
+  const void* ahead_last_nout = nullptr;
+  bool ev_call_valid[2] = {false, false};
   std::vector<std::pair<const int*, int>> mixed_started;   // the same for the groups of the last mixed call (lead plan)
   const int* ahead_started = nullptr;
   int ahead_n = 0;
@@ -376,6 +380,7 @@ void spx_plan_destroy(spx_plan_t plan) {
   for (auto& e : plan->ev_chunk) if (e) (void)hipEventDestroy(e);
   for (auto& e : plan->trial.ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : plan->ev_walk) if (e) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); }
+  for (auto& e : plan->ev_call) if (e) (void)hipEventDestroy(e);
   for (auto& g : plan->stage) {
     if (g.done) { (void)hipEventSynchronize(g.done); (void)hipEventDestroy(g.done); }
     if (g.p) (void)hipHostFree(g.p);
@@ -554,6 +559,23 @@ static int dev_side_streams(int dev, hipStream_t* side, hipStream_t* side2) {
     if (hipStreamCreateWithFlags(&s2[d], hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(s1[d]); s1[d] = nullptr; s2[d] = nullptr; return -1; }
   }
   *side = s1[d]; *side2 = s2[d];
+  return 0;
+}
+
+// The walk kernels of consecutive pipelined calls take turns on two streams of the library's (run_impl): the device's SECOND
+// side stream -- idle in that order: the tension kernel runs behind the analysis on the first -- and one more.  Four streams
+// per device in all, the caller's included: one per hardware queue of HIP's default four, whatever order they are first used in
+// (with a fifth stream two of them shared a queue, or queues of one pipe, depending on which mode the process had run first:
+// 1.43 against 1.39 ms per step on the bench batch).
+static int dev_walk_streams(int dev, hipStream_t* w0, hipStream_t* w1) {
+  static std::mutex mu;
+  static hipStream_t s3[64];
+  hipStream_t side = nullptr, side2 = nullptr;
+  if (dev_side_streams(dev, &side, &side2)) return -1;
+  const int d = (dev >= 0 && dev < 64) ? dev : 0;
+  std::lock_guard<std::mutex> g(mu);
+  if (!s3[d] && hipStreamCreateWithFlags(&s3[d], hipStreamNonBlocking) != hipSuccess) { s3[d] = nullptr; return -1; }
+  *w0 = side2; *w1 = s3[d];
   return 0;
 }
 
@@ -748,6 +770,31 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   int* d_order = reinterpret_cast<int*>(w + L.off_order);
   int* d_flags = reinterpret_cast<int*>(w + L.off_flags);
   int* d_ready = reinterpret_cast<int*>(w + L.off_ready);
+  // Pipelined calls, second half: their WALK kernels overlap too.  The walk kernel of a pipelined call goes to one of two
+  // streams of the library's, taking turns, and the caller's stream only waits for it: two walk workgroups per CU run at
+  // nearly full speed each (a 512-stream call's walk kernel takes 1.71 ms where a 256-stream call's takes 1.64), the long
+  // chains of one batch no longer hold the next batch back, and the next-but-one call's analysis runs beside whichever walk is
+  // alone on its CUs.  Bench batch: 1.60 -> 1.45 ms per step.  (SPX_AHEAD_WALK1=1: the walk kernels on the caller's stream,
+  // one after the other, as the mode was first built.)
+  static const bool walk1_env = getenv("SPX_AHEAD_WALK1") != nullptr;
+  const bool walk2 = !walk1_env && ahead && !force && !seq_ahead;
+  hipStream_t stw = st;   // the stream the walk kernel goes to
+  if (walk2) {
+    hipStream_t w0 = nullptr, w1 = nullptr;
+    if (dev_walk_streams(plan->device, &w0, &w1)) return fail(-1, "spx_batch: no walk streams");
+    const int cur = plan->ahead_calls & 1;
+    stw = cur ? w1 : w0;
+    if (!plan->ev_call[cur]) HIPCHK(hipEventCreateWithFlags(&plan->ev_call[cur], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(plan->ev_call[cur], st));        // the caller's stream as it stands now
+    plan->ev_call_valid[cur] = true;
+    // whatever the caller had queued by the PREVIOUS call (the consumer of the output this call overwrites, two buffers taking
+    // turns) -- not this call's state of the stream, which ends with the wait for the previous call's walk kernel; a caller
+    // that hands over the previous call's out / n_out again gets exactly that wait
+    const bool same_out = out == plan->ahead_last_out || n_out == plan->ahead_last_nout;
+    if (same_out) HIPCHK(hipStreamWaitEvent(stw, plan->ev_call[cur], 0));
+    else if (plan->ev_call_valid[cur ^ 1]) HIPCHK(hipStreamWaitEvent(stw, plan->ev_call[cur ^ 1], 0));
+  }
+  if (do_w && !force) { plan->ahead_last_out = out; plan->ahead_last_nout = n_out; }
   hipStream_t sa = st;  // stream the analysis launches go to
   if (nch > 1 || concurrent || ahead) {
     if (!plan->side) {
@@ -833,7 +880,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     SpxStreamDev* dj = dstreams + (size_t)c * n;
     auto launch_walk = [&]() {
       hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, st); }
+      if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, stw); }
       static const bool diag_nowait = spx_tuning_env("SPX_DIAG_NOWAIT") != nullptr;  // DIAGNOSTIC ONLY: the walk reads the speeds
       // the previous identical call left in the scratch array instead of waiting for this call's (timing experiments)
       // Kernels in sequence, and every stream of the call (of all groups of a mixed call) can have a CU to itself: ask for
@@ -847,8 +894,8 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       // (AHEAD: the counts are all published by the time the kernel starts -- its one poll returns at once -- and its
       // workgroups count themselves in for the next call's gate)
       spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, ((concurrent && !diag_nowait) || ahead) ? d_ready : nullptr,
-                      speedup_only, st, false, lds_min, lean_walk && (concurrent || ahead));
-      if (timed) { (void)hipEventRecord(e1, st); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({e0, e1, 1}); } }
+                      speedup_only, stw, false, lds_min, lean_walk && (concurrent || ahead));
+      if (timed) { (void)hipEventRecord(e1, stw); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({e0, e1, 1}); } }
     };
     // Concurrent mode on an IDLE device (the first call after a synchronisation): kernels start as their launches arrive,
     // and the analysis launch arrives a few tens of microseconds before the walk launch.  Its tiles then fill the CUs' LDS
@@ -897,7 +944,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       if (concurrent) HIPCHK(hipEventRecord(plan->ev_tension, stn));
       if (ahead) {   // the walk kernel starts when every speed of the call is there
         HIPCHK(hipEventRecord(plan->ev_tension, stn));
-        HIPCHK(hipStreamWaitEvent(st, plan->ev_tension, 0));
+        HIPCHK(hipStreamWaitEvent(stw, plan->ev_tension, 0));
       }
       launch_walk();
       if (ahead_forced && force->started_out) *force->started_out = d_ready + n;
@@ -906,7 +953,8 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
         // walk kernels of the two calls before it, pipelined or not)
         const int cur = plan->ahead_calls & 1;
         if (!plan->ev_walk[cur]) HIPCHK(hipEventCreateWithFlags(&plan->ev_walk[cur], hipEventDisableTiming));
-        HIPCHK(hipEventRecord(plan->ev_walk[cur], st));
+        HIPCHK(hipEventRecord(plan->ev_walk[cur], stw));
+        if (stw != st) HIPCHK(hipStreamWaitEvent(st, plan->ev_walk[cur], 0));   // the caller's stream is done when the walk is
         plan->ev_walk_valid[cur] = true;
         plan->ahead_calls++;
         plan->ahead_last_ws = ws;
