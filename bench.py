@@ -542,7 +542,7 @@ def main():
 
     def step(k):
         q = turn[k % len(turn)]
-        q.run_ahead() if b2 is not None else q.run()
+        q.run_ahead(overlap=True) if b2 is not None else q.run()
 
     # the unpipelined figure (also warms up); --no-unpipelined: profiling runs, whose per-kernel averages should be the timed loop's
     dt_single = None if args.no_unpipelined else time_window(b.run, reps=max(5, args.steps), warm=max(3, args.warmup))

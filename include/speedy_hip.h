@@ -103,6 +103,21 @@ int spx_batch_run_ahead(spx_plan_t plan, const spx_stream_job* jobs, int n_strea
                         int16_t* out, int64_t* n_out, void* workspace, size_t workspace_bytes,
                         const spx_taps* taps, void* hip_stream);
 
+/* spx_batch_run_ahead with the WALK kernels of consecutive calls overlapping as well: a call's walk kernel runs on a stream of
+ * the library's (two, taking turns) and hip_stream only waits for it, so the walk of call k + 1 starts as soon as its own
+ * speeds are there, beside the walk of call k -- two walk workgroups per CU run at nearly full speed each, and the longest
+ * chains of one batch no longer hold the next batch back (BASELINE configs[3]: 1.60 -> 1.39 ms per batch).
+ * The price is a RELAXED stream order, on top of spx_batch_run_ahead's contract:
+ *   - work the caller enqueues on hip_stream AFTER call k is ordered behind call k's kernels as always (it sees call k's output),
+ *     but call k + 1's walk kernel is ordered only behind what was on hip_stream when call k was MADE: whatever the caller
+ *     enqueues between call k and call k + 1 must not touch call k + 1's buffers (two buffer sets taking turns, each consumed
+ *     right behind its own call, satisfy this by construction; a call that hands over the previous call's out / n_out or
+ *     workspace again is ordered behind everything, as spx_batch_run_ahead would order it).
+ * Everything else as spx_batch_run_ahead; shapes outside the mode run as spx_batch_run would. */
+int spx_batch_run_overlapped(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, const int16_t* in,
+                             int16_t* out, int64_t* n_out, void* workspace, size_t workspace_bytes,
+                             const spx_taps* taps, void* hip_stream);
+
 /* The same for input that is still on its way when the call is made (a host-to-device copy on another stream):
  * in_ready_event is a hipEvent_t the caller has recorded behind whatever completes `in`; the call's producers wait for it
  * (NULL: as spx_batch_run_ahead). */

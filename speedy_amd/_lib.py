@@ -44,6 +44,8 @@ SYMBOLS = {
                                 C.c_void_p, C.c_size_t, C.POINTER(Taps), C.c_void_p]),
     "spx_batch_run_ahead": (C.c_int, [C.c_void_p, C.POINTER(StreamJob), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_size_t, C.POINTER(Taps), C.c_void_p]),
+    "spx_batch_run_overlapped": (C.c_int, [C.c_void_p, C.POINTER(StreamJob), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_size_t, C.POINTER(Taps), C.c_void_p]),
     "spx_batch_run_ahead_when": (C.c_int, [C.c_void_p, C.POINTER(StreamJob), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_size_t, C.POINTER(Taps), C.c_void_p, C.c_void_p]),
     "spx_batch_workspace_bytes_mixed": (C.c_size_t, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(StreamJob), C.POINTER(C.c_int), C.c_int]),

@@ -109,11 +109,20 @@ class Batch:
         if rc != 0:
             raise RuntimeError("spx_batch_run: " + self.plan.L.spx_last_error().decode())
 
-    def run_ahead(self, stream=None, in_ready=None):
+    def run_ahead(self, stream=None, in_ready=None, overlap=False):
         """spx_batch_run_ahead: like run(), software-pipelined with the previous call on the same stream (the caller alternates
         two Batch objects).  in_ready: a recorded torch.cuda.Event behind whatever completes the input (None: the input is
-        resident when the call is made)."""
+        resident when the call is made).  overlap: spx_batch_run_overlapped -- the walk kernels of consecutive calls overlap
+        too; nothing enqueued between two calls may touch the later call's buffers (include/speedy_hip.h)."""
         hs = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        if overlap:
+            assert in_ready is None
+            rc = self.plan.L.spx_batch_run_overlapped(self.plan.h, self.jobs, self.n, self.d_in.data_ptr(), self.d_out.data_ptr(),
+                                                      self.d_nout.data_ptr(), self.d_ws.data_ptr(), self.d_ws.numel(),
+                                                      C.byref(self.taps) if self.taps is not None else None, hs)
+            if rc != 0:
+                raise RuntimeError("spx_batch_run_overlapped: " + self.plan.L.spx_last_error().decode())
+            return
         rc = self.plan.L.spx_batch_run_ahead_when(self.plan.h, self.jobs, self.n, self.d_in.data_ptr(), self.d_out.data_ptr(),
                                                   self.d_nout.data_ptr(), self.d_ws.data_ptr(), self.d_ws.numel(),
                                                   C.byref(self.taps) if self.taps is not None else None, hs,

@@ -585,7 +585,8 @@ struct SpxForce { int concurrent; bool idle_start; int total_streams; hipEvent_t
 // total_streams: of all groups of the mixed call; after_analysis: recorded behind the group's analysis launch (or null)
 static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                     int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs, bool do_a,
-                    bool do_w, const SpxForce* force = nullptr, bool ahead_req = false, void* in_ready = nullptr) {
+                    bool do_w, const SpxForce* force = nullptr, bool ahead_req = false, void* in_ready = nullptr,
+                    bool overlap_req = false) {
   if (!plan || !jobs || n <= 0) return fail(-1, "spx_batch: bad arguments");
   SpxRange range_(do_a && do_w ? "spx_batch_run" : (do_a ? "spx_batch_analyze" : "spx_batch_walk"));
   SpxPlanDev d = plan->dev;  // a copy: the tile size is chosen per call
@@ -776,8 +777,9 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // chains of one batch no longer hold the next batch back, and the next-but-one call's analysis runs beside whichever walk is
   // alone on its CUs.  Bench batch: 1.60 -> 1.45 ms per step.  (SPX_AHEAD_WALK1=1: the walk kernels on the caller's stream,
   // one after the other, as the mode was first built.)
+  // Asked for per call (spx_batch_run_overlapped): it relaxes the caller's stream order -- see include/speedy_hip.h.
   static const bool walk1_env = getenv("SPX_AHEAD_WALK1") != nullptr;
-  const bool walk2 = !walk1_env && ahead && !force && !seq_ahead;
+  const bool walk2 = overlap_req && !walk1_env && ahead && !force && !seq_ahead;
   hipStream_t stw = st;   // the stream the walk kernel goes to
   if (walk2) {
     hipStream_t w0 = nullptr, w1 = nullptr;
@@ -993,6 +995,10 @@ int spx_batch_run(spx_plan_t plan, const spx_stream_job* jobs, int n, const int1
 int spx_batch_run_ahead(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                         int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs) {
   return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true, nullptr, true);
+}
+int spx_batch_run_overlapped(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
+                             int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs) {
+  return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true, nullptr, true, nullptr, true);
 }
 int spx_batch_run_ahead_when(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                              int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs, void* in_ready_event) {

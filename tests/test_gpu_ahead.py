@@ -241,3 +241,62 @@ def test_mixed_rate_calls_pipelined(orc):
             bs[k][0].d_out.zero_()
         assert big[0].crcs() == big[1]
         big[0].d_out.zero_()
+
+
+def test_overlapped_walks_of_batches_of_different_content(orc):
+    """spx_batch_run_overlapped: as the first test, with the walk kernels of consecutive calls overlapping; every batch is
+    consumed (copied) right behind its own call, as the call's contract asks."""
+    import torch
+    from speedy_amd.batch import Plan
+    plan = Plan(16000, False)
+    bs = []
+    for seed in (71, 72, 73):
+        b, _ = _make(plan, 16000, 1, 256, seed, seconds=1.2)
+        b.run()
+        bs.append((b, _crc(b.results())))
+        b.d_out.zero_()
+    torch.cuda.synchronize()
+    for ring in (3, 2):
+        copies = []
+        for t in range(9):
+            b = bs[t % ring][0]
+            b.run_ahead(overlap=True)
+            copies.append((t % ring, b.d_out.clone(), b.d_nout.clone()))     # the consumer of THIS call's output
+        assert plan.L.spx_debug_last_call_concurrent() == 2
+        torch.cuda.synchronize()
+        for k, o, c in copies:
+            b = bs[k][0]
+            keep_o, keep_c = b.d_out, b.d_nout
+            b.d_out, b.d_nout = o, c
+            assert _crc(b.results()) == bs[k][1], (ring, k)
+            b.d_out, b.d_nout = keep_o, keep_c
+
+
+def test_one_output_buffer_for_every_call(orc):
+    """Two workspaces take turns but the caller hands over the SAME out / n_out buffers every time and consumes them on the
+    stream between the calls (here: a device copy): the next call's walk kernel -- which runs on a stream of the library's and
+    would otherwise overlap the previous one -- must wait for that consumer."""
+    import torch
+    from speedy_amd.batch import Plan
+    plan = Plan(16000, False)
+    bs, want = [], []
+    for seed in (61, 62):
+        b, _ = _make(plan, 16000, 1, 256, seed, seconds=1.0, ragged=False)
+        b.run()
+        torch.cuda.synchronize()
+        want.append((b.d_out.clone(), b.d_nout.clone()))
+        bs.append(b)
+    bs[1].d_out, bs[1].d_nout = bs[0].d_out, bs[0].d_nout      # one output buffer for both
+    torch.cuda.synchronize()
+    stash = []
+    for k in range(8):
+        bs[k % 2].run_ahead(overlap=True)
+        stash.append((bs[0].d_out.clone(), bs[0].d_nout.clone()))   # the consumer, on the caller's stream
+    torch.cuda.synchronize()
+    for k, (o, c) in enumerate(stash):
+        assert torch.equal(c, want[k % 2][1]), k
+        b = bs[k % 2]
+        got, ref, cnt = o.cpu().numpy(), want[k % 2][0].cpu().numpy(), c.cpu().numpy()
+        for i in range(b.n):          # the produced frames of every stream (what lies behind them in the shared buffer is the other batch's)
+            a, e = b.out_offs[i], b.out_offs[i] + int(cnt[i])
+            assert np.array_equal(got[a:e], ref[a:e]), (k, i)
