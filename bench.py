@@ -530,8 +530,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
-    # Consecutive steps are software-pipelined by the library (spx_batch_run_ahead, include/speedy_hip.h): two Batch objects
-    # with the SAME resident input take turns, step k + 1's analysis and tension kernels run beside step k's walk kernel.
+    # Consecutive steps are software-pipelined by the library (spx_batch_run_overlapped, include/speedy_hip.h): two Batch objects
+    # with the SAME resident input take turns, step k + 1's analysis and tension kernels run beside step k's walk kernel, and
+    # the walk kernels of consecutive steps overlap too (two streams of the library's taking turns).
     # Every step is the whole hot path over one batch of 256 streams; nothing is cached or skipped.  (--no-pipeline: one
     # Batch, spx_batch_run call after call, as rounds 1-4 timed it; reported as `unpipelined` in every line.)
     b2 = None
@@ -730,13 +731,14 @@ def main():
                                 "first-write-to-last-drained-read rate is `pcie_inclusive`, the drop-in API's rate with 256 "
                                 "live sonicStream handles is `api_256_handles`.  ONE rule for every figure in this line: a single "
                                 "timed window of consecutive steps after untimed warm-up steps -- no best-of-N anywhere.  "
-                                + ("Consecutive steps are software-pipelined by the library (spx_batch_run_ahead): two batches with the "
+                                + ("Consecutive steps are software-pipelined by the library (spx_batch_run_overlapped): two batches with the "
                                    "same resident input take turns, step k+1's analysis and tension kernels run beside step k's walk "
-                                   "kernel; every step is the whole hot path over one batch.  `unpipelined` is spx_batch_run on one "
+                                   "kernel and the walk kernels of consecutive steps overlap (so `roofline.kernel_avg_launch_ms` of the "
+                                   "walk kernel is LONGER than `ms_per_step`); every step is the whole hot path over one batch.  `unpipelined` is spx_batch_run on one "
                                    "batch, call after call (what rounds 1-4 reported as `value`)" if b2 is not None else
                                    "spx_batch_run on one batch, call after call (--no-pipeline)"),
             "pipelined": b2 is not None and last_mode == 2,
-            "launch_mode_of_the_timed_calls": {2: "pipelined with the previous call (spx_batch_run_ahead)", 1: "three kernels side by side",
+            "launch_mode_of_the_timed_calls": {2: "pipelined with the previous call (spx_batch_run_overlapped)", 1: "three kernels side by side",
                                                0: "kernels in sequence"}.get(last_mode, str(last_mode)),
             "unpipelined": None if dt_single is None else
                            {"ms_per_step": dt_single * 1e3, "value": n_in * world / dt_single / 1e6, "unit": "Msamples/s",
