@@ -530,16 +530,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
-    # Consecutive steps are software-pipelined by the library (spx_batch_run_overlapped, include/speedy_hip.h): two Batch objects
+    # Consecutive steps are software-pipelined by the library (spx_batch_run_overlapped, include/speedy_hip.h): three Batch objects
     # with the SAME resident input take turns, step k + 1's analysis and tension kernels run beside step k's walk kernel, and
     # the walk kernels of consecutive steps overlap too (two streams of the library's taking turns).
     # Every step is the whole hot path over one batch of 256 streams; nothing is cached or skipped.  (--no-pipeline: one
     # Batch, spx_batch_run call after call, as rounds 1-4 timed it; reported as `unpipelined` in every line.)
-    b2 = None
+    b2 = b3 = None
     if not args.no_pipeline:
+        # THREE sets of buffers taking turns: with two, a step's producers wait for the walk kernel two steps back (the last user
+        # of their workspace); with three they start while the walk kernels of both previous steps are still running
+        # (1.385 -> 1.33 ms per step)
         b2 = Batch(plan, [n] * STREAMS_PER_GPU, 1, SPEED, 1.0, 0.0)
         b2.d_in.copy_(b.d_in)
-    turn = [b, b2] if b2 is not None else [b]
+        b3 = Batch(plan, [n] * STREAMS_PER_GPU, 1, SPEED, 1.0, 0.0)
+        b3.d_in.copy_(b.d_in)
+    turn = [b, b2, b3] if b2 is not None else [b]
 
     def step(k):
         q = turn[k % len(turn)]
@@ -567,9 +572,10 @@ def main():
     n_in = n * STREAMS_PER_GPU
     outs = b.results()
     if b2 is not None:   # both turns of the pipeline produced the same bytes
-        outs2 = b2.results()
-        assert len(outs2) == len(outs) and all(np.array_equal(x, y) for x, y in zip(outs, outs2)), "the two batches of the pipelined loop differ"
-        del outs2
+        for q in (b2, b3):
+            outs2 = q.results()
+            assert len(outs2) == len(outs) and all(np.array_equal(x, y) for x, y in zip(outs, outs2)), "the batches of the pipelined loop differ"
+            del outs2
     n_out = int(sum(o.size for o in outs))
     chain_steps = b.step_counts()         # pitch searches per stream: the length of every stream's dependent chain
     if dt_single is not None:
@@ -731,7 +737,7 @@ def main():
                                 "first-write-to-last-drained-read rate is `pcie_inclusive`, the drop-in API's rate with 256 "
                                 "live sonicStream handles is `api_256_handles`.  ONE rule for every figure in this line: a single "
                                 "timed window of consecutive steps after untimed warm-up steps -- no best-of-N anywhere.  "
-                                + ("Consecutive steps are software-pipelined by the library (spx_batch_run_overlapped): two batches with the "
+                                + ("Consecutive steps are software-pipelined by the library (spx_batch_run_overlapped): three batches with the "
                                    "same resident input take turns, step k+1's analysis and tension kernels run beside step k's walk "
                                    "kernel and the walk kernels of consecutive steps overlap (so `roofline.kernel_avg_launch_ms` of the "
                                    "walk kernel is LONGER than `ms_per_step`); every step is the whole hot path over one batch.  `unpipelined` is spx_batch_run on one "

@@ -88,13 +88,13 @@ struct spx_plan {
   hipEvent_t ev_tension = nullptr;
   hipEvent_t ev_start = nullptr;
   hipEvent_t ev_chunk[SPX_MAX_CHUNKS] = {};
-  // spx_batch_run_ahead: the walk kernels of the plan's previous two calls (ring of two events), the workspace, stream and
-  // started-counter of the last one
-  hipEvent_t ev_walk[2] = {nullptr, nullptr};
-  bool ev_walk_valid[2] = {false, false};
+  // spx_batch_run_ahead: the walk kernels of the plan's previous FOUR calls (ring_wait / ring_record below), the started-counter
+  // of the last one
+  hipEvent_t ev_walk[4] = {nullptr, nullptr, nullptr, nullptr};   // slot = call number mod 4
+  bool ev_walk_valid[4] = {false, false, false, false};
+  void* ring_ws[4] = {nullptr, nullptr, nullptr, nullptr};         // the workspace and the caller's stream of the call in the slot
+  hipStream_t ring_st[4] = {nullptr, nullptr, nullptr, nullptr};
   int ahead_calls = 0;
-  void* ahead_last_ws = nullptr;
-  hipStream_t ahead_last_stream = nullptr;
   hipEvent_t ev_call[2] = {nullptr, nullptr};   // the caller's stream as it stood when the last two pipelined calls were made
   const void* ahead_last_out = nullptr;
   const void* ahead_last_nout = nullptr;
@@ -579,6 +579,42 @@ static int dev_walk_streams(int dev, hipStream_t* w0, hipStream_t* w1) {
   return 0;
 }
 
+// Which earlier calls a pipelined call's producers wait for (on `sa`), and how a call leaves its end in the ring.
+// The walk kernels of pipelined calls may run on two streams taking turns (spx_batch_run_overlapped), so "the call before" says
+// nothing about the calls before that one: the producers wait for
+//   - the calls three and four back, always: between them they close both walk streams' histories (everything older is done),
+//     which also covers a caller that rotates three or four workspaces;
+//   - the calls one and two back when they used THIS workspace (two workspaces taking turns: the call two back) or another
+//     caller stream (then the order of the caller's stream says nothing about them).
+// A caller that rotates three workspaces therefore gets its producers started while the walk kernels of BOTH previous calls are
+// still running.
+static int ring_wait(spx_plan* plan, hipStream_t sa, const void* ws, hipStream_t st) {
+  const int c = plan->ahead_calls & 3;
+  for (int back = 4; back >= 1; back--) {
+    const int j = (c + 4 - back) & 3;          // slot of the call `back` calls ago
+    if (!plan->ev_walk_valid[j]) continue;
+    if (back >= 3 || plan->ring_ws[j] == ws || plan->ring_st[j] != st) HIPCHK(hipStreamWaitEvent(sa, plan->ev_walk[j], 0));
+  }
+  return 0;
+}
+static bool ring_previous_in_flight(spx_plan* plan) {
+  const int j = (plan->ahead_calls + 3) & 3;
+  const bool f = plan->ev_walk_valid[j] && hipEventQuery(plan->ev_walk[j]) == hipErrorNotReady;
+  (void)hipGetLastError();
+  return f;
+}
+static int ring_record(spx_plan* plan, hipStream_t on, void* ws, hipStream_t st) {
+  const int c = plan->ahead_calls & 3;
+  if (!plan->ev_walk[c]) HIPCHK(hipEventCreateWithFlags(&plan->ev_walk[c], hipEventDisableTiming));
+  HIPCHK(hipEventRecord(plan->ev_walk[c], on));
+  if (on != st) HIPCHK(hipStreamWaitEvent(st, plan->ev_walk[c], 0));   // the caller's stream is done when the walk is
+  plan->ev_walk_valid[c] = true;
+  plan->ring_ws[c] = ws;
+  plan->ring_st[c] = st;
+  plan->ahead_calls++;
+  return 0;
+}
+
 struct SpxForce { int concurrent; bool idle_start; int total_streams; hipEvent_t after_analysis; hipStream_t ahead_sa; const int** started_out; };
 // ahead_sa: the group of a pipelined mixed call -- its producers go to this stream at once (spx_batch_run_mixed_ahead orders it);
 // started_out: where the group's walk workgroups count themselves in (for the next call's gate)
@@ -849,11 +885,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       // this call's producers must not touch a workspace the walk kernel of an earlier call still reads: with the caller
       // alternating two workspaces that is the call before the previous one (the older event of the ring); a caller that
       // hands over the previous call's workspace again waits for that call instead (correct, and no overlap)
-      const int cur = plan->ahead_calls & 1;          // this call's slot of the ring = the slot of the call two back
-      // (the previous call's too when it used this workspace, or another stream: then the ring's order says nothing)
-      if ((ws == plan->ahead_last_ws || st != plan->ahead_last_stream) && plan->ev_walk_valid[cur ^ 1])
-        HIPCHK(hipStreamWaitEvent(sa, plan->ev_walk[cur ^ 1], 0));
-      if (plan->ev_walk_valid[cur]) HIPCHK(hipStreamWaitEvent(sa, plan->ev_walk[cur], 0));
+      if (ring_wait(plan, sa, ws, st)) return -2;
       if (in_ready) HIPCHK(hipStreamWaitEvent(sa, static_cast<hipEvent_t>(in_ready), 0));   // the caller's "input is there"
     }
     if (!ahead && in_ready) HIPCHK(hipStreamWaitEvent(st, static_cast<hipEvent_t>(in_ready), 0));
@@ -916,9 +948,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     // walk kernel becomes runnable at the same moment as this analysis: when the walk before it retires)
     // (only while that call is still in flight: then its workspace, where the counter lives, is alive by the usual contract)
     if (ahead && !force && plan->ahead_started != nullptr && plan->ahead_n > 0 && !no_gate) {
-      const int prev = (plan->ahead_calls & 1) ^ 1;
-      const bool in_flight = plan->ev_walk_valid[prev] && hipEventQuery(plan->ev_walk[prev]) == hipErrorNotReady;
-      (void)hipGetLastError();
+      const bool in_flight = ring_previous_in_flight(plan);
       // (a longer bound than the idle-start gate's: the previous walk kernel may itself be waiting for something of the
       // caller's -- an output buffer still being copied out -- and a gate that gives up early lets this call's analysis fill the
       // CUs first, which costs the previous call half its speed; ~2 ms)
@@ -953,14 +983,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       if (c == nch - 1 && !force) {
         // every call of the plan that walks leaves its event in the ring (a pipelined call orders its producers behind the
         // walk kernels of the two calls before it, pipelined or not)
-        const int cur = plan->ahead_calls & 1;
-        if (!plan->ev_walk[cur]) HIPCHK(hipEventCreateWithFlags(&plan->ev_walk[cur], hipEventDisableTiming));
-        HIPCHK(hipEventRecord(plan->ev_walk[cur], stw));
-        if (stw != st) HIPCHK(hipStreamWaitEvent(st, plan->ev_walk[cur], 0));   // the caller's stream is done when the walk is
-        plan->ev_walk_valid[cur] = true;
-        plan->ahead_calls++;
-        plan->ahead_last_ws = ws;
-        plan->ahead_last_stream = st;
+        if (ring_record(plan, stw, ws, st)) return -2;
         plan->ahead_started = (concurrent || ahead) ? d_ready + n : nullptr;   // (only these walk kernels count themselves in)
         plan->ahead_n = n;
       }
@@ -1217,12 +1240,8 @@ static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job
     // workspace when two take turns; the previous call too if it used this workspace or another stream), and -- while the
     // previous call is still in flight -- behind gate kernels that wait until its walk workgroups have been placed
     std::lock_guard<std::mutex> ring_lock(lead->mu);
-    const int cur = lead->ahead_calls & 1;
-    if ((ws == lead->ahead_last_ws || st != lead->ahead_last_stream) && lead->ev_walk_valid[cur ^ 1])
-      HIPCHK(hipStreamWaitEvent(dev_s1, lead->ev_walk[cur ^ 1], 0));
-    if (lead->ev_walk_valid[cur]) HIPCHK(hipStreamWaitEvent(dev_s1, lead->ev_walk[cur], 0));
-    const bool in_flight = lead->ev_walk_valid[cur ^ 1] && hipEventQuery(lead->ev_walk[cur ^ 1]) == hipErrorNotReady;
-    (void)hipGetLastError();
+    if (ring_wait(lead, dev_s1, ws, st)) return -2;
+    const bool in_flight = ring_previous_in_flight(lead);
     if (in_flight)
       for (const auto& sn : lead->mixed_started)
         if (sn.first && sn.second > 0) hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, dev_s1, sn.first, sn.second, 8000u);
@@ -1267,13 +1286,7 @@ static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job
   {
     // every mixed call leaves its end in the lead plan's ring (a pipelined call orders its producers behind the two calls before it)
     std::lock_guard<std::mutex> ring_lock(lead->mu);
-    const int cur = lead->ahead_calls & 1;
-    if (!lead->ev_walk[cur]) HIPCHK(hipEventCreateWithFlags(&lead->ev_walk[cur], hipEventDisableTiming));
-    HIPCHK(hipEventRecord(lead->ev_walk[cur], st));
-    lead->ev_walk_valid[cur] = true;
-    lead->ahead_calls++;
-    lead->ahead_last_ws = ws;
-    lead->ahead_last_stream = st;
+    if (ring_record(lead, st, ws, st)) return -2;
     lead->ahead_started = nullptr;
     lead->ahead_n = 0;
     lead->mixed_started.clear();

@@ -72,3 +72,19 @@ print("spx_batch_run_ahead, two batches alternating  %.3f ms per batch" % (dt * 
 for b in bs:
     got = [zlib.crc32(np.ascontiguousarray(o).tobytes()) for o in b.results()]
     print("outputs equal spx_batch_run's:", got == ref)
+
+# overlapped walk kernels, two and three batches taking turns
+bs.append(Batch(plan, [n] * ns, 1, 3.5, 1.0, 0.0))
+bs[2].d_in.copy_(bs[0].d_in)
+for turns in (2, 3, 2, 3):
+    for label, reps in (("warm", 6), ("timed", 30)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(reps):
+            bs[k % turns].run_ahead(overlap=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+    print("spx_batch_run_overlapped, %d batches taking turns  %.3f ms per batch" % (turns, dt * 1e3))
+for b in bs:
+    got = [zlib.crc32(np.ascontiguousarray(o).tobytes()) for o in b.results()]
+    print("outputs equal spx_batch_run's:", got == ref)
