@@ -193,6 +193,10 @@ int spx_debug_analysis_info(int sample_rate, int* out3);
  * `denominators` random speeds (speed - 1 log-uniform in [2^exp_lo, 2^exp_hi)) x every count 1 .. 4096 x both numerator forms;
  * returns the number of mismatches (0 is the only acceptable answer), -1 on a runtime error. */
 long long spx_debug_fdiv_check(unsigned seed, unsigned denominators, int exp_lo, int exp_hi);
+/* The same for the analysis kernel's scale-free fp32 / fp64 divisions and its fp64 square root (spx_log.h): `threads` x
+ * `per_thread` pseudo-random operands of the ranges the kernel feeds them; the number of results that differ from the IEEE
+ * sequences' (0 is the only acceptable answer), -1 on a runtime error. */
+long long spx_debug_arith_check(unsigned seed, unsigned threads, unsigned per_thread);
 /* Diagnostics: 1 if the last spx_batch_run / analyze+walk call of this process took the concurrent three-kernel mode, 2 if it was
  * pipelined with the previous call (spx_batch_run_ahead), 0 if it launched its kernels in sequence (another process holds the
  * device's concurrent-mode lock, a tuning variable, the batch shape). */

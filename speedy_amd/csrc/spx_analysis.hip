@@ -646,7 +646,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
           const double2 w = wu[u];
           const double xr = er + (w.x * o_r - w.y * o_i);
           const double xi = ei + (w.x * o_i + w.y * o_r);
-          const float mag = (float)__builtin_sqrt(xr * xr + xi * xi);
+          const float mag = spx_sqrt64_to_f32(xr * xr + xi * xi);
           mrow[k] = mag;
           if (spec_out) {
             spec_out[k] = mag;
@@ -823,7 +823,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
           const double2 w = tw2p[k];
           const double xr = er + (w.x * o_r - w.y * o_i);
           const double xi = ei + (w.x * o_i + w.y * o_r);
-          const float mag = (float)__builtin_sqrt(xr * xr + xi * xi);
+          const float mag = spx_sqrt64_to_f32(xr * xr + xi * xi);
           mrow[k] = mag;
           if (spec_out) {
             spec_out[k] = mag;
@@ -876,7 +876,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
           const double2 w = tw2p[k];
           const double xr = er + (w.x * o_r - w.y * o_i);
           const double xi = ei + (w.x * o_i + w.y * o_r);
-          const float mag = (float)__builtin_sqrt(xr * xr + xi * xi);
+          const float mag = spx_sqrt64_to_f32(xr * xr + xi * xi);
           mrow[k] = mag;
           if (spec_out) {
             spec_out[k] = mag;
@@ -998,7 +998,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
           const double2 w = tw2q[k];
           const double xr = er + (w.x * o_r - w.y * o_i);
           const double xi = ei + (w.x * o_i + w.y * o_r);
-          const float mag = (float)__builtin_sqrt(xr * xr + xi * xi);
+          const float mag = spx_sqrt64_to_f32(xr * xr + xi * xi);
           mrow[k] = mag;
           if (spec_out) {
             spec_out[k] = mag;
@@ -1119,7 +1119,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       const double2 w = *reinterpret_cast<const double2*>(ltw2 + 2 * k);
       const double xr = er + (w.x * o_r - w.y * o_i);
       const double xi = ei + (w.x * o_i + w.y * o_r);
-      const float mag = (float)__builtin_sqrt(xr * xr + xi * xi);
+      const float mag = spx_sqrt64_to_f32(xr * xr + xi * xi);
       mrow[k] = mag;
       if (spec_out) {
         spec_out[k] = mag;
@@ -1201,7 +1201,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
     if (cur > thr && last > thr) {
       const float eps = 2.2204e-16f;
       const float nc = cur * fInv[sl], nl = last * fInv[sl - 1];
-      const float ratio = (nc + eps) / (nl + eps);
+      const float ratio = spx_fdiv32(nc + eps, nl + eps);
       term = __builtin_fabs(spx_log((double)ratio));                           // speedy.c:715-717
     }
     return term;
@@ -1265,7 +1265,8 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
             gate[t] = in && cur > thr && last > thr;                           // speedy.c:705-717
             const float eps = 2.2204e-16f;
             const float nc = cur * fInv[fl + 1], nl = last * fInv[fl];
-            const float ratio = (nc + eps) / (nl + eps);
+            // (both operands in [2.2e-16, ~1e3] whenever the gate is open: spx_fdiv32's range; a closed gate's quotient is not used)
+            const float ratio = spx_fdiv32(nc + eps, nl + eps);
             xr[t] = gate[t] ? ratio : 2.0f;
           }
           const spx_log_parts p0 = spx_log_main((double)xr[0]), p1 = spx_log_main((double)xr[1]);
@@ -1348,6 +1349,42 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   }
   ASTAMP(7);
   ASTAMP_FLUSH
+}
+
+// Diagnostic (tests/test_gpu_parity.py): the scale-free division and square-root sequences of spx_log.h against the
+// compiler's IEEE sequences, bit for bit, on pseudo-random operands of the ranges the analysis kernel feeds them (and, for
+// the square root, on zero / tiny / huge arguments, which must take the library sequence).  Returns the number of mismatches.
+__global__ void spx_arith_check_kernel(unsigned seed, unsigned per_thread, unsigned long long* bad) {
+  unsigned long long st = (unsigned long long)seed * 0x9E3779B97F4A7C15ull + (blockIdx.x * blockDim.x + threadIdx.x) * 0xD1B54A32D192ED03ull + 1;
+  auto next = [&]() { st ^= st >> 12; st ^= st << 25; st ^= st >> 27; return st * 0x2545F4914F6CDD1Dull; };
+  unsigned long long miss = 0;
+  for (unsigned i = 0; i < per_thread; i++) {
+    const unsigned long long a = next(), b = next(), c = next();
+    // float operands 2^u (1 + m), u in [-53, 3]
+    const float fn = __uint_as_float((unsigned)((127 - 53 + (a % 57)) << 23) | (unsigned)((a >> 8) & 0x7fffff));
+    const float fd = __uint_as_float((unsigned)((127 - 53 + (b % 57)) << 23) | (unsigned)((b >> 8) & 0x7fffff));
+    if (__float_as_uint(spx_fdiv32(fn, fd)) != __float_as_uint(fn / fd)) miss++;
+    // f / (2 + f), |f| = 2^u (1 + m), u in [-21, -2]: what spx_log_main divides
+    const long long fb = ((long long)(1023 - 21 + (c % 20)) << 52) | (long long)((c >> 8) & 0xfffffffffffffll) | ((c >> 63) ? (1ll << 63) : 0);
+    const double f = __longlong_as_double(fb);
+    if (__double_as_longlong(spx_fdiv64(f, 2.0 + f)) != __double_as_longlong(f / (2.0 + f))) miss++;
+    // square roots: 2^u (1 + m), u in [-800, 1010] (both ends beyond the fast sequence's range), and zero now and then
+    const long long xb = ((long long)(1023 - 800 + (a >> 33) % 1811) << 52) | (long long)((b >> 10) & 0xfffffffffffffll);
+    const double x = ((c & 1023) == 0) ? 0.0 : __longlong_as_double(xb);
+    if (__float_as_uint(spx_sqrt64_to_f32(x)) != __float_as_uint((float)__builtin_sqrt(x))) miss++;
+  }
+  if (miss) atomicAdd(bad, miss);
+}
+extern "C" long long spx_debug_arith_check(unsigned seed, unsigned threads, unsigned per_thread) {
+  unsigned long long* d = nullptr;
+  unsigned long long h = 0;
+  if (hipMalloc(&d, sizeof(h)) != hipSuccess) return -1;
+  if (hipMemcpy(d, &h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return -1; }
+  const unsigned blocks = (threads + 255) / 256;
+  hipLaunchKernelGGL(spx_arith_check_kernel, dim3(blocks), dim3(256), 0, nullptr, seed, per_thread, d);
+  const bool ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(d);
+  return ok ? (long long)h : -1;
 }
 
 void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int n_tiles,

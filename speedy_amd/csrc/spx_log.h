@@ -14,6 +14,49 @@
 // of zero is involved.  spx_log_finish replaces the value for the rare arguments (zero, negative, subnormal, infinite,
 // NaN, |x - 1| < 2^-20 after scaling) by the full sequence's; callers with several terms in flight run every main half
 // first and the finishes after, so that the terms' instructions interleave.
+// Correctly rounded n / d WITHOUT the scaling and fix-up halves of the IEEE division sequence (v_div_scale x 2, v_div_fmas'
+// scale flag, v_div_fixup): the same reciprocal refinement and the same two correction steps the compiler emits, which IS the
+// whole sequence when neither operand is anywhere near the exponent range's ends (the scale steps multiply by 1, v_div_fmas is
+// a plain fma, v_div_fixup returns the quotient as it is).  Eight instructions instead of eleven.  Callers guarantee normal,
+// finite, non-zero operands whose exponents differ by far less than the format's range.
+__device__ __forceinline__ double spx_fdiv64(double n, double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  const double q = n * r;
+  const double res = __builtin_fma(-d, q, n);
+  return __builtin_fma(res, r, q);
+}
+__device__ __forceinline__ float spx_fdiv32(float n, float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r, 1.0f);
+  r = __builtin_fmaf(e, r, r);
+  float q = n * r;
+  float t = __builtin_fmaf(-d, q, n);
+  q = __builtin_fmaf(t, r, q);
+  t = __builtin_fmaf(-d, q, n);
+  return __builtin_fmaf(t, r, q);
+}
+// (float)sqrt(x) for a double x: the compiler's correctly rounded sequence (v_rsq_f64, one coupled refinement of root and half
+// reciprocal root, two corrections of the root) without its scaling by 2^256 for arguments below 2^-767 and without its
+// selects for zero / infinity -- arguments outside [2^-767, 2^1000], zero among them, take the library sequence.
+__device__ __forceinline__ float spx_sqrt64_to_f32(double x) {
+  if (__builtin_expect(!(x >= 0x1p-767 && x <= 0x1p+1000), 0)) return (float)__builtin_sqrt(x);
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return (float)g;
+}
+
 struct spx_log_parts {
   double res;
   bool rare;
@@ -95,7 +138,9 @@ __device__ __forceinline__ spx_log_parts spx_log_main(double x) {
   k += (i >> 20);
   const double f = xm - 1.0;
   const double dk = (double)k;
-  const double s = f / (2.0 + f);
+  // (2 + f is in [1.7, 2.42]; |f| >= 2^-20 wherever this value is used: the near-one arguments are `rare`.  For them, for zero
+  // and for subnormal x the quotient below is never used -- but it must not trap: f = 0 gives 0 * r = 0, no harm)
+  const double s = spx_fdiv64(f, 2.0 + f);
   const double z = s * s;
   const double w = z * z;
   const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));

@@ -800,3 +800,12 @@ def test_fast_division_equals_the_ieee_quotient():
     for speed in (9.9e17, 3.0e18, 1.0e30):
         outs, _ = compress_batch([x], 16000, 1, speed, 0.0, 0.0, False)
         assert np.array_equal(outs[0], pyorc.compress_sound(x, 16000, 1, speed, 0.0, 0.0, False, chunk=x.size, taps=False)["out"]), speed
+
+
+def test_scale_free_division_and_square_root_equal_the_ieee_sequences():
+    """The analysis kernel's fp32 ratio, fp64 log quotient and fp64 square root run the compiler's IEEE sequences without their
+    scaling / fix-up halves (spx_log.h): 3 x 2^26 pseudo-random operands of the ranges the kernel feeds them, bit for bit."""
+    from speedy_amd._lib import lib
+    L = lib()
+    for seed in (1, 2):
+        assert L.spx_debug_arith_check(seed, 1 << 18, 256) == 0
