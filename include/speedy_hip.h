@@ -176,6 +176,8 @@ int spx_timing_collect(double* sum_ms_analyze, double* sum_ms_walk, int* n_calls
 /* "analysis;tension;walk": the kernels (template arguments included, as a profiler prints them) that serve a batch of
  * n_streams streams with at most max_channels channels; speedup_only = every job has speed > 1. */
 const char* spx_batch_kernel_names(spx_plan_t plan, int n_streams, int max_channels, int speedup_only);
+/* The same with the walk kernel in its lean form (what spx_batch_run_overlapped launches when three or more workspaces take turns). */
+const char* spx_batch_kernel_names_lean(spx_plan_t plan, int n_streams, int max_channels, int speedup_only);
 /* Diagnostics: the form of the walk kernel launched last in this process, 16 * search waves + output waves (68 = the usual
  * 4 + 4, 64 = the lean form of the concurrent mode at 22.05 kHz mono, 32 = the throughput form), 0 = the general kernel. */
 int spx_debug_last_walk_form(void);

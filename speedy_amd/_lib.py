@@ -68,6 +68,7 @@ SYMBOLS = {
     "spx_timing_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "spx_timing_last_tension_ms": (C.c_double, []),
     "spx_batch_kernel_names": (C.c_char_p, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "spx_batch_kernel_names_lean": (C.c_char_p, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "spx_debug_last_walk_form": (C.c_int, []),
     "spx_debug_kernel_vgprs": (C.c_int, [C.c_int]),
     "spx_debug_last_call_concurrent": (C.c_int, []),

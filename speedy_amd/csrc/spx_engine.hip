@@ -669,7 +669,17 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
         return c.lds + spx_tension_lds_bytes() + 2 * spx_analysis_lds_bytes(d) <= lds_u &&
                ((c.waves + 3) / 4) * spx_walk_vgprs(d, n, maxC, speedup_only, lean) + spx_tension_vgprs() + 2 * spx_analysis_vgprs(d) <= 512;
       };
-      if (!fits(wcfg, false) && fits(lc, true)) { lean_walk = true; wcfg = lc; }
+      // ... and when the walk kernels of consecutive calls overlap (spx_batch_run_overlapped) the lean form is the better one
+      // whatever fits: the walk kernels have time to spare there (two in flight, 1.9 ms each, against a period of 1.15), what
+      // the period waits for is the analysis kernel, and beside two LEAN walk workgroups a SIMD holds two analysis waves
+      // (2 x 128 + 2 x 128 registers) where it holds one beside two full ones (4 x 96 + 128): analysis 1.13 -> 0.93 ms,
+      // 1.34 -> 1.15 ms per step on the bench batch.  (SPX_OVERLAP_FULL_WALK=1: the full form, for A/B.)
+      // With only TWO workspaces taking turns a call's producers wait for the walk kernel two calls back, the period is
+      // (walk + analysis) / 2, and the shorter walk kernel of the full form wins (1.39 against 1.43 ms): the ring knows.
+      static const bool full_walk = getenv("SPX_OVERLAP_FULL_WALK") != nullptr;
+      const int two_back = (plan->ahead_calls + 2) & 3;
+      const bool two_workspaces = plan->ev_walk_valid[two_back] && plan->ring_ws[two_back] == ws;
+      if ((!fits(wcfg, false) && fits(lc, true)) || (overlap_req && !full_walk && !two_workspaces && fits(lc, true))) { lean_walk = true; wcfg = lc; }
     }
   }
   const size_t per_stream_lds = wcfg.lds + spx_tension_lds_bytes();
@@ -1339,10 +1349,19 @@ int spx_batch_read_steps_mixed(const spx_plan_t* plans, int n_plans, const spx_s
 
 // Names of the kernels a batch of this shape is served by, as a profiler prints them (without "void" and the argument
 // list): "analysis;tension;walk".  bench.py keys its roofline object and profiles/pmc_traffic.json with them.
+static const char* kernel_names(spx_plan_t plan, int n_streams, int max_channels, int speedup_only, bool lean);
 const char* spx_batch_kernel_names(spx_plan_t plan, int n_streams, int max_channels, int speedup_only) {
+  return kernel_names(plan, n_streams, max_channels, speedup_only, false);
+}
+// ... with the walk kernel in its lean form (no output waves): what spx_batch_run_overlapped launches when three or more
+// workspaces take turns, and the concurrent mode at 22.05 kHz mono
+const char* spx_batch_kernel_names_lean(spx_plan_t plan, int n_streams, int max_channels, int speedup_only) {
+  return kernel_names(plan, n_streams, max_channels, speedup_only, true);
+}
+static const char* kernel_names(spx_plan_t plan, int n_streams, int max_channels, int speedup_only, bool lean) {
   static thread_local char buf[256];
   const SpxPlanDev& d = plan->dev;
-  const SpxWalkConfig c = spx_walk_config(d, n_streams, max_channels < 1 ? 1 : max_channels, speedup_only != 0);
+  const SpxWalkConfig c = spx_walk_config(d, n_streams, max_channels < 1 ? 1 : max_channels, speedup_only != 0, false, lean);
   char walk[96];
   if (c.fast_kernel)
     {
