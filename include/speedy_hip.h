@@ -107,7 +107,8 @@ int spx_batch_run_ahead(spx_plan_t plan, const spx_stream_job* jobs, int n_strea
  * the library's (two, taking turns) and hip_stream only waits for it, so the walk of call k + 1 starts as soon as its own
  * speeds are there, beside the walk of call k -- two walk workgroups per CU run at nearly full speed each, and the longest
  * chains of one batch no longer hold the next batch back (BASELINE configs[3]: 1.60 -> 1.39 ms per batch with two buffer sets
- * taking turns, 1.34 with three: a call's producers then start while the walk kernels of both previous calls are running).
+ * taking turns, 1.16 with three: a call's producers then start while the walk kernels of both previous calls are running, and
+ * the walk kernel is launched in its lean form, which leaves the analysis kernel two waves per SIMD beside two walk workgroups).
  * The price is a RELAXED stream order, on top of spx_batch_run_ahead's contract:
  *   - work the caller enqueues on hip_stream AFTER call k is ordered behind call k's kernels as always (it sees call k's output),
  *     but call k + 1's walk kernel is ordered only behind what was on hip_stream when call k was MADE: whatever the caller
