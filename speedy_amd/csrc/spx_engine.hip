@@ -827,14 +827,19 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   static const bool walk1_env = getenv("SPX_AHEAD_WALK1") != nullptr;
   const bool walk2 = overlap_req && !walk1_env && ahead && !force && !seq_ahead;
   hipStream_t stw = st;   // the stream the walk kernel goes to
+  if (do_w && !force) {
+    // every walking call of the plan notes where the caller's stream stands when it is made (an overlapped call orders its
+    // walk kernel behind the PREVIOUS call's note, whatever kind of call that was)
+    const int cur = plan->ahead_calls & 1;
+    if (!plan->ev_call[cur]) HIPCHK(hipEventCreateWithFlags(&plan->ev_call[cur], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(plan->ev_call[cur], st));
+    plan->ev_call_valid[cur] = true;
+  }
   if (walk2) {
     hipStream_t w0 = nullptr, w1 = nullptr;
     if (dev_walk_streams(plan->device, &w0, &w1)) return fail(-1, "spx_batch: no walk streams");
     const int cur = plan->ahead_calls & 1;
     stw = cur ? w1 : w0;
-    if (!plan->ev_call[cur]) HIPCHK(hipEventCreateWithFlags(&plan->ev_call[cur], hipEventDisableTiming));
-    HIPCHK(hipEventRecord(plan->ev_call[cur], st));        // the caller's stream as it stands now
-    plan->ev_call_valid[cur] = true;
     // whatever the caller had queued by the PREVIOUS call (the consumer of the output this call overwrites, two buffers taking
     // turns) -- not this call's state of the stream, which ends with the wait for the previous call's walk kernel; a caller
     // that hands over the previous call's out / n_out again gets exactly that wait

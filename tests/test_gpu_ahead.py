@@ -303,3 +303,39 @@ def test_one_output_buffer_for_every_call(orc):
         for i in range(b.n):          # the produced frames of every stream (what lies behind them in the shared buffer is the other batch's)
             a, e = b.out_offs[i], b.out_offs[i] + int(cnt[i])
             assert np.array_equal(got[a:e], ref[a:e]), (k, i)
+
+
+def test_plain_calls_between_overlapped_ones_with_consumers(orc):
+    """Two buffer sets, every output consumed (copied) right behind its call, and every third call a plain spx_batch_run: the
+    overlapped call behind a plain one must still wait for the consumer of the buffer it overwrites (the note of where the
+    caller's stream stood is left by every call, not only by overlapped ones)."""
+    import torch
+    from speedy_amd.batch import Plan
+    plan = Plan(16000, False)
+    bs = []
+    for seed in (81, 82):
+        b, _ = _make(plan, 16000, 1, 256, seed, seconds=1.0)
+        b.run()
+        bs.append((b, _crc(b.results())))
+        b.d_out.zero_()
+    torch.cuda.synchronize()
+    copies = []
+    for t in range(12):
+        b = bs[t % 2][0]
+        if t % 3 == 2:
+            b.run()
+        else:
+            b.run_ahead(overlap=True)
+        # a slow consumer: several passes over the output before the copy that is kept
+        scratch = b.d_out.clone()
+        for _ in range(4):
+            scratch = scratch + b.d_out
+        copies.append((t % 2, b.d_out.clone(), b.d_nout.clone(), scratch))
+    torch.cuda.synchronize()
+    for k, o, c, scratch in copies:
+        b = bs[k][0]
+        assert torch.equal(scratch, (o.to(torch.int32) * 5).to(torch.int16)), k
+        keep_o, keep_c = b.d_out, b.d_nout
+        b.d_out, b.d_nout = o, c
+        assert _crc(b.results()) == bs[k][1], k
+        b.d_out, b.d_nout = keep_o, keep_c
