@@ -339,3 +339,43 @@ def test_plain_calls_between_overlapped_ones_with_consumers(orc):
         b.d_out, b.d_nout = o, c
         assert _crc(b.results()) == bs[k][1], k
         b.d_out, b.d_nout = keep_o, keep_c
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_call_sequences(orc, seed):
+    """Four batches of different content, sixty calls in a random order (a batch may come twice in a row, or after one, two or
+    three others), each call plain, pipelined or overlapped at random, every output copied right behind its own call: every copy
+    must hold what spx_batch_run gives for that batch."""
+    import torch
+    from speedy_amd.batch import Plan
+    rng = np.random.default_rng(1000 + seed)
+    rate = int(rng.choice([16000, 16000, 22050]))
+    plan = Plan(rate, False)
+    bs = []
+    for j in range(4):
+        b, _ = _make(plan, rate, 1, int(rng.choice([256, 256, 131])), 90 + 10 * seed + j, seconds=float(rng.uniform(0.5, 1.2)))
+        b.run()
+        bs.append((b, _crc(b.results())))
+        b.d_out.zero_()
+    torch.cuda.synchronize()
+    copies = []
+    for t in range(60):
+        k = int(rng.integers(0, 4))
+        b = bs[k][0]
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            b.run()
+        elif kind == 1:
+            b.run_ahead()
+        else:
+            b.run_ahead(overlap=True)
+        copies.append((k, b.d_out.clone(), b.d_nout.clone()))
+        if rng.integers(0, 8) == 0:
+            torch.cuda.synchronize()       # a pause now and then: the pipeline drains and fills again
+    torch.cuda.synchronize()
+    for t, (k, o, c) in enumerate(copies):
+        b = bs[k][0]
+        keep_o, keep_c = b.d_out, b.d_nout
+        b.d_out, b.d_nout = o, c
+        assert _crc(b.results()) == bs[k][1], (seed, t, k)
+        b.d_out, b.d_nout = keep_o, keep_c
