@@ -290,79 +290,56 @@ def spawn_ranks(args):
     sys.exit(rc)
 
 
-def pcie_pipeline(plan, streams, n, reps, warm=3, nbuf=None, ahead=None):
-    """PCIe-inclusive steady state (SURVEY.md 8d "first write to last drained read"): pinned host input -> HBM, the step,
-    a device-side gather of the produced frames, one copy to pinned host memory -- `nbuf` sets of device buffers on three HIP
-    streams, so that the H2D of later batches and the D2H of earlier ones overlap the step of batch k.
-    ahead (environment SPX_BENCH_PCIE=ahead; NOT the default): consecutive steps software-pipelined by the library
-    (spx_batch_run_ahead_when with the H2D's event) on three sets of buffers.  Measured: 2.35 ms per batch with two sets (the
-    copy-in of batch k + 1 can only start when step k - 1 has finished with its buffer, so the analysis behind it comes too late
-    to run beside step k) and 2.3-3.5 with three (this loop waits on the host for step k - 1 before it issues batch k + 1)
-    against a steady 2.0-2.1 for plain calls on two sets: the default.
-    Returns seconds per batch."""
+PCIE_LINK_PEAK_GBS = 63.0   # PCIe 5.0 x16, one direction: 32 GT/s x 16 lanes x 128/130 / 8 (the link the MI355X OAM sits on)
+
+
+def pcie_pipeline(plan, streams, n, reps=200, warm=50, depth=4):
+    """PCIe-inclusive STEADY STATE (SURVEY.md 8d "first write to last drained read"; the reference's caller loop,
+    speedy_wave.cc:199-220, with a batch of streams as its unit) on the library's owning pipeline object (spx_pipeline,
+    include/speedy_hip.h): pinned host input -> spx_pipeline_submit -> spx_pipeline_wait -> the produced frames of every stream,
+    densely packed, in pinned host memory.  The library issues the H2D copy, the overlapped batch call and the gather into host
+    memory itself; this loop only submits and, `depth - 1` tickets later, waits -- so up to `depth` batches are in flight.
+    Timed over `reps` batches after `warm` untimed ones WITHOUT a pause in between: the figure is the interval between the
+    completions of ticket warm - 1 and ticket warm + reps - 1, i.e. the pipeline's output rate in its steady phase.
+    Returns a dict (seconds per batch, per-batch completion intervals, the H2D link rate measured alone, CRCs of the last batch)."""
     import torch
-    from speedy_amd.batch import Batch
-    if ahead is None:
-        ahead = os.environ.get("SPX_BENCH_PCIE", "plain") == "ahead"
-    if nbuf is None:
-        nbuf = int(os.environ.get("SPX_BENCH_PCIE_NBUF", "4" if ahead else "2"))
-    lag = int(os.environ.get("SPX_BENCH_PCIE_LAG", "2" if ahead else "1"))   # the host drains batch k - lag after issuing batch k
-    bs = [Batch(plan, [n] * len(streams), 1, SPEED, 1.0, 0.0) for _ in range(nbuf)]
-    h_in = torch.empty(bs[0].d_in.numel(), dtype=torch.int16).pin_memory()
-    h_in.zero_()
-    off = 0
-    for x in streams:
-        h_in[off:off + x.size] = torch.from_numpy(x)
-        off += x.size
-    h_out = [torch.zeros(b.d_out.numel(), dtype=torch.int16).pin_memory() for b in bs]
-    h_offs = [torch.zeros(b.n + 1, dtype=torch.int64).pin_memory() for b in bs]
-    s_h2d, s_run, s_d2h = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
-    ev_in = [torch.cuda.Event() for _ in bs]
-    ev_done = [torch.cuda.Event() for _ in bs]
-    ev_out = [torch.cuda.Event() for _ in bs]
-    packed = [None] * nbuf
-    totals = []
-    t0 = 0.0
-
-    def drain(k):  # output of batch k: wait for its step (long finished in steady state), then one D2H of the exact size
-        i = k % nbuf
-        ev_done[i].synchronize()
-        total = int(h_offs[i][-1])
-        totals.append(total)
-        with torch.cuda.stream(s_d2h):
-            h_out[i][:total].copy_(packed[i][:total], non_blocking=True)
-            ev_out[i].record(s_d2h)
-
-    for k in range(warm + reps):
-        if k == warm:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        i = k % nbuf
-        with torch.cuda.stream(s_h2d):
-            if k >= nbuf:
-                s_h2d.wait_event(ev_done[i])      # the step of batch k - nbuf has finished reading this input buffer
-            bs[i].d_in.copy_(h_in, non_blocking=True)
-            ev_in[i].record(s_h2d)
-        with torch.cuda.stream(s_run):
-            if k >= nbuf:
-                s_run.wait_event(ev_out[i])       # the output of batch k - nbuf has left this buffer
-            if ahead:
-                bs[i].run_ahead(stream=s_run, in_ready=ev_in[i])   # (its producers wait for the copy-in themselves)
-            else:
-                s_run.wait_event(ev_in[i])
-                bs[i].run(stream=s_run)
-            packed[i], d_offs = bs[i].pack_outputs(stream=s_run)
-            h_offs[i].copy_(d_offs, non_blocking=True)
-            ev_done[i].record(s_run)
+    from speedy_amd.batch import Pipeline
+    pipe = Pipeline(plan, [n] * len(streams), 1, SPEED, 1.0, 0.0, depth=depth)
+    h_in = torch.from_numpy(pipe.pack(streams)).pin_memory()
+    # the link alone: the same 82 MB, host to device, copy after copy on one stream (the floor of this leg)
+    d_probe = torch.empty(h_in.numel(), dtype=torch.int16, device="cuda")
+    s_probe = torch.cuda.Stream()
+    with torch.cuda.stream(s_probe):
+        for _ in range(5):
+            d_probe.copy_(h_in, non_blocking=True)
+        s_probe.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            d_probe.copy_(h_in, non_blocking=True)
+        s_probe.synchronize()
+    h2d_alone_s = (time.perf_counter() - t0) / 20
+    del d_probe
+    lag = pipe.depth - 1
+    tickets, done = [], []
+    total = warm + reps
+    for k in range(total):
+        tickets.append(pipe.submit(h_in))
         if k >= lag:
-            drain(k - lag)
-    for k in range(max(0, warm + reps - lag), warm + reps):
-        drain(k)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    last = (warm + reps - 1) % nbuf   # what arrived in host memory is what the device packed (outside the timed region)
-    assert torch.equal(h_out[last][:totals[-1]], packed[last][:totals[-1]].cpu()), "PCIe pipeline: host copy differs"
-    return dt, totals[-1]
+            pipe.wait(tickets[k - lag])        # the drained read: batch k - lag is in host memory
+            done.append(time.perf_counter())
+    for t in tickets[total - lag:]:
+        pipe.wait(t)
+        done.append(time.perf_counter())
+    dt = (done[total - 1] - done[warm - 1]) / reps
+    iv = np.diff(np.asarray(done[warm - 1:total])) * 1e3
+    outs = pipe.results(tickets[-1])
+    res = {"dt": dt, "total": int(sum(o.size for o in outs)), "crcs": [zlib.crc32(np.ascontiguousarray(o).tobytes()) for o in outs],
+           "h2d_alone_s": h2d_alone_s, "depth": pipe.depth, "reps": reps, "warm": warm,
+           "interval_ms": {"p10": float(np.percentile(iv, 10)), "p50": float(np.percentile(iv, 50)), "p90": float(np.percentile(iv, 90)),
+                           "max": float(iv.max())},
+           "walk_form": int(plan.L.spx_debug_last_walk_form()), "last_mode": int(plan.L.spx_debug_last_call_concurrent())}
+    pipe.close()
+    return res
 
 
 def standalone_analysis_ms(plan, batch, reps=10, warm=3):
@@ -435,11 +412,10 @@ def main():
         streams_ = make_streams(STREAMS_PER_GPU, n_, rk)
         if os.environ.get("SPX_SHARED_GPU"):
             pass   # (ranks sharing a GPU: the engine runs its kernels in sequence, as in the parent)
-        # (SPX_BENCH_PCIE_WARM: a longer untimed lead-in.  Measured: 3 batches -> 2.02 ms per batch, 200 batches -> 2.21: the
-        # pipeline settles into a slower phase relation of its three streams after some tenths of a second; the leg keeps the
-        # short window every other leg of this file uses.)
-        dt_, total_ = pcie_pipeline(plan_, streams_, n_, reps=reps, warm=int(os.environ.get("SPX_BENCH_PCIE_WARM", "3")))
-        print(json.dumps({"dt": dt_, "total": total_}), flush=True)
+        # (round 5: the steady phase -- >= 200 timed batches behind >= 50 untimed ones, no pause between them)
+        res_ = pcie_pipeline(plan_, streams_, n_, reps=max(200, reps), warm=int(os.environ.get("SPX_BENCH_PCIE_WARM", "50")),
+                             depth=int(os.environ.get("SPX_BENCH_PCIE_DEPTH", "4")))
+        print(json.dumps(res_), flush=True)
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -463,8 +439,7 @@ def main():
                                 "%d,%d,%d" % (dev_index, rank, max(10, args.steps))], capture_output=True, text=True, timeout=900)
         if child.returncode != 0:
             sys.exit("bench.py: the PCIe leg failed: " + child.stderr[-1500:])
-        res = json.loads([ln for ln in child.stdout.splitlines() if ln.startswith("{")][-1])
-        pcie_early = (res["dt"], res["total"])
+        pcie_early = json.loads([ln for ln in child.stdout.splitlines() if ln.startswith("{")][-1])
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (the product has no CPU path)")
     torch.cuda.set_device(dev_index)
@@ -538,23 +513,31 @@ def main():
     # the walk kernels of consecutive steps overlap too (two streams of the library's taking turns).
     # Every step is the whole hot path over one batch of 256 streams; nothing is cached or skipped.  (--no-pipeline: one
     # Batch, spx_batch_run call after call, as rounds 1-4 timed it; reported as `unpipelined` in every line.)
-    b2 = b3 = None
+    # Round 5: through the library's OWNING pipeline object (spx_pipeline, include/speedy_hip.h) -- the same object the
+    # PCIe-inclusive leg runs on, here with the input resident in HBM (spx_pipeline_submit(.., in_is_device = 1)) and the outputs
+    # left in device memory (SPX_PIPELINE_DEVICE_OUT): the buffer sets, the streams and the relaxed stream order are the
+    # library's business, not this file's.
+    pipe = None
+    tickets = []
     if not args.no_pipeline:
-        # THREE sets of buffers taking turns: with two, a step's producers wait for the walk kernel two steps back (the last user
-        # of their workspace); with three they start while the walk kernels of both previous steps are still running
-        # (1.385 -> 1.33 ms per step)
-        b2 = Batch(plan, [n] * STREAMS_PER_GPU, 1, SPEED, 1.0, 0.0)
-        b2.d_in.copy_(b.d_in)
-        b3 = Batch(plan, [n] * STREAMS_PER_GPU, 1, SPEED, 1.0, 0.0)
-        b3.d_in.copy_(b.d_in)
-    turn = [b, b2, b3] if b2 is not None else [b]
+        from speedy_amd.batch import Pipeline
+        pipe = Pipeline(plan, [n] * STREAMS_PER_GPU, 1, SPEED, 1.0, 0.0, depth=int(os.environ.get("SPX_BENCH_DEPTH", "4")), device_out=True)
 
     def step(k):
-        q = turn[k % len(turn)]
-        q.run_ahead(overlap=True) if b2 is not None else q.run()
+        if pipe is not None:
+            tickets.append(pipe.submit(b.d_in))
+        else:
+            b.run()
 
     # the unpipelined figure (also warms up); --no-unpipelined: profiling runs, whose per-kernel averages should be the timed loop's
     dt_single = None if args.no_unpipelined else time_window(b.run, reps=max(5, args.steps), warm=max(3, args.warmup))
+    if dt_single is None:
+        # (the batch whose outputs and chain lengths the line reports; its kernels in sequence: a profiler that serialises kernels
+        # must not meet the concurrent mode's polling kernels)
+        L.spx_set_concurrent(0)
+        b.run()
+        torch.cuda.synchronize()
+        L.spx_set_concurrent(0 if args.serial else 1)
     for k in range(args.warmup):
         step(k)
     barrier()
@@ -573,10 +556,11 @@ def main():
     ms_tension = float(L.spx_timing_last_tension_ms()) / max(1, nc.value)
     dt = max_over_ranks(dt)
     n_in = n * STREAMS_PER_GPU
+    walk_form = int(L.spx_debug_last_walk_form())
     outs = b.results()
-    if b2 is not None:   # both turns of the pipeline produced the same bytes
-        for q in (b2, b3):
-            outs2 = q.results()
+    if pipe is not None:   # every buffer set of the pipeline holds the plain call's bytes
+        for t in tickets[-pipe.depth:]:
+            outs2 = pipe.results(t)
             assert len(outs2) == len(outs) and all(np.array_equal(x, y) for x, y in zip(outs, outs2)), "the batches of the pipelined loop differ"
             del outs2
     n_out = int(sum(o.size for o in outs))
@@ -624,15 +608,30 @@ def main():
     pcie = None
     if not args.no_pcie:
         barrier()
-        dt1, total = pcie_early
+        dt1, total = pcie_early["dt"], pcie_early["total"]
         assert total == n_out, (total, n_out)
+        # what arrived in host memory is what the resident steps produce, stream by stream
+        assert pcie_early["crcs"] == [zlib.crc32(np.ascontiguousarray(o).tobytes()) for o in outs], "PCIe leg: outputs differ from the resident steps'"
         dt1 = max_over_ranks(dt1)
+        in_bytes, out_bytes = 2 * n_in, 2 * n_out
         pcie = {"value": n_in * world / dt1 / 1e6, "unit": "Msamples/s", "ms_per_step": dt1 * 1e3,
                 "vs_resident_step": dt1 / (dt / args.steps),
-                "note": "every rank, MAX over ranks: pinned host int16 input -> HBM, the step, device-side gather, one D2H "
-                        "of the produced int16 output; double-buffered on three HIP streams (H2D of batch k+1 and D2H "
-                        "of batch k-1 overlap the step of batch k); one window of %d batches; plain spx_batch_run calls; the leg "
-                        "runs first, in a child process, before this process touches the GPU" % max(10, args.steps)}
+                "batches_timed": pcie_early["reps"], "batches_warmup": pcie_early["warm"], "buffer_sets": pcie_early["depth"],
+                "completion_interval_ms": pcie_early["interval_ms"],
+                # the fourth roofline of the line: the host-to-device link (the input is 3x the output: H2D is the busier direction)
+                "link": {"bound": "pcie_h2d", "h2d_gbs": in_bytes / dt1 / 1e9, "d2h_gbs": out_bytes / dt1 / 1e9,
+                         "link_peak_gbs": PCIE_LINK_PEAK_GBS, "frac": in_bytes / dt1 / 1e9 / PCIE_LINK_PEAK_GBS,
+                         "h2d_alone_gbs": in_bytes / pcie_early["h2d_alone_s"] / 1e9,
+                         "h2d_alone_ms": pcie_early["h2d_alone_s"] * 1e3,
+                         "frac_of_h2d_alone": pcie_early["h2d_alone_s"] / dt1,
+                         "peak_source": "PCIe 5.0 x16, one direction: 32 GT/s x 16 lanes x 128/130 / 8 = 63 GB/s; h2d_alone = the same "
+                                        "82 MB copied host -> device back to back with nothing else running (the floor of this leg)"},
+                "note": "every rank, MAX over ranks: pinned host int16 input -> spx_pipeline_submit -> spx_pipeline_wait -> the produced "
+                        "int16 frames of all streams in pinned host memory (include/speedy_hip.h: the library's owning pipeline object "
+                        "issues the H2D copy, the overlapped batch call and the gather into host memory itself; %d buffer sets); the "
+                        "steady phase: the interval between the completions of batch %d and batch %d, no pause before the timed window; "
+                        "the leg runs first, in a child process, before this process touches the GPU; every stream's output CRC equals "
+                        "the resident steps'" % (pcie_early["depth"], pcie_early["warm"], pcie_early["warm"] + pcie_early["reps"])}
 
     # BASELINE configs[4].  (1) WEAK: every rank one GPU's shard of 256 mixed streams (global streams 256 r .. 256 r + 255) in
     # one call.  (2) STRONG: the fixed batch of --total-streams streams, rank r of N its contiguous block, one call per rank.
@@ -693,7 +692,7 @@ def main():
         algo_bytes = 2 * 1 * (n_in + n_out)  # int16 read once + int16 written once, per launch
         # the kernels that served the batch, by the names a profiler prints (template arguments included)
         # (the pipelined loop on three workspaces launches the walk kernel in its lean form)
-        names_fn = L.spx_batch_kernel_names_lean if (b2 is not None and last_mode == 2) else L.spx_batch_kernel_names
+        names_fn = L.spx_batch_kernel_names_lean if (pipe is not None and last_mode == 2 and walk_form == 16 * 4) else L.spx_batch_kernel_names
         k_analysis, k_tension, k_walk = names_fn(plan.h, STREAMS_PER_GPU, 1, 1).decode().split(";")
         dom, dom_ms = (k_walk, ms_walk) if ms_walk >= ms_analyze else (k_analysis, ms_analyze)
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -734,6 +733,25 @@ def main():
                                    "the path cannot contract to FMA: its rounding points are the reference's (-ffp-contract=off)",
                     "definition": "fp64 operations of the DFT spec per frame (tools/flop_count.py, profiles/flop_model.json) x frames / "
                                   "the analysis kernel ALONE (spx_batch_analyze, one window of 10 launches, HIP events)"}
+        # The roofline that BINDS the pipelined loop (round-4 review): every wave64 VALU instruction occupies its SIMD for 4 cycles,
+        # so the three kernels' VALU wave-instructions per batch (SQ_INSTS_VALU, profiles/sq_counters.json, tools/sq_counters.sh)
+        # x 4 / (SIMDs x clock) is the least time a batch can take whatever overlaps with whatever.
+        valu_issue = None
+        sq = load_json("sq_counters.json")
+        if sq:
+            cnt = sq.get("counters", {})
+            per = {k: cnt.get(k, {}).get("SQ_INSTS_VALU") for k in (k_analysis, k_tension, k_walk)}
+            if all(v is not None for v in per.values()):
+                cus = int(torch.cuda.get_device_properties(dev_index).multi_processor_count)
+                simds = 4 * cus
+                floor_ms = sum(per.values()) * 4.0 / simds / (clock_mhz * 1e6) * 1e3
+                valu_issue = {"bound": "VALU issue (wave64 instructions x 4 cycles per SIMD)", "valu_wave_insts_per_batch": per,
+                              "simds": simds, "clock_mhz": clock_mhz, "floor_ms_per_step": floor_ms, "ms_per_step": ms_step,
+                              "frac": floor_ms / ms_step, "hbm_frac_at_floor": algo_bytes / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "source": "profiles/sq_counters.json (" + str(sq.get("note", ""))[:160] + ")",
+                              "definition": "sum of SQ_INSTS_VALU of the step's three kernels x 4 cycles / (SIMDs x clock) / ms_per_step: the "
+                                            "share of the step during which every SIMD of the chip would have to issue a vector instruction; "
+                                            "hbm_frac_at_floor = the HBM fraction the path would reach AT this bound"}
         line = {
             "metric": "Msamples/s processed (16 kHz mono, 3.5x nonlinear)",
             "value": total_in / dt / 1e6, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -742,15 +760,17 @@ def main():
                                 "first-write-to-last-drained-read rate is `pcie_inclusive`, the drop-in API's rate with 256 "
                                 "live sonicStream handles is `api_256_handles`.  ONE rule for every figure in this line: a single "
                                 "timed window of consecutive steps after untimed warm-up steps -- no best-of-N anywhere.  "
-                                + ("Consecutive steps are software-pipelined by the library (spx_batch_run_overlapped): three batches with the "
-                                   "same resident input take turns, step k+1's analysis and tension kernels run beside step k's walk "
-                                   "kernel and the walk kernels of consecutive steps overlap (so `roofline.kernel_avg_launch_ms` of the "
-                                   "walk kernel is LONGER than `ms_per_step`); every step is the whole hot path over one batch.  `unpipelined` is spx_batch_run on one "
-                                   "batch, call after call (what rounds 1-4 reported as `value`)" if b2 is not None else
+                                + ("The timed steps go through the library's owning pipeline object (spx_pipeline: submit after submit "
+                                   "of the resident input, outputs left in device memory; config.buffer_sets buffer sets owned by the "
+                                   "library): step k+1's analysis and tension kernels run beside step k's walk kernel and the walk "
+                                   "kernels of consecutive steps overlap (so `roofline.kernel_avg_launch_ms` of the walk kernel is LONGER "
+                                   "than `ms_per_step`); every step is the whole hot path over one batch.  config.unpipelined_ms_per_step "
+                                   "is spx_batch_run on one batch, call after call (what rounds 1-4 reported as `value`)" if pipe is not None else
                                    "spx_batch_run on one batch, call after call (--no-pipeline)"),
-            "pipelined": b2 is not None and last_mode == 2,
+            "pipelined": pipe is not None and last_mode == 2,
             "launch_mode_of_the_timed_calls": {2: "pipelined with the previous call (spx_batch_run_overlapped)", 1: "three kernels side by side",
                                                0: "kernels in sequence"}.get(last_mode, str(last_mode)),
+            "walk_form": {68: "4 search + 4 output waves", 64: "lean: 4 search waves that also do the output work", 32: "throughput form"}.get(walk_form, str(walk_form)),
             "unpipelined": None if dt_single is None else
                            {"ms_per_step": dt_single * 1e3, "value": n_in * world / dt_single / 1e6, "unit": "Msamples/s",
                             "note": "spx_batch_run on ONE batch, call after call (its three kernels side by side, the walk "
@@ -761,6 +781,13 @@ def main():
             "config": {"workload": "BASELINE configs[3]: %d streams/GPU x %d s, 16 kHz mono int16, speed 3.5, "
                                    "nonlinear 1.0, feedback 0" % (STREAMS_PER_GPU, SECONDS),
                        "streams_per_gpu": STREAMS_PER_GPU, "samples_per_stream": n,
+                       # how `value` was produced, where a parsed record finds it (round-4 review): the like-for-like figure of rounds
+                       # 1-4, the buffer sets the library owns for the pipelined steps, the walk kernels in flight at a time
+                       "unpipelined_ms_per_step": None if dt_single is None else dt_single * 1e3,
+                       "buffer_sets": (pipe.depth if pipe is not None else 1),
+                       "walk_launches_in_flight": (2 if (pipe is not None and last_mode == 2) else 1),
+                       "timed_through": ("spx_pipeline_submit (device-resident input, SPX_PIPELINE_DEVICE_OUT)" if pipe is not None else "spx_batch_run"),
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "parallelism": "streams sharded %d/GPU, no data-path collective" % STREAMS_PER_GPU,
                        "launcher": "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else
                                    ("bench.py --gpus (self-spawned ranks)" if world > 1 else "single process"),
@@ -789,7 +816,7 @@ def main():
                                     "workgroup per CU (DESIGN.md 5.3, 6); `bound` names the roofline the contract asks "
                                     "to be priced against; `latency` and `valu_fp64` are the rooflines that bound the two "
                                     "big kernels, `large_batch.hbm` the HBM fraction where the path is throughput-bound",
-                         "latency": latency, "valu_fp64": valu},
+                         "latency": latency, "valu_fp64": valu, "valu_issue": valu_issue},
         }
         if large is not None:
             line["large_batch"] = large

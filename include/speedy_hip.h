@@ -94,11 +94,13 @@ int spx_batch_run(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, co
  * analysis and tension kernels are enqueued on a stream of the library's and start AT ONCE -- beside the walk kernel of the
  * previous call, which is still running on hip_stream -- and its own walk kernel follows on hip_stream with every speed ready.
  * Same results as spx_batch_run.  The caller's side of the contract:
- *   - `in` is complete in device memory when the call is made (the analysis does not wait for work queued on hip_stream);
+ *   - `in` is complete in device memory when the call is made (the analysis does not wait for work queued on hip_stream), and
+ *     nothing still pending on hip_stream touches workspace, taps, out or n_out: the call's staging, analysis and tension kernels
+ *     write the workspace and the taps on the library's stream at once;
  *   - consecutive calls alternate (at least) two workspaces / out / n_out buffers; a call that hands over the previous call's
  *     workspace again waits for that call to finish instead (correct, no overlap);
  *   - hip_stream is the same stream call after call; when it has drained, every kernel of every call issued on it has.
- * Batches that do not fit the shape (more streams than CUs, taps of many kinds ...) run exactly as spx_batch_run would. */
+ * Batches that do not fit the shape (more streams than CUs, kernels that do not fit side by side ...) run exactly as spx_batch_run would. */
 int spx_batch_run_ahead(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, const int16_t* in,
                         int16_t* out, int64_t* n_out, void* workspace, size_t workspace_bytes,
                         const spx_taps* taps, void* hip_stream);
@@ -126,6 +128,55 @@ int spx_batch_run_overlapped(spx_plan_t plan, const spx_stream_job* jobs, int n_
 int spx_batch_run_ahead_when(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, const int16_t* in,
                              int16_t* out, int64_t* n_out, void* workspace, size_t workspace_bytes,
                              const spx_taps* taps, void* hip_stream, void* in_ready_event);
+
+/* ---- the owning pipeline (round 5): batch after batch of one shape, host memory to host memory ----
+ * What the reference's caller loop does per stream -- write a chunk, read what is ready, again (speedy_wave.cc:154-242) -- for a
+ * caller that feeds BATCHES: spx_pipeline_submit hands over one batch of input (host or device memory), spx_pipeline_wait returns
+ * that batch's output.  The object OWNS everything in between: `depth` sets of device buffers (input, output, workspace), pinned
+ * host buffers for the output, its HIP streams and events.  Inside, the library issues the host-to-device copy, the three kernels
+ * in the overlapped order of spx_batch_run_overlapped (batch k + 1's analysis beside batch k's walk kernel, the walk kernels of
+ * consecutive batches overlapping) and a gather kernel that writes the produced frames of all streams, densely packed, straight
+ * into pinned host memory -- no device-to-host copy is enqueued and no host thread waits inside submit, so copies in, kernels and
+ * copies out of up to `depth` batches are in flight at once.  The relaxed stream order that spx_batch_run_overlapped asks its
+ * caller to respect is an implementation detail here: nobody else can touch the buffers.
+ *   jobs      the shape of every batch: n_in, channels, speed, nonlinear, feedback and in_off (where stream i starts in a batch's
+ *             input, in int16 values); out_off / out_cap are ignored (the pipeline lays the outputs out itself, capacity =
+ *             spx_plan_out_capacity_for)
+ *   plans / plan_index   as in spx_batch_run_mixed, for batches that mix sample rates (spx_pipeline_create: one plan)
+ *   depth     buffer sets, 2 .. 8 (0 = the default, 4); 3 or more let the walk kernels of consecutive batches overlap fully
+ *   flags     SPX_PIPELINE_DEVICE_OUT: the outputs stay in device memory (no gather, no copy out)
+ * Not thread-safe: one host thread (or external locking) per pipeline; several pipelines may be alive at once. */
+typedef struct spx_pipeline* spx_pipeline_t;
+#define SPX_PIPELINE_DEVICE_OUT 1u
+spx_pipeline_t spx_pipeline_create(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, int depth, unsigned flags);
+spx_pipeline_t spx_pipeline_create_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index,
+                                         int n_streams, int depth, unsigned flags);
+void spx_pipeline_destroy(spx_pipeline_t p);
+int spx_pipeline_depth(spx_pipeline_t p);
+/* int16 values of one batch's input: max over streams of in_off + n_in * channels. */
+size_t spx_pipeline_input_values(spx_pipeline_t p);
+/* Pinned host staging (spx_pipeline_input_values() int16 values) for the batch the NEXT submit hands over: a caller that produces
+ * its input there saves a host copy and gets the full link rate.  Blocks until the copy that last read this buffer (`depth`
+ * submits ago) has finished.  Any other host pointer (pinned or pageable) may be given to submit as well. */
+int16_t* spx_pipeline_host_input(spx_pipeline_t p);
+/* Hand over one batch.  in: HOST memory (in_is_device = 0) -- must stay unchanged until the batch's input has been copied
+ * (spx_pipeline_input_consumed, or the batch's spx_pipeline_wait) -- or DEVICE memory (in_is_device = 1), complete when the call is
+ * made and unchanged until the batch's spx_pipeline_wait returns.  Returns the batch's ticket (0, 1, 2 ...) or a negative error.
+ * At most `depth` batches are in flight: the call waits for the batch `depth` tickets back first. */
+int64_t spx_pipeline_submit(spx_pipeline_t p, const int16_t* in, int in_is_device);
+int spx_pipeline_input_consumed(spx_pipeline_t p, int64_t ticket);
+/* Wait for a batch.  On return
+ *   *out      the output samples: pinned HOST memory owned by the pipeline (DEVICE memory with SPX_PIPELINE_DEVICE_OUT)
+ *   *offsets  HOST int64[n_streams + 1]: stream i's samples are out[offsets[i] .. offsets[i] + counts[i] * channels[i]); every
+ *             offset is a multiple of 32 values (64 bytes); offsets[n_streams] = the extent of the packed output
+ *   *counts   int64[n_streams]: produced frames per stream as spx_batch_run's n_out (negative = capacity overflow); HOST memory,
+ *             DEVICE memory with SPX_PIPELINE_DEVICE_OUT
+ * valid until `depth` more batches have been submitted.  Tickets may be waited for in any order, each at most once per buffer
+ * life; a ticket whose buffers have been handed to a later batch returns an error. */
+int spx_pipeline_wait(spx_pipeline_t p, int64_t ticket, const int16_t** out, const int64_t** offsets, const int64_t** counts);
+/* Pinned host memory for callers without HIP headers (the input of spx_pipeline_submit at the full link rate). */
+void* spx_host_alloc(size_t bytes);
+void spx_host_free(void* p);
 
 /* The two stages separately (same arguments); spx_batch_run = analyze then walk. */
 int spx_batch_analyze(spx_plan_t plan, const spx_stream_job* jobs, int n_streams, const int16_t* in,
@@ -192,6 +243,12 @@ int spx_debug_kernel_vgprs(int which);
  * size): the engine's choice of launch mode is arithmetic over them. */
 int spx_debug_walk_info(int sample_rate, int channels, int n_streams, int speedup_only, int short_jobs, int lean, int* out5);
 int spx_debug_analysis_info(int sample_rate, int* out3);
+/* Diagnostics: the 22 resource numbers the engine's launch-mode decision (speedy_amd/csrc/spx_mode.h, a pure function) is fed for a
+ * batch of this shape: CUs, LDS per CU, the walk kernel's form as picked and in its lean form (LDS, waves, VGPRs, fast kernel?, output
+ * waves; lean form exists?), the tension kernel's LDS and VGPRs, the analysis tiles (the plan's, 16, 8 frames) and the analysis
+ * kernel's LDS and VGPRs with the plan's tile and with the small one.  profiles/kernel_resources.json holds them for the shapes
+ * tests/test_mode_table.py decides on the CPU. */
+int spx_debug_mode_resources(int sample_rate, int channels, int n_streams, int speedup_only, long long* out22);
 /* Diagnostics: the walk kernel's five-instruction division for the candidate step lengths against the IEEE quotient, for
  * `denominators` random speeds (speed - 1 log-uniform in [2^exp_lo, 2^exp_hi)) x every count 1 .. 4096 x both numerator forms;
  * returns the number of mismatches (0 is the only acceptable answer), -1 on a runtime error. */

@@ -76,6 +76,18 @@ SYMBOLS = {
     "spx_debug_arith_check": (C.c_longlong, [C.c_uint, C.c_uint, C.c_uint]),
     "spx_debug_walk_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "spx_debug_analysis_info": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "spx_debug_mode_resources": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)]),
+    "spx_pipeline_create": (C.c_void_p, [C.c_void_p, C.POINTER(StreamJob), C.c_int, C.c_int, C.c_uint]),
+    "spx_pipeline_create_mixed": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(StreamJob), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_uint]),
+    "spx_pipeline_destroy": (None, [C.c_void_p]),
+    "spx_pipeline_depth": (C.c_int, [C.c_void_p]),
+    "spx_pipeline_input_values": (C.c_size_t, [C.c_void_p]),
+    "spx_pipeline_host_input": (C.c_void_p, [C.c_void_p]),
+    "spx_pipeline_submit": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int]),
+    "spx_pipeline_input_consumed": (C.c_int, [C.c_void_p, C.c_int64]),
+    "spx_pipeline_wait": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "spx_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "spx_host_free": (None, [C.c_void_p]),
     "spx_device_alloc": (C.c_void_p, [C.c_size_t]),
     "spx_device_free": (None, [C.c_void_p]),
     "spx_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -307,6 +307,128 @@ class MixedBatch:
                     features=self.t_features[fo * 15:(fo + K) * 15].cpu().numpy().reshape(K, 15))
 
 
+class Pipeline:
+    """spx_pipeline (include/speedy_hip.h): batch after batch of ONE shape, host memory to host memory -- the library owns the
+    device buffer sets, the pinned output buffers, its streams and events, and overlaps copies in, kernels and copies out of up
+    to `depth` batches.  The caller loop of the reference (speedy_wave.cc:154-242: write a chunk, read what is ready) for a caller
+    whose unit is a batch of streams.
+
+        pipe = Pipeline(plan, lengths, channels, speed)
+        t = pipe.submit(x)            # x: packed int16 input of one batch (numpy / pinned torch tensor; device tensor: device=True)
+        outs = pipe.results(t)        # list of per-stream int16 arrays (copies); pipe.wait(t) returns the raw views
+
+    plans / plan_index: a batch that mixes sample rates (spx_pipeline_create_mixed)."""
+
+    def __init__(self, plan, lengths, channels, speed, nonlinear=1.0, feedback=0.0, depth=0, device_out=False, plan_index=None):
+        plans = list(plan) if isinstance(plan, (list, tuple)) else [plan]
+        self.plans = plans
+        self.L = plans[0].L
+        n = len(lengths)
+        self.n = n
+        ch = np.broadcast_to(np.asarray(channels, np.int32), (n,)).copy()
+        sp = np.broadcast_to(np.asarray(speed, np.float32), (n,)).copy()
+        nlv = np.broadcast_to(np.asarray(nonlinear, np.float32), (n,)).copy()
+        fb = np.broadcast_to(np.asarray(feedback, np.float32), (n,)).copy()
+        self.lengths, self.channels = np.asarray(lengths, np.int64), ch
+        self.jobs = (StreamJob * n)()
+        self.in_offs = []
+        in_off = 0
+        for i in range(n):
+            j = self.jobs[i]
+            j.in_off, j.n_in, j.out_off, j.out_cap = in_off, int(self.lengths[i]), 0, 0   # (the pipeline lays the outputs out itself)
+            j.channels, j.speed, j.nonlinear, j.feedback = int(ch[i]), float(sp[i]), float(nlv[i]), float(fb[i])
+            self.in_offs.append(in_off)
+            in_off += int(self.lengths[i]) * int(ch[i])
+        self.total_in = in_off
+        self.device_out = bool(device_out)
+        flags = 1 if device_out else 0
+        if plan_index is None and len(plans) == 1:
+            self.h = self.L.spx_pipeline_create(plans[0].h, self.jobs, n, int(depth), flags)
+        else:
+            self._pidx = (C.c_int * n)(*[int(v) for v in (plan_index if plan_index is not None else [0] * n)])
+            self._hplans = (C.c_void_p * len(plans))(*[p.h for p in plans])
+            self.h = self.L.spx_pipeline_create_mixed(self._hplans, len(plans), self.jobs, self._pidx, n, int(depth), flags)
+        if not self.h:
+            raise RuntimeError("spx_pipeline_create: " + self.L.spx_last_error().decode())
+        self.depth = self.L.spx_pipeline_depth(self.h)
+        assert self.L.spx_pipeline_input_values(self.h) == self.total_in or n == 0
+        self._keep = {}   # ticket -> the input object (host memory must stay alive until its copy has been made)
+
+    def pack(self, streams):
+        """One batch's input as the pipeline expects it: the streams (int16 numpy arrays, interleaved) one after the other."""
+        host = np.zeros(self.total_in, np.int16)
+        for i, x in enumerate(streams):
+            x = np.ascontiguousarray(x, np.int16).ravel()
+            assert x.size == int(self.lengths[i]) * int(self.channels[i])
+            host[self.in_offs[i]:self.in_offs[i] + x.size] = x
+        return host
+
+    def host_input(self):
+        """The pinned staging buffer of the NEXT submit as an int16 numpy view (fill it, then submit(it))."""
+        ptr = self.L.spx_pipeline_host_input(self.h)
+        if not ptr:
+            raise RuntimeError("spx_pipeline_host_input: " + self.L.spx_last_error().decode())
+        return np.ctypeslib.as_array((C.c_int16 * self.total_in).from_address(ptr))
+
+    def submit(self, x, device=False):
+        if isinstance(x, torch.Tensor):
+            assert x.dtype == torch.int16 and x.is_contiguous() and x.numel() >= self.total_in
+            device = x.is_cuda
+            ptr = x.data_ptr()
+        else:
+            x = np.ascontiguousarray(x, np.int16)
+            assert x.size >= self.total_in
+            ptr = x.ctypes.data
+        t = self.L.spx_pipeline_submit(self.h, ptr, 1 if device else 0)
+        if t < 0:
+            raise RuntimeError("spx_pipeline_submit: " + self.L.spx_last_error().decode())
+        self._keep[t] = x
+        self._keep.pop(t - 2 * self.depth, None)
+        return t
+
+    def wait(self, ticket):
+        """(out, offsets, counts) of a batch: numpy views of the pipeline's pinned host buffers -- device_out: (data pointer of the
+        int16 output in device memory, offsets as a numpy array, data pointer of the int64 counts in device memory)."""
+        o, f, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        rc = self.L.spx_pipeline_wait(self.h, int(ticket), C.byref(o), C.byref(f), C.byref(c))
+        if rc != 0:
+            raise RuntimeError("spx_pipeline_wait: " + self.L.spx_last_error().decode())
+        offsets = np.ctypeslib.as_array((C.c_int64 * (self.n + 1)).from_address(f.value))
+        if self.device_out:
+            return o.value, offsets, c.value
+        counts = np.ctypeslib.as_array((C.c_int64 * self.n).from_address(c.value))
+        out = np.ctypeslib.as_array((C.c_int16 * max(1, int(offsets[self.n]))).from_address(o.value))
+        return out, offsets, counts
+
+    def results(self, ticket):
+        """Per-stream int16 outputs of a batch (copies; raises on overflow / a lost producer)."""
+        out, offsets, counts = self.wait(ticket)
+        if self.device_out:
+            cnt = torch.empty(self.n, dtype=torch.int64)
+            self.L.spx_copy_to_host(cnt.data_ptr(), counts, self.n * 8, None)
+            self.L.spx_stream_synchronize(None)
+            counts = cnt.numpy()
+            total = int(offsets[self.n])
+            host = torch.empty(total, dtype=torch.int16)
+            self.L.spx_copy_to_host(host.data_ptr(), out, total * 2, None)
+            self.L.spx_stream_synchronize(None)
+            out = host.numpy()
+        if (counts < 0).any():
+            raise RuntimeError("output capacity exceeded / lost producer for streams %s" % np.nonzero(counts < 0)[0][:8])
+        return [out[int(offsets[i]):int(offsets[i]) + int(counts[i]) * int(self.channels[i])].copy() for i in range(self.n)]
+
+    def close(self):
+        if self.h:
+            self.L.spx_pipeline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 def compress_batch(streams, sample_rate, channels, speed, nonlinear=1.0, feedback=0.0, match_matlab=False,
                    taps=False, spectrogram_taps=False):
     """One-call convenience: returns (list of outputs, Batch)."""

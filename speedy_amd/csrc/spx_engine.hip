@@ -13,6 +13,7 @@
 
 #include "../../include/speedy_hip.h"
 #include "spx_internal.h"
+#include "spx_mode.h"
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -75,11 +76,15 @@ struct spx_plan {
   // sequence; 22.05 kHz mono: 3.0-4.6 against 2.3-3.2), so the second call of a shape runs concurrently and the third in
   // sequence, both bracketed by events on the caller's stream, and later calls take the faster.  Results do not depend on it.
   struct Trial {
-    long long key = -1;
-    int calls = 0;
-    int choice = -1;  // -1 undecided, 0 sequential, 1 concurrent
+    SpxModeTrial state = {-1, 0, -1};   // key, calls, choice (-1 undecided, 0 sequential, 1 concurrent): spx_mode.h
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // [mode][begin / end]
   } trial;
+  std::map<long long, SpxModeResources> res_cache;   // mode_resources: per batch shape
+  // spx_batch_run of more streams than CUs, split into overlapping sub-batches (run_split): the event its sub-batches' producers
+  // wait for (two, taking turns), and how the call that last used a workspace was split (spx_batch_read_steps must find the states)
+  hipEvent_t ev_split[2] = {nullptr, nullptr};
+  unsigned split_calls = 0;
+  std::map<const void*, int> split_of;
   void* tables = nullptr;  // one device allocation behind dev.tw/tw2/window/taper*
   // time-chunk pipelining of one batch call: the analysis of chunk c+1 runs on `side` while the walk of chunk c
   // runs on the caller's stream
@@ -215,6 +220,7 @@ int64_t spx_internal_out_bound(const SpxPlanDev& P, int64_t n_in, float speed, b
   return (int64_t)((double)(n_in + 2 * (int64_t)P.maxRequired) * (2.0 / s)) + slack;
 }
 
+void spx_internal_set_error(const char* msg) { g_err = msg ? msg : ""; }   // other translation units' errors reach spx_last_error
 extern "C" {
 
 const char* spx_last_error(void) { return g_err.c_str(); }
@@ -381,6 +387,7 @@ void spx_plan_destroy(spx_plan_t plan) {
   for (auto& e : plan->trial.ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : plan->ev_walk) if (e) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); }
   for (auto& e : plan->ev_call) if (e) (void)hipEventDestroy(e);
+  for (auto& e : plan->ev_split) if (e) (void)hipEventDestroy(e);
   for (auto& g : plan->stage) {
     if (g.done) { (void)hipEventSynchronize(g.done); (void)hipEventDestroy(g.done); }
     if (g.p) (void)hipHostFree(g.p);
@@ -411,7 +418,7 @@ int64_t spx_plan_out_capacity(spx_plan_t p, int64_t n_in, float speed) {
 }  // extern "C"
 bool spx_internal_analysis_fits(const SpxPlanDev& d) { return spx_analysis_lds_bytes(d) <= 160 * 1024; }
 
-const SpxPlanDev* spx_internal_shared_plan(int sample_rate, int match_matlab) {
+static spx_plan* shared_plan_full(int sample_rate, int match_matlab) {
   static std::mutex mu;
   static std::map<std::pair<int, std::pair<int, int>>, spx_plan*> cache;  // (device, (rate, mode)): tables are per device
   std::lock_guard<std::mutex> g(mu);
@@ -419,11 +426,15 @@ const SpxPlanDev* spx_internal_shared_plan(int sample_rate, int match_matlab) {
   (void)hipGetDevice(&dev);
   auto key = std::make_pair(dev, std::make_pair(sample_rate, match_matlab ? 1 : 0));
   auto it = cache.find(key);
-  if (it != cache.end()) return &it->second->dev;
+  if (it != cache.end()) return it->second;
   spx_plan* p = spx_plan_create(sample_rate, match_matlab);
   if (!p) return nullptr;
   cache[key] = p;
-  return &p->dev;
+  return p;
+}
+const SpxPlanDev* spx_internal_shared_plan(int sample_rate, int match_matlab) {
+  spx_plan* p = shared_plan_full(sample_rate, match_matlab);
+  return p ? &p->dev : nullptr;
 }
 int64_t spx_internal_frames_for(const SpxPlanDev& d, int64_t n_in) { return frames_for(d, n_in); }
 extern "C" {
@@ -452,9 +463,6 @@ static Layout layout_for(const SpxPlanDev& d, const spx_stream_job* jobs, int n)
   return L;
 }
 
-size_t spx_batch_workspace_bytes(spx_plan_t plan, const spx_stream_job* jobs, int n_streams) {
-  return layout_for(plan->dev, jobs, n_streams).total;
-}
 
 // Job tables for `nch` consecutive time chunks of every stream: chunk c covers the input up to n_c frames
 // (n_c = n_in for the last chunk), starts where chunk c-1 stopped (frame_begin) and carries the state record.
@@ -541,8 +549,7 @@ static hipEvent_t take_event() {
   return e;
 }
 
-// `force`: the call is one group of a mixed-rate batch (spx_batch_run_mixed): the launch mode was decided for all groups
-// together, and the device guard is held by the caller.
+}  // extern "C"
 // The two side streams of the concurrent mode (analysis, tension) and of the time-chunk pipeline are per DEVICE, created once:
 // HIP maps streams onto a few hardware queues in creation order, and a queue runs its kernels in order -- with side streams
 // per plan, the second plan of a process got a tension stream that shared the caller stream's queue, its walk kernel waited
@@ -579,21 +586,36 @@ static int dev_walk_streams(int dev, hipStream_t* w0, hipStream_t* w1) {
   return 0;
 }
 
-// Which earlier calls a pipelined call's producers wait for (on `sa`), and how a call leaves its end in the ring.
-// The walk kernels of pipelined calls may run on two streams taking turns (spx_batch_run_overlapped), so "the call before" says
-// nothing about the calls before that one: the producers wait for
+// ---- the plan's ring of earlier calls (every call of a plan that walks -- plain, pipelined, mixed -- goes through it) ----
+// ring_note: where the caller's stream stands when the call is MADE (an overlapped call orders its walk kernel behind the
+// PREVIOUS call's note, whatever kind of call that was).
+// ring_wait: which earlier calls a pipelined call's producers wait for (on `sa`).  The walk kernels of pipelined calls may run
+// on two streams taking turns (spx_batch_run_overlapped), so "the call before" says nothing about the calls before that one:
 //   - the calls three and four back, always: between them they close both walk streams' histories (everything older is done),
 //     which also covers a caller that rotates three or four workspaces;
 //   - the calls one and two back when they used THIS workspace (two workspaces taking turns: the call two back) or another
 //     caller stream (then the order of the caller's stream says nothing about them).
 // A caller that rotates three workspaces therefore gets its producers started while the walk kernels of BOTH previous calls are
-// still running.
-static int ring_wait(spx_plan* plan, hipStream_t sa, const void* ws, hipStream_t st) {
+// still running.  *waited_prev: the producers were made to wait for the call right before this one (nothing of it is in flight
+// by the time they run: no gate for its walk kernel, see run_impl).
+// ring_record: how a call leaves its end -- and its output buffers -- in the ring.
+static int ring_note(spx_plan* plan, hipStream_t st) {
+  const int cur = plan->ahead_calls & 1;
+  if (!plan->ev_call[cur]) HIPCHK(hipEventCreateWithFlags(&plan->ev_call[cur], hipEventDisableTiming));
+  HIPCHK(hipEventRecord(plan->ev_call[cur], st));
+  plan->ev_call_valid[cur] = true;
+  return 0;
+}
+static int ring_wait(spx_plan* plan, hipStream_t sa, const void* ws, hipStream_t st, bool* waited_prev) {
   const int c = plan->ahead_calls & 3;
+  if (waited_prev) *waited_prev = false;
   for (int back = 4; back >= 1; back--) {
     const int j = (c + 4 - back) & 3;          // slot of the call `back` calls ago
     if (!plan->ev_walk_valid[j]) continue;
-    if (back >= 3 || plan->ring_ws[j] == ws || plan->ring_st[j] != st) HIPCHK(hipStreamWaitEvent(sa, plan->ev_walk[j], 0));
+    if (back >= 3 || plan->ring_ws[j] == ws || plan->ring_st[j] != st) {
+      HIPCHK(hipStreamWaitEvent(sa, plan->ev_walk[j], 0));
+      if (back == 1 && waited_prev) *waited_prev = true;
+    }
   }
   return 0;
 }
@@ -603,7 +625,7 @@ static bool ring_previous_in_flight(spx_plan* plan) {
   (void)hipGetLastError();
   return f;
 }
-static int ring_record(spx_plan* plan, hipStream_t on, void* ws, hipStream_t st) {
+static int ring_record(spx_plan* plan, hipStream_t on, void* ws, hipStream_t st, const void* out, const void* n_out) {
   const int c = plan->ahead_calls & 3;
   if (!plan->ev_walk[c]) HIPCHK(hipEventCreateWithFlags(&plan->ev_walk[c], hipEventDisableTiming));
   HIPCHK(hipEventRecord(plan->ev_walk[c], on));
@@ -611,20 +633,163 @@ static int ring_record(spx_plan* plan, hipStream_t on, void* ws, hipStream_t st)
   plan->ev_walk_valid[c] = true;
   plan->ring_ws[c] = ws;
   plan->ring_st[c] = st;
+  plan->ahead_last_out = out;
+  plan->ahead_last_nout = n_out;
   plan->ahead_calls++;
   return 0;
 }
 
+// ---- the inputs of spx_choose_mode (spx_mode.h) ----
+static SpxModeEnv mode_env() {
+  // the developers' A/B switches exist in builds with -DSPX_TUNING only (spx_tuning_env); read once per process
+  static const SpxModeEnv fixed = [] {
+    SpxModeEnv e;
+    memset(&e, 0, sizeof(e));
+    e.serial = spx_tuning_env("SPX_SERIAL") != nullptr;             // kernels back to back on one stream
+    e.no_lean = spx_tuning_env("SPX_NO_LEAN_WALK") != nullptr;
+    e.small_tile = spx_tuning_env("SPX_TILE_SMALL") != nullptr;     // the 8-frame tile whenever concurrent
+    e.ahead_any = spx_tuning_env("SPX_AHEAD_ANY") != nullptr;       // the pipelined order whatever the co-residency arithmetic says
+    e.full_walk = spx_tuning_env("SPX_OVERLAP_FULL_WALK") != nullptr;   // overlapped calls keep the full walk form
+    e.walk1 = spx_tuning_env("SPX_AHEAD_WALK1") != nullptr;         // pipelined calls' walk kernels on the caller's stream, one after the other
+    e.no_excl = spx_tuning_env("SPX_NO_EXCLUSIVE_CU") != nullptr;
+    e.trial_force = spx_tuning_env("SPX_TRIAL_FORCE") ? atoi(spx_tuning_env("SPX_TRIAL_FORCE")) : -1;
+    return e;
+  }();
+  SpxModeEnv e = fixed;
+  e.concurrent_enabled = g_concurrent.load() != 0;
+  e.chunks_set = g_chunks_set.load();
+  e.chunks = g_chunks.load();
+  return e;
+}
+static bool device_ours_cb(void* ctx) { return device_is_ours(*static_cast<int*>(ctx)); }
+static SpxModeWalk mode_walk(const SpxPlanDev& d, int n, int maxC, bool speedup_only, bool lean) {
+  const SpxWalkConfig c = spx_walk_config(d, n, maxC, speedup_only, false, lean);
+  SpxModeWalk w;
+  w.lds = c.lds; w.waves = c.waves; w.fast_kernel = c.fast_kernel; w.nwc = c.nwc;
+  w.vgprs = spx_walk_vgprs(d, n, maxC, speedup_only, lean);
+  return w;
+}
+// (cached per plan and shape: the register queries and spx_walk_config are not free, and the engine asks on every call)
+static const SpxModeResources& mode_resources(spx_plan* plan, int n, int maxC, bool speedup_only) {
+  const long long key = ((long long)n << 16) ^ ((long long)maxC << 1) ^ (speedup_only ? 1 : 0);
+  auto it = plan->res_cache.find(key);
+  if (it != plan->res_cache.end()) return it->second;
+  const SpxPlanDev& d = plan->dev;
+  SpxModeResources R;
+  memset(&R, 0, sizeof(R));
+  R.cu_count = plan->cu_count;
+  R.lds_per_cu = plan->lds_per_cu;
+  R.walk = mode_walk(d, n, maxC, speedup_only, false);
+  R.walk_lean = R.walk;
+  if (maxC == 1 && n <= plan->cu_count && R.walk.fast_kernel && R.walk.nwc > 0) {
+    R.walk_lean = mode_walk(d, n, maxC, speedup_only, true);
+    R.lean_valid = true;
+  }
+  R.tension_lds = spx_tension_lds_bytes();
+  R.tension_vgprs = spx_tension_vgprs();
+  R.tile_default = d.tile_frames;
+  R.tile_big = spx_analysis_tile_frames();
+  R.tile_small = spx_analysis_small_tile_frames();
+  SpxPlanDev d8 = d;
+  d8.tile_frames = R.tile_small;
+  R.an_lds_default = spx_analysis_lds_bytes(d);
+  R.an_vgprs_default = spx_analysis_vgprs(d);
+  R.an_lds_small = spx_analysis_lds_bytes(d8);
+  R.an_vgprs_small = spx_analysis_vgprs(d8);
+  if (plan->res_cache.size() > 64) plan->res_cache.clear();
+  return plan->res_cache.emplace(key, R).first->second;
+}
+// Diagnostics: the resource numbers spx_choose_mode is fed for a batch of this shape, in the order of the fields cu_count ..
+// an_vgprs_small of speedy_amd/csrc/spx_mode_table.cpp's query (22 values).  tools/kernel_resources.py writes them to
+// profiles/kernel_resources.json, the CPU table test (tests/test_mode_table.py) reads them from there, and
+// tests/test_gpu_parity.py checks the file against the library.
+extern "C" int spx_debug_mode_resources(int sample_rate, int channels, int n_streams, int speedup_only, long long* out) {
+  spx_plan* plan = shared_plan_full(sample_rate, 0);
+  if (!plan || !out || n_streams < 1) return -1;
+  std::lock_guard<std::mutex> g(plan->mu);
+  const SpxModeResources& R = mode_resources(plan, n_streams, channels < 1 ? 1 : channels, speedup_only != 0);
+  const long long v[22] = {R.cu_count, (long long)R.lds_per_cu, (long long)R.walk.lds, R.walk.waves, R.walk.vgprs, R.walk.fast_kernel, R.walk.nwc,
+                           (long long)R.walk_lean.lds, R.walk_lean.waves, R.walk_lean.vgprs, R.walk_lean.fast_kernel, R.walk_lean.nwc, R.lean_valid,
+                           (long long)R.tension_lds, R.tension_vgprs, R.tile_default, R.tile_big, R.tile_small, (long long)R.an_lds_default,
+                           (long long)R.an_lds_small, R.an_vgprs_default, R.an_vgprs_small};
+  for (int i = 0; i < 22; i++) out[i] = v[i];
+  return 0;
+}
+
+// Job tables (and, concurrent mode, the tile order) go through a plan-owned pinned slot -- the copy is asynchronous and must not
+// read host memory that dies when the call returns -- and reach the workspace by ONE small kernel on `on` that also clears the
+// hand-off flags: a single stream operation where two copies and two fills (each its own DMA packet with barriers around it)
+// cost the concurrent mode 0.13 ms a call.  *done: the slot's event, recorded behind the kernel.
+static int stage_tables(spx_plan* plan, const std::vector<SpxStreamDev>& sv, const std::vector<int>& order, SpxStreamDev* dstreams,
+                        int* d_order, int* d_flags, unsigned n_flags, int* d_ready, unsigned n_ready, hipStream_t on, hipEvent_t* done) {
+  const size_t b_sv = sizeof(SpxStreamDev) * sv.size(), b_or = sizeof(int) * order.size();
+  SpxStage& G = plan->stage[plan->stage_next];
+  plan->stage_next ^= 1;
+  if (G.done) HIPCHK(hipEventSynchronize(G.done));  // the kernel that last read this slot (two calls ago) has retired
+  else HIPCHK(hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
+  if (G.cap < b_sv + b_or) {
+    if (G.p) (void)hipHostFree(G.p);
+    G.p = nullptr; G.cap = 0;
+    const size_t cap = (b_sv + b_or) * 2 + 4096;
+    HIPCHK(hipHostMalloc(&G.p, cap, hipHostMallocDefault));
+    G.cap = cap;
+  }
+  unsigned char* hp = static_cast<unsigned char*>(G.p);
+  memcpy(hp, sv.data(), b_sv);
+  if (b_or) memcpy(hp + b_sv, order.data(), b_or);
+  hipLaunchKernelGGL(spx_stage_kernel, dim3(64), dim3(256), 0, on, reinterpret_cast<const unsigned*>(hp),
+                     reinterpret_cast<unsigned*>(dstreams), (unsigned)(b_sv / 4), reinterpret_cast<unsigned*>(d_order), (unsigned)(b_or / 4),
+                     reinterpret_cast<unsigned*>(d_flags), n_flags, reinterpret_cast<unsigned*>(d_ready), n_ready);
+  HIPCHK(hipEventRecord(G.done, on));
+  *done = G.done;
+  return 0;
+}
+
+// HIP events around a launch while spx_set_timing is on (no host synchronisation is added to the call).
+struct SpxTimed {
+  hipEvent_t a = nullptr, b = nullptr;
+  hipStream_t s = nullptr;
+  int kind = 0;
+  SpxTimed(bool on, int kind_, hipStream_t s_) : s(s_), kind(kind_) {
+    if (on) { a = take_event(); b = take_event(); (void)hipEventRecord(a, s); }
+  }
+  ~SpxTimed() {
+    if (!a) return;
+    (void)hipEventRecord(b, s);
+    std::lock_guard<std::mutex> g(g_tmu);
+    g_ev_pending.push_back({a, b, kind});
+  }
+};
+
+// `force`: the call is one group of a mixed-rate batch (spx_batch_run_mixed): the launch mode was decided for all groups
+// together, and the device guard is held by the caller.
+//   ahead_sa: the group of a pipelined mixed call -- its producers go to this stream at once (spx_batch_run_mixed_ahead orders it);
+//   started_out: where the group's walk workgroups count themselves in (for the next call's gate)
+//   total_streams: of all groups of the mixed call; after_analysis: recorded behind the group's analysis launch (or null)
 struct SpxForce { int concurrent; bool idle_start; int total_streams; hipEvent_t after_analysis; hipStream_t ahead_sa; const int** started_out; };
-// ahead_sa: the group of a pipelined mixed call -- its producers go to this stream at once (spx_batch_run_mixed_ahead orders it);
-// started_out: where the group's walk workgroups count themselves in (for the next call's gate)
-// total_streams: of all groups of the mixed call; after_analysis: recorded behind the group's analysis launch (or null)
+struct SpxCallOpts {
+  const SpxForce* force = nullptr;
+  bool ahead_req = false;      // spx_batch_run_ahead: pipelined with the plan's previous call where the shape allows
+  bool overlap_req = false;    // spx_batch_run_overlapped: ... and its walk kernel beside the previous call's
+  void* in_ready = nullptr;    // hipEvent_t: the producers wait for it (the caller's "input is there")
+  bool sub = false;            // a sub-batch of a plain call the engine has split (run_split): its `out` is the whole call's, never
+                               // "the previous call's output buffer handed over again"
+};
+
+// One batch call: decide the launch mode (spx_choose_mode, a pure function of the inputs collected here), then execute it.
+// The three launch orders give the same results:
+//   in sequence  -- staging, analysis, tension, walk on the caller's stream (time chunks: the analysis of chunk c + 1 on a side
+//                   stream beside the walk of chunk c);
+//   concurrent   -- analysis and tension kernels on the device's two side streams, the walk kernel at once on the caller's:
+//                   tiles of frames, then speeds, are handed over through flags the consumers poll;
+//   ahead        -- staging, analysis and tension kernels on the side stream AT ONCE, beside the previous call's walk kernel;
+//                   the walk kernel behind them on the caller's stream, or (walk2) on one of the library's two walk streams.
 static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                     int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs, bool do_a,
-                    bool do_w, const SpxForce* force = nullptr, bool ahead_req = false, void* in_ready = nullptr,
-                    bool overlap_req = false) {
+                    bool do_w, const SpxCallOpts& opt = SpxCallOpts()) {
   if (!plan || !jobs || n <= 0) return fail(-1, "spx_batch: bad arguments");
   SpxRange range_(do_a && do_w ? "spx_batch_run" : (do_a ? "spx_batch_analyze" : "spx_batch_walk"));
+  const SpxForce* force = opt.force;
   SpxPlanDev d = plan->dev;  // a copy: the tile size is chosen per call
   Layout L = layout_for(d, jobs, n);
   if (ws_bytes < L.total || !ws) return fail(-1, "spx_batch: workspace too small");
@@ -634,169 +799,59 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     if (jobs[i].channels > maxC) maxC = jobs[i].channels;
     if (!(jobs[i].speed > 1.0f && jobs[i].speed < SPX_FAST_MAX_SPEED && jobs[i].nonlinear >= 0.0f && jobs[i].nonlinear <= 1.0f)) speedup_only = false;
   }
-  // Concurrent mode: the analysis kernel goes to a side stream in "earliest frames first" tile order and publishes a
-  // flag per tile; the tension kernel (second side stream) turns ready tiles into per-frame speeds and publishes their
-  // count; the walk kernel starts at once on the caller's stream and runs every event whose speed is there.  Same
-  // arithmetic, same results; only the serialisation of the kernels goes.
-  static const bool env_serial = spx_tuning_env("SPX_SERIAL") != nullptr;  // tuning: kernels back to back on one stream
-  // The three kernels hand frames over through flags that consumers poll.  Polling workgroups hold their CU resources
-  // while they wait, so the mode is only safe if the analysis kernel -- which waits for nothing -- can always place a
-  // workgroup somewhere: then it runs to completion whatever happens, and everything downstream follows.  A CU is
-  // closed to it once the consumers (walk + tension workgroup of a stream) hold more than lds_per_cu - analysis_lds
-  // bytes of its LDS or more than 32 - 4 of its wave slots; however the dispatcher packs them, n streams can close at
-  // most (their total LDS) / (that LDS bound) plus (their total waves) / 29 CUs.  Concurrent iff that leaves a CU open
-  // (in practice the dispatcher spreads 256 workgroups one per CU and none is closed).  Batches beyond the bound run
-  // the kernels in stream order instead (same results).
   std::lock_guard<std::mutex> plan_lock(plan->mu);
-  const int cu_count = plan->cu_count;
-  const size_t lds_per_cu = plan->lds_per_cu;
-  SpxWalkConfig wcfg = spx_walk_config(d, n, maxC, speedup_only);
-  if (wcfg.lds > 160 * 1024)   // one CU's LDS; the window holds every channel of maxRequired + 64 frames at least
+  const SpxModeResources& R = mode_resources(plan, n, maxC, speedup_only);
+  if (R.walk.lds > 160 * 1024)   // one CU's LDS; the window holds every channel of maxRequired + 64 frames at least
     return fail(-1, "spx_batch: too many channels for the walk kernel's LDS window");
-  // The LEAN walk form for the concurrent mode (round 3): where a stream's walk workgroup in its usual form (4 search + 4
-  // output waves: TWO walk waves per SIMD) leaves no room for two analysis waves or workgroups beside it, but the form
-  // without output waves does -- 22.05 kHz mono: 2 x 112 + 48 + 2 x 168 registers does not fit a SIMD's 512, 128 + 48 + 2 x 168
-  // does -- the walk gives up its output waves (its search waves then cross-fade and copy themselves, from the LDS window: a
-  // few percent of the chain) and the call keeps the concurrent mode (mono only: a multi-channel stream's cross-fades read
-  // the input from HBM, which the chain cannot wait for).
-  bool lean_walk = false;
-  static const bool no_lean = spx_tuning_env("SPX_NO_LEAN_WALK") != nullptr;   // A/B
-  if (do_a && do_w && maxC == 1 && n <= plan->cu_count && wcfg.fast_kernel && wcfg.nwc > 0 && !no_lean && !force) {
-    const SpxWalkConfig lc = spx_walk_config(d, n, maxC, speedup_only, false, true);
-    if (lc.fast_kernel && lc.nwc == 0) {
-      const size_t lds_u = plan->lds_per_cu > 6144 ? plan->lds_per_cu - 6144 : plan->lds_per_cu;
-      auto fits = [&](const SpxWalkConfig& c, bool lean) {
-        return c.lds + spx_tension_lds_bytes() + 2 * spx_analysis_lds_bytes(d) <= lds_u &&
-               ((c.waves + 3) / 4) * spx_walk_vgprs(d, n, maxC, speedup_only, lean) + spx_tension_vgprs() + 2 * spx_analysis_vgprs(d) <= 512;
-      };
-      // ... and when the walk kernels of consecutive calls overlap (spx_batch_run_overlapped) the lean form is the better one
-      // whatever fits: the walk kernels have time to spare there (two in flight, 1.9 ms each, against a period of 1.15), what
-      // the period waits for is the analysis kernel, and beside two LEAN walk workgroups a SIMD holds two analysis waves
-      // (2 x 128 + 2 x 128 registers) where it holds one beside two full ones (4 x 96 + 128): analysis 1.13 -> 0.93 ms,
-      // 1.34 -> 1.15 ms per step on the bench batch.  (SPX_OVERLAP_FULL_WALK=1: the full form, for A/B.)
-      // With only TWO workspaces taking turns a call's producers wait for the walk kernel two calls back, the period is
-      // (walk + analysis) / 2, and the shorter walk kernel of the full form wins (1.39 against 1.43 ms): the ring knows.
-      static const bool full_walk = getenv("SPX_OVERLAP_FULL_WALK") != nullptr;
-      const int two_back = (plan->ahead_calls + 2) & 3;
-      const bool two_workspaces = plan->ev_walk_valid[two_back] && plan->ring_ws[two_back] == ws;
-      if ((!fits(wcfg, false) && fits(lc, true)) || (overlap_req && !full_walk && !two_workspaces && fits(lc, true))) { lean_walk = true; wcfg = lc; }
-    }
-  }
-  const size_t per_stream_lds = wcfg.lds + spx_tension_lds_bytes();
-  const size_t per_stream_waves = (size_t)wcfg.waves + 4;  // walk (spx_launch_walk's choice) + tension
-  bool co_resident = false, doubtful = false;
-  // Two tile sizes: the smaller one costs the analysis about a fifth more time (one halo frame per 8 instead of per 16)
-  // but a quarter less LDS; it is taken when that is what lets two analysis workgroups sit beside a stream's
-  // workgroups, i.e. when it buys the concurrent mode (16 kHz stereo, for instance).
-  // (6 KB of slack in the occupancy condition: filled to the last kilobyte, a CU that happens to hold two tension
-  // workgroups has no room for the walk workgroup, which then only starts when the analysis drains -- measured at
-  // 22.05 kHz, where the small tile fits with 2 KB to spare and the call got slower, not faster)
-  const size_t lds_usable = lds_per_cu > 6144 ? lds_per_cu - 6144 : lds_per_cu;
-  if (per_stream_lds + 2 * spx_analysis_lds_bytes(d) > lds_usable && do_a && do_w && d.tile_frames == spx_analysis_tile_frames()) {
-    SpxPlanDev d8 = d;
-    d8.tile_frames = spx_analysis_small_tile_frames();
-    if (per_stream_lds + 2 * spx_analysis_lds_bytes(d8) <= lds_usable) d.tile_frames = d8.tile_frames;
-  }
-  static const bool env_small_tile = spx_tuning_env("SPX_TILE_SMALL") != nullptr;  // tuning: the 8-frame tile whenever concurrent
-  if (env_small_tile && do_a && do_w && d.tile_frames == spx_analysis_tile_frames()) d.tile_frames = spx_analysis_small_tile_frames();
-  if (spx_analysis_lds_bytes(d) < lds_per_cu) {
-    const size_t lds_closing = lds_per_cu - spx_analysis_lds_bytes(d) + 1;
-    const size_t closed = ((size_t)n * per_stream_lds) / lds_closing + ((size_t)n * per_stream_waves) / 29;
-    // ... and the mode is built for ONE stream per CU (the analysis keeps two workgroups' worth of room on every CU): with
-    // the throughput-form walk kernel the bound alone would admit 640 streams, whose polling workgroups then leave the
-    // analysis a fifth of the machine (10.9 ms per call against 4.5 in sequence)
-    co_resident = closed < (size_t)cu_count && n <= cu_count;
-    // ... and only worth it when the analysis keeps its throughput beside the consumers: a stream's workgroups and
-    // still two analysis workgroups on a CU (measured at 22.05 kHz, where only one fits: 4.1 ms back to back, 5.2 ms concurrent)
-    if (per_stream_lds + 2 * spx_analysis_lds_bytes(d) > lds_usable) co_resident = false;
-    // ... and the same for the register file: a SIMD holds ceil(waves / 4) waves of the walk workgroup and one of the
-    // tension workgroup; two analysis waves must fit the rest of its 512 registers per lane.  (16 kHz: 2 x 96 + 56 + 2 x 128
-    // = 504.  22.05 kHz: 2 x 112 + 56 + 2 x 168 does not fit -- one analysis wave per SIMD stretched the analysis from
-    // 1.0 to 2.5-3.2 ms and the walk waited: 3.0-4.6 ms per call against 2.3-3.2 in sequence.)
-    if (co_resident) {
-      const int walk_regs = ((wcfg.waves + 3) / 4) * spx_walk_vgprs(d, n, maxC, speedup_only, lean_walk);
-      if (walk_regs + spx_tension_vgprs() + 2 * spx_analysis_vgprs(d) > 512) {
-        if (walk_regs + spx_tension_vgprs() + spx_analysis_vgprs(d) > 512) co_resident = false;  // not even one
-        else doubtful = true;  // one analysis wave per SIMD: decided by trial (spx_plan::Trial)
-      }
-    }
-  }
-  int trial_slot = -1;  // 0 / 1: this call is the timed trial of the sequential / concurrent mode
-  if (co_resident && doubtful && do_a && do_w && g_concurrent.load() && !env_serial && !force) {
-    spx_plan::Trial& T = plan->trial;
-    const long long key = ((long long)n << 40) ^ ((long long)L.total_frames << 8) ^ (maxC << 1) ^ (speedup_only ? 1 : 0);
-    static const int force = spx_tuning_env("SPX_TRIAL_FORCE") ? atoi(spx_tuning_env("SPX_TRIAL_FORCE")) : -1;  // tuning: 0 / 1 = no trial
-    if (T.key != key) { T.key = key; T.calls = 0; T.choice = force; }
-    if (T.choice < 0 && T.calls >= 3 && hipEventQuery(T.ev[1]) == hipSuccess && hipEventQuery(T.ev[3]) == hipSuccess) {
-      float ms_seq = 0, ms_con = 0;
-      if (hipEventElapsedTime(&ms_seq, T.ev[0], T.ev[1]) == hipSuccess &&
-          hipEventElapsedTime(&ms_con, T.ev[2], T.ev[3]) == hipSuccess)
-        T.choice = ms_con < ms_seq ? 1 : 0;
-      static const bool dbg = getenv("SPX_DEBUG_TRIAL") != nullptr;
-      if (dbg) fprintf(stderr, "[spx trial] n=%d maxC=%d: concurrent %.3f ms, in sequence %.3f ms -> %s\n", n, maxC, ms_con,
-                       ms_seq, T.choice ? "concurrent" : "sequence");
-    }
-    (void)hipGetLastError();
-    if (T.choice >= 0) co_resident = T.choice == 1;
-    else if (T.calls == 0) { }                                      // first call of the shape: concurrent, untimed (cold)
-    else if (T.calls == 1) { trial_slot = 1; }                      // second: concurrent, timed
-    else if (T.calls == 2) { trial_slot = 0; co_resident = false; } // third: in sequence, timed
-    else co_resident = false;                                       // timings not in yet: in sequence
-    T.calls++;
-  }
-  bool want_concurrent = g_concurrent.load() && !env_serial && co_resident && do_a && do_w;
-  if (want_concurrent && !device_is_ours(plan->device)) want_concurrent = false;   // another process works on this GPU
-  if (force) want_concurrent = force->concurrent != 0 && do_a && do_w;
   hipStream_t st = static_cast<hipStream_t>(hs);
-  // AHEAD (spx_batch_run_ahead, round 4): consecutive calls on DIFFERENT workspaces are software-pipelined -- this call's
-  // staging, analysis and tension kernels go to the side stream at once, beside the PREVIOUS call's walk kernel, which is
-  // still running on the caller's stream; its own walk kernel follows on the caller's stream with every speed ready: no
-  // consumer polls a producer (nothing to deadlock, no guard), and no walk waits for its first frames.  Same shapes as the
-  // concurrent mode (one stream per CU, two analysis workgroups beside a stream's walk and tension workgroups).
-  const bool ahead_forced = force && force->ahead_sa != nullptr && do_a && do_w;   // a group of spx_batch_run_mixed_ahead
-  // ... and a batch whose kernels run in sequence (no two analysis workgroups beside a stream's own, e.g. 22.05 kHz stereo)
-  // can still be pipelined with its predecessor if ONE analysis workgroup fits beside a walk workgroup that asks for a CU of
-  // its own (LDS) and one analysis wave beside its waves (registers): the walk kernels keep their exclusive placement, the next
-  // call's analysis fills what they leave -- the order the groups of a pipelined mixed call run in
-  bool seq_ahead = false;
-  if (ahead_req && !want_concurrent && !force && do_a && do_w && n <= cu_count && g_concurrent.load() && !env_serial && trial_slot < 0 &&
-      (!g_chunks_set.load() || g_chunks.load() == 1)) {
-    SpxPlanDev dd = plan->dev;   // (the default tile: no co-residency tile games in this order)
-    const size_t walk_lds = std::max(wcfg.lds, lds_per_cu / 2 + 1024);
-    const int walk_regs = ((wcfg.waves + 3) / 4) * spx_walk_vgprs(d, n, maxC, speedup_only, false);
-    seq_ahead = walk_lds + spx_tension_lds_bytes() + spx_analysis_lds_bytes(dd) <= lds_usable &&
-                walk_regs + spx_tension_vgprs() + spx_analysis_vgprs(dd) <= 512 && !lean_walk && device_is_ours(plan->device);
-  }
-  static const bool ahead_any = spx_tuning_env("SPX_AHEAD_ANY") != nullptr;   // tuning: the pipelined order whatever the co-residency arithmetic says
-  const bool ahead = ahead_forced || seq_ahead ||
-                     (ahead_req && (want_concurrent || (ahead_any && do_a && do_w && n <= cu_count && g_concurrent.load())) && !doubtful && !force &&
-                      trial_slot < 0 && (!g_chunks_set.load() || g_chunks.load() == 1));
-  if (ahead) want_concurrent = false;
-  // another concurrent-mode call still in flight on this device, on a different stream?  Then this one runs its kernels
-  // in sequence (SpxDevGuard above); the guard stays locked until this call has left its own event behind.
+  // ---- decide ----
+  SpxModeShape S;
+  S.n = n; S.max_channels = maxC; S.do_a = do_a; S.do_w = do_w; S.has_frames = L.total_frames > 0;
+  S.forced = force != nullptr;
+  S.force_concurrent = force && force->concurrent != 0;
+  S.force_ahead = force && force->ahead_sa != nullptr;
+  S.force_total_streams = force ? force->total_streams : n;
+  S.ahead_req = opt.ahead_req; S.overlap_req = opt.overlap_req;
+  const SpxModeEnv E = mode_env();
+  SpxModeRuntime T;
+  memset(&T, 0, sizeof(T));
+  const int two_back = (plan->ahead_calls + 2) & 3;
+  T.two_workspaces = plan->ev_walk_valid[two_back] && plan->ring_ws[two_back] == ws;
+  T.trial_key = ((long long)n << 40) ^ ((long long)L.total_frames << 8) ^ (maxC << 2) ^ (speedup_only ? 2 : 0) ^ (opt.overlap_req ? 1 : 0);
+  T.device_ours = device_ours_cb;
+  T.device_ctx = &plan->device;
+  spx_plan::Trial& TR = plan->trial;
+  if (TR.state.key == T.trial_key && TR.state.choice < 0 && TR.state.calls >= 3 && TR.ev[1] && TR.ev[3] &&
+      hipEventQuery(TR.ev[1]) == hipSuccess && hipEventQuery(TR.ev[3]) == hipSuccess)
+    T.trial_times_ready = hipEventElapsedTime(&T.ms_seq, TR.ev[0], TR.ev[1]) == hipSuccess &&
+                          hipEventElapsedTime(&T.ms_con, TR.ev[2], TR.ev[3]) == hipSuccess;
+  (void)hipGetLastError();
+  SpxMode M = spx_choose_mode(S, R, E, T, TR.state);
+  // another concurrent-mode call still in flight on this device, on a different stream?  Then this one runs its kernels in
+  // sequence (SpxDevGuard above); the guard stays locked until this call has left its own event behind.
   SpxDevGuard& guard = g_guard[(plan->device >= 0 && plan->device < 64) ? plan->device : 0];
   std::unique_lock<std::mutex> guard_lock(guard.mu, std::defer_lock);
   bool idle_start = force ? force->idle_start : false;
-  if (want_concurrent && !force) {
+  if (M.want_concurrent && !force) {
     guard_lock.lock();
     const hipError_t q = guard.valid ? hipEventQuery(guard.last) : hipSuccess;
-    idle_start = (q == hipSuccess);   // the previous concurrent-mode call (if any) has drained
-    if (guard.valid && guard.last_stream != st && q == hipErrorNotReady) want_concurrent = false;
     (void)hipGetLastError();  // hipErrorNotReady is not an error of this call
-    if (!want_concurrent) guard_lock.unlock();
+    idle_start = (q == hipSuccess);   // the previous concurrent-mode call (if any) has drained
+    if (guard.valid && guard.last_stream != st && q == hipErrorNotReady) {
+      T.guard_busy = true;
+      M = spx_choose_mode(S, R, E, T, TR.state);
+      guard_lock.unlock();
+    }
   }
-  if (!want_concurrent && (!ahead || seq_ahead)) d.tile_frames = plan->dev.tile_frames;  // no concurrency: default tile
-  // Pipelining in time needs both stages in one call; the separate entry points run one chunk.  A batch too large for
-  // the concurrent mode gets four time chunks unless the caller chose a count: the analysis of chunk c+1 then overlaps
-  // the walk of chunk c through ordinary stream ordering (measured at 512 / 1024 streams x 10 s: 5.32 -> 4.76 ms and
-  // 9.94 -> 9.28 ms per call; no difference at 2048).
-  int nch = (do_a && do_w) ? g_chunks.load() : 1;
-  // (two time chunks once the walk is in its throughput form, more than two streams per CU: 2048 streams 9.7 -> 9.6 ms;
-  // below that the chains are the run time and the kernels run back to back: 512 streams 3.63 against 3.99 chunked)
-  if (do_a && do_w && !g_chunks_set.load() && !want_concurrent && n > 2 * cu_count) nch = 2;
-  if (ahead) nch = 1;
-  if (nch < 1) nch = 1;
-  if (nch > SPX_MAX_CHUNKS) nch = SPX_MAX_CHUNKS;
+  static const bool dbg_trial = getenv("SPX_DEBUG_TRIAL") != nullptr;
+  if (dbg_trial && TR.state.choice < 0 && M.trial_next.choice >= 0 && T.trial_times_ready)
+    fprintf(stderr, "[spx trial] n=%d maxC=%d: concurrent %.3f ms, in sequence %.3f ms -> %s\n", n, maxC, T.ms_con, T.ms_seq,
+            M.trial_next.choice ? "concurrent" : "sequence");
+  TR.state = M.trial_next;
+  d.tile_frames = M.tile_frames;
+  const int nch = M.nch;
+  const bool concurrent = M.concurrent, ahead = M.ahead;
+  // ---- execute ----
   std::vector<SpxStreamDev> sv;
   std::vector<int> tiles;
   int rc = build_streams(d, jobs, n, nch, sv, tiles);
@@ -806,49 +861,34 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   SpxStreamState* states = reinterpret_cast<SpxStreamState*>(w + L.off_states);
   SpxFrameRec* rec = reinterpret_cast<SpxFrameRec*>(w + L.off_rec);
   float* scratch = reinterpret_cast<float*>(w + L.off_scratch);
-  SpxTapsDev td = taps_of(taps);
-  const bool timed = g_timing.load() && do_a && do_w;
-  const bool concurrent = want_concurrent && nch == 1 && tiles[0] > 0;
-  if (do_a && do_w) g_last_concurrent.store(concurrent ? 1 : (ahead ? 2 : 0), std::memory_order_relaxed);
-  static const bool dbg_mode = getenv("SPX_DEBUG_MODE") != nullptr;   // one line per call: what was decided and why
-  if (dbg_mode)
-    fprintf(stderr, "[spx mode] rate %d n %d maxC %d: co_resident %d doubtful %d lean %d want_concurrent %d chunks %d tiles %d -> %s\n", d.rate, n,
-            maxC, (int)co_resident, (int)doubtful, (int)lean_walk, (int)want_concurrent, nch, tiles[0], concurrent ? "concurrent" : "sequence");
   int* d_order = reinterpret_cast<int*>(w + L.off_order);
   int* d_flags = reinterpret_cast<int*>(w + L.off_flags);
   int* d_ready = reinterpret_cast<int*>(w + L.off_ready);
-  // Pipelined calls, second half: their WALK kernels overlap too.  The walk kernel of a pipelined call goes to one of two
-  // streams of the library's, taking turns, and the caller's stream only waits for it: two walk workgroups per CU run at
-  // nearly full speed each (a 512-stream call's walk kernel takes 1.71 ms where a 256-stream call's takes 1.64), the long
-  // chains of one batch no longer hold the next batch back, and the next-but-one call's analysis runs beside whichever walk is
-  // alone on its CUs.  Bench batch: 1.60 -> 1.45 ms per step.  (SPX_AHEAD_WALK1=1: the walk kernels on the caller's stream,
-  // one after the other, as the mode was first built.)
-  // Asked for per call (spx_batch_run_overlapped): it relaxes the caller's stream order -- see include/speedy_hip.h.
-  static const bool walk1_env = getenv("SPX_AHEAD_WALK1") != nullptr;
-  const bool walk2 = overlap_req && !walk1_env && ahead && !force && !seq_ahead;
-  hipStream_t stw = st;   // the stream the walk kernel goes to
-  if (do_w && !force) {
-    // every walking call of the plan notes where the caller's stream stands when it is made (an overlapped call orders its
-    // walk kernel behind the PREVIOUS call's note, whatever kind of call that was)
-    const int cur = plan->ahead_calls & 1;
-    if (!plan->ev_call[cur]) HIPCHK(hipEventCreateWithFlags(&plan->ev_call[cur], hipEventDisableTiming));
-    HIPCHK(hipEventRecord(plan->ev_call[cur], st));
-    plan->ev_call_valid[cur] = true;
-  }
-  if (walk2) {
+  SpxTapsDev td = taps_of(taps);
+  const bool timed = g_timing.load() && do_a && do_w;
+  if (do_a && do_w) g_last_concurrent.store(concurrent ? 1 : (ahead ? 2 : 0), std::memory_order_relaxed);
+  static const bool dbg_mode = getenv("SPX_DEBUG_MODE") != nullptr;   // one line per call: what was decided and why
+  if (dbg_mode)
+    fprintf(stderr, "[spx mode] rate %d n %d maxC %d: co_resident %d doubtful %d lean %d want_concurrent %d chunks %d tiles %d -> %s%s\n",
+            d.rate, n, maxC, (int)M.co_resident, (int)M.doubtful, (int)M.launch_lean, (int)M.want_concurrent, nch, tiles[0],
+            concurrent ? "concurrent" : (ahead ? (M.seq_ahead ? "ahead (kernels in sequence)" : "ahead") : "sequence"),
+            M.walk2 ? ", walk kernels overlapping" : "");
+  // the stream the walk kernel goes to: the caller's, or (walk2) one of the library's two, taking turns -- ordered behind whatever
+  // the caller had queued by the PREVIOUS call (the consumer of the output this call overwrites, two buffers taking turns) and not
+  // behind this call's state of the stream, which ends with the wait for the previous call's walk kernel; a caller that hands over
+  // the previous call's out / n_out again gets exactly that wait
+  hipStream_t stw = st;
+  if (do_w && !force && ring_note(plan, st)) return -2;
+  if (M.walk2) {
     hipStream_t w0 = nullptr, w1 = nullptr;
     if (dev_walk_streams(plan->device, &w0, &w1)) return fail(-1, "spx_batch: no walk streams");
     const int cur = plan->ahead_calls & 1;
     stw = cur ? w1 : w0;
-    // whatever the caller had queued by the PREVIOUS call (the consumer of the output this call overwrites, two buffers taking
-    // turns) -- not this call's state of the stream, which ends with the wait for the previous call's walk kernel; a caller
-    // that hands over the previous call's out / n_out again gets exactly that wait
-    const bool same_out = out == plan->ahead_last_out || n_out == plan->ahead_last_nout;
+    const bool same_out = !opt.sub && (out == plan->ahead_last_out || n_out == plan->ahead_last_nout);
     if (same_out) HIPCHK(hipStreamWaitEvent(stw, plan->ev_call[cur], 0));
     else if (plan->ev_call_valid[cur ^ 1]) HIPCHK(hipStreamWaitEvent(stw, plan->ev_call[cur ^ 1], 0));
   }
-  if (do_w && !force) { plan->ahead_last_out = out; plan->ahead_last_nout = n_out; }
-  hipStream_t sa = st;  // stream the analysis launches go to
+  hipStream_t sa = st;  // the stream the analysis launches go to
   if (nch > 1 || concurrent || ahead) {
     if (!plan->side) {
       if (dev_side_streams(plan->device, &plan->side, &plan->side2)) return fail(-1, "spx_batch: no side streams");
@@ -856,12 +896,8 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       HIPCHK(hipEventCreateWithFlags(&plan->ev_tension, hipEventDisableTiming));
       for (auto& e : plan->ev_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    sa = plan->side;
-    if (ahead_forced) sa = force->ahead_sa;
+    sa = M.ahead_forced ? force->ahead_sa : plan->side;
   }
-  // job tables (and, concurrent mode, the tile order) go through a plan-owned pinned slot: the copies are asynchronous
-  // and must not read host memory that dies when this function returns
-  hipEvent_t staged_ev = nullptr;
   std::vector<int> order;
   if (concurrent) {
     // tile ids in launch order: tile t of every stream before tile t+1 of any
@@ -876,131 +912,93 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       for (int i = 0; i < n; i++)
         if (t < cnt[i]) order.push_back(sv[i].first_tile + t);
   }
-  {
-    const size_t b_sv = sizeof(SpxStreamDev) * sv.size(), b_or = sizeof(int) * order.size();
-    SpxStage& G = plan->stage[plan->stage_next];
-    plan->stage_next ^= 1;
-    if (G.done) HIPCHK(hipEventSynchronize(G.done));  // the copies that last read this slot (two calls ago) have retired
-    else HIPCHK(hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
-    if (G.cap < b_sv + b_or) {
-      if (G.p) (void)hipHostFree(G.p);
-      G.p = nullptr; G.cap = 0;
-      const size_t cap = (b_sv + b_or) * 2 + 4096;
-      HIPCHK(hipHostMalloc(&G.p, cap, hipHostMallocDefault));
-      G.cap = cap;
-    }
-    unsigned char* hp = static_cast<unsigned char*>(G.p);
-    memcpy(hp, sv.data(), b_sv);
-    if (b_or) memcpy(hp + b_sv, order.data(), b_or);
-    // one small kernel reads the pinned slot over PCIe and clears the hand-off flags: a single stream operation where
-    // two copies and two fills (each its own DMA packet with barriers around it) cost the concurrent mode 0.13 ms a call
-    const unsigned w_sv = (unsigned)(b_sv / 4), w_or = concurrent ? (unsigned)(b_or / 4) : 0u;
-    const unsigned z_fl = concurrent ? (unsigned)tiles[0] : 0u, z_rd = (concurrent || ahead) ? (unsigned)n + 1u : 0u;
-    if (ahead && !force) {
-      // this call's producers must not touch a workspace the walk kernel of an earlier call still reads: with the caller
-      // alternating two workspaces that is the call before the previous one (the older event of the ring); a caller that
-      // hands over the previous call's workspace again waits for that call instead (correct, and no overlap)
-      if (ring_wait(plan, sa, ws, st)) return -2;
-      if (in_ready) HIPCHK(hipStreamWaitEvent(sa, static_cast<hipEvent_t>(in_ready), 0));   // the caller's "input is there"
-    }
-    if (!ahead && in_ready) HIPCHK(hipStreamWaitEvent(st, static_cast<hipEvent_t>(in_ready), 0));
-    hipLaunchKernelGGL(spx_stage_kernel, dim3(64), dim3(256), 0, ahead ? sa : st, reinterpret_cast<const unsigned*>(hp),
-                       reinterpret_cast<unsigned*>(dstreams), w_sv, reinterpret_cast<unsigned*>(d_order), w_or,
-                       reinterpret_cast<unsigned*>(d_flags), z_fl, reinterpret_cast<unsigned*>(d_ready), z_rd);
-    HIPCHK(hipEventRecord(G.done, ahead ? sa : st));
-    staged_ev = G.done;
+  bool waited_prev = false;
+  if (ahead && !force) {
+    // this call's producers must not touch a workspace the walk kernel of an earlier call still reads (ring_wait)
+    if (ring_wait(plan, sa, ws, st, &waited_prev)) return -2;
+    if (opt.in_ready) HIPCHK(hipStreamWaitEvent(sa, static_cast<hipEvent_t>(opt.in_ready), 0));
   }
-  if (trial_slot >= 0) {  // bracket this call on the caller's stream (spx_plan::Trial)
-    hipEvent_t& e0 = plan->trial.ev[2 * trial_slot];
+  if (!ahead && opt.in_ready) HIPCHK(hipStreamWaitEvent(st, static_cast<hipEvent_t>(opt.in_ready), 0));
+  hipEvent_t staged_ev = nullptr;
+  rc = stage_tables(plan, sv, order, dstreams, d_order, d_flags, concurrent ? (unsigned)tiles[0] : 0u, d_ready,
+                    (concurrent || ahead) ? (unsigned)n + 1u : 0u, ahead ? sa : st, &staged_ev);
+  if (rc) return rc;
+  if (M.trial_slot >= 0) {  // bracket this call on the caller's stream (spx_plan::Trial)
+    hipEvent_t& e0 = TR.ev[2 * M.trial_slot];
     if (!e0) HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventRecord(e0, st));
   }
   if (sa != st && !ahead) {
-    // the side stream starts after everything already queued on the caller's stream (job tables, cleared flags, and
-    // the previous call's walk, which still reads the frame records this call's analysis will overwrite)
-    // (the staging slot's event marks exactly that point of the caller's stream: one stream operation fewer in front of
-    // the walk kernel than a second event record)
-    hipEvent_t es = staged_ev;
-    if (!es) { es = plan->ev_start; HIPCHK(hipEventRecord(plan->ev_start, st)); }
-    HIPCHK(hipStreamWaitEvent(sa, es, 0));
-    if (concurrent) HIPCHK(hipStreamWaitEvent(plan->side2, es, 0));
+    // the side stream starts after everything already queued on the caller's stream (job tables, cleared flags, and the previous
+    // call's walk, which still reads the frame records this call's analysis will overwrite): the staging slot's event marks
+    // exactly that point of the caller's stream
+    HIPCHK(hipStreamWaitEvent(sa, staged_ev, 0));
+    if (concurrent) HIPCHK(hipStreamWaitEvent(plan->side2, staged_ev, 0));
   }
+  static const bool no_gate = spx_tuning_env("SPX_NO_GATE") != nullptr;  // A/B only
+  static const unsigned gate_spins = [] { const char* e = spx_tuning_env("SPX_GATE_SPINS"); return e ? (unsigned)atoi(e) : 1200u; }();
+  static const bool diag_nowait = spx_tuning_env("SPX_DIAG_NOWAIT") != nullptr;  // DIAGNOSTIC ONLY: the walk reads the speeds the
+  // previous identical call left in the scratch array instead of waiting for this call's (timing experiments)
   for (int c = 0; c < nch; c++) {
     SpxStreamDev* dj = dstreams + (size_t)c * n;
-    auto launch_walk = [&]() {
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, stw); }
-      static const bool diag_nowait = spx_tuning_env("SPX_DIAG_NOWAIT") != nullptr;  // DIAGNOSTIC ONLY: the walk reads the speeds
-      // the previous identical call left in the scratch array instead of waiting for this call's (timing experiments)
-      // Kernels in sequence, and every stream of the call (of all groups of a mixed call) can have a CU to itself: ask for
-      // more than half a CU's LDS per walk workgroup, so that they DO get one each.  Walk kernels of several groups launched
-      // side by side, or a walk kernel placed while another group's analysis fills the CUs, otherwise land two to a CU here
-      // and there, and those chains end the call: the configs[4] shard 3.30 -> 3.04 ms per step (profiles/r03/r03ad_config4_lds_min.txt).
-      // (The concurrent mode needs that LDS for the analysis workgroups beside the walk; its idle-start gate does this job.)
-      static const bool no_excl = spx_tuning_env("SPX_NO_EXCLUSIVE_CU") != nullptr;   // A/B
-      const int total = force ? force->total_streams : n;
-      const size_t lds_min = (!concurrent && (!ahead || ahead_forced || seq_ahead) && !no_excl && nch == 1 && total <= cu_count) ? lds_per_cu / 2 + 1024 : 0;
-      // (AHEAD: the counts are all published by the time the kernel starts -- its one poll returns at once -- and its
-      // workgroups count themselves in for the next call's gate)
-      spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, ((concurrent && !diag_nowait) || ahead) ? d_ready : nullptr,
-                      speedup_only, stw, false, lds_min, lean_walk && (concurrent || ahead));
-      if (timed) { (void)hipEventRecord(e1, stw); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({e0, e1, 1}); } }
-    };
-    // Concurrent mode on an IDLE device (the first call after a synchronisation): kernels start as their launches arrive,
-    // and the analysis launch arrives a few tens of microseconds before the walk launch.  Its tiles then fill the CUs' LDS
-    // and the walk workgroups land two to a CU wherever room is left -- the whole step waits for those chains (3.06
-    // instead of 2.21 ms in 40 % of such calls, tools/stall_probe3.py; with the host running ahead the walk kernel sits
-    // right behind the staging kernel in its queue and is placed first by itself).  The walk kernel cannot simply be
-    // enqueued first: HIP maps streams onto a few hardware queues, and producers queued behind a waiting consumer in a
-    // shared queue never start (every consumer is enqueued after its producers, which is safe with any mapping).  So an
-    // idle start holds the analysis stream back with a gate kernel until the walk kernel's workgroups have been placed
-    // (they count themselves in; spx_gate_kernel).
-    static const bool no_gate = spx_tuning_env("SPX_NO_GATE") != nullptr;  // A/B only
-    static const unsigned gate_spins = [] { const char* e = spx_tuning_env("SPX_GATE_SPINS"); return e ? (unsigned)atoi(e) : 1200u; }();
+    // Concurrent mode on an IDLE device (the first call after a synchronisation): kernels start as their launches arrive, and the
+    // analysis launch arrives a few tens of microseconds before the walk launch.  Its tiles then fill the CUs' LDS and the walk
+    // workgroups land two to a CU wherever room is left -- the whole step waits for those chains (3.06 instead of 2.21 ms in 40 %
+    // of such calls; with the host running ahead the walk kernel sits right behind the staging kernel in its queue and is placed
+    // first by itself).  The walk kernel cannot simply be enqueued first: HIP maps streams onto a few hardware queues, and
+    // producers queued behind a waiting consumer in a shared queue never start (every consumer is enqueued after its producers,
+    // which is safe with any mapping).  So an idle start holds the analysis stream back with a gate kernel until the walk kernel's
+    // workgroups have been placed (they count themselves in; spx_gate_kernel).
     if (concurrent && do_w && idle_start && !no_gate)
       hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, sa, d_ready + n, n, gate_spins);
-    // AHEAD: the analysis must not fill the CUs before the PREVIOUS call's walk workgroups have been placed one per CU (its
-    // walk kernel becomes runnable at the same moment as this analysis: when the walk before it retires)
-    // (only while that call is still in flight: then its workspace, where the counter lives, is alive by the usual contract)
-    if (ahead && !force && plan->ahead_started != nullptr && plan->ahead_n > 0 && !no_gate) {
-      const bool in_flight = ring_previous_in_flight(plan);
-      // (a longer bound than the idle-start gate's: the previous walk kernel may itself be waiting for something of the
-      // caller's -- an output buffer still being copied out -- and a gate that gives up early lets this call's analysis fill the
-      // CUs first, which costs the previous call half its speed; ~2 ms)
-      if (in_flight) hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, sa, plan->ahead_started, plan->ahead_n, 8000u);
-    }
+    // AHEAD: the analysis must not fill the CUs before the PREVIOUS call's walk workgroups have been placed one per CU (its walk
+    // kernel becomes runnable at the same moment as this analysis: when the walk before it retires) -- only while that call is
+    // still in flight (then its workspace, where the counter lives, is alive by the usual contract), and not when the producers
+    // wait for that very call anyway (a caller handing the same workspace over again: the counter is THIS workspace's, this
+    // call's staging kernel has just cleared it, and the gate would spin its full bound for a count nobody raises -- round 4:
+    // 3.6 ms per call where a plain call takes 1.6).  A longer bound than the idle-start gate's: the previous walk kernel may
+    // itself be waiting for something of the caller's (an output buffer still being copied out), and a gate that gives up early
+    // lets this call's analysis fill the CUs first, which costs the previous call half its speed; ~2 ms.
+    if (ahead && !force && c == 0 && plan->ahead_started != nullptr && plan->ahead_n > 0 && !no_gate && !waited_prev &&
+        ring_previous_in_flight(plan))
+      hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, sa, plan->ahead_started, plan->ahead_n, 8000u);
     if (do_a && tiles[c] > 0) {
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (timed) { e0 = take_event(); e1 = take_event(); (void)hipEventRecord(e0, sa); }
-      spx_launch_analysis(d, dj, n, tiles[c], in, rec, td, concurrent ? d_order : nullptr,
-                          concurrent ? d_flags : nullptr, sa);
-      if (timed) { (void)hipEventRecord(e1, sa); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({e0, e1, 0}); } }
+      SpxTimed tm(timed, 0, sa);
+      spx_launch_analysis(d, dj, n, tiles[c], in, rec, td, concurrent ? d_order : nullptr, concurrent ? d_flags : nullptr, sa);
     }
     if (force && force->after_analysis && c == nch - 1) HIPCHK(hipEventRecord(force->after_analysis, sa));
     if (sa != st) HIPCHK(hipEventRecord(plan->ev_chunk[c], sa));
     if (sa != st && !concurrent && !ahead) HIPCHK(hipStreamWaitEvent(st, plan->ev_chunk[c], 0));
     if (do_w) {
-      // frame-rate stage: after the analysis on the same stream, or -- concurrent -- beside it on its own stream,
-      // consuming tile flags and publishing the count of ready speeds (AHEAD: behind the analysis on the side stream)
+      // frame-rate stage: after the analysis on the same stream, or -- concurrent -- beside it on its own stream, consuming tile
+      // flags and publishing the count of ready speeds (AHEAD: behind the analysis on the side stream)
       hipStream_t stn = concurrent ? plan->side2 : (ahead ? sa : st);
-      hipEvent_t t0 = nullptr, t1 = nullptr;
-      if (timed) { t0 = take_event(); t1 = take_event(); (void)hipEventRecord(t0, stn); }
-      spx_launch_tension(d, dj, n, states, rec, scratch, td, concurrent ? d_flags : nullptr,
-                         (concurrent || ahead) ? d_ready : nullptr, stn);
-      if (timed) { (void)hipEventRecord(t1, stn); { std::lock_guard<std::mutex> g(g_tmu); g_ev_pending.push_back({t0, t1, 2}); } }
-      if (concurrent) HIPCHK(hipEventRecord(plan->ev_tension, stn));
-      if (ahead) {   // the walk kernel starts when every speed of the call is there
-        HIPCHK(hipEventRecord(plan->ev_tension, stn));
-        HIPCHK(hipStreamWaitEvent(stw, plan->ev_tension, 0));
+      {
+        SpxTimed tm(timed, 2, stn);
+        spx_launch_tension(d, dj, n, states, rec, scratch, td, concurrent ? d_flags : nullptr, (concurrent || ahead) ? d_ready : nullptr, stn);
       }
-      launch_walk();
-      if (ahead_forced && force->started_out) *force->started_out = d_ready + n;
+      if (concurrent || ahead) HIPCHK(hipEventRecord(plan->ev_tension, stn));
+      if (ahead) HIPCHK(hipStreamWaitEvent(stw, plan->ev_tension, 0));   // the walk kernel starts when every speed of the call is there
+      {
+        // Kernels in sequence, and every stream of the call (of all groups of a mixed call) can have a CU to itself: ask for more
+        // than half a CU's LDS per walk workgroup, so that they DO get one each.  Walk kernels of several groups launched side by
+        // side, or a walk kernel placed while another group's analysis fills the CUs, otherwise land two to a CU here and there,
+        // and those chains end the call (configs[4] shard 3.30 -> 3.04 ms, profiles/r03/r03ad_config4_lds_min.txt).  (The
+        // concurrent mode needs that LDS for the analysis workgroups beside the walk; its idle-start gate does this job.)
+        // AHEAD: the counts are all published by the time the kernel starts -- its one poll returns at once -- and its workgroups
+        // count themselves in for the next call's gate.
+        SpxTimed tm(timed, 1, stw);
+        spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, ((concurrent && !diag_nowait) || ahead) ? d_ready : nullptr,
+                        speedup_only, stw, false, M.exclusive_cu ? R.lds_per_cu / 2 + 1024 : 0, M.launch_lean);
+      }
+      if (M.ahead_forced && force->started_out) *force->started_out = d_ready + n;
       if (c == nch - 1 && !force) {
-        // every call of the plan that walks leaves its event in the ring (a pipelined call orders its producers behind the
-        // walk kernels of the two calls before it, pipelined or not)
-        if (ring_record(plan, stw, ws, st)) return -2;
+        // every call of the plan that walks leaves its event in the ring (a pipelined call orders its producers behind the walk
+        // kernels of the calls before it, pipelined or not)
+        if (ring_record(plan, stw, ws, st, out, n_out)) return -2;
         plan->ahead_started = (concurrent || ahead) ? d_ready + n : nullptr;   // (only these walk kernels count themselves in)
         plan->ahead_n = n;
+        plan->mixed_started.clear();
       }
     }
     // the caller's stream is "done" only when the side launches have retired too
@@ -1016,8 +1014,8 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     guard.last_stream = st;
     guard.valid = true;
   }
-  if (trial_slot >= 0) {
-    hipEvent_t& e1 = plan->trial.ev[2 * trial_slot + 1];
+  if (M.trial_slot >= 0) {
+    hipEvent_t& e1 = TR.ev[2 * M.trial_slot + 1];
     if (!e1) HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e1, st));
   }
@@ -1026,21 +1024,128 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   return 0;
 }
 
+// ---- a plain call of more streams than the device has CUs, split into sub-batches that overlap one another (round 5) ----
+// One spx_batch_run of 257 .. 4 x CUs streams used to run its kernels in sequence (512 streams: 2.87 ms, where two overlapped
+// 256-stream calls take 2.31).  Now the engine cuts such a batch into ceil(n / CUs) sub-batches of equal size -- same streams, in
+// job order; their workspaces carved from the caller's; the caller's in / out / n_out as they are -- and issues them as
+// overlapped calls on the plan's ring, so that sub-batch k + 1's analysis runs beside sub-batch k's walk kernel and the walk
+// kernels of consecutive sub-batches overlap.  The caller keeps the PLAIN stream order: every sub-batch's producers wait for an
+// event recorded on hip_stream when the call is made, and hip_stream waits for every sub-batch's walk kernel.  Taken only where
+// a sub-batch would run in the pipelined order with overlapping walk kernels (spx_choose_mode on the sub-shape says so); all
+// other batches run as one call.
+struct SplitPlan { int k; std::vector<int> first; std::vector<size_t> ws_off, ws_bytes; size_t total; };
+static SplitPlan split_geometry(const spx_plan* plan, const spx_stream_job* jobs, int n) {
+  SplitPlan P;
+  P.k = 1; P.total = 0;
+  static const int max_mult = [] { const char* e = spx_tuning_env("SPX_SPLIT_MAX"); return e ? atoi(e) : 4; }();
+  const int cu = plan->cu_count > 0 ? plan->cu_count : 1;
+  if (n <= cu || n > max_mult * cu) return P;
+  P.k = (n + cu - 1) / cu;
+  size_t o = 0;
+  for (int i = 0; i < P.k; i++) {
+    const int a = (int)((long long)n * i / P.k), b = (int)((long long)n * (i + 1) / P.k);
+    P.first.push_back(a);
+    const size_t bytes = layout_for(plan->dev, jobs + a, b - a).total;
+    P.ws_off.push_back(o); P.ws_bytes.push_back(bytes);
+    o += (bytes + 255) & ~(size_t)255;
+  }
+  P.first.push_back(n);
+  P.total = o;
+  return P;
+}
+static int run_split(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out, int64_t* n_out, void* ws,
+                     size_t ws_bytes, const spx_taps* taps, void* hs) {
+  if (!plan || !jobs || n <= 0) return fail(-1, "spx_batch: bad arguments");
+  SplitPlan P = split_geometry(plan, jobs, n);
+  if (P.k > 1 && (g_chunks_set.load() || ws_bytes < P.total)) P.k = 1;
+  if (P.k > 1) {
+    // would a sub-batch take the pipelined order with overlapping walk kernels?
+    int maxC = 1;
+    bool speedup_only = true;
+    for (int i = 0; i < n; i++) {
+      if (jobs[i].channels > maxC) maxC = jobs[i].channels;
+      if (!(jobs[i].speed > 1.0f && jobs[i].speed < SPX_FAST_MAX_SPEED && jobs[i].nonlinear >= 0.0f && jobs[i].nonlinear <= 1.0f)) speedup_only = false;
+    }
+    std::lock_guard<std::mutex> plan_lock(plan->mu);
+    const int m = P.first[1] - P.first[0];
+    const SpxModeResources& R = mode_resources(plan, m, maxC, speedup_only);
+    SpxModeShape S;
+    memset(&S, 0, sizeof(S));
+    S.n = m; S.max_channels = maxC; S.do_a = S.do_w = true; S.has_frames = true; S.force_total_streams = m;
+    S.ahead_req = S.overlap_req = true;
+    SpxModeRuntime T;
+    memset(&T, 0, sizeof(T));
+    T.trial_key = -2;
+    T.device_ours = device_ours_cb;
+    T.device_ctx = &plan->device;
+    const SpxModeTrial none = {-1, 0, -1};
+    const SpxMode M = spx_choose_mode(S, R, mode_env(), T, none);
+    if (!(M.ahead && M.walk2)) P.k = 1;
+  }
+  { std::lock_guard<std::mutex> g(plan->mu); plan->split_of[ws] = P.k; if (plan->split_of.size() > 64) { plan->split_of.clear(); plan->split_of[ws] = P.k; } }
+  if (P.k <= 1) return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true);
+  hipStream_t st = static_cast<hipStream_t>(hs);
+  hipEvent_t ev = nullptr;
+  {
+    // (one event per call in flight would be the exact thing; two taking turns are enough: the event is waited for by the
+    // sub-batches' producer streams, and those are ordered behind the previous split call's by the ring)
+    std::lock_guard<std::mutex> g(plan->mu);
+    hipEvent_t& e = plan->ev_split[plan->split_calls++ & 1];
+    if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ev = e;
+  }
+  HIPCHK(hipEventRecord(ev, st));
+  int64_t rows = 0;
+  for (int i = 0; i < P.k; i++) {
+    const int a = P.first[i], m = P.first[i + 1] - a;
+    spx_taps t;
+    if (taps) {
+      t = *taps;
+      if (t.tension) t.tension += rows;
+      if (t.speed) t.speed += rows;
+      if (t.features) t.features += rows * SPX_FEATURE_COUNT;
+      if (t.spectrogram) t.spectrogram += rows * (int64_t)plan->dev.N;
+      if (t.normalized) t.normalized += rows * (int64_t)plan->dev.W;
+      for (int j = a; j < a + m; j++) rows += jobs[j].nonlinear != 0.0f ? frames_for(plan->dev, jobs[j].n_in) : 0;
+    }
+    SpxCallOpts o;
+    o.ahead_req = o.overlap_req = o.sub = true;
+    o.in_ready = ev;
+    const int rc = run_impl(plan, jobs + a, m, in, out, n_out + a, static_cast<unsigned char*>(ws) + P.ws_off[i], P.ws_bytes[i],
+                            taps ? &t : nullptr, hs, true, true, o);
+    if (rc) return rc;   // (what the earlier sub-batches enqueued is already joined to hip_stream: ring_record)
+  }
+  return 0;
+}
+
+int spx_internal_run(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out, int64_t* n_out, void* ws,
+                     size_t ws_bytes, const spx_taps* taps, void* hs, bool ahead, bool overlap, void* in_ready) {
+  SpxCallOpts o;
+  o.ahead_req = ahead; o.overlap_req = overlap; o.in_ready = in_ready;
+  return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true, o);
+}
+
+extern "C" {
+// (the larger of the one-call layout and the sub-batch layouts: which of the two a spx_batch_run takes is decided per call)
+size_t spx_batch_workspace_bytes(spx_plan_t plan, const spx_stream_job* jobs, int n_streams) {
+  if (!plan || !jobs || n_streams < 1) return 0;
+  return std::max(layout_for(plan->dev, jobs, n_streams).total, split_geometry(plan, jobs, n_streams).total);
+}
 int spx_batch_run(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                   int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs) {
-  return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true);
+  return run_split(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs);
 }
 int spx_batch_run_ahead(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                         int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs) {
-  return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true, nullptr, true);
+  return spx_internal_run(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, false, nullptr);
 }
 int spx_batch_run_overlapped(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                              int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs) {
-  return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true, nullptr, true, nullptr, true);
+  return spx_internal_run(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true, nullptr);
 }
 int spx_batch_run_ahead_when(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                              int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs, void* in_ready_event) {
-  return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true, nullptr, true, in_ready_event);
+  return spx_internal_run(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, false, in_ready_event);
 }
 int spx_batch_analyze(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, void* ws,
                       size_t ws_bytes, const spx_taps* taps, void* hs) {
@@ -1096,7 +1201,14 @@ size_t spx_batch_workspace_bytes_mixed(const spx_plan_t* plans, int n_plans, con
 }
 static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
                       const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps,
-                      void* hs, bool ahead_req);
+                      void* hs, bool ahead_req, void* in_ready = nullptr);
+}  // extern "C"
+// (spx_pipeline.hip: a pipelined mixed call whose producers wait for an "input is there" event)
+int spx_internal_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n, const int16_t* in,
+                           int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, void* hs, bool ahead, void* in_ready) {
+  return mixed_impl(plans, n_plans, jobs, plan_index, n, in, out, n_out, ws, ws_bytes, nullptr, hs, ahead, in_ready);
+}
+extern "C" {
 int spx_batch_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
                         const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, void* hs) {
   return mixed_impl(plans, n_plans, jobs, plan_index, n, in, out, n_out, ws, ws_bytes, nullptr, hs, false);
@@ -1115,7 +1227,7 @@ int spx_batch_run_mixed_ahead(const spx_plan_t* plans, int n_plans, const spx_st
 }
 static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
                       const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps,
-                      void* hs, bool ahead_req) {
+                      void* hs, bool ahead_req, void* in_ready) {
   if (!plans || n_plans < 1 || n_plans > 8 || !jobs || n <= 0) return fail(-1, "spx_batch_run_mixed: bad arguments");
   SpxRange range_("spx_batch_run_mixed");
   std::vector<std::vector<spx_stream_job>> gj;
@@ -1127,13 +1239,10 @@ static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job
   hipStream_t st = static_cast<hipStream_t>(hs);
   spx_plan* lead = plans[0];
   for (int g = 0; g < n_plans; g++) if (plans[g]->device != lead->device) return fail(-1, "spx_batch_run_mixed: plans of different devices");
-  // ---- the launch mode, for all groups together (the rules of run_impl, summed / maximised over the groups) ----
-  size_t cons_lds = 0, cons_waves = 0, max_ps_lds = 0, max_an_lds = 0;
-  int max_walk_regs = 0, max_an_regs = 0, groups = 0;
-  bool fits_one = true;
+  // ---- the launch mode, for all groups together (spx_choose_mixed_mode: the rules of run_impl, summed / maximised over the groups) ----
+  std::vector<SpxModeGroup> G;
   for (int g = 0; g < n_plans; g++) {
     if (gj[g].empty()) continue;
-    groups++;
     const SpxPlanDev& d = plans[g]->dev;
     int maxC = 1; bool speedup_only = true, any_nl = false;
     for (const auto& j : gj[g]) {
@@ -1141,56 +1250,56 @@ static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job
       if (!(j.speed > 1.0f && j.speed < SPX_FAST_MAX_SPEED && j.nonlinear >= 0.0f && j.nonlinear <= 1.0f)) speedup_only = false;
       any_nl = any_nl || j.nonlinear != 0.0f;
     }
-    const int ng = (int)gj[g].size();
-    const SpxWalkConfig wc = spx_walk_config(d, ng, maxC, speedup_only);
-    if (wc.lds > 160 * 1024) return fail(-1, "spx_batch_run_mixed: too many channels for the walk kernel's LDS window");
-    const size_t ps = wc.lds + spx_tension_lds_bytes();
-    cons_lds += (size_t)ng * ps; cons_waves += (size_t)ng * (wc.waves + 4);
-    max_ps_lds = std::max(max_ps_lds, ps);
-    if (any_nl) {
-      max_an_lds = std::max(max_an_lds, spx_analysis_lds_bytes(d));
-      max_an_regs = std::max(max_an_regs, spx_analysis_vgprs(d));
-    }
-    max_walk_regs = std::max(max_walk_regs, ((wc.waves + 3) / 4) * spx_walk_vgprs(d, ng, maxC, speedup_only));
+    SpxModeGroup mg;
+    mg.n = (int)gj[g].size();
+    mg.walk = mode_walk(d, mg.n, maxC, speedup_only, false);
+    if (mg.walk.lds > 160 * 1024) return fail(-1, "spx_batch_run_mixed: too many channels for the walk kernel's LDS window");
+    mg.any_nonlinear = any_nl;
+    mg.an_lds = spx_analysis_lds_bytes(d);
+    mg.an_vgprs = spx_analysis_vgprs(d);
+    G.push_back(mg);
   }
-  bool concurrent = false;
-  const size_t lds_per_cu = lead->lds_per_cu;
-  if (max_an_lds > 0 && max_an_lds < lds_per_cu && n <= lead->cu_count) {
-    const size_t closed = cons_lds / (lds_per_cu - max_an_lds + 1) + cons_waves / 29;
-    concurrent = closed < (size_t)lead->cu_count;
-    // ... and worth it only while the analysis keeps its throughput beside the consumers: two analysis workgroups beside a
-    // stream's own on a CU, two analysis waves beside them on a SIMD (run_impl's rule).  Measured on the configs[4] shard
-    // (multi-channel walk kernel, 120 registers; 22.05 kHz analysis, 168): with ONE analysis wave per SIMD the analysis runs at
-    // a third of its speed and everything waits for it -- 5.4 ms per step concurrent against 3.8 in sequence.
-    const size_t lds_usable = lds_per_cu > 6144 ? lds_per_cu - 6144 : lds_per_cu;
-    if (max_ps_lds + 2 * max_an_lds > lds_usable) concurrent = false;
-    fits_one = max_walk_regs + spx_tension_vgprs() + 2 * max_an_regs <= 512;
-    if (!fits_one) concurrent = false;
-  }
-  static const bool env_serial = spx_tuning_env("SPX_SERIAL") != nullptr;
+  const int groups = (int)G.size();
   static const int env_mixed = spx_tuning_env("SPX_MIXED_MODE") ? atoi(spx_tuning_env("SPX_MIXED_MODE")) : -1;   // tuning: 0 sequence, 1 concurrent
-  if (!g_concurrent.load() || env_serial || groups == 0) concurrent = false;
-  if (env_mixed >= 0 && max_an_lds > 0) concurrent = env_mixed == 1;
-  if (concurrent && !device_is_ours(lead->device)) concurrent = false;
+  static const bool no_sjf = spx_tuning_env("SPX_MIXED_NO_ORDER") != nullptr;   // A/B
+  SpxModeRuntime T;
+  memset(&T, 0, sizeof(T));
+  T.device_ours = device_ours_cb;
+  T.device_ctx = &lead->device;
+  const SpxModeEnv E = mode_env();
+  SpxMixedMode MM = spx_choose_mixed_mode(G.data(), groups, n, lead->cu_count, lead->lds_per_cu, spx_tension_lds_bytes(), spx_tension_vgprs(),
+                                          E, env_mixed, no_sjf, ahead_req, T);
   // ---- the device guard, once for the whole call ----
   SpxDevGuard& guard = g_guard[(lead->device >= 0 && lead->device < 64) ? lead->device : 0];
   std::unique_lock<std::mutex> guard_lock(guard.mu, std::defer_lock);
   SpxForce force = {0, false, n, nullptr, nullptr, nullptr};
-  // pipelined with the previous call (spx_batch_run_mixed_ahead): kernels in sequence, one stream per CU at most
-  const bool ahead = ahead_req && !concurrent && g_concurrent.load() && !env_serial && groups > 0 && n <= lead->cu_count &&
-                     device_is_ours(lead->device);
-  if (concurrent) {
+  if (MM.concurrent) {
     guard_lock.lock();
     const hipError_t q = guard.valid ? hipEventQuery(guard.last) : hipSuccess;
-    force.idle_start = (q == hipSuccess);
-    if (guard.valid && guard.last_stream != st && q == hipErrorNotReady) concurrent = false;
     (void)hipGetLastError();
-    if (!concurrent) guard_lock.unlock();
+    force.idle_start = (q == hipSuccess);
+    if (guard.valid && guard.last_stream != st && q == hipErrorNotReady) {
+      T.guard_busy = true;
+      MM = spx_choose_mixed_mode(G.data(), groups, n, lead->cu_count, lead->lds_per_cu, spx_tension_lds_bytes(), spx_tension_vgprs(), E,
+                                 env_mixed, no_sjf, ahead_req, T);
+      guard_lock.unlock();
+    }
   }
+  const bool concurrent = MM.concurrent;
+  // pipelined with the previous call (spx_batch_run_mixed_ahead): kernels in sequence, one stream per CU at most
+  const bool ahead = MM.ahead;
   force.concurrent = concurrent ? 1 : 0;
   // ---- fork: every group on its plan's own stream ----
   std::lock_guard<std::mutex> lead_lock(lead->mix_mu);
+  {
+    // every call that goes through the lead plan's ring notes where the caller's stream stands when it is made: the next
+    // spx_batch_run_overlapped on that plan orders its walk kernel behind THIS note (round 4 left it to plain calls only, and
+    // an overlapped call behind a mixed one was ordered behind a stale note)
+    std::lock_guard<std::mutex> ring_lock(lead->mu);
+    if (ring_note(lead, st)) return -2;
+  }
   if (!lead->ev_fork) HIPCHK(hipEventCreateWithFlags(&lead->ev_fork, hipEventDisableTiming));
+  if (in_ready && !ahead) HIPCHK(hipStreamWaitEvent(st, static_cast<hipEvent_t>(in_ready), 0));   // (ahead: the producers' stream waits for it)
   HIPCHK(hipEventRecord(lead->ev_fork, st));
   unsigned char* w = static_cast<unsigned char*>(ws);
   int64_t* d_nout = reinterpret_cast<int64_t*>(w + M.off_nout);
@@ -1238,8 +1347,7 @@ static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job
   // 22.05 kHz at 0.87 instead of 0.92; the call ends with the later group's walk kernel).
   std::vector<int> ord;
   for (int g = 0; g < n_plans; g++) if (!gj[g].empty()) ord.push_back(g);
-  static const bool no_sjf = spx_tuning_env("SPX_MIXED_NO_ORDER") != nullptr;   // A/B
-  const bool chain_analyses = !concurrent && !no_sjf && ord.size() > 1;
+  const bool chain_analyses = MM.chain_analyses;
   if (chain_analyses) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return plans[a]->dev.rate < plans[b]->dev.rate; });
   // Which stream a group runs on.  Kernels in sequence (every mix measured so far): the first group on the CALLER's stream,
   // the second on the device's second side stream (idle in this mode), further groups on their plans' own streams -- so the
@@ -1254,9 +1362,13 @@ static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job
     // the producers' stream: behind the walk kernels of the lead plan's call before the previous one (the last user of this
     // workspace when two take turns; the previous call too if it used this workspace or another stream), and -- while the
     // previous call is still in flight -- behind gate kernels that wait until its walk workgroups have been placed
+    // (no gates when the producers wait for the previous call anyway -- the same workspace handed over again: its counters are
+    // the ones this call's staging kernels clear, and a gate would spin its full bound for counts nobody raises)
     std::lock_guard<std::mutex> ring_lock(lead->mu);
-    if (ring_wait(lead, dev_s1, ws, st)) return -2;
-    const bool in_flight = ring_previous_in_flight(lead);
+    bool waited_prev = false;
+    if (ring_wait(lead, dev_s1, ws, st, &waited_prev)) return -2;
+    const bool in_flight = !waited_prev && ring_previous_in_flight(lead);
+    if (in_ready) HIPCHK(hipStreamWaitEvent(dev_s1, static_cast<hipEvent_t>(in_ready), 0));   // the caller's "input is there"
     if (in_flight)
       for (const auto& sn : lead->mixed_started)
         if (sn.first && sn.second > 0) hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, dev_s1, sn.first, sn.second, 8000u);
@@ -1285,8 +1397,10 @@ static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job
       f.after_analysis = p->ev_an;
       prev_an = p->ev_an;
     }
+    SpxCallOpts go;
+    go.force = &f;
     rc = run_impl(p, gj[g].data(), (int)gj[g].size(), in, out, d_nout + gpos[g], w + M.ws_off[g], M.ws_bytes[g], taps ? &gtaps[g] : nullptr, gs,
-                  true, true, &f);
+                  true, true, go);
     // (also when the group failed: whatever it -- and the groups before it -- enqueued on their streams still reads the
     // caller's buffers, so the caller's stream waits for it before the error is returned)
     const std::string err = rc ? g_err : std::string();
@@ -1301,7 +1415,7 @@ static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job
   {
     // every mixed call leaves its end in the lead plan's ring (a pipelined call orders its producers behind the two calls before it)
     std::lock_guard<std::mutex> ring_lock(lead->mu);
-    if (ring_record(lead, st, ws, st)) return -2;
+    if (ring_record(lead, st, ws, st, out, n_out)) return -2;
     lead->ahead_started = nullptr;
     lead->ahead_n = 0;
     lead->mixed_started.clear();
@@ -1331,7 +1445,17 @@ static int read_steps(const SpxPlanDev& d, const spx_stream_job* jobs, int n, co
 }
 int spx_batch_read_steps(spx_plan_t plan, const spx_stream_job* jobs, int n, const void* ws, int32_t* steps, void* hs) {
   if (!plan || !jobs || n <= 0 || !ws || !steps) return fail(-1, "spx_batch_read_steps: bad arguments");
-  return read_steps(plan->dev, jobs, n, ws, steps, static_cast<hipStream_t>(hs));
+  int k = 1;
+  { std::lock_guard<std::mutex> g(plan->mu); auto it = plan->split_of.find(ws); if (it != plan->split_of.end()) k = it->second; }
+  if (k <= 1) return read_steps(plan->dev, jobs, n, ws, steps, static_cast<hipStream_t>(hs));
+  // the call that last ran on this workspace was split into sub-batches (run_split): their state records sit in their slices
+  const SplitPlan P = split_geometry(plan, jobs, n);
+  for (int i = 0; i < P.k; i++) {
+    const int a = P.first[i], m = P.first[i + 1] - a;
+    const int rc = read_steps(plan->dev, jobs + a, m, static_cast<const unsigned char*>(ws) + P.ws_off[i], steps + a, static_cast<hipStream_t>(hs));
+    if (rc) return rc;
+  }
+  return 0;
 }
 int spx_batch_read_steps_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
                                const void* ws, int32_t* steps, void* hs) {

@@ -136,6 +136,26 @@ def test_c_batch_example(orc, tmp_path, name, speed, nl, copies, split):
     assert np.array_equal(np.fromfile(out, dtype="<i2"), ref)
 
 
+@pytest.mark.parametrize("name,speed,nl,copies,batches,depth", [("tapestry.wav", 3.5, 1.0, 64, 9, 4), ("tapestry22050.wav", 1.5, 1.0, 7, 5, 2),
+                                                                ("tapestry.wav", 2.0, 0.0, 300, 4, 3)])
+def test_c_pipeline_example(orc, tmp_path, name, speed, nl, copies, batches, depth):
+    """INTEGRATION.md section 2 "batch after batch" as a plain C99 program (tools/pipeline_example.c over include/speedy_hip.h, no
+    HIP headers): batches of COPIES streams through one spx_pipeline, host memory to host memory, inputs produced in the
+    pipeline's staging buffer and in a pinned buffer of the caller's by turns -- every stream of every batch equal to the oracle's."""
+    exe = os.path.join(ROOT, "speedy_amd", "lib", "pipeline_example")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "speedy_amd", "csrc"), "pipeexample"])
+    x, rate, ch = read_wav(name)
+    x = x[: 3 * rate * ch]
+    raw, out = str(tmp_path / "in.raw"), str(tmp_path / "out.raw")
+    x.astype("<i2").tofile(raw)
+    r = subprocess.run([exe, raw, str(rate), str(ch), str(speed), str(nl), str(copies), str(batches), str(depth), out],
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr + r.stdout
+    ref = orc.compress_sound(x, rate, ch, speed, nl, 0.0, False, chunk=1000 if nl else x.size // ch, taps=False)["out"]
+    assert np.array_equal(np.fromfile(out, dtype="<i2"), ref)
+
+
 @pytest.mark.parametrize("seed,handles,env", [(1, 24, {}), (2, 40, {}), (3, 16, {}),
                                               # a frame arena that must grow several times, a staging area that forces runs
                                               (4, 48, {"SPX_POOL_FRAMES": "1024"}),

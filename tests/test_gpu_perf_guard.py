@@ -39,6 +39,58 @@ def measure_walk_ms(steps=12, warm=4):
     return out, names[2]
 
 
+def measure_pipelined(steps=40, warm=12):
+    """The headline's loop: the bench batch through the owning pipeline object (resident input, outputs left on the device).
+    Two windows; per window (ms per step, average launch of the walk kernel -- its LEAN form, two launches in flight -- in ms)."""
+    import time
+    import torch
+    import bench
+    from speedy_amd.batch import Batch, Pipeline, Plan
+    n = bench.RATE * bench.SECONDS
+    plan = Plan(bench.RATE, False)
+    b = Batch(plan, [n] * bench.STREAMS_PER_GPU, 1, bench.SPEED, 1.0, 0.0)
+    b.upload(bench.make_streams(bench.STREAMS_PER_GPU, n, 0))
+    pipe = Pipeline(plan, [n] * bench.STREAMS_PER_GPU, 1, bench.SPEED, 1.0, 0.0, depth=4, device_out=True)
+    L = plan.L
+    out = []
+    for _ in range(2):
+        for _ in range(warm):
+            pipe.submit(b.d_in)
+        torch.cuda.synchronize()
+        L.spx_set_timing(1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe.submit(b.d_in)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        L.spx_set_timing(0)
+        sa, sw, nc = C.c_double(0), C.c_double(0), C.c_int(0)
+        L.spx_timing_collect(C.byref(sa), C.byref(sw), C.byref(nc))
+        out.append((dt * 1e3, sw.value / max(1, nc.value)))
+    form = L.spx_debug_last_walk_form()
+    names = (L.spx_batch_kernel_names_lean if form == 64 else L.spx_batch_kernel_names)(plan.h, bench.STREAMS_PER_GPU, 1, 1).decode().split(";")
+    pipe.close()
+    return out, names[2]
+
+
+def test_pipelined_step_and_lean_walk_kernel_within_10_percent_of_reference():
+    """Round 5: the guard also watches the kernel the HEADLINE runs on -- the lean walk form inside the pipelined loop -- and the
+    step time of that loop (profiles/perf_reference.json "pipelined", written by tools/perf_reference.py)."""
+    ref = json.load(open(os.path.join(ROOT, "profiles", "perf_reference.json"))).get("pipelined")
+    if not ref:
+        pytest.skip("profiles/perf_reference.json has no 'pipelined' entry yet (python tools/perf_reference.py on the GPU box)")
+    (a, b), kernel = measure_pipelined()
+    if abs(a[0] - b[0]) > 0.04 * min(a[0], b[0]):
+        pytest.skip("noisy box: two windows of the pipelined loop %.3f / %.3f ms per step" % (a[0], b[0]))
+    assert kernel == ref["kernel"], (kernel, ref["kernel"])
+    step, walk = min(a[0], b[0]), min(a[1], b[1])
+    msg = "pipelined loop %.3f ms per step (reference %.3f), lean walk kernel %.3f ms per launch (reference %.3f)" % (
+        step, ref["ms_per_step"], walk, ref["walk_ms_per_launch"])
+    assert step <= 1.10 * ref["ms_per_step"] and walk <= 1.10 * ref["walk_ms_per_launch"], msg
+    if step > 1.05 * ref["ms_per_step"]:
+        pytest.skip(msg + " -- between 5 and 10 %: check on another box")
+
+
 def test_walk_kernel_within_5_percent_of_reference():
     ref = json.load(open(os.path.join(ROOT, "profiles", "perf_reference.json")))
     (a, b), kernel = measure_walk_ms()

@@ -1,0 +1,195 @@
+"""spx_pipeline (include/speedy_hip.h): the owning pipeline -- batch after batch of one shape, host memory to host memory, with
+the library issuing the copy in, the overlapped batch call and the gather into pinned host memory itself.  Whatever is in flight
+beside a batch, its output must be the oracle's (and spx_batch_run's)."""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _crc(outs):
+    return [zlib.crc32(np.ascontiguousarray(o).tobytes()) for o in outs]
+
+
+def _signals(rate, ch, n_streams, seed, lens):
+    from speedy_amd.synth import speech_like
+    base = [speech_like(max(lens), rate, seed=1000 * seed + i, channels=ch) for i in range(min(n_streams, 10))]
+    return [base[i % len(base)][: lens[i] * ch] for i in range(n_streams)]
+
+
+@pytest.mark.parametrize("rate,ch,n_streams,depth", [(16000, 1, 256, 4), (16000, 1, 256, 3), (16000, 1, 61, 2), (22050, 1, 256, 4),
+                                                     (16000, 2, 128, 3), (48000, 2, 40, 4), (16000, 1, 600, 3)])
+def test_batches_of_different_content_through_the_pipeline(orc, rate, ch, n_streams, depth):
+    """Three batches of one shape and DIFFERENT content go through the pipeline again and again (14 submits, tickets waited for
+    with a lag, as a caller that keeps the device busy would): every ticket's output must be what spx_batch_run gives for that
+    content, and that is checked against the oracle on three streams per content."""
+    import torch
+    from speedy_amd.batch import Batch, Pipeline, Plan
+    plan = Plan(rate, False)
+    rng = np.random.default_rng(n_streams * 7 + depth)
+    lens = [int(rate * rng.uniform(0.4, 1.1)) for _ in range(n_streams)]
+    b = Batch(plan, lens, ch, 3.5, 1.0, 0.0)
+    contents, want = [], []
+    for seed in (11, 12, 13):
+        xs = _signals(rate, ch, n_streams, seed, lens)
+        b.upload(xs)
+        b.run()
+        crcs = _crc(b.results())
+        for i in (0, n_streams // 2, n_streams - 1):
+            ref = orc.compress_sound(xs[i], rate, ch, 3.5, 1.0, 0.0, False, chunk=1000)
+            assert crcs[i] == zlib.crc32(np.ascontiguousarray(ref["out"]).tobytes()), (seed, i)
+        want.append(crcs)
+    pipe = Pipeline(plan, lens, ch, 3.5, 1.0, 0.0, depth=depth)
+    assert pipe.depth == depth
+    for xs_seed in (11, 12, 13):
+        contents.append(torch.from_numpy(pipe.pack(_signals(rate, ch, n_streams, xs_seed, lens))).pin_memory())
+    tickets = []
+    lag = depth - 1
+    for k in range(14):
+        tickets.append((pipe.submit(contents[k % 3]), k % 3))
+        if k >= lag:
+            t, c = tickets[k - lag]
+            assert _crc(pipe.results(t)) == want[c], (k, t, c)
+    for t, c in tickets[len(tickets) - lag:]:
+        assert _crc(pipe.results(t)) == want[c], (t, c)
+    if (rate, ch, n_streams) == (16000, 1, 256):
+        assert plan.L.spx_debug_last_call_concurrent() == 2          # the headline's shape takes the pipelined order
+        assert plan.L.spx_debug_last_walk_form() == (16 * 4 + 0 if depth >= 3 else 16 * 4 + 4)   # ... lean walk kernels from three buffer sets on
+    # an expired ticket is refused, a future one too
+    with pytest.raises(RuntimeError):
+        pipe.wait(tickets[0][0])
+    with pytest.raises(RuntimeError):
+        pipe.wait(tickets[-1][0] + 1)
+    pipe.close()
+
+
+def test_offsets_are_aligned_and_counts_are_the_batch_calls(orc):
+    import torch
+    from speedy_amd.batch import Batch, Pipeline, Plan
+    plan = Plan(16000, False)
+    lens = [16000 + 137 * i for i in range(33)]
+    xs = _signals(16000, 1, 33, 5, lens)
+    b = Batch(plan, lens, 1, 2.0, 0.0, 0.0)       # linear jobs: the TSM stage alone
+    b.upload(xs)
+    b.run()
+    res = b.results()
+    pipe = Pipeline(plan, lens, 1, 2.0, 0.0, 0.0, depth=2)
+    t = pipe.submit(pipe.pack(xs))                 # pageable host memory is accepted as well
+    out, offsets, counts = pipe.wait(t)
+    assert all(int(o) % 32 == 0 for o in offsets)
+    assert [int(c) for c in counts] == [r.size for r in res]
+    for i in range(33):
+        assert np.array_equal(out[int(offsets[i]):int(offsets[i]) + int(counts[i])], res[i]), i
+    pipe.close()
+
+
+def test_device_input_and_device_output(orc):
+    """The resident form (bench.py's `value`): the input is a device tensor, the outputs stay in device memory."""
+    import torch
+    from speedy_amd.batch import Batch, Pipeline, Plan
+    plan = Plan(16000, False)
+    lens = [24000] * 256
+    xs = _signals(16000, 1, 256, 21, lens)
+    b = Batch(plan, lens, 1, 3.5, 1.0, 0.0)
+    b.upload(xs)
+    b.run()
+    want = _crc(b.results())
+    ref = orc.compress_sound(xs[3], 16000, 1, 3.5, 1.0, 0.0, False, chunk=1000)
+    assert want[3] == zlib.crc32(np.ascontiguousarray(ref["out"]).tobytes())
+    pipe = Pipeline(plan, lens, 1, 3.5, 1.0, 0.0, depth=4, device_out=True)
+    d_in = b.d_in
+    ts = [pipe.submit(d_in) for _ in range(9)]
+    for t in ts[-4:]:
+        assert _crc(pipe.results(t)) == want, t
+    pipe.close()
+
+
+def test_staging_buffer_of_the_pipeline(orc):
+    """spx_pipeline_host_input: the caller produces each batch's input in the pipeline's own pinned staging buffer."""
+    from speedy_amd.batch import Batch, Pipeline, Plan
+    plan = Plan(22050, False)
+    lens = [22050] * 40
+    b = Batch(plan, lens, 2, 1.5, 1.0, 0.0)
+    want = []
+    packed = []
+    pipe = Pipeline(plan, lens, 2, 1.5, 1.0, 0.0, depth=3)
+    for seed in (31, 32):
+        xs = _signals(22050, 2, 40, seed, lens)
+        b.upload(xs)
+        b.run()
+        want.append(_crc(b.results()))
+        packed.append(pipe.pack(xs))
+    ref = orc.compress_sound(_signals(22050, 2, 40, 32, lens)[7], 22050, 2, 1.5, 1.0, 0.0, False, chunk=1000)
+    assert want[1][7] == zlib.crc32(np.ascontiguousarray(ref["out"]).tobytes())
+    ts = []
+    for k in range(8):
+        h = pipe.host_input()
+        h[:] = packed[k % 2]
+        ts.append((pipe.submit(h), k % 2))
+    for t, c in ts[-3:]:
+        assert _crc(pipe.results(t)) == want[c], (t, c)
+    pipe.close()
+
+
+def test_mixed_rate_pipeline(orc):
+    """spx_pipeline_create_mixed: one GPU's kind of BASELINE configs[4] shard (16 / 22.05 kHz, mono / stereo, 1.5x / 3.5x) in small."""
+    import torch
+    from speedy_amd.batch import MixedBatch, Pipeline, Plan
+    from speedy_amd.synth import speech_like
+    rates = [16000, 22050]
+    plans = [Plan(r, False) for r in rates]
+    n = 120
+    pidx = [i % 2 for i in range(n)]
+    chs = [1 if (i // 2) % 2 == 0 else 2 for i in range(n)]
+    speeds = [1.5 if (i // 4) % 2 == 0 else 3.5 for i in range(n)]
+    lens = [int(rates[pidx[i]] * (0.5 + 0.004 * i)) for i in range(n)]
+    want, packed = [], []
+    mb = MixedBatch(plans, pidx, lens, chs, speeds, 1.0, 0.0)
+    pipe = Pipeline(plans, lens, chs, speeds, 1.0, 0.0, depth=3, plan_index=pidx)
+    for seed in (41, 42, 43):
+        xs = [speech_like(lens[i], rates[pidx[i]], seed=seed * 100 + (i % 12), channels=chs[i]) for i in range(n)]
+        mb.upload(xs)
+        mb.run()
+        want.append(mb.crcs())
+        for i in (0, 61, n - 1):
+            ref = orc.compress_sound(xs[i], rates[pidx[i]], chs[i], speeds[i], 1.0, 0.0, False, chunk=1000)
+            assert want[-1][i] == zlib.crc32(np.ascontiguousarray(ref["out"]).tobytes()), (seed, i)
+        packed.append(torch.from_numpy(pipe.pack(xs)).pin_memory())
+    ts = [(pipe.submit(packed[k % 3]), k % 3) for k in range(3)]
+    for k in range(3, 12):
+        t, c = ts[k - 2]
+        assert _crc(pipe.results(t)) == want[c], (t, c)
+        ts.append((pipe.submit(packed[k % 3]), k % 3))
+    for t, c in ts[-2:]:
+        assert _crc(pipe.results(t)) == want[c], (t, c)
+    pipe.close()
+
+
+def test_two_pipelines_and_plain_calls_side_by_side(orc):
+    """Two pipelines of different plans alive at once, with plain spx_batch_run calls of a third shape in between."""
+    from speedy_amd.batch import Batch, Pipeline, Plan
+    p16, p22 = Plan(16000, False), Plan(22050, False)
+    l16, l22 = [16000] * 256, [11025] * 100
+    x16, x22 = _signals(16000, 1, 256, 51, l16), _signals(22050, 1, 100, 52, l22)
+    b16, b22 = Batch(p16, l16, 1, 3.5, 1.0, 0.0), Batch(p22, l22, 1, 3.5, 1.0, 0.0)
+    b16.upload(x16); b16.run(); w16 = _crc(b16.results())
+    b22.upload(x22); b22.run(); w22 = _crc(b22.results())
+    for i, (x, rate, w) in enumerate(((x16[5], 16000, w16[5]), (x22[9], 22050, w22[9]))):
+        ref = orc.compress_sound(x, rate, 1, 3.5, 1.0, 0.0, False, chunk=1000)
+        assert w == zlib.crc32(np.ascontiguousarray(ref["out"]).tobytes()), i
+    pa, pb = Pipeline(p16, l16, 1, 3.5, 1.0, 0.0, depth=3), Pipeline(p22, l22, 1, 3.5, 1.0, 0.0, depth=2)
+    ia, ib = pa.pack(x16), pb.pack(x22)
+    ta, tb = [], []
+    for k in range(6):
+        ta.append(pa.submit(ia))
+        tb.append(pb.submit(ib))
+        if k % 2:
+            b16.run()
+    for t in ta[-3:]:
+        assert _crc(pa.results(t)) == w16
+    for t in tb[-2:]:
+        assert _crc(pb.results(t)) == w22
+    assert _crc(b16.results()) == w16
+    pa.close(); pb.close()

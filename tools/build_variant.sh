@@ -9,7 +9,7 @@ mkdir -p ../lib/ab ../lib/obj
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function"
 /opt/rocm/bin/hipcc $FLAGS $EXTRA -c spx_hot.hip -o ../lib/obj/spx_hot_$NAME.o
 OBJ=""
-for o in spx_walk spx_engine sonic2_api speedy_api spx_rate sonic2_pool wave_compat; do OBJ="$OBJ ../lib/obj/$o.o"; done
+for o in spx_walk spx_engine spx_pipeline sonic2_api speedy_api spx_rate sonic2_pool wave_compat; do OBJ="$OBJ ../lib/obj/$o.o"; done
 /opt/rocm/bin/hipcc $FLAGS -shared -o ../lib/ab/libspeedy_hip_$NAME.so ../lib/obj/spx_hot_$NAME.o $OBJ
 rm -f ../lib/obj/spx_hot_$NAME.o
 echo "built speedy_amd/lib/ab/libspeedy_hip_$NAME.so"
