@@ -91,3 +91,20 @@ def test_config4_strong_scaling_partitions_agree():
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["ok"] and out["config4_streams_checked"] == 512 and out["runs"]["2"]["n_ranks_seen"] == 2
+
+
+def test_eight_ranks_functionally_on_one_gpu():
+    """The world size the target names, before a node exists (round-4 review): `bench.py --gpus 8` with eight self-spawned ranks
+    SHARING this box's GPU over gloo -- port allocation, the per-device lock file, the handshake, the time-outs and the
+    strong-scaling partition of configs[4] at N = 8 -- and tools/check_scale.py's CRC agreement between the 1-rank and the 8-rank
+    runs: 2 048 headline streams and all 2 048 configs[4] streams (one call at N = 1, eight 256-stream shards at N = 8).  No
+    scaling number is asked for: the ranks take turns on one device."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_scale.py"), "--gpus", "1,8", "--backend", "gloo",
+                        "--config4", "--total-streams", "2048", "--steps", "1"],
+                       capture_output=True, text=True, timeout=3000, env=env)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2500:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["ok"] and out["config4_streams_checked"] == 2048, out
+    run8 = out["runs"]["8"]
+    assert run8["n_ranks_seen"] == 8 and run8["backend"] == "gloo" and run8["ranks"] == list(range(8)), run8

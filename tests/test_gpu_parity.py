@@ -13,6 +13,7 @@ import pytest
 from util import read_wav
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-4  # north_star: "float spectrogram/tension within 1e-4"
 
 
@@ -782,6 +783,22 @@ def test_kernel_resources_of_every_form_the_engine_selects():
     L.spx_debug_analysis_info(22050, a); a22 = a[0]
     ten = L.spx_debug_kernel_vgprs(0)
     assert 2 * w16 + ten + 2 * a16 <= 512 and lean22 + ten + 2 * a22 <= 512, (w16, lean22, a16, a22, ten)
+
+
+def test_committed_kernel_resources_are_the_librarys():
+    """profiles/kernel_resources.json -- what tests/test_mode_table.py replays the engine's launch-mode decision from on the CPU --
+    against the library on this box (spx_debug_mode_resources: spx_walk_config, the LDS layouts, hipFuncGetAttributes).  A kernel
+    change that moves a number must come with a refreshed file (python tools/kernel_resources.py), and the CPU table then shows
+    whether a mode moved with it."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    want = json.load(open(os.path.join(ROOT, "profiles", "kernel_resources.json")))
+    got = kernel_resources.collect()
+    assert got["fields"] == want["fields"]
+    assert got["shapes"] == want["shapes"], {k: (dict(zip(got["fields"], v)), dict(zip(got["fields"], want["shapes"].get(k, []))))
+                                             for k, v in got["shapes"].items() if v != want["shapes"].get(k)}
 
 
 def test_fast_division_equals_the_ieee_quotient():
