@@ -523,6 +523,8 @@ def main():
         from speedy_amd.batch import Pipeline
         pipe = Pipeline(plan, [n] * STREAMS_PER_GPU, 1, SPEED, 1.0, 0.0, depth=int(os.environ.get("SPX_BENCH_DEPTH", "4")), device_out=True)
 
+    pipe_depth = pipe.depth if pipe is not None else 1
+
     def step(k):
         if pipe is not None:
             tickets.append(pipe.submit(b.d_in))
@@ -563,6 +565,7 @@ def main():
             outs2 = pipe.results(t)
             assert len(outs2) == len(outs) and all(np.array_equal(x, y) for x, y in zip(outs, outs2)), "the batches of the pipelined loop differ"
             del outs2
+        pipe.close()   # (its streams and buffers go before the other legs run)
     n_out = int(sum(o.size for o in outs))
     chain_steps = b.step_counts()         # pitch searches per stream: the length of every stream's dependent chain
     if dt_single is not None:
@@ -784,7 +787,7 @@ def main():
                        # how `value` was produced, where a parsed record finds it (round-4 review): the like-for-like figure of rounds
                        # 1-4, the buffer sets the library owns for the pipelined steps, the walk kernels in flight at a time
                        "unpipelined_ms_per_step": None if dt_single is None else dt_single * 1e3,
-                       "buffer_sets": (pipe.depth if pipe is not None else 1),
+                       "buffer_sets": (pipe_depth if pipe is not None else 1),
                        "walk_launches_in_flight": (2 if (pipe is not None and last_mode == 2) else 1),
                        "timed_through": ("spx_pipeline_submit (device-resident input, SPX_PIPELINE_DEVICE_OUT)" if pipe is not None else "spx_batch_run"),
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),

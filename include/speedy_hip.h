@@ -257,6 +257,11 @@ long long spx_debug_fdiv_check(unsigned seed, unsigned denominators, int exp_lo,
  * `per_thread` pseudo-random operands of the ranges the kernel feeds them; the number of results that differ from the IEEE
  * sequences' (0 is the only acceptable answer), -1 on a runtime error. */
 long long spx_debug_arith_check(unsigned seed, unsigned threads, unsigned per_thread);
+/* The analysis kernel's natural log ("log spec v2", DESIGN.md 4a: its argument is always a float quotient, speedy.c:716-717) over
+ * EVERY positive normal float: block b = the 2^20 float patterns b << 20 ..; sums[b] (HOST uint64[2040], blocks 8 .. 2039 filled) =
+ * the sum of the results' bit patterns modulo 2^64.  The oracle computes the same sums (oracle/orc_logcheck.c): equal sums, block
+ * for block, are bit-equality on the whole domain.  Returns 0, negative on error. */
+int spx_debug_log_check(unsigned first_block, unsigned end_block, unsigned long long* sums);
 /* Diagnostics: 1 if the last spx_batch_run / analyze+walk call of this process took the concurrent three-kernel mode, 2 if it was
  * pipelined with the previous call (spx_batch_run_ahead), 0 if it launched its kernels in sequence (another process holds the
  * device's concurrent-mode lock, a tuning variable, the batch shape). */

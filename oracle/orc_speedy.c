@@ -11,9 +11,12 @@
  *      neither of which exists in this image.  The transform here is the repo's own "DFT spec"
  *      (DESIGN.md): a W-point double-precision mixed-radix Stockham transform of the packed real
  *      frame followed by the real-input untangle, magnitude = (float)sqrt(re*re + im*im).
- *   2. log(): the reference calls libm's log (speedy.c:716).  orc_log below is a fixed operation
- *      sequence (the classic fdlibm polynomial) so that the HIP kernel can reproduce it bit for bit;
- *      it agrees with glibc's log to <= 1 ulp (tests/test_oracle_dft_log.py).
+ *   2. log(): the reference calls libm's log (speedy.c:716) on a FLOAT quotient promoted to double (speedy.c:716-717:
+ *      float + float, float / float).  orc_log_spec below is a fixed operation sequence so that the HIP kernel can
+ *      reproduce it bit for bit: for a positive normal float argument "log spec v2" (round 5: a 128-entry table, an exact
+ *      argument reduction r = z * invc - 1, a degree-7 polynomial with fused multiply-adds), for every other
+ *      double "log spec v1" (orc_log: the classic fdlibm sequence, no FMA).  Both agree with glibc's log to <= 1 ulp -- v2
+ *      over ALL 2^31 positive floats (oracle/orc_logcheck.c runs them; tests/test_oracle_dft_log.py).
  */
 #include "orc_speedy.h"
 
@@ -29,6 +32,54 @@
 #define kFrameRateHz 100.0 /* speedy.c:90 */
 #define kMinimumSpeed 0.01 /* speedy.c:92 */
 #define ORC_MAX_HYST (12 + 12 + 1)
+
+/* log spec v2: for x = a positive normal float.
+ *   bits = pattern of x;  t = bits - 0x3f328000;  k = t >> 23 (arithmetic);  i = (t >> 16) & 127;
+ *   z = float with pattern bits - (t & 0xff800000): x = 2^k z, z in [0.697265625, 1.39453125), bucket 77 centred on 1.0
+ *   r = fma(z, invc[i], -1): EXACT (24-bit x 24-bit significands; the difference from 1 is below 2^-7.9)
+ *   log x = k ln2 + logc[i] + log1p(r),  logc[i] = logc_hi[i] (a multiple of 2^-43) + logc_lo[i] (a float):
+ *     w = fma(k, Ln2hi, logc_hi[i])  (EXACT: Ln2hi has 42 significant bits);  hi = w + r;  lo = (w - hi) + r  (exact two-sum: w = 0
+ *     or |w| > |r|);  lo = fma(k, Ln2lo, lo + logc_lo[i])
+ *     p = fma(1/7, r, -1/6); p = fma(p, r, 1/5); p = fma(p, r, -1/4); p = fma(p, r, 1/3); p = fma(p, r, -1/2)
+ *     result = fma(r * r, p, lo) + hi
+ * Every operation is an IEEE-754 double operation (fma = one rounding), so the sequence means the same on any machine. */
+#include "orc_log_table.h"
+static const struct { double logc_hi; float invc, logc_lo; } orc_log_tab[128] = {ORC_LOG_TABLE_ENTRIES};
+static int orc_log_spec_v = 2;
+void orc_set_log_spec(int v) { orc_log_spec_v = v == 1 ? 1 : 2; } /* 1: the fdlibm sequence for every argument (round 1-4's spec) */
+int orc_get_log_spec(void) { return orc_log_spec_v; }
+double orc_log(double x);
+double orc_log_v2_f32(float xf) { /* xf positive, normal, finite */
+  static const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
+  uint32_t bits, t, zb;
+  float z;
+  memcpy(&bits, &xf, 4);
+  t = bits - 0x3f328000u;
+  const int32_t k = (int32_t)t >> 23;
+  const uint32_t i = (t >> 16) & 127u;
+  zb = bits - (t & 0xff800000u);
+  memcpy(&z, &zb, 4);
+  const double r = fma((double)z, (double)orc_log_tab[i].invc, -1.0);
+  const double kd = (double)k;
+  const double w = fma(kd, Ln2hi, orc_log_tab[i].logc_hi);
+  const double hi = w + r;
+  double lo = (w - hi) + r;
+  lo = fma(kd, Ln2lo, lo + (double)orc_log_tab[i].logc_lo);
+  const double r2 = r * r;
+  double p = fma(0x1.2492492492492p-3, r, -0x1.5555555555555p-3); /* 1/7, -1/6 */
+  p = fma(p, r, 0x1.999999999999ap-3);                            /* 1/5 */
+  p = fma(p, r, -0.25);
+  p = fma(p, r, 0x1.5555555555555p-2);                            /* 1/3 */
+  p = fma(p, r, -0.5);
+  return fma(r2, p, lo) + hi;
+}
+/* The log the analysis uses: v2 where the argument is a positive normal float (always, on the path: speedy.c:716-717 forms
+ * a float quotient of two floats >= 2.2e-16), v1 for anything else a caller of the unit-level hooks may feed it. */
+double orc_log_spec(double x) {
+  const float xf = (float)x;
+  if (orc_log_spec_v == 2 && (double)xf == x && xf >= 0x1p-126f && xf <= 0x1.fffffep+127f) return orc_log_v2_f32(xf);
+  return orc_log(x);
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* First-order filter, speedy.c:50-88                                                          */
@@ -205,9 +256,28 @@ static void orc_plan_destroy(orc_plan* p) {
 #define S5_2 0.58778525229247313
 #define S3_1 0.86602540378443865
 
+/* DFT spec v2 (round 5): the same transform with the multiply-add pairs of the twiddle products, of the radix-3 / 5 /
+ * prime butterflies and of the untangle FUSED (fma = one rounding) -- what FFTW's own codelets do on a machine that has the
+ * instruction, and a quarter fewer operations for the kernel.  orc_set_dft_spec(1): the unfused sequence of rounds 1-4. */
+static int orc_dft_spec_v = 1; /* (2 once the kernel follows) */
+void orc_set_dft_spec(int v) { orc_dft_spec_v = v == 1 ? 1 : 2; }
+int orc_get_dft_spec(void) { return orc_dft_spec_v; }
+/* y = b * w (a twiddle or pointwise product), v2: re = fma(br, wr, -(bi wi)), im = fma(br, wi, bi wr) */
+static inline void orc_cmul(double br, double bi, double wr, double wi, double* yr, double* yi) {
+  if (orc_dft_spec_v == 2) {
+    *yr = fma(br, wr, -(bi * wi));
+    *yi = fma(br, wi, bi * wr);
+  } else {
+    *yr = br * wr - bi * wi;
+    *yi = br * wi + bi * wr;
+  }
+}
+
 /* One radix-r butterfly: a[i] (re,im) for i<r -> b[j].  Fixed operation order. */
+static void orc_butterfly_v2(const orc_plan* P, int r, const double* ar, const double* ai, double* br, double* bi);
 static void orc_butterfly(const orc_plan* P, int r, const double* ar, const double* ai, double* br,
                           double* bi) {
+  if (orc_dft_spec_v == 2 && r != 2 && r != 4) { orc_butterfly_v2(P, r, ar, ai, br, bi); return; }
   if (r == 2) {
     br[0] = ar[0] + ar[1]; bi[0] = ai[0] + ai[1];
     br[1] = ar[0] - ar[1]; bi[1] = ai[0] - ai[1];
@@ -274,6 +344,58 @@ static void orc_butterfly(const orc_plan* P, int r, const double* ar, const doub
   }
 }
 
+/* v2 of the butterflies that multiply (radix 2 and 4 only add):
+ *   radix 3:  t2 = fma(-1/2, t1, a0)
+ *   radix 5:  m1 = fma(C2, t2, fma(C1, t1, a0)), m2 = fma(C1, t2, fma(C2, t1, a0)), n1 = fma(S1, t3, S2 t4), n2 = fma(S2, t3, -(S1 t4))
+ *   prime r:  P_j = fma(c, u_i, P_j), Q_j = s v_1 then fma(s, v_i, Q_j)                                                     */
+static void orc_butterfly_v2(const orc_plan* P, int r, const double* ar, const double* ai, double* br, double* bi) {
+  if (r == 3) {
+    double t1r = ar[1] + ar[2], t1i = ai[1] + ai[2];
+    double t2r = fma(-0.5, t1r, ar[0]), t2i = fma(-0.5, t1i, ai[0]);
+    double t3r = S3_1 * (ar[1] - ar[2]), t3i = S3_1 * (ai[1] - ai[2]);
+    br[0] = ar[0] + t1r; bi[0] = ai[0] + t1i;
+    br[1] = t2r + t3i; bi[1] = t2i - t3r;
+    br[2] = t2r - t3i; bi[2] = t2i + t3r;
+  } else if (r == 5) {
+    double t1r = ar[1] + ar[4], t1i = ai[1] + ai[4];
+    double t2r = ar[2] + ar[3], t2i = ai[2] + ai[3];
+    double t3r = ar[1] - ar[4], t3i = ai[1] - ai[4];
+    double t4r = ar[2] - ar[3], t4i = ai[2] - ai[3];
+    br[0] = (ar[0] + t1r) + t2r; bi[0] = (ai[0] + t1i) + t2i;
+    double m1r = fma(C5_2, t2r, fma(C5_1, t1r, ar[0])), m1i = fma(C5_2, t2i, fma(C5_1, t1i, ai[0]));
+    double m2r = fma(C5_1, t2r, fma(C5_2, t1r, ar[0])), m2i = fma(C5_1, t2i, fma(C5_2, t1i, ai[0]));
+    double n1r = fma(S5_1, t3r, S5_2 * t4r), n1i = fma(S5_1, t3i, S5_2 * t4i);
+    double n2r = fma(S5_2, t3r, -(S5_1 * t4r)), n2i = fma(S5_2, t3i, -(S5_1 * t4i));
+    br[1] = m1r + n1i; bi[1] = m1i - n1r;
+    br[4] = m1r - n1i; bi[4] = m1i + n1r;
+    br[2] = m2r + n2i; bi[2] = m2i - n2r;
+    br[3] = m2r - n2i; bi[3] = m2i + n2r;
+  } else {
+    int step = P->n / r;
+    int h = (r - 1) / 2;
+    double ur[h + 1], ui[h + 1], vr[h + 1], vi[h + 1];
+    double b0r = ar[0], b0i = ai[0];
+    for (int i = 1; i <= h; i++) {
+      ur[i] = ar[i] + ar[r - i]; ui[i] = ai[i] + ai[r - i];
+      vr[i] = ar[i] - ar[r - i]; vi[i] = ai[i] - ai[r - i];
+      b0r = b0r + ur[i]; b0i = b0i + ui[i];
+    }
+    br[0] = b0r; bi[0] = b0i;
+    for (int j = 1; j <= h; j++) {
+      double pr = ar[0], pi = ai[0], qr = 0.0, qi = 0.0;
+      for (int i = 1; i <= h; i++) {
+        int t = ((i * j) % r) * step;
+        double c = P->tw[2 * t], sn = P->tw[2 * t + 1];
+        pr = fma(c, ur[i], pr); pi = fma(c, ui[i], pi);
+        if (i == 1) { qr = sn * vr[i]; qi = sn * vi[i]; }
+        else { qr = fma(sn, vr[i], qr); qi = fma(sn, vi[i], qi); }
+      }
+      br[j] = pr - qi; bi[j] = pi + qr;
+      br[r - j] = pr + qi; bi[r - j] = pi - qr;
+    }
+  }
+}
+
 /* X[0] = x[0] + A[0];  X[g^-q] = x[0] + c[q],  c = a (*) b cyclically, a[p] = x[g^p], b[q] = w^(g^-q):
  * A = F(a), C = A .* F(b), c = conj(F(conj(C))) / (n-1), all with the (n-1)-point plan.  Fixed operation order. */
 static void orc_plan_execute_rader(orc_plan* P, const double* in, double* out) {
@@ -287,8 +409,8 @@ static void orc_plan_execute_rader(orc_plan* P, const double* in, double* out) {
   double A0r = A[0], A0i = A[1];
   for (int k = 0; k < m; k++) {
     double br = P->bfft[2 * k], bi = P->bfft[2 * k + 1];
-    double cr = A[2 * k] * br - A[2 * k + 1] * bi;
-    double ci = A[2 * k] * bi + A[2 * k + 1] * br;
+    double cr, ci;
+    orc_cmul(A[2 * k], A[2 * k + 1], br, bi, &cr, &ci);
     a[2 * k] = cr; a[2 * k + 1] = -ci; /* conj(C) */
   }
   orc_plan_execute(P->sub, a, c);
@@ -326,8 +448,7 @@ static void orc_plan_execute(orc_plan* P, const double* in, double* out) {
           int t = (int)(((long)s * p * j) % n);
           double wr = P->tw[2 * t], wi = P->tw[2 * t + 1];
           int o = q + s * (r * p + j);
-          y[2 * o] = br[j] * wr - bi[j] * wi;
-          y[2 * o + 1] = br[j] * wi + bi[j] * wr;
+          orc_cmul(br[j], bi[j], wr, wi, &y[2 * o], &y[2 * o + 1]);
         }
       }
     }
@@ -396,13 +517,21 @@ static void orc_specplan_run(orc_specplan* sp, const float* x, float* mags) {
     int k2 = (W - k) % W;
     double a_r = Z[2 * k], a_i = Z[2 * k + 1];
     double b_r = Z[2 * k2], b_i = -Z[2 * k2 + 1];
-    double er = 0.5 * (a_r + b_r), ei = 0.5 * (a_i + b_i);
     double dr = a_r - b_r, di = a_i - b_i;
-    double o_r = 0.5 * di, o_i = -0.5 * dr;
     double c = sp->tw2[2 * k], s = sp->tw2[2 * k + 1];
-    double xr = er + (c * o_r - s * o_i);
-    double xi = ei + (c * o_i + s * o_r);
-    mags[k] = (float)sqrt(xr * xr + xi * xi);
+    if (orc_dft_spec_v == 2) {
+      /* v2: 2 X[k] = (Z[k] + conj Z[W-k]) - i e^{-2 pi i k/N} (Z[k] - conj Z[W-k]) with the products fused, the halving after the root
+       * (exact):  2 xr = fma(c, di, fma(s, dr, ar + br)),  2 xi = fma(s, di, fma(-c, dr, ai + bi)),  |X| = (float)(0.5 sqrt(fma(2xr, 2xr, 2xi 2xi))) */
+      double xr2 = fma(c, di, fma(s, dr, a_r + b_r));
+      double xi2 = fma(s, di, fma(-c, dr, a_i + b_i));
+      mags[k] = (float)(0.5 * sqrt(fma(xr2, xr2, xi2 * xi2)));
+    } else {
+      double er = 0.5 * (a_r + b_r), ei = 0.5 * (a_i + b_i);
+      double o_r = 0.5 * di, o_i = -0.5 * dr;
+      double xr = er + (c * o_r - s * o_i);
+      double xi = ei + (c * o_i + s * o_r);
+      mags[k] = (float)sqrt(xr * xr + xi * xi);
+    }
   }
   mags[W] = (float)fabs(Z[0] - Z[1]);
   for (int k = W + 1; k < N; k++) mags[k] = mags[N - k];
@@ -636,7 +765,7 @@ void orc_speedyComputeSpectralDifference(orc_speedyStream s, const float* spectr
     if (spectrogram[i] > bin_threshold && last_spectrogram[i] > bin_threshold) {
       /* float sum, float sum, float quotient; log and fabs in double; float accumulator */
       s_local_spectral_difference +=
-          fabs(orc_log((s->normalized_spectrogram[i] + eps) / (s->normalized_last_spectrogram[i] + eps)));
+          fabs(orc_log_spec((s->normalized_spectrogram[i] + eps) / (s->normalized_last_spectrogram[i] + eps)));
     }
   }
   s_emphasis_weighted_local_difference = s_local_spectral_difference * s_energy_hysteresis;

@@ -69,7 +69,13 @@ float orc_speedyNormalizeByEnergy(const float* spectrogram, float* normalized, i
 
 /* ---- DFT building blocks (exposed so tests can check them against a naive DFT) ---- */
 /* Natural log with a fixed, libm-independent operation sequence (DESIGN.md "log spec"). */
-double orc_log(double x);
+double orc_log(double x);          /* log spec v1: the fdlibm sequence, any double */
+double orc_log_v2_f32(float x);    /* log spec v2: a positive normal float */
+double orc_log_spec(double x);     /* what the analysis calls: v2 for positive normal floats, v1 otherwise */
+void orc_set_log_spec(int v);      /* 1: v1 for every argument (A/B against round 1-4's spec); 2: the default */
+int orc_get_log_spec(void);
+void orc_set_dft_spec(int v);      /* 1: the unfused transform of rounds 1-4; 2 (default): multiply-add pairs fused */
+int orc_get_dft_spec(void);
 /* Forward complex DFT of length n (any n >= 1): in/out are interleaved re,im doubles. */
 void orc_dft_forward(int n, const double* in, double* out);
 /* O(n^2) definition, long-double accumulation; the checker for orc_dft_forward. */

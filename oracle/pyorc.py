@@ -64,6 +64,13 @@ def lib():
         "orc_speedyGetSpeechChanges": (f, [vp]),
         "orc_speedyNormalizeByEnergy": (f, [c_float_p, c_float_p, i]),
         "orc_log": (C.c_double, [C.c_double]),
+        "orc_log_v2_f32": (C.c_double, [C.c_float]),
+        "orc_logcheck_run": (C.c_int, [C.c_uint, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "orc_log_spec": (C.c_double, [C.c_double]),
+        "orc_set_log_spec": (None, [C.c_int]),
+        "orc_get_log_spec": (C.c_int, []),
+        "orc_set_dft_spec": (None, [C.c_int]),
+        "orc_get_dft_spec": (C.c_int, []),
         "orc_dft_forward": (None, [i, c_double_p, c_double_p]),
         "orc_dft_naive": (None, [i, c_double_p, c_double_p]),
         "orc_spectrum_magnitudes": (None, [i, c_float_p, c_float_p]),

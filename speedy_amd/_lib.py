@@ -74,6 +74,7 @@ SYMBOLS = {
     "spx_debug_last_call_concurrent": (C.c_int, []),
     "spx_debug_fdiv_check": (C.c_longlong, [C.c_uint, C.c_uint, C.c_int, C.c_int]),
     "spx_debug_arith_check": (C.c_longlong, [C.c_uint, C.c_uint, C.c_uint]),
+    "spx_debug_log_check": (C.c_int, [C.c_uint, C.c_uint, C.POINTER(C.c_ulonglong)]),
     "spx_debug_walk_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "spx_debug_analysis_info": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "spx_debug_mode_resources": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)]),

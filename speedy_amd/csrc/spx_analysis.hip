@@ -55,15 +55,23 @@ int spx_analysis_tiny_tile_frames() { return SPX_TF_TINY; }
 // row stride of the magnitudes in LDS (floats): 16-byte rows, so that the energy chain reads four bins per instruction
 static __host__ __device__ constexpr int spx_mag_stride(int W) { return (W + 4) & ~3; }
 static __host__ __device__ constexpr int spx_cb(int tf) { return tf <= 8 ? 2 * SPX_CB : SPX_CB; }
+// The work area holds the transform buffers first and then, aliased, the |log ratio| terms with the table of log spec v2
+// (spx_log.h: 128 entries of 16 bytes) behind them: terms_bytes is where the table starts.
+#ifdef SPX_LOG_V1
+#define SPX_LOG_LDS_BYTES 0
+#else
+#define SPX_LOG_LDS_BYTES 2048
+#endif
+static __host__ __device__ inline size_t terms_bytes(int W, int tf, bool ct) {
+  const size_t b = ct ? (size_t)2 * tf * (spx_cb(tf) + 1) * sizeof(double)   // two blocks of log terms
+                      : (size_t)tf * (W + 1) * sizeof(double);               // every term of the tile
+  return (b + 15) & ~(size_t)15;
+}
 static __host__ __device__ inline size_t work_bytes(int W, int tf, bool ct = false, int dft_waves = 4) {
   if (dft_waves < 1 || dft_waves > 4) dft_waves = 4;
-  if (ct) {
-    size_t a = (size_t)4 * 2 * W * sizeof(double);             // 4 waves x W complex, stages in place
-    size_t b = (size_t)2 * tf * (spx_cb(tf) + 1) * sizeof(double); // aliased: two blocks of log terms
-    return (a > b ? a : b);
-  }
-  size_t a = (size_t)dft_waves * 2 * 2 * W * sizeof(double);   // transforming waves x ping-pong x W complex
-  size_t b = (size_t)tf * (W + 1) * sizeof(double);          // aliased: log terms
+  const size_t a = ct ? (size_t)4 * 2 * W * sizeof(double)                   // 4 waves x W complex, stages in place
+                      : (size_t)dft_waves * 2 * 2 * W * sizeof(double);      // transforming waves x ping-pong x W complex
+  const size_t b = terms_bytes(W, tf, ct) + SPX_LOG_LDS_BYTES;
   return (a > b ? a : b);
 }
 // 16 kHz (W = 240 = 4*4*3*5) and 22.05 kHz (W = 330 = 2*3*5*11) have their own instantiations of the kernel; every
@@ -1149,6 +1157,13 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
       if (lane == 0) fThr[s] = (float)((double)mx / 100.0);                      // speedy.c:709
     }
+#ifndef SPX_LOG_V1
+    // ... and bring the table of log spec v2 into the work area behind the terms (the transform buffers are free by now; the
+    // barrier at the end of this phase publishes it): 128 entries of 16 bytes, one per lane of waves 1 and 2
+    if (tid < SPX_WAVE + 128)
+      reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(work) + terms_bytes(W, TF, WCT != 0))[tid - SPX_WAVE] =
+          reinterpret_cast<const uint4*>(spx_log_table_dev)[tid - SPX_WAVE];
+#endif
   } else if (tid <= TF) {
     const float4* r4 = reinterpret_cast<const float4*>(mags + (size_t)tid * MS);
     float e = 0.0f;
@@ -1192,6 +1207,18 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   ASTAMP(5);
 
   const int nfr = j1 - j0;
+#ifndef SPX_LOG_V1
+  const SpxLogEntry* ltab = reinterpret_cast<const SpxLogEntry*>(reinterpret_cast<const unsigned char*>(work) + terms_bytes(W, TF, WCT != 0));
+  // log spec v2 for a float quotient; anything but a positive normal float (only explicit float frames of the unit-level API can
+  // produce one) takes v1, as in the oracle
+  auto log_of_ratio = [&](float ratio) -> double {
+    double v = spx_log_v2_f32(ratio, ltab);
+    if (__builtin_expect(!spx_log_v2_domain(ratio), 0)) v = spx_log_v1((double)ratio);
+    return v;
+  };
+#else
+  auto log_of_ratio = [&](float ratio) -> double { return spx_log_v1((double)ratio); };
+#endif
   // gated |log ratio| term of (frame f of the tile, bin i): speedy.c:705-717
   auto log_term = [&](int f, int i) -> double {
     const int sl = f + 1;
@@ -1202,7 +1229,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       const float eps = 2.2204e-16f;
       const float nc = cur * fInv[sl], nl = last * fInv[sl - 1];
       const float ratio = spx_fdiv32(nc + eps, nl + eps);
-      term = __builtin_fabs(spx_log((double)ratio));                           // speedy.c:715-717
+      term = __builtin_fabs(log_of_ratio(ratio));                              // speedy.c:715-717
     }
     return term;
   };
@@ -1269,9 +1296,16 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
             const float ratio = spx_fdiv32(nc + eps, nl + eps);
             xr[t] = gate[t] ? ratio : 2.0f;
           }
+#ifdef SPX_LOG_V1
           const spx_log_parts p0 = spx_log_main((double)xr[0]), p1 = spx_log_main((double)xr[1]);
           const double t0 = gate[0] ? __builtin_fabs(spx_log_finish(p0, (double)xr[0])) : 0.0;
           const double t1 = gate[1] ? __builtin_fabs(spx_log_finish(p1, (double)xr[1])) : 0.0;
+#else
+          // (a closed gate's argument is 2.0f: inside the domain, its value unused)
+          const double l0 = log_of_ratio(xr[0]), l1 = log_of_ratio(xr[1]);
+          const double t0 = gate[0] ? __builtin_fabs(l0) : 0.0;
+          const double t1 = gate[1] ? __builtin_fabs(l1) : 0.0;
+#endif
           if (ok[0]) tb[fi[0] * CBS + ci[0]] = t0;
           if (ok[1]) tb[fi[1] * CBS + ci[1]] = t1;
         }
@@ -1385,6 +1419,48 @@ extern "C" long long spx_debug_arith_check(unsigned seed, unsigned threads, unsi
   const bool ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
   (void)hipFree(d);
   return ok ? (long long)h : -1;
+}
+
+// Diagnostic (tests/test_gpu_parity.py): log spec v2 over EVERY positive normal float.  Workgroup b takes the 2^20 float patterns
+// b << 20 .. and leaves the sum of the results' bit patterns (mod 2^64) in sums[b]; oracle/orc_logcheck.c computes the same sums
+// with the oracle's orc_log_v2_f32 -- equal sums block for block = the GPU's log is the oracle's on the whole domain.  The table
+// is read from LDS, as the analysis kernel reads it.
+__global__ void __launch_bounds__(256) spx_log_check_kernel(unsigned first_block, unsigned long long* __restrict__ sums) {
+#ifndef SPX_LOG_V1
+  __shared__ SpxLogEntry tab[128];
+  __shared__ unsigned long long acc;
+  if (threadIdx.x < 128) reinterpret_cast<uint4*>(tab)[threadIdx.x] = reinterpret_cast<const uint4*>(spx_log_table_dev)[threadIdx.x];
+  if (threadIdx.x == 0) acc = 0;
+  __syncthreads();
+  const unsigned b = first_block + blockIdx.x;
+  unsigned long long sum = 0;
+  for (unsigned i = threadIdx.x; i < (1u << 20); i += 256) {
+    const float x = __uint_as_float((b << 20) | i);
+    sum += (unsigned long long)__double_as_longlong(spx_log_v2_f32(x, tab));
+  }
+  atomicAdd(&acc, sum);
+  __syncthreads();
+  if (threadIdx.x == 0) sums[b] = acc;
+#endif
+}
+// sums: HOST uint64[2040] indexed by block (blocks 8 .. 2039 = the positive normal floats); returns 0, -1 on a runtime error,
+// -3 in a build with log spec v1 (-DSPX_LOG_V1)
+extern "C" int spx_debug_log_check(unsigned first_block, unsigned end_block, unsigned long long* sums) {
+#ifdef SPX_LOG_V1
+  (void)first_block; (void)end_block; (void)sums;
+  return -3;
+#else
+  if (first_block < 8) first_block = 8;
+  if (end_block > 2040) end_block = 2040;
+  if (!sums || first_block >= end_block) return -1;
+  unsigned long long* d = nullptr;
+  if (hipMalloc(&d, 2040 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  bool ok = hipMemset(d, 0, 2040 * sizeof(unsigned long long)) == hipSuccess;
+  if (ok) hipLaunchKernelGGL(spx_log_check_kernel, dim3(end_block - first_block), dim3(256), 0, nullptr, first_block, d);
+  ok = ok && hipDeviceSynchronize() == hipSuccess && hipMemcpy(sums, d, 2040 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(d);
+  return ok ? 0 : -1;
+#endif
 }
 
 void spx_launch_analysis(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int n_tiles,

@@ -19,6 +19,17 @@
 #define M_PI 3.14159265358979323846
 #endif
 
+// HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and a queue runs its kernels
+// in order.  This library alone holds up to five streams per device that must not block one another (the caller's or the
+// pipeline object's run stream, the side stream, two walk streams, the pipeline's copy stream): with four queues two of them
+// share one, which two depends on the order of creation, and the end-to-end rate then read 2.0, 2.6 or 4.3 ms per batch in round 4
+// (profiles/r04/r05u_hw_queues.txt).  The runtime reads the variable at its first call, so the library asks for eight queues when
+// it is LOADED -- unless the application has set the variable itself (never overridden), or says SPX_KEEP_HW_QUEUES=1.  A process
+// that has made HIP calls before loading the library keeps what it had: INTEGRATION.md "Environment".
+__attribute__((constructor(101))) static void spx_default_hw_queues() {
+  if (!getenv("SPX_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -220,6 +231,7 @@ int64_t spx_internal_out_bound(const SpxPlanDev& P, int64_t n_in, float speed, b
   return (int64_t)((double)(n_in + 2 * (int64_t)P.maxRequired) * (2.0 / s)) + slack;
 }
 
+static int dev_walk_streams(int dev, hipStream_t* w0, hipStream_t* w1);   // (defined with the launch code below)
 void spx_internal_set_error(const char* msg) { g_err = msg ? msg : ""; }   // other translation units' errors reach spx_last_error
 extern "C" {
 
@@ -349,6 +361,15 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
   }
   for (int i = 0; i <= d.F; i++) tf[i] = (d.F - i) / (float)d.F;    // speedy.c:597
   for (int i = 0; i <= d.Pp; i++) tp[i] = (d.Pp - i) / (float)d.Pp;  // speedy.c:604
+  {
+    // The library's own streams of this device -- the side stream, the two walk streams -- are created NOW, before anything the
+    // process creates later (a pipeline object's run and copy streams, the caller's own): HIP maps streams onto hardware queues
+    // and pipes in creation order, and with the pipeline's two streams created FIRST its resident loop read 1.15 instead of 1.03 ms
+    // per batch (profiles/r05/r5c_order_probe.txt).
+    hipStream_t w0 = nullptr, w1 = nullptr;
+    (void)dev_walk_streams(p->device, &w0, &w1);
+    (void)hipGetLastError();
+  }
   if (hipMalloc(&p->tables, bytes) != hipSuccess ||
       hipMemcpy(p->tables, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
     fail(-2, "spx_plan_create: device allocation/copy failed (is a GPU visible?)");
@@ -625,11 +646,11 @@ static bool ring_previous_in_flight(spx_plan* plan) {
   (void)hipGetLastError();
   return f;
 }
-static int ring_record(spx_plan* plan, hipStream_t on, void* ws, hipStream_t st, const void* out, const void* n_out) {
+static int ring_record(spx_plan* plan, hipStream_t on, void* ws, hipStream_t st, const void* out, const void* n_out, bool detached = false) {
   const int c = plan->ahead_calls & 3;
   if (!plan->ev_walk[c]) HIPCHK(hipEventCreateWithFlags(&plan->ev_walk[c], hipEventDisableTiming));
   HIPCHK(hipEventRecord(plan->ev_walk[c], on));
-  if (on != st) HIPCHK(hipStreamWaitEvent(st, plan->ev_walk[c], 0));   // the caller's stream is done when the walk is
+  if (on != st && !detached) HIPCHK(hipStreamWaitEvent(st, plan->ev_walk[c], 0));   // the caller's stream is done when the walk is
   plan->ev_walk_valid[c] = true;
   plan->ring_ws[c] = ws;
   plan->ring_st[c] = st;
@@ -774,6 +795,14 @@ struct SpxCallOpts {
   void* in_ready = nullptr;    // hipEvent_t: the producers wait for it (the caller's "input is there")
   bool sub = false;            // a sub-batch of a plain call the engine has split (run_split): its `out` is the whole call's, never
                                // "the previous call's output buffer handed over again"
+  // The pipeline object's calls (spx_pipeline.hip): done_event (a hipEvent_t) is recorded behind everything the call enqueued --
+  // and with `detached`, a call whose walk kernel goes to one of the library's walk streams does not touch hip_stream AT ALL
+  // (no note, no wait for the walk kernel: the event is recorded on the walk stream).  A caller stream that carries nothing but
+  // waits for walk kernels is a hardware queue whose head is a blocked barrier packet for 2 ms of every 2; depending on where
+  // that queue happens to land among the process's queues, the kernels of the side stream were dispatched 50 us late after each
+  // such packet (profiles/r05/r5e_trace_*.txt, r5f_queue_probe.txt: 1.14 against 1.03 ms per batch).
+  void* done_event = nullptr;
+  bool detached = false;
 };
 
 // One batch call: decide the launch mode (spx_choose_mode, a pure function of the inputs collected here), then execute it.
@@ -878,14 +907,16 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // behind this call's state of the stream, which ends with the wait for the previous call's walk kernel; a caller that hands over
   // the previous call's out / n_out again gets exactly that wait
   hipStream_t stw = st;
-  if (do_w && !force && ring_note(plan, st)) return -2;
+  const bool detached = opt.detached && M.walk2 && !force;
+  if (do_w && !force && !detached && ring_note(plan, st)) return -2;
   if (M.walk2) {
     hipStream_t w0 = nullptr, w1 = nullptr;
     if (dev_walk_streams(plan->device, &w0, &w1)) return fail(-1, "spx_batch: no walk streams");
     const int cur = plan->ahead_calls & 1;
     stw = cur ? w1 : w0;
     const bool same_out = !opt.sub && (out == plan->ahead_last_out || n_out == plan->ahead_last_nout);
-    if (same_out) HIPCHK(hipStreamWaitEvent(stw, plan->ev_call[cur], 0));
+    if (detached) { }   // (the owner of the buffers orders their consumers itself: spx_pipeline waits for done_event on the host)
+    else if (same_out) HIPCHK(hipStreamWaitEvent(stw, plan->ev_call[cur], 0));
     else if (plan->ev_call_valid[cur ^ 1]) HIPCHK(hipStreamWaitEvent(stw, plan->ev_call[cur ^ 1], 0));
   }
   hipStream_t sa = st;  // the stream the analysis launches go to
@@ -995,7 +1026,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       if (c == nch - 1 && !force) {
         // every call of the plan that walks leaves its event in the ring (a pipelined call orders its producers behind the walk
         // kernels of the calls before it, pipelined or not)
-        if (ring_record(plan, stw, ws, st, out, n_out)) return -2;
+        if (ring_record(plan, stw, ws, st, out, n_out, detached)) return -2;
         plan->ahead_started = (concurrent || ahead) ? d_ready + n : nullptr;   // (only these walk kernels count themselves in)
         plan->ahead_n = n;
         plan->mixed_started.clear();
@@ -1019,26 +1050,31 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     if (!e1) HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e1, st));
   }
+  if (opt.done_event && do_w) HIPCHK(hipEventRecord(static_cast<hipEvent_t>(opt.done_event), detached ? stw : st));
   if (timed) { std::lock_guard<std::mutex> g(g_tmu); g_calls_pending++; }
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-// ---- a plain call of more streams than the device has CUs, split into sub-batches that overlap one another (round 5) ----
-// One spx_batch_run of 257 .. 4 x CUs streams used to run its kernels in sequence (512 streams: 2.87 ms, where two overlapped
-// 256-stream calls take 2.31).  Now the engine cuts such a batch into ceil(n / CUs) sub-batches of equal size -- same streams, in
-// job order; their workspaces carved from the caller's; the caller's in / out / n_out as they are -- and issues them as
-// overlapped calls on the plan's ring, so that sub-batch k + 1's analysis runs beside sub-batch k's walk kernel and the walk
-// kernels of consecutive sub-batches overlap.  The caller keeps the PLAIN stream order: every sub-batch's producers wait for an
-// event recorded on hip_stream when the call is made, and hip_stream waits for every sub-batch's walk kernel.  Taken only where
-// a sub-batch would run in the pipelined order with overlapping walk kernels (spx_choose_mode on the sub-shape says so); all
-// other batches run as one call.
+// ---- a call of more streams than the device has CUs, split into sub-batches that overlap one another (round 5) ----
+// A batch of 257 .. 2 x CUs streams runs its kernels in sequence as ONE call (512 streams: 2.85 ms), where two 256-stream calls in
+// the overlapped order take 2.3.  So an OVERLAPPED call of that size (spx_batch_run_overlapped, the pipeline object) is cut into
+// two sub-batches of equal size -- same streams, in job order; their workspaces carved from the caller's; in / out / n_out as they
+// are -- issued as overlapped calls on the plan's ring: sub-batch k + 1's analysis runs beside sub-batch k's walk kernel, the
+// walk kernels overlap, and so do those of consecutive calls.  Taken only where a sub-batch would run in the pipelined order with
+// overlapping walk kernels (spx_choose_mode on the sub-shape says so).
+// PLAIN calls are NOT split (measured, profiles/r05/r5b_scale_streams.txt): spx_batch_run promises plain stream order, so every
+// sub-batch's producers must wait for the caller's stream as it stood at the call and nothing of the NEXT call can start before
+// this call's last walk kernel ends -- 512 streams 3.21 ms split against 2.85 as one call, 1 024 streams 5.63 against 4.34 (the
+// throughput-form walk kernel).  Above two streams per CU the throughput form wins in every order (1 024 streams: four
+// overlapped 256-stream calls 4.8 ms).  (SPX_SPLIT_PLAIN / SPX_SPLIT_MAX in the tuning build: the A/B.)
+#define SPX_SPLIT_LIMIT 4   // sub-batches the workspace is sized for
 struct SplitPlan { int k; std::vector<int> first; std::vector<size_t> ws_off, ws_bytes; size_t total; };
-static SplitPlan split_geometry(const spx_plan* plan, const spx_stream_job* jobs, int n) {
+static SplitPlan split_geometry(const spx_plan* plan, const spx_stream_job* jobs, int n, int max_mult) {
   SplitPlan P;
   P.k = 1; P.total = 0;
-  static const int max_mult = [] { const char* e = spx_tuning_env("SPX_SPLIT_MAX"); return e ? atoi(e) : 4; }();
   const int cu = plan->cu_count > 0 ? plan->cu_count : 1;
+  if (max_mult > SPX_SPLIT_LIMIT) max_mult = SPX_SPLIT_LIMIT;
   if (n <= cu || n > max_mult * cu) return P;
   P.k = (n + cu - 1) / cu;
   size_t o = 0;
@@ -1054,9 +1090,12 @@ static SplitPlan split_geometry(const spx_plan* plan, const spx_stream_job* jobs
   return P;
 }
 static int run_split(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out, int64_t* n_out, void* ws,
-                     size_t ws_bytes, const spx_taps* taps, void* hs) {
+                     size_t ws_bytes, const spx_taps* taps, void* hs, const SpxCallOpts& opt) {
   if (!plan || !jobs || n <= 0) return fail(-1, "spx_batch: bad arguments");
-  SplitPlan P = split_geometry(plan, jobs, n);
+  static const int max_overlapped = [] { const char* e = spx_tuning_env("SPX_SPLIT_MAX"); return e ? atoi(e) : 2; }();
+  static const int max_plain = [] { const char* e = spx_tuning_env("SPX_SPLIT_PLAIN"); return e ? atoi(e) : 1; }();
+  const bool plain = !opt.ahead_req;
+  SplitPlan P = split_geometry(plan, jobs, n, plain ? max_plain : (opt.overlap_req ? max_overlapped : 1));
   if (P.k > 1 && (g_chunks_set.load() || ws_bytes < P.total)) P.k = 1;
   if (P.k > 1) {
     // would a sub-batch take the pipelined order with overlapping walk kernels?
@@ -1082,19 +1121,20 @@ static int run_split(spx_plan_t plan, const spx_stream_job* jobs, int n, const i
     const SpxMode M = spx_choose_mode(S, R, mode_env(), T, none);
     if (!(M.ahead && M.walk2)) P.k = 1;
   }
-  { std::lock_guard<std::mutex> g(plan->mu); plan->split_of[ws] = P.k; if (plan->split_of.size() > 64) { plan->split_of.clear(); plan->split_of[ws] = P.k; } }
-  if (P.k <= 1) return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true);
+  { std::lock_guard<std::mutex> g(plan->mu); if (plan->split_of.size() > 64) plan->split_of.clear(); plan->split_of[ws] = P.k; }
+  if (P.k <= 1) return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true, opt);
   hipStream_t st = static_cast<hipStream_t>(hs);
-  hipEvent_t ev = nullptr;
-  {
-    // (one event per call in flight would be the exact thing; two taking turns are enough: the event is waited for by the
-    // sub-batches' producer streams, and those are ordered behind the previous split call's by the ring)
+  void* ready = opt.in_ready;
+  if (plain) {
+    // plain stream order: every sub-batch's producers wait for the caller's stream as it stands now (one event per call in
+    // flight would be the exact thing; two taking turns are enough: the event is waited for by the sub-batches' producer
+    // streams, and those are ordered behind the previous split call's by the ring)
     std::lock_guard<std::mutex> g(plan->mu);
     hipEvent_t& e = plan->ev_split[plan->split_calls++ & 1];
     if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    ev = e;
+    HIPCHK(hipEventRecord(e, st));
+    ready = e;
   }
-  HIPCHK(hipEventRecord(ev, st));
   int64_t rows = 0;
   for (int i = 0; i < P.k; i++) {
     const int a = P.first[i], m = P.first[i + 1] - a;
@@ -1109,8 +1149,10 @@ static int run_split(spx_plan_t plan, const spx_stream_job* jobs, int n, const i
       for (int j = a; j < a + m; j++) rows += jobs[j].nonlinear != 0.0f ? frames_for(plan->dev, jobs[j].n_in) : 0;
     }
     SpxCallOpts o;
-    o.ahead_req = o.overlap_req = o.sub = true;
-    o.in_ready = ev;
+    o.ahead_req = o.overlap_req = true;
+    o.sub = i > 0 || plain;      // (the first sub-batch of an overlapped call is ordered like the call itself: "the same out buffer again")
+    o.in_ready = ready;
+    if (i == P.k - 1) o.done_event = opt.done_event;   // (on hip_stream, which waits for every sub-batch's walk kernel: never detached)
     const int rc = run_impl(plan, jobs + a, m, in, out, n_out + a, static_cast<unsigned char*>(ws) + P.ws_off[i], P.ws_bytes[i],
                             taps ? &t : nullptr, hs, true, true, o);
     if (rc) return rc;   // (what the earlier sub-batches enqueued is already joined to hip_stream: ring_record)
@@ -1119,33 +1161,34 @@ static int run_split(spx_plan_t plan, const spx_stream_job* jobs, int n, const i
 }
 
 int spx_internal_run(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out, int64_t* n_out, void* ws,
-                     size_t ws_bytes, const spx_taps* taps, void* hs, bool ahead, bool overlap, void* in_ready) {
+                     size_t ws_bytes, const spx_taps* taps, void* hs, bool ahead, bool overlap, void* in_ready, void* done_event,
+                     bool detached) {
   SpxCallOpts o;
-  o.ahead_req = ahead; o.overlap_req = overlap; o.in_ready = in_ready;
-  return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true, o);
+  o.ahead_req = ahead; o.overlap_req = overlap; o.in_ready = in_ready; o.done_event = done_event; o.detached = detached;
+  return run_split(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, o);
 }
 
 extern "C" {
 // (the larger of the one-call layout and the sub-batch layouts: which of the two a spx_batch_run takes is decided per call)
 size_t spx_batch_workspace_bytes(spx_plan_t plan, const spx_stream_job* jobs, int n_streams) {
   if (!plan || !jobs || n_streams < 1) return 0;
-  return std::max(layout_for(plan->dev, jobs, n_streams).total, split_geometry(plan, jobs, n_streams).total);
+  return std::max(layout_for(plan->dev, jobs, n_streams).total, split_geometry(plan, jobs, n_streams, SPX_SPLIT_LIMIT).total);
 }
 int spx_batch_run(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                   int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs) {
-  return run_split(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs);
+  return run_split(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, SpxCallOpts());
 }
 int spx_batch_run_ahead(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                         int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs) {
-  return spx_internal_run(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, false, nullptr);
+  return spx_internal_run(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, false, nullptr, nullptr, false);
 }
 int spx_batch_run_overlapped(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                              int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs) {
-  return spx_internal_run(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true, nullptr);
+  return spx_internal_run(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true, nullptr, nullptr, false);
 }
 int spx_batch_run_ahead_when(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
                              int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs, void* in_ready_event) {
-  return spx_internal_run(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, false, in_ready_event);
+  return spx_internal_run(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, false, in_ready_event, nullptr, false);
 }
 int spx_batch_analyze(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, void* ws,
                       size_t ws_bytes, const spx_taps* taps, void* hs) {
@@ -1449,7 +1492,8 @@ int spx_batch_read_steps(spx_plan_t plan, const spx_stream_job* jobs, int n, con
   { std::lock_guard<std::mutex> g(plan->mu); auto it = plan->split_of.find(ws); if (it != plan->split_of.end()) k = it->second; }
   if (k <= 1) return read_steps(plan->dev, jobs, n, ws, steps, static_cast<hipStream_t>(hs));
   // the call that last ran on this workspace was split into sub-batches (run_split): their state records sit in their slices
-  const SplitPlan P = split_geometry(plan, jobs, n);
+  const SplitPlan P = split_geometry(plan, jobs, n, SPX_SPLIT_LIMIT);
+  if (P.k != k) return fail(-1, "spx_batch_read_steps: the jobs are not those of the call that last ran on this workspace");
   for (int i = 0; i < P.k; i++) {
     const int a = P.first[i], m = P.first[i + 1] - a;
     const int rc = read_steps(plan->dev, jobs + a, m, static_cast<const unsigned char*>(ws) + P.ws_off[i], steps + a, static_cast<hipStream_t>(hs));

@@ -25,7 +25,7 @@
 #include "spx_internal.h"
 
 int spx_internal_run(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out, int64_t* n_out, void* ws,
-                     size_t ws_bytes, const spx_taps* taps, void* hs, bool ahead, bool overlap, void* in_ready);
+                     size_t ws_bytes, const spx_taps* taps, void* hs, bool ahead, bool overlap, void* in_ready, void* done_event, bool detached);
 int spx_internal_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n, const int16_t* in,
                            int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, void* hs, bool ahead, void* in_ready);
 void spx_internal_set_error(const char* msg);
@@ -130,7 +130,7 @@ static int pfail(int code, const std::string& msg) { spx_internal_set_error(msg.
 
 static void pipeline_free(spx_pipeline* p) {
   if (!p) return;
-  if (p->s_run) (void)hipStreamSynchronize(p->s_run);
+  (void)hipStreamSynchronize(p->s_run);
   if (p->s_h2d) (void)hipStreamSynchronize(p->s_h2d);
   for (auto& S : p->slots) {
     if (S.ev_done) { if (S.ticket >= 0) (void)hipEventSynchronize(S.ev_done); (void)hipEventDestroy(S.ev_done); }
@@ -178,6 +178,13 @@ static int pipeline_build(spx_pipeline* p) {
   p->ws_bytes = p->mixed ? spx_batch_workspace_bytes_mixed(p->plans.data(), (int)p->plans.size(), p->jobs.data(), p->plan_index.data(), n)
                          : spx_batch_workspace_bytes(p->plans[0], p->jobs.data(), n);
   if (!p->ws_bytes) return -1;
+#ifdef SPX_TUNING
+  // A/B: where the run stream lands among the hardware queues (dummy streams created in front of it), its priority, the null stream
+  if (const char* e = getenv("SPX_PIPE_DUMMY_STREAMS")) for (int i = 0; i < atoi(e); i++) { hipStream_t d; (void)hipStreamCreateWithFlags(&d, hipStreamNonBlocking); }
+  if (getenv("SPX_PIPE_NULL_STREAM")) p->s_run = nullptr;
+  else if (const char* e = getenv("SPX_PIPE_PRIO")) { PCHK(hipStreamCreateWithPriority(&p->s_run, hipStreamNonBlocking, atoi(e))); }
+  else
+#endif
   PCHK(hipStreamCreateWithFlags(&p->s_run, hipStreamNonBlocking));
   PCHK(hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking));
   const size_t tab_bytes = (size_t)n * (2 * sizeof(int64_t) + sizeof(int));
@@ -282,13 +289,20 @@ int64_t spx_pipeline_submit(spx_pipeline_t p, const int16_t* in, int in_is_devic
     in_ready = S.ev_in;
   }
   int rc;
+  const bool host_out = !(p->flags & SPX_PIPELINE_DEVICE_OUT);
+  // With the outputs left on the device nothing of a batch has to run behind its walk kernel: the call is DETACHED from the run
+  // stream (spx_engine.hip SpxCallOpts) -- the batch's event is recorded on the walk stream itself and the run stream stays empty.
+  bool event_recorded = false;
   if (p->mixed)
     rc = spx_internal_run_mixed(p->plans.data(), (int)p->plans.size(), p->jobs.data(), p->plan_index.data(), p->n, dev_in, S.d_out, S.d_nout,
                                 S.ws, p->ws_bytes, p->s_run, true, in_ready);
-  else
-    rc = spx_internal_run(p->plans[0], p->jobs.data(), p->n, dev_in, S.d_out, S.d_nout, S.ws, p->ws_bytes, nullptr, p->s_run, true, true, in_ready);
+  else {
+    rc = spx_internal_run(p->plans[0], p->jobs.data(), p->n, dev_in, S.d_out, S.d_nout, S.ws, p->ws_bytes, nullptr, p->s_run, true, true, in_ready,
+                          host_out ? nullptr : S.ev_done, !host_out);
+    event_recorded = !host_out;
+  }
   if (rc) return rc;
-  if (!(p->flags & SPX_PIPELINE_DEVICE_OUT)) {
+  if (host_out) {
     const int n = p->n;
     const int64_t* d_off = p->d_tab;
     const int64_t* d_cap = p->d_tab + n;
@@ -297,7 +311,7 @@ int64_t spx_pipeline_submit(spx_pipeline_t p, const int16_t* in, int in_is_devic
     const int wgs = n < p->pack_wgs ? n : p->pack_wgs;
     hipLaunchKernelGGL(spx_pipe_copy_kernel, dim3(wgs), dim3(256), 0, p->s_run, S.d_out, d_off, S.d_offsets, n, S.h_out);
   }
-  PCHK(hipEventRecord(S.ev_done, p->s_run));
+  if (!event_recorded) PCHK(hipEventRecord(S.ev_done, p->s_run));
   PCHK(hipGetLastError());
   S.ticket = ticket;
   p->next_ticket++;

@@ -258,7 +258,8 @@ def test_mixed_rate_calls_pipelined(orc):
         big[0].d_out.zero_()
 
 
-@pytest.mark.parametrize("rate,ch,n_streams", [(16000, 1, 256), (22050, 1, 256), (16000, 2, 200), (22050, 2, 128), (48000, 1, 64)])
+@pytest.mark.parametrize("rate,ch,n_streams", [(16000, 1, 256), (22050, 1, 256), (16000, 2, 200), (22050, 2, 128), (48000, 1, 64),
+                                               (16000, 1, 390), (22050, 1, 512)])    # (more streams than CUs: two overlapping sub-batches per call)
 def test_overlapped_walks_of_batches_of_different_content(orc, rate, ch, n_streams):
     """spx_batch_run_overlapped: as the first test, with the walk kernels of consecutive calls overlapping (in their lean form
     where three workspaces take turns and the streams are mono); every batch is consumed (copied) right behind its own call, as

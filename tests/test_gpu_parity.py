@@ -819,6 +819,24 @@ def test_fast_division_equals_the_ieee_quotient():
         assert np.array_equal(outs[0], pyorc.compress_sound(x, 16000, 1, speed, 0.0, 0.0, False, chunk=x.size, taps=False)["out"]), speed
 
 
+def test_log_spec_v2_gpu_equals_oracle_on_every_positive_normal_float(orc):
+    """Log spec v2 on the GPU (spx_log.h, the table read from LDS as the analysis kernel reads it) against the oracle's
+    orc_log_v2_f32 over ALL 2 130 706 432 positive normal floats -- every argument the kernel can ever meet: checksums of the
+    results' bit patterns per block of 2^20 float patterns, 2 032 blocks, equal one by one (spx_debug_log_check against
+    oracle/orc_logcheck.c)."""
+    import ctypes as C
+    from speedy_amd._lib import lib
+    L = lib()
+    gpu = (C.c_ulonglong * 2040)()
+    assert L.spx_debug_log_check(8, 2040, gpu) == 0
+    cpu = (C.c_uint64 * 2040)()
+    threads = max(1, min(32, len(os.sched_getaffinity(0))))
+    assert orc.lib().orc_logcheck_run(8, 2040, threads, 0, cpu, None, None) == 0
+    bad = [b for b in range(8, 2040) if gpu[b] != cpu[b]]
+    assert not bad, (len(bad), bad[:8])
+    assert len({int(v) for v in gpu[8:2040]}) > 2000     # (the sums are not trivially equal)
+
+
 def test_scale_free_division_and_square_root_equal_the_ieee_sequences():
     """The analysis kernel's fp32 ratio, fp64 log quotient and fp64 square root run the compiler's IEEE sequences without their
     scaling / fix-up halves (spx_log.h): 3 x 2^26 pseudo-random operands of the ranges the kernel feeds them, bit for bit."""

@@ -20,7 +20,9 @@ def _signals(rate, ch, n_streams, seed, lens):
 
 
 @pytest.mark.parametrize("rate,ch,n_streams,depth", [(16000, 1, 256, 4), (16000, 1, 256, 3), (16000, 1, 61, 2), (22050, 1, 256, 4),
-                                                     (16000, 2, 128, 3), (48000, 2, 40, 4), (16000, 1, 600, 3)])
+                                                     (16000, 2, 128, 3), (48000, 2, 40, 4), (16000, 1, 600, 3),
+                                                     # 257 .. 512 streams: every batch call is cut into two overlapping sub-batches (run_split)
+                                                     (16000, 1, 400, 3), (16000, 1, 512, 4), (16000, 2, 300, 3)])
 def test_batches_of_different_content_through_the_pipeline(orc, rate, ch, n_streams, depth):
     """Three batches of one shape and DIFFERENT content go through the pipeline again and again (14 submits, tickets waited for
     with a lag, as a caller that keeps the device busy would): every ticket's output must be what spx_batch_run gives for that

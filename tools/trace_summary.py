@@ -1,0 +1,22 @@
+"""Per-kernel durations and the period of a steady loop from a rocprofv3 --kernel-trace CSV (the last `n` launches of each kernel):
+python tools/trace_summary.py kernel_trace.csv [n]"""
+import csv
+import sys
+from collections import defaultdict
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+by = defaultdict(list)
+for r in rows:
+    name = r["Kernel_Name"]
+    name = name[5:] if name.startswith("void ") else name
+    name = name.split("(")[0]
+    by[name].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?")))
+for name, v in sorted(by.items()):
+    v.sort()
+    v = v[-n:]
+    dur = [(e - s) / 1e3 for s, e, _ in v]
+    per = [(v[i + 1][0] - v[i][0]) / 1e3 for i in range(len(v) - 1)]
+    q = sorted({x[2] for x in v})
+    print("%-52s n %3d  dur avg %8.1f us (min %8.1f max %8.1f)  start-to-start avg %8.1f us  queues %s" % (
+        name[:52], len(v), sum(dur) / len(dur), min(dur), max(dur), (sum(per) / len(per)) if per else 0.0, ",".join(q)))
