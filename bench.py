@@ -48,7 +48,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 RATE, SECONDS, STREAMS_PER_GPU, SPEED = 16000, 10, 256, 3.5
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-FP64_VALU_PEAK_TFLOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # fp64 vector operations/s without FMA: 39.3 (see `peak_source` in the line)
+FP64_VALU_PEAK_TFLOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # fp64 vector instructions x lanes per second: 39.3 T (see `peak_source` in the line)
 
 
 def make_streams(n_streams, n, rank):
@@ -731,10 +731,13 @@ def main():
             peak = FP64_VALU_PEAK_TFLOPS
             valu = {"bound": "fp64 vector ALU", "kernel": k_analysis, "flop_per_frame": flop, "frames_per_launch": frames,
                     "standalone_ms": ms_analysis_alone, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
-                    "peak_source": "MI355X fp64 vector rate WITHOUT fused multiply-add: 256 CUs x 4 SIMDs x 16 fp64 lanes/clk x 2.4 GHz "
-                                   "= 39.3 T operations/s (half of the 78.6 TFLOP/s FMA figure, itself half of the guide's 157.3 fp32); "
-                                   "the path cannot contract to FMA: its rounding points are the reference's (-ffp-contract=off)",
-                    "definition": "fp64 operations of the DFT spec per frame (tools/flop_count.py, profiles/flop_model.json) x frames / "
+                    "fma_per_frame": fm[str(RATE)].get("of_which_fma"),
+                    "peak_source": "MI355X fp64 vector INSTRUCTION rate: 256 CUs x 4 SIMDs x 16 fp64 lanes/clk x 2.4 GHz = 39.3 T operations/s "
+                                   "(the 78.6 TFLOP/s FMA figure counts every fma twice; here an fma is ONE operation, as are a division and a "
+                                   "square root).  Since round 5 the DFT and log specs fuse their multiply-add pairs explicitly (DESIGN.md 4, 4a: "
+                                   "12 646 operations per frame at 16 kHz, 5 033 of them fma; 19 355 unfused in rounds 1-4), so `achieved` fell "
+                                   "with the operation count while the kernel got faster",
+                    "definition": "fp64 operations of the DFT and log specs per frame (tools/flop_count.py, profiles/flop_model.json) x frames / "
                                   "the analysis kernel ALONE (spx_batch_analyze, one window of 10 launches, HIP events)"}
         # The roofline that BINDS the pipelined loop (round-4 review): every wave64 VALU instruction occupies its SIMD for 4 cycles,
         # so the three kernels' VALU wave-instructions per batch (SQ_INSTS_VALU, profiles/sq_counters.json, tools/sq_counters.sh)

@@ -259,7 +259,7 @@ static void orc_plan_destroy(orc_plan* p) {
 /* DFT spec v2 (round 5): the same transform with the multiply-add pairs of the twiddle products, of the radix-3 / 5 /
  * prime butterflies and of the untangle FUSED (fma = one rounding) -- what FFTW's own codelets do on a machine that has the
  * instruction, and a quarter fewer operations for the kernel.  orc_set_dft_spec(1): the unfused sequence of rounds 1-4. */
-static int orc_dft_spec_v = 1; /* (2 once the kernel follows) */
+static int orc_dft_spec_v = 2;
 void orc_set_dft_spec(int v) { orc_dft_spec_v = v == 1 ? 1 : 2; }
 int orc_get_dft_spec(void) { return orc_dft_spec_v; }
 /* y = b * w (a twiddle or pointwise product), v2: re = fma(br, wr, -(bi wi)), im = fma(br, wi, bi wr) */
@@ -521,10 +521,10 @@ static void orc_specplan_run(orc_specplan* sp, const float* x, float* mags) {
     double c = sp->tw2[2 * k], s = sp->tw2[2 * k + 1];
     if (orc_dft_spec_v == 2) {
       /* v2: 2 X[k] = (Z[k] + conj Z[W-k]) - i e^{-2 pi i k/N} (Z[k] - conj Z[W-k]) with the products fused, the halving after the root
-       * (exact):  2 xr = fma(c, di, fma(s, dr, ar + br)),  2 xi = fma(s, di, fma(-c, dr, ai + bi)),  |X| = (float)(0.5 sqrt(fma(2xr, 2xr, 2xi 2xi))) */
+       * (exact):  2 xr = fma(c, di, fma(s, dr, ar + br)),  2 xi = fma(s, di, fma(-c, dr, ai + bi)),  |X| = (float)sqrt(fma(2xr, 2xr, 2xi 2xi) / 4) */
       double xr2 = fma(c, di, fma(s, dr, a_r + b_r));
       double xi2 = fma(s, di, fma(-c, dr, a_i + b_i));
-      mags[k] = (float)(0.5 * sqrt(fma(xr2, xr2, xi2 * xi2)));
+      mags[k] = (float)sqrt(0.25 * fma(xr2, xr2, xi2 * xi2));
     } else {
       double er = 0.5 * (a_r + b_r), ei = 0.5 * (a_i + b_i);
       double o_r = 0.5 * di, o_i = -0.5 * dr;

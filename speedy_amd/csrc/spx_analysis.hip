@@ -134,6 +134,25 @@ __device__ __forceinline__ void wave_sync() {
 
 #include "spx_log.h"  // spx_log: the fdlibm operation sequence of DESIGN.md "log spec"
 
+// Untangle of the packed transform and magnitude of bin k:  X[k] = (Z[k] + conj Z[W-k]) / 2 - (i / 2) e^{-2 pi i k / N} (Z[k] - conj Z[W-k]);
+// (ar, ai) = Z[k], (b_r, b_i) = conj Z[W-k], w = (cos, -sin)(2 pi k / N).
+//   v2:  2 xr = fma(wx, di, fma(wy, dr, ar + br)),  2 xi = fma(wy, di, fma(-wx, dr, ai + bi)),  |X| = (float)sqrt(fma(2xr, 2xr, 2xi 2xi) / 4)
+//   v1:  the halves first, the products and sums unfused (rounds 1-4)
+__device__ __forceinline__ float spx_untangle_mag(double ar, double ai, double b_r, double b_i, double2 w) {
+  const double dr = ar - b_r, di = ai - b_i;
+#ifdef SPX_DFT_V1
+  const double er = 0.5 * (ar + b_r), ei = 0.5 * (ai + b_i);
+  const double o_r = 0.5 * di, o_i = -0.5 * dr;
+  const double xr = er + (w.x * o_r - w.y * o_i);
+  const double xi = ei + (w.x * o_i + w.y * o_r);
+  return spx_sqrt64_to_f32(xr * xr + xi * xi);
+#else
+  const double xr2 = __builtin_fma(w.x, di, __builtin_fma(w.y, dr, ar + b_r));
+  const double xi2 = __builtin_fma(w.y, di, __builtin_fma(-w.x, dr, ai + b_i));
+  return spx_sqrt64_to_f32(0.25 * __builtin_fma(xr2, xr2, xi2 * xi2));
+#endif
+}
+
 #define C5_1 0.30901699437494742
 #define C5_2 (-0.80901699437494742)
 #define S5_1 0.95105651629515357
@@ -144,16 +163,37 @@ struct cplx {
   double r, i;
 };
 
+// ---- DFT spec v2 (round 5): the multiply-add pairs of the twiddle products, of the radix-3 / 5 / prime butterflies
+// and of the untangle are FUSED (fma = one rounding) -- oracle/orc_speedy.c orc_cmul / orc_butterfly_v2 / orc_specplan_run are the
+// same sequences.  -DSPX_DFT_V1: the unfused transform of rounds 1-4 (A/B against orc_set_dft_spec(1)). ----
+#ifdef SPX_DFT_V1
+#define SPX_FMA_OR(a, b, c, unfused) (unfused)
+#else
+#define SPX_FMA_OR(a, b, c, unfused) __builtin_fma((a), (b), (c))
+#endif
+// b * w (a twiddle, or the pointwise product of Rader's convolution): re = fma(br, wx, -(bi wy)), im = fma(br, wy, bi wx)
+__host__ __device__ __forceinline__ cplx spx_cmul(cplx b, double wx, double wy) {
+  return {SPX_FMA_OR(b.r, wx, -(b.i * wy), b.r * wx - b.i * wy), SPX_FMA_OR(b.r, wy, b.i * wx, b.r * wy + b.i * wx)};
+}
+// radix 3: a0 - t1 / 2
+__host__ __device__ __forceinline__ double spx_bf3h(double a0, double t1) { return SPX_FMA_OR(-0.5, t1, a0, a0 - 0.5 * t1); }
+// radix 5: (a0 + c1 t1) + c2 t2;  s1 t3 + s2 t4;  s2 t3 - s1 t4
+__host__ __device__ __forceinline__ double spx_bf5m(double a0, double c1, double t1, double c2, double t2) {
+  return SPX_FMA_OR(c2, t2, __builtin_fma(c1, t1, a0), (a0 + c1 * t1) + c2 * t2);
+}
+__host__ __device__ __forceinline__ double spx_bf5n(double s1, double t3, double s2, double t4) { return SPX_FMA_OR(s1, t3, s2 * t4, s1 * t3 + s2 * t4); }
+__host__ __device__ __forceinline__ double spx_bf5d(double s2, double t3, double s1, double t4) { return SPX_FMA_OR(s2, t3, -(s1 * t4), s2 * t3 - s1 * t4); }
+// odd prime radix: P += c u,  Q += s v
+__host__ __device__ __forceinline__ double spx_acc(double p, double w, double u) { return SPX_FMA_OR(w, u, p, p + w * u); }
+
 __host__ __device__ __forceinline__ cplx ld(const double* buf, int idx) {
   const double2 v = *reinterpret_cast<const double2*>(buf + 2 * idx);
   return {v.x, v.y};
 }
 __host__ __device__ __forceinline__ void st_tw(double* buf, int idx, cplx b, const double* tw, int t) {
   const double2 w = *reinterpret_cast<const double2*>(tw + 2 * t);
-  double2 o;
-  o.x = b.r * w.x - b.i * w.y;
-  o.y = b.r * w.y + b.i * w.x;
-  *reinterpret_cast<double2*>(buf + 2 * idx) = o;
+  const cplx v = spx_cmul(b, w.x, w.y);
+  *reinterpret_cast<double2*>(buf + 2 * idx) = make_double2(v.r, v.i);
 }
 
 // One Stockham stage of radix r over the W-point transform held in x (-> y).  s = product of earlier radices.
@@ -194,7 +234,7 @@ __host__ __device__ void dft_stage(const int W, const double* tw, int r, int s, 
       const int p = (int)(((unsigned)b * inv_s) >> 20), q = b - p * s;
       cplx a0 = ld(x, b), a1 = ld(x, b + span), a2 = ld(x, b + 2 * span);
       cplx t1 = {a1.r + a2.r, a1.i + a2.i};
-      cplx t2 = {a0.r - 0.5 * t1.r, a0.i - 0.5 * t1.i};
+      cplx t2 = {spx_bf3h(a0.r, t1.r), spx_bf3h(a0.i, t1.i)};
       cplx t3 = {S3_1 * (a1.r - a2.r), S3_1 * (a1.i - a2.i)};
       cplx b0 = {a0.r + t1.r, a0.i + t1.i};
       cplx b1 = {t2.r + t3.i, t2.i - t3.r}, b2 = {t2.r - t3.i, t2.i + t3.r};
@@ -212,10 +252,10 @@ __host__ __device__ void dft_stage(const int W, const double* tw, int r, int s, 
       cplx t1 = {a1.r + a4.r, a1.i + a4.i}, t2 = {a2.r + a3.r, a2.i + a3.i};
       cplx t3 = {a1.r - a4.r, a1.i - a4.i}, t4 = {a2.r - a3.r, a2.i - a3.i};
       cplx b0 = {(a0.r + t1.r) + t2.r, (a0.i + t1.i) + t2.i};
-      cplx m1 = {(a0.r + C5_1 * t1.r) + C5_2 * t2.r, (a0.i + C5_1 * t1.i) + C5_2 * t2.i};
-      cplx m2 = {(a0.r + C5_2 * t1.r) + C5_1 * t2.r, (a0.i + C5_2 * t1.i) + C5_1 * t2.i};
-      cplx n1 = {S5_1 * t3.r + S5_2 * t4.r, S5_1 * t3.i + S5_2 * t4.i};
-      cplx n2 = {S5_2 * t3.r - S5_1 * t4.r, S5_2 * t3.i - S5_1 * t4.i};
+      cplx m1 = {spx_bf5m(a0.r, C5_1, t1.r, C5_2, t2.r), spx_bf5m(a0.i, C5_1, t1.i, C5_2, t2.i)};
+      cplx m2 = {spx_bf5m(a0.r, C5_2, t1.r, C5_1, t2.r), spx_bf5m(a0.i, C5_2, t1.i, C5_1, t2.i)};
+      cplx n1 = {spx_bf5n(S5_1, t3.r, S5_2, t4.r), spx_bf5n(S5_1, t3.i, S5_2, t4.i)};
+      cplx n2 = {spx_bf5d(S5_2, t3.r, S5_1, t4.r), spx_bf5d(S5_2, t3.i, S5_1, t4.i)};
       cplx b1 = {m1.r + n1.i, m1.i - n1.r}, b4 = {m1.r - n1.i, m1.i + n1.r};
       cplx b2 = {m2.r + n2.i, m2.i - n2.r}, b3 = {m2.r - n2.i, m2.i + n2.r};
       const int o = q + s * 5 * p;
@@ -248,9 +288,9 @@ __host__ __device__ void dft_stage(const int W, const double* tw, int r, int s, 
         const cplx u = {ai.r + ar.r, ai.i + ar.i}, v = {ai.r - ar.r, ai.i - ar.i};
         const double2 w = *reinterpret_cast<const double2*>(tw + 2 * (t * step));
         B0.r = B0.r + u.r; B0.i = B0.i + u.i;
-        P.r = P.r + w.x * u.r; P.i = P.i + w.x * u.i;
+        P.r = spx_acc(P.r, w.x, u.r); P.i = spx_acc(P.i, w.x, u.i);
         if (i == 1) { Q.r = w.y * v.r; Q.i = w.y * v.i; }
-        else { Q.r = Q.r + w.y * v.r; Q.i = Q.i + w.y * v.i; }
+        else { Q.r = spx_acc(Q.r, w.y, v.r); Q.i = spx_acc(Q.i, w.y, v.i); }
       }
       const cplx bj = {P.r - Q.i, P.i + Q.r}, brj = {P.r + Q.i, P.i - Q.r};
       const int o = q + s * r * p;
@@ -287,7 +327,7 @@ __device__ __forceinline__ int mono_sample(const int16_t* __restrict__ in, int64
 }
 
 // cplx helpers of the specialised transform (same operation order as dft_stage / st_tw)
-__device__ __forceinline__ cplx cmul_tw(cplx b, double2 w) { return {b.r * w.x - b.i * w.y, b.r * w.y + b.i * w.x}; }
+__device__ __forceinline__ cplx cmul_tw(cplx b, double2 w) { return spx_cmul(b, w.x, w.y); }
 __device__ __forceinline__ void st(double* buf, int idx, cplx v) {
   *reinterpret_cast<double2*>(buf + 2 * idx) = make_double2(v.r, v.i);
 }
@@ -306,7 +346,7 @@ __device__ __forceinline__ void ct_bfly(const cplx (&a)[R], cplx (&o)[R]) {
     o[1] = {a[0].r - a[1].r, a[0].i - a[1].i};
   } else if constexpr (R == 3) {
     const cplx t1 = {a[1].r + a[2].r, a[1].i + a[2].i};
-    const cplx t2 = {a[0].r - 0.5 * t1.r, a[0].i - 0.5 * t1.i};
+    const cplx t2 = {spx_bf3h(a[0].r, t1.r), spx_bf3h(a[0].i, t1.i)};
     const cplx t3 = {S3_1 * (a[1].r - a[2].r), S3_1 * (a[1].i - a[2].i)};
     o[0] = {a[0].r + t1.r, a[0].i + t1.i};
     o[1] = {t2.r + t3.i, t2.i - t3.r};
@@ -322,10 +362,10 @@ __device__ __forceinline__ void ct_bfly(const cplx (&a)[R], cplx (&o)[R]) {
     const cplx t1 = {a[1].r + a[4].r, a[1].i + a[4].i}, t2 = {a[2].r + a[3].r, a[2].i + a[3].i};
     const cplx t3 = {a[1].r - a[4].r, a[1].i - a[4].i}, t4 = {a[2].r - a[3].r, a[2].i - a[3].i};
     o[0] = {(a[0].r + t1.r) + t2.r, (a[0].i + t1.i) + t2.i};
-    const cplx m1 = {(a[0].r + C5_1 * t1.r) + C5_2 * t2.r, (a[0].i + C5_1 * t1.i) + C5_2 * t2.i};
-    const cplx m2 = {(a[0].r + C5_2 * t1.r) + C5_1 * t2.r, (a[0].i + C5_2 * t1.i) + C5_1 * t2.i};
-    const cplx n1 = {S5_1 * t3.r + S5_2 * t4.r, S5_1 * t3.i + S5_2 * t4.i};
-    const cplx n2 = {S5_2 * t3.r - S5_1 * t4.r, S5_2 * t3.i - S5_1 * t4.i};
+    const cplx m1 = {spx_bf5m(a[0].r, C5_1, t1.r, C5_2, t2.r), spx_bf5m(a[0].i, C5_1, t1.i, C5_2, t2.i)};
+    const cplx m2 = {spx_bf5m(a[0].r, C5_2, t1.r, C5_1, t2.r), spx_bf5m(a[0].i, C5_2, t1.i, C5_1, t2.i)};
+    const cplx n1 = {spx_bf5n(S5_1, t3.r, S5_2, t4.r), spx_bf5n(S5_1, t3.i, S5_2, t4.i)};
+    const cplx n2 = {spx_bf5d(S5_2, t3.r, S5_1, t4.r), spx_bf5d(S5_2, t3.i, S5_1, t4.i)};
     o[1] = {m1.r + n1.i, m1.i - n1.r};
     o[4] = {m1.r - n1.i, m1.i + n1.r};
     o[2] = {m2.r + n2.i, m2.i - n2.r};
@@ -418,9 +458,9 @@ __device__ __forceinline__ void ct_stage_prime_last(double* buf, const int lane,
 #pragma unroll
       for (int i = 1; i <= H; i++) {
         const double wx = wc[(i * jj) % R - 1], wy = ws[(i * jj) % R - 1];
-        Pj.r = Pj.r + wx * uu[i - 1].r; Pj.i = Pj.i + wx * uu[i - 1].i;
+        Pj.r = spx_acc(Pj.r, wx, uu[i - 1].r); Pj.i = spx_acc(Pj.i, wx, uu[i - 1].i);
         if (i == 1) { Qj.r = wy * vv[0].r; Qj.i = wy * vv[0].i; }
-        else { Qj.r = Qj.r + wy * vv[i - 1].r; Qj.i = Qj.i + wy * vv[i - 1].i; }
+        else { Qj.r = spx_acc(Qj.r, wy, vv[i - 1].r); Qj.i = spx_acc(Qj.i, wy, vv[i - 1].i); }
       }
       st(buf, lane + SPAN * jj, cplx{Pj.r - Qj.i, Pj.i + Qj.r});
       st(buf, lane + SPAN * (R - jj), cplx{Pj.r + Qj.i, Pj.i - Qj.r});
@@ -605,7 +645,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
           if (b3i < 80) {
             const cplx a0 = q0[u], a1 = q1[u], a2 = q2[u];
             const cplx t1 = {a1.r + a2.r, a1.i + a2.i};
-            const cplx t2 = {a0.r - 0.5 * t1.r, a0.i - 0.5 * t1.i};
+            const cplx t2 = {spx_bf3h(a0.r, t1.r), spx_bf3h(a0.i, t1.i)};
             const cplx t3 = {S3_1 * (a1.r - a2.r), S3_1 * (a1.i - a2.i)};
             const cplx b0 = {a0.r + t1.r, a0.i + t1.i};
             const cplx b1 = {t2.r + t3.i, t2.i - t3.r}, b2 = {t2.r - t3.i, t2.i + t3.r};
@@ -625,10 +665,10 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
         const cplx t1 = {a1.r + a4.r, a1.i + a4.i}, t2 = {a2.r + a3.r, a2.i + a3.i};
         const cplx t3 = {a1.r - a4.r, a1.i - a4.i}, t4 = {a2.r - a3.r, a2.i - a3.i};
         const cplx b0 = {(a0.r + t1.r) + t2.r, (a0.i + t1.i) + t2.i};
-        const cplx m1 = {(a0.r + C5_1 * t1.r) + C5_2 * t2.r, (a0.i + C5_1 * t1.i) + C5_2 * t2.i};
-        const cplx m2 = {(a0.r + C5_2 * t1.r) + C5_1 * t2.r, (a0.i + C5_2 * t1.i) + C5_1 * t2.i};
-        const cplx n1 = {S5_1 * t3.r + S5_2 * t4.r, S5_1 * t3.i + S5_2 * t4.i};
-        const cplx n2 = {S5_2 * t3.r - S5_1 * t4.r, S5_2 * t3.i - S5_1 * t4.i};
+        const cplx m1 = {spx_bf5m(a0.r, C5_1, t1.r, C5_2, t2.r), spx_bf5m(a0.i, C5_1, t1.i, C5_2, t2.i)};
+        const cplx m2 = {spx_bf5m(a0.r, C5_2, t1.r, C5_1, t2.r), spx_bf5m(a0.i, C5_2, t1.i, C5_1, t2.i)};
+        const cplx n1 = {spx_bf5n(S5_1, t3.r, S5_2, t4.r), spx_bf5n(S5_1, t3.i, S5_2, t4.i)};
+        const cplx n2 = {spx_bf5d(S5_2, t3.r, S5_1, t4.r), spx_bf5d(S5_2, t3.i, S5_1, t4.i)};
         const cplx b1 = {m1.r + n1.i, m1.i - n1.r}, b4 = {m1.r - n1.i, m1.i + n1.r};
         const cplx b2 = {m2.r + n2.i, m2.i - n2.r}, b3 = {m2.r - n2.i, m2.i + n2.r};
         st(bufB, b, b0);
@@ -648,13 +688,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
           const int k2 = (k == 0) ? 0 : 240 - k;
           const cplx a = ld(bufB, k), c = ld(bufB, k2);
           const double b_r = c.r, b_i = -c.i;
-          const double er = 0.5 * (a.r + b_r), ei = 0.5 * (a.i + b_i);
-          const double dr = a.r - b_r, di = a.i - b_i;
-          const double o_r = 0.5 * di, o_i = -0.5 * dr;
-          const double2 w = wu[u];
-          const double xr = er + (w.x * o_r - w.y * o_i);
-          const double xi = ei + (w.x * o_i + w.y * o_r);
-          const float mag = spx_sqrt64_to_f32(xr * xr + xi * xi);
+          const float mag = spx_untangle_mag(a.r, a.i, b_r, b_i, wu[u]);
           mrow[k] = mag;
           if (spec_out) {
             spec_out[k] = mag;
@@ -739,7 +773,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
           if (b < 110) {
             const cplx a0 = q0[u], a1 = q1[u], a2 = q2[u];
             const cplx t1 = {a1.r + a2.r, a1.i + a2.i};
-            const cplx t2 = {a0.r - 0.5 * t1.r, a0.i - 0.5 * t1.i};
+            const cplx t2 = {spx_bf3h(a0.r, t1.r), spx_bf3h(a0.i, t1.i)};
             const cplx t3 = {S3_1 * (a1.r - a2.r), S3_1 * (a1.i - a2.i)};
             const cplx b0 = {a0.r + t1.r, a0.i + t1.i};
             const cplx b1 = {t2.r + t3.i, t2.i - t3.r}, b2 = {t2.r - t3.i, t2.i + t3.r};
@@ -769,10 +803,10 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
             const cplx t1 = {a1.r + a4.r, a1.i + a4.i}, t2 = {a2.r + a3.r, a2.i + a3.i};
             const cplx t3 = {a1.r - a4.r, a1.i - a4.i}, t4 = {a2.r - a3.r, a2.i - a3.i};
             const cplx b0 = {(a0.r + t1.r) + t2.r, (a0.i + t1.i) + t2.i};
-            const cplx m1 = {(a0.r + C5_1 * t1.r) + C5_2 * t2.r, (a0.i + C5_1 * t1.i) + C5_2 * t2.i};
-            const cplx m2 = {(a0.r + C5_2 * t1.r) + C5_1 * t2.r, (a0.i + C5_2 * t1.i) + C5_1 * t2.i};
-            const cplx n1 = {S5_1 * t3.r + S5_2 * t4.r, S5_1 * t3.i + S5_2 * t4.i};
-            const cplx n2 = {S5_2 * t3.r - S5_1 * t4.r, S5_2 * t3.i - S5_1 * t4.i};
+            const cplx m1 = {spx_bf5m(a0.r, C5_1, t1.r, C5_2, t2.r), spx_bf5m(a0.i, C5_1, t1.i, C5_2, t2.i)};
+            const cplx m2 = {spx_bf5m(a0.r, C5_2, t1.r, C5_1, t2.r), spx_bf5m(a0.i, C5_2, t1.i, C5_1, t2.i)};
+            const cplx n1 = {spx_bf5n(S5_1, t3.r, S5_2, t4.r), spx_bf5n(S5_1, t3.i, S5_2, t4.i)};
+            const cplx n2 = {spx_bf5d(S5_2, t3.r, S5_1, t4.r), spx_bf5d(S5_2, t3.i, S5_1, t4.i)};
             const cplx b1 = {m1.r + n1.i, m1.i - n1.r}, b4 = {m1.r - n1.i, m1.i + n1.r};
             const cplx b2 = {m2.r + n2.i, m2.i - n2.r}, b3 = {m2.r - n2.i, m2.i + n2.r};
             const int p = (int)(((unsigned)b * 10923u) >> 16);  // b / 6 for b < 66
@@ -825,13 +859,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
           const int k2 = (k == 0) ? 0 : 330 - k;
           const cplx a = ld(bufA, k), c = ld(bufA, k2);
           const double b_r = c.r, b_i = -c.i;
-          const double er = 0.5 * (a.r + b_r), ei = 0.5 * (a.i + b_i);
-          const double dr = a.r - b_r, di = a.i - b_i;
-          const double o_r = 0.5 * di, o_i = -0.5 * dr;
-          const double2 w = tw2p[k];
-          const double xr = er + (w.x * o_r - w.y * o_i);
-          const double xi = ei + (w.x * o_i + w.y * o_r);
-          const float mag = spx_sqrt64_to_f32(xr * xr + xi * xi);
+          const float mag = spx_untangle_mag(a.r, a.i, b_r, b_i, tw2p[k]);
           mrow[k] = mag;
           if (spec_out) {
             spec_out[k] = mag;
@@ -878,13 +906,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
           const int k2 = (k == 0) ? 0 : WCT - k;
           const cplx a = ld(bufA, k), c = ld(bufA, k2);
           const double b_r = c.r, b_i = -c.i;
-          const double er = 0.5 * (a.r + b_r), ei = 0.5 * (a.i + b_i);
-          const double dr = a.r - b_r, di = a.i - b_i;
-          const double o_r = 0.5 * di, o_i = -0.5 * dr;
-          const double2 w = tw2p[k];
-          const double xr = er + (w.x * o_r - w.y * o_i);
-          const double xi = ei + (w.x * o_i + w.y * o_r);
-          const float mag = spx_sqrt64_to_f32(xr * xr + xi * xi);
+          const float mag = spx_untangle_mag(a.r, a.i, b_r, b_i, tw2p[k]);
           mrow[k] = mag;
           if (spec_out) {
             spec_out[k] = mag;
@@ -977,9 +999,8 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
         const int k = ((ln + 64 * u < 165) ? ln + 64 * u : 0) + 165 * i;
         const cplx a = ld(bufA, k);
         const double2 b = bfq[k];
-        const double cr = a.r * b.x - a.i * b.y;
-        const double ci = a.r * b.y + a.i * b.x;
-        return cplx{cr, -ci};
+        const cplx cc = spx_cmul(a, b.x, b.y);
+        return cplx{cc.r, -cc.i};
       });
       ct_stage<M, 3, 4>(bufA, twMq, ln, ct_from_buf<M, 3>{bufA, ln});
       ct_stage<M, 5, 12>(bufA, twMq, ln, ct_from_buf<M, 5>{bufA, ln});
@@ -1000,13 +1021,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
             c = {x0.r + c2r, x0.i + c2i};
           }
           const double b_r = c.r, b_i = -c.i;
-          const double er = 0.5 * (a.r + b_r), ei = 0.5 * (a.i + b_i);
-          const double dr = a.r - b_r, di = a.i - b_i;
-          const double o_r = 0.5 * di, o_i = -0.5 * dr;
-          const double2 w = tw2q[k];
-          const double xr = er + (w.x * o_r - w.y * o_i);
-          const double xi = ei + (w.x * o_i + w.y * o_r);
-          const float mag = spx_sqrt64_to_f32(xr * xr + xi * xi);
+          const float mag = spx_untangle_mag(a.r, a.i, b_r, b_i, tw2q[k]);
           mrow[k] = mag;
           if (spec_out) {
             spec_out[k] = mag;
@@ -1081,9 +1096,8 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
           for (int k = lane; k < M; k += SPX_WAVE) {
             const cplx a = ld(x, k);
             const double2 b = *reinterpret_cast<const double2*>(P.bfft + 2 * k);
-            const double cr = a.r * b.x - a.i * b.y;
-            const double ci = a.r * b.y + a.i * b.x;
-            *reinterpret_cast<double2*>(x + 2 * k) = make_double2(cr, -ci);
+            const cplx cc = spx_cmul(a, b.x, b.y);
+            *reinterpret_cast<double2*>(x + 2 * k) = make_double2(cc.r, -cc.i);
           }
           wave_sync();
         }
@@ -1121,13 +1135,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       const int k2 = (k == 0) ? 0 : W - k;
       cplx a = ld(x, k), bb = ld(x, k2);
       const double b_r = bb.r, b_i = -bb.i;
-      const double er = 0.5 * (a.r + b_r), ei = 0.5 * (a.i + b_i);
-      const double dr = a.r - b_r, di = a.i - b_i;
-      const double o_r = 0.5 * di, o_i = -0.5 * dr;
-      const double2 w = *reinterpret_cast<const double2*>(ltw2 + 2 * k);
-      const double xr = er + (w.x * o_r - w.y * o_i);
-      const double xi = ei + (w.x * o_i + w.y * o_r);
-      const float mag = spx_sqrt64_to_f32(xr * xr + xi * xi);
+      const float mag = spx_untangle_mag(a.r, a.i, b_r, b_i, *reinterpret_cast<const double2*>(ltw2 + 2 * k));
       mrow[k] = mag;
       if (spec_out) {
         spec_out[k] = mag;

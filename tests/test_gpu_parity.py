@@ -773,9 +773,12 @@ def test_kernel_resources_of_every_form_the_engine_selects():
         assert got[3] == form, ((rate, ch, n, short, lean), got)
         assert 0 < got[0] <= vg and 0 <= got[1] <= sc, ((rate, ch, n, short, lean), got, (vg, sc))
     a = (C.c_int * 3)()
-    for rate, vg in ((16000, 128), (22050, 168), (44100, 256), (48000, 256), (32000, 160), (24000, 136), (8000, 88), (11025, 120)):   # <= 256: two waves per SIMD
+    # (22.05 kHz: since the fused transform of round 5 the 16-frame instantiation keeps four dwords in scratch at its 168 registers --
+    # three waves per SIMD -- and is 5 % faster all the same, profiles/r05/r5i_dft_ab.txt)
+    for rate, vg, sc in ((16000, 128, 0), (22050, 168, 16), (44100, 256, 0), (48000, 256, 0), (32000, 160, 0), (24000, 136, 0), (8000, 88, 0),
+                         (11025, 120, 0)):   # <= 256: two waves per SIMD
         assert L.spx_debug_analysis_info(rate, a) == 0
-        assert 0 < a[0] <= vg and a[1] == 0, (rate, list(a))
+        assert 0 < a[0] <= vg and 0 <= a[1] <= sc, (rate, list(a))
     # the budgets of the concurrent mode, from the same source
     L.spx_debug_walk_info(16000, 1, 256, 1, 0, 0, out); w16 = out[0]
     L.spx_debug_walk_info(22050, 1, 256, 1, 0, 1, out); lean22 = out[0]
