@@ -683,16 +683,30 @@ static SpxModeEnv mode_env() {
   return e;
 }
 static bool device_ours_cb(void* ctx) { return device_is_ours(*static_cast<int*>(ctx)); }
-static SpxModeWalk mode_walk(const SpxPlanDev& d, int n, int maxC, bool speedup_only, bool lean) {
-  const SpxWalkConfig c = spx_walk_config(d, n, maxC, speedup_only, false, lean);
+// What kind of speeds a batch's jobs bring: speedup_only -- every job speeds up (the walk kernel specialised for speeds >= 1
+// applies); any_speed -- not all do, but every speed is one the speed-up kernel's slow-down instantiations take (round 5).
+struct SpxSpeedClass { int maxC; bool speedup_only, any_speed; };
+static SpxSpeedClass speed_class(const spx_stream_job* jobs, int n) {
+  SpxSpeedClass c = {1, true, true};
+  for (int i = 0; i < n; i++) {
+    if (jobs[i].channels > c.maxC) c.maxC = jobs[i].channels;
+    const bool ok = jobs[i].speed > 0.0f && jobs[i].speed < SPX_FAST_MAX_SPEED && jobs[i].nonlinear >= 0.0f && jobs[i].nonlinear <= 1.0f;
+    if (!(ok && jobs[i].speed > 1.0f)) c.speedup_only = false;
+    if (!ok) c.any_speed = false;
+  }
+  if (c.speedup_only) c.any_speed = false;   // (the flag means: slow-down jobs are there)
+  return c;
+}
+static SpxModeWalk mode_walk(const SpxPlanDev& d, int n, int maxC, bool speedup_only, bool lean, bool any_speed = false) {
+  const SpxWalkConfig c = spx_walk_config(d, n, maxC, speedup_only, false, lean, any_speed);
   SpxModeWalk w;
   w.lds = c.lds; w.waves = c.waves; w.fast_kernel = c.fast_kernel; w.nwc = c.nwc;
-  w.vgprs = spx_walk_vgprs(d, n, maxC, speedup_only, lean);
+  w.vgprs = spx_walk_vgprs(d, n, maxC, speedup_only, lean, any_speed);
   return w;
 }
 // (cached per plan and shape: the register queries and spx_walk_config are not free, and the engine asks on every call)
-static const SpxModeResources& mode_resources(spx_plan* plan, int n, int maxC, bool speedup_only) {
-  const long long key = ((long long)n << 16) ^ ((long long)maxC << 1) ^ (speedup_only ? 1 : 0);
+static const SpxModeResources& mode_resources(spx_plan* plan, int n, int maxC, bool speedup_only, bool any_speed = false) {
+  const long long key = ((long long)n << 16) ^ ((long long)maxC << 2) ^ (any_speed ? 2 : 0) ^ (speedup_only ? 1 : 0);
   auto it = plan->res_cache.find(key);
   if (it != plan->res_cache.end()) return it->second;
   const SpxPlanDev& d = plan->dev;
@@ -700,10 +714,10 @@ static const SpxModeResources& mode_resources(spx_plan* plan, int n, int maxC, b
   memset(&R, 0, sizeof(R));
   R.cu_count = plan->cu_count;
   R.lds_per_cu = plan->lds_per_cu;
-  R.walk = mode_walk(d, n, maxC, speedup_only, false);
+  R.walk = mode_walk(d, n, maxC, speedup_only, false, any_speed);
   R.walk_lean = R.walk;
   if (maxC == 1 && n <= plan->cu_count && R.walk.fast_kernel && R.walk.nwc > 0) {
-    R.walk_lean = mode_walk(d, n, maxC, speedup_only, true);
+    R.walk_lean = mode_walk(d, n, maxC, speedup_only, true, any_speed);
     R.lean_valid = true;
   }
   R.tension_lds = spx_tension_lds_bytes();
@@ -728,7 +742,7 @@ extern "C" int spx_debug_mode_resources(int sample_rate, int channels, int n_str
   spx_plan* plan = shared_plan_full(sample_rate, 0);
   if (!plan || !out || n_streams < 1) return -1;
   std::lock_guard<std::mutex> g(plan->mu);
-  const SpxModeResources& R = mode_resources(plan, n_streams, channels < 1 ? 1 : channels, speedup_only != 0);
+  const SpxModeResources& R = mode_resources(plan, n_streams, channels < 1 ? 1 : channels, speedup_only != 0, speedup_only == 0);
   const long long v[22] = {R.cu_count, (long long)R.lds_per_cu, (long long)R.walk.lds, R.walk.waves, R.walk.vgprs, R.walk.fast_kernel, R.walk.nwc,
                            (long long)R.walk_lean.lds, R.walk_lean.waves, R.walk_lean.vgprs, R.walk_lean.fast_kernel, R.walk_lean.nwc, R.lean_valid,
                            (long long)R.tension_lds, R.tension_vgprs, R.tile_default, R.tile_big, R.tile_small, (long long)R.an_lds_default,
@@ -822,14 +836,11 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   SpxPlanDev d = plan->dev;  // a copy: the tile size is chosen per call
   Layout L = layout_for(d, jobs, n);
   if (ws_bytes < L.total || !ws) return fail(-1, "spx_batch: workspace too small");
-  int maxC = 1;
-  bool speedup_only = true;  // every job speeds up: the walk kernel specialised for speeds >= 1 applies
-  for (int i = 0; i < n; i++) {
-    if (jobs[i].channels > maxC) maxC = jobs[i].channels;
-    if (!(jobs[i].speed > 1.0f && jobs[i].speed < SPX_FAST_MAX_SPEED && jobs[i].nonlinear >= 0.0f && jobs[i].nonlinear <= 1.0f)) speedup_only = false;
-  }
+  const SpxSpeedClass SC = speed_class(jobs, n);
+  const int maxC = SC.maxC;
+  const bool speedup_only = SC.speedup_only, any_speed = SC.any_speed;
   std::lock_guard<std::mutex> plan_lock(plan->mu);
-  const SpxModeResources& R = mode_resources(plan, n, maxC, speedup_only);
+  const SpxModeResources& R = mode_resources(plan, n, maxC, speedup_only, any_speed);
   if (R.walk.lds > 160 * 1024)   // one CU's LDS; the window holds every channel of maxRequired + 64 frames at least
     return fail(-1, "spx_batch: too many channels for the walk kernel's LDS window");
   hipStream_t st = static_cast<hipStream_t>(hs);
@@ -846,7 +857,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   memset(&T, 0, sizeof(T));
   const int two_back = (plan->ahead_calls + 2) & 3;
   T.two_workspaces = plan->ev_walk_valid[two_back] && plan->ring_ws[two_back] == ws;
-  T.trial_key = ((long long)n << 40) ^ ((long long)L.total_frames << 8) ^ (maxC << 2) ^ (speedup_only ? 2 : 0) ^ (opt.overlap_req ? 1 : 0);
+  T.trial_key = ((long long)n << 40) ^ ((long long)L.total_frames << 8) ^ (maxC << 3) ^ (any_speed ? 4 : 0) ^ (speedup_only ? 2 : 0) ^ (opt.overlap_req ? 1 : 0);
   T.device_ours = device_ours_cb;
   T.device_ctx = &plan->device;
   spx_plan::Trial& TR = plan->trial;
@@ -1020,7 +1031,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
         // count themselves in for the next call's gate.
         SpxTimed tm(timed, 1, stw);
         spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, ((concurrent && !diag_nowait) || ahead) ? d_ready : nullptr,
-                        speedup_only, stw, false, M.exclusive_cu ? R.lds_per_cu / 2 + 1024 : 0, M.launch_lean);
+                        speedup_only, stw, false, M.exclusive_cu ? R.lds_per_cu / 2 + 1024 : 0, M.launch_lean, any_speed);
       }
       if (M.ahead_forced && force->started_out) *force->started_out = d_ready + n;
       if (c == nch - 1 && !force) {
@@ -1099,15 +1110,11 @@ static int run_split(spx_plan_t plan, const spx_stream_job* jobs, int n, const i
   if (P.k > 1 && (g_chunks_set.load() || ws_bytes < P.total)) P.k = 1;
   if (P.k > 1) {
     // would a sub-batch take the pipelined order with overlapping walk kernels?
-    int maxC = 1;
-    bool speedup_only = true;
-    for (int i = 0; i < n; i++) {
-      if (jobs[i].channels > maxC) maxC = jobs[i].channels;
-      if (!(jobs[i].speed > 1.0f && jobs[i].speed < SPX_FAST_MAX_SPEED && jobs[i].nonlinear >= 0.0f && jobs[i].nonlinear <= 1.0f)) speedup_only = false;
-    }
+    const SpxSpeedClass SC = speed_class(jobs, n);
+    const int maxC = SC.maxC;
     std::lock_guard<std::mutex> plan_lock(plan->mu);
     const int m = P.first[1] - P.first[0];
-    const SpxModeResources& R = mode_resources(plan, m, maxC, speedup_only);
+    const SpxModeResources& R = mode_resources(plan, m, maxC, SC.speedup_only, SC.any_speed);
     SpxModeShape S;
     memset(&S, 0, sizeof(S));
     S.n = m; S.max_channels = maxC; S.do_a = S.do_w = true; S.has_frames = true; S.force_total_streams = m;
@@ -1287,15 +1294,13 @@ static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job
   for (int g = 0; g < n_plans; g++) {
     if (gj[g].empty()) continue;
     const SpxPlanDev& d = plans[g]->dev;
-    int maxC = 1; bool speedup_only = true, any_nl = false;
-    for (const auto& j : gj[g]) {
-      maxC = std::max(maxC, (int)j.channels);
-      if (!(j.speed > 1.0f && j.speed < SPX_FAST_MAX_SPEED && j.nonlinear >= 0.0f && j.nonlinear <= 1.0f)) speedup_only = false;
-      any_nl = any_nl || j.nonlinear != 0.0f;
-    }
+    const SpxSpeedClass SC = speed_class(gj[g].data(), (int)gj[g].size());
+    const int maxC = SC.maxC;
+    bool any_nl = false;
+    for (const auto& j : gj[g]) any_nl = any_nl || j.nonlinear != 0.0f;
     SpxModeGroup mg;
     mg.n = (int)gj[g].size();
-    mg.walk = mode_walk(d, mg.n, maxC, speedup_only, false);
+    mg.walk = mode_walk(d, mg.n, maxC, SC.speedup_only, false, SC.any_speed);
     if (mg.walk.lds > 160 * 1024) return fail(-1, "spx_batch_run_mixed: too many channels for the walk kernel's LDS window");
     mg.any_nonlinear = any_nl;
     mg.an_lds = spx_analysis_lds_bytes(d);
@@ -1534,9 +1539,11 @@ const char* spx_batch_kernel_names_lean(spx_plan_t plan, int n_streams, int max_
 static const char* kernel_names(spx_plan_t plan, int n_streams, int max_channels, int speedup_only, bool lean) {
   static thread_local char buf[256];
   const SpxPlanDev& d = plan->dev;
-  const SpxWalkConfig c = spx_walk_config(d, n_streams, max_channels < 1 ? 1 : max_channels, speedup_only != 0, false, lean);
+  const SpxWalkConfig c = spx_walk_config(d, n_streams, max_channels < 1 ? 1 : max_channels, speedup_only != 0, false, lean, speedup_only == 0);
   char walk[96];
-  if (c.fast_kernel)
+  if (c.fast_kernel && c.slow)
+    snprintf(walk, sizeof(walk), "spx_walk_fast_kernel<%d, %d, 0, 0, %d>", c.nwm, c.nwc >= 4 ? 4 : 0, max_channels > 1 ? 3 : 2);
+  else if (c.fast_kernel)
     {
       const bool ct_rate = d.rate == 16000 || d.rate == 22050;
       const bool lng = ct_rate && c.nwm == 4 && c.nwc >= 4 && c.wcap == 8192;   // spx_launch_walk_fast's long-window instantiations
@@ -1570,9 +1577,9 @@ int spx_debug_kernel_vgprs(int which) {
 int spx_debug_walk_info(int sample_rate, int channels, int n_streams, int speedup_only, int short_jobs, int lean, int* out) {
   const SpxPlanDev* P = spx_internal_shared_plan(sample_rate, 0);
   if (!P || !out) return -1;
-  const SpxWalkConfig c = spx_walk_config(*P, n_streams, channels < 1 ? 1 : channels, speedup_only != 0, short_jobs != 0, lean != 0);
+  const SpxWalkConfig c = spx_walk_config(*P, n_streams, channels < 1 ? 1 : channels, speedup_only != 0, short_jobs != 0, lean != 0, speedup_only == 0);
   int scratch = -1;
-  out[0] = spx_walk_kernel_regs(*P, n_streams, channels, speedup_only != 0, short_jobs != 0, lean != 0, &scratch);
+  out[0] = spx_walk_kernel_regs(*P, n_streams, channels, speedup_only != 0, short_jobs != 0, lean != 0, &scratch, speedup_only == 0);
   out[1] = scratch;
   out[2] = (int)c.lds;
   out[3] = c.fast_kernel ? 16 * c.nwm + c.nwc : 0;

@@ -170,10 +170,13 @@ void spx_launch_tension(const SpxPlanDev& P, const SpxStreamDev* streams, int n_
                         hipStream_t st);
 // speedup_only: every job has speed > 1 and 0 <= nonlinear <= 1 (and a streamed job has never had another setting),
 // so the time-scale stage only ever sees speeds >= 1: selects the walk kernel specialised for that.
+// any_speed (round 5; the batch engine): the jobs do NOT all speed up, but every speed the time-scale stage can be given is a valid
+// one below SPX_FAST_MAX_SPEED -- the speed-up kernel's instantiations that also run libsonic's insertPitchPeriod serve the batch
+// (spx_walk_fast.hip, MC + 2) instead of the general kernel.
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int max_channels,
                      const int16_t* in, int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
                      const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs = false, size_t lds_min = 0,
-                     bool lean = false);
+                     bool lean = false, bool any_speed = false);
 size_t spx_analysis_lds_bytes(const SpxPlanDev& P);
 int spx_analysis_ct_window(const SpxPlanDev& P);
 // The DFT of the spec run on the host (same operation order as the kernel): used to build the Rader tables.
@@ -187,18 +190,20 @@ struct SpxWalkConfig {
   int nwm, nwc, wcap;  // spx_walk_fast_kernel: search waves, output waves, window frames
   int waves;         // waves per stream of the kernel that will run
   size_t lds;        // its LDS bytes per stream
+  bool slow;         // the fast kernel's instantiation that also serves speeds below 1
 };
 // short_jobs: the streams bring a few pitch steps each (coalesced sonic2.h writes): latency form whatever their number
 // lean: no output waves (and the usual window) although the streams have a CU each -- the search waves do the output work:
 // one walk wave per SIMD instead of two, which is what lets two analysis waves of 168 registers sit beside it (22.05 kHz)
 SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only, bool short_jobs = false,
-                              bool lean = false);
+                              bool lean = false, bool any_speed = false);
 // spx_walk_fast.hip
 size_t spx_walk_fast_lds_bytes(const SpxPlanDev& P, int wcap);
 bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm);
 void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, const int16_t* in,
                           int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
-                          const int* speed_ready, int nwm, int nwc, int wcap, int max_channels, hipStream_t st, size_t lds_min = 0);
+                          const int* speed_ready, int nwm, int nwc, int wcap, int max_channels, hipStream_t st, size_t lds_min = 0,
+                          bool slow = false);
 // n_out value of a stream whose producer kernel never delivered (concurrent mode poll limit): not an overflow
 #define SPX_NOUT_LOST_PRODUCER INT64_MIN
 size_t spx_tension_lds_bytes();
@@ -208,9 +213,9 @@ size_t spx_tension_lds_bytes();
 int spx_kernel_vgprs(const void* fn, int* scratch_bytes = nullptr);   // spx_engine.hip (one cache, behind a mutex)
 int spx_tension_vgprs();
 int spx_analysis_vgprs(const SpxPlanDev& P, int* scratch_bytes = nullptr);
-int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only, bool lean = false);
+int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only, bool lean = false, bool any_speed = false);
 int spx_walk_kernel_regs(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only, bool short_jobs, bool lean,
-                         int* scratch_bytes);
+                         int* scratch_bytes, bool any_speed = false);
 // speedyComputeSpeedFromTension (speedy.c:768-788) on the stream's state record: *speed_out = requested speed, the
 // duration sums of the record advance.
 void spx_launch_speed_from_tension(SpxStreamState* state, float tension, float Rg, float feedback, float* speed_out,

@@ -158,6 +158,10 @@ static inline SpxMode spx_mode_pass(const SpxModeShape& S, const SpxModeResource
   M.ahead = M.ahead_forced || seq_ahead ||
             (S.ahead_req && (want_concurrent || (E.ahead_any && both && S.n <= R.cu_count && E.concurrent_enabled)) && !doubtful &&
              !S.forced && trial_slot < 0 && chunks_free);
+  // a batch without a single analysis frame (linear jobs only: the TSM stage alone) has no producers to run ahead of anything: its
+  // walk kernel on the caller's stream, call after call (measured, profiles/r05/r5k_scale_configs.txt: 16 kHz linear 0.5x 2.86 ms
+  // plain against 3.55 in the pipelined order)
+  if (!S.has_frames && !M.ahead_forced) { M.ahead = false; seq_ahead = false; M.seq_ahead = false; }
   if (M.ahead) want_concurrent = false;
   if (want_concurrent && !S.forced && T.guard_busy) want_concurrent = false;
   M.want_concurrent = want_concurrent;

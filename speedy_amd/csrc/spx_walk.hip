@@ -935,11 +935,13 @@ static int walk_mode(const SpxPlanDev& P, int maxC, bool speedup_only) {
 
 // Kernel variant, waves per stream and LDS per stream for a batch: the one place the launcher and the engine's
 // co-residency arithmetic both ask.
-SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool short_jobs, bool lean) {
+SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool short_jobs, bool lean, bool any_speed) {
   if (maxC < 1) maxC = 1;
   const WalkTuning& T = walk_tuning();
   SpxWalkConfig c;
-  c.mode = walk_mode(P, maxC, speedup_only);
+  static const bool no_slow_fast = spx_tuning_env("SPX_NO_SLOW_FAST") != nullptr;   // A/B: slow-down batches on the general kernel
+  const bool slow = !speedup_only && any_speed && !no_slow_fast;
+  c.mode = walk_mode(P, maxC, speedup_only || slow);
   c.fast_kernel = ((c.mode == 1 || c.mode == 2) && !T.old_fast);  // spx_walk_fast_kernel: mono and (round 2) multi-channel
   // Waves per stream of spx_walk_kernel.  Measured on MI355X, 10 s streams (ms per call; 2 / 4 / 8 waves): 256 streams
   // 3.67 / 3.19 / 2.91 (walk kernel alone), 512: 5.40 / 4.78 / 5.63, 1024: 10.3 / 9.3 / 10.5, 2048: 19.7 / 17.7 / -.
@@ -976,8 +978,9 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   c.wcap = throughput ? 1536 : 4096;
   // long jobs with at most two streams per CU on the rate-specialised kernels with output waves: the 8192-frame window (half
   // as many refills; spx_walk_fast.hip, SPEC = 1)
+  // (not for the instantiations that serve slow-down: those exist in their plan-driven form only)
   if (!throughput && !short_jobs && c.fast_kernel && c.nwm == 4 && c.nwc == 4 && (P.rate == 16000 || P.rate == 22050) && T.nwm <= 0 &&
-      T.nwc < 0) c.wcap = 8192;
+      T.nwc < 0 && !slow) c.wcap = 8192;
   // rates from 24 kHz (the eight-search-wave form): a step needs up to 2 x maxRequired frames of window, so the 4096-frame window
   // is refilled every ~2 700 frames at 44.1 kHz -- 160 times per 10 s stream; twice the window, a third of the refills
   if (!throughput && !short_jobs && c.fast_kernel && P.skip >= 6 && T.wcap <= 0) c.wcap = 8192;
@@ -999,6 +1002,7 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   }
   // without spx_walk_fast_kernel: modes 1 / 2 of spx_walk_kernel hold one lag per lane and the 4096-frame window
   if (!c.fast_kernel && c.mode != 0 && !((8 * P.skip + 1) <= 64 && walk_lds_layout(P, maxC).wcap == 4096)) c.mode = 0;
+  c.slow = slow && c.fast_kernel;
   if (c.fast_kernel) {
     c.mode = 1;
     if (c.nwm == 8) c.nwc = 4;           // the eight-search-wave form always has its four output waves
@@ -1010,10 +1014,11 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   }
   return c;
 }
-int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC, int* scratch_bytes = nullptr);
-int spx_walk_kernel_regs(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool short_jobs, bool lean, int* scratch_bytes) {
-  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC < 1 ? 1 : maxC, speedup_only, short_jobs, lean);
-  if (cfg.fast_kernel) return spx_walk_fast_vgprs(P, cfg.nwm, cfg.nwc, cfg.wcap, maxC, scratch_bytes);
+int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC, int* scratch_bytes = nullptr, bool slow = false);
+int spx_walk_kernel_regs(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool short_jobs, bool lean, int* scratch_bytes,
+                         bool any_speed) {
+  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC < 1 ? 1 : maxC, speedup_only, short_jobs, lean, any_speed);
+  if (cfg.fast_kernel) return spx_walk_fast_vgprs(P, cfg.nwm, cfg.nwc, cfg.wcap, maxC, scratch_bytes, cfg.slow);
   const void* fn;
 #define SPX_FN_W(NWV) (cfg.mode == 1 ? reinterpret_cast<const void*>(spx_walk_kernel<NWV, 1>)   \
                        : cfg.mode == 2 ? reinterpret_cast<const void*>(spx_walk_kernel<NWV, 2>) \
@@ -1028,8 +1033,8 @@ int spx_walk_kernel_regs(const SpxPlanDev& P, int n_streams, int maxC, bool spee
 #undef SPX_FN_W
   return spx_kernel_vgprs(fn, scratch_bytes);
 }
-int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool lean) {
-  return spx_walk_kernel_regs(P, n_streams, maxC, speedup_only, false, lean, nullptr);
+int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool lean, bool any_speed) {
+  return spx_walk_kernel_regs(P, n_streams, maxC, speedup_only, false, lean, nullptr, any_speed);
 }
 size_t spx_walk_lds_bytes(const SpxPlanDev& P, int maxC, bool speedup_only) {
   return spx_walk_config(P, 256, maxC, speedup_only).lds;
@@ -1040,14 +1045,14 @@ extern "C" int spx_debug_last_walk_form(void) { return g_last_walk_form.load(std
 
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int maxC, const int16_t* in,
                      int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
-                     const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs, size_t lds_min, bool lean) {
+                     const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs, size_t lds_min, bool lean, bool any_speed) {
   if (n_streams <= 0) return;
   if (maxC < 1) maxC = 1;
-  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC, speedup_only, short_jobs, lean);
+  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC, speedup_only, short_jobs, lean, any_speed);
   g_last_walk_form.store(cfg.fast_kernel ? 16 * cfg.nwm + cfg.nwc : 0, std::memory_order_relaxed);
   if (cfg.fast_kernel) {
     spx_launch_walk_fast(P, streams, n_streams, in, out, n_out, states, scratch, speed_ready, cfg.nwm, cfg.nwc, cfg.wcap,
-                         maxC, st, lds_min);
+                         maxC, st, lds_min, cfg.slow);
     return;
   }
   const int fast = cfg.mode;

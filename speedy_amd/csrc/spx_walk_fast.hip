@@ -613,7 +613,10 @@ extern "C" long long spx_debug_fdiv_check(unsigned seed, unsigned denominators, 
 // (The parameter's name is history: round 2 tried speculative refine searches on the output waves -- the previous step's coarse winner
 // predicts this step's refine window in 30-60 % of steps -- bit-exact and SLOWER, 2.44 against 2.06 ms: DESIGN.md 5.3; the
 // protocol lived here behind this parameter until round 3 and is in the history, commit dd0437d and before.)
-// MC: 0 = mono streams only (the instantiation of the bench), 1 = any channel count up to 8 per stream.
+// MC: 0 = mono streams only (the instantiation of the bench), 1 = any channel count up to 8 per stream; + 2 (round 5): the
+// instantiation also serves events at speeds BELOW 1 (libsonic's insertPitchPeriod) -- a batch with slow-down
+// jobs no longer falls back to the general kernel.  The search is the same; what differs is what a step does with its period
+// (run_event_slow below).  Instantiations without the bit compile to the code they always had.
 template <int NWM, int NWC, int RATE, int SPEC, int MC>
 #ifndef SPX_TP_WAVES
 #define SPX_TP_WAVES 4   // minimum waves per SIMD the throughput instantiations (NWC == 0) are compiled for
@@ -625,7 +628,8 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   constexpr int NT = 64 * (NWM + NWC);
   constexpr int FCG = fcg_of(NWM), FRG = frg_of(NWM);
   static_assert(SPEC == 0 || (SPEC == 1 && RATE != 0 && NWC > 0), "SPEC = 1: the long window of the rate-specialised kernels with output waves");
-  constexpr bool MCH = MC != 0;
+  constexpr bool MCH = (MC & 1) != 0;
+  constexpr bool SLOWK = (MC & 2) != 0;
   // WIDE: refine searches of up to 121 lags (8 skip + 1; 44.1 kHz: 89, 48 kHz: 97) -- two lags per lane in the refine select,
   // sum buffers of 128 words.  The eight-search-wave form only (its rectangle has the lanes for that many lags).
   constexpr bool WIDE = NWM == 8;
@@ -1005,9 +1009,15 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   // (Round 3 tried issuing the NEXT step's coarse loads from the end of a step, in front of the bookkeeping between two steps:
   // 3 % slower at every code placement, profiles/r03/r03y_pf_pads.txt -- the round trip was not what the chain waited for.)
 
-  auto find_period = [&](pos_t pos, bool ge2, float sm1, float twom, float rinv, int& n_ret, int& rem_ret, auto hot)
+  // kind (the general call site of an instantiation that serves slow-down only): which candidate formula the step takes --
+  //   0  speed >= 2:       n = (int)(p / (speed - 1))                     1  1 < speed < 2:     n = p, rem = (int)(p (2 - speed) / (speed - 1))
+  //   2  speed < 0.5:      n = (int)(p speed / (1 - speed))               3  0.5 <= speed < 1:  n = p, rem = (int)(p (2 speed - 1) / (1 - speed))
+  // with `sm1` the divisor and `twom` the numerator's factor as the caller prepared them; IEEE divisions there.
+  auto find_period = [&](pos_t pos, bool ge2, float sm1, float twom, float rinv, int& n_ret, int& rem_ret, auto hot, int kind = 0)
                          __attribute__((always_inline)) -> int {
     (void)hot;  // std::true_type from the hot loop: its copy of this code has ge2 a constant
+    (void)kind;
+    constexpr bool ANYK = SLOWK && !decltype(hot)::value;
     if constexpr (NWC == 0) nsteps++;   // (with output waves THEY count the step commands, off the chain)
     FSTAMP(1);
     if (SPX_UNLIKELY(!(wbase >= 0 && pos >= wbase && pos + need <= wbase + LY.wcap))) {
@@ -1075,8 +1085,14 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         nLane = ge2 ? (int)(fp / sm1) : pc;
         remLane = ge2 ? 0 : (int)(fp * twom / sm1);
 #else
-        nLane = ge2 ? (int)fast_div(fp, sm1, rinv) : pc;
-        remLane = ge2 ? 0 : (int)fast_div(fp * twom, sm1, rinv);
+        if constexpr (ANYK) {
+          const int q = (int)((kind == 0 ? fp : fp * twom) / sm1);
+          nLane = (kind & 1) ? pc : q;
+          remLane = (kind & 1) ? q : 0;
+        } else {
+          nLane = ge2 ? (int)fast_div(fp, sm1, rinv) : pc;
+          remLane = ge2 ? 0 : (int)fast_div(fp * twom, sm1, rinv);
+        }
 #endif
         if constexpr (WIDE) {
           const int pc2 = (lane == 63) ? prevPeriod : p2;
@@ -1085,8 +1101,14 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
           nLane2 = ge2 ? (int)(fp2 / sm1) : pc2;
           remLane2 = ge2 ? 0 : (int)(fp2 * twom / sm1);
 #else
-          nLane2 = ge2 ? (int)fast_div(fp2, sm1, rinv) : pc2;
-          remLane2 = ge2 ? 0 : (int)fast_div(fp2 * twom, sm1, rinv);
+          if constexpr (ANYK) {
+            const int q2 = (int)((kind == 0 ? fp2 : fp2 * twom) / sm1);
+            nLane2 = (kind & 1) ? pc2 : q2;
+            remLane2 = (kind & 1) ? q2 : 0;
+          } else {
+            nLane2 = ge2 ? (int)fast_div(fp2, sm1, rinv) : pc2;
+            remLane2 = ge2 ? 0 : (int)fast_div(fp2 * twom, sm1, rinv);
+          }
 #endif
         }
       }
@@ -1159,7 +1181,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         pos += n;
       } else {
         int n, rem;
-        const int period = find_period(pos, ge2, sm1, twom, rinv, n, rem, std::false_type());
+        const int period = find_period(pos, ge2, sm1, twom, rinv, n, rem, std::false_type(), ge2 ? 0 : 1);
         if (!ge2) remaining = rem;
         if (out_n + n > X.out_cap) overflow = 1;
         // a failed step (n == 0) is no branch of its own: it hands over no cross-fade (xf_n = 0), leaves pos where it is and ends
@@ -1169,6 +1191,43 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         out_n += n;
         pos += failed ? 0 : period + n;
         FSTAMP(10);
+      }
+    } while (!failed && pos + maxRequired <= availE);
+    if (!failed) base = pos;
+  };
+
+  // The same for an event at a speed BELOW 1 (SLOWK instantiations): libsonic's insertPitchPeriod.  A step copies the period at the
+  // position through (`period` frames, a plain copy command), cross-fades n frames from the period BEHIND the position down into
+  // the one AT it -- the usual cross-fade with the ramps swapped: down = pos + period, up = down - period -- and consumes n frames:
+  // n = (int)(period speed / (1 - speed)) below 0.5, else n = period with (int)(period (2 speed - 1) / (1 - speed)) frames copied
+  // through afterwards.  A step with n == 0 (a very low speed and a short period) has ALREADY emitted its period when it fails --
+  // the dependency appends before it reports -- and leaves the position where it was.
+  auto run_event_slow = [&](float speed, pos_t availE) __attribute__((always_inline)) {
+    const bool lt05 = speed < 0.5f;
+    const float den = 1.0f - speed, fac = lt05 ? speed : 2.0f * speed - 1.0f;
+    pos_t pos = base;
+    bool failed = false;
+    do {
+      if (remaining > 0) {
+        int n = remaining;
+        if (n > maxRequired) n = maxRequired;
+        if (out_n + n > X.out_cap) overflow = 1;
+        FAST_PUBLISH(FCMD_COPY, n, pos, out_n, 0);
+        if (NWC > 0) fast_sync();
+        out_n += n;
+        remaining -= n;
+        pos += n;
+      } else {
+        int n, rem;
+        const int period = find_period(pos, false, den, fac, 0.0f, n, rem, std::false_type(), lt05 ? 2 : 3);
+        if (!lt05) remaining = rem;
+        if (out_n + period + n > X.out_cap) overflow = 1;
+        failed = n == 0;
+        FAST_PUBLISH(FCMD_COPY, period, pos, out_n, 0);   // (with the previous step's cross-fade, as every command)
+        if (NWC > 0) fast_sync();
+        xf_n = n; xf_down = (int)(pos - wbase) + period; xf_period = -period; xf_out = out_n + period;
+        out_n += period + n;
+        pos += n;
       }
     } while (!failed && pos + maxRequired <= availE);
     if (!failed) base = pos;
@@ -1300,7 +1359,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
             if (SPX_UNLIKELY(runnable == 0)) break;
             const int e = __builtin_ctzll(runnable);
             const float speed = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, spv), e));
-            if (SPX_UNLIKELY(((unityMask >> e) & 1) != 0 || !(speed < 2.0f))) break;
+            if (SPX_UNLIKELY(((unityMask >> e) & 1) != 0 || !(speed < 2.0f) || (SLOWK && !(speed > 1.0f)))) break;
             i = e;
             const pos_t availE = (linear && !flushBlk) ? n_tsm : availBlk + (i + 1) * perEvent;
             const float sm1 = speed - 1.0f, twom = 2.0f - speed;
@@ -1352,7 +1411,8 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
           base = availE;
         } else {
           const float speed = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, spv), i));
-          run_event(speed, availE);
+          if (SLOWK && speed < 1.0f) run_event_slow(speed, availE);
+          else run_event(speed, availE);
         }
         FSTAMP(11);
         i++;
@@ -1411,8 +1471,14 @@ bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm) {
 }
 
 // numRegs of the instantiation spx_launch_walk_fast picks for (nwm, nwc) at this plan's rate
-int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC, int* scratch_bytes) {
+int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC, int* scratch_bytes, bool slow) {
   const void* fn = nullptr;
+  if (slow) {   // the plan-driven instantiations that also serve speeds below 1 (MC + 2)
+#define SPX_FN_SLOW(M, C) (maxC > 1 ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 0, 0, 3>) : reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 0, 0, 2>))
+    fn = nwm == 8 ? SPX_FN_SLOW(8, 4) : nwm == 2 ? SPX_FN_SLOW(2, 0) : (nwc >= 4 ? SPX_FN_SLOW(4, 4) : SPX_FN_SLOW(4, 0));
+#undef SPX_FN_SLOW
+    return spx_kernel_vgprs(fn, scratch_bytes);
+  }
 #define SPX_FN_RM(M, C, MCV) (P.rate == 16000 && wcap == SPX_CT_WCAP_OF(M, C) ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 16000, 0, MCV>) \
                         : P.rate == 22050 && wcap == SPX_CT_WCAP_OF(M, C) ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 22050, 0, MCV>) \
                         : reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 0, 0, MCV>))
@@ -1437,7 +1503,7 @@ int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int max
 
 void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, const int16_t* in,
                           int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
-                          const int* speed_ready, int nwm, int nwc, int wcap, int maxC, hipStream_t st, size_t lds_min) {
+                          const int* speed_ready, int nwm, int nwc, int wcap, int maxC, hipStream_t st, size_t lds_min, bool slow) {
   if (n_streams <= 0) return;
   const FastLds LY = fast_lds_layout(P, wcap);
   // lds_min: the caller wants these workgroups ONE to a CU (it asks for more than half a CU's LDS): walk kernels of several
@@ -1460,6 +1526,17 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
   SPX_LAUNCH_FAST(4, 4);
   return;
 #endif
+  if (slow) {
+    // batches with slow-down jobs: the plan-driven instantiations with the insertPitchPeriod event (MC + 2), the forms
+    // spx_walk_config picks (4 + 4, 4 + 0, 2 + 0, 8 + 4)
+#define SPX_LAUNCH_SLOW(M, C) do { if (maxC > 1) SPX_LAUNCH_FAST_RSM(M, C, 0, 0, 3); else SPX_LAUNCH_FAST_RSM(M, C, 0, 0, 2); } while (0)
+    if (nwm == 8) SPX_LAUNCH_SLOW(8, 4);
+    else if (nwm == 2) SPX_LAUNCH_SLOW(2, 0);
+    else if (nwc >= 4) SPX_LAUNCH_SLOW(4, 4);
+    else SPX_LAUNCH_SLOW(4, 0);
+#undef SPX_LAUNCH_SLOW
+    return;
+  }
   // SPX_FAST_FORMS -- the forms the SHIPPED library carries are the ones spx_walk_config selects by itself: 4 + 4 waves (one or two
   // streams per CU; with the long window at the two BASELINE rates), 4 + 0 (lean form, short jobs beyond one stream per CU),
   // 2 + 0 (throughput form), each rate-specialised for 16 / 22.05 kHz and generic, mono-only and multi-channel; 8 + 4 generic

@@ -724,6 +724,29 @@ def test_walk_form_follows_the_co_residency_arithmetic(orc):
     assert forms[(22050, 2)] == 16 * 4 + 4, forms
 
 
+@pytest.mark.parametrize("rate,ch", [(16000, 1), (22050, 2), (44100, 1)])
+def test_slow_down_batches_run_on_the_speed_up_kernel(orc, rate, ch):
+    """Round 5: a batch with slow-down jobs (libsonic's insertPitchPeriod) no longer falls back to the general walk kernel -- the
+    speed-up kernel's instantiations with the slow-down event serve it (spx_walk_fast.hip, MC + 2).  Speeds below 0.5, between 0.5
+    and 1, unity, above 1 and above 2 in ONE batch, linear and nonlinear, a speed so low that steps fail: bit-equal to the oracle,
+    and the form of the kernel that ran is the fast one."""
+    from speedy_amd.batch import Batch, Plan
+    from speedy_amd.synth import speech_like
+    plan = Plan(rate, False)
+    speeds = [0.3, 0.5, 0.75, 0.99, 1.0, 1.3, 2.0, 3.5, 0.02, 0.45, 0.6, 0.9]
+    nls = [1.0, 0.0, 1.0, 1.0, 0.0, 0.0, 1.0, 1.0, 0.0, 1.0, 0.3, 0.0]
+    n = int(rate * 1.2)
+    xs = [speech_like(n, rate, seed=300 + i, channels=ch) for i in range(len(speeds))]
+    b = Batch(plan, [n] * len(speeds), ch, speeds, nls, 0.0)
+    b.upload(xs)
+    b.run()
+    outs = b.results()
+    assert plan.L.spx_debug_last_walk_form() != 0, "a slow-down batch ran on the general kernel"
+    for i, (x, got) in enumerate(zip(xs, outs)):
+        ref = orc.compress_sound(x, rate, ch, speeds[i], nls[i], 0.0, False, chunk=n, taps=False)["out"]
+        assert np.array_equal(got, ref), (i, speeds[i], nls[i], got.size, ref.size)
+
+
 def test_register_budgets_of_the_concurrent_mode():
     """The concurrent mode needs two analysis waves beside a stream's walk and tension waves on a SIMD's 512 registers
     (DESIGN.md 2).  Both cases that matter are tight: 16 kHz mono 2 x 96 + tension + 2 x 128, and 22.05 kHz mono with the lean

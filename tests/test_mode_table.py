@@ -135,8 +135,10 @@ def test_separate_halves_guard_and_forced_groups(table):
     # another concurrent-mode call in flight on the device: this one runs in sequence
     a = table("16000,1,256,1", guard_busy=1)
     assert (kind(a), a["want_concurrent"], a["tile_frames"]) == ("sequence", 0, 16)
-    # a batch without a single analysis frame has nothing to hand over
+    # a batch without a single analysis frame has nothing to hand over -- and nothing to run ahead of anything
     assert table("16000,1,256,1", has_frames=0)["concurrent"] == 0
+    a = table("16000,1,256,1", has_frames=0, ahead_req=1, overlap_req=1)
+    assert (kind(a), a["walk2"], a["launch_lean"]) == ("sequence", 0, 0)
     # a group of a mixed-rate call takes what was decided for all groups together
     a = table("16000,2,128,1", forced=1, force_concurrent=0, force_ahead=1, force_total_streams=256, ahead_req=0)
     assert (kind(a), a["ahead_forced"], a["walk2"], a["exclusive_cu"], a["asked_device"]) == ("ahead", 1, 0, 1, 0)

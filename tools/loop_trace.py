@@ -12,9 +12,9 @@ from speedy_amd.batch import Batch, Pipeline, Plan  # noqa: E402
 
 kind = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-n, S = bench.RATE * bench.SECONDS, bench.STREAMS_PER_GPU
+n, S = bench.RATE * bench.SECONDS, int(os.environ.get("SPX_PROBE_STREAMS", bench.STREAMS_PER_GPU))
 plan = Plan(bench.RATE, False)
-streams = bench.make_streams(S, n, 0)
+streams = (bench.make_streams(bench.STREAMS_PER_GPU, n, 0) * ((S + 255) // 256))[:S]
 if kind == "turns3":
     bs = [Batch(plan, [n] * S, 1, bench.SPEED, 1.0, 0.0) for _ in range(3)]
     for b in bs:
@@ -42,4 +42,5 @@ t0 = time.perf_counter()
 for k in range(steps):
     fn(12 + k)
 torch.cuda.synchronize()
-print("%s: %.3f ms per step" % (kind, (time.perf_counter() - t0) / steps * 1e3))
+dt = (time.perf_counter() - t0) / steps
+print("%s (%d streams): %.3f ms per step, %.0f Msamples/s" % (kind, S, dt * 1e3, S * n / dt / 1e6))
