@@ -119,8 +119,10 @@ def test_shapes_outside_every_mode(table):
         for kw in (dict(), dict(ahead_req=1), dict(ahead_req=1, overlap_req=1)):
             a = table(shape, **kw)
             assert (kind(a), a["exclusive_cu"], a["launch_lean"]) == ("sequence", 1, 0), (shape, kw)
-    a = table("16000,1,256,0")      # slow-down jobs: the general walk kernel -- its workgroups fit beside the analysis: concurrent
-    assert kind(a) in ("concurrent", "sequence") and a["launch_lean"] == 0
+    # slow-down jobs (round 5: the speed-up kernel's plan-driven instantiation with the insertPitchPeriod event, 128 registers):
+    # two of its waves per SIMD leave no room for two analysis waves, its lean form does -- the concurrent mode with the lean form
+    a = table("16000,1,256,0")
+    assert (kind(a), a["launch_lean"], a["doubtful"]) == ("concurrent", 1, 0)
     # more streams than CUs: kernels in sequence; the throughput regime (more than two per CU) in two time chunks
     a = table("16000,1,512,1")
     assert (kind(a), a["nch"], a["exclusive_cu"]) == ("sequence", 1, 0)
