@@ -925,6 +925,19 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     if (dev_walk_streams(plan->device, &w0, &w1)) return fail(-1, "spx_batch: no walk streams");
     const int cur = plan->ahead_calls & 1;
     stw = cur ? w1 : w0;
+#ifdef SPX_TUNING
+    {
+      // A/B: THREE walk streams taking turns (a third lean walk kernel may take the places the short chains of the other two leave)
+      static const bool three = getenv("SPX_WALK_STREAMS3") != nullptr;
+      static hipStream_t w2[64];
+      if (three) {
+        const int dv = (plan->device >= 0 && plan->device < 64) ? plan->device : 0;
+        if (!w2[dv]) HIPCHK(hipStreamCreateWithFlags(&w2[dv], hipStreamNonBlocking));
+        const int k3 = plan->ahead_calls % 3;
+        stw = k3 == 0 ? w0 : (k3 == 1 ? w1 : w2[dv]);
+      }
+    }
+#endif
     const bool same_out = !opt.sub && (out == plan->ahead_last_out || n_out == plan->ahead_last_nout);
     if (detached) { }   // (the owner of the buffers orders their consumers itself: spx_pipeline waits for done_event on the host)
     else if (same_out) HIPCHK(hipStreamWaitEvent(stw, plan->ev_call[cur], 0));

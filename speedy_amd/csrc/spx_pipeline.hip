@@ -276,6 +276,8 @@ int64_t spx_pipeline_submit(spx_pipeline_t p, const int16_t* in, int in_is_devic
   void* in_ready = nullptr;
   if (!in_is_device) {
     // (the kernels that last read d_in are behind ev_done, waited for above: the copy may start at once)
+    // ONE copy stream: with two taking turns -- so that the next 82 MB copy starts while the previous one still runs and the
+    // 50 - 80 us between two chained copies go -- the leg read 1.73 - 1.75 ms per batch against 1.67 (profiles/r05/r5o_copy_streams.txt).
     if (!S.d_in) {
       // + 64 values behind the input: the walk kernels' aligned window refill may read a few frames past a stream's end; zeroed
       // once, never written again
@@ -309,6 +311,10 @@ int64_t spx_pipeline_submit(spx_pipeline_t p, const int16_t* in, int in_is_devic
     const int* d_ch = reinterpret_cast<const int*>(p->d_tab + 2 * (size_t)n);
     hipLaunchKernelGGL(spx_pipe_offsets_kernel, dim3(1), dim3(256), 0, p->s_run, S.d_nout, d_ch, d_cap, n, S.d_offsets, S.h_meta, S.h_meta + n + 1);
     const int wgs = n < p->pack_wgs ? n : p->pack_wgs;
+#ifdef SPX_TUNING
+    static const bool no_gather = getenv("SPX_PIPE_NO_GATHER") != nullptr;   // DIAGNOSTIC: what the gather kernel costs the others (no output!)
+    if (!no_gather)
+#endif
     hipLaunchKernelGGL(spx_pipe_copy_kernel, dim3(wgs), dim3(256), 0, p->s_run, S.d_out, d_off, S.d_offsets, n, S.h_out);
   }
   if (!event_recorded) PCHK(hipEventRecord(S.ev_done, p->s_run));
