@@ -15,6 +15,10 @@
 // 2.3-3.5 ms per batch with the pipelined calls); a copy of the capacity moves three times the bytes.  The kernel needs neither,
 // and it is narrow (SPX_PIPE_PACK_WGS workgroups): PCIe writes are posted, a few waves keep the link busy, and the CUs stay with the
 // chains of the next batches' walk kernels -- the runtime's own copy kernel is launched full-width.
+// Measured against it (round 5, profiles/r05/r5s_copy_out.txt): the gathered frames to HBM first and out by hipMemcpyAsync, sized
+// from the last batch that came back (the rest of a batch that outgrew the copy fetched at wait time) -- the runtime performs
+// that copy with its full-width shader kernel (__amd_rocclr_copyBuffer, 0.53 - 0.56 ms per 27 MB), and the leg read 1.78 - 1.83 ms
+// per batch against 1.67 - 1.70.  Not kept.
 #include <string.h>
 
 #include <mutex>
