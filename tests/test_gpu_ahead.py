@@ -431,3 +431,39 @@ def test_random_call_sequences(orc, seed):
         b.d_out, b.d_nout = o, c
         assert _crc(b.results()) == bs[k][1], (seed, t, k)
         b.d_out, b.d_nout = keep_o, keep_c
+
+
+def test_sub_batches_of_an_overlapped_call_with_taps(orc):
+    """An overlapped call of 257 .. 512 streams is cut into two overlapping sub-batches (run_split): every tap row -- tension, speed,
+    features, spectrogram, normalised spectrum -- must land where the one-call layout puts it (rows of stream s at the sum of the
+    frame counts of the streams before it, whatever sub-batch it fell into), and hold the oracle's values."""
+    import torch
+    from speedy_amd.batch import Batch, Plan
+    from speedy_amd.synth import speech_like
+    rate, n_streams = 16000, 300
+    plan = Plan(rate, False)
+    rng = np.random.default_rng(5)
+    lens = [int(rate * rng.uniform(0.3, 0.7)) for _ in range(n_streams)]
+    base = [speech_like(max(lens), rate, seed=700 + i) for i in range(10)]
+    xs = [base[i % 10][: lens[i]] for i in range(n_streams)]
+    plain = Batch(plan, lens, 1, 3.5, 1.0, 0.0, taps=True, spectrogram_taps=True)
+    plain.upload(xs)
+    plain.run()
+    want = _crc(plain.results())
+    bs = []
+    for _ in range(2):
+        b = Batch(plan, lens, 1, 3.5, 1.0, 0.0, taps=True, spectrogram_taps=True)
+        b.upload(xs)
+        bs.append(b)
+    torch.cuda.synchronize()
+    for k in range(4):
+        bs[k % 2].run_ahead(overlap=True)
+    torch.cuda.synchronize()
+    for b in bs:
+        assert _crc(b.results()) == want
+        for i in (0, 149, 150, 151, 299):       # both sides of the cut
+            got, ref = b.tap_arrays(i), plain.tap_arrays(i)
+            for key in ("tension", "speed", "features", "spectrogram", "normalized"):
+                assert np.array_equal(got[key], ref[key]), (i, key)
+    o = orc.compress_sound(xs[151], rate, 1, 3.5, 1.0, 0.0, False, chunk=1000)
+    assert np.array_equal(bs[0].tap_arrays(151)["speed"], o["speed"]) and np.array_equal(bs[0].tap_arrays(151)["tension"], o["tension"])
