@@ -706,7 +706,9 @@ def main():
         pt = load_json("pmc_traffic.json")
         if pt:
             traffic = pt.get(dom, {}).get("hbm_bytes_per_launch")
-            traffic_note = pt.get("_note")
+            # (how THIS kernel's counters were taken: the lean walk form inside the pipelined loop, where the profiler may serialise
+            # the launches -- fine for byte counts -- or the serial-mode passes of the other kernels)
+            traffic_note = pt.get(dom, {}).get("source") or pt.get("_note")
         # ---- the two rooflines that actually bound the path (SURVEY 8d "report all three") ----
         clock_mhz = float(getattr(torch.cuda.get_device_properties(dev_index), "clock_rate", 2400000)) / 1e3   # nominal shader clock (2 400 MHz)
         lm = load_json("latency_model.json")
