@@ -115,6 +115,7 @@ struct spx_plan {
   const void* ahead_last_out = nullptr;
   const void* ahead_last_nout = nullptr;
   bool ev_call_valid[2] = {false, false};
+  hipStream_t ev_call_st[2] = {nullptr, nullptr};   // ... and which stream each note was taken on (a detached call leaves none)
   std::vector<std::pair<const int*, int>> mixed_started;   // the same for the groups of the last mixed call (lead plan)
   const int* ahead_started = nullptr;
   int ahead_n = 0;
@@ -625,6 +626,7 @@ static int ring_note(spx_plan* plan, hipStream_t st) {
   if (!plan->ev_call[cur]) HIPCHK(hipEventCreateWithFlags(&plan->ev_call[cur], hipEventDisableTiming));
   HIPCHK(hipEventRecord(plan->ev_call[cur], st));
   plan->ev_call_valid[cur] = true;
+  plan->ev_call_st[cur] = st;
   return 0;
 }
 static int ring_wait(spx_plan* plan, hipStream_t sa, const void* ws, hipStream_t st, bool* waited_prev) {
@@ -920,6 +922,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   hipStream_t stw = st;
   const bool detached = opt.detached && M.walk2 && !force;
   if (do_w && !force && !detached && ring_note(plan, st)) return -2;
+  if (do_w && !force && detached) { plan->ev_call_valid[plan->ahead_calls & 1] = false; plan->ev_call_st[plan->ahead_calls & 1] = nullptr; }
   if (M.walk2) {
     hipStream_t w0 = nullptr, w1 = nullptr;
     if (dev_walk_streams(plan->device, &w0, &w1)) return fail(-1, "spx_batch: no walk streams");
@@ -939,8 +942,11 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     }
 #endif
     const bool same_out = !opt.sub && (out == plan->ahead_last_out || n_out == plan->ahead_last_nout);
+    // (the previous call of the plan on ANOTHER stream, or a detached one -- a pipeline object at work on the same plan: its note says
+    // nothing about this caller's stream, so the walk kernel is ordered behind everything that is on it now)
+    const bool foreign_prev = !plan->ev_call_valid[cur ^ 1] || plan->ev_call_st[cur ^ 1] != st;
     if (detached) { }   // (the owner of the buffers orders their consumers itself: spx_pipeline waits for done_event on the host)
-    else if (same_out) HIPCHK(hipStreamWaitEvent(stw, plan->ev_call[cur], 0));
+    else if (same_out || (foreign_prev && plan->ahead_calls > 0)) HIPCHK(hipStreamWaitEvent(stw, plan->ev_call[cur], 0));
     else if (plan->ev_call_valid[cur ^ 1]) HIPCHK(hipStreamWaitEvent(stw, plan->ev_call[cur ^ 1], 0));
   }
   hipStream_t sa = st;  // the stream the analysis launches go to

@@ -194,4 +194,26 @@ def test_two_pipelines_and_plain_calls_side_by_side(orc):
     for t in tb[-2:]:
         assert _crc(pb.results(t)) == w22
     assert _crc(b16.results()) == w16
-    pa.close(); pb.close()
+    # ... and the caller's OWN overlapped calls on the plan a detached pipeline is working on (outputs left on the device: its calls
+    # leave no note of any stream in the plan's ring): every copy taken right behind a call holds that call's output
+    import torch
+    pd = Pipeline(p16, l16, 1, 3.5, 1.0, 0.0, depth=4, device_out=True)
+    b16b = Batch(p16, l16, 1, 3.5, 1.0, 0.0)
+    b16b.upload(x16)
+    b16.d_out.zero_(); b16b.d_out.zero_()
+    torch.cuda.synchronize()
+    copies, td = [], []
+    for k in range(8):
+        td.append(pd.submit(b16.d_in))
+        q = (b16, b16b)[k % 2]
+        q.run_ahead(overlap=True)
+        copies.append((q, q.d_out.clone(), q.d_nout.clone()))
+    torch.cuda.synchronize()
+    for q, o, c in copies:
+        keep_o, keep_c = q.d_out, q.d_nout
+        q.d_out, q.d_nout = o, c
+        assert _crc(q.results()) == w16
+        q.d_out, q.d_nout = keep_o, keep_c
+    for t in td[-4:]:
+        assert _crc(pd.results(t)) == w16
+    pa.close(); pb.close(); pd.close()
