@@ -923,11 +923,11 @@ static const WalkTuning& walk_tuning() {
 }
 
 // Which kernel variant a batch gets: 0 general, 1 speed-up mono, 2 speed-up multi-channel.  FAST: all streams speeding
-// up (speed > 1, 0 <= nonlinear <= 1: the stage never sees a speed below 1), decimated search, at most 64 lags in the coarse
-// search and 121 in the refine search (rates below 64 kHz; spx_walk_fast_supports has the last word per wave count), and
+// up (speed > 1, 0 <= nonlinear <= 1: the stage never sees a speed below 1), decimated search, at most 128 lags in the coarse
+// search (more than 64: the wide-coarse instantiations, round 5 -- 11.025 kHz has 72) and 121 in the refine search (rates below 64 kHz; spx_walk_fast_supports has the last word per wave count), and
 // skip x channels <= 56 (the refill's exact division of the decimated planes).
 static int walk_mode(const SpxPlanDev& P, int maxC, bool speedup_only) {
-  if (speedup_only && P.skip >= 2 && (P.maxPeriod / P.skip - P.minPeriod / P.skip + 1) <= 64 && (8 * P.skip + 1) <= 121 &&
+  if (speedup_only && P.skip >= 2 && (P.maxPeriod / P.skip - P.minPeriod / P.skip + 1) <= 128 && (8 * P.skip + 1) <= 121 &&
       P.skip * maxC <= 56 && maxC <= 8 && !walk_tuning().generic)
     return (maxC == 1) ? 1 : 2;
   return 0;
@@ -1001,7 +1001,8 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
     if (c.nwm < 4) c.nwm = 4; else if (c.nwm < 8) c.nwm = 8; else c.fast_kernel = false;
   }
   // without spx_walk_fast_kernel: modes 1 / 2 of spx_walk_kernel hold one lag per lane and the 4096-frame window
-  if (!c.fast_kernel && c.mode != 0 && !((8 * P.skip + 1) <= 64 && walk_lds_layout(P, maxC).wcap == 4096)) c.mode = 0;
+  if (!c.fast_kernel && c.mode != 0 && !((8 * P.skip + 1) <= 64 && (P.maxPeriod / P.skip - P.minPeriod / P.skip + 1) <= 64 &&
+                                           walk_lds_layout(P, maxC).wcap == 4096)) c.mode = 0;
   c.slow = slow && c.fast_kernel;
   if (c.fast_kernel) {
     c.mode = 1;

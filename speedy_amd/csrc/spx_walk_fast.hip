@@ -125,9 +125,14 @@ extern "C" void spx_debug_fstamps(unsigned long long* out, int reset) {
 // LDS layout (bytes), shared by host and device
 struct FastLds {
   int off_cmd, off_wait, off_sumC, off_sumR, off_sumS, off_inv, off_mono, off_monoB, off_pl, off_plB, plStrideB, total, wcap;
-  int off_sumW;   // refine searches of more than 64 lags (rates from 32 kHz: 8 skip + 1 lags): two buffers of 128 sums + spare words
+  int off_sumW;   // refine searches of more than 64 lags (rates from 32 kHz: 8 skip + 1 lags): two buffers of 128 sums + spare words;
+                  // or (round 5) COARSE searches of more than 64 lags (rates of about 9.8 - 12 and 14.7 - 16 kHz: 11.025 kHz has 72)
 };
-static __host__ __device__ inline FastLds fast_lds_layout_i(int maxPeriod, int skip_, int wcap) {
+// more than one coarse lag per lane of the coarse select (then two: fast_wide_coarse instantiations, SPEC = 2)
+static __host__ __device__ inline bool fast_wide_coarse(int minPeriod, int maxPeriod, int skip) {
+  return skip > 0 && (maxPeriod / skip - minPeriod / skip + 1) > 64;
+}
+static __host__ __device__ inline FastLds fast_lds_layout_i(int minPeriod, int maxPeriod, int skip_, int wcap) {
   FastLds L;
   L.wcap = wcap;
   int o = 0;
@@ -147,12 +152,12 @@ static __host__ __device__ inline FastLds fast_lds_layout_i(int maxPeriod, int s
   L.off_pl = o; o += plb + SPX_PAD_PL;
   L.off_plB = o; o += plb;
   L.off_sumW = o;
-  if (skip >= 6) o += 512 * 4;   // (the rates the eight-search-wave form serves) behind everything else: no other offset moves
+  if (skip >= 6 || fast_wide_coarse(minPeriod, maxPeriod, skip)) o += 512 * 4;   // (the rates the eight-search-wave form serves, or the wide coarse select) behind everything else: no other offset moves
   L.total = o;
   return L;
 }
 static __host__ __device__ inline FastLds fast_lds_layout(const SpxPlanDev& P, int wcap) {
-  return fast_lds_layout_i(P.maxPeriod, P.skip, wcap);
+  return fast_lds_layout_i(P.minPeriod, P.maxPeriod, P.skip, wcap);
 }
 
 // What the output side needs to know about the stream.
@@ -627,7 +632,13 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
                      const float* scratch_base, const int* speed_ready, int wcap) {
   constexpr int NT = 64 * (NWM + NWC);
   constexpr int FCG = fcg_of(NWM), FRG = frg_of(NWM);
-  static_assert(SPEC == 0 || (SPEC == 1 && RATE != 0 && NWC > 0), "SPEC = 1: the long window of the rate-specialised kernels with output waves");
+  static_assert(SPEC == 0 || (SPEC == 1 && RATE != 0 && NWC > 0) || (SPEC == 2 && RATE == 0 && NWM == 4),
+                "SPEC = 1: the long window of the rate-specialised kernels with output waves; SPEC = 2: the wide coarse select, plan-driven, four search waves");
+  // WIDEC (SPEC = 2, round 5): coarse searches of 65 .. 128 lags -- two lags per lane in the coarse select (lags lane and 64 + lane),
+  // sum buffers of 128 words in the block behind the layout (off_sumW).  11.025 kHz (72 coarse lags at skip 2) leaves the
+  // general kernel with this.
+  constexpr bool WIDEC = SPEC == 2;
+  constexpr int CS = WIDEC ? 128 : 64;       // words per coarse sum buffer
   constexpr bool MCH = (MC & 1) != 0;
   constexpr bool SLOWK = (MC & 2) != 0;
   // WIDE: refine searches of up to 121 lags (8 skip + 1; 44.1 kHz: 89, 48 kHz: 97) -- two lags per lane in the refine select,
@@ -645,7 +656,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   const int maxRequired = 2 * maxP;
   const int B = CT ? (int)(RATE / 100.0) : P.B;
   if (CT) wcap = SPEC == 1 ? SPX_CT_WCAP_LONG : SPX_CT_WCAP_OF(NWM, NWC);
-  const FastLds LY = fast_lds_layout_i(maxP, skip, wcap);
+  const FastLds LY = fast_lds_layout_i(minP, maxP, skip, wcap);
 
   FastOut X;
   X.C = MCH ? S.channels : 1;
@@ -654,7 +665,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   X.lds = lds;
   X.out_cap = (pos_t)(S.out_cap > 0x7fffffff ? 0x7fffffff : S.out_cap);
   X.offA0 = LY.off_mono;
-  unsigned* sumC = reinterpret_cast<unsigned*>(lds + LY.off_sumC);
+  unsigned* sumC = reinterpret_cast<unsigned*>(lds + (WIDEC ? LY.off_sumW : LY.off_sumC));
   unsigned* sumR = reinterpret_cast<unsigned*>(lds + (WIDE ? LY.off_sumW : LY.off_sumR));
   int* cmd = reinterpret_cast<int*>(lds + LY.off_cmd);
   int* sWait = reinterpret_cast<int*>(lds + LY.off_wait);  // [0] polled count, [1] search-wave arrivals, [2] speculation done
@@ -663,6 +674,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     for (int t = tid; t <= maxP; t += NT) invw[t] = t > 0 ? 65536.0 / (double)t : 0.0;
     for (int t = tid; t < 128; t += NT) { sumC[t] = 0; sumR[t] = 0; }
     if constexpr (WIDE) { for (int t = 128 + tid; t < 512; t += NT) sumR[t] = 0; }
+    if constexpr (WIDEC) { for (int t = 128 + tid; t < 512; t += NT) sumC[t] = 0; }
     if (tid < 4) sWait[tid] = 0;
     for (int t = tid; t < 2 * FCMD_INTS; t += NT) cmd[t] = 0;
   }
@@ -954,6 +966,8 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   }
   const double scaleC = 65536.0 / (double)(minC + lane);
   const bool validC = lane < nC;
+  const double scaleC2 = WIDEC ? 65536.0 / (double)(minC + 64 + lane) : 0.0;   // the lane's second coarse lag, 64 + lane
+  const bool validC2 = WIDEC && lane + 64 < nC;
 
   // Hand the pending cross-fade (and, for FCMD_COPY, a plain copy) to the output waves.  Every command is followed by
   // exactly one workgroup barrier before the next command is published, and the two slots alternate, so a slot is
@@ -1045,7 +1059,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
           unsigned d = 0;
 #pragma unroll
           for (int k = 0; k < 4; k++) d = __builtin_amdgcn_sad_u16(a[g][k] & cMask[g][k], b[g][k] & cMask[g][k], d);
-          atomicAdd(&sumC[tg * 64 + cLag[g]], d);  // (idle lanes: a word of their own, see the dealing)
+          atomicAdd(&sumC[tg * CS + cLag[g]], d);  // (idle lanes: a word of their own, see the dealing)
         }
       }
       FSTAMP(3);
@@ -1053,10 +1067,14 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       fast_sync();
       FSTAMP(4);
       SPX_PROBE(4);   // behind the first barrier, in front of the coarse select
-      if (wave == 0) sumC[(1 - tg) * 64 + lane] = 0;  // the buffer the previous step used: everyone is past it
-      const unsigned dsum = sumC[tg * 64 + lane];
+      if (wave == 0) {                                 // the buffer the previous step used: everyone is past it
+        sumC[(1 - tg) * CS + lane] = 0;
+        if constexpr (WIDEC) sumC[(1 - tg) * CS + 64 + lane] = 0;
+      }
+      const unsigned dsum = sumC[tg * CS + lane];
       unsigned kmin;
-      bestC = fast_select(dsum, scaleC, validC, false, minC, kmin);
+      if constexpr (WIDEC) bestC = fast_select2(dsum, sumC[tg * CS + 64 + lane], scaleC, scaleC2, validC, validC2, false, minC, kmin);
+      else bestC = fast_select(dsum, scaleC, validC, false, minC, kmin);
     }
     FSTAMP(5);
     SPX_PROBE(5);   // behind the coarse select, in front of the refine set-up
@@ -1463,6 +1481,8 @@ bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm) {
   if (nlag > (nwm == 8 ? 121 : 63)) return false;   // one lag per lane of the refine select (two in the eight-wave form); lane 63 / 127 = the previous period
   if (nwm == 8 && skip < 6) return false;            // (that form's sum buffers exist in the layout from skip 6 on)
   if (nwm < 2) return false;   // (one search wave per stream was tried in round 3: no faster than two; not instantiated)
+  const int nC = maxC - minC + 1;
+  if (nC > 128 || (nC > 64 && nwm != 4)) return false;   // the coarse select: one lag per lane, two in the wide-coarse instantiations (four search waves)
   if (nch < 3) return false;   // up to three left-over pairs of the rectangle, one per chunk
   const int chM = (65536 + nch - 1) / nch;
   for (int c0 = 0; c0 <= P.maxPeriod / 2 + 1; c0++)
@@ -1473,6 +1493,13 @@ bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm) {
 // numRegs of the instantiation spx_launch_walk_fast picks for (nwm, nwc) at this plan's rate
 int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC, int* scratch_bytes, bool slow) {
   const void* fn = nullptr;
+  if (fast_wide_coarse(P.minPeriod, P.maxPeriod, P.skip)) {   // the wide-coarse instantiations (SPEC = 2): plan-driven, 4 + 4 or 4 + 0 waves
+#define SPX_FN_WC(C) (slow ? (maxC > 1 ? reinterpret_cast<const void*>(spx_walk_fast_kernel<4, C, 0, 2, 3>) : reinterpret_cast<const void*>(spx_walk_fast_kernel<4, C, 0, 2, 2>)) \
+                           : (maxC > 1 ? reinterpret_cast<const void*>(spx_walk_fast_kernel<4, C, 0, 2, 1>) : reinterpret_cast<const void*>(spx_walk_fast_kernel<4, C, 0, 2, 0>)))
+    fn = nwc >= 4 ? SPX_FN_WC(4) : SPX_FN_WC(0);
+#undef SPX_FN_WC
+    return spx_kernel_vgprs(fn, scratch_bytes);
+  }
   if (slow) {   // the plan-driven instantiations that also serve speeds below 1 (MC + 2)
 #define SPX_FN_SLOW(M, C) (maxC > 1 ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 0, 0, 3>) : reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 0, 0, 2>))
     fn = nwm == 8 ? SPX_FN_SLOW(8, 4) : nwm == 2 ? SPX_FN_SLOW(2, 0) : (nwc >= 4 ? SPX_FN_SLOW(4, 4) : SPX_FN_SLOW(4, 0));
@@ -1526,6 +1553,18 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
   SPX_LAUNCH_FAST(4, 4);
   return;
 #endif
+  if (fast_wide_coarse(P.minPeriod, P.maxPeriod, P.skip)) {
+    // more than 64 coarse lags (11.025 kHz): the wide-coarse instantiations (SPEC = 2), plan-driven, 4 + 4 or 4 + 0 waves
+    // (spx_walk_fast_supports admits four search waves only there)
+#define SPX_LAUNCH_WC(C)                                                                                                  \
+  do {                                                                                                                    \
+    if (slow) { if (maxC > 1) SPX_LAUNCH_FAST_RSM(4, C, 0, 2, 3); else SPX_LAUNCH_FAST_RSM(4, C, 0, 2, 2); }              \
+    else { if (maxC > 1) SPX_LAUNCH_FAST_RSM(4, C, 0, 2, 1); else SPX_LAUNCH_FAST_RSM(4, C, 0, 2, 0); }                   \
+  } while (0)
+    if (nwc >= 4) SPX_LAUNCH_WC(4); else SPX_LAUNCH_WC(0);
+#undef SPX_LAUNCH_WC
+    return;
+  }
   if (slow) {
     // batches with slow-down jobs: the plan-driven instantiations with the insertPitchPeriod event (MC + 2), the forms
     // spx_walk_config picks (4 + 4, 4 + 0, 2 + 0, 8 + 4)

@@ -747,6 +747,32 @@ def test_slow_down_batches_run_on_the_speed_up_kernel(orc, rate, ch):
         assert np.array_equal(got, ref), (i, speeds[i], nls[i], got.size, ref.size)
 
 
+@pytest.mark.parametrize("rate,ch", [(11025, 1), (11025, 2), (9800, 1), (11900, 1), (15000, 1), (15999, 2)])
+def test_rates_with_more_than_64_coarse_lags_run_on_the_speed_up_kernel(orc, rate, ch):
+    """Round 5: the rates whose coarse pitch search has more than 64 lags (about 9.8 - 12 kHz at skip 2 -- 11.025 kHz has 72 -- and
+    14.7 - 16 kHz at skip 3) leave the general walk kernel: two coarse lags per lane in the coarse select (spx_walk_fast.hip WIDEC,
+    SPEC = 2).  Speed-up and slow-down jobs, linear and nonlinear, bit-equal to the oracle; the form that ran is the fast one
+    wherever the coarse triangle fits the search lanes (11.9 kHz: 558 groups of pairs for 512 lane slots -- the general kernel)."""
+    from speedy_amd.batch import Batch, Plan
+    from speedy_amd.synth import speech_like
+    plan = Plan(rate, False)
+    n = int(rate * 1.5)
+    for speeds, nls in (([3.5, 2.0, 1.3, 2.7, 3.5], [1.0, 0.0, 1.0, 0.3, 0.0]), ([0.4, 3.5, 0.8, 1.0, 1.7], [1.0, 1.0, 0.0, 0.0, 1.0])):
+        xs = [speech_like(n + 53 * i, rate, seed=700 + i, channels=ch) for i in range(len(speeds))]
+        b = Batch(plan, [x.size // ch for x in xs], ch, speeds, nls, 0.0)
+        b.upload(xs)
+        b.run()
+        outs = b.results()
+        form = plan.L.spx_debug_last_walk_form()
+        if rate == 11900:
+            assert form == 0
+        else:
+            assert form in (16 * 4 + 4, 16 * 4 + 0), (rate, ch, form)
+        for i, (x, got) in enumerate(zip(xs, outs)):
+            ref = orc.compress_sound(x, rate, ch, speeds[i], nls[i], 0.0, False, chunk=x.size // ch, taps=False)["out"]
+            assert np.array_equal(got, ref), (rate, ch, i, speeds[i], nls[i], got.size, ref.size)
+
+
 def test_register_budgets_of_the_concurrent_mode():
     """The concurrent mode needs two analysis waves beside a stream's walk and tension waves on a SIMD's 512 registers
     (DESIGN.md 2).  Both cases that matter are tight: 16 kHz mono 2 x 96 + tension + 2 x 128, and 22.05 kHz mono with the lean

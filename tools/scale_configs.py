@@ -14,7 +14,7 @@ chunks = int(os.environ.get("SPX_CHUNKS", "0"))  # 0 = the engine's own choice
 only = [int(v) for v in os.environ.get("SPX_ONLY_RATES", "").split(",") if v]
 for rate, ch, speed, nl in [(16000, 1, 3.5, 1.0), (16000, 1, 1.5, 1.0), (22050, 1, 1.5, 1.0), (22050, 1, 3.5, 1.0),
                             (16000, 2, 3.5, 1.0), (22050, 2, 1.5, 1.0), (44100, 1, 3.5, 1.0), (48000, 2, 3.5, 1.0),
-                            (16000, 1, 2.0, 0.0), (16000, 1, 0.5, 1.0), (16000, 1, 0.5, 0.0), (16000, 1, 0.25, 0.0), (22050, 2, 0.8, 1.0)]:
+                            (16000, 1, 2.0, 0.0), (16000, 1, 0.5, 1.0), (16000, 1, 0.5, 0.0), (16000, 1, 0.25, 0.0), (22050, 2, 0.8, 1.0), (11025, 1, 3.5, 1.0), (12000, 1, 3.5, 1.0)]:
     if only and rate not in only:
         continue
     n = 10 * rate
