@@ -547,6 +547,21 @@ __device__ __forceinline__ int fast_writelane_impl(int v, int old, T) { return o
 #define fast_writelane(V, LANE, OLD) ([&] { int o_ = (OLD); const int v_ = uni((int)(V)); \
   asm volatile("v_writelane_b32 %0, %1, " #LANE : "+v"(o_) : "s"(v_)); return o_; }())
 
+// A masked pair of a SAD: both operands ANDed with the mask.  (Round 5 tried ONE v_bfi_b32 in front of the v_sad_u16 instead -- the
+// halves the mask switches off read `a` on both sides, four instructions fewer per coarse group and one per ragged task: bit-equal
+// and 0.2 - 1 % SLOWER in both launch orders, profiles/r05/r5u_bfi_ab.txt: the VOP3 encoding is eight bytes where v_and is four, and
+// the step loop's speed follows its fetch lines more than its instruction count.  -DSPX_SAD_BFI builds it.)
+#ifdef SPX_SAD_BFI
+__device__ __forceinline__ unsigned sad_masked_b(unsigned m, unsigned b, unsigned a) {
+  unsigned r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(b), "v"(a));
+  return r;
+}
+#define SPX_SAD_MASKED(M, A, B, ACC) __builtin_amdgcn_sad_u16((A), sad_masked_b((M), (B), (A)), (ACC))
+#else
+#define SPX_SAD_MASKED(M, A, B, ACC) __builtin_amdgcn_sad_u16((A) & (M), (B) & (M), (ACC))
+#endif
+
 // byte address of the aligned dword holding elements (e, e+1) of a u16 array kept twice, the second copy shifted by one
 // element: base + 2e for even e, (base of the shifted copy - 2) + 2e for odd e;  d2 = shiftedBase - 2 - base
 __device__ __forceinline__ int pair_addr(int base, int d2, int e) { return base + 2 * e + (e & 1) * d2; }
@@ -827,7 +842,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
 #pragma unroll
     for (int k = 0; k < FRG; k++) {
       if (k < nRG) {
-        const unsigned dr = __builtin_amdgcn_sad_u16(ra[k] & rm[k], rb[k] & rm[k], 0u);
+        const unsigned dr = SPX_SAD_MASKED(rm[k], ra[k], rb[k], 0u);
         // an idle lane's zero goes to a word of its own in the spare block behind the two sum buffers (sums + 128 + lane stays
         // inside it from either buffer), not into a sum other lanes add into: same-address atomics of a wave are served in turn
         atomicAdd(&sums[rm[k] ? rt[k] : RIDLE + lane], dr);
@@ -1058,7 +1073,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         if (g < nGC) {
           unsigned d = 0;
 #pragma unroll
-          for (int k = 0; k < 4; k++) d = __builtin_amdgcn_sad_u16(a[g][k] & cMask[g][k], b[g][k] & cMask[g][k], d);
+          for (int k = 0; k < 4; k++) d = SPX_SAD_MASKED(cMask[g][k], a[g][k], b[g][k], d);
           atomicAdd(&sumC[tg * CS + cLag[g]], d);  // (idle lanes: a word of their own, see the dealing)
         }
       }
