@@ -164,6 +164,8 @@ int16_t* spx_pipeline_host_input(spx_pipeline_t p);
  * made and unchanged until the batch's spx_pipeline_wait returns.  Returns the batch's ticket (0, 1, 2 ...) or a negative error.
  * At most `depth` batches are in flight: the call waits for the batch `depth` tickets back first. */
 int64_t spx_pipeline_submit(spx_pipeline_t p, const int16_t* in, int in_is_device);
+/* Blocks until the input handed over with `ticket` may be overwritten: the copy in has finished (host input), the batch's kernels
+ * have finished (device input: they read it to the end).  0, or a negative error (unknown ticket). */
 int spx_pipeline_input_consumed(spx_pipeline_t p, int64_t ticket);
 /* Wait for a batch.  On return
  *   *out      the output samples: pinned HOST memory owned by the pipeline (DEVICE memory with SPX_PIPELINE_DEVICE_OUT)

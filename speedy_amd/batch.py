@@ -386,6 +386,11 @@ class Pipeline:
         self._keep.pop(t - 2 * self.depth, None)
         return t
 
+    def input_consumed(self, ticket):
+        """Blocks until the input handed over with `ticket` may be overwritten (host input: copied in; device input: batch done)."""
+        if self.L.spx_pipeline_input_consumed(self.h, int(ticket)) != 0:
+            raise RuntimeError("spx_pipeline_input_consumed: " + self.L.spx_last_error().decode())
+
     def wait(self, ticket):
         """(out, offsets, counts) of a batch: numpy views of the pipeline's pinned host buffers -- device_out: (data pointer of the
         int16 output in device memory, offsets as a numpy array, data pointer of the int64 counts in device memory)."""

@@ -514,6 +514,10 @@ static int build_streams(const SpxPlanDev& d, const spx_stream_job* jobs, int n,
     for (int c = 0; c < nch; c++) {
       int64_t n_c = j.n_in;
       if (c < nch - 1) n_c = (j.n_in * (c + 1) / nch) / d.B * d.B;
+#ifdef SPX_TUNING
+      static const int frac = [] { const char* e = getenv("SPX_CHUNK_FRAC"); return e ? atoi(e) : 0; }();   // A/B: the first of two chunks, percent
+      if (frac > 0 && nch == 2 && c == 0) n_c = (j.n_in * frac / 100) / d.B * d.B;
+#endif
       SpxStreamDev& s = v[(size_t)c * n + i];
       s.in_off = j.in_off; s.n_in = n_c; s.out_off = j.out_off; s.out_cap = j.out_cap;
       s.channels = j.channels; s.speed = j.speed; s.nonlinear = j.nonlinear; s.feedback = j.feedback;

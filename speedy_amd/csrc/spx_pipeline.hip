@@ -21,7 +21,6 @@
 // per batch against 1.67 - 1.70.  Not kept.
 #include <string.h>
 
-#include <mutex>
 #include <string>
 #include <vector>
 
@@ -105,7 +104,8 @@ struct SpxPipeSlot {
   hipEvent_t ev_in = nullptr;     // the input has arrived in d_in
   hipEvent_t ev_done = nullptr;   // kernels and gather done: the output is in host memory, d_in / d_out may be reused
   int64_t ticket = -1;
-  bool in_recorded = false;
+  bool in_recorded = false;       // ev_in has been recorded at least once (h_in / d_in have a copy to wait for)
+  bool in_host = false;           // this ticket's input came from host memory: consumed once ev_in has passed (device input: ev_done)
 };
 struct spx_pipeline {
   std::vector<spx_plan_t> plans;
@@ -124,7 +124,6 @@ struct spx_pipeline {
   int pack_wgs = 64;
 };
 
-static thread_local std::string g_pipe_err;
 static int pfail(int code, const std::string& msg) { spx_internal_set_error(msg.c_str()); return code; }
 #define PCHK(expr)                                                                             \
   do {                                                                                         \
@@ -307,7 +306,14 @@ int64_t spx_pipeline_submit(spx_pipeline_t p, const int16_t* in, int in_is_devic
                           host_out ? nullptr : S.ev_done, !host_out);
     event_recorded = !host_out;
   }
-  if (rc) return rc;
+  if (rc) {
+    // part of the batch may have been enqueued on this buffer set: nothing of it is handed out, and nothing is left in flight
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+    S.ticket = -1;
+    return rc;
+  }
+  S.in_host = !in_is_device;
   if (host_out) {
     const int n = p->n;
     const int64_t* d_off = p->d_tab;
@@ -336,7 +342,9 @@ static SpxPipeSlot* slot_of(spx_pipeline_t p, int64_t ticket) {
 int spx_pipeline_input_consumed(spx_pipeline_t p, int64_t ticket) {
   SpxPipeSlot* S = slot_of(p, ticket);
   if (!S) return pfail(-1, "spx_pipeline_input_consumed: unknown ticket, or its buffers have been handed to a later batch");
-  if (S->in_recorded) PCHK(hipEventSynchronize(S->ev_in));
+  // host input: the copy in has read it; device input: the kernels read it until the batch is done (the walk kernel copies from it)
+  if (S->in_host) PCHK(hipEventSynchronize(S->ev_in));
+  else PCHK(hipEventSynchronize(S->ev_done));
   return 0;
 }
 int spx_pipeline_wait(spx_pipeline_t p, int64_t ticket, const int16_t** out, const int64_t** offsets, const int64_t** counts) {

@@ -217,3 +217,48 @@ def test_two_pipelines_and_plain_calls_side_by_side(orc):
     for t in td[-4:]:
         assert _crc(pd.results(t)) == w16
     pa.close(); pb.close(); pd.close()
+
+
+def test_input_may_be_overwritten_once_consumed(orc):
+    """spx_pipeline_input_consumed: a HOST input may be overwritten once its copy in has been made, a DEVICE input only once the
+    batch is done (the walk kernel reads it to the end) -- overwriting right behind the call never changes a batch's output, for
+    either kind, with several batches in flight."""
+    import torch
+    from speedy_amd.batch import Pipeline, Plan
+    from speedy_amd.synth import speech_like
+    rate, n = 16000, 24000
+    plan = Plan(rate, False)
+    lens = [n - 100 * i for i in range(40)]
+    xa = [speech_like(l, rate, seed=900 + i) for i, l in enumerate(lens)]
+    xb = [speech_like(l, rate, seed=950 + i) for i, l in enumerate(lens)]
+    pipe = Pipeline(plan, lens, 1, 3.0, 1.0, 0.0, depth=3)
+    ia, ib = pipe.pack(xa), pipe.pack(xb)
+    want = {}
+    for key, inp in (("a", ia), ("b", ib)):
+        want[key] = _crc(pipe.results(pipe.submit(inp)))
+    assert want["a"] != want["b"]
+    # host memory: one buffer, refilled as soon as each batch's input has been consumed
+    buf = ia.copy()
+    seq, tickets = "abbaabab", []
+    for k, key in enumerate(seq):
+        buf[:] = ia if key == "a" else ib
+        t = pipe.submit(buf)
+        pipe.input_consumed(t)
+        buf[:] = 0x5555                       # garbage behind the copy
+        tickets.append(t)
+        if k >= 2:
+            assert _crc(pipe.results(tickets[k - 2])) == want[seq[k - 2]], k
+    # device memory: the same with a device buffer; consumed = the batch is done
+    dbuf = torch.empty(pipe.total_in, dtype=torch.int16, device="cuda")
+    da, db = torch.from_numpy(ia).cuda(), torch.from_numpy(ib).cuda()
+    for key in "abba":
+        dbuf.copy_(da if key == "a" else db)
+        torch.cuda.synchronize()
+        t = pipe.submit(dbuf)
+        pipe.input_consumed(t)
+        dbuf.fill_(0x5555)
+        torch.cuda.synchronize()
+        assert _crc(pipe.results(t)) == want[key], key
+    with pytest.raises(RuntimeError):
+        pipe.input_consumed(10 ** 6)
+    pipe.close()
