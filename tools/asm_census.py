@@ -1,7 +1,9 @@
 """Static census of one kernel's ISA: instructions per basic block by unit (VALU / SALU / LDS / VMEM, fp64 among the VALU), with
 the loop nesting the compiler's comments give.  Input: the .s file of `hipcc --save-temps` (make resource-usage leaves none; see
 tools/README in DESIGN.md 5.1) and a substring of the mangled kernel name.
-Usage: python tools/asm_census.py FILE.s NAME_SUBSTRING [MIN_INSTRUCTIONS]"""
+Usage: python tools/asm_census.py FILE.s NAME_SUBSTRING [MIN_INSTRUCTIONS]
+       python tools/asm_census.py FILE.s NAME_SUBSTRING --scratch     (only the blocks that hold scratch instructions, with what
+                                                                       the blocks in front of them branch on)"""
 import re
 import sys
 
@@ -45,8 +47,29 @@ def census(path, sub, nmin=12):
     return f, order, stats
 
 
+def scratch_blocks(f, order, stats):
+    blk = 'entry'
+    out = {}
+    for l in f:
+        m = re.match(r'^(\.LBB\d+_\d+):', l)
+        if m:
+            blk = m.group(1)
+            continue
+        if 'scratch_' in l:
+            out.setdefault(blk, []).append(l.strip().split(';')[0].strip())
+    return out
+
+
 if __name__ == "__main__":
     f, order, stats = census(sys.argv[1], sys.argv[2])
+    if "--scratch" in sys.argv:
+        sb = scratch_blocks(f, order, stats)
+        tot = sum(len(v) for v in sb.values())
+        print("%s: %d scratch instructions in %d of %d blocks" % (sys.argv[2], tot, len(sb), len(order)))
+        for b in order:
+            if b in sb:
+                print("  %-12s %2d of %4d instructions  %s" % (b, len(sb[b]), stats[b]['n'], stats[b]['hdr'][:100]))
+        raise SystemExit(0)
     nmin = int(sys.argv[3]) if len(sys.argv) > 3 else 12
     tot = dict(n=0, valu=0, salu=0, lds=0, vmem=0, f64=0)
     for b in order:
