@@ -484,13 +484,36 @@ __device__ __forceinline__ double uniform_f64(double v) {  // a wave-uniform dou
 
 // packed point n of frame j: z[n] = v[2n] + i v[2n+1], v = pre-emphasised samples times the window (speedy.c:416-425,
 // :442); fr = the frame's first mono sample in the staged span, w0 / w1 = window[2n], window[2n+1]
+// One windowed, pre-emphasised sample as the transform takes it (speedy.c:553-565, 416-425, 442):
+//   x = (float)(m / 32768.0), xp likewise;  y = (float)(1.0 (double)x - 0.97 (double)xp);  v = (double)(y * w)
+// from the int16 samples m, mp THEMSELVES (round 5).  x = m 2^-15 exactly (sixteen bits in a float), and every operation behind it
+// commutes with that power-of-two factor as long as nothing is subnormal -- RN(0.97 (mp 2^-15)) = RN(0.97 mp) 2^-15, the
+// difference and its rounding to float likewise, RN32((yy 2^-15) w) = RN32(yy (w 2^-15)) -- and nothing is: a nonzero m - 0.97 mp
+// is at least ~0.01 in magnitude, the Hamming window at least 0.08.  So the scale moves into the window value (w15 = w 2^-15, once
+// per lane) and the three value-preserving conversions per sample (double -> float -> double of x, and the scaling itself) go:
+// 44 -> 26 instructions for the four samples of a lane in the 16 kHz kernel.  Bit-identical, the spec (oracle) is untouched.
+// md, mpd: (double)m, (double)mp.  -DSPX_PREEMPH_V1: the literal sequence.
+#ifdef SPX_PREEMPH_V1
+#define SPX_WIN_SCALE 1.0f
+__device__ __forceinline__ float spx_preemph_win_f32(double md, double mpd, float w) {
+  const float x = (float)(md / 32768.0), xp = (float)(mpd / 32768.0);
+  const float y = (float)(1.0 * (double)x - 0.97 * (double)xp);
+  return y * w;
+}
+#else
+#define SPX_WIN_SCALE 0x1p-15f
+__device__ __forceinline__ float spx_preemph_win_f32(double md, double mpd, float w15) {
+  const float yy = (float)(md - 0.97 * mpd);
+  return yy * w15;
+}
+#endif
+__device__ __forceinline__ double spx_preemph_win(double md, double mpd, float w) { return (double)spx_preemph_win_f32(md, mpd, w); }
 __device__ __forceinline__ cplx packed_point(const short* fr, int n, int j, int prev0, float w0, float w1) {
   const int i0 = 2 * n;
   const int m0 = fr[i0], m1 = fr[i0 + 1];
   const int mp0 = (i0 > 0) ? (int)fr[i0 - 1] : ((j > 0) ? (int)fr[prev0] : 0);
-  const float x0 = (float)(m0 / 32768.0), x1 = (float)(m1 / 32768.0), xp0 = (float)(mp0 / 32768.0);
-  const float y0 = (float)(1.0 * (double)x0 - 0.97 * (double)xp0), y1 = (float)(1.0 * (double)x1 - 0.97 * (double)x0);
-  return {(double)(y0 * w0), (double)(y1 * w1)};
+  const double d0 = (double)m0;
+  return {spx_preemph_win(d0, (double)mp0, w0 * SPX_WIN_SCALE), spx_preemph_win((double)m1, d0, w1 * SPX_WIN_SCALE)};
 }
 
 // WCT != 0: the kernel is compiled for that window size (16 kHz: W = 240 = 4*4*3*5) -- see the phase-1 comment.
@@ -586,6 +609,8 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
 #pragma unroll
     for (int u = 0; u < 4; u++) { const int k = lane + 64 * u; wu[u] = tw2p[k < 240 ? k : 0]; }
     wn[0] = P.window[2 * bb]; wn[1] = P.window[2 * bb + 1]; wn[2] = P.window[2 * bb + 120]; wn[3] = P.window[2 * bb + 121];
+#pragma unroll
+    for (int k = 0; k < 4; k++) wn[k] *= SPX_WIN_SCALE;   // (spx_preemph_win: the samples' 2^-15 lives in the window value)
     for (int s = wave; s <= TF; s += 4) {
       const int j = j0 - 1 + s;
       float* mrow = mags + (size_t)s * MS;
@@ -601,11 +626,9 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
         const int m0 = fr[i0], m1 = fr[i0 + 1], m2 = fr[i1], m3 = fr[i1 + 1];
         const int mp0 = (i0 > 0) ? (int)fr[i0 - 1] : ((j > 0) ? (int)fr[(240 - B) - 1] : 0);
         const int mp2 = fr[i1 - 1];
-        const float x0 = (float)(m0 / 32768.0), x1 = (float)(m1 / 32768.0), x2 = (float)(m2 / 32768.0),
-                    x3 = (float)(m3 / 32768.0), xp0 = (float)(mp0 / 32768.0), xp2 = (float)(mp2 / 32768.0);
-        const float y0 = (float)(1.0 * (double)x0 - 0.97 * (double)xp0), y1 = (float)(1.0 * (double)x1 - 0.97 * (double)x0);
-        const float y2 = (float)(1.0 * (double)x2 - 0.97 * (double)xp2), y3 = (float)(1.0 * (double)x3 - 0.97 * (double)x2);
-        const cplx a0 = {(double)(y0 * wn[0]), (double)(y1 * wn[1])}, a1 = {(double)(y2 * wn[2]), (double)(y3 * wn[3])};
+        const double d0 = (double)m0, d2 = (double)m2;
+        const cplx a0 = {spx_preemph_win(d0, (double)mp0, wn[0]), spx_preemph_win((double)m1, d0, wn[1])},
+                   a1 = {spx_preemph_win(d2, (double)mp2, wn[2]), spx_preemph_win((double)m3, d2, wn[3])};
         const cplx b0 = {a0.r + a1.r, a0.i + a1.i}, b2 = {a0.r - a1.r, a0.i - a1.i};
         const cplx b1 = {a0.r + a1.i, a0.i - a1.r}, b3 = {a0.r - a1.i, a0.i + a1.r};
         st(bufA, 4 * b, b0);
@@ -714,7 +737,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
     for (int u = 0; u < 3; u++) {
       const int b1 = (lane + 64 * u < 165) ? lane + 64 * u : 0;
       w1[u] = twp[b1];
-      wn[u][0] = P.window[2 * b1]; wn[u][1] = P.window[2 * b1 + 1];
+      wn[u][0] = P.window[2 * b1] * SPX_WIN_SCALE; wn[u][1] = P.window[2 * b1 + 1] * SPX_WIN_SCALE;   // (spx_preemph_win)
     }
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -749,9 +772,8 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
           const int i0 = 2 * b;
           const int m0 = fr[i0], m1 = fr[i0 + 1];
           const int mp0 = (i0 > 0) ? (int)fr[i0 - 1] : ((j > 0) ? (int)fr[(330 - B) - 1] : 0);
-          const float x0 = (float)(m0 / 32768.0), x1 = (float)(m1 / 32768.0), xp0 = (float)(mp0 / 32768.0);
-          const float y0 = (float)(1.0 * (double)x0 - 0.97 * (double)xp0), y1 = (float)(1.0 * (double)x1 - 0.97 * (double)x0);
-          const cplx a0 = {(double)(y0 * wn[u][0]), (double)(y1 * wn[u][1])};
+          const double d0 = (double)m0;
+          const cplx a0 = {spx_preemph_win(d0, (double)mp0, wn[u][0]), spx_preemph_win((double)m1, d0, wn[u][1])};
           st(bufA, 2 * b, a0);
           st(bufA, 2 * b + 1, cmul_tw(a0, w1[u]));
         }
@@ -972,9 +994,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
         if (i < 661) {
           const int m = fr[i];
           const int mp = (i > 0) ? (int)fr[i - 1] : ((j > 0) ? (int)fr[prev0] : 0);
-          const float x = (float)(m / 32768.0), xp = (float)(mp / 32768.0);
-          const float y = (float)(1.0 * (double)x - 0.97 * (double)xp);      // speedy.c:422
-          vf[i] = y * winq[i];                                               // speedy.c:442 / :462
+          vf[i] = spx_preemph_win_f32((double)m, (double)mp, winq[i] * SPX_WIN_SCALE);   // speedy.c:422, :442 / :462
         }
       }
       if (lane == 0) vf[661] = 0.0f;   // the imaginary half of point 330 is padding
