@@ -1,5 +1,6 @@
 """configs[4] as ONE spx_batch_run_mixed call of N streams (default 2048: `config4_full`), a few steps -- for a kernel trace:
-   rocprofv3 --kernel-trace --output-format csv -d DIR -o c4 -- python3 tools/c4_trace.py [N] [steps]
+   rocprofv3 --kernel-trace --output-format csv -d DIR -o c4 -- python3 tools/c4_trace.py [N] [steps] [ahead]
+   (ahead: two batches taking turns through spx_batch_run_mixed_ahead, the bench's `config4_shard` loop at N = 256)
    python3 tools/trace_summary.py DIR/.../c4_kernel_trace.csv"""
 import os
 import sys
@@ -17,12 +18,17 @@ ids = list(range(n))
 streams = C4.make_streams(ids, threads=8)
 plans = [Plan(r, False) for r in C4.RATES]
 b = C4.mixed_batch(plans, ids, streams)
-for _ in range(4):
-    b.run()
-    torch.cuda.synchronize()
+ahead = len(sys.argv) > 3 and sys.argv[3] == "ahead"
+turn = [b, C4.mixed_batch(plans, ids, streams)] if ahead else [b]
+run = (lambda k: turn[k % 2].run_ahead()) if ahead else (lambda k: b.run())
+for k in range(4):
+    run(k)
+    if not ahead:
+        torch.cuda.synchronize()
+torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(steps):
-    b.run()
+for k in range(steps):
+    run(k)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print("config4 x %d streams, one mixed call: %.3f ms per step, %.0f Msamples/s" % (n, dt * 1e3, C4.input_frames(ids) / dt / 1e6))
+print("config4 x %d streams, one mixed call%s: %.3f ms per step, %.0f Msamples/s" % (n, " (pipelined)" if ahead else "", dt * 1e3, C4.input_frames(ids) / dt / 1e6))
