@@ -96,6 +96,7 @@ struct SpxPool {
   std::vector<int64_t> res_off, res_cap;
   std::vector<void*> blocks[48];           // device block cache by log2(bytes)
   double t_prep = 0, t_tab = 0, t_launch = 0, t_wait = 0, t_post = 0;   // SPX_POOL_TIMES=1: host seconds per phase
+  double t_l[5] = {0, 0, 0, 0, 0};   // ... and per launch of a one-group round: stage, analysis, tension, walk, gather
 };
 
 static SpxPool* g_pools[64];
@@ -480,19 +481,26 @@ static bool pool_run(SpxPool* P) {
   hipLaunchKernelGGL(spx_pool_stage_kernel, dim3(grid), dim3(256), 0, P->hs, reinterpret_cast<const unsigned*>(hA),
                      reinterpret_cast<unsigned*>(dA), n_words, hD, dStates, (unsigned)n, hC, (unsigned)copies.size(), P->hIn.p,
                      hM, (unsigned)moves.size());
+  auto tl = std::chrono::steady_clock::now();
+  auto lap = [&](int k) { const auto t = std::chrono::steady_clock::now(); P->t_l[k] += std::chrono::duration<double>(t - tl).count(); tl = t; };
+  lap(0);
   const SpxTapsDev no_taps = {nullptr, nullptr, nullptr, nullptr, nullptr};
   for (const Group& g : groups) {
     const SpxPlanDev& PL = *items[g.i0].s->plan;
     const int ng = (int)(g.i1 - g.i0);
     if (g.tiles > 0) spx_launch_analysis(PL, dA + g.i0, ng, g.tiles, nullptr, P->aRec, no_taps, nullptr, nullptr, P->hs);
+    lap(1);
     bool any_nl = false;
     for (size_t i = g.i0; i < g.i1; i++) any_nl = any_nl || items[i].J.nonlinear;
     if (any_nl) spx_launch_tension(PL, dA + g.i0, ng, dStates + g.i0, P->aRec, P->aScr, no_taps, nullptr, nullptr, P->hs);
+    lap(2);
     spx_launch_walk(PL, dW + g.i0, ng, g.maxC, nullptr, nullptr, dNout + g.i0, dStates + g.i0, P->aScr, nullptr,
                     items[g.i0].J.speedupKernel, P->hs, /*short_jobs=*/true);
+    lap(3);
   }
   const unsigned gy = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, (max_slice + 8191) / 8192));
   hipLaunchKernelGGL(spx_pool_gather_kernel, dim3((unsigned)n, gy), dim3(256), 0, P->hs, hD, dStates, dNout, hR, hOut);
+  lap(4);
   const hipError_t le = hipGetLastError();
   const auto tp3 = std::chrono::steady_clock::now();
   // The run is a few tens of microseconds of GPU work: waiting for it in the runtime's blocking way costs about as much
@@ -683,5 +691,8 @@ void speedyHipPoolStats(unsigned long long* runs, unsigned long long* jobs) {
     fprintf(stderr, "[spx pool] %llu runs, host us per run: prepare %.1f, tables %.1f, launches %.1f, wait %.1f, post %.1f\n", P->runs,
             1e6 * P->t_prep / P->runs, 1e6 * P->t_tab / P->runs, 1e6 * P->t_launch / P->runs, 1e6 * P->t_wait / P->runs,
             1e6 * P->t_post / P->runs);
+  if (P && getenv("SPX_POOL_TIMES") && P->runs)
+    fprintf(stderr, "[spx pool]   launches: stage %.1f, analysis %.1f, tension %.1f, walk %.1f, gather %.1f us\n", 1e6 * P->t_l[0] / P->runs,
+            1e6 * P->t_l[1] / P->runs, 1e6 * P->t_l[2] / P->runs, 1e6 * P->t_l[3] / P->runs, 1e6 * P->t_l[4] / P->runs);
 }
 }
