@@ -255,6 +255,10 @@ int spx_debug_mode_resources(int sample_rate, int channels, int n_streams, int s
  * `denominators` random speeds (speed - 1 log-uniform in [2^exp_lo, 2^exp_hi)) x every count 1 .. 4096 x both numerator forms;
  * returns the number of mismatches (0 is the only acceptable answer), -1 on a runtime error. */
 long long spx_debug_fdiv_check(unsigned seed, unsigned denominators, int exp_lo, int exp_hi);
+/* The cross-fade's quotient (spx_walk_fast.hip xfade_quot: reciprocal by Newton steps, fused multiply-add, truncating conversion)
+ * against the integer division, for every n in [n_lo, n_hi] (1 .. 4096) and every numerator k n + {-1, 0, 1}, |k| <= 32768.
+ * Returns the number of mismatches, -1 on a bad range or a runtime error. */
+long long spx_debug_xfade_check(int n_lo, int n_hi);
 /* The same for the analysis kernel's scale-free fp32 / fp64 divisions and its fp64 square root (spx_log.h): `threads` x
  * `per_thread` pseudo-random operands of the ranges the kernel feeds them; the number of results that differ from the IEEE
  * sequences' (0 is the only acceptable answer), -1 on a runtime error. */

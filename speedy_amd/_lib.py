@@ -73,6 +73,7 @@ SYMBOLS = {
     "spx_debug_kernel_vgprs": (C.c_int, [C.c_int]),
     "spx_debug_last_call_concurrent": (C.c_int, []),
     "spx_debug_fdiv_check": (C.c_longlong, [C.c_uint, C.c_uint, C.c_int, C.c_int]),
+    "spx_debug_xfade_check": (C.c_longlong, [C.c_int, C.c_int]),
     "spx_debug_arith_check": (C.c_longlong, [C.c_uint, C.c_uint, C.c_uint]),
     "spx_debug_log_check": (C.c_int, [C.c_uint, C.c_uint, C.POINTER(C.c_ulonglong)]),
     "spx_debug_walk_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),

@@ -185,30 +185,111 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// The cross-fade's quotient num / n, truncated toward zero (libsonic overlapAdd), for |num| <= 32768 n, n <= 4096:
+//   q = (int)fma((double)num, inv, copysign(2^-20, num)),   inv = 1 / n to within 2^-40 relative
+// Exact: a non-integer quotient is at least 1/n >= 2^-12 away from the next integer towards which the 2^-20 pushes, an integer one
+// lands 2^-20 on the far side of itself, and the error of the product is below 2^27 2^-12 2^-40 = 2^-25.  So the reciprocal needs
+// no IEEE division (round 5: v_rcp_f64 and two Newton steps -- five instructions for the compiler's twelve; in the lean form they
+// are on the chain, once per step), the sign needs no absolute value / negate pair (the conversion truncates toward zero by
+// itself), and the numerator d (n - t) + u t is two 24-bit multiplications (|d|, |u| <= 2^15, n <= 2^12).  Checked against the
+// integer division for every n and every num = k n + {-1, 0, 1}: spx_debug_xfade_check (tests/test_gpu_parity.py).
+// -DSPX_XFADE_V1: the round-1 sequence.
+__device__ __forceinline__ double xfade_rcp(int n) {
+#ifdef SPX_XFADE_V1
+  return 1.0 / (double)n;
+#else
+  const double nd = (double)n;
+  double r = __builtin_amdgcn_rcp(nd);
+  r = __builtin_fma(__builtin_fma(-nd, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-nd, r, 1.0), r, r);
+  return r;
+#endif
+}
+__device__ __forceinline__ int xfade_num(int d, int nt, int u, int t) {
+#ifdef SPX_XFADE_V1
+  return d * nt + u * t;
+#else
+  return __mul24(d, nt) + __mul24(u, t);
+#endif
+}
+// ... from the window's BIASED samples D = d + 32768, U = u + 32768 (what the LDS window holds): d (n - t) + u t =
+// D (n - t) + U t - 32768 n -- two unsigned 24-bit multiplications on the values as they are read and one subtraction of a
+// wave-uniform constant, instead of two bias subtractions and two signed multiplications
+__device__ __forceinline__ int xfade_num_biased(unsigned D, int nt, unsigned U, int t, int n) {
+#ifdef SPX_XFADE_V1
+  return ((int)D - 32768) * nt + ((int)U - 32768) * t;
+#else
+  return (int)(__umul24(D, (unsigned)nt) + __umul24(U, (unsigned)t)) - (n << 15);
+#endif
+}
+__device__ __forceinline__ int xfade_quot(int num, double inv) {
+#ifdef SPX_XFADE_V1
+  const int mag = num < 0 ? -num : num;
+  const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
+  return num < 0 ? -qm : qm;
+#else
+  const double x = (double)num;
+  return (int)__builtin_fma(x, inv, __builtin_copysign(9.5367431640625e-07, x));
+#endif
+}
+__global__ void spx_xfade_check_kernel(int n_lo, int n_hi, unsigned* mismatches) {
+  // block = one n; threads stride over k = -32768 .. 32768, num = k n + {-1, 0, 1} clipped to |num| <= 32768 n
+  const int n = n_lo + (int)blockIdx.x;
+  if (n > n_hi) return;
+  const double inv = xfade_rcp(n);
+  const long long lim = 32768ll * n;
+  unsigned bad = 0;
+  for (int k = -32768 + (int)threadIdx.x; k <= 32768; k += (int)blockDim.x)
+    for (int e = -1; e <= 1; e++) {
+      const long long v = (long long)k * n + e;
+      if (v < -lim || v > lim) continue;
+      const int num = (int)v;
+      bad += (xfade_quot(num, inv) != num / n);
+    }
+  // the numerator's two forms on a few operands per thread
+  for (int t = (int)threadIdx.x; t <= n; t += (int)blockDim.x) {
+    const int d = 32767 - ((17 * t) & 0xffff), u = -32768 + ((23 * t + 7 * n) & 0xffff);   // both over the whole int16 range
+    bad += (xfade_num(d, n - t, u, t) != d * (n - t) + u * t);
+    bad += (xfade_num_biased((unsigned)(d + 32768), n - t, (unsigned)(u + 32768), t, n) != d * (n - t) + u * t);
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+extern "C" long long spx_debug_xfade_check(int n_lo, int n_hi) {
+  if (n_lo < 1 || n_hi > 4096 || n_hi < n_lo) return -1;
+  unsigned* d = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(unsigned)) != hipSuccess) return -1;
+  (void)hipMemset(d, 0, sizeof(unsigned));
+  hipLaunchKernelGGL(spx_xfade_check_kernel, dim3(n_hi - n_lo + 1), dim3(256), 0, nullptr, n_lo, n_hi, d);
+  unsigned h = 0;
+  const hipError_t e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  return e == hipSuccess ? (long long)h : -1;
+}
+
 // Every output sample of the stream is produced here: by the NWC output waves on command, or -- NWC == 0 -- by the search
 // waves themselves.  `t0` = index of this thread among the NTO threads doing output work.
 //   cross-fade (libsonic overlapAdd): out[t] = (down[t]*(n-t) + up[t]*t)/n, integer, truncating toward zero; both runs
-//     lie in the LDS window.  |numerator| <= 32768*n < 2^31; the quotient is trunc(|num| * (1/n) + 2^-20) in double,
-//     exact: non-integer quotients are at least 1/n >= 2^-11 below the next integer, integer ones land 2^-20 above.
+//     lie in the LDS window.  The quotient: xfade_quot above.
 //   copy: n frames from absolute input position src (straight from HBM, coalesced; beyond `limit` = flush padding = 0).
 template <int NTO, bool MC>
 __device__ __forceinline__ void fast_outputs(const FastOut& X, int t0, int xf_n, int xf_down, int xf_period, pos_t xf_out,
                                              int cp_n, pos_t cp_src, pos_t cp_out, pos_t limit, pos_t wbase) {
   const int C = MC ? X.C : 1;  // MC = false: the mono-only instantiation (no channel arithmetic at all)
   if (xf_n > 0) {
-    const double inv = 1.0 / (double)xf_n;
+    const double inv = xfade_rcp(xf_n);
     pos_t room = X.out_cap - xf_out;
     const int nv = room > xf_n ? xf_n : (room < 0 ? 0 : (int)room);
     if (C == 1) {
       int16_t* __restrict__ dst = X.out + (size_t)xf_out;
       const unsigned short* wd = reinterpret_cast<const unsigned short*>(X.lds + X.offA0) + xf_down;
       const unsigned short* wu = wd + xf_period;
+      // (a handful of iterations at most -- n <= maxPeriod < 1024 -- so no interleaved copy of the loop: it costs the forms that do
+      // their own output work registers, and every form code)
+#ifndef SPX_XFADE_V1
+#pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
+#endif
       for (int t = t0; t < nv; t += NTO) {
-        const int d = (int)wd[t] - 32768, u = (int)wu[t] - 32768;
-        const int num = d * (xf_n - t) + u * t;
-        const int mag = num < 0 ? -num : num;
-        const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
-        dst[t] = (int16_t)(num < 0 ? -qm : qm);
+        dst[t] = (int16_t)xfade_quot(xfade_num_biased(wd[t], xf_n - t, wu[t], t, xf_n), inv);
       }
     } else {
       // several channels: the window holds the channel mean only; the two ramps come from the input itself (these waves
@@ -220,13 +301,13 @@ __device__ __forceinline__ void fast_outputs(const FastOut& X, int t0, int xf_n,
       const int total = nv * C;
       const unsigned invC = (0x10000u + (unsigned)C - 1u) / (unsigned)C;  // e / C for e < 8192, C <= 8
       const int realD = (int)((limit - ad) * C), realU = (int)((limit - au) * C);  // elements of real input (may be <= 0)
+#ifndef SPX_XFADE_V1
+#pragma clang loop unroll(disable) interleave(disable) vectorize(disable)
+#endif
       for (int e = t0; e < total; e += NTO) {
         const int t = (C == 2) ? (e >> 1) : (int)(((unsigned)e * invC) >> 16);
         const int d = (e < realD) ? (int)rd[e] : 0, u = (e < realU) ? (int)ru[e] : 0;
-        const int num = d * (xf_n - t) + u * t;
-        const int mag = num < 0 ? -num : num;
-        const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
-        dst[e] = (int16_t)(num < 0 ? -qm : qm);
+        dst[e] = (int16_t)xfade_quot(xfade_num(d, xf_n - t, u, t), inv);
       }
     }
   }
@@ -856,6 +937,12 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     if constexpr (NWC > 0) {
       int seq = 0;
       int nsteps = 0;  // step commands seen = pitch searches of this job: counted HERE, off the chain (SpxWalkState::steps)
+      // this thread's index among the output threads, formed HERE: hoisted into the kernel's prologue the compiler once kept it in
+      // scratch (the 96-register forms), reloaded it in front of this loop, and the reload's s_waitcnt vmcnt(0) -- placed at the first
+      // use, inside the loop -- made every command wait for the previous command's STORES as well: the plain call's walk kernel
+      // 1.70 -> 1.80 ms (round 5, profiles/r05/r5ac_variant_times.txt)
+      int t0o = tid - 64 * NWM;
+      asm volatile("" : "+v"(t0o));
       pos_t wb = -1, lim = (pos_t)(S.n_in + S.tsm_shift);  // window base / input limit as the commands have announced them
       for (;;) {
         fast_sync();  // the barrier that follows every published command
@@ -867,7 +954,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         const pos_t nb = uni(c[9]);
         if (type != FCMD_STEP) lim = uni(c[8]);  // a step command carries fields 0..4 only
 #ifndef SPX_EXP_NO_OUTPUT   // (diagnostic builds: the output waves only take part in the barriers -- WRONG audio, same chain)
-        fast_outputs<64 * NWC, MCH>(X, tid - 64 * NWM, xf_n, xf_down, xf_period, xf_out, type == FCMD_STEP ? 0 : cp_n, cp_src,
+        fast_outputs<64 * NWC, MCH>(X, t0o, xf_n, xf_down, xf_period, xf_out, type == FCMD_STEP ? 0 : cp_n, cp_src,
                                cp_out, lim, wb);
 #endif
         if (type == FCMD_STEP) {

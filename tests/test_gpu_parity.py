@@ -853,6 +853,16 @@ def test_committed_kernel_resources_are_the_librarys():
                                              for k, v in got["shapes"].items() if v != want["shapes"].get(k)}
 
 
+def test_cross_fade_quotient_equals_the_integer_division():
+    """The walk kernels' cross-fade divides d (n - t) + u t by n, truncating toward zero (libsonic overlapAdd).  Round 5 forms the
+    quotient with a Newton reciprocal, one fused multiply-add with a signed 2^-20 and the truncating conversion -- in the lean walk
+    form these instructions are on the chain.  Against the integer division for EVERY n up to 4096 and every numerator k n - 1,
+    k n, k n + 1 with |k| <= 32768 (the cases a rounding error could flip), and the 24-bit numerator against the 32-bit one."""
+    from speedy_amd._lib import lib
+    assert lib().spx_debug_xfade_check(1, 4096) == 0
+    assert lib().spx_debug_xfade_check(0, 10) == -1
+
+
 def test_fast_division_equals_the_ieee_quotient():
     """The walk kernel forms the candidate step lengths n = (int)(period / (speed - 1)) with a per-event reciprocal and two
     correction rounds -- the IEEE division sequence without its scaling and fix-up halves, which are no-ops for these operands
