@@ -985,6 +985,9 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   }
   if (!ahead && opt.in_ready) HIPCHK(hipStreamWaitEvent(st, static_cast<hipEvent_t>(opt.in_ready), 0));
   hipEvent_t staged_ev = nullptr;
+  // (Round 5 tried staging a DETACHED call's tables on its own, otherwise empty, run stream -- beside the previous call's producers
+  // instead of in front of this call's on the producers' stream: 1.045 against 0.94 ms per step.  A stream that holds nothing but
+  // waits and one small kernel is exactly the "blocked barrier packets" case of INTEGRATION.md's hardware-queue section.)
   rc = stage_tables(plan, sv, order, dstreams, d_order, d_flags, concurrent ? (unsigned)tiles[0] : 0u, d_ready,
                     (concurrent || ahead) ? (unsigned)n + 1u : 0u, ahead ? sa : st, &staged_ev);
   if (rc) return rc;
