@@ -558,12 +558,21 @@ __global__ void spx_gate_kernel(const int* started, int n_walk, unsigned max_spi
 // Job tables (and tile order) from the plan's pinned staging slot into the workspace, hand-off flags cleared.
 __global__ void __launch_bounds__(256)
 spx_stage_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst_a, unsigned n_a, unsigned* __restrict__ dst_b,
-                 unsigned n_b, unsigned* __restrict__ zero_a, unsigned nz_a, unsigned* __restrict__ zero_b, unsigned nz_b) {
+                 unsigned n_b, unsigned* __restrict__ zero_a, unsigned nz_a, unsigned* __restrict__ zero_b, unsigned nz_b,
+                 const int* gate_started, int gate_n, unsigned gate_spins) {
   const unsigned stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
   for (unsigned i = t0; i < n_a; i += stride) dst_a[i] = src[i];
   for (unsigned i = t0; i < n_b; i += stride) dst_b[i] = src[n_a + i];
   for (unsigned i = t0; i < nz_a; i += stride) zero_a[i] = 0u;
   for (unsigned i = t0; i < nz_b; i += stride) zero_b[i] = 0u;
+  // ... and, for a pipelined call, the gate of spx_gate_kernel in the same launch (one kernel and one dispatch less on the
+  // producers' stream, whose chain is as long as the walk streams' period since round 5): the counter is the PREVIOUS call's
+  if (gate_started != nullptr && t0 == 0) {
+    for (unsigned i = 0; i < gate_spins; i++) {
+      if (__hip_atomic_load(gate_started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gate_n) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
 }
 extern "C" {
 
@@ -762,7 +771,8 @@ extern "C" int spx_debug_mode_resources(int sample_rate, int channels, int n_str
 // hand-off flags: a single stream operation where two copies and two fills (each its own DMA packet with barriers around it)
 // cost the concurrent mode 0.13 ms a call.  *done: the slot's event, recorded behind the kernel.
 static int stage_tables(spx_plan* plan, const std::vector<SpxStreamDev>& sv, const std::vector<int>& order, SpxStreamDev* dstreams,
-                        int* d_order, int* d_flags, unsigned n_flags, int* d_ready, unsigned n_ready, hipStream_t on, hipEvent_t* done) {
+                        int* d_order, int* d_flags, unsigned n_flags, int* d_ready, unsigned n_ready, hipStream_t on, hipEvent_t* done,
+                        const int* gate_started = nullptr, int gate_n = 0, unsigned gate_spins = 0) {
   const size_t b_sv = sizeof(SpxStreamDev) * sv.size(), b_or = sizeof(int) * order.size();
   SpxStage& G = plan->stage[plan->stage_next];
   plan->stage_next ^= 1;
@@ -780,7 +790,7 @@ static int stage_tables(spx_plan* plan, const std::vector<SpxStreamDev>& sv, con
   if (b_or) memcpy(hp + b_sv, order.data(), b_or);
   hipLaunchKernelGGL(spx_stage_kernel, dim3(64), dim3(256), 0, on, reinterpret_cast<const unsigned*>(hp),
                      reinterpret_cast<unsigned*>(dstreams), (unsigned)(b_sv / 4), reinterpret_cast<unsigned*>(d_order), (unsigned)(b_or / 4),
-                     reinterpret_cast<unsigned*>(d_flags), n_flags, reinterpret_cast<unsigned*>(d_ready), n_ready);
+                     reinterpret_cast<unsigned*>(d_flags), n_flags, reinterpret_cast<unsigned*>(d_ready), n_ready, gate_started, gate_n, gate_spins);
   HIPCHK(hipEventRecord(G.done, on));
   *done = G.done;
   return 0;
@@ -988,8 +998,22 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // (Round 5 tried staging a DETACHED call's tables on its own, otherwise empty, run stream -- beside the previous call's producers
   // instead of in front of this call's on the producers' stream: 1.045 against 0.94 ms per step.  A stream that holds nothing but
   // waits and one small kernel is exactly the "blocked barrier packets" case of INTEGRATION.md's hardware-queue section.)
+  static const bool no_gate = spx_tuning_env("SPX_NO_GATE") != nullptr;  // A/B only
+  static const bool split_gate = spx_tuning_env("SPX_SPLIT_GATE") != nullptr;  // A/B only: the pipelined call's gate as a kernel of its own
+  // AHEAD: the analysis must not fill the CUs before the PREVIOUS call's walk workgroups have been placed one per CU (its walk
+  // kernel becomes runnable at the same moment as this analysis: when the walk before it retires) -- only while that call is
+  // still in flight (then its workspace, where the counter lives, is alive by the usual contract), and not when the producers
+  // wait for that very call anyway (a caller handing the same workspace over again: the counter is THIS workspace's, this
+  // call's staging kernel has just cleared it, and the gate would spin its full bound for a count nobody raises -- round 4:
+  // 3.6 ms per call where a plain call takes 1.6).  A longer bound than the idle-start gate's: the previous walk kernel may
+  // itself be waiting for something of the caller's (an output buffer still being copied out), and a gate that gives up early
+  // lets this call's analysis fill the CUs first, which costs the previous call half its speed; ~2 ms.  The gate runs at the end of
+  // the staging kernel (same stream, nothing in between).
+  const bool ahead_gate = ahead && !force && plan->ahead_started != nullptr && plan->ahead_n > 0 && !no_gate && !waited_prev &&
+                          ring_previous_in_flight(plan);
   rc = stage_tables(plan, sv, order, dstreams, d_order, d_flags, concurrent ? (unsigned)tiles[0] : 0u, d_ready,
-                    (concurrent || ahead) ? (unsigned)n + 1u : 0u, ahead ? sa : st, &staged_ev);
+                    (concurrent || ahead) ? (unsigned)n + 1u : 0u, ahead ? sa : st, &staged_ev,
+                    (ahead_gate && !split_gate) ? plan->ahead_started : nullptr, plan->ahead_n, 8000u);
   if (rc) return rc;
   if (M.trial_slot >= 0) {  // bracket this call on the caller's stream (spx_plan::Trial)
     hipEvent_t& e0 = TR.ev[2 * M.trial_slot];
@@ -1003,7 +1027,6 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     HIPCHK(hipStreamWaitEvent(sa, staged_ev, 0));
     if (concurrent) HIPCHK(hipStreamWaitEvent(plan->side2, staged_ev, 0));
   }
-  static const bool no_gate = spx_tuning_env("SPX_NO_GATE") != nullptr;  // A/B only
   static const unsigned gate_spins = [] { const char* e = spx_tuning_env("SPX_GATE_SPINS"); return e ? (unsigned)atoi(e) : 1200u; }();
   static const bool diag_nowait = spx_tuning_env("SPX_DIAG_NOWAIT") != nullptr;  // DIAGNOSTIC ONLY: the walk reads the speeds the
   // previous identical call left in the scratch array instead of waiting for this call's (timing experiments)
@@ -1019,16 +1042,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     // workgroups have been placed (they count themselves in; spx_gate_kernel).
     if (concurrent && do_w && idle_start && !no_gate)
       hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, sa, d_ready + n, n, gate_spins);
-    // AHEAD: the analysis must not fill the CUs before the PREVIOUS call's walk workgroups have been placed one per CU (its walk
-    // kernel becomes runnable at the same moment as this analysis: when the walk before it retires) -- only while that call is
-    // still in flight (then its workspace, where the counter lives, is alive by the usual contract), and not when the producers
-    // wait for that very call anyway (a caller handing the same workspace over again: the counter is THIS workspace's, this
-    // call's staging kernel has just cleared it, and the gate would spin its full bound for a count nobody raises -- round 4:
-    // 3.6 ms per call where a plain call takes 1.6).  A longer bound than the idle-start gate's: the previous walk kernel may
-    // itself be waiting for something of the caller's (an output buffer still being copied out), and a gate that gives up early
-    // lets this call's analysis fill the CUs first, which costs the previous call half its speed; ~2 ms.
-    if (ahead && !force && c == 0 && plan->ahead_started != nullptr && plan->ahead_n > 0 && !no_gate && !waited_prev &&
-        ring_previous_in_flight(plan))
+    if (ahead_gate && split_gate && c == 0)
       hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, sa, plan->ahead_started, plan->ahead_n, 8000u);
     if (do_a && tiles[c] > 0) {
       SpxTimed tm(timed, 0, sa);
