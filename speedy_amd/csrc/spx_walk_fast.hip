@@ -266,6 +266,10 @@ extern "C" long long spx_debug_xfade_check(int n_lo, int n_hi) {
   return e == hipSuccess ? (long long)h : -1;
 }
 
+// (Round 5, tried and dropped: the forms without output waves preparing a cross-fade when it is DECIDED -- the reciprocal, and the
+// thread's two window samples loaded from LDS, at the end of the step before -- so that the step which performs it on the chain
+// finds them ready.  Bit-equal, 1 % SLOWER in the pipelined loop (0.983 against 0.974 ms per step): four more live registers per
+// lane across the whole step and the reciprocal in every wave cost more than the two round trips they hide.)
 // Every output sample of the stream is produced here: by the NWC output waves on command, or -- NWC == 0 -- by the search
 // waves themselves.  `t0` = index of this thread among the NTO threads doing output work.
 //   cross-fade (libsonic overlapAdd): out[t] = (down[t]*(n-t) + up[t]*t)/n, integer, truncating toward zero; both runs
