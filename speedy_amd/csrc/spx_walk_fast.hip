@@ -340,6 +340,9 @@ __device__ __forceinline__ void fast_outputs(const FastOut& X, int t0, int xf_n,
 // (General code, mono: sixteen 2-byte LDS writes per thread, a barrier, then the planes from fourteen 2-byte LDS reads and
 // sixteen 2-byte writes per thread -- 5 700 cycles per refill, 5 % of a 16 kHz chain; the walk kernel of the bench batch
 // 2.10 -> 2.06 ms with this pass, profiles/r03/r03z_refill.txt.)
+// (Round 5, tried and dropped: both rounds of the threads' loads issued before the first round is used -- 256 threads cover a
+// 4096-frame window in two rounds -- 1 % SLOWER in the pipelined loop and 3 % on the stereo forms: eight more registers in the
+// refill, spilled in the capped forms, for a latency the step loop does not wait on as long as assumed.)
 template <int NT, int SKIP, bool STEREO>
 __device__ __forceinline__ void fast_refill_onepass(const FastOut& X, const FastLds& LY, pos_t nb) {
   constexpr int NF = 4 * SKIP - 1;                    // frames a thread needs
