@@ -6,7 +6,7 @@
 #   gpurun -- bash tools/asan_host.sh [seeds]
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
-[ -f speedy_amd/lib/asan/api_fuzz ] || make -s -C speedy_amd/csrc asan-host || exit 1
+[ -f speedy_amd/lib/asan/pipeline_example ] || make -s -C speedy_amd/csrc asan-host || exit 1
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 mkdir -p gpurun_out
 LOG=gpurun_out/asan_host.log
@@ -15,5 +15,17 @@ for seed in $(seq 1 ${1:-6}); do
   timeout 600 speedy_amd/lib/asan/api_fuzz $seed $((16 + 8 * (seed % 5))) 3000 >> $LOG 2>&1 || echo "api_fuzz seed $seed FAILED (rc $?)" >> $LOG
 done
 timeout 300 speedy_amd/lib/asan/stream_bench 64 4 >> $LOG 2>&1 || echo "stream_bench FAILED" >> $LOG
+# ... and the two C99 programs over include/speedy_hip.h: the batch call and the owning pipeline object (round 5), each checking its
+# own outputs
+RAW=gpurun_out/asan_in.raw
+tail -c +45 tests/golden/tapestry.wav | head -c 96000 > $RAW     # 3 s of 16 kHz mono PCM16 behind the 44-byte header
+if [ -f speedy_amd/lib/asan/batch_example ]; then
+  timeout 600 speedy_amd/lib/asan/batch_example $RAW 16000 1 3.5 1 40 1 gpurun_out/asan_out1.raw >> $LOG 2>&1 || echo "batch_example FAILED (rc $?)" >> $LOG
+fi
+if [ -f speedy_amd/lib/asan/pipeline_example ]; then
+  timeout 600 speedy_amd/lib/asan/pipeline_example $RAW 16000 1 3.5 1 64 9 4 gpurun_out/asan_out2.raw >> $LOG 2>&1 || echo "pipeline_example FAILED (rc $?)" >> $LOG
+  timeout 600 speedy_amd/lib/asan/pipeline_example $RAW 16000 1 1.5 0 300 5 3 gpurun_out/asan_out3.raw >> $LOG 2>&1 || echo "pipeline_example (300 streams: sub-batches) FAILED (rc $?)" >> $LOG
+  cmp gpurun_out/asan_out1.raw gpurun_out/asan_out2.raw >> $LOG 2>&1 || echo "batch and pipeline outputs differ FAILED" >> $LOG
+fi
 cut -c1-220 $LOG | tail -12
 echo "sanitizer reports: $(grep -c 'ERROR: AddressSanitizer\|runtime error\|FAILED' $LOG)"
