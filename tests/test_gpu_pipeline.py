@@ -262,3 +262,53 @@ def test_input_may_be_overwritten_once_consumed(orc):
     with pytest.raises(RuntimeError):
         pipe.input_consumed(10 ** 6)
     pipe.close()
+
+
+def test_refused_arguments_edge_shapes_and_destroy_in_flight(orc):
+    """What the pipeline refuses (depth 1 or above 8, no streams, a plan index out of range, a bad job), the shapes at the edge --
+    ONE stream, streams too short for a single analysis frame or EMPTY beside ordinary ones, linear jobs (no analysis at all),
+    a slow-down job -- against the oracle, and a pipeline destroyed with batches still in flight."""
+    import ctypes as C
+    from speedy_amd.batch import Pipeline, Plan, StreamJob
+    from speedy_amd.synth import speech_like
+    rate = 16000
+    plan = Plan(rate, False)
+    L = plan.L
+    for depth in (1, 9, -1):
+        with pytest.raises(RuntimeError):
+            Pipeline(plan, [8000] * 4, 1, 3.0, 1.0, 0.0, depth=depth)
+    jobs = (StreamJob * 1)()
+    assert not L.spx_pipeline_create(plan.h, jobs, 0, 0, 0) and b"bad arguments" in L.spx_last_error()
+    with pytest.raises(RuntimeError):
+        Pipeline([plan], [8000] * 2, 1, 3.0, 1.0, 0.0, plan_index=[0, 1])
+    with pytest.raises(RuntimeError):
+        Pipeline(plan, [8000, 8000], [1, 0], 3.0, 1.0, 0.0)       # channels < 1
+    # edge shapes
+    cases = [([24000], [3.0], [1.0]),                                  # one stream
+             ([24000, 0, 100, 239, 16000, 1], [3.0, 2.0, 3.5, 2.5, 1.5, 2.0], [1.0, 1.0, 1.0, 1.0, 1.0, 1.0]),   # empty / shorter than a window
+             ([20000, 12000, 16000], [2.0, 0.5, 1.0], [0.0, 0.0, 0.0])]    # linear only: speed-up, slow-down, unity
+    for lens, speeds, nls in cases:
+        xs = [speech_like(n, rate, seed=1100 + i) if n else np.zeros(0, np.int16) for i, n in enumerate(lens)]
+        pipe = Pipeline(plan, lens, 1, speeds, nls, 0.0, depth=2)
+        inp = pipe.pack(xs)
+        ts = [pipe.submit(inp) for _ in range(3)]
+        outs = pipe.results(ts[-1])
+        assert _crc(pipe.results(ts[-2])) == _crc(outs)
+        for i, (x, got) in enumerate(zip(xs, outs)):
+            ref = orc.compress_sound(x, rate, 1, speeds[i], nls[i], 0.0, False, chunk=max(1, x.size), taps=False)["out"] if x.size else np.zeros(0, np.int16)
+            assert np.array_equal(got, ref), (lens, i, got.size, ref.size)
+        pipe.close()
+    # destroyed with batches in flight (and never waited for): nothing hangs, the plan serves the next pipeline
+    n = 10 * rate
+    big = [speech_like(n, rate, seed=1200 + i) for i in range(8)] * 32
+    pipe = Pipeline(plan, [n] * 256, 1, 3.5, 1.0, 0.0, depth=4)
+    inp = pipe.pack(big)
+    for _ in range(6):
+        pipe.submit(inp)
+    pipe.close()
+    pipe = Pipeline(plan, [n] * 256, 1, 3.5, 1.0, 0.0, depth=3)
+    t = pipe.submit(inp)
+    outs = pipe.results(t)
+    ref = orc.compress_sound(big[3], rate, 1, 3.5, 1.0, 0.0, False, chunk=1000, taps=False)["out"]
+    assert np.array_equal(outs[3], ref) and np.array_equal(outs[3 + 8 * 31], ref)
+    pipe.close()
