@@ -17,6 +17,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 ids = list(range(n))
 streams = C4.make_streams(ids, threads=8)
 plans = [Plan(r, False) for r in C4.RATES]
+if int(os.environ.get("SPX_CHUNKS", "0")) > 0:     # A/B: the number of time chunks of a large call (0 / unset = the engine's own choice: 2)
+    plans[0].L.spx_set_pipeline_chunks(int(os.environ["SPX_CHUNKS"]))
 b = C4.mixed_batch(plans, ids, streams)
 ahead = len(sys.argv) > 3 and sys.argv[3] == "ahead"
 turn = [b, C4.mixed_batch(plans, ids, streams)] if ahead else [b]
