@@ -312,3 +312,49 @@ def test_refused_arguments_edge_shapes_and_destroy_in_flight(orc):
     ref = orc.compress_sound(big[3], rate, 1, 3.5, 1.0, 0.0, False, chunk=1000, taps=False)["out"]
     assert np.array_equal(outs[3], ref) and np.array_equal(outs[3 + 8 * 31], ref)
     pipe.close()
+
+
+def test_two_host_threads_each_with_a_pipeline_on_one_plan(orc):
+    """Two host threads, each submitting to a pipeline of its own, both on ONE plan (the plan's ring of calls, its staging slots and
+    the library's side and walk streams are shared; a pipeline itself is not thread-safe and is not shared): every batch of either
+    thread holds its own content's output."""
+    import threading
+    from speedy_amd.batch import Batch, Pipeline, Plan
+    from speedy_amd.synth import speech_like
+    rate, n = 16000, 40000
+    plan = Plan(rate, False)
+    shapes = {"a": ([n] * 200, 3.5), "b": ([n - 333 * (i % 7) for i in range(150)], 2.0)}
+    xs = {k: [speech_like(l, rate, seed=(1300 if k == "a" else 1500) + i) for i, l in enumerate(v[0])] for k, v in shapes.items()}
+    want = {}
+    for k, (lens, speed) in shapes.items():
+        b = Batch(plan, lens, 1, speed, 1.0, 0.0)
+        b.upload(xs[k])
+        b.run()
+        outs = b.results()
+        want[k] = _crc(outs)
+        ref = orc.compress_sound(xs[k][5], rate, 1, speed, 1.0, 0.0, False, chunk=1000, taps=False)["out"]
+        assert np.array_equal(outs[5], ref)
+    errors = []
+
+    def work(k):
+        try:
+            lens, speed = shapes[k]
+            pipe = Pipeline(plan, lens, 1, speed, 1.0, 0.0, depth=3)
+            inp = pipe.pack(xs[k])
+            ts = []
+            for j in range(10):
+                ts.append(pipe.submit(inp))
+                if j >= 2:
+                    assert _crc(pipe.results(ts[j - 2])) == want[k], (k, j)
+            for t in ts[-2:]:
+                assert _crc(pipe.results(t)) == want[k], (k, t)
+            pipe.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in shapes]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errors, errors
