@@ -353,7 +353,7 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
   const int cnt = maxRequired / skip;
   if (!FAST && !direct) {
     const int div = skip * C;
-    const double inv = 1.0 / (double)div;
+    const double inv = xfade_rcp(div);
     for (int t = tid; t < cnt + 2; t += NT) {
       int sum = 0;
       if (C == 1) {
@@ -364,10 +364,8 @@ __device__ __forceinline__ int find_pitch_period(const SpxPlanDev& P, WalkCtx& X
         const short* w = X.raw + (size_t)(o + t * skip) * C;
         for (int j = 0; j < div; j++) sum += w[j];
       }
-      // truncating sum / div via the exact double-reciprocal form (see emit_overlap_add)
-      const int mag = sum < 0 ? -sum : sum;
-      const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
-      const unsigned short u = (unsigned short)((sum < 0 ? -qm : qm) + 32768);
+      // truncating sum / div via the exact double-reciprocal form (xfade_quot: |sum| <= 32768 div)
+      const unsigned short u = (unsigned short)(xfade_quot(sum, inv) + 32768);
       X.dnH[t] = u;
       if (t > 0) X.dnHB[t - 1] = u;
     }
@@ -470,14 +468,13 @@ __device__ __forceinline__ void emit_copy(const WalkCtx& X, WalkState& st, pos_t
 }
 
 // Append n frames of cross-fade: out[t] = (down[t]*(n-t) + up[t]*t)/n, integer, truncating toward zero.
-// |numerator| <= 32768*n < 2^31; the quotient is taken as trunc(|num| * (1/n) + 2^-20) in double, which is exact:
-// non-integer quotients are at least 1/n >= 2^-11 below the next integer, integer ones land 2^-20 above.
+// |numerator| <= 32768*n < 2^31; the quotient: xfade_rcp / xfade_quot (spx_walk_common.h).
 template <int NW, int FAST>
 __device__ __forceinline__ void emit_overlap_add(const WalkCtx& X, pos_t a_down, pos_t a_up, int n,
                                                  pos_t out_at) {
   constexpr int NT = 64 * NW;
   const int C = (FAST == 1) ? 1 : X.C;
-  const double inv = 1.0 / (double)n;
+  const double inv = xfade_rcp(n);
   pos_t nv64 = X.out_cap - out_at;
   const int nv = nv64 > n ? n : (nv64 < 0 ? 0 : (int)nv64);
   int16_t* __restrict__ dst = X.out + (size_t)out_at * C;
@@ -489,10 +486,7 @@ __device__ __forceinline__ void emit_overlap_add(const WalkCtx& X, pos_t a_down,
     // FAST: n <= maxPeriod < 512 (rates below 32 kHz), so with eight waves this is one predicated pass, no loop
     for (int t = threadIdx.x; t < nv; t += NT) {
       const int d = (int)wd[t] - 32768, u = (int)wu[t] - 32768;
-      const int num = d * (n - t) + u * t;
-      const int mag = num < 0 ? -num : num;
-      const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
-      dst[t] = (int16_t)(num < 0 ? -qm : qm);
+      dst[t] = (int16_t)xfade_quot(d * (n - t) + u * t, inv);
       if (FAST && NT >= 512) break;
     }
   } else if (FAST == 2) {
@@ -504,10 +498,7 @@ __device__ __forceinline__ void emit_overlap_add(const WalkCtx& X, pos_t a_down,
     for (int e = threadIdx.x; e < total; e += NT) {
       const int t = (C == 2) ? (e >> 1) : (int)(((unsigned)e * invC) >> 16);
       const int d = rd[e], u = ru[e];
-      const int num = d * (n - t) + u * t;
-      const int mag = num < 0 ? -num : num;
-      const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
-      dst[e] = (int16_t)(num < 0 ? -qm : qm);
+      dst[e] = (int16_t)xfade_quot(d * (n - t) + u * t, inv);
     }
   } else {
     const int total = nv * C;
@@ -515,10 +506,7 @@ __device__ __forceinline__ void emit_overlap_add(const WalkCtx& X, pos_t a_down,
       int t = e, c = 0;
       if (C != 1) { t = e / C; c = e - t * C; }
       const int d = any_sample(X, a_down + t, c), u = any_sample(X, a_up + t, c);
-      const int num = d * (n - t) + u * t;
-      const int mag = num < 0 ? -num : num;
-      const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
-      dst[e] = (int16_t)(num < 0 ? -qm : qm);
+      dst[e] = (int16_t)xfade_quot(d * (n - t) + u * t, inv);
     }
   }
 }

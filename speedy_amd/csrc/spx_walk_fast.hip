@@ -185,26 +185,8 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// The cross-fade's quotient num / n, truncated toward zero (libsonic overlapAdd), for |num| <= 32768 n, n <= 4096:
-//   q = (int)fma((double)num, inv, copysign(2^-20, num)),   inv = 1 / n to within 2^-40 relative
-// Exact: a non-integer quotient is at least 1/n >= 2^-12 away from the next integer towards which the 2^-20 pushes, an integer one
-// lands 2^-20 on the far side of itself, and the error of the product is below 2^27 2^-12 2^-40 = 2^-25.  So the reciprocal needs
-// no IEEE division (round 5: v_rcp_f64 and two Newton steps -- five instructions for the compiler's twelve; in the lean form they
-// are on the chain, once per step), the sign needs no absolute value / negate pair (the conversion truncates toward zero by
-// itself), and the numerator d (n - t) + u t is two 24-bit multiplications (|d|, |u| <= 2^15, n <= 2^12).  Checked against the
-// integer division for every n and every num = k n + {-1, 0, 1}: spx_debug_xfade_check (tests/test_gpu_parity.py).
-// -DSPX_XFADE_V1: the round-1 sequence.
-__device__ __forceinline__ double xfade_rcp(int n) {
-#ifdef SPX_XFADE_V1
-  return 1.0 / (double)n;
-#else
-  const double nd = (double)n;
-  double r = __builtin_amdgcn_rcp(nd);
-  r = __builtin_fma(__builtin_fma(-nd, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-nd, r, 1.0), r, r);
-  return r;
-#endif
-}
+// (The cross-fade's quotient -- xfade_rcp, xfade_quot -- lives in spx_walk_common.h: the general walk kernel uses it too.)
+// Its numerator d (n - t) + u t as two 24-bit multiplications (|d|, |u| <= 2^15, n <= 2^12):
 __device__ __forceinline__ int xfade_num(int d, int nt, int u, int t) {
 #ifdef SPX_XFADE_V1
   return d * nt + u * t;
@@ -220,16 +202,6 @@ __device__ __forceinline__ int xfade_num_biased(unsigned D, int nt, unsigned U, 
   return ((int)D - 32768) * nt + ((int)U - 32768) * t;
 #else
   return (int)(__umul24(D, (unsigned)nt) + __umul24(U, (unsigned)t)) - (n << 15);
-#endif
-}
-__device__ __forceinline__ int xfade_quot(int num, double inv) {
-#ifdef SPX_XFADE_V1
-  const int mag = num < 0 ? -num : num;
-  const int qm = (int)((double)mag * inv + 9.5367431640625e-07);
-  return num < 0 ? -qm : qm;
-#else
-  const double x = (double)num;
-  return (int)__builtin_fma(x, inv, __builtin_copysign(9.5367431640625e-07, x));
 #endif
 }
 __global__ void spx_xfade_check_kernel(int n_lo, int n_hi, unsigned* mismatches) {
