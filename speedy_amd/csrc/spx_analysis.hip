@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "spx_internal.h"
+#include "spx_walk_common.h"   // wave_max_f (the DPP reduction of non-negative floats as unsigned integers)
 
 #ifndef SPX_TF
 #define SPX_TF 16  // frames per tile (plus one halo slot)
@@ -1177,6 +1178,7 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
   // not depend on the order) by the other three waves meanwhile.  (Rounds 1-3: load, multiply, add, maximum and a register
   // copy per bin on the chain's wave: 23-40 cycles per bin, 10-27 % of a tile's time.)
   if (wave > 0) {
+#ifdef SPX_ROWMAX_V1
     for (int s = wave - 1; s <= TF; s += 3) {
       const float* mrow = mags + (size_t)s * MS;
       float mx = 0.0f;
@@ -1185,6 +1187,30 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
       for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
       if (lane == 0) fThr[s] = (float)((double)mx / 100.0);                      // speedy.c:709
     }
+#else
+    // Round 5.  The magnitudes are non-negative floats, so their maximum is the maximum of their bit patterns as unsigned integers:
+    // four bins per 16-byte LDS read, v_max_u32 without the canonicalising copies fmaxf needs, the wave's maximum by a DPP
+    // reduction (six instructions; __shfl_xor was six LDS round trips), and the division by 100 -- an fp64 IEEE sequence -- ONCE for
+    // all the rows of the wave (lane j keeps the maximum of the wave's j-th row) instead of once per row on lane 0.  These three
+    // waves, not the energy chain on wave 0, were what phase 2 waited for.
+    unsigned keep = 0u;   // lane j: bit pattern of the maximum of row wave - 1 + 3 j
+    int nrows = 0;
+    for (int s = wave - 1; s <= TF; s += 3, nrows++) {
+      const unsigned* mrow = reinterpret_cast<const unsigned*>(mags + (size_t)s * MS);
+      unsigned m = 0u;
+      for (int q = lane; 4 * q < W; q += SPX_WAVE) {
+        const uint4 v = *reinterpret_cast<const uint4*>(mrow + 4 * q);
+        const unsigned a = (q == 0) ? 0u : v.x;                                  // bin 0 is not part of the maximum (speedy.c:709)
+        const unsigned b = (4 * q + 1 < W) ? v.y : 0u, c = (4 * q + 2 < W) ? v.z : 0u, d = (4 * q + 3 < W) ? v.w : 0u;
+        const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+        const unsigned abcd = ab > cd ? ab : cd;
+        m = m > abcd ? m : abcd;
+      }
+      const float mx = wave_max_f(__builtin_bit_cast(float, m));
+      if (lane == nrows) keep = __builtin_bit_cast(unsigned, mx);
+    }
+    if (lane < nrows) fThr[wave - 1 + 3 * lane] = (float)((double)__builtin_bit_cast(float, keep) / 100.0);   // speedy.c:709
+#endif
 #ifndef SPX_LOG_V1
     // ... and bring the table of log spec v2 into the work area behind the terms (the transform buffers are free by now; the
     // barrier at the end of this phase publishes it): 128 entries of 16 bytes, one per lane of waves 1 and 2
