@@ -1324,28 +1324,55 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
     double* tblk = work;  // [2][TF][CBS]
     constexpr int NBLK = (WCT - 1 + CB - 1) / CB;
     float lsd = 0.0f;
+    // What a term lane needs of its two frames is the same for every block: the two rows of magnitudes, the frame's threshold and
+    // the two inverse norms (round 5: they were re-derived, and the three scalars re-read from LDS, for every term -- a fifth of
+    // the term's instructions; -DSPX_TERMS_V1: that code).
+    int fi[2], ci[2];
+    bool ok[2];
+#ifndef SPX_TERMS_V1
+    const float* rowc[2];
+    const float* rowl[2];
+    float thrv[2], invc[2], invl[2];
+#endif
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int it = tid - SPX_WAVE + t * (SPX_BLOCK - SPX_WAVE);
+      fi[t] = wave > 0 ? it / CB : 0;
+      ci[t] = wave > 0 ? it - fi[t] * CB : 0;
+      ok[t] = wave > 0 && fi[t] < nfr;                                         // (bins past the window: a term of 0, see the chain)
+#ifndef SPX_TERMS_V1
+      const int fl = ok[t] ? fi[t] : 0;
+      rowc[t] = mags + (size_t)(fl + 1) * MS;
+      rowl[t] = mags + (size_t)fl * MS;
+      thrv[t] = fThr[fl + 1];
+      invc[t] = fInv[fl + 1];
+      invl[t] = fInv[fl];
+#endif
+    }
     for (int k = 0; k <= NBLK; k++) {
       if (wave > 0) {
         if (k < NBLK) {
           double* tb = tblk + (size_t)(k & 1) * TF * CBS;
           // the lane's two terms, their straight-line halves first (spx_log.h) so that the two interleave
-          int fi[2], ci[2];
-          bool ok[2], gate[2];
+          bool gate[2];
           float xr[2];
 #pragma unroll
           for (int t = 0; t < 2; t++) {
-            const int it = tid - SPX_WAVE + t * (SPX_BLOCK - SPX_WAVE);
-            fi[t] = it / CB;
-            ci[t] = it - fi[t] * CB;
             const int i = 1 + k * CB + ci[t];
-            ok[t] = fi[t] < nfr;                                               // (bins past the window: a term of 0, see the chain)
             const bool in = ok[t] && i < WCT;
+#ifdef SPX_TERMS_V1
             const int fl = in ? fi[t] : 0, il = in ? i : 1;
             const float cur = mags[(size_t)(fl + 1) * MS + il], last = mags[(size_t)fl * MS + il];
             const float thr = fThr[fl + 1];
+            const float fic = fInv[fl + 1], fil = fInv[fl];
+#else
+            const int il = (i < WCT) ? i : 1;
+            const float cur = rowc[t][il], last = rowl[t][il];
+            const float thr = thrv[t], fic = invc[t], fil = invl[t];
+#endif
             gate[t] = in && cur > thr && last > thr;                           // speedy.c:705-717
             const float eps = 2.2204e-16f;
-            const float nc = cur * fInv[fl + 1], nl = last * fInv[fl];
+            const float nc = cur * fic, nl = last * fil;
             // (both operands in [2.2e-16, ~1e3] whenever the gate is open: spx_fdiv32's range; a closed gate's quotient is not used)
             const float ratio = spx_fdiv32(nc + eps, nl + eps);
             xr[t] = gate[t] ? ratio : 2.0f;
