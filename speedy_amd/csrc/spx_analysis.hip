@@ -863,9 +863,18 @@ spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int 
 #pragma unroll
           for (int i = 1; i <= 5; i++) {
             const double wx = wc[(i * jj) % 11 - 1], wy = ws[(i * jj) % 11 - 1];  // (cos, -sin)(2 pi k / 11), k = (i jj) mod 11
+            // (spx_acc: fused in DFT spec v2, as orc_butterfly_v2's odd-prime branch and ct_stage_prime_last -- until the end of round 5
+            // this hand-written stage had kept the unfused sums of spec v1: an fp64 last-bit difference from the oracle that a float
+            // magnitude shows about once in 2^29 values)
+#ifdef SPX_R11_V1   // (what the stage did until then: tools/r11_probe.py compares the two builds with the oracle)
             Pj.r = Pj.r + wx * u5[i - 1].r; Pj.i = Pj.i + wx * u5[i - 1].i;
             if (i == 1) { Qj.r = wy * v5[0].r; Qj.i = wy * v5[0].i; }
             else { Qj.r = Qj.r + wy * v5[i - 1].r; Qj.i = Qj.i + wy * v5[i - 1].i; }
+#else
+            Pj.r = spx_acc(Pj.r, wx, u5[i - 1].r); Pj.i = spx_acc(Pj.i, wx, u5[i - 1].i);
+            if (i == 1) { Qj.r = wy * v5[0].r; Qj.i = wy * v5[0].i; }
+            else { Qj.r = spx_acc(Qj.r, wy, v5[i - 1].r); Qj.i = spx_acc(Qj.i, wy, v5[i - 1].i); }
+#endif
           }
           st(bufA, lane + 30 * jj, cplx{Pj.r - Qj.i, Pj.i + Qj.r});
           st(bufA, lane + 30 * (11 - jj), cplx{Pj.r + Qj.i, Pj.i - Qj.r});

@@ -773,6 +773,37 @@ def test_rates_with_more_than_64_coarse_lags_run_on_the_speed_up_kernel(orc, rat
             assert np.array_equal(got, ref), (rate, ch, i, speeds[i], nls[i], got.size, ref.size)
 
 
+def test_dft_spec_v2_on_frames_sensitive_to_the_radix_11_fusion(orc):
+    """The 22.05 kHz window is 330 = 2 x 3 x 5 x 11 points; DFT spec v2 fuses the multiply-adds of the odd-prime butterfly (oracle
+    orc_butterfly_v2, kernel spx_acc).  Until the end of round 5 the kernel's hand-written radix-11 stage had kept the unfused sums:
+    an fp64 last-bit difference that a float magnitude shows about once in 1e9 values -- tools/r11_probe.py found six such frames
+    in ten million (profiles/r05/r5ah_r11_probe.txt), and these are they: the spectrogram tap of each against the oracle's."""
+    from speedy_amd.batch import Batch, Plan
+    rate = 22050
+    cases = [(116, 202, 96), (175, 40, 76), (188, 224, 41), (339, 70, 3), (374, 1, 62), (384, 228, 40)]
+    xs = [np.random.default_rng([seed, i]).integers(-20000, 20000, size=rate).astype(np.int16) for seed, i, _ in cases]
+    plan = Plan(rate, False)
+    b = Batch(plan, [rate] * len(xs), 1, 3.0, 1.0, 0.0, taps=True, spectrogram_taps=True)
+    b.upload(xs)
+    b.run()
+    L = orc.lib()
+    for k, ((seed, i, f), x) in enumerate(zip(cases, xs)):
+        rows = []
+        h = L.orc_sonicCreateStream(rate, 1, 0)
+        nb = L.orc_sonicSpectrogramSize(h)
+        cb = orc.FEATURES_FN(lambda s, t, p: rows.append(np.ctypeslib.as_array(p, shape=(nb,)).copy()))
+        L.orc_sonicSpectrogramCallback(h, cb)
+        L.orc_sonicSetSpeed(h, 3.0)
+        L.orc_sonicEnableNonlinearSpeedup(h, 1.0)
+        L.orc_sonicWriteShortToStream(h, orc.sptr(x), x.size)
+        L.orc_sonicDestroyStream(h)
+        got = b.tap_arrays(k)["spectrogram"]
+        ref = np.array(rows, np.float32)
+        assert got.shape == ref.shape
+        assert np.array_equal(got[f], ref[f]), (seed, i, f, int((got[f] != ref[f]).sum()))
+        assert np.array_equal(got, ref), (seed, i)
+
+
 def test_register_budgets_of_the_concurrent_mode():
     """The concurrent mode needs two analysis waves beside a stream's walk and tension waves on a SIMD's 512 registers
     (DESIGN.md 2).  Both cases that matter are tight: 16 kHz mono 2 x 96 + tension + 2 x 128, and 22.05 kHz mono with the lean

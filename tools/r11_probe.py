@@ -1,0 +1,65 @@
+"""Does the 22.05 kHz analysis kernel's transform equal the oracle's at the fp64 level?  A float magnitude shows an fp64 last-bit
+difference about once in 2^29 values, so: MANY frames of noise through the GPU's spectrogram tap, one 64-bit hash per frame.
+  python3 tools/r11_probe.py run OUT.npy BATCHES          (SPEEDY_HIP_LIB selects the library build)
+  python3 tools/r11_probe.py compare A.npy B.npy          every frame whose hash differs between two builds, and which of the two the
+                                                          ORACLE's spectrogram of that frame agrees with
+(round 5: the hand-written radix-11 stage had kept the unfused sums of DFT spec v1; profiles/r05/r5ah_r11_probe.txt)"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+RATE, NS, SECS = int(os.environ.get("SPX_PROBE_RATE", "22050")), 256, 1   # (SPX_PROBE_RATE: any rate; two builds / two settings of one build)
+
+
+def stream(seed, i):
+    return np.random.default_rng([seed, i]).integers(-20000, 20000, size=RATE * SECS).astype(np.int16)
+
+
+def hashes(rows):   # rows: (frames, N) float32 -> int64 per frame
+    return rows.view(np.int32).astype(np.int64).sum(axis=1)
+
+
+if sys.argv[1] == "run":
+    import torch
+    from speedy_amd.batch import Batch, Plan
+    out, batches = sys.argv[2], int(sys.argv[3])
+    plan = Plan(RATE, False)
+    b = Batch(plan, [RATE * SECS] * NS, 1, 3.0, 1.0, 0.0, taps=True, spectrogram_taps=True)
+    res = []
+    for seed in range(batches):
+        b.upload([stream(seed, i) for i in range(NS)])
+        b.run()
+        torch.cuda.synchronize()
+        h = b.t_spec.view(torch.int32).view(-1, plan.N).to(torch.int64).sum(dim=1)
+        res.append(h.cpu().numpy())
+    np.save(out, np.stack(res))
+    print("frames per batch", res[0].size, "batches", batches)
+else:
+    A, B = np.load(sys.argv[2]), np.load(sys.argv[3])
+    assert A.shape == B.shape
+    diff = np.argwhere(A != B)
+    print("rate %d: %d of %d frames differ between the two builds" % (RATE, len(diff), A.size))
+    from oracle import pyorc as orc
+    L = orc.lib()
+    T = A.shape[1] // NS
+    agree = {"first": 0, "second": 0, "neither": 0}
+    for seed, idx in diff[:40]:
+        i, f = idx // T, idx % T
+        x = stream(int(seed), int(i))
+        rows = []
+        h = L.orc_sonicCreateStream(RATE, 1, 0)
+        nb = L.orc_sonicSpectrogramSize(h)
+        cb = orc.FEATURES_FN(lambda s, t, p: rows.append(np.ctypeslib.as_array(p, shape=(nb,)).copy()))
+        L.orc_sonicSpectrogramCallback(h, cb)
+        L.orc_sonicSetSpeed(h, 3.0)
+        L.orc_sonicEnableNonlinearSpeedup(h, 1.0)
+        L.orc_sonicWriteShortToStream(h, orc.sptr(x), x.size)
+        L.orc_sonicDestroyStream(h)
+        ho = int(hashes(np.array(rows[int(f)], np.float32)[None, :])[0])
+        k = "first" if ho == A[seed, idx] else ("second" if ho == B[seed, idx] else "neither")
+        agree[k] += 1
+        print("batch %d stream %d frame %d: the oracle agrees with the %s build" % (seed, i, f, k))
+    print(agree)
