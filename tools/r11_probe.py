@@ -28,18 +28,35 @@ if sys.argv[1] == "run":
     out, batches = sys.argv[2], int(sys.argv[3])
     plan = Plan(RATE, False)
     b = Batch(plan, [RATE * SECS] * NS, 1, 3.0, 1.0, 0.0, taps=True, spectrogram_taps=True)
-    res = []
+    res, res2, res3 = [], [], []
     for seed in range(batches):
         b.upload([stream(seed, i) for i in range(NS)])
         b.run()
         torch.cuda.synchronize()
         h = b.t_spec.view(torch.int32).view(-1, plan.N).to(torch.int64).sum(dim=1)
         res.append(h.cpu().numpy())
+        # ... and the frame-rate stage's taps (15 features, tension, speed per tension frame): everything behind the magnitudes
+        w = torch.arange(1, 16, device=b.t_features.device, dtype=torch.int64)
+        hf = (b.t_features.view(torch.int32).view(-1, 15).to(torch.int64) * w).sum(dim=1) + 31 * b.t_tension.view(torch.int32).to(torch.int64) \
+            + 37 * b.t_speed.view(torch.int32).to(torch.int64)
+        res2.append(hf.cpu().numpy())
+        # ... and the audio itself: one weighted sum of the whole output buffer and the produced counts per batch
+        o = b.d_out.to(torch.int64)
+        res3.append(int((o * (torch.arange(o.numel(), device=o.device, dtype=torch.int64) % 65521 + 1)).sum().item()) ^ int(b.d_nout.sum().item()))
     np.save(out, np.stack(res))
+    np.save(out.replace(".npy", "_audio.npy"), np.array(res3, np.int64))
+    np.save(out.replace(".npy", "_features.npy"), np.stack(res2))
     print("frames per batch", res[0].size, "batches", batches)
 else:
     A, B = np.load(sys.argv[2]), np.load(sys.argv[3])
     assert A.shape == B.shape
+    fa, fb = sys.argv[2].replace(".npy", "_features.npy"), sys.argv[3].replace(".npy", "_features.npy")
+    if os.path.exists(fa) and os.path.exists(fb):
+        FA, FB = np.load(fa), np.load(fb)
+        print("rate %d: %d of %d tension frames differ in features / tension / speed" % (RATE, int((FA != FB).sum()), FA.size))
+    aa, ab = sys.argv[2].replace(".npy", "_audio.npy"), sys.argv[3].replace(".npy", "_audio.npy")
+    if os.path.exists(aa) and os.path.exists(ab):
+        print("rate %d: %d of %d batches differ in the output audio" % (RATE, int((np.load(aa) != np.load(ab)).sum()), np.load(aa).size))
     diff = np.argwhere(A != B)
     print("rate %d: %d of %d frames differ between the two builds" % (RATE, len(diff), A.size))
     from oracle import pyorc as orc
