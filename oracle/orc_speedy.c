@@ -18,6 +18,9 @@
  *      double "log spec v1" (orc_log: the classic fdlibm sequence, no FMA).  Both agree with glibc's log to <= 1 ulp -- v2
  *      over ALL 2^31 positive floats (oracle/orc_logcheck.c runs them; tests/test_oracle_dft_log.py).
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE   /* sincos */
+#endif
 #include "orc_speedy.h"
 
 #include <assert.h>
@@ -215,6 +218,16 @@ static int orc_primitive_root(int n) { /* smallest g whose powers visit all of 1
   return 0;
 }
 
+/* A twiddle factor (cos, -sin)(a): ONE sincos call.  Part of the DFT spec: glibc's sincos and its sin / cos
+ * round a few table entries differently in the last bit, and a compiler may or may not merge a cos and a sin of one argument into a
+ * sincos (gcc does from -O1 on, clang does not) -- so the call is spelled out here and in the library's table builder
+ * (spx_engine.hip spx_twiddle), and the two tables are the same whatever built them. */
+static inline void orc_twiddle(double a, double* c, double* ms) {
+  double sn, cs;
+  sincos(a, &sn, &cs);
+  *c = cs;
+  *ms = -sn;
+}
 static orc_plan* orc_plan_create(int n) {
   orc_plan* p = (orc_plan*)calloc(1, sizeof(orc_plan));
   p->n = n;
@@ -222,8 +235,7 @@ static orc_plan* orc_plan_create(int n) {
   p->tw = (double*)malloc(sizeof(double) * 2 * n);
   p->work = (double*)malloc(sizeof(double) * 8 * n);
   for (int t = 0; t < n; t++) {
-    p->tw[2 * t] = cos(2.0 * M_PI * t / n);
-    p->tw[2 * t + 1] = -sin(2.0 * M_PI * t / n);
+    orc_twiddle(2.0 * M_PI * t / n, &p->tw[2 * t], &p->tw[2 * t + 1]);
   }
   if (orc_use_rader(n)) {
     int m = n - 1;
@@ -495,8 +507,7 @@ static orc_specplan* orc_specplan_create(int W) {
   sp->z = (double*)malloc(sizeof(double) * 2 * W);
   sp->Z = (double*)malloc(sizeof(double) * 2 * W);
   for (int k = 0; k < W; k++) {
-    sp->tw2[2 * k] = cos(2.0 * M_PI * k / (2.0 * W));
-    sp->tw2[2 * k + 1] = -sin(2.0 * M_PI * k / (2.0 * W));
+    orc_twiddle(2.0 * M_PI * k / (2.0 * W), &sp->tw2[2 * k], &sp->tw2[2 * k + 1]);
   }
   return sp;
 }

@@ -333,17 +333,24 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
   int* perm = reinterpret_cast<int*>(tp + n_tp + 8);
   int* iperm = perm + n_ri;
   int* qlog = iperm + n_ri;
+  // A twiddle factor (cos, -sin)(a) is ONE sincos call -- part of the DFT spec since the end of round 5: glibc's sincos
+  // and its separate sin / cos round a few entries differently in the last bit; gcc merges a cos and a sin of one argument into a
+  // sincos, clang (this file's host compiler) does not, so until then the oracle's tables (gcc) and these differed in a few last
+  // bits -- an fp64 difference that float magnitudes show about once in 1e9 values (tools/r11_probe.py found it).
+  auto spx_twiddle = [](double a, double* c, double* ms) {
+    double sn, cs;
+    sincos(a, &sn, &cs);
+    *c = cs;
+    *ms = -sn;
+  };
   for (int t = 0; t < W; t++) {
-    tw[2 * t] = cos(2.0 * M_PI * t / W);
-    tw[2 * t + 1] = -sin(2.0 * M_PI * t / W);
-    tw2[2 * t] = cos(2.0 * M_PI * t / (2.0 * W));
-    tw2[2 * t + 1] = -sin(2.0 * M_PI * t / (2.0 * W));
+    spx_twiddle(2.0 * M_PI * t / W, &tw[2 * t], &tw[2 * t + 1]);
+    spx_twiddle(2.0 * M_PI * t / (2.0 * W), &tw2[2 * t], &tw2[2 * t + 1]);
     win[t] = 0.54 - 0.46 * cos(2 * M_PI * t / (W - 1.0));  // speedy.c:256-258
   }
   if (rader) {
     for (int t = 0; t < M; t++) {
-      twM[2 * t] = cos(2.0 * M_PI * t / M);
-      twM[2 * t + 1] = -sin(2.0 * M_PI * t / M);
+      spx_twiddle(2.0 * M_PI * t / M, &twM[2 * t], &twM[2 * t + 1]);
     }
     int g = 2;  // smallest primitive root of W
     for (; g < W; g++) {

@@ -778,9 +778,20 @@ def test_dft_spec_v2_on_frames_sensitive_to_the_radix_11_fusion(orc):
     orc_butterfly_v2, kernel spx_acc).  Until the end of round 5 the kernel's hand-written radix-11 stage had kept the unfused sums:
     an fp64 last-bit difference that a float magnitude shows about once in 1e9 values -- tools/r11_probe.py found six such frames
     in ten million (profiles/r05/r5ah_r11_probe.txt), and these are they: the spectrogram tap of each against the oracle's."""
+    _sensitive_frames(orc, 22050, [(116, 202, 96), (175, 40, 76), (188, 224, 41), (339, 70, 3), (374, 1, 62), (384, 228, 40)])
+
+
+def test_twiddle_tables_are_the_oracles_on_frames_that_told_them_apart(orc):
+    """The same probe, one level deeper (frames sensitive to the spec VERSION, the oracle on both specs), showed the GPU's transform
+    and the oracle's differing at the fp64 level at 32 - 48 kHz in both specs: the twiddle tables.  Both sides wrote cos(a), -sin(a);
+    gcc merges the pair into glibc's sincos, clang -- the library's host compiler -- does not, and sincos rounds a few entries
+    differently in the last bit.  A twiddle is now one explicit sincos call on both sides (DFT spec).  These are the two
+    48 kHz frames of that probe whose magnitudes were one float ulp off the oracle's."""
+    _sensitive_frames(orc, 48000, [(13, 255, 23), (30, 25, 42)])
+
+
+def _sensitive_frames(orc, rate, cases):
     from speedy_amd.batch import Batch, Plan
-    rate = 22050
-    cases = [(116, 202, 96), (175, 40, 76), (188, 224, 41), (339, 70, 3), (374, 1, 62), (384, 228, 40)]
     xs = [np.random.default_rng([seed, i]).integers(-20000, 20000, size=rate).astype(np.int16) for seed, i, _ in cases]
     plan = Plan(rate, False)
     b = Batch(plan, [rate] * len(xs), 1, 3.0, 1.0, 0.0, taps=True, spectrogram_taps=True)

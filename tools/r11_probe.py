@@ -61,6 +61,9 @@ else:
     print("rate %d: %d of %d frames differ between the two builds" % (RATE, len(diff), A.size))
     from oracle import pyorc as orc
     L = orc.lib()
+    if os.environ.get("SPX_PROBE_ORACLE_SPEC"):   # the oracle on DFT spec 1 (the unfused transform of rounds 1 - 4) instead of 2
+        L.orc_set_dft_spec(int(os.environ["SPX_PROBE_ORACLE_SPEC"]))
+        print("oracle DFT spec", L.orc_get_dft_spec())
     T = A.shape[1] // NS
     agree = {"first": 0, "second": 0, "neither": 0}
     for seed, idx in diff[:40]:
@@ -79,4 +82,14 @@ else:
         k = "first" if ho == A[seed, idx] else ("second" if ho == B[seed, idx] else "neither")
         agree[k] += 1
         print("batch %d stream %d frame %d: the oracle agrees with the %s build" % (seed, i, f, k))
+        if os.environ.get("SPX_PROBE_DETAIL"):   # this process's library on that stream: which bins differ from the oracle's, by how much
+            from speedy_amd.batch import Batch, Plan
+            plan = Plan(RATE, False)
+            bb = Batch(plan, [x.size], 1, 3.0, 1.0, 0.0, taps=True, spectrogram_taps=True)
+            bb.upload([x])
+            bb.run()
+            g = bb.tap_arrays(0)["spectrogram"][int(f)]
+            o = np.array(rows[int(f)], np.float32)
+            for kk in np.nonzero(g != o)[0]:
+                print("      bin %d: this library %.9g  oracle %.9g  (%d float ulps)" % (kk, g[kk], o[kk], int(g[kk:kk + 1].view(np.int32)[0]) - int(o[kk:kk + 1].view(np.int32)[0])))
     print(agree)
