@@ -790,6 +790,22 @@ def test_twiddle_tables_are_the_oracles_on_frames_that_told_them_apart(orc):
     _sensitive_frames(orc, 48000, [(13, 255, 23), (30, 25, 42)])
 
 
+@pytest.mark.parametrize("rate,batches", [(16000, 40), (22050, 40), (44100, 12), (48000, 12), (11025, 12)])
+def test_every_frame_against_the_oracle_at_scale(rate, batches):
+    """The library against the ORACLE ITSELF on every frame of batches x 256 one-second noise streams: the CPU port with hashing
+    callbacks (oracle/orc_bench.c orc_bench_run_hashed, every host core) hands back one hash per spectrogram row and one per tension
+    frame (15 features + tension + speed), and so does the GPU from its taps -- a million frames per rate here (tools/r11_probe.py
+    oracle 400: ten million per rate, profiles/r05/r5ah_r11_probe.txt).  What a float hides from a test of a few thousand frames --
+    an fp64 last-bit difference shows once in 1e9 magnitudes -- it does not hide from this one: the same comparison found the two
+    defects of round 5 (an unfused stage, the twiddle tables) at six and fifteen frames in ten million."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import r11_probe
+    bad_spec, n_spec, bad_tap, n_tap = r11_probe.against_the_oracle(rate, batches, verbose=False)
+    assert n_spec >= batches * 256 * 90 and n_tap >= batches * 256 * 70, (n_spec, n_tap)
+    assert bad_spec == 0 and bad_tap == 0, (rate, bad_spec, n_spec, bad_tap, n_tap)
+
+
 def _sensitive_frames(orc, rate, cases):
     from speedy_amd.batch import Batch, Plan
     xs = [np.random.default_rng([seed, i]).integers(-20000, 20000, size=rate).astype(np.int16) for seed, i, _ in cases]

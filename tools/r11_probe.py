@@ -3,6 +3,9 @@ difference about once in 2^29 values, so: MANY frames of noise through the GPU's
   python3 tools/r11_probe.py run OUT.npy BATCHES          (SPEEDY_HIP_LIB selects the library build)
   python3 tools/r11_probe.py compare A.npy B.npy          every frame whose hash differs between two builds, and which of the two the
                                                           ORACLE's spectrogram of that frame agrees with
+  python3 tools/r11_probe.py oracle BATCHES               the library against the ORACLE ITSELF, every frame: the CPU port with hashing
+                                                          callbacks (oracle/orc_bench.c orc_bench_run_hashed, all host cores) -- spectrogram
+                                                          rows and features / tension / speed, frame for frame
 (round 5: the hand-written radix-11 stage had kept the unfused sums of DFT spec v1; profiles/r05/r5ah_r11_probe.txt)"""
 import os
 import sys
@@ -22,7 +25,66 @@ def hashes(rows):   # rows: (frames, N) float32 -> int64 per frame
     return rows.view(np.int32).astype(np.int64).sum(axis=1)
 
 
-if sys.argv[1] == "run":
+def against_the_oracle(rate, batches, verbose=True):
+    """(spectrogram rows that differ, rows compared, tension frames that differ, tension frames compared) -- the library against the CPU port."""
+    global RATE
+    RATE = rate
+    import ctypes as C
+    import subprocess
+    import torch
+    from speedy_amd.batch import Batch, Plan
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liborc_bench.so"])
+    L = C.CDLL(os.path.join(ROOT, "oracle", "liborc_bench.so"))
+    L.orc_bench_run_hashed.restype = C.c_double
+    L.orc_bench_run_hashed.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    plan = Plan(RATE, False)
+    n = RATE * SECS
+    b = Batch(plan, [n] * NS, 1, 3.0, 1.0, 0.0, taps=True, spectrogram_taps=True)
+    T = int(b.frames[0])
+    K = max(0, T - plan.F + 1)
+    MAXF = T + 8
+    threads = len(os.sched_getaffinity(0))
+    bad_spec = bad_tap = 0
+    w = None
+    t_cpu = 0.0
+    for seed in range(batches):
+        xs = [stream(seed, i) for i in range(NS)]
+        b.upload(xs)
+        b.run()
+        torch.cuda.synchronize()
+        hs = b.t_spec.view(torch.int32).view(-1, plan.N).to(torch.int64).sum(dim=1).cpu().numpy().reshape(NS, T)
+        if w is None:
+            w = torch.arange(1, 16, device=b.t_features.device, dtype=torch.int64)
+        ht = ((b.t_features.view(torch.int32).view(-1, 15).to(torch.int64) * w).sum(dim=1) + 31 * b.t_tension.view(torch.int32).to(torch.int64)
+              + 37 * b.t_speed.view(torch.int32).to(torch.int64)).cpu().numpy().reshape(NS, -1)
+        buf = np.ascontiguousarray(np.concatenate(xs), np.int16)
+        osp = np.zeros((NS, MAXF), np.int64)
+        otp = np.zeros((NS, MAXF), np.int64)
+        nsp = np.zeros(NS, np.int32)
+        ntp = np.zeros(NS, np.int32)
+        t_cpu += L.orc_bench_run_hashed(buf.ctypes.data, n, NS, RATE, 1, 3.0, 1.0, 0.0, 0, 1000, threads, MAXF, osp.ctypes.data,
+                                        otp.ctypes.data, nsp.ctypes.data, ntp.ctypes.data)
+        assert int(nsp.min()) >= T and int(ntp.min()) >= K, (int(nsp.min()), T, int(ntp.min()), K)
+        ds = np.argwhere(hs != osp[:, :T])
+        dt = np.argwhere(ht[:, :K] != otp[:, :K])
+        bad_spec += len(ds)
+        bad_tap += len(dt)
+        for i, f in ds[:5]:
+            print("batch %d stream %d frame %d: spectrogram row differs from the oracle's" % (seed, i, f))
+        for i, f in dt[:5]:
+            print("batch %d stream %d tension frame %d: features / tension / speed differ from the oracle's" % (seed, i, f))
+    if verbose:
+        print("rate %d: %d batches x %d streams: %d of %d spectrogram rows and %d of %d tension frames differ from the ORACLE's (CPU port %.1f s on %d threads)"
+              % (RATE, batches, NS, bad_spec, batches * NS * T, bad_tap, batches * NS * K, t_cpu, threads))
+    return bad_spec, batches * NS * T, bad_tap, batches * NS * K
+
+
+if __name__ != "__main__":
+    pass
+elif sys.argv[1] == "oracle":
+    against_the_oracle(RATE, int(sys.argv[2]))
+elif sys.argv[1] == "run":
     import torch
     from speedy_amd.batch import Batch, Plan
     out, batches = sys.argv[2], int(sys.argv[3])
