@@ -806,6 +806,18 @@ def test_every_frame_against_the_oracle_at_scale(rate, batches):
     assert bad_spec == 0 and bad_tap == 0, (rate, bad_spec, n_spec, bad_tap, n_tap)
 
 
+@pytest.mark.parametrize("rate", [16000, 22050])
+def test_output_audio_against_the_oracle_at_scale(rate):
+    """... and the audio: 2 048 two-second noise streams per rate (eight batches cycling through mono / stereo, speeds 0.4 ... 5.5,
+    linear / nonlinear, duration feedback), CRC-32 per stream against the CPU port's (tools/r11_probe.py audio 80: 20 480 streams at
+    each of four rates, none differs)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import r11_probe
+    bad, total = r11_probe.audio_against_the_oracle(rate, 8, verbose=False)
+    assert total == 2048 and bad == 0, (rate, bad, total)
+
+
 def _sensitive_frames(orc, rate, cases):
     from speedy_amd.batch import Batch, Plan
     xs = [np.random.default_rng([seed, i]).integers(-20000, 20000, size=rate).astype(np.int16) for seed, i, _ in cases]

@@ -25,7 +25,7 @@ def hashes(rows):   # rows: (frames, N) float32 -> int64 per frame
     return rows.view(np.int32).astype(np.int64).sum(axis=1)
 
 
-def against_the_oracle(rate, batches, verbose=True):
+def against_the_oracle(rate, batches, verbose=True, channels=1, match_matlab=False, feedback=0.0, speed=3.0):
     """(spectrogram rows that differ, rows compared, tension frames that differ, tension frames compared) -- the library against the CPU port."""
     global RATE
     RATE = rate
@@ -38,9 +38,9 @@ def against_the_oracle(rate, batches, verbose=True):
     L.orc_bench_run_hashed.restype = C.c_double
     L.orc_bench_run_hashed.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    plan = Plan(RATE, False)
+    plan = Plan(RATE, match_matlab)
     n = RATE * SECS
-    b = Batch(plan, [n] * NS, 1, 3.0, 1.0, 0.0, taps=True, spectrogram_taps=True)
+    b = Batch(plan, [n] * NS, channels, speed, 1.0, feedback, taps=True, spectrogram_taps=True)
     T = int(b.frames[0])
     K = max(0, T - plan.F + 1)
     MAXF = T + 8
@@ -49,7 +49,8 @@ def against_the_oracle(rate, batches, verbose=True):
     w = None
     t_cpu = 0.0
     for seed in range(batches):
-        xs = [stream(seed, i) for i in range(NS)]
+        xs = [np.random.default_rng([seed, i, channels]).integers(-20000, 20000, size=n * channels).astype(np.int16) if channels > 1
+              else stream(seed, i) for i in range(NS)]
         b.upload(xs)
         b.run()
         torch.cuda.synchronize()
@@ -63,7 +64,7 @@ def against_the_oracle(rate, batches, verbose=True):
         otp = np.zeros((NS, MAXF), np.int64)
         nsp = np.zeros(NS, np.int32)
         ntp = np.zeros(NS, np.int32)
-        t_cpu += L.orc_bench_run_hashed(buf.ctypes.data, n, NS, RATE, 1, 3.0, 1.0, 0.0, 0, 1000, threads, MAXF, osp.ctypes.data,
+        t_cpu += L.orc_bench_run_hashed(buf.ctypes.data, n, NS, RATE, channels, speed, 1.0, feedback, 1 if match_matlab else 0, 1000, threads, MAXF, osp.ctypes.data,
                                         otp.ctypes.data, nsp.ctypes.data, ntp.ctypes.data)
         assert int(nsp.min()) >= T and int(ntp.min()) >= K, (int(nsp.min()), T, int(ntp.min()), K)
         ds = np.argwhere(hs != osp[:, :T])
@@ -75,15 +76,57 @@ def against_the_oracle(rate, batches, verbose=True):
         for i, f in dt[:5]:
             print("batch %d stream %d tension frame %d: features / tension / speed differ from the oracle's" % (seed, i, f))
     if verbose:
-        print("rate %d: %d batches x %d streams: %d of %d spectrogram rows and %d of %d tension frames differ from the ORACLE's (CPU port %.1f s on %d threads)"
-              % (RATE, batches, NS, bad_spec, batches * NS * T, bad_tap, batches * NS * K, t_cpu, threads))
+        print("rate %d ch %d mm %d fb %.2f speed %.1f: %d batches x %d streams: %d of %d spectrogram rows and %d of %d tension frames differ from the ORACLE's (CPU port %.1f s on %d threads)"
+              % (RATE, channels, int(match_matlab), feedback, speed, batches, NS, bad_spec, batches * NS * T, bad_tap, batches * NS * K, t_cpu, threads))
     return bad_spec, batches * NS * T, bad_tap, batches * NS * K
+
+
+def audio_against_the_oracle(rate, batches, verbose=True):
+    """(streams whose OUTPUT AUDIO differs from the CPU port's, streams compared): batch k takes the k-th of a cycle of (channels,
+    speed, nonlinear, feedback) settings on both sides of 1; two-second noise streams of ragged lengths; CRC-32 per stream."""
+    import ctypes as C
+    import subprocess
+    import zlib
+    from speedy_amd.batch import Batch, Plan
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liborc_bench.so"])
+    L = C.CDLL(os.path.join(ROOT, "oracle", "liborc_bench.so"))
+    L.orc_bench_run.restype = C.c_double
+    L.orc_bench_run.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    settings = [(1, 3.5, 1.0, 0.0), (1, 2.0, 0.0, 0.0), (2, 1.5, 1.0, 0.1), (1, 1.2, 1.0, 0.0), (1, 0.7, 0.0, 0.0), (2, 3.0, 1.0, 0.0),
+                (1, 0.4, 1.0, 0.0), (1, 5.5, 0.3, 0.2)]
+    plan = Plan(rate, False)
+    threads = len(os.sched_getaffinity(0))
+    bad = total = 0
+    for k in range(batches):
+        ch, speed, nl, fb = settings[k % len(settings)]
+        n = 2 * rate - 97 * (k % 11)
+        xs = [np.random.default_rng([k, i, 7]).integers(-20000, 20000, size=n * ch).astype(np.int16) for i in range(NS)]
+        b = Batch(plan, [n] * NS, ch, speed, nl, fb)
+        b.upload(xs)
+        b.run()
+        outs = b.results()
+        buf = np.ascontiguousarray(np.concatenate(xs), np.int16)
+        frames = (C.c_long * NS)()
+        crcs = (C.c_uint32 * NS)()
+        L.orc_bench_run(buf.ctypes.data, n, NS, rate, ch, speed, nl, fb, 0, 1000, threads, frames, crcs)
+        for i in range(NS):
+            if zlib.crc32(np.ascontiguousarray(outs[i]).tobytes()) != crcs[i] or outs[i].size != frames[i] * ch:
+                bad += 1
+                if verbose and bad <= 5:
+                    print("batch %d stream %d (ch %d speed %.1f nl %.1f fb %.1f): the output differs from the oracle's" % (k, i, ch, speed, nl, fb))
+        total += NS
+    if verbose:
+        print("rate %d: the OUTPUT AUDIO of %d of %d streams differs from the ORACLE's (%d batches, settings cycled)" % (rate, bad, total, batches))
+    return bad, total
 
 
 if __name__ != "__main__":
     pass
-elif sys.argv[1] == "oracle":
-    against_the_oracle(RATE, int(sys.argv[2]))
+elif sys.argv[1] == "audio":
+    audio_against_the_oracle(RATE, int(sys.argv[2]))
+elif sys.argv[1] == "oracle":   # [channels match_matlab feedback speed]
+    against_the_oracle(RATE, int(sys.argv[2]), True, *([int(sys.argv[3]), bool(int(sys.argv[4])), float(sys.argv[5]), float(sys.argv[6])] if len(sys.argv) > 6 else []))
 elif sys.argv[1] == "run":
     import torch
     from speedy_amd.batch import Batch, Plan
