@@ -90,3 +90,50 @@ def test_log_spec_dispatch(orc):
         assert L.orc_log_spec(1.5) == L.orc_log(1.5)
     finally:
         L.orc_set_log_spec(2)
+
+
+@pytest.mark.parametrize("n", [7, 11, 13, 31])
+def test_twiddles_are_one_sincos_call(orc, n):
+    """DFT spec: a twiddle (cos, -sin)(2 pi t / n) is ONE glibc sincos call -- sincos and the separate sin / cos
+    round a few entries differently in the last bit, and a compiler may or may not merge the pair (gcc does, clang does not: the GPU's
+    tables and the oracle's once differed that way).  An odd-prime transform of the unit impulse at index 1 hands the table back
+    unchanged -- u_1 = 1, P_j = fma(c, 1, 0), Q_j = s * 1 -- so the oracle's entries can be compared with libm's sincos bit for bit
+    (outputs j and n - j are the conjugate pair built from entry min(j, n - j): the butterfly reads half the table)."""
+    import ctypes as C
+    import ctypes.util
+    import math
+    libm = C.CDLL(ctypes.util.find_library("m"))
+    libm.sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    libm.sincos.restype = None
+    x = np.zeros(2 * n)
+    x[2] = 1.0                                   # (re, im) interleaved: element 1 = 1 + 0i
+    out = np.zeros(2 * n)
+    orc.lib().orc_dft_forward(n, x.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double)))
+    for j in range(n):
+        s, c = C.c_double(), C.c_double()
+        t = min(j, n - j)
+        libm.sincos(2.0 * math.pi * t / n, C.byref(s), C.byref(c))
+        im = -s.value if j == t else s.value
+        assert out[2 * j] == c.value and out[2 * j + 1] == im, (n, j, out[2 * j], c.value, out[2 * j + 1], im)
+
+
+@pytest.mark.parametrize("n,t", [(240, 32), (360, 48), (480, 64), (720, 96)])
+def test_twiddle_entries_that_tell_sincos_from_sin(orc, n, t):
+    """The same pin on entries where this glibc's sincos and sin disagree in the last bit (the angle 2 pi 2/15).  In a composite
+    transform whose first radix leaves more than t outputs per branch, output t of the unit impulse at index 1 is table entry t
+    times 1 + 0i through a butterfly of zeros: exact.  Where the two libm routes do disagree the oracle must side with sincos."""
+    import ctypes as C
+    import ctypes.util
+    libm = C.CDLL(ctypes.util.find_library("m"))
+    libm.sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    libm.sincos.restype = None
+    x = np.zeros(2 * n)
+    x[2] = 1.0
+    out = np.zeros(2 * n)
+    orc.lib().orc_dft_forward(n, orc.dptr(x), orc.dptr(out))
+    a = 2.0 * math.pi * t / n
+    s, c = C.c_double(), C.c_double()
+    libm.sincos(a, C.byref(s), C.byref(c))
+    assert out[2 * t] == c.value and out[2 * t + 1] == -s.value
+    if s.value != math.sin(a):
+        assert out[2 * t + 1] != -math.sin(a)
