@@ -1,6 +1,7 @@
 """spx_pipeline (include/speedy_hip.h): the owning pipeline -- batch after batch of one shape, host memory to host memory, with
 the library issuing the copy in, the overlapped batch call and the gather into pinned host memory itself.  Whatever is in flight
 beside a batch, its output must be the oracle's (and spx_batch_run's)."""
+import os
 import zlib
 
 import numpy as np
@@ -358,3 +359,16 @@ def test_two_host_threads_each_with_a_pipeline_on_one_plan(orc):
     for t in th:
         t.join(timeout=300)
     assert not errors, errors
+
+
+@pytest.mark.parametrize("rate", [16000, 22050])
+def test_pipelined_batches_against_the_oracle_at_scale(rate):
+    """The path the bench's `value` is measured on -- device-resident input, outputs left on the device, four buffer sets, walk
+    kernels of consecutive batches overlapping -- against the CPU port at scale: seven settings (mono / stereo, speeds 0.7 ... 5.5,
+    linear / nonlinear, duration feedback) x 4 batches x 256 two-second noise streams, three batches in flight, CRC-32 per stream
+    (tools/r11_probe.py pipeline 40: 71 680 streams per rate, profiles/r05/r5zg_pipeline_probe.txt)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import r11_probe
+    bad, total = r11_probe.pipeline_audio_against_the_oracle(rate, 4, verbose=False)
+    assert total == 7 * 4 * 256 and bad == 0, (rate, bad, total)

@@ -6,6 +6,8 @@ difference about once in 2^29 values, so: MANY frames of noise through the GPU's
   python3 tools/r11_probe.py oracle BATCHES               the library against the ORACLE ITSELF, every frame: the CPU port with hashing
                                                           callbacks (oracle/orc_bench.c orc_bench_run_hashed, all host cores) -- spectrogram
                                                           rows and features / tension / speed, frame for frame
+  python3 tools/r11_probe.py audio BATCHES | pipeline BATCHES    the OUTPUT AUDIO of every stream against the CPU port's (CRC-32), plain
+                                                          calls with the settings cycled | through the owning pipeline object
 (round 5: the hand-written radix-11 stage had kept the unfused sums of DFT spec v1; profiles/r05/r5ah_r11_probe.txt)"""
 import os
 import sys
@@ -121,10 +123,67 @@ def audio_against_the_oracle(rate, batches, verbose=True):
     return bad, total
 
 
+def pipeline_audio_against_the_oracle(rate, batches, verbose=True, seconds=2):
+    """The same comparison through the OWNING PIPELINE OBJECT the bench's headline runs on (spx_pipeline: device-resident input, outputs
+    left on the device, four buffer sets, the walk kernels of consecutive batches overlapping, each batch's producers beside the
+    walk kernels before it): one pipeline per setting, `batches` batches through each with three in flight; every stream's CRC-32
+    against the CPU port's.  (streams that differ, streams compared)"""
+    import ctypes as C
+    import subprocess
+    import zlib
+    import torch
+    from speedy_amd.batch import Pipeline, Plan
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liborc_bench.so"])
+    L = C.CDLL(os.path.join(ROOT, "oracle", "liborc_bench.so"))
+    L.orc_bench_run.restype = C.c_double
+    L.orc_bench_run.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    settings = [(1, 3.5, 1.0, 0.0), (1, 2.0, 0.0, 0.0), (2, 1.5, 1.0, 0.1), (1, 1.2, 1.0, 0.0), (2, 3.0, 1.0, 0.0), (1, 5.5, 0.3, 0.2),
+                (1, 0.7, 0.0, 0.0)]
+    plan = Plan(rate, False)
+    threads = len(os.sched_getaffinity(0))
+    bad = total = 0
+    for s, (ch, speed, nl, fb) in enumerate(settings):
+        n = seconds * rate - 131 * s
+        pipe = Pipeline(plan, [n] * NS, ch, speed, nl, fb, depth=4, device_out=True)
+        flight = []
+
+        def check(k, t, buf):
+            nonlocal bad, total
+            outs = pipe.results(t)
+            frames = (C.c_long * NS)()
+            crcs = (C.c_uint32 * NS)()
+            L.orc_bench_run(buf.ctypes.data, n, NS, rate, ch, speed, nl, fb, 0, 1000, threads, frames, crcs)
+            for i in range(NS):
+                if zlib.crc32(np.ascontiguousarray(outs[i]).tobytes()) != crcs[i] or outs[i].size != frames[i] * ch:
+                    bad += 1
+                    if verbose and bad <= 5:
+                        print("setting %d batch %d stream %d (ch %d speed %.1f nl %.1f fb %.1f): the output differs from the oracle's"
+                              % (s, k, i, ch, speed, nl, fb))
+            total += NS
+
+        for k in range(batches):
+            buf = np.random.default_rng([s, k, 11]).integers(-20000, 20000, size=NS * n * ch).astype(np.int16)
+            dev = torch.from_numpy(buf).cuda()
+            flight.append((k, pipe.submit(dev), buf, dev))
+            if len(flight) > 3:
+                k0, t0, b0, _ = flight.pop(0)
+                check(k0, t0, b0)
+        for k0, t0, b0, _ in flight:
+            check(k0, t0, b0)
+        pipe.close()
+    if verbose:
+        print("rate %d: through the pipeline object, the OUTPUT AUDIO of %d of %d streams differs from the ORACLE's (%d settings x %d batches)"
+              % (rate, bad, total, len(settings), batches))
+    return bad, total
+
+
 if __name__ != "__main__":
     pass
 elif sys.argv[1] == "audio":
     audio_against_the_oracle(RATE, int(sys.argv[2]))
+elif sys.argv[1] == "pipeline":
+    pipeline_audio_against_the_oracle(RATE, int(sys.argv[2]))
 elif sys.argv[1] == "oracle":   # [channels match_matlab feedback speed]
     against_the_oracle(RATE, int(sys.argv[2]), True, *([int(sys.argv[3]), bool(int(sys.argv[4])), float(sys.argv[5]), float(sys.argv[6])] if len(sys.argv) > 6 else []))
 elif sys.argv[1] == "run":
