@@ -467,3 +467,15 @@ def test_sub_batches_of_an_overlapped_call_with_taps(orc):
                 assert np.array_equal(got[key], ref[key]), (i, key)
     o = orc.compress_sound(xs[151], rate, 1, 3.5, 1.0, 0.0, False, chunk=1000)
     assert np.array_equal(bs[0].tap_arrays(151)["speed"], o["speed"]) and np.array_equal(bs[0].tap_arrays(151)["tension"], o["tension"])
+
+
+def test_mixed_batches_against_the_oracle_at_scale():
+    """BASELINE configs[4]'s shard shape (256 streams: two rates, mono and stereo, speeds 1.5 and 3.5 in one spx_batch_run_mixed call),
+    eight batches of ragged two-second noise streams, plain and pipelined calls taking turns: every stream's CRC-32 against the CPU
+    port's (tools/r11_probe.py mixed 80: 20 480 streams, none differs -- profiles/r05/r5zh_mixed_probe.txt)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import r11_probe
+    bad, total = r11_probe.mixed_audio_against_the_oracle(8, verbose=False)
+    assert total == 8 * 256 and bad == 0, (bad, total)

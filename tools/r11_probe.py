@@ -178,10 +178,79 @@ def pipeline_audio_against_the_oracle(rate, batches, verbose=True, seconds=2):
     return bad, total
 
 
+def mixed_audio_against_the_oracle(batches, verbose=True, seconds=2):
+    """BASELINE configs[4]'s shard shape -- 256 streams, stream i at 16 kHz if i is even else 22.05 kHz, mono if (i / 2) is even else
+    stereo, speed 1.5 if (i / 4) is even else 3.5, nonlinear -- as ONE spx_batch_run_mixed call per batch: noise streams of ragged
+    lengths, even batches as plain calls, odd ones pipelined (run_ahead, two batch objects taking turns, the way bench.py's
+    config4 leg is timed); every stream's CRC-32 against the CPU port's, kind by kind.  (streams that differ, streams compared)"""
+    import ctypes as C
+    import subprocess
+    import zlib
+    from speedy_amd import config4 as C4
+    from speedy_amd.batch import MixedBatch, Plan
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liborc_bench.so"])
+    L = C.CDLL(os.path.join(ROOT, "oracle", "liborc_bench.so"))
+    L.orc_bench_run.restype = C.c_double
+    L.orc_bench_run.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    plans = [Plan(r, False) for r in C4.RATES]
+    threads = len(os.sched_getaffinity(0))
+    ids = list(range(NS))
+    bad = total = 0
+    turn = {}
+    pending = []
+
+    def check(k, b, xs, lens):
+        nonlocal bad, total
+        outs = b.results()
+        for kind in range(8):
+            members = [i for i in ids if C4.kind(i) == kind]
+            rate, ch, speed = C4.cfg(kind)
+            n = lens[kind]
+            buf = np.ascontiguousarray(np.concatenate([xs[i] for i in members]), np.int16)
+            frames = (C.c_long * len(members))()
+            crcs = (C.c_uint32 * len(members))()
+            L.orc_bench_run(buf.ctypes.data, n, len(members), rate, ch, speed, 1.0, 0.0, 0, 1000, threads, frames, crcs)
+            for j, i in enumerate(members):
+                if zlib.crc32(np.ascontiguousarray(outs[i]).tobytes()) != crcs[j] or outs[i].size != frames[j] * ch:
+                    bad += 1
+                    if verbose and bad <= 5:
+                        print("batch %d stream %d (rate %d ch %d speed %.1f): the output differs from the oracle's" % (k, i, rate, ch, speed))
+            total += len(members)
+
+    for k in range(batches):
+        lens = [seconds * C4.cfg(kind)[0] - 89 * ((k + kind) % 7) for kind in range(8)]   # per kind: the oracle call takes one length
+        xs = [np.random.default_rng([k, i, 13]).integers(-20000, 20000, size=lens[C4.kind(i)] * C4.cfg(i)[1]).astype(np.int16) for i in ids]
+        key = (tuple(lens), k % 4)
+        b = turn.get(key)
+        if b is None:
+            b = MixedBatch(plans, [C4.RATES.index(C4.cfg(i)[0]) for i in ids], [lens[C4.kind(i)] for i in ids],
+                           [C4.cfg(i)[1] for i in ids], [C4.cfg(i)[2] for i in ids], 1.0, 0.0)
+            if len(turn) >= 8:
+                turn.pop(next(iter(turn)))
+            turn[key] = b
+        b.upload(xs)
+        if k % 2 == 0:
+            b.run()
+        else:
+            b.run_ahead()
+        pending.append((k, b, xs, lens))
+        if len(pending) > 1:          # the previous batch is checked while this one runs
+            check(*pending.pop(0))
+    for q in pending:
+        check(*q)
+    if verbose:
+        print("configs[4] shard shape: the OUTPUT AUDIO of %d of %d streams differs from the ORACLE's (%d mixed batches, plain and pipelined calls taking turns)"
+              % (bad, total, batches))
+    return bad, total
+
+
 if __name__ != "__main__":
     pass
 elif sys.argv[1] == "audio":
     audio_against_the_oracle(RATE, int(sys.argv[2]))
+elif sys.argv[1] == "mixed":
+    mixed_audio_against_the_oracle(int(sys.argv[2]))
 elif sys.argv[1] == "pipeline":
     pipeline_audio_against_the_oracle(RATE, int(sys.argv[2]))
 elif sys.argv[1] == "oracle":   # [channels match_matlab feedback speed]
