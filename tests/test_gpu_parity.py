@@ -873,7 +873,7 @@ def test_kernel_resources_of_every_form_the_engine_selects():
         (16000, 2, 256, 0, 0): (16 * 4 + 4, 96, 136),     # <4, 4, 16000, 1, 1>
         (22050, 1, 256, 0, 0): (16 * 4 + 4, 120, 0),      # <4, 4, 22050, 1, 0>
         (22050, 1, 256, 0, 1): (16 * 4 + 0, 128, 12),      # <4, 0, 22050, 0, 0>: the lean form of the concurrent mode
-        (22050, 2, 256, 0, 0): (16 * 4 + 4, 128, 28),     # <4, 4, 22050, 1, 1>
+        (22050, 2, 256, 0, 0): (16 * 4 + 4, 128, 36),     # <4, 4, 22050, 1, 1> (36 under the max-memory-clause scheduling of round 5, 28 before)
         (16000, 1, 2048, 0, 0): (16 * 2 + 0, 128, 28),    # <2, 0, 16000, 0, 0>: the throughput form
         (16000, 2, 2048, 0, 0): (16 * 2 + 0, 128, 108),
         (22050, 1, 2048, 0, 0): (16 * 2 + 0, 128, 80),

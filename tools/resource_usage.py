@@ -13,7 +13,8 @@ FLAGS = ("-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast
 def main():
     rows = {}
     for src in ("spx_hot.hip", "spx_walk.hip"):
-        r = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + sys.argv[1:] + ["-c", src, "-o", "/dev/null"],
+        hot = ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"] if src == "spx_hot.hip" else []   # (the Makefile's SPX_HOT_SCHED)
+        r = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + hot + sys.argv[1:] + ["-c", src, "-o", "/dev/null"],
                            cwd=os.path.join(ROOT, "speedy_amd", "csrc"), capture_output=True, text=True)
         cur = None
         for line in r.stderr.splitlines():
