@@ -218,15 +218,38 @@ static int orc_primitive_root(int n) { /* smallest g whose powers visit all of 1
   return 0;
 }
 
-/* A twiddle factor (cos, -sin)(a): ONE sincos call.  Part of the DFT spec: glibc's sincos and its sin / cos
- * round a few table entries differently in the last bit, and a compiler may or may not merge a cos and a sin of one argument into a
- * sincos (gcc does from -O1 on, clang does not) -- so the call is spelled out here and in the library's table builder
- * (spx_engine.hip spx_twiddle), and the two tables are the same whatever built them. */
-static inline void orc_twiddle(double a, double* c, double* ms) {
+/* A twiddle factor (cos, -sin)(2 pi k / n): orc_twiddle.h -- IEEE-754 double operations only, no libm call, the same bits on every
+ * machine (DFT spec tables v3, round 6).  Rounds 1-5 called the box's libm (round 5: "one glibc sincos call"); orc_set_twiddle_spec(2)
+ * gives those tables back for A/B (a plan reads the setting when it is created). */
+#include <stdio.h>
+#include "orc_twiddle.h"
+#include "orc_twiddle_hashes.h"
+static int orc_twiddle_spec_v = 3;
+void orc_set_twiddle_spec(int v) { orc_twiddle_spec_v = v == 2 ? 2 : 3; }
+int orc_get_twiddle_spec(void) { return orc_twiddle_spec_v; }
+void orc_twiddle_entry(long k, long n, double* c, double* s) { orc_sincos_2pi(k, n, c, s); }
+unsigned long long orc_twiddle_hash(long den, long count) { return (unsigned long long)orc_twiddle_table_hash(den, count); }
+static inline void orc_twiddle(long k, long n, double* c, double* ms) {
   double sn, cs;
-  sincos(a, &sn, &cs);
+  if (orc_twiddle_spec_v == 2) sincos(2.0 * M_PI * (double)k / (double)n, &sn, &cs);
+  else orc_sincos_2pi(k, n, &cs, &sn);
   *c = cs;
-  *ms = -sn;
+  *ms = 0.0 - sn;
+}
+/* the tables of the sizes the library compiles in are pinned (orc_twiddle_hashes.h, generated from a 60-digit evaluation):
+ * a build whose arithmetic strays (fast-math, a contracted multiply-add) is refused here instead of producing other audio */
+static void orc_check_twiddles(long den, long count, const double* tw) {
+  if (orc_twiddle_spec_v != 3) return;
+  for (unsigned i = 0; i < sizeof(orc_twiddle_pins) / sizeof(orc_twiddle_pins[0]); i++) {
+    if (orc_twiddle_pins[i].den != den || orc_twiddle_pins[i].count != count) continue;
+    uint64_t h = 0xcbf29ce484222325ull;
+    const unsigned char* b = (const unsigned char*)tw;
+    for (long j = 0; j < 16 * count; j++) { h ^= b[j]; h *= 0x100000001b3ull; }
+    if (h != orc_twiddle_pins[i].hash) {
+      fprintf(stderr, "oracle: twiddle table (2 pi t / %ld, %ld entries) does not hash to its pinned value -- built with fast-math or fp contraction?\n", den, count);
+      abort();
+    }
+  }
 }
 static orc_plan* orc_plan_create(int n) {
   orc_plan* p = (orc_plan*)calloc(1, sizeof(orc_plan));
@@ -235,8 +258,9 @@ static orc_plan* orc_plan_create(int n) {
   p->tw = (double*)malloc(sizeof(double) * 2 * n);
   p->work = (double*)malloc(sizeof(double) * 8 * n);
   for (int t = 0; t < n; t++) {
-    orc_twiddle(2.0 * M_PI * t / n, &p->tw[2 * t], &p->tw[2 * t + 1]);
+    orc_twiddle(t, n, &p->tw[2 * t], &p->tw[2 * t + 1]);
   }
+  orc_check_twiddles(n, n, p->tw);
   if (orc_use_rader(n)) {
     int m = n - 1;
     p->sub = orc_plan_create(m);
@@ -507,8 +531,9 @@ static orc_specplan* orc_specplan_create(int W) {
   sp->z = (double*)malloc(sizeof(double) * 2 * W);
   sp->Z = (double*)malloc(sizeof(double) * 2 * W);
   for (int k = 0; k < W; k++) {
-    orc_twiddle(2.0 * M_PI * k / (2.0 * W), &sp->tw2[2 * k], &sp->tw2[2 * k + 1]);
+    orc_twiddle(k, 2L * W, &sp->tw2[2 * k], &sp->tw2[2 * k + 1]);
   }
+  orc_check_twiddles(2L * W, W, sp->tw2);
   return sp;
 }
 static void orc_specplan_destroy(orc_specplan* sp) {
@@ -617,8 +642,13 @@ orc_speedyStream orc_speedyCreateStream(int sample_rate, int match_matlab) { /* 
   s->spectrogram_history = (float**)calloc(s->spec_hist, sizeof(float*));
   for (int i = 0; i < s->spec_hist; i++)
     s->spectrogram_history[i] = (float*)calloc(s->fft_size, sizeof(float));
-  for (int i = 0; i < s->window_size; i++) /* speedy.c:256-258: double expression -> float */
-    s->window[i] = 0.54 - 0.46 * cos(2 * M_PI * i / (s->window_size - 1.0));
+  for (int i = 0; i < s->window_size; i++) { /* speedy.c:256-258: double expression -> float */
+    /* the cosine from orc_twiddle.h (no libm call: the same window on every machine); spec 2: libm's, as rounds 1-5 */
+    double c, sn;
+    if (orc_twiddle_spec_v == 2 || s->window_size < 2) c = cos(2 * M_PI * i / (s->window_size - 1.0));
+    else orc_sincos_2pi(i, s->window_size - 1, &c, &sn);
+    s->window[i] = 0.54 - 0.46 * c;
+  }
   s->mean_spectrogram_energy = 2.14204; /* speedy.c:263-267 */
   s->mean_emphasis_weighted_local_difference = 123.837;
   s->mean_emphasis_weighted_lpf = 123.979;

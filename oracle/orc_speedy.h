@@ -76,6 +76,12 @@ void orc_set_log_spec(int v);      /* 1: v1 for every argument (A/B against roun
 int orc_get_log_spec(void);
 void orc_set_dft_spec(int v);      /* 1: the unfused transform of rounds 1-4; 2 (default): multiply-add pairs fused */
 int orc_get_dft_spec(void);
+/* the twiddle tables and the Hamming window's cosine: 3 (default, round 6): orc_twiddle.h -- IEEE double operations only, the same bits
+ * on every machine; 2: the box's libm (one sincos call per entry), as rounds 1-5.  Read when a stream / plan is created. */
+void orc_set_twiddle_spec(int v);
+int orc_get_twiddle_spec(void);
+void orc_twiddle_entry(long k, long n, double* c, double* s);   /* cos, sin (2 pi k / n) */
+unsigned long long orc_twiddle_hash(long den, long count);      /* FNV-1a of the table (cos, -sin)(2 pi t / den), t < count */
 /* Forward complex DFT of length n (any n >= 1): in/out are interleaved re,im doubles. */
 void orc_dft_forward(int n, const double* in, double* out);
 /* O(n^2) definition, long-double accumulation; the checker for orc_dft_forward. */

@@ -71,6 +71,10 @@ def lib():
         "orc_get_log_spec": (C.c_int, []),
         "orc_set_dft_spec": (None, [C.c_int]),
         "orc_get_dft_spec": (C.c_int, []),
+        "orc_set_twiddle_spec": (None, [C.c_int]),
+        "orc_get_twiddle_spec": (C.c_int, []),
+        "orc_twiddle_entry": (None, [C.c_long, C.c_long, c_double_p, c_double_p]),
+        "orc_twiddle_hash": (C.c_ulonglong, [C.c_long, C.c_long]),
         "orc_dft_forward": (None, [i, c_double_p, c_double_p]),
         "orc_dft_naive": (None, [i, c_double_p, c_double_p]),
         "orc_spectrum_magnitudes": (None, [i, c_float_p, c_float_p]),

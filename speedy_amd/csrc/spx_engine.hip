@@ -14,6 +14,8 @@
 #include "../../include/speedy_hip.h"
 #include "spx_internal.h"
 #include "spx_mode.h"
+#include "spx_twiddle.h"
+#include "spx_twiddle_hashes.h"
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -67,6 +69,10 @@ struct SpxRange {
 };
 
 #define SPX_MAX_CHUNKS 16
+// The plan's ring of earlier calls (ring_wait below) and the library's walk streams per device (dev_walk_streams): the walk kernels
+// of consecutive pipelined calls take turns on up to SPX_MAX_WALK_STREAMS streams, and the ring remembers twice as many calls.
+#define SPX_MAX_WALK_STREAMS 4
+#define SPX_RING (2 * SPX_MAX_WALK_STREAMS)
 // Pinned staging slot for the small host tables of a call (job tables, tile order): the async copies read it after the
 // call has returned, so it is plan-owned and reused only once its copies have retired.
 struct SpxStage {
@@ -106,10 +112,10 @@ struct spx_plan {
   hipEvent_t ev_chunk[SPX_MAX_CHUNKS] = {};
   // spx_batch_run_ahead: the walk kernels of the plan's previous FOUR calls (ring_wait / ring_record below), the started-counter
   // of the last one
-  hipEvent_t ev_walk[4] = {nullptr, nullptr, nullptr, nullptr};   // slot = call number mod 4
-  bool ev_walk_valid[4] = {false, false, false, false};
-  void* ring_ws[4] = {nullptr, nullptr, nullptr, nullptr};         // the workspace and the caller's stream of the call in the slot
-  hipStream_t ring_st[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_walk[SPX_RING] = {};   // slot = call number mod SPX_RING
+  bool ev_walk_valid[SPX_RING] = {};
+  void* ring_ws[SPX_RING] = {};         // the workspace and the caller's stream of the call in the slot
+  hipStream_t ring_st[SPX_RING] = {};
   int ahead_calls = 0;
   hipEvent_t ev_call[2] = {nullptr, nullptr};   // the caller's stream as it stood when the last two pipelined calls were made
   const void* ahead_last_out = nullptr;
@@ -232,11 +238,25 @@ int64_t spx_internal_out_bound(const SpxPlanDev& P, int64_t n_in, float speed, b
   return (int64_t)((double)(n_in + 2 * (int64_t)P.maxRequired) * (2.0 / s)) + slack;
 }
 
-static int dev_walk_streams(int dev, hipStream_t* w0, hipStream_t* w1);   // (defined with the launch code below)
+static int dev_walk_streams(int dev, hipStream_t* w, int n);   // (defined with the launch code below)
+static int walk_stream_count();
 void spx_internal_set_error(const char* msg) { g_err = msg ? msg : ""; }   // other translation units' errors reach spx_last_error
 extern "C" {
 
 const char* spx_last_error(void) { return g_err.c_str(); }
+// (host-only diagnostics, no GPU needed: tests/test_oracle_twiddle.py compares the library's twiddle routine with the oracle's and
+// with a 60-digit evaluation entry by entry)
+void spx_debug_twiddle_entry(long k, long n, double* c, double* s) { spx_tw::sincos_2pi(k, n, c, s); }
+unsigned long long spx_debug_twiddle_hash(long den, long count) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (long t = 0; t < count; t++) {
+    double e[2];
+    spx_tw::entry(t, den, e);
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(e);
+    for (int i = 0; i < 16; i++) { h ^= b[i]; h *= 0x100000001b3ull; }
+  }
+  return h;
+}
 int spx_abi_version(void) { return 1; }
 
 static int factor_radices(int n, int* radix) {  // DESIGN.md "DFT spec": 4s, then 2, 3s, 5s, other primes ascending
@@ -333,25 +353,18 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
   int* perm = reinterpret_cast<int*>(tp + n_tp + 8);
   int* iperm = perm + n_ri;
   int* qlog = iperm + n_ri;
-  // A twiddle factor (cos, -sin)(a) is ONE sincos call -- part of the DFT spec since the end of round 5: glibc's sincos
-  // and its separate sin / cos round a few entries differently in the last bit; gcc merges a cos and a sin of one argument into a
-  // sincos, clang (this file's host compiler) does not, so until then the oracle's tables (gcc) and these differed in a few last
-  // bits -- an fp64 difference that float magnitudes show about once in 1e9 values (tools/r11_probe.py found it).
-  auto spx_twiddle = [](double a, double* c, double* ms) {
-    double sn, cs;
-    sincos(a, &sn, &cs);
-    *c = cs;
-    *ms = -sn;
-  };
+  // A twiddle factor (cos, -sin)(2 pi t / den) comes from spx_twiddle.h: IEEE double operations on the integers (t, den), no libm call --
+  // the same bits on every machine (round 6; rounds 1-5 took the box's libm, round 5 "one sincos call", so GPU == oracle held on any
+  // one box only).  The Hamming window's cosine likewise (speedy.c:256-258: a double expression stored as float).
   for (int t = 0; t < W; t++) {
-    spx_twiddle(2.0 * M_PI * t / W, &tw[2 * t], &tw[2 * t + 1]);
-    spx_twiddle(2.0 * M_PI * t / (2.0 * W), &tw2[2 * t], &tw2[2 * t + 1]);
-    win[t] = 0.54 - 0.46 * cos(2 * M_PI * t / (W - 1.0));  // speedy.c:256-258
+    spx_tw::entry(t, W, &tw[2 * t]);
+    spx_tw::entry(t, 2L * W, &tw2[2 * t]);
+    double c = 1.0, sn = 0.0;
+    if (W > 1) spx_tw::sincos_2pi(t, W - 1, &c, &sn);
+    win[t] = 0.54 - 0.46 * c;  // speedy.c:256-258
   }
   if (rader) {
-    for (int t = 0; t < M; t++) {
-      spx_twiddle(2.0 * M_PI * t / M, &twM[2 * t], &twM[2 * t + 1]);
-    }
+    for (int t = 0; t < M; t++) spx_tw::entry(t, M, &twM[2 * t]);
     int g = 2;  // smallest primitive root of W
     for (; g < W; g++) {
       long v = 1;
@@ -367,6 +380,18 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
     for (int q = 0; q < M; q++) { b[2 * q] = tw[2 * iperm[q]]; b[2 * q + 1] = tw[2 * iperm[q] + 1]; }
     spx_host_dft(M, d.radixM, d.nstagesM, twM, b.data(), bfft);
   }
+  // the tables of the compiled-in window sizes are pinned (spx_twiddle_hashes.h, generated by tools/twiddle_tables.py from a 60-digit
+  // evaluation): a build whose host arithmetic strays (fast-math, a contracted multiply-add) is refused here, loudly
+  {
+    const struct { long den, count; const double* t; } built[3] = {{W, W, tw}, {2L * W, W, tw2}, {rader ? M : 0, rader ? M : 0, twM}};
+    for (const auto& b : built)
+      for (const auto& pin : spx_twiddle_pins)
+        if (b.count > 0 && pin.den == b.den && pin.count == b.count && spx_tw::fnv1a(b.t, 16 * (size_t)b.count) != pin.hash) {
+          delete p;
+          fail(-1, "spx_plan_create: a twiddle table does not hash to its pinned value (spx_twiddle_hashes.h) -- host code built with fast-math or fp contraction?");
+          return nullptr;
+        }
+  }
   for (int i = 0; i <= d.F; i++) tf[i] = (d.F - i) / (float)d.F;    // speedy.c:597
   for (int i = 0; i <= d.Pp; i++) tp[i] = (d.Pp - i) / (float)d.Pp;  // speedy.c:604
   {
@@ -374,8 +399,8 @@ spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
     // process creates later (a pipeline object's run and copy streams, the caller's own): HIP maps streams onto hardware queues
     // and pipes in creation order, and with the pipeline's two streams created FIRST its resident loop read 1.15 instead of 1.03 ms
     // per batch (profiles/r05/r5c_order_probe.txt).
-    hipStream_t w0 = nullptr, w1 = nullptr;
-    (void)dev_walk_streams(p->device, &w0, &w1);
+    hipStream_t w[SPX_MAX_WALK_STREAMS];
+    (void)dev_walk_streams(p->device, w, walk_stream_count());
     (void)hipGetLastError();
   }
   if (hipMalloc(&p->tables, bytes) != hipSuccess ||
@@ -611,20 +636,31 @@ static int dev_side_streams(int dev, hipStream_t* side, hipStream_t* side2) {
   return 0;
 }
 
-// The walk kernels of consecutive pipelined calls take turns on two streams of the library's (run_impl): the device's SECOND
-// side stream -- idle in that order: the tension kernel runs behind the analysis on the first -- and one more.  Four streams
-// per device in all, the caller's included: one per hardware queue of HIP's default four, whatever order they are first used in
-// (with a fifth stream two of them shared a queue, or queues of one pipe, depending on which mode the process had run first:
-// 1.43 against 1.39 ms per step on the bench batch).
-static int dev_walk_streams(int dev, hipStream_t* w0, hipStream_t* w1) {
+// The walk kernels of consecutive pipelined calls take turns on streams of the library's (run_impl): the device's SECOND side
+// stream -- idle in that order: the tension kernel runs behind the analysis on the first -- and up to three more.  Round 4 ran two
+// (four streams per device in all, the caller's included: one per hardware queue of HIP's default four); since round 5 the library
+// asks for eight hardware queues, and round 6 lets the mode decide how many walk launches are in flight (walk_stream_count).
+static int walk_stream_count() {
+  static const int n = [] {
+    const char* e = spx_tuning_env("SPX_WALK_STREAMS");
+    if (!e && spx_tuning_env("SPX_WALK_STREAMS3")) return 3;
+    const int v = e ? atoi(e) : 2;
+    return v < 1 ? 1 : (v > SPX_MAX_WALK_STREAMS ? SPX_MAX_WALK_STREAMS : v);
+  }();
+  return n;
+}
+static int dev_walk_streams(int dev, hipStream_t* w, int n) {
   static std::mutex mu;
-  static hipStream_t s3[64];
+  static hipStream_t s3[64][SPX_MAX_WALK_STREAMS];   // [.][0] unused: the first walk stream is the second side stream
   hipStream_t side = nullptr, side2 = nullptr;
   if (dev_side_streams(dev, &side, &side2)) return -1;
   const int d = (dev >= 0 && dev < 64) ? dev : 0;
   std::lock_guard<std::mutex> g(mu);
-  if (!s3[d] && hipStreamCreateWithFlags(&s3[d], hipStreamNonBlocking) != hipSuccess) { s3[d] = nullptr; return -1; }
-  *w0 = side2; *w1 = s3[d];
+  w[0] = side2;
+  for (int i = 1; i < n && i < SPX_MAX_WALK_STREAMS; i++) {
+    if (!s3[d][i] && hipStreamCreateWithFlags(&s3[d][i], hipStreamNonBlocking) != hipSuccess) { s3[d][i] = nullptr; return -1; }
+    w[i] = s3[d][i];
+  }
   return 0;
 }
 
@@ -632,10 +668,11 @@ static int dev_walk_streams(int dev, hipStream_t* w0, hipStream_t* w1) {
 // ring_note: where the caller's stream stands when the call is MADE (an overlapped call orders its walk kernel behind the
 // PREVIOUS call's note, whatever kind of call that was).
 // ring_wait: which earlier calls a pipelined call's producers wait for (on `sa`).  The walk kernels of pipelined calls may run
-// on two streams taking turns (spx_batch_run_overlapped), so "the call before" says nothing about the calls before that one:
-//   - the calls three and four back, always: between them they close both walk streams' histories (everything older is done),
-//     which also covers a caller that rotates three or four workspaces;
-//   - the calls one and two back when they used THIS workspace (two workspaces taking turns: the call two back) or another
+// on up to SPX_MAX_WALK_STREAMS streams taking turns (spx_batch_run_overlapped), so "the call before" says nothing about the
+// calls before that one.  The ring remembers SPX_RING = 2 x that many calls:
+//   - the older half, always: SPX_MAX_WALK_STREAMS consecutive calls close every walk stream's history (everything older is
+//     done), which also covers a caller that rotates more workspaces than the ring's younger half remembers;
+//   - the younger half when they used THIS workspace (two workspaces taking turns: the call two back) or another
 //     caller stream (then the order of the caller's stream says nothing about them).
 // A caller that rotates three workspaces therefore gets its producers started while the walk kernels of BOTH previous calls are
 // still running.  *waited_prev: the producers were made to wait for the call right before this one (nothing of it is in flight
@@ -650,12 +687,12 @@ static int ring_note(spx_plan* plan, hipStream_t st) {
   return 0;
 }
 static int ring_wait(spx_plan* plan, hipStream_t sa, const void* ws, hipStream_t st, bool* waited_prev) {
-  const int c = plan->ahead_calls & 3;
+  const int c = plan->ahead_calls % SPX_RING;
   if (waited_prev) *waited_prev = false;
-  for (int back = 4; back >= 1; back--) {
-    const int j = (c + 4 - back) & 3;          // slot of the call `back` calls ago
+  for (int back = SPX_RING; back >= 1; back--) {
+    const int j = (c + SPX_RING - back) % SPX_RING;          // slot of the call `back` calls ago
     if (!plan->ev_walk_valid[j]) continue;
-    if (back >= 3 || plan->ring_ws[j] == ws || plan->ring_st[j] != st) {
+    if (back > SPX_RING / 2 || plan->ring_ws[j] == ws || plan->ring_st[j] != st) {
       HIPCHK(hipStreamWaitEvent(sa, plan->ev_walk[j], 0));
       if (back == 1 && waited_prev) *waited_prev = true;
     }
@@ -663,13 +700,13 @@ static int ring_wait(spx_plan* plan, hipStream_t sa, const void* ws, hipStream_t
   return 0;
 }
 static bool ring_previous_in_flight(spx_plan* plan) {
-  const int j = (plan->ahead_calls + 3) & 3;
+  const int j = (plan->ahead_calls + SPX_RING - 1) % SPX_RING;
   const bool f = plan->ev_walk_valid[j] && hipEventQuery(plan->ev_walk[j]) == hipErrorNotReady;
   (void)hipGetLastError();
   return f;
 }
 static int ring_record(spx_plan* plan, hipStream_t on, void* ws, hipStream_t st, const void* out, const void* n_out, bool detached = false) {
-  const int c = plan->ahead_calls & 3;
+  const int c = plan->ahead_calls % SPX_RING;
   if (!plan->ev_walk[c]) HIPCHK(hipEventCreateWithFlags(&plan->ev_walk[c], hipEventDisableTiming));
   HIPCHK(hipEventRecord(plan->ev_walk[c], on));
   if (on != st && !detached) HIPCHK(hipStreamWaitEvent(st, plan->ev_walk[c], 0));   // the caller's stream is done when the walk is
@@ -878,7 +915,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   const SpxModeEnv E = mode_env();
   SpxModeRuntime T;
   memset(&T, 0, sizeof(T));
-  const int two_back = (plan->ahead_calls + 2) & 3;
+  const int two_back = (plan->ahead_calls + SPX_RING - 2) % SPX_RING;
   T.two_workspaces = plan->ev_walk_valid[two_back] && plan->ring_ws[two_back] == ws;
   T.trial_key = ((long long)n << 40) ^ ((long long)L.total_frames << 8) ^ (maxC << 3) ^ (any_speed ? 4 : 0) ^ (speedup_only ? 2 : 0) ^ (opt.overlap_req ? 1 : 0);
   T.device_ours = device_ours_cb;
@@ -945,23 +982,11 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   if (do_w && !force && !detached && ring_note(plan, st)) return -2;
   if (do_w && !force && detached) { plan->ev_call_valid[plan->ahead_calls & 1] = false; plan->ev_call_st[plan->ahead_calls & 1] = nullptr; }
   if (M.walk2) {
-    hipStream_t w0 = nullptr, w1 = nullptr;
-    if (dev_walk_streams(plan->device, &w0, &w1)) return fail(-1, "spx_batch: no walk streams");
+    hipStream_t wst[SPX_MAX_WALK_STREAMS];
+    const int nws = walk_stream_count();
+    if (dev_walk_streams(plan->device, wst, nws)) return fail(-1, "spx_batch: no walk streams");
     const int cur = plan->ahead_calls & 1;
-    stw = cur ? w1 : w0;
-#ifdef SPX_TUNING
-    {
-      // A/B: THREE walk streams taking turns (a third lean walk kernel may take the places the short chains of the other two leave)
-      static const bool three = getenv("SPX_WALK_STREAMS3") != nullptr;
-      static hipStream_t w2[64];
-      if (three) {
-        const int dv = (plan->device >= 0 && plan->device < 64) ? plan->device : 0;
-        if (!w2[dv]) HIPCHK(hipStreamCreateWithFlags(&w2[dv], hipStreamNonBlocking));
-        const int k3 = plan->ahead_calls % 3;
-        stw = k3 == 0 ? w0 : (k3 == 1 ? w1 : w2[dv]);
-      }
-    }
-#endif
+    stw = wst[plan->ahead_calls % nws];
     const bool same_out = !opt.sub && (out == plan->ahead_last_out || n_out == plan->ahead_last_nout);
     // (the previous call of the plan on ANOTHER stream, or a detached one -- a pipeline object at work on the same plan: its note says
     // nothing about this caller's stream, so the walk kernel is ordered behind everything that is on it now)

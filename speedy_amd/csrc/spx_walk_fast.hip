@@ -1054,6 +1054,12 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   // exactly one workgroup barrier before the next command is published, and the two slots alternate, so a slot is
   // rewritten only after the output waves have consumed it.  Field k of a command is written by lane k of the last
   // search wave (v_writelane: no EXEC juggling).  NWC == 0: the search waves do the output work themselves.
+#ifdef SPX_EXP_NO_OUTPUT_LEAN   // (diagnostic builds: the forms without output waves produce NO audio -- the chain's length without its output work)
+#define SPX_LEAN_OUTPUTS(CP_N, CP_SRC, CP_OUT) do { } while (0)
+#else
+#define SPX_LEAN_OUTPUTS(CP_N, CP_SRC, CP_OUT) \
+  fast_outputs<64 * NWM, MCH>(X, tid, xf_n, xf_down, xf_period, xf_out, (int)(CP_N), (pos_t)(CP_SRC), (pos_t)(CP_OUT), limit, wbase)
+#endif
 #define FAST_PUBLISH(TYPE, CP_N, CP_SRC, CP_OUT, NB)                                                                   \
   do {                                                                                                                 \
     if constexpr (NWC > 0) {                                                                                           \
@@ -1075,8 +1081,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
       }                                                                                                                \
       seq++;                                                                                                           \
     } else {                                                                                                           \
-      fast_outputs<64 * NWM, MCH>(X, tid, xf_n, xf_down, xf_period, xf_out, (int)(CP_N), (pos_t)(CP_SRC), (pos_t)(CP_OUT),  \
-                             limit, wbase);                                                                            \
+      SPX_LEAN_OUTPUTS(CP_N, CP_SRC, CP_OUT);                                                                          \
     }                                                                                                                  \
     xf_n = 0;                                                                                                          \
   } while (0)
@@ -1545,6 +1550,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
     if (n_out) n_out[blockIdx.x] = overflow == 2 ? INT64_MIN : (overflow ? -(int64_t)out_n : (int64_t)out_n);
   }
 #undef FAST_PUBLISH
+#undef SPX_LEAN_OUTPUTS
 }
 
 size_t spx_walk_fast_lds_bytes(const SpxPlanDev& P, int wcap) { return (size_t)fast_lds_layout(P, wcap).total; }

@@ -92,9 +92,18 @@ def test_log_spec_dispatch(orc):
         L.orc_set_log_spec(2)
 
 
+@pytest.fixture
+def libm_twiddles(orc):
+    L = orc.lib()
+    L.orc_set_twiddle_spec(2)
+    yield
+    L.orc_set_twiddle_spec(3)
+
+
 @pytest.mark.parametrize("n", [7, 11, 13, 31])
-def test_twiddles_are_one_sincos_call(orc, n):
-    """DFT spec: a twiddle (cos, -sin)(2 pi t / n) is ONE glibc sincos call -- sincos and the separate sin / cos
+def test_twiddles_are_one_sincos_call(orc, n, libm_twiddles):
+    """(Twiddle spec 2, the tables of round 5 -- still selectable: orc_set_twiddle_spec(2); spec 3, the default since round 6, takes no
+    libm call at all: tests/test_oracle_twiddle.py.)  DFT spec: a twiddle (cos, -sin)(2 pi t / n) is ONE glibc sincos call -- sincos and the separate sin / cos
     round a few entries differently in the last bit, and a compiler may or may not merge the pair (gcc does, clang does not: the GPU's
     tables and the oracle's once differed that way).  An odd-prime transform of the unit impulse at index 1 hands the table back
     unchanged -- u_1 = 1, P_j = fma(c, 1, 0), Q_j = s * 1 -- so the oracle's entries can be compared with libm's sincos bit for bit
@@ -118,8 +127,8 @@ def test_twiddles_are_one_sincos_call(orc, n):
 
 
 @pytest.mark.parametrize("n,t", [(240, 32), (360, 48), (480, 64), (720, 96)])
-def test_twiddle_entries_that_tell_sincos_from_sin(orc, n, t):
-    """The same pin on entries where this glibc's sincos and sin disagree in the last bit (the angle 2 pi 2/15).  In a composite
+def test_twiddle_entries_that_tell_sincos_from_sin(orc, n, t, libm_twiddles):
+    """(Twiddle spec 2.)  The same pin on entries where this glibc's sincos and sin disagree in the last bit (the angle 2 pi 2/15).  In a composite
     transform whose first radix leaves more than t outputs per branch, output t of the unit impulse at index 1 is table entry t
     times 1 + 0i through a butterfly of zeros: exact.  Where the two libm routes do disagree the oracle must side with sincos."""
     import ctypes as C

@@ -33,7 +33,7 @@ elif kind == "pipe_host":
 else:
     b = Batch(plan, [n] * S, 1, bench.SPEED, 1.0, 0.0)
     b.upload(streams)
-    pipe = Pipeline(plan, [n] * S, 1, bench.SPEED, 1.0, 0.0, depth=4, device_out=True)
+    pipe = Pipeline(plan, [n] * S, 1, bench.SPEED, 1.0, 0.0, depth=int(os.environ.get("SPX_PROBE_DEPTH", "4")), device_out=True)
     fn = lambda k: pipe.submit(b.d_in)  # noqa: E731
 for k in range(12):
     fn(k)
