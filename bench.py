@@ -21,6 +21,7 @@ Beside `value` the line carries (every figure ONE timed window of consecutive st
                       (STRONG scaling; N = 1 runs all of it in one call)
   api_256_handles     the drop-in API with 256 live sonicStream handles on one host thread
   cpu_baseline        the CPU port on the host cores, with the output CRCs of the GPU legs checked against it
+  cpu_baseline_fftw   the same with the reference's FFT library when the box has libfftw3 (dlopen); {"fftw": "absent"} otherwise
 
 Prints ONE JSON line on rank 0.
 """
@@ -134,6 +135,38 @@ def cpu_baseline(streams, gpu_outputs, budget_s=12.0, c4_checks=None, rate_check
            "sample": "%d streams (the %d bench streams%s, %d s each), one stream per task on %d POSIX threads, "
                      "oracle built -O3 -march=native -ffp-contract=off (oracle/orc_bench.c)"
                      % (k, len(streams), ", cycled" if k > len(streams) else "", SECONDS, cores)}
+    # "if libfftw3 happens to exist on the box, add an FFTW-backed run as the reference FFTW/CPU path".  Looked up at
+    # run time (dlopen, oracle/orc_speedy.c orc_fftw_available); the call shape is the reference's (speedy.c:228-231, 458-473:
+    # fftw_plan_dft_1d, N-point complex, FFTW_ESTIMATE, cabs).  Same sample, same threads; its output against the port's.
+    L.orc_fftw_available.restype = C.c_int
+    L.orc_set_fft_backend.restype = C.c_int
+    L.orc_set_fft_backend.argtypes = [C.c_int]
+    if L.orc_fftw_available() and L.orc_set_fft_backend(1) == 1:
+        try:
+            fdt, fcrcs = run(sample, cores)
+            W = int(1.5 * RATE / 100.0)
+            L.orc_spectrum_magnitudes.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+            rng = np.random.default_rng(1)
+            num = den = 0.0
+            for _ in range(32):
+                x = (rng.standard_normal(W) * 0.1).astype(np.float32)
+                a, b = np.zeros(2 * W, np.float32), np.zeros(2 * W, np.float32)
+                L.orc_set_fft_backend(1)
+                L.orc_spectrum_magnitudes(W, x.ctypes.data, a.ctypes.data)
+                L.orc_set_fft_backend(0)
+                L.orc_spectrum_magnitudes(W, x.ctypes.data, b.ctypes.data)
+                num += float(np.sum(b.astype(np.float64) ** 2))
+                den += float(np.sum((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+            res["cpu_baseline_fftw"] = {
+                "value": k * n / fdt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port with the reference's FFT library",
+                "fftw": "libfftw3 (dlopen), fftw_plan_dft_1d N-point complex, FFTW_ESTIMATE (speedy.c:228-231,458-473)",
+                "streams_with_output_equal_to_the_port": sum(1 for a, b in zip(fcrcs, crcs) if a == b), "streams": len(crcs),
+                "spectrogram_snr_db_vs_port": (10.0 * float(np.log10(num / den)) if den > 0 else float("inf"))}
+        finally:
+            L.orc_set_fft_backend(0)
+    else:
+        res["cpu_baseline_fftw"] = {"fftw": "absent", "note": "no libfftw3.so.3 on this box (dlopen); the baseline above is the port's own "
+                                    "double-precision mixed-radix DFT (SURVEY 8d)"}
     if c4_checks:
         from speedy_amd import config4 as C4
         chk = {}
@@ -847,6 +880,7 @@ def main():
             line["api_256_handles"] = api_many_handles()
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (bench contract)
             line["cpu_baseline"] = cpu_baseline(streams, outs, c4_checks=c4_checks, rate_checks=rate_checks)
+            line["cpu_baseline_fftw"] = line["cpu_baseline"].pop("cpu_baseline_fftw", {"fftw": "absent"})
             for name, r in line["cpu_baseline"].get("other_rates_crc_check", {}).items():
                 line["other_rates"][name]["output_crc_mismatches_vs_cpu_port"] = r["output_crc_mismatches_vs_gpu"]
                 line["other_rates"][name]["streams_checked_against_cpu_port"] = r["streams_checked"]

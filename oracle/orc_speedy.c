@@ -521,7 +521,46 @@ typedef struct {
   double* tw2;     /* e^{-2 pi i k / (2W)}, k < W */
   double* z;       /* 2W doubles */
   double* Z;       /* 2W doubles */
+  void* fftw;      /* FFTW backend (orc_set_fft_backend(1), when the box has libfftw3): an N-point complex plan ... */
+  double* fin;     /* ... its input, 2N doubles */
+  double* fout;    /* ... and its output */
 } orc_specplan;
+
+/* ---- the reference's shipped FFT library, when the box has one (reference speedy.c:228-231, 458-473, Makefile:9) ----
+ * libfftw3 is looked up at RUN time (dlopen): nothing links against it, nothing needs its header.  With the backend on, a frame's
+ * spectrum is what the reference's FFTW build computes: the windowed frame (float products) zero-padded to N COMPLEX doubles,
+ * fftw_plan_dft_1d(N, in, out, FFTW_FORWARD, FFTW_ESTIMATE), |X[i]| = cabs -> float.  It is a second CPU baseline of bench.py
+ * ("cpu_baseline_fftw") and a cross-check of the port's spectra -- never the parity oracle (its last bits are FFTW's codelets'). */
+#include <dlfcn.h>
+#include <pthread.h>
+static struct {
+  int tried, ok;
+  void* (*plan_dft_1d)(int, void*, void*, int, unsigned);
+  void (*execute)(void*);
+  void (*destroy_plan)(void*);
+} orc_fftw;
+static pthread_mutex_t orc_fftw_mu = PTHREAD_MUTEX_INITIALIZER;   /* FFTW's planner is not thread-safe (reference: one global planner) */
+static int orc_fft_backend_v = 0;
+int orc_fftw_available(void) {
+  pthread_mutex_lock(&orc_fftw_mu);
+  if (!orc_fftw.tried) {
+    orc_fftw.tried = 1;
+    void* h = dlopen("libfftw3.so.3", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("libfftw3.so", RTLD_NOW | RTLD_LOCAL);
+    if (h) {
+      *(void**)&orc_fftw.plan_dft_1d = dlsym(h, "fftw_plan_dft_1d");
+      *(void**)&orc_fftw.execute = dlsym(h, "fftw_execute");
+      *(void**)&orc_fftw.destroy_plan = dlsym(h, "fftw_destroy_plan");
+      orc_fftw.ok = orc_fftw.plan_dft_1d && orc_fftw.execute && orc_fftw.destroy_plan;
+    }
+  }
+  const int ok = orc_fftw.ok;
+  pthread_mutex_unlock(&orc_fftw_mu);
+  return ok;
+}
+/* 0 (default): the port's own transform (the DFT spec: what the GPU equals bit for bit); 1: FFTW, if there.  Returns the backend in
+ * force.  Read when a stream is created. */
+int orc_set_fft_backend(int v) { orc_fft_backend_v = (v == 1 && orc_fftw_available()) ? 1 : 0; return orc_fft_backend_v; }
 
 static orc_specplan* orc_specplan_create(int W) {
   orc_specplan* sp = (orc_specplan*)calloc(1, sizeof(orc_specplan));
@@ -534,15 +573,32 @@ static orc_specplan* orc_specplan_create(int W) {
     orc_twiddle(k, 2L * W, &sp->tw2[2 * k], &sp->tw2[2 * k + 1]);
   }
   orc_check_twiddles(2L * W, W, sp->tw2);
+  if (orc_fft_backend_v == 1 && orc_fftw_available()) {
+    const int N = 2 * W;
+    sp->fin = (double*)calloc((size_t)2 * N, sizeof(double));   /* (the reference uses fftw_malloc: alignment only) */
+    sp->fout = (double*)calloc((size_t)2 * N, sizeof(double));
+    pthread_mutex_lock(&orc_fftw_mu);
+    sp->fftw = orc_fftw.plan_dft_1d(N, sp->fin, sp->fout, -1 /* FFTW_FORWARD */, 1u << 6 /* FFTW_ESTIMATE */);   /* speedy.c:228-231 */
+    pthread_mutex_unlock(&orc_fftw_mu);
+  }
   return sp;
 }
 static void orc_specplan_destroy(orc_specplan* sp) {
   if (!sp) return;
   orc_plan_destroy(sp->plan);
+  if (sp->fftw) { pthread_mutex_lock(&orc_fftw_mu); orc_fftw.destroy_plan(sp->fftw); pthread_mutex_unlock(&orc_fftw_mu); }
+  free(sp->fin); free(sp->fout);
   free(sp->tw2); free(sp->z); free(sp->Z); free(sp);
 }
 static void orc_specplan_run(orc_specplan* sp, const float* x, float* mags) {
   int W = sp->W, N = 2 * W;
+  if (sp->fftw) { /* speedy.c:458-473 */
+    for (int i = 0; i < W; i++) { sp->fin[2 * i] = (double)x[i]; sp->fin[2 * i + 1] = 0.0; }
+    for (int i = W; i < N; i++) { sp->fin[2 * i] = 0.0; sp->fin[2 * i + 1] = 0.0; }
+    orc_fftw.execute(sp->fftw);
+    for (int i = 0; i < N; i++) mags[i] = (float)hypot(sp->fout[2 * i], sp->fout[2 * i + 1]);   /* cabs */
+    return;
+  }
   for (int n = 0; n < W; n++) {
     sp->z[2 * n] = (2 * n < W) ? (double)x[2 * n] : 0.0;
     sp->z[2 * n + 1] = (2 * n + 1 < W) ? (double)x[2 * n + 1] : 0.0;

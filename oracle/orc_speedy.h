@@ -78,6 +78,9 @@ void orc_set_dft_spec(int v);      /* 1: the unfused transform of rounds 1-4; 2 
 int orc_get_dft_spec(void);
 /* the twiddle tables and the Hamming window's cosine: 3 (default, round 6): orc_twiddle.h -- IEEE double operations only, the same bits
  * on every machine; 2: the box's libm (one sincos call per entry), as rounds 1-5.  Read when a stream / plan is created. */
+/* the reference's shipped FFT (FFTW, double): used for a second CPU baseline when the box has libfftw3 (dlopen at run time) */
+int orc_fftw_available(void);
+int orc_set_fft_backend(int v);   /* 0: the port's transform (default); 1: FFTW if available.  Returns the backend in force */
 void orc_set_twiddle_spec(int v);
 int orc_get_twiddle_spec(void);
 void orc_twiddle_entry(long k, long n, double* c, double* s);   /* cos, sin (2 pi k / n) */
