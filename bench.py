@@ -98,6 +98,38 @@ def usable_cpus():
     return n, quota
 
 
+def bind_to_gpu_numa(dev_index):
+    """Pin this process's host threads to the CPUs of its GPU's NUMA node (with the host-to-device link as the
+    end-to-end bound and eight ranks on two sockets, an unbound rank measures placement luck).  The device's PCI address comes from
+    torch's device properties (no GPU work), the node and its CPUs from sysfs; the affinity is only ever NARROWED (the CPUs the
+    process may already use, intersected with the node's).  Returns what was found and done -- it goes into config.ranks."""
+    info = {"numa_node": None, "cpus_allowed": len(os.sched_getaffinity(0)), "bound": False, "pci": None}
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(dev_index)
+        pci = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        info["pci"] = pci
+        base = "/sys/bus/pci/devices/" + pci
+        node = int(open(base + "/numa_node").read().strip())
+        info["numa_node"] = node
+        cpus = set()
+        for part in open(base + "/local_cpulist").read().strip().split(","):
+            if not part:
+                continue
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        mine = os.sched_getaffinity(0)
+        want = mine & cpus
+        if node >= 0 and want and want != mine and not os.environ.get("SPX_BENCH_NO_BIND"):
+            os.sched_setaffinity(0, want)
+            info["bound"] = True
+        info["cpus_allowed"] = len(os.sched_getaffinity(0))
+        info["node_cpus"] = len(cpus)
+    except Exception as e:  # noqa: BLE001  (no sysfs entry, no such property: recorded, never fatal)
+        info["error"] = repr(e)[:120]
+    return info
+
+
 def cpu_baseline(streams, gpu_outputs, budget_s=12.0, c4_checks=None, rate_checks=None):
     """The CPU oracle (kind "port": C restatement of the reference path; the reference itself is unbuildable here,
     DESIGN.md "Oracle") on the host cores of this machine: oracle/orc_bench.c -- POSIX threads, one stream per task,
@@ -401,6 +433,13 @@ def standalone_analysis_ms(plan, batch, reps=10, warm=3):
     return e0.elapsed_time(e1) / reps
 
 
+def load_scratch_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "gpurun_out", name)))
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def load_json(name):
     try:
         return json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -445,6 +484,7 @@ def main():
         from speedy_amd.batch import Plan
         dev, rk, reps = (int(v) for v in args.pcie_child.split(","))
         torch.cuda.set_device(dev)
+        numa_ = bind_to_gpu_numa(dev)
         n_ = RATE * SECONDS
         plan_ = Plan(RATE, False)
         streams_ = make_streams(STREAMS_PER_GPU, n_, rk)
@@ -453,6 +493,7 @@ def main():
         # (round 5: the steady phase -- >= 200 timed batches behind >= 50 untimed ones, no pause between them)
         res_ = pcie_pipeline(plan_, streams_, n_, reps=max(200, reps), warm=int(os.environ.get("SPX_BENCH_PCIE_WARM", "50")),
                              depth=int(os.environ.get("SPX_BENCH_PCIE_DEPTH", "4")))
+        res_["numa"] = numa_
         print(json.dumps(res_), flush=True)
         return
 
@@ -481,6 +522,7 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (the product has no CPU path)")
     torch.cuda.set_device(dev_index)
+    numa = bind_to_gpu_numa(dev_index)
     dist = None
     red_dev = "cuda"
     backend = args.backend
@@ -511,7 +553,9 @@ def main():
         handshake_ms = (time.perf_counter() - t_h) * 1e3
         assert layout.shape == (world, 2) and int(layout[:, 0].sum()) == world * STREAMS_PER_GPU
         info = {"rank": rank, "local_rank": local_rank, "device_id": dev_index, "device": torch.cuda.get_device_name(dev_index),
-                "host": socket.gethostname(), "pid": os.getpid()}
+                "host": socket.gethostname(), "pid": os.getpid(), "numa_node": numa["numa_node"], "cpus_allowed": numa["cpus_allowed"],
+                "bound_to_numa_node": numa["bound"], "pci": numa["pci"],
+                "h2d_alone_gbs": (2 * STREAMS_PER_GPU * RATE * SECONDS / pcie_early["h2d_alone_s"] / 1e9) if pcie_early else None}
         rank_info = [None] * world
         dist.all_gather_object(rank_info, info)
 
@@ -615,12 +659,18 @@ def main():
     # the analysis kernel alone (its fp64 vector roofline), rank 0's device
     ms_analysis_alone = standalone_analysis_ms(plan, b) if rank == 0 else None
 
-    # the throughput regime: 2 048 streams of the headline kind in ONE call (the 256 bench streams, eight times), rank 0's device
+    # the throughput regime: 2 048 streams of the headline kind in ONE call (2 048 distinct signals), rank 0's device
     large = None
     if not args.no_large_batch and rank == 0:
         nl = 8 * STREAMS_PER_GPU
         bl = Batch(plan, [n] * nl, 1, SPEED, 1.0, 0.0)
-        bl.d_in[: n * nl].copy_(b.d_in[: n * STREAMS_PER_GPU].repeat(8))
+        # 2 048 DISTINCT signals (seeds 1234 + 0 .. 2047; the first 256 are the bench's own): eight copies of 256 streams would make
+        # all eight copies of a chain end together, which flatters the walk kernel's tail
+        bl.d_in[: n * STREAMS_PER_GPU].copy_(b.d_in[: n * STREAMS_PER_GPU])
+        for blk in range(1, 8):
+            extra = make_streams(STREAMS_PER_GPU, n, blk)   # seeds blk * 256 + i
+            bl.d_in[blk * n * STREAMS_PER_GPU:(blk + 1) * n * STREAMS_PER_GPU].copy_(torch.from_numpy(np.concatenate(extra)))
+            del extra
         dtl = time_window(bl.run, reps=5, warm=3)
         nout_l = bl.d_nout.cpu().numpy()
         assert (nout_l > 0).all()
@@ -631,7 +681,7 @@ def main():
                          "algorithmic_bytes_per_step": algo_l, "of": "the whole call (analysis, tension and walk kernels of two pipelined time chunks)"},
                  "kernels": {"analysis": ka, "tension": kt, "walk": kw},
                  "note": "BASELINE configs[3]'s kind at eight times its batch: %d x %d s, 16 kHz mono, 3.5x nonlinear, ONE spx_batch_run "
-                         "per step (the 256 bench streams, eight times); the walk kernel in its throughput form" % (nl, SECONDS)}
+                         "per step, %d distinct signals (seeds 1234 + 0 .. %d); the walk kernel in its throughput form" % (nl, SECONDS, nl, nl - 1)}
         del bl
         torch.cuda.empty_cache()
 
@@ -834,6 +884,8 @@ def main():
                        "walk_launches_in_flight": (2 if (pipe is not None and last_mode == 2) else 1),
                        "timed_through": ("spx_pipeline_submit (device-resident input, SPX_PIPELINE_DEVICE_OUT)" if pipe is not None else "spx_batch_run"),
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       # what tests/test_gpu_perf_guard.py did on this box, if it ran here (guarded: false = the box was too noisy to judge)
+                       "perf_guard": load_scratch_json("perf_guard.json"),
                        "parallelism": "streams sharded %d/GPU, no data-path collective" % STREAMS_PER_GPU,
                        "launcher": "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else
                                    ("bench.py --gpus (self-spawned ranks)" if world > 1 else "single process"),
@@ -842,7 +894,10 @@ def main():
                        "n_ranks_seen": (int(layout.shape[0]) if world > 1 else 1),
                        "handshake_ms": handshake_ms,
                        "ranks": rank_info if rank_info is not None else
-                                [{"rank": 0, "device_id": dev_index, "device": torch.cuda.get_device_name(dev_index)}],
+                                [{"rank": 0, "device_id": dev_index, "device": torch.cuda.get_device_name(dev_index),
+                                  "numa_node": numa["numa_node"], "cpus_allowed": numa["cpus_allowed"], "bound_to_numa_node": numa["bound"],
+                                  "pci": numa["pci"],
+                                  "h2d_alone_gbs": (2 * n_in / pcie_early["h2d_alone_s"] / 1e9) if pcie_early else None}],
                        "stream_seeds": "1234 + global stream index (rank * %d + i), all distinct" % STREAMS_PER_GPU,
                        "realtime_factor_per_stream": SECONDS / (ms_step * 1e-3),
                        "out_samples_per_gpu": n_out, "pipeline_chunks": args.chunks,

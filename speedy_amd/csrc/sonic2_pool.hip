@@ -19,6 +19,20 @@
 // together become one job, which the kernels' event model treats like the reference treats consecutive writes.  Per-handle
 // results equal the reference's call for call (tests/test_gpu_pool.py: interleaved handles against the oracle shim).
 //
+// Several host threads (round 6).  A stream is not thread-safe, distinct streams are independent (sonic2.h:54-84) -- so a server
+// runs the reference's loop (speedy_wave.cc:199-220: write a chunk, read what is ready) on one thread per group of handles.  Until
+// round 6 the pool's mutex was held across a whole run, GPU wait included: a thread could not even STAGE a write while another
+// thread's run was in flight, every read ran a launch sequence for one or two handles, and T threads were no faster than one
+// (14 Msamples/s whatever the number of handles).  Now (flat combining):
+//   * one run at a time, but the mutex is released while the GPU works: other threads stage their writes meanwhile, into the second
+//     of two pinned input areas (the run's stage kernel is still reading the first);
+//   * a read that needs a result and finds a run in flight waits for it; the first thread to find the pool idle becomes the
+//     combiner and runs EVERYTHING staged by any thread -- after a bounded look (a few microseconds at a time while new work keeps
+//     arriving, SPX_POOL_GATHER_US in all) for the threads that were just served and are about to write again -- so T threads
+//     in the write -> read order cost one launch sequence per round, not T;
+//   * a call on a handle that is part of the run in flight waits for that run (its state is the run's until the results are in).
+// Results per handle are what they always were: the jobs are formed per handle from that handle's own staged writes.
+//
 // Device memory: a handle keeps its own sliding input / output allocations (sonic2_stream.h); the kernels of a pooled
 // launch get NULL base pointers and per-stream offsets that are the allocations' absolute element addresses.  The
 // per-frame arrays (records, scratch) are indexed by the kernels through ONE offset per stream, so for pooled handles
@@ -29,7 +43,9 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 
 #include "sonic2_stream.h"
 
@@ -71,6 +87,11 @@ struct PoolResult { SpxStreamState st; int64_t n; };
 
 struct SpxPool {
   std::mutex mu;
+  std::condition_variable cv;      // a run has finished (running -> false, its handles' inRun -> false)
+  bool running = false;            // a run owns hTab / hRes / dWs / the stream, and the input area it was staged in
+  std::atomic<unsigned> gen{0};    // runs finished: a waiting thread polls it for a while before it blocks (wait_for_run)
+  std::thread::id first_thread;    // the batching look costs a single-threaded caller nothing: only once a second thread is seen
+  bool have_first = false, multi = false;
   int device = 0;
   hipStream_t hs = nullptr;
   // frame arena
@@ -82,14 +103,16 @@ struct SpxPool {
   std::vector<std::pair<int64_t, int64_t>> arenaLater;   // ranges to free once the run in preparation has been launched
   // waiting work
   std::vector<sonicStream> waiting;
+  std::vector<sonicStream> run;            // the handles of the run in flight
   size_t waitingSegs = 0;
-  PinBuf hIn, hTab, hRes;
+  PinBuf hInBuf[2], hTab, hRes;    // writes are staged in hInBuf[hCur]; a run reads the other one
+  int hCur = 0;
   size_t hInUsed = 0;
   unsigned char* dWs = nullptr;
   size_t dWsCap = 0;
   unsigned long long runs = 0, jobs = 0;   // statistics (speedyHipPoolStats)
   SpxDeferred* defer = nullptr;            // the run in preparation
-  struct Item { sonicStream s; SpxJobPlan J; };
+  struct Item { sonicStream s; SpxJobPlan J; std::vector<sonicStreamStruct::Seg> segs; bool flush; };
   std::vector<Item> items;                 // the run's tables (capacity kept from run to run)
   std::vector<PoolCopy> copies;
   std::vector<SpxMove> moves;
@@ -309,8 +332,9 @@ spx_pool_gather_kernel(const PoolDesc* __restrict__ desc, const SpxStreamState* 
 }
 
 // ---------------- running what waits ----------------
-static bool place_input(SpxPool* P, sonicStream s, std::vector<PoolCopy>& copies, SpxDeferred* defer) {
-  if (s->segs.empty()) return true;
+static bool place_input(SpxPool* P, sonicStream s, const std::vector<sonicStreamStruct::Seg>& segs, std::vector<PoolCopy>& copies,
+                        SpxDeferred* defer) {
+  if (segs.empty()) return true;
   const SpxPlanDev& PL = *s->plan;
   const int64_t C = s->channels;
   SlideBuf<int16_t>& dst = s->dIn;
@@ -322,7 +346,7 @@ static bool place_input(SpxPool* P, sonicStream s, std::vector<PoolCopy>& copies
   if (keepFrom < 0) keepFrom = 0;
   dst.filled = s->devIn * C;
   if (!dst.ensure(keepFrom * C, s->nIn * C + 64, P->hs, 1 << 17, defer)) return false;
-  for (const auto& g : s->segs) {
+  for (const auto& g : segs) {
     const int64_t total = g.frames * C;
     for (int64_t k = 0; k < total; k += 16384) {
       PoolCopy c;
@@ -335,16 +359,36 @@ static bool place_input(SpxPool* P, sonicStream s, std::vector<PoolCopy>& copies
   return true;
 }
 
-static void drop_waiting(SpxPool* P) {
-  for (sonicStream s : P->waiting) { s->poolPending = false; s->pendingFlush = false; s->segs.clear(); }
-  P->waiting.clear();
-  P->waitingSegs = 0;
-  P->hInUsed = 0;
+// A run is over (or could not be launched): its handles belong to their callers again.  Pool mutex held.
+static void end_run(SpxPool* P, std::vector<sonicStream>& run) {
+  for (sonicStream s : run) s->inRun = false;
+  run.clear();
+  P->running = false;
+  P->gen.fetch_add(1, std::memory_order_release);
+  P->cv.notify_all();
 }
 
-// Everything that waits, one launch sequence per (plan, kernel variant) group, one synchronisation.  Pool mutex held.
-static bool pool_run(SpxPool* P) {
+// Everything that waits, one launch sequence per (plan, kernel variant) group, one synchronisation.  Called with the pool mutex
+// held through `lk`, with no run in flight; returns with it held.  The mutex is released twice on the way: for the bounded look
+// for more staged work (several threads only), and while the GPU works.
+static bool pool_run(SpxPool* P, std::unique_lock<std::mutex>& lk) {
   if (P->waiting.empty()) return true;
+  P->running = true;   // from here on other threads stage and wait; nobody else starts a run
+  if (P->multi) {
+    // The combiner's look: threads whose handles the previous run served are writing again right now -- a few microseconds at a
+    // time while the waiting list keeps growing, SPX_POOL_GATHER_US (default 24) in all.  One launch sequence for all of them
+    // instead of one for those that happened to be staged and one for the rest.
+    static const double gather_us = [] { const char* e = getenv("SPX_POOL_GATHER_US"); return e ? atof(e) : 24.0; }();
+    const auto t_g = std::chrono::steady_clock::now();
+    size_t seen;
+    do {
+      seen = P->waiting.size();
+      lk.unlock();
+      const auto t_s = std::chrono::steady_clock::now();
+      while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_s).count() < 4.0) { }
+      lk.lock();
+    } while (P->waiting.size() > seen && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_g).count() < gather_us);
+  }
   (void)hipSetDevice(P->device);
   typedef SpxPool::Item Item;
   // (the run's tables live in the pool and keep their capacity: no allocation on the hot path)
@@ -352,16 +396,30 @@ static bool pool_run(SpxPool* P) {
   std::vector<PoolCopy>& copies = P->copies;
   items.clear();
   copies.clear();
-  items.reserve(P->waiting.size());
+  // the run takes the waiting list and the input area it was staged in; staging goes on in the other area
+  std::vector<sonicStream>& run = P->run;
+  run.swap(P->waiting);
+  P->waiting.clear();
+  P->waitingSegs = 0;
+  const unsigned char* run_in = P->hInBuf[P->hCur].p;
+  P->hCur ^= 1;
+  P->hInUsed = 0;
+  items.reserve(run.size());
   SpxDeferred defer;
   defer.pool = P;
   P->defer = &defer;
   const auto tp0 = std::chrono::steady_clock::now();
-  for (sonicStream s : P->waiting) {
+  for (sonicStream s : run) {
+    s->poolPending = false;
+    s->inRun = true;
     items.emplace_back();
     Item& it = items.back();   // prepared in place
     it.s = s;
-    if (s->failed || !place_input(P, s, copies, &defer) || !spx_prepare_job(s, s->pendingFlush, false, P->hs, P, it.J, &defer)) {
+    it.segs.clear();
+    it.segs.swap(s->segs);
+    it.flush = s->pendingFlush;
+    s->pendingFlush = false;
+    if (s->failed || !place_input(P, s, it.segs, copies, &defer) || !spx_prepare_job(s, it.flush, false, P->hs, P, it.J, &defer)) {
       if (!s->failed) spx_stream_fail(s, "preparing the staged work failed (device allocation)");
       items.pop_back();
     }
@@ -378,7 +436,7 @@ static bool pool_run(SpxPool* P) {
     }
   } releaser{P, &defer};
   const size_t n = items.size();
-  if (n == 0) { drop_waiting(P); return true; }
+  if (n == 0) { end_run(P, run); return true; }
   // moves in pieces of 64 KB, one workgroup each
   std::vector<SpxMove>& moves = P->moves;
   moves.clear();
@@ -415,7 +473,7 @@ static bool pool_run(SpxPool* P) {
   const size_t b_tab = o_moves + sizeof(SpxMove) * moves.size();
   auto give_up = [&](const char* why) {   // nothing was launched: the waiting handles cannot be served
     for (auto& it : items) spx_stream_fail(it.s, why);
-    drop_waiting(P);
+    end_run(P, run);
     return false;
   };
   if (!P->hTab.reserve(b_tab + 64, 0)) return give_up("pinned table allocation failed");
@@ -479,7 +537,7 @@ static bool pool_run(SpxPool* P) {
   const unsigned grid = std::max<unsigned>(std::max<unsigned>((unsigned)(copies.size() + moves.size()), (n_words + 255) / 256), 1u);
   const auto tp2 = std::chrono::steady_clock::now();
   hipLaunchKernelGGL(spx_pool_stage_kernel, dim3(grid), dim3(256), 0, P->hs, reinterpret_cast<const unsigned*>(hA),
-                     reinterpret_cast<unsigned*>(dA), n_words, hD, dStates, (unsigned)n, hC, (unsigned)copies.size(), P->hIn.p,
+                     reinterpret_cast<unsigned*>(dA), n_words, hD, dStates, (unsigned)n, hC, (unsigned)copies.size(), run_in,
                      hM, (unsigned)moves.size());
   auto tl = std::chrono::steady_clock::now();
   auto lap = [&](int k) { const auto t = std::chrono::steady_clock::now(); P->t_l[k] += std::chrono::duration<double>(t - tl).count(); tl = t; };
@@ -506,6 +564,9 @@ static bool pool_run(SpxPool* P) {
   // The run is a few tens of microseconds of GPU work: waiting for it in the runtime's blocking way costs about as much
   // again in wake-up latency.  Poll the stream for a while (SPX_POOL_SPIN_US, default 2000 us), then block.
   static const long spin_us = [] { const char* e = getenv("SPX_POOL_SPIN_US"); return e ? atol(e) : 2000L; }();
+  // (the mutex is free while the GPU works: other threads stage their next writes -- on handles that are not part of this run --
+  // and queue up behind it; everything this run owns stays untouched until the lock is back)
+  lk.unlock();
   hipError_t se = hipErrorNotReady;
   if (spin_us > 0) {
     const auto t_spin = std::chrono::steady_clock::now();
@@ -515,11 +576,12 @@ static bool pool_run(SpxPool* P) {
     if (se == hipErrorNotReady) (void)hipGetLastError();
   }
   if (se == hipErrorNotReady) se = hipStreamSynchronize(P->hs);
+  lk.lock();
   const auto tp4 = std::chrono::steady_clock::now();
   if (le != hipSuccess || se != hipSuccess) {
     const std::string why = std::string("coalesced launch failed: ") + hipGetErrorString(le != hipSuccess ? le : se);
     for (auto& it : items) spx_stream_fail(it.s, why);
-    drop_waiting(P);
+    end_run(P, run);
     return false;
   }
   for (size_t i = 0; i < n; i++) {
@@ -554,7 +616,7 @@ static bool pool_run(SpxPool* P) {
   }
   P->runs++;
   P->jobs += n;
-  drop_waiting(P);
+  end_run(P, run);
   const auto tp5 = std::chrono::steady_clock::now();
   auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
   P->t_prep += sec(tp0, tp1); P->t_tab += sec(tp1, tp2); P->t_launch += sec(tp2, tp3); P->t_wait += sec(tp3, tp4); P->t_post += sec(tp4, tp5);
@@ -564,20 +626,64 @@ static bool pool_run(SpxPool* P) {
 static void enlist(SpxPool* P, sonicStream s) {
   if (!s->poolPending) { s->poolPending = true; P->waiting.push_back(s); }
 }
+// Wait for the run in flight to end.  A run is tens of microseconds: blocking in the kernel costs a thread about as much again to
+// wake up, so it polls the run counter for a while first (mutex released; SPX_POOL_SPIN_US bounds it, 200 us at most), then blocks.
+static void wait_for_run(SpxPool* P, std::unique_lock<std::mutex>& lk) {
+  static const double spin_us = [] { const char* e = getenv("SPX_POOL_SPIN_US"); const double v = e ? atof(e) : 2000.0; return v < 200.0 ? v : 200.0; }();
+  const unsigned g0 = P->gen.load(std::memory_order_acquire);
+  if (spin_us > 0) {
+    lk.unlock();
+    const auto t0 = std::chrono::steady_clock::now();
+    while (P->gen.load(std::memory_order_acquire) == g0 &&
+           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < spin_us) {
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    lk.lock();
+  }
+  if (P->gen.load(std::memory_order_acquire) == g0 && P->running) P->cv.wait(lk);
+}
+// every entry point: which threads use the pool (the batching look is for several), and a handle that is part of the run in
+// flight is the run's until its results are in
+static void enter(SpxPool* P, sonicStream s, std::unique_lock<std::mutex>& lk) {
+  if (!P->multi) {
+    const std::thread::id me = std::this_thread::get_id();
+    if (!P->have_first) { P->first_thread = me; P->have_first = true; }
+    else if (P->first_thread != me) P->multi = true;
+  }
+  while (s->inRun) wait_for_run(P, lk);
+}
+// run what waits until `s` has nothing staged any more (another thread's run may serve it; several runs may pass first)
+static bool settle_locked(SpxPool* P, sonicStream s, std::unique_lock<std::mutex>& lk) {
+  bool ok = true;
+  for (;;) {
+    if (s->inRun || (s->poolPending && P->running)) { wait_for_run(P, lk); continue; }
+    if (!s->poolPending) return ok && !s->failed.load(std::memory_order_acquire);
+    ok = pool_run(P, lk) && ok;
+  }
+}
+// ... or everything staged by anybody (bounded staging): waits for the run in flight, then runs once
+static bool run_all_locked(SpxPool* P, std::unique_lock<std::mutex>& lk) {
+  while (P->running) wait_for_run(P, lk);
+  return pool_run(P, lk);
+}
 
 int spx_pool_write(sonicStream s, const short* in, int sampleCount) {
   SpxPool* P = pool_of(s);
-  std::lock_guard<std::mutex> g(P->mu);
+  std::unique_lock<std::mutex> lk(P->mu);
+  enter(P, s, lk);
   if (spx_stream_failed(s)) return 0;
-  if (s->pendingFlush && (!pool_run(P) || spx_stream_failed(s))) return 0;   // a write behind a staged flush is the next job
+  if (s->pendingFlush && (!settle_locked(P, s, lk) || spx_stream_failed(s))) return 0;   // a write behind a staged flush is the next job
   if (s->nIn + sampleCount + s->tsmShift >= (1ll << 30)) {
     spx_api_error("stream longer than 2^30 frames is not supported");
     return 0;
   }
   const size_t bytes = sizeof(short) * (size_t)sampleCount * s->channels;
   const size_t off = (P->hInUsed + 15) & ~(size_t)15;
-  if (!P->hIn.reserve(off + bytes + 32, P->hInUsed)) { spx_api_error("pinned staging allocation failed"); return 0; }
-  memcpy(P->hIn.p + off, in, bytes);   // the caller's buffer is free again when this call returns
+  PinBuf& hIn = P->hInBuf[P->hCur];
+  if (!hIn.reserve(off + bytes + 32, P->hInUsed)) { spx_api_error("pinned staging allocation failed"); return 0; }
+  memcpy(hIn.p + off, in, bytes);   // the caller's buffer is free again when this call returns
   P->hInUsed = off + bytes;
   s->segs.push_back({s->nIn, off, (int64_t)sampleCount});
   s->nIn += sampleCount;
@@ -585,15 +691,16 @@ int spx_pool_write(sonicStream s, const short* in, int sampleCount) {
   enlist(P, s);
   // bounded staging: a caller that only ever writes still makes progress (and the device buffers keep sliding)
   static const size_t limit = [] { const char* e = getenv("SPX_POOL_STAGE_BYTES"); return e ? (size_t)atoll(e) : (size_t)8 << 20; }();
-  if (P->hInUsed > limit || P->waitingSegs > 8192) return pool_run(P) && !spx_stream_failed(s) ? 1 : 0;
+  if (P->hInUsed > limit || P->waitingSegs > 8192) return run_all_locked(P, lk) && !spx_stream_failed(s) ? 1 : 0;
   return 1;
 }
 
 int spx_pool_flush(sonicStream s) {
   SpxPool* P = pool_of(s);
-  std::lock_guard<std::mutex> g(P->mu);
+  std::unique_lock<std::mutex> lk(P->mu);
+  enter(P, s, lk);
   if (spx_stream_failed(s)) return 0;
-  if (s->pendingFlush && (!pool_run(P) || spx_stream_failed(s))) return 0;
+  if (s->pendingFlush && (!settle_locked(P, s, lk) || spx_stream_failed(s))) return 0;
   s->pendingFlush = true;
   enlist(P, s);
   return 1;
@@ -601,15 +708,17 @@ int spx_pool_flush(sonicStream s) {
 
 bool spx_pool_sync(sonicStream s) {
   SpxPool* P = pool_of(s);
-  std::lock_guard<std::mutex> g(P->mu);
+  std::unique_lock<std::mutex> lk(P->mu);
+  enter(P, s, lk);
   if (!s->poolPending) return true;
-  return pool_run(P);
+  return settle_locked(P, s, lk);
 }
 
 int spx_pool_read(sonicStream s, short* out, int bufferSize) {
   SpxPool* P = pool_of(s);
-  std::lock_guard<std::mutex> g(P->mu);
-  if (s->poolPending && !pool_run(P)) return 0;
+  std::unique_lock<std::mutex> lk(P->mu);
+  enter(P, s, lk);
+  if (s->poolPending) (void)settle_locked(P, s, lk);
   (void)spx_stream_failed(s);   // (what the host holds is still delivered; the reason is this thread's last error)
   int64_t n = s->outKnown - s->outRead;
   if (n <= 0 || bufferSize <= 0) return 0;
@@ -634,9 +743,11 @@ int spx_pool_read(sonicStream s, short* out, int bufferSize) {
 // has those frames: a pooled handle's output window starts at its read position like an eager one's).
 bool spx_pool_leave(sonicStream s) {
   SpxPool* P = pool_of(s);
-  std::lock_guard<std::mutex> g(P->mu);
+  std::unique_lock<std::mutex> lk(P->mu);
+  enter(P, s, lk);
   (void)hipSetDevice(P->device);
-  if (s->poolPending && !pool_run(P)) return false;
+  if (s->poolPending && !settle_locked(P, s, lk)) return false;
+  while (P->running) wait_for_run(P, lk);   // (the copies below use the pool's stream and the arena: not beside a run)
   if (s->arenaStart >= 0) {
     SpxFrameRec* nr = nullptr;
     float* ns = nullptr;
@@ -661,12 +772,15 @@ bool spx_pool_leave(sonicStream s) {
 
 void spx_pool_forget(sonicStream s) {
   SpxPool* P = pool_of(s);
-  std::lock_guard<std::mutex> g(P->mu);
+  std::unique_lock<std::mutex> lk(P->mu);
+  enter(P, s, lk);
+  while (P->running) wait_for_run(P, lk);   // (its blocks return to the cache and its arena range to the free lists: not beside a run's tables)
   if (s->poolPending) {
     for (size_t i = 0; i < P->waiting.size(); i++)
       if (P->waiting[i] == s) { P->waiting.erase(P->waiting.begin() + (ptrdiff_t)i); break; }
     P->waitingSegs -= std::min(P->waitingSegs, s->segs.size());
     s->poolPending = false;
+    s->segs.clear();
     if (P->waiting.empty()) { P->hInUsed = 0; P->waitingSegs = 0; }
   }
   arena_release(P, s);

@@ -171,6 +171,7 @@ struct sonicStreamStruct {  // speedyConnectionStruct + the parts of libsonic's 
   // host, the pool runs them for all waiting handles in one launch sequence, synchronously.
   bool pooled = false;
   bool poolPending = false;     // on the pool's waiting list
+  bool inRun = false;           // part of the pool's run in flight: every call on the handle waits for that run (pool mutex)
   bool pendingFlush = false;    // ... with a flush behind the staged writes
   int64_t devIn = 0;            // frames of input that have reached dIn (nIn counts the staged ones too)
   struct Seg { int64_t pos; size_t src_off; int64_t frames; };   // staged write: stream position, offset in the pool's pinned input area

@@ -108,7 +108,6 @@ struct spx_plan {
   hipStream_t side = nullptr;
   hipStream_t side2 = nullptr;   // concurrent mode: the tension kernel's stream
   hipEvent_t ev_tension = nullptr;
-  hipEvent_t ev_wout = nullptr;     // deferred output on the output stream: "the walk kernel is done"
   hipEvent_t ev_start = nullptr;
   hipEvent_t ev_chunk[SPX_MAX_CHUNKS] = {};
   // spx_batch_run_ahead: the walk kernels of the plan's previous FOUR calls (ring_wait / ring_record below), the started-counter
@@ -437,7 +436,6 @@ void spx_plan_destroy(spx_plan_t plan) {
   if (plan->mix_stage.done) { (void)hipEventSynchronize(plan->mix_stage.done); (void)hipEventDestroy(plan->mix_stage.done); }
   if (plan->mix_stage.p) (void)hipHostFree(plan->mix_stage.p);
   if (plan->ev_tension) (void)hipEventDestroy(plan->ev_tension);
-  if (plan->ev_wout) (void)hipEventDestroy(plan->ev_wout);
   if (plan->ev_start) (void)hipEventDestroy(plan->ev_start);
   for (auto& e : plan->ev_chunk) if (e) (void)hipEventDestroy(e);
   for (auto& e : plan->trial.ev) if (e) (void)hipEventDestroy(e);
@@ -457,15 +455,6 @@ int spx_plan_fft_size(spx_plan_t p) { return p->dev.N; }
 int spx_plan_future(spx_plan_t p) { return p->dev.F; }
 int spx_plan_max_required(spx_plan_t p) { return p->dev.maxRequired; }
 
-}  // extern "C"
-int64_t spx_internal_rec_cap(const SpxPlanDev& d, int64_t n_in) {
-  if (n_in < 0) n_in = 0;
-  const int64_t consumed = n_in + 2 * (int64_t)d.maxRequired;                 // the flush pads 2 maxRequired zeros
-  const int64_t steps = consumed / (d.minPeriod + 1) + 1;                       // a step that emits consumes period + n > minPeriod frames
-  const int64_t events = n_in / (d.B > 0 ? d.B : 1) + 4;                        // one failed step and one pass-through per event at most
-  return 2 * steps + 3 * events + consumed / SPX_REC_MAX_COPY + 32;            // + a copy pass per step, long copies cut up
-}
-extern "C" {
 static int64_t frames_for(const SpxPlanDev& d, int64_t n_in) {
   // frame j is sent to the analysis once sample j*B + W has been written (soniclib.c:440-444)
   if (n_in < d.W + 1) return 0;
@@ -505,10 +494,9 @@ int64_t spx_internal_frames_for(const SpxPlanDev& d, int64_t n_in) { return fram
 extern "C" {
 
 struct Layout {
-  size_t off_streams, off_states, off_rec, off_scratch, off_order, off_flags, off_ready, off_outrec, off_outcnt, total;
+  size_t off_streams, off_states, off_rec, off_scratch, off_order, off_flags, off_ready, total;
   int64_t max_tiles;
   int64_t total_frames;
-  int64_t total_outrecs;
 };
 static Layout layout_for(const SpxPlanDev& d, const spx_stream_job* jobs, int n) {
   Layout L;
@@ -525,12 +513,6 @@ static Layout layout_for(const SpxPlanDev& d, const spx_stream_job* jobs, int n)
   L.off_order = o;   o += ((sizeof(int) * (size_t)L.max_tiles + 255) & ~(size_t)255);
   L.off_flags = o;   o += ((sizeof(int) * (size_t)L.max_tiles + 255) & ~(size_t)255);
   L.off_ready = o;   o += ((sizeof(int) * ((size_t)n + 1) + 255) & ~(size_t)255);   // + the count of walk workgroups that have started
-  // deferred output (spx_internal.h): the records of the walk forms without output waves, and two ints per stream
-  int64_t nr = 0;
-  for (int i = 0; i < n; i++) nr += spx_internal_rec_cap(d, jobs[i].n_in);
-  L.total_outrecs = nr;
-  L.off_outrec = o;  o += ((sizeof(SpxOutRec) * (size_t)nr + 255) & ~(size_t)255);
-  L.off_outcnt = o;  o += ((sizeof(int) * 2 * (size_t)n + 255) & ~(size_t)255);
   L.total = o;
   return L;
 }
@@ -542,7 +524,7 @@ static int build_streams(const SpxPlanDev& d, const spx_stream_job* jobs, int n,
                          std::vector<SpxStreamDev>& v, std::vector<int>& tiles_per_chunk) {
   v.resize((size_t)n * nch);
   tiles_per_chunk.assign(nch, 0);
-  int64_t fo = 0, ro = 0;
+  int64_t fo = 0;
   const int TF = d.tile_frames;
   for (int i = 0; i < n; i++) {
     const spx_stream_job& j = jobs[i];
@@ -576,14 +558,11 @@ static int build_streams(const SpxPlanDev& d, const spx_stream_job* jobs, int n,
       s.frame_begin = (int32_t)Tprev;
       s.flags = (c == 0 ? SPX_F_INIT : 0) | (c == nch - 1 ? SPX_F_FLUSH : 0);
       s.frame_off = fo;
-      s.rec_off = ro;
-      s.rec_cap = (int32_t)std::min<int64_t>(spx_internal_rec_cap(d, j.n_in), 0x7fffffff);
       s.first_tile = tiles_per_chunk[c];
       tiles_per_chunk[c] += (int)((T - Tprev + TF - 1) / TF);
       Tprev = T;
     }
     fo += Ttot;
-    ro += spx_internal_rec_cap(d, j.n_in);
   }
   return 0;
 }
@@ -669,30 +648,6 @@ static int walk_stream_count() {
     return v < 1 ? 1 : (v > SPX_MAX_WALK_STREAMS ? SPX_MAX_WALK_STREAMS : v);
   }();
   return n;
-}
-static bool output_own_stream() {
-  static const bool off = spx_tuning_env("SPX_NO_OUT_STREAM") != nullptr;
-  return !off;
-}
-static hipStream_t dev_output_stream(int dev) {
-  static std::mutex mu;
-  static hipStream_t s[64];
-  const int d = (dev >= 0 && dev < 64) ? dev : 0;
-  std::lock_guard<std::mutex> g(mu);
-  if (!s[d] && hipStreamCreateWithFlags(&s[d], hipStreamNonBlocking) != hipSuccess) { s[d] = nullptr; (void)hipGetLastError(); }
-  return s[d];
-}
-static bool tension_own_stream() {
-  static const bool on = spx_tuning_env("SPX_TENSION_STREAM") != nullptr;
-  return on;
-}
-static hipStream_t dev_tension_stream(int dev) {
-  static std::mutex mu;
-  static hipStream_t s[64];
-  const int d = (dev >= 0 && dev < 64) ? dev : 0;
-  std::lock_guard<std::mutex> g(mu);
-  if (!s[d] && hipStreamCreateWithFlags(&s[d], hipStreamNonBlocking) != hipSuccess) { s[d] = nullptr; (void)hipGetLastError(); }
-  return s[d];
 }
 static int dev_walk_streams(int dev, hipStream_t* w, int n) {
   static std::mutex mu;
@@ -1010,7 +965,6 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   int* d_flags = reinterpret_cast<int*>(w + L.off_flags);
   int* d_ready = reinterpret_cast<int*>(w + L.off_ready);
   SpxTapsDev td = taps_of(taps);
-  SpxDefer defer = {reinterpret_cast<SpxOutRec*>(w + L.off_outrec), reinterpret_cast<int*>(w + L.off_outcnt), false};
   const bool timed = g_timing.load() && do_a && do_w;
   if (do_a && do_w) g_last_concurrent.store(concurrent ? 1 : (ahead ? 2 : 0), std::memory_order_relaxed);
   static const bool dbg_mode = getenv("SPX_DEBUG_MODE") != nullptr;   // one line per call: what was decided and why
@@ -1024,7 +978,6 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   // behind this call's state of the stream, which ends with the wait for the previous call's walk kernel; a caller that hands over
   // the previous call's out / n_out again gets exactly that wait
   hipStream_t stw = st;
-  hipStream_t sdone = nullptr;   // the stream the call's last kernel runs on (set with stw below; the output stream with deferred output)
   const bool detached = opt.detached && M.walk2 && !force;
   if (do_w && !force && !detached && ring_note(plan, st)) return -2;
   if (do_w && !force && detached) { plan->ev_call_valid[plan->ahead_calls & 1] = false; plan->ev_call_st[plan->ahead_calls & 1] = nullptr; }
@@ -1042,7 +995,6 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     else if (same_out || (foreign_prev && plan->ahead_calls > 0)) HIPCHK(hipStreamWaitEvent(stw, plan->ev_call[cur], 0));
     else if (plan->ev_call_valid[cur ^ 1]) HIPCHK(hipStreamWaitEvent(stw, plan->ev_call[cur ^ 1], 0));
   }
-  sdone = stw;
   hipStream_t sa = st;  // the stream the analysis launches go to
   if (nch > 1 || concurrent || ahead) {
     if (!plan->side) {
@@ -1135,13 +1087,6 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
       // frame-rate stage: after the analysis on the same stream, or -- concurrent -- beside it on its own stream, consuming tile
       // flags and publishing the count of ready speeds (AHEAD: behind the analysis on the side stream)
       hipStream_t stn = concurrent ? plan->side2 : (ahead ? sa : st);
-      if (ahead && !force && tension_own_stream()) {
-        // (round 6) the tension kernel of a pipelined call on a stream of its own, behind the analysis' event: the producers' stream
-        // goes straight on to the NEXT call's staging and analysis kernels -- its chain is stage + analysis per call instead of
-        // stage + analysis + tension, and that chain is what the pipelined loop's period waits for once the walk kernels are shorter
-        hipStream_t ts = dev_tension_stream(plan->device);
-        if (ts) { HIPCHK(hipStreamWaitEvent(ts, plan->ev_chunk[c], 0)); stn = ts; }
-      }
       {
         SpxTimed tm(timed, 2, stn);
         spx_launch_tension(d, dj, n, states, rec, scratch, td, concurrent ? d_flags : nullptr, (concurrent || ahead) ? d_ready : nullptr, stn);
@@ -1158,27 +1103,13 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
         // count themselves in for the next call's gate.
         SpxTimed tm(timed, 1, stw);
         spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, ((concurrent && !diag_nowait) || ahead) ? d_ready : nullptr,
-                        speedup_only, stw, false, M.exclusive_cu ? R.lds_per_cu / 2 + 1024 : 0, M.launch_lean, any_speed, &defer);
-      }
-      // deferred output: the forms without output waves recorded their cross-fades and copies; expanded here, behind the walk
-      // kernel (a kernel of the whole chip's width, tens of microseconds).  Overlapping walk kernels (walk2): on the device's
-      // output stream behind an event, so that the walk stream goes straight on to the walk kernel of the call after next --
-      // the call's end (ring, done event) is then the output stream's.
-      if (defer.launched) {
-        hipStream_t so = (M.walk2 && output_own_stream()) ? dev_output_stream(plan->device) : nullptr;
-        if (so) {
-          if (!plan->ev_wout) HIPCHK(hipEventCreateWithFlags(&plan->ev_wout, hipEventDisableTiming));
-          HIPCHK(hipEventRecord(plan->ev_wout, stw));
-          HIPCHK(hipStreamWaitEvent(so, plan->ev_wout, 0));
-          sdone = so;
-        }
-        spx_launch_outputs(dj, n, maxC, in, out, defer.recs, defer.counts, sdone);
+                        speedup_only, stw, false, M.exclusive_cu ? R.lds_per_cu / 2 + 1024 : 0, M.launch_lean, any_speed);
       }
       if (M.ahead_forced && force->started_out) *force->started_out = d_ready + n;
       if (c == nch - 1 && !force) {
         // every call of the plan that walks leaves its event in the ring (a pipelined call orders its producers behind the walk
         // kernels of the calls before it, pipelined or not)
-        if (ring_record(plan, sdone, ws, st, out, n_out, detached)) return -2;
+        if (ring_record(plan, stw, ws, st, out, n_out, detached)) return -2;
         plan->ahead_started = (concurrent || ahead) ? d_ready + n : nullptr;   // (only these walk kernels count themselves in)
         plan->ahead_n = n;
         plan->mixed_started.clear();
@@ -1202,7 +1133,7 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
     if (!e1) HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e1, st));
   }
-  if (opt.done_event && do_w) HIPCHK(hipEventRecord(static_cast<hipEvent_t>(opt.done_event), detached ? sdone : st));
+  if (opt.done_event && do_w) HIPCHK(hipEventRecord(static_cast<hipEvent_t>(opt.done_event), detached ? stw : st));
   if (timed) { std::lock_guard<std::mutex> g(g_tmu); g_calls_pending++; }
   HIPCHK(hipGetLastError());
   return 0;

@@ -91,32 +91,8 @@ struct SpxStreamDev {
   int32_t tension_to;    // SPX_F_TENSION_RANGE: compute tension frames [tension_skip, tension_to)
   int32_t handed_in;     // SPX_F_HANDED_IN: ring buffers handed to the TSM stage before this job ...
   int32_t ring_bufs;     // ... and complete ring buffers that exist (n_in is the TSM input's length there, not the ring's)
-  int32_t rec_cap;       // deferred output (SpxOutRec): records this stream may write, from rec_off on (0: none -- the walk
-  int64_t rec_off;       // kernel then produces its samples itself)
+  int32_t pad4;
 };
-
-// Deferred output (round 6).  The walk forms WITHOUT output waves (lean 4 + 0: the headline's; throughput 2 + 0) used to produce a
-// step's samples on their search waves -- on the chain, a ninth of it.  Their deferred instantiations write one 16-byte record per
-// cross-fade / copy instead, and spx_output_kernel (spx_output.hip) expands the records of all streams afterwards: a wave per
-// record, every sample independent, off every chain.
-//   out     first output frame
-//   src     TSM position of the first input frame: the ramp-down run of a cross-fade, or the copy's source
-//   n       frames (bits 0-29); bit 30: the stream's flush limit applies (input from there on reads as the flush's zero padding;
-//           otherwise the limit is the written input, n_in + tsm_shift)
-//   period  cross-fade: the ramp-up run starts at src + period (libsonic overlapAdd);  0: a plain copy
-struct SpxOutRec { int32_t out, src, n, period; };
-#define SPX_REC_FLUSH_LIMIT (1 << 30)
-#define SPX_REC_MAX_COPY 4096   // a longer copy is cut into records of at most this many frames (one wave expands a record)
-struct SpxDefer {
-  SpxOutRec* recs;   // the batch's records (SpxStreamDev::rec_off indexes it)
-  int* counts;       // [2 i] records stream i wrote, [2 i + 1] its flush limit
-  bool launched;     // out: spx_launch_walk chose a deferred instantiation -- the caller runs spx_launch_outputs behind it
-};
-void spx_launch_outputs(const SpxStreamDev* streams, int n_streams, int max_channels, const int16_t* in, int16_t* out,
-                        const SpxOutRec* recs, const int* counts, hipStream_t st);
-// records a stream of n_in frames can write at most (a step consumes more than minPeriod frames, a copy pass maxRequired or a step's
-// remainder, an event is B frames): the workspace is sized with it, the kernel never writes beyond it
-int64_t spx_internal_rec_cap(const SpxPlanDev& P, int64_t n_in);
 
 // TSM-stage state (libsonic's stream struct) in absolute stream coordinates.
 struct SpxWalkState {
@@ -200,7 +176,7 @@ void spx_launch_tension(const SpxPlanDev& P, const SpxStreamDev* streams, int n_
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int max_channels,
                      const int16_t* in, int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
                      const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs = false, size_t lds_min = 0,
-                     bool lean = false, bool any_speed = false, SpxDefer* defer = nullptr);
+                     bool lean = false, bool any_speed = false);
 size_t spx_analysis_lds_bytes(const SpxPlanDev& P);
 int spx_analysis_ct_window(const SpxPlanDev& P);
 // The DFT of the spec run on the host (same operation order as the kernel): used to build the Rader tables.
@@ -227,9 +203,7 @@ bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm);
 void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, const int16_t* in,
                           int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
                           const int* speed_ready, int nwm, int nwc, int wcap, int max_channels, hipStream_t st, size_t lds_min = 0,
-                          bool slow = false, SpxDefer* defer = nullptr);
-// the forms spx_launch_walk_fast has deferred instantiations of (no output waves, speed-up only, not the wide-coarse ones)
-bool spx_walk_fast_defers(const SpxPlanDev& P, int nwc, bool slow);
+                          bool slow = false);
 // n_out value of a stream whose producer kernel never delivered (concurrent mode poll limit): not an overflow
 #define SPX_NOUT_LOST_PRODUCER INT64_MIN
 size_t spx_tension_lds_bytes();

@@ -1003,13 +1003,11 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   }
   return c;
 }
-int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC, int* scratch_bytes = nullptr, bool slow = false, bool defer = false);
+int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC, int* scratch_bytes = nullptr, bool slow = false);
 int spx_walk_kernel_regs(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool short_jobs, bool lean, int* scratch_bytes,
                          bool any_speed) {
   const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC < 1 ? 1 : maxC, speedup_only, short_jobs, lean, any_speed);
-  // (the batch engine runs the forms without output waves in their deferred-output instantiations, spx_launch_walk_fast; the
-  // coalesced streaming path -- short jobs -- keeps the ones that write their samples themselves)
-  if (cfg.fast_kernel) return spx_walk_fast_vgprs(P, cfg.nwm, cfg.nwc, cfg.wcap, maxC, scratch_bytes, cfg.slow, !short_jobs);
+  if (cfg.fast_kernel) return spx_walk_fast_vgprs(P, cfg.nwm, cfg.nwc, cfg.wcap, maxC, scratch_bytes, cfg.slow);
   const void* fn;
 #define SPX_FN_W(NWV) (cfg.mode == 1 ? reinterpret_cast<const void*>(spx_walk_kernel<NWV, 1>)   \
                        : cfg.mode == 2 ? reinterpret_cast<const void*>(spx_walk_kernel<NWV, 2>) \
@@ -1036,16 +1034,14 @@ extern "C" int spx_debug_last_walk_form(void) { return g_last_walk_form.load(std
 
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int maxC, const int16_t* in,
                      int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
-                     const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs, size_t lds_min, bool lean, bool any_speed,
-                     SpxDefer* defer) {
-  if (defer) defer->launched = false;
+                     const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs, size_t lds_min, bool lean, bool any_speed) {
   if (n_streams <= 0) return;
   if (maxC < 1) maxC = 1;
   const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC, speedup_only, short_jobs, lean, any_speed);
   g_last_walk_form.store(cfg.fast_kernel ? 16 * cfg.nwm + cfg.nwc : 0, std::memory_order_relaxed);
   if (cfg.fast_kernel) {
     spx_launch_walk_fast(P, streams, n_streams, in, out, n_out, states, scratch, speed_ready, cfg.nwm, cfg.nwc, cfg.wcap,
-                         maxC, st, lds_min, cfg.slow, short_jobs ? nullptr : defer);
+                         maxC, st, lds_min, cfg.slow);
     return;
   }
   const int fast = cfg.mode;

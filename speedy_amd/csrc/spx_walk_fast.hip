@@ -704,8 +704,7 @@ template <int NWM, int NWC, int RATE, int SPEC, int MC>
 __global__ void __launch_bounds__(64 * (NWM + NWC)) __attribute__((amdgpu_waves_per_eu((RATE == 16000 && NWC > 0) ? 5 : (NWC == 0 ? SPX_TP_WAVES : (NWM == 8 ? 3 : 4)), (RATE == 16000 && NWC > 0) ? 5 : 8)))
 spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, const int16_t* __restrict__ in_base,
                      int16_t* __restrict__ out_base, int64_t* __restrict__ n_out, SpxStreamState* __restrict__ states,
-                     const float* scratch_base, const int* speed_ready, int wcap, SpxOutRec* __restrict__ out_recs,
-                     int* __restrict__ out_counts) {
+                     const float* scratch_base, const int* speed_ready, int wcap) {
   constexpr int NT = 64 * (NWM + NWC);
   constexpr int FCG = fcg_of(NWM), FRG = frg_of(NWM);
   static_assert(SPEC == 0 || (SPEC == 1 && RATE != 0 && NWC > 0) || (SPEC == 2 && RATE == 0 && NWM == 4),
@@ -717,11 +716,6 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   constexpr int CS = WIDEC ? 128 : 64;       // words per coarse sum buffer
   constexpr bool MCH = (MC & 1) != 0;
   constexpr bool SLOWK = (MC & 2) != 0;
-  // DEFERK (MC + 4, round 6): the forms without output waves write one SpxOutRec per cross-fade / copy instead of producing the
-  // samples on their search waves; spx_output_kernel expands the records afterwards (spx_internal.h "Deferred output").  What leaves
-  // the chain: the cross-fade's reciprocal, its two LDS reads, the quotient and the store of every step, and the copies' loops.
-  constexpr bool DEFERK = (MC & 4) != 0;
-  static_assert(!DEFERK || (NWC == 0 && !SLOWK && SPEC == 0), "deferred output: forms without output waves, speed-up only");
   // WIDE: refine searches of up to 121 lags (8 skip + 1; 44.1 kHz: 89, 48 kHz: 97) -- two lags per lane in the refine select,
   // sum buffers of 128 words.  The eight-search-wave form only (its rectangle has the lanes for that many lags).
   constexpr bool WIDE = NWM == 8;
@@ -1060,43 +1054,6 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   // exactly one workgroup barrier before the next command is published, and the two slots alternate, so a slot is
   // rewritten only after the output waves have consumed it.  Field k of a command is written by lane k of the last
   // search wave (v_writelane: no EXEC juggling).  NWC == 0: the search waves do the output work themselves.
-  // DEFERK: one record = four ints, field k written by lane k of wave 0 (v_writelane, one 16-byte store); every search wave
-  // counts.  A record beyond the stream's capacity (spx_internal_rec_cap: cannot happen) lands on the last slot and flags the
-  // stream as overflowed.
-  int nrec = 0, recFlag = 0;
-  pos_t flushLim = 0;
-  (void)nrec; (void)recFlag; (void)flushLim;
-  int* const recW = DEFERK ? reinterpret_cast<int*>(out_recs + S.rec_off) : nullptr;
-  const int recCap = DEFERK ? S.rec_cap : 0;
-  auto emit_rec = [&](pos_t o, pos_t src, int n, int period) __attribute__((always_inline)) {
-    if constexpr (DEFERK) {
-      if (wave == 0) {
-        int rec_ = 0;
-        rec_ = fast_writelane((int)o, 0, rec_);
-        rec_ = fast_writelane((int)src, 1, rec_);
-        rec_ = fast_writelane(n | recFlag, 2, rec_);
-        rec_ = fast_writelane(period, 3, rec_);
-        const int slot = nrec < recCap ? nrec : recCap - 1;
-        if (lane < 4) recW[4 * slot + lane] = rec_;
-      }
-      nrec++;
-    }
-  };
-  auto emit_copy = [&](pos_t o, pos_t src, pos_t n) __attribute__((always_inline)) {
-    if constexpr (DEFERK) {
-      while (SPX_UNLIKELY(n > SPX_REC_MAX_COPY)) {   // (a long pass-through at unity speed: one wave expands a record)
-        emit_rec(o, src, SPX_REC_MAX_COPY, 0);
-        o += SPX_REC_MAX_COPY; src += SPX_REC_MAX_COPY; n -= SPX_REC_MAX_COPY;
-      }
-      if (n > 0) emit_rec(o, src, (int)n, 0);
-    }
-  };
-  // a step's cross-fade: handed to the output waves with the next command (or written by the search waves then), or -- DEFERK -- recorded
-#define SPX_STEP_XFADE(N, POS, PERIOD, OUT)                                                                    \
-  do {                                                                                                         \
-    if constexpr (DEFERK) emit_rec((OUT), (POS), (N), (PERIOD));                                               \
-    else { xf_n = (N); xf_down = (int)((POS) - wbase); xf_period = (PERIOD); xf_out = (OUT); }                 \
-  } while (0)
 #ifdef SPX_EXP_NO_OUTPUT_LEAN   // (diagnostic builds: the forms without output waves produce NO audio -- the chain's length without its output work)
 #define SPX_LEAN_OUTPUTS(CP_N, CP_SRC, CP_OUT) do { } while (0)
 #else
@@ -1123,8 +1080,6 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         cmd[(seq & 1) * FCMD_INTS + lane] = rec_;                                                                      \
       }                                                                                                                \
       seq++;                                                                                                           \
-    } else if constexpr (DEFERK) {                                                                                     \
-      emit_copy((pos_t)(CP_OUT), (pos_t)(CP_SRC), (pos_t)(CP_N));                                                      \
     } else {                                                                                                           \
       SPX_LEAN_OUTPUTS(CP_N, CP_SRC, CP_OUT);                                                                          \
     }                                                                                                                  \
@@ -1336,7 +1291,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         // a failed step (n == 0) is no branch of its own: it hands over no cross-fade (xf_n = 0), leaves pos where it is and ends
         // the loop through its condition
         failed = n == 0;
-        SPX_STEP_XFADE(n, pos, period, out_n);
+        xf_n = n; xf_down = (int)(pos - wbase); xf_period = period; xf_out = out_n;
         out_n += n;
         pos += failed ? 0 : period + n;
         FSTAMP(10);
@@ -1441,7 +1396,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
         nIn = 1;
         const pos_t remainingS = avail - base;
         expected = out_n + uni((int)(((float)remainingS / tailSpeed + 0) / 1.0f + 0.5f));
-        if constexpr (NWC == 0 && MCH && !DEFERK) {
+        if constexpr (NWC == 0 && MCH) {
           // a cross-fade still waiting to be written takes its ramps from the input at wbase + offset (several channels:
           // the window holds the mean only): write it while wbase is still the window it was decided in
           if (xf_n > 0) {
@@ -1450,7 +1405,6 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
           }
         }
         limit = avail;  // everything from here on reads as the flush's zero padding
-        if constexpr (DEFERK) { recFlag = SPX_REC_FLUSH_LIMIT; flushLim = avail; }
         wbase = -1;     // the window may hold samples past the new limit: the next step refills it
       }
       const pos_t idx = blk0 + lane;
@@ -1488,7 +1442,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
               const int period = find_period(pos, true, sm1, 0.0f, rinv, n, rem, std::true_type());
               if (out_n + n > X.out_cap) overflow = 1;
               failed = n == 0;
-              SPX_STEP_XFADE(n, pos, period, out_n);
+              xf_n = n; xf_down = (int)(pos - wbase); xf_period = period; xf_out = out_n;
               out_n += n;
               pos += failed ? 0 : period + n;
               FSTAMP(10);
@@ -1532,7 +1486,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
                 remaining = rem;
                 if (out_n + n > X.out_cap) overflow = 1;
                 failed = n == 0;
-                SPX_STEP_XFADE(n, pos, period, out_n);
+                xf_n = n; xf_down = (int)(pos - wbase); xf_period = period; xf_out = out_n;
                 out_n += n;
                 pos += failed ? 0 : period + n;
               }
@@ -1580,10 +1534,6 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   FAST_PUBLISH(FCMD_EXIT, 0, 0, 0, 0);
   if (NWC > 0) fast_sync();
   FSTAMP_FLUSH
-  if constexpr (DEFERK) {
-    if (nrec > recCap) overflow = 1;
-    if (tid == 0) { out_counts[2 * blockIdx.x] = nrec < recCap ? nrec : recCap; out_counts[2 * blockIdx.x + 1] = (int)flushLim; }
-  }
   if (tid == 0) {
     SpxWalkState W;
     W.base = base; W.out_n = out_n; W.avail = avail; W.remaining = remaining;
@@ -1601,7 +1551,6 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
   }
 #undef FAST_PUBLISH
 #undef SPX_LEAN_OUTPUTS
-#undef SPX_STEP_XFADE
 }
 
 size_t spx_walk_fast_lds_bytes(const SpxPlanDev& P, int wcap) { return (size_t)fast_lds_layout(P, wcap).total; }
@@ -1629,9 +1578,8 @@ bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm) {
 }
 
 // numRegs of the instantiation spx_launch_walk_fast picks for (nwm, nwc) at this plan's rate
-int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC, int* scratch_bytes, bool slow, bool defer) {
+int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC, int* scratch_bytes, bool slow) {
   const void* fn = nullptr;
-  defer = defer && spx_walk_fast_defers(P, nwc, slow);
   if (fast_wide_coarse(P.minPeriod, P.maxPeriod, P.skip)) {   // the wide-coarse instantiations (SPEC = 2): plan-driven, 4 + 4 or 4 + 0 waves
 #define SPX_FN_WC(C) (slow ? (maxC > 1 ? reinterpret_cast<const void*>(spx_walk_fast_kernel<4, C, 0, 2, 3>) : reinterpret_cast<const void*>(spx_walk_fast_kernel<4, C, 0, 2, 2>)) \
                            : (maxC > 1 ? reinterpret_cast<const void*>(spx_walk_fast_kernel<4, C, 0, 2, 1>) : reinterpret_cast<const void*>(spx_walk_fast_kernel<4, C, 0, 2, 0>)))
@@ -1649,11 +1597,9 @@ int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int max
                         : P.rate == 22050 && wcap == SPX_CT_WCAP_OF(M, C) ? reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 22050, 0, MCV>) \
                         : reinterpret_cast<const void*>(spx_walk_fast_kernel<M, C, 0, 0, MCV>))
 #define SPX_FN_R(M, C) (maxC > 1 ? SPX_FN_RM(M, C, 1) : SPX_FN_RM(M, C, 0))
-#define SPX_FN_RD(M) (maxC > 1 ? SPX_FN_RM(M, 0, 5) : SPX_FN_RM(M, 0, 4))   // the deferred-output instantiations (MC + 4)
   if (nwm == 4 && nwc >= 4 && wcap == SPX_CT_WCAP_LONG && (P.rate == 16000 || P.rate == 22050))
     fn = P.rate == 16000 ? (maxC > 1 ? reinterpret_cast<const void*>(spx_walk_fast_kernel<4, 4, 16000, 1, 1>) : reinterpret_cast<const void*>(spx_walk_fast_kernel<4, 4, 16000, 1, 0>))
                          : (maxC > 1 ? reinterpret_cast<const void*>(spx_walk_fast_kernel<4, 4, 22050, 1, 1>) : reinterpret_cast<const void*>(spx_walk_fast_kernel<4, 4, 22050, 1, 0>));
-  else if (defer && nwc == 0 && (nwm == 2 || nwm == 4)) fn = nwm == 2 ? SPX_FN_RD(2) : SPX_FN_RD(4);
 #ifdef SPX_TUNING
   else if (nwm == 8) fn = SPX_FN_R(8, 4);
   else if (nwm == 2) fn = nwc >= 1 ? SPX_FN_R(2, 1) : SPX_FN_R(2, 0);
@@ -1664,30 +1610,22 @@ int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int max
   else if (nwm == 2) fn = SPX_FN_R(2, 0);
   else fn = nwc >= 4 ? SPX_FN_R(4, 4) : SPX_FN_R(4, 0);
 #endif
-#undef SPX_FN_RD
 #undef SPX_FN_R
 #undef SPX_FN_RM
   return spx_kernel_vgprs(fn, scratch_bytes);
 }
 
-bool spx_walk_fast_defers(const SpxPlanDev& P, int nwc, bool slow) {
-  return nwc == 0 && !slow && !fast_wide_coarse(P.minPeriod, P.maxPeriod, P.skip);
-}
-
 void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, const int16_t* in,
                           int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
-                          const int* speed_ready, int nwm, int nwc, int wcap, int maxC, hipStream_t st, size_t lds_min, bool slow,
-                          SpxDefer* defer) {
+                          const int* speed_ready, int nwm, int nwc, int wcap, int maxC, hipStream_t st, size_t lds_min, bool slow) {
   if (n_streams <= 0) return;
-  SpxOutRec* d_recs = nullptr;
-  int* d_counts = nullptr;
   const FastLds LY = fast_lds_layout(P, wcap);
   // lds_min: the caller wants these workgroups ONE to a CU (it asks for more than half a CU's LDS): walk kernels of several
   // groups launched side by side otherwise land two to a CU here and there, and those chains end the call (spx_engine.hip)
   const size_t lds_req = (size_t)LY.total > lds_min ? (size_t)LY.total : lds_min;
 #define SPX_LAUNCH_FAST_RSM(M, C, R, SPECV, MCV)                                                                               \
   hipLaunchKernelGGL((spx_walk_fast_kernel<M, C, R, SPECV, MCV>), dim3(n_streams), dim3(64 * (M + C)), lds_req, st, P, streams, \
-                     in, out, n_out, states, scratch, speed_ready, wcap, d_recs, d_counts)
+                     in, out, n_out, states, scratch, speed_ready, wcap)
 #define SPX_LAUNCH_FAST_RS(M, C, R, SPECV)                                                                                \
   do { if (maxC > 1) SPX_LAUNCH_FAST_RSM(M, C, R, SPECV, 1); else SPX_LAUNCH_FAST_RSM(M, C, R, SPECV, 0); } while (0)
 #define SPX_LAUNCH_FAST_R(M, C, R) SPX_LAUNCH_FAST_RS(M, C, R, 0)
@@ -1723,21 +1661,6 @@ void spx_launch_walk_fast(const SpxPlanDev& P, const SpxStreamDev* streams, int 
     else if (nwc >= 4) SPX_LAUNCH_SLOW(4, 4);
     else SPX_LAUNCH_SLOW(4, 0);
 #undef SPX_LAUNCH_SLOW
-    return;
-  }
-  if (defer && defer->recs && spx_walk_fast_defers(P, nwc, slow) && (nwm == 2 || nwm == 4)) {
-    // deferred output (round 6): the forms without output waves record their cross-fades and copies; the caller expands them
-    // behind this launch (spx_launch_outputs)
-    d_recs = defer->recs; d_counts = defer->counts;
-    defer->launched = true;
-#define SPX_LAUNCH_FAST_D(M)                                                                                                    \
-  do {                                                                                                                         \
-    if (P.rate == 16000 && wcap == SPX_CT_WCAP_OF(M, 0)) { if (maxC > 1) SPX_LAUNCH_FAST_RSM(M, 0, 16000, 0, 5); else SPX_LAUNCH_FAST_RSM(M, 0, 16000, 0, 4); }      \
-    else if (P.rate == 22050 && wcap == SPX_CT_WCAP_OF(M, 0)) { if (maxC > 1) SPX_LAUNCH_FAST_RSM(M, 0, 22050, 0, 5); else SPX_LAUNCH_FAST_RSM(M, 0, 22050, 0, 4); } \
-    else { if (maxC > 1) SPX_LAUNCH_FAST_RSM(M, 0, 0, 0, 5); else SPX_LAUNCH_FAST_RSM(M, 0, 0, 0, 4); }                          \
-  } while (0)
-    if (nwm == 2) SPX_LAUNCH_FAST_D(2); else SPX_LAUNCH_FAST_D(4);
-#undef SPX_LAUNCH_FAST_D
     return;
   }
   // SPX_FAST_FORMS -- the forms the SHIPPED library carries are the ones spx_walk_config selects by itself: 4 + 4 waves (one or two

@@ -28,6 +28,10 @@ def test_bench_two_ranks_same_bytes_as_solo(tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
     assert line["config"]["n_ranks_seen"] == 2 and line["config"]["backend"] == "gloo" and line["config"]["handshake_ms"] > 0
     assert [r["rank"] for r in line["config"]["ranks"]] == [0, 1] and all("device" in r for r in line["config"]["ranks"])
+    # round 6: every rank says where it ran -- the NUMA node of its GPU, the CPUs it was left with, whether it was bound there
+    for rk in line["config"]["ranks"]:
+        assert {"numa_node", "cpus_allowed", "bound_to_numa_node", "pci", "h2d_alone_gbs"} <= set(rk), rk
+        assert rk["cpus_allowed"] >= 1
     assert line["config"]["streams_per_gpu"] == bench.STREAMS_PER_GPU
     n = bench.RATE * bench.SECONDS
     plan = Plan(bench.RATE, False)
@@ -108,3 +112,4 @@ def test_eight_ranks_functionally_on_one_gpu():
     assert out["ok"] and out["config4_streams_checked"] == 2048, out
     run8 = out["runs"]["8"]
     assert run8["n_ranks_seen"] == 8 and run8["backend"] == "gloo" and run8["ranks"] == list(range(8)), run8
+    assert len(run8["rank_numa"]) == 8 and all(len(v) == 3 and v[1] >= 1 for v in run8["rank_numa"]), run8   # (round 6: where each rank ran)

@@ -13,6 +13,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _record(test, guarded, detail):
+    """A skipped guard is green: what each guard actually did goes into gpurun_out/perf_guard.json, and bench.py copies the file
+    into its line (config.perf_guard) -- a record can then tell a guarded run from one whose box was too noisy to judge."""
+    path = os.path.join(ROOT, "gpurun_out", "perf_guard.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        cur = json.load(open(path)) if os.path.exists(path) else {}
+        cur[test] = {"guarded": bool(guarded), "detail": detail}
+        json.dump(cur, open(path, "w"), indent=1)
+    except Exception:  # noqa: BLE001
+        pass
+
+
 def measure_walk_ms(steps=12, warm=4):
     import torch
     import bench
@@ -81,11 +94,13 @@ def test_pipelined_step_and_lean_walk_kernel_within_10_percent_of_reference():
         pytest.skip("profiles/perf_reference.json has no 'pipelined' entry yet (python tools/perf_reference.py on the GPU box)")
     (a, b), kernel = measure_pipelined()
     if abs(a[0] - b[0]) > 0.04 * min(a[0], b[0]):
+        _record("pipelined", False, "noisy box: two windows %.3f / %.3f ms per step" % (a[0], b[0]))
         pytest.skip("noisy box: two windows of the pipelined loop %.3f / %.3f ms per step" % (a[0], b[0]))
     assert kernel == ref["kernel"], (kernel, ref["kernel"])
     step, walk = min(a[0], b[0]), min(a[1], b[1])
     msg = "pipelined loop %.3f ms per step (reference %.3f), lean walk kernel %.3f ms per launch (reference %.3f)" % (
         step, ref["ms_per_step"], walk, ref["walk_ms_per_launch"])
+    _record("pipelined", True, msg)
     assert step <= 1.10 * ref["ms_per_step"] and walk <= 1.10 * ref["walk_ms_per_launch"], msg
     if step > 1.05 * ref["ms_per_step"]:
         pytest.skip(msg + " -- between 5 and 10 %: check on another box")
@@ -95,6 +110,7 @@ def test_walk_kernel_within_5_percent_of_reference():
     ref = json.load(open(os.path.join(ROOT, "profiles", "perf_reference.json")))
     (a, b), kernel = measure_walk_ms()
     if abs(a - b) > 0.03 * min(a, b):
+        _record("walk_kernel", False, "noisy box: two measurements %.3f / %.3f ms" % (a, b))
         pytest.skip("noisy box: two measurements of the walk kernel %.3f / %.3f ms" % (a, b))
     got = min(a, b)
     assert kernel == ref["kernel"], (kernel, ref["kernel"])
@@ -104,6 +120,7 @@ def test_walk_kernel_within_5_percent_of_reference():
     # boxes of this pool differ by up to 3 % among themselves (same library, same streams: 2.28 ... 2.35 ms seen in round 3):
     # 5 .. 10 % above the reference is reported, not failed -- it needs a look on a second box (tools/perf_reference.py);
     # beyond 10 % it is a regression on any box
+    _record("walk_kernel", True, msg)
     assert excess <= 0.10, msg
     if excess > 0.05:
         pytest.skip(msg + " -- between 5 and 10 %: check on another box")
@@ -139,9 +156,12 @@ def test_shipped_code_placement_is_within_1_percent_of_its_neighbours():
             assert r.returncode == 0, r.stderr[-1500:]
             ms, spread = [float(v) for v in [ln for ln in r.stdout.splitlines() if ln.startswith("WALK")][-1].split()[1:]]
             if spread > 0.01:
+                _record("code_placement", False, "noisy box: %s measured twice %.1f %% apart" % (name, 100 * spread))
                 pytest.skip("noisy box: %s measured twice %.1f %% apart" % (name, 100 * spread))
             got[name].append(ms)
     best = {k: min(v) for k, v in got.items()}
     if max(abs(a - b) / min(a, b) for a, b in got.values()) > 0.007:
+        _record("code_placement", False, "noisy box: rounds disagree %r" % got)
         pytest.skip("noisy box: rounds disagree %r" % got)
+    _record("code_placement", True, "%r" % best)
     assert best["shipped"] <= 1.01 * min(best.values()), "SPX_WALK_PAD is no longer the best offset: %r -- re-run tools/walk_pad_sweep.sh" % best

@@ -280,3 +280,67 @@ def test_handles_on_two_threads(orc):
     assert not errors, errors
     for (speed, rep), v in got.items():
         assert np.array_equal(v, want[speed]), (speed, rep)
+
+
+def test_sixteen_threads_in_the_references_call_order_equal_oracle_call_for_call(orc):
+    """Round 6 (flat combining, sonic2_pool.hip): sixteen host threads, each with four handles of mixed kinds, each running the
+    REFERENCE's loop on its own handles -- write a chunk, read what is ready, next handle (speedy_wave.cc:199-220) -- at the same
+    time.  Every call of every handle must return the oracle's count and bytes (the oracle is driven by the same thread right
+    beside the handle), and the pool must have combined the threads' writes into common launch sequences."""
+    from speedy_amd.sonic2 import SonicStream, pool_stats
+    T, M = 16, 4
+    cfg = _configs(T * M, 3)
+    runs0, jobs0 = pool_stats()
+    errors = []
+    start = threading.Barrier(T)
+
+    def worker(t):
+        try:
+            mine = cfg[t * M:(t + 1) * M]
+            refs = [_Ref(orc, c["rate"], c["ch"], c["speed"], c["nl"], c["fb"], c["mm"]) for c in mine]
+            hs = []
+            for c in mine:
+                s = SonicStream(c["rate"], c["ch"], c["mm"])
+                s.set_speed(c["speed"]); s.enable_nonlinear(c["nl"]); s.set_feedback(c["fb"])
+                hs.append(s)
+            start.wait()
+            chunk = 1000
+            pos = 0
+            longest = max(c["x"].size // c["ch"] for c in mine)
+            while pos < longest:
+                for i, c in enumerate(mine):
+                    if pos >= c["x"].size // c["ch"]:
+                        continue
+                    seg = c["x"][pos * c["ch"]:(pos + chunk) * c["ch"]]
+                    refs[i].write(seg)
+                    assert hs[i].write_short(seg) == 1
+                    want = refs[i].read(chunk)
+                    got = hs[i].read_short(chunk)
+                    assert got.size == want.size and np.array_equal(got, want), (t, i, pos, got.size, want.size)
+                pos += chunk
+            for i in range(M):
+                refs[i].flush()
+                assert hs[i].flush() == 1
+                while True:
+                    want = refs[i].read(4096)
+                    got = hs[i].read_short(4096)
+                    assert np.array_equal(got, want), (t, i, "drain")
+                    if want.size == 0:
+                        break
+                refs[i].close()
+                hs[i].close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e)[:500])
+            try:
+                start.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors[:3]
+    runs, jobs = pool_stats()
+    assert runs > runs0 and (jobs - jobs0) / (runs - runs0) > 1.5, (runs - runs0, jobs - jobs0)

@@ -43,7 +43,8 @@ def main():
             line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
             lines[n] = {"value": line["value"], "ms_per_step": line["ms_per_step"], "n_ranks_seen": line["config"]["n_ranks_seen"],
                         "backend": line["config"]["backend"],
-                        "ranks": [r["rank"] for r in line["config"]["ranks"]]}
+                        "ranks": [r["rank"] for r in line["config"]["ranks"]],
+                        "rank_numa": [[r.get("numa_node"), r.get("cpus_allowed"), r.get("bound_to_numa_node")] for r in line["config"]["ranks"]]}
             per = line["config"]["streams_per_gpu"]
             for rank in range(n):
                 got = json.load(open("%s.rank%d.json" % (crc, rank)))

@@ -2,11 +2,16 @@
  * throughput of the drop-in API.  Every round writes `chunk` frames to each handle and then reads from each -- the
  * reference CLI's loop (speedy_wave.cc:199-231) turned sideways, as a server with N live streams runs it.
  *
- *   stream_bench STREAMS [SECONDS=10] [CHUNK=1000] [SPEED=3.5] [NONLINEAR=1] [ORDER=rounds|percall] [RATE=16000]
+ *   stream_bench STREAMS [SECONDS=10] [CHUNK=1000] [SPEED=3.5] [NONLINEAR=1] [ORDER=rounds|percall|threads:T] [RATE=16000]
  *
- * ORDER=percall reads right after each write (nothing can be coalesced: one launch sequence per handle per write).
+ * ORDER=percall reads right after each write, handle by handle -- the reference's own call order (speedy_wave.cc:199-220,
+ * sonic_test.cc:384-392) on one thread: one launch sequence per handle per write.
+ * ORDER=threads:T (round 6): T host threads, each with STREAMS / T handles of its own, each running that same write -> read loop
+ * over its handles -- a server's shape for an API whose streams are independent but not thread-safe (sonic2.h:54-84).  The
+ * library combines what the threads stage into common launch sequences (sonic2_pool.hip, flat combining).
  * Prints one line of JSON. */
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -40,6 +45,40 @@ static void synth(short* x, int n, int rate, unsigned seed) {
   }
 }
 
+typedef struct {
+  sonicStream* h;       /* this thread's handles */
+  int n_h, first;       /* their number, index of the first (source selection) */
+  short** src;
+  int n_src, n, chunk;
+  long long total_out, rounds;
+  unsigned long long crc;
+  int failed;
+  pthread_barrier_t* start;
+} worker_t;
+
+/* one thread of ORDER=threads:T: write a chunk to a handle, read what is ready, next handle (speedy_wave.cc:199-220 per handle) */
+static void* thread_main(void* arg) {
+  worker_t* w = (worker_t*)arg;
+  short* out = (short*)malloc(sizeof(short) * (size_t)(w->chunk > 8192 ? w->chunk : 8192));
+  int pos, i, got;
+  pthread_barrier_wait(w->start);
+  for (pos = w->chunk; pos < w->n; pos += w->chunk) {
+    const int k = pos + w->chunk <= w->n ? w->chunk : w->n - pos;
+    for (i = 0; i < w->n_h; i++) {
+      if (sonicWriteShortToStream(w->h[i], w->src[(w->first + i) % w->n_src] + pos, k) != 1) { w->failed = 1; free(out); return NULL; }
+      got = sonicReadShortFromStream(w->h[i], out, w->chunk);
+      w->total_out += got;
+      if (got > 0) w->crc = w->crc * 1315423911ull + (unsigned short)out[got - 1];
+    }
+    w->rounds++;
+  }
+  for (i = 0; i < w->n_h; i++) sonicFlushStream(w->h[i]);
+  for (i = 0; i < w->n_h; i++)
+    while ((got = sonicReadShortFromStream(w->h[i], out, 8192)) > 0) w->total_out += got;
+  free(out);
+  return NULL;
+}
+
 int main(int argc, char** argv) {
   const int streams = argc > 1 ? atoi(argv[1]) : 16;
   const double seconds = argc > 2 ? atof(argv[2]) : 10.0;
@@ -47,6 +86,7 @@ int main(int argc, char** argv) {
   const float speed = argc > 4 ? (float)atof(argv[4]) : 3.5f;
   const float nonlinear = argc > 5 ? (float)atof(argv[5]) : 1.0f;
   const int percall = argc > 6 && strcmp(argv[6], "percall") == 0;
+  const int threads = (argc > 6 && strncmp(argv[6], "threads:", 8) == 0) ? atoi(argv[6] + 8) : 0;
   const int rate = argc > 7 ? atoi(argv[7]) : 16000;
   const int n = (int)(seconds * rate);
   const int n_src = 8;
@@ -73,6 +113,38 @@ int main(int argc, char** argv) {
   for (i = 0; i < streams; i++) sonicWriteShortToStream(h[i], src[i % n_src], chunk < n ? chunk : n);
   for (i = 0; i < streams; i++) total_out += sonicReadShortFromStream(h[i], out, 8192);
   total_out = 0;
+  if (threads > 0) {
+    const int T = threads < streams ? threads : streams;
+    pthread_t* th = (pthread_t*)calloc((size_t)T, sizeof(pthread_t));
+    worker_t* w = (worker_t*)calloc((size_t)T, sizeof(worker_t));
+    pthread_barrier_t start;
+    int t, bad = 0;
+    pthread_barrier_init(&start, NULL, (unsigned)T + 1u);
+    for (t = 0; t < T; t++) {
+      const int a = (int)((long long)streams * t / T), b = (int)((long long)streams * (t + 1) / T);
+      w[t].h = h + a; w[t].n_h = b - a; w[t].first = a; w[t].src = src; w[t].n_src = n_src; w[t].n = n; w[t].chunk = chunk;
+      w[t].start = &start;
+      if (pthread_create(&th[t], NULL, thread_main, &w[t]) != 0) { fprintf(stderr, "pthread_create failed\n"); return 1; }
+    }
+    pthread_barrier_wait(&start);
+    t0 = now_s();
+    for (t = 0; t < T; t++) pthread_join(th[t], NULL);
+    t1 = now_s();
+    for (t = 0; t < T; t++) { total_out += w[t].total_out; crc ^= w[t].crc * (unsigned long long)(t + 1); bad |= w[t].failed; if (w[t].rounds > rounds) rounds = w[t].rounds; }
+    if (bad) { fprintf(stderr, "a thread's write failed: %s\n", speedyHipLastError()); return 1; }
+    {
+      const double dt = t1 - t0, in_frames = (double)streams * (double)(n - chunk);
+      unsigned long long runs = 0, jobs = 0;
+      speedyHipPoolStats(&runs, &jobs);
+      printf("{\"streams\": %d, \"threads\": %d, \"rate\": %d, \"seconds_each\": %.1f, \"chunk\": %d, \"speed\": %.2f, \"nonlinear\": %.2f, "
+             "\"order\": \"threads\", \"wall_s\": %.4f, \"msamples_per_s\": %.2f, \"x_realtime_per_stream\": %.1f, "
+             "\"us_per_round\": %.1f, \"frames_out\": %lld, \"launch_sequences\": %llu, \"handles_per_sequence\": %.1f, \"crc\": %llu}\n",
+             streams, T, rate, seconds, chunk, speed, nonlinear, dt, in_frames / dt * 1e-6, ((double)(n - chunk) / rate) / dt,
+             dt / (double)(rounds ? rounds : 1) * 1e6, total_out, runs, runs ? (double)jobs / (double)runs : 0.0, crc);
+    }
+    for (i = 0; i < streams; i++) sonicDestroyStream(h[i]);
+    return 0;
+  }
   t0 = now_s();
   for (pos = chunk; pos < n; pos += chunk) {
     const int w = pos + chunk <= n ? chunk : n - pos;
