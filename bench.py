@@ -19,7 +19,9 @@ Beside `value` the line carries (every figure ONE timed window of consecutive st
   config4_shard       one GPU's 256-stream shard of BASELINE configs[4] (weak: every rank its shard)
   config4_full        ALL of configs[4]: the fixed batch of --total-streams (2 048) mixed streams, rank r of N takes block r
                       (STRONG scaling; N = 1 runs all of it in one call)
-  api_256_handles     the drop-in API with 256 live sonicStream handles on one host thread
+  api_256_handles     the drop-in API with 256 live sonicStream handles on one host thread (write all, then read all)
+  api_percall_256     ... in the reference's own call order (write, read, next handle) on one thread
+  api_threads         ... and on 16 host threads x 16 handles (64 x 4 and 256 x 1 beside it)
   cpu_baseline        the CPU port on the host cores, with the output CRCs of the GPU legs checked against it
   cpu_baseline_fftw   the same with the reference's FFT library when the box has libfftw3 (dlopen); {"fftw": "absent"} otherwise
 
@@ -225,26 +227,41 @@ def cpu_baseline(streams, gpu_outputs, budget_s=12.0, c4_checks=None, rate_check
     return res
 
 
-def api_many_handles(streams=256, seconds=40.0):
-    """The same configuration through the reference's own API (include/sonic2.h): 256 live sonicStream handles on ONE host
-    thread, every round writes 1000 frames to each handle and then reads from each (speedy_wave.cc:199-220 per handle).
-    A C program (tools/stream_bench.c) in a child process; host-to-device and device-to-host transfers included.  ONE run
-    (one timed window of seconds * 16 rounds), like every other figure of the line."""
+def api_many_handles(streams=256, seconds=40.0, order="rounds"):
+    """The same configuration through the reference's own API (include/sonic2.h) with 256 live sonicStream handles, a C program
+    (tools/stream_bench.c) in a child process; host-to-device and device-to-host transfers included.  ONE run, like every other
+    figure of the line.  `order`:
+      rounds      one host thread; every round writes 1000 frames to each handle and THEN reads from each (api_256_handles)
+      percall     one host thread in the reference's own call order -- write a chunk, read right away, next handle
+                  (speedy_wave.cc:199-220, sonic_test.cc:384-392): one launch sequence per handle per write (api_percall_256)
+      threads:T   T host threads, each running that write -> read loop over its own 256 / T handles: the library combines what
+                  the threads stage into common launch sequences (sonic2_pool.hip, flat combining; api_threads)"""
     exe = os.path.join(ROOT, "speedy_amd", "lib", "stream_bench")
     try:
         if not os.path.exists(exe):
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "speedy_amd", "csrc"), "streambench"])
-        out = subprocess.run([exe, str(streams), str(seconds), "1000", str(SPEED), "1", "rounds", str(RATE)],
-                             capture_output=True, text=True, timeout=600)
+        out = subprocess.run([exe, str(streams), str(seconds), "1000", str(SPEED), "1", order, str(RATE)],
+                             capture_output=True, text=True, timeout=900)
         if out.returncode != 0:
             return {"error": out.stderr.strip()[-300:]}
         best = json.loads(out.stdout.strip().splitlines()[-1])
-        return {"value": best["msamples_per_s"], "unit": "Msamples/s", "streams": streams, "chunk_frames": 1000,
-                "x_realtime_per_stream": best["x_realtime_per_stream"], "us_per_round": best["us_per_round"],
-                "handles_per_launch_sequence": best["handles_per_sequence"], "seconds_per_handle": seconds,
-                "note": "sonicWriteShortToStream x %d handles, then sonicReadShortFromStream x %d handles, per round; one host "
-                        "thread; staged writes of all handles run as one launch sequence (sonic2_pool.hip); synthetic "
-                        "speech-like input generated in C; one run" % (streams, streams)}
+        res = {"value": best["msamples_per_s"], "unit": "Msamples/s", "streams": streams, "chunk_frames": 1000, "order": order,
+               "x_realtime_per_stream": best["x_realtime_per_stream"], "us_per_round": best["us_per_round"],
+               "handles_per_launch_sequence": best["handles_per_sequence"], "seconds_per_handle": seconds}
+        if order == "rounds":
+            res["note"] = ("sonicWriteShortToStream x %d handles, then sonicReadShortFromStream x %d handles, per round; one host "
+                           "thread; staged writes of all handles run as one launch sequence (sonic2_pool.hip); synthetic "
+                           "speech-like input generated in C; one run" % (streams, streams))
+        elif order == "percall":
+            res["note"] = ("the reference's call order on one host thread: write 1000 frames to a handle, read, next handle -- every read "
+                           "needs its write's result, so every write is a launch sequence of its own")
+        else:
+            res["threads"] = best.get("threads")
+            res["note"] = ("%s host threads x %d handles each, every thread in the reference's call order (write, read, next handle); a "
+                           "thread cannot have more than one write outstanding, so a launch sequence carries at most one handle per "
+                           "thread: the ceiling is threads x 1000 frames per sequence latency (~0.1 ms), whatever the handle count"
+                           % (best.get("threads"), streams // max(1, int(best.get("threads") or 1))))
+        return res
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)[:300]}
 
@@ -933,6 +950,12 @@ def main():
             line["config4_full"] = c4f
         if not args.no_api and world == 1:
             line["api_256_handles"] = api_many_handles()
+            # the reference's OWN call order: one thread, then 16 threads x 16 handles, then a thread per handle
+            line["api_percall_256"] = api_many_handles(seconds=4.0, order="percall")
+            line["api_threads"] = api_many_handles(seconds=16.0, order="threads:16")
+            line["api_threads"]["more_threads"] = {
+                "64x4": {k: v for k, v in api_many_handles(seconds=16.0, order="threads:64").items() if k in ("value", "handles_per_launch_sequence", "x_realtime_per_stream", "error")},
+                "256x1": {k: v for k, v in api_many_handles(seconds=16.0, order="threads:256").items() if k in ("value", "handles_per_launch_sequence", "x_realtime_per_stream", "error")}}
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (bench contract)
             line["cpu_baseline"] = cpu_baseline(streams, outs, c4_checks=c4_checks, rate_checks=rate_checks)
             line["cpu_baseline_fftw"] = line["cpu_baseline"].pop("cpu_baseline_fftw", {"fftw": "absent"})

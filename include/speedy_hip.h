@@ -161,7 +161,10 @@ size_t spx_pipeline_input_values(spx_pipeline_t p);
 int16_t* spx_pipeline_host_input(spx_pipeline_t p);
 /* Hand over one batch.  in: HOST memory (in_is_device = 0) -- must stay unchanged until the batch's input has been copied
  * (spx_pipeline_input_consumed, or the batch's spx_pipeline_wait) -- or DEVICE memory (in_is_device = 1), complete when the call is
- * made and unchanged until the batch's spx_pipeline_wait returns.  Returns the batch's ticket (0, 1, 2 ...) or a negative error.
+ * made and unchanged until the batch's spx_pipeline_wait returns; a device buffer is passed to the kernels as it is, and their
+ * aligned window loads may touch up to 64 int16 values behind the last stream's end: it must be ALLOCATED for
+ * spx_pipeline_input_values() + 64 values (the content of the padding does not matter; the same holds for the `in` of the
+ * spx_batch_* calls).  Returns the batch's ticket (0, 1, 2 ...) or a negative error.
  * At most `depth` batches are in flight: the call waits for the batch `depth` tickets back first. */
 int64_t spx_pipeline_submit(spx_pipeline_t p, const int16_t* in, int in_is_device);
 /* Blocks until the input handed over with `ticket` may be overwritten: the copy in has finished (host input), the batch's kernels

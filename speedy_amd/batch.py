@@ -374,6 +374,8 @@ class Pipeline:
         if isinstance(x, torch.Tensor):
             assert x.dtype == torch.int16 and x.is_contiguous() and x.numel() >= self.total_in
             device = x.is_cuda
+            # (include/speedy_hip.h: a device input is used in place and must be allocated 64 values past the last stream's end)
+            assert not device or x.numel() >= self.total_in + 64, "device input: allocate spx_pipeline_input_values() + 64 int16 values"
             ptr = x.data_ptr()
         else:
             x = np.ascontiguousarray(x, np.int16)

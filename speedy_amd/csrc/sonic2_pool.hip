@@ -37,6 +37,7 @@
 // launch get NULL base pointers and per-stream offsets that are the allocations' absolute element addresses.  The
 // per-frame arrays (records, scratch) are indexed by the kernels through ONE offset per stream, so for pooled handles
 // they live in a pool-wide frame arena: slot f = {rec[f], scr[4f..4f+3]}; a handle owns a power-of-two range of slots.
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -89,6 +90,7 @@ struct SpxPool {
   std::mutex mu;
   std::condition_variable cv;      // a run has finished (running -> false, its handles' inRun -> false)
   bool running = false;            // a run owns hTab / hRes / dWs / the stream, and the input area it was staged in
+  int waiters = 0;                 // threads inside wait_for_run (mutex)
   std::atomic<unsigned> gen{0};    // runs finished: a waiting thread polls it for a while before it blocks (wait_for_run)
   std::thread::id first_thread;    // the batching look costs a single-threaded caller nothing: only once a second thread is seen
   bool have_first = false, multi = false;
@@ -631,18 +633,27 @@ static void enlist(SpxPool* P, sonicStream s) {
 static void wait_for_run(SpxPool* P, std::unique_lock<std::mutex>& lk) {
   static const double spin_us = [] { const char* e = getenv("SPX_POOL_SPIN_US"); const double v = e ? atof(e) : 2000.0; return v < 200.0 ? v : 200.0; }();
   const unsigned g0 = P->gen.load(std::memory_order_acquire);
-  if (spin_us > 0) {
+  P->waiters++;
+  // (polling is for a handful of server threads on CPUs of their own; dozens of waiters -- more threads than CPUs, most likely --
+  // block at once: 256 threads on 16 CPUs served 104 Msamples/s blocking and 52 polling, profiles/r06/r6h_api_threads.txt)
+  if (spin_us > 0 && P->waiters <= 32) {
     lk.unlock();
     const auto t0 = std::chrono::steady_clock::now();
-    while (P->gen.load(std::memory_order_acquire) == g0 &&
-           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < spin_us) {
+    for (;;) {
+      if (P->gen.load(std::memory_order_acquire) != g0) break;
+      const double waited = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      if (waited >= spin_us) break;
+      // (more waiting threads than CPUs -- a cgroup quota does not show in the affinity mask: after a short pure spin the poll gives
+      // its time slice away, so that the combiner and the threads it serves are not kept off the CPUs by their own waiters)
+      if (waited > 20.0) sched_yield();
 #if defined(__x86_64__)
-      __builtin_ia32_pause();
+      else __builtin_ia32_pause();
 #endif
     }
     lk.lock();
   }
   if (P->gen.load(std::memory_order_acquire) == g0 && P->running) P->cv.wait(lk);
+  P->waiters--;
 }
 // every entry point: which threads use the pool (the batching look is for several), and a handle that is part of the run in
 // flight is the run's until its results are in

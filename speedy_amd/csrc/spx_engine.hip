@@ -1,25 +1,5 @@
-// C-ABI of the batch engine (include/speedy_hip.h): plan tables, workspace layout, kernel launches.
-#include <algorithm>
-#include <math.h>
-#include <cmath>
-#include <stdio.h>
-#include <string.h>
-
-#include <atomic>
-#include <map>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "../../include/speedy_hip.h"
-#include "spx_internal.h"
-#include "spx_mode.h"
-#include "spx_twiddle.h"
-#include "spx_twiddle_hashes.h"
-
-#ifndef M_PI
-#define M_PI 3.14159265358979323846
-#endif
+// C-ABI of the batch engine (include/speedy_hip.h): one batch call -- workspace layout, staging, streams, the ring of earlier calls, launches (plans: spx_plan.hip; mixed-rate calls: spx_mixed.hip).
+#include "spx_engine.h"
 
 // HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and a queue runs its kernels
 // in order.  This library alone holds up to five streams per device that must not block one another (the caller's or the
@@ -29,135 +9,33 @@
 // it is LOADED -- unless the application has set the variable itself (never overridden), or says SPX_KEEP_HW_QUEUES=1.  A process
 // that has made HIP calls before loading the library keeps what it had: INTEGRATION.md "Environment".
 __attribute__((constructor(101))) static void spx_default_hw_queues() {
-  if (!getenv("SPX_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  if (getenv("SPX_KEEP_HW_QUEUES") || getenv("GPU_MAX_HW_QUEUES")) return;
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  // (said once where somebody asked to be told what the library decides: it changed the process's environment)
+  if (getenv("SPX_DEBUG_MODE")) fprintf(stderr, "[spx] GPU_MAX_HW_QUEUES was unset: set to 8 at load time (SPX_KEEP_HW_QUEUES=1 leaves the environment alone)\n");
 }
 
-static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) {
-  g_err = msg;
-  return code;
-}
-#define HIPCHK(expr)                                                                          \
-  do {                                                                                        \
-    hipError_t e_ = (expr);                                                                   \
-    if (e_ != hipSuccess) return fail(-2, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-  } while (0)
-
-// roctx ranges around the host side of a batch call (rocprofv3 --marker-trace shows them next to the kernels).  The
-// tracer library is looked up at run time: the product has no link-time dependency on it and works without it.
-#include <dlfcn.h>
-struct SpxRoctx {
-  int (*push)(const char*) = nullptr;
-  int (*pop)() = nullptr;
-  SpxRoctx() {
-    // rocprofv3 follows the rocprofiler-sdk flavour of the API; the roctracer one (libroctx64) is the fallback
-    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_LOCAL);
-    if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_LOCAL);
-    if (!h) h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_LOCAL);
-    if (!h) h = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_LOCAL);
-    if (h) {
-      push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
-      pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
-      if (!push || !pop) { push = nullptr; pop = nullptr; }
-    }
-  }
-};
-struct SpxRange {
-  static SpxRoctx& api() { static SpxRoctx a; return a; }
-  explicit SpxRange(const char* name) { if (api().push) api().push(name); }
-  ~SpxRange() { if (api().pop) api().pop(); }
-};
-
-#define SPX_MAX_CHUNKS 16
-// The plan's ring of earlier calls (ring_wait below) and the library's walk streams per device (dev_walk_streams): the walk kernels
-// of consecutive pipelined calls take turns on up to SPX_MAX_WALK_STREAMS streams, and the ring remembers twice as many calls.
-#define SPX_MAX_WALK_STREAMS 4
-#define SPX_RING (2 * SPX_MAX_WALK_STREAMS)
-// Pinned staging slot for the small host tables of a call (job tables, tile order): the async copies read it after the
-// call has returned, so it is plan-owned and reused only once its copies have retired.
-struct SpxStage {
-  void* p = nullptr;
-  size_t cap = 0;
-  hipEvent_t done = nullptr;
-};
-struct spx_plan {
-  SpxPlanDev dev;
-  int device = 0;           // the HIP device the tables live on; calls must be made with it current
-  int cu_count = 1;
-  size_t lds_per_cu = 65536;
-  std::mutex mu;            // one launch sequence at a time per plan: side streams, events and staging are plan-owned
-  SpxStage stage[2];
-  int stage_next = 0;
-  // Mode trial for batch shapes where the register file admits only ONE analysis wave per SIMD beside the consumers:
-  // whether the concurrent mode pays then depends on how long the walk is (16 kHz stereo: 3.4 ms concurrent, 3.8 in
-  // sequence; 22.05 kHz mono: 3.0-4.6 against 2.3-3.2), so the second call of a shape runs concurrently and the third in
-  // sequence, both bracketed by events on the caller's stream, and later calls take the faster.  Results do not depend on it.
-  struct Trial {
-    SpxModeTrial state = {-1, 0, -1};   // key, calls, choice (-1 undecided, 0 sequential, 1 concurrent): spx_mode.h
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // [mode][begin / end]
-  } trial;
-  std::map<long long, SpxModeResources> res_cache;   // mode_resources: per batch shape
-  // spx_batch_run of more streams than CUs, split into overlapping sub-batches (run_split): the event its sub-batches' producers
-  // wait for (two, taking turns), and how the call that last used a workspace was split (spx_batch_read_steps must find the states)
-  hipEvent_t ev_split[2] = {nullptr, nullptr};
-  unsigned split_calls = 0;
-  std::map<const void*, int> split_of;
-  void* tables = nullptr;  // one device allocation behind dev.tw/tw2/window/taper*
-  // time-chunk pipelining of one batch call: the analysis of chunk c+1 runs on `side` while the walk of chunk c
-  // runs on the caller's stream
-  hipStream_t side = nullptr;
-  hipStream_t side2 = nullptr;   // concurrent mode: the tension kernel's stream
-  hipEvent_t ev_tension = nullptr;
-  hipEvent_t ev_start = nullptr;
-  hipEvent_t ev_chunk[SPX_MAX_CHUNKS] = {};
-  // spx_batch_run_ahead: the walk kernels of the plan's previous FOUR calls (ring_wait / ring_record below), the started-counter
-  // of the last one
-  hipEvent_t ev_walk[SPX_RING] = {};   // slot = call number mod SPX_RING
-  bool ev_walk_valid[SPX_RING] = {};
-  void* ring_ws[SPX_RING] = {};         // the workspace and the caller's stream of the call in the slot
-  hipStream_t ring_st[SPX_RING] = {};
-  int ahead_calls = 0;
-  hipEvent_t ev_call[2] = {nullptr, nullptr};   // the caller's stream as it stood when the last two pipelined calls were made
-  const void* ahead_last_out = nullptr;
-  const void* ahead_last_nout = nullptr;
-  bool ev_call_valid[2] = {false, false};
-  hipStream_t ev_call_st[2] = {nullptr, nullptr};   // ... and which stream each note was taken on (a detached call leaves none)
-  std::vector<std::pair<const int*, int>> mixed_started;   // the same for the groups of the last mixed call (lead plan)
-  const int* ahead_started = nullptr;
-  int ahead_n = 0;
-  // spx_batch_run_mixed: this plan's group runs on `mix`; the first plan of a call also lends the fork event and a staging slot
-  hipStream_t mix = nullptr;
-  hipEvent_t ev_join = nullptr, ev_fork = nullptr, ev_an = nullptr;
-  std::mutex mix_mu;
-  SpxStage mix_stage;
-};
+thread_local std::string g_spx_err;
 
 // Timing: one set of four HIP events per timed call, recorded on the launch stream and resolved lazily by
 // spx_timing_collect (so that the timed region itself carries no host synchronisation).
 // Process-wide switches are atomics; the event lists behind spx_timing_collect are guarded by g_tmu.  spx_batch_run may be
 // called from several host threads (one plan per thread, or one plan shared: launches on a plan are serialised by its mutex).
-static std::atomic<bool> g_timing{false};
-static std::atomic<int> g_last_concurrent{0};   // spx_debug_last_call_concurrent (2 = pipelined with the previous call)
-static std::atomic<int> g_concurrent{1};  // spx_set_concurrent: analysis and walk kernels on two streams, tile-flag hand-off
-static std::atomic<bool> g_chunks_set{false};  // the caller chose a chunk count (spx_set_pipeline_chunks)
-static std::atomic<int> g_chunks{1};  // spx_set_pipeline_chunks (measured on MI355X, 256 x 10 s: 1 -> 5.09 ms, 2 -> 5.25, 4 -> 5.54 per step)
-struct EvPair { hipEvent_t a, b; int kind; };  // kind 0 = analysis launch, 1 = walk launch, 2 = tension launch
-static std::mutex g_tmu;
-static std::vector<EvPair> g_ev_pending;
-static std::vector<hipEvent_t> g_ev_free;
-static int g_calls_pending = 0;
+std::atomic<bool> g_timing{false};
+std::atomic<int> g_last_concurrent{0};   // spx_debug_last_call_concurrent (2 = pipelined with the previous call)
+std::atomic<int> g_concurrent{1};  // spx_set_concurrent: analysis and walk kernels on two streams, tile-flag hand-off
+std::atomic<bool> g_chunks_set{false};  // the caller chose a chunk count (spx_set_pipeline_chunks)
+std::atomic<int> g_chunks{1};  // spx_set_pipeline_chunks (measured on MI355X, 256 x 10 s: 1 -> 5.09 ms, 2 -> 5.25, 4 -> 5.54 per step)
+std::mutex g_tmu;
+std::vector<EvPair> g_ev_pending;
+std::vector<hipEvent_t> g_ev_free;
+int g_calls_pending = 0;
 
 // Concurrent mode keeps polling workgroups resident; its deadlock-freedom bound (run_impl) counts the streams of ONE
 // call.  A second concurrent-mode call in flight on the same device (another plan, thread or stream) would break it, so
 // per device the last concurrent call leaves an event behind, and a call that finds it unfinished on a different stream
 // takes the sequential launch order instead (same results).  Calls on the same stream are ordered by the stream.
-struct SpxDevGuard {
-  std::mutex mu;
-  hipEvent_t last = nullptr;
-  hipStream_t last_stream = nullptr;
-  bool valid = false;
-};
-static SpxDevGuard g_guard[64];
+SpxDevGuard g_guard[64];
 
 // Allocated VGPRs of a kernel (hipFuncGetAttributes, rounded up to the granule of 8), cached per function: the query is not
 // free and the engine asks on every call.  Several plans may ask from several threads at once.
@@ -224,281 +102,10 @@ static bool device_is_ours(int dev) {
   return true;
 }
 
-// Upper bound on the frames a stream can produce from n_in input frames (flush padding included here).
-// speed >= 1: the stage never emits more than it consumes (the nonlinear speed stays >= 1, speedy.c:772).
-// speed < 1: one pitch step at speed s emits at most 2/s frames per frame consumed -- for s < 0.5 it emits
-// period + n and consumes n = (int)(period*s/(1-s)) >= 1, and period/n <= 2(1-s)/s because floor(x) >= x/2 for
-// x >= 1; for 0.5 <= s < 1 the ratio is (2*period + r)/(period + r) <= 2.  The nonlinear speed can sit at the
-// kMinimumSpeed clamp 0.01 (speedy.c:92,776) whatever the requested speed.
-int64_t spx_internal_out_bound(const SpxPlanDev& P, int64_t n_in, float speed, bool nonlinear) {
-  const int64_t slack = 4 * (int64_t)P.maxRequired + 1024;
-  if (speed >= 1.0f) return n_in + slack;
-  double s = nonlinear ? 0.01 : (double)speed;
-  if (s < 1e-4) s = 1e-4;
-  return (int64_t)((double)(n_in + 2 * (int64_t)P.maxRequired) * (2.0 / s)) + slack;
-}
-
-static int dev_walk_streams(int dev, hipStream_t* w, int n);   // (defined with the launch code below)
-static int walk_stream_count();
-void spx_internal_set_error(const char* msg) { g_err = msg ? msg : ""; }   // other translation units' errors reach spx_last_error
 extern "C" {
-
-const char* spx_last_error(void) { return g_err.c_str(); }
-// (host-only diagnostics, no GPU needed: tests/test_oracle_twiddle.py compares the library's twiddle routine with the oracle's and
-// with a 60-digit evaluation entry by entry)
-void spx_debug_twiddle_entry(long k, long n, double* c, double* s) { spx_tw::sincos_2pi(k, n, c, s); }
-unsigned long long spx_debug_twiddle_hash(long den, long count) {
-  uint64_t h = 0xcbf29ce484222325ull;
-  for (long t = 0; t < count; t++) {
-    double e[2];
-    spx_tw::entry(t, den, e);
-    const unsigned char* b = reinterpret_cast<const unsigned char*>(e);
-    for (int i = 0; i < 16; i++) { h ^= b[i]; h *= 0x100000001b3ull; }
-  }
-  return h;
-}
-int spx_abi_version(void) { return 1; }
-
-static int factor_radices(int n, int* radix) {  // DESIGN.md "DFT spec": 4s, then 2, 3s, 5s, other primes ascending
-  int ns = 0;
-  while (n % 4 == 0) { radix[ns++] = 4; n /= 4; }
-  while (n % 2 == 0) { radix[ns++] = 2; n /= 2; }
-  while (n % 3 == 0) { radix[ns++] = 3; n /= 3; }
-  while (n % 5 == 0) { radix[ns++] = 5; n /= 5; }
-  for (int p = 7; n > 1; p += 2)
-    while (n % p == 0) { radix[ns++] = p; n /= p; }
-  return ns;
-}
-
-spx_plan_t spx_plan_create(int sample_rate, int match_matlab) {
-  if (sample_rate < 1000 || sample_rate > 127999) {  // the walk kernel holds <= 256 lags per search
-    fail(-1, "spx_plan_create: unsupported sample rate");
-    return nullptr;
-  }
-  spx_plan* p = new spx_plan();
-  SpxPlanDev& d = p->dev;
-  memset(&d, 0, sizeof(d));
-  {
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&p->device) == hipSuccess && hipGetDeviceProperties(&prop, p->device) == hipSuccess) {
-      p->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
-      p->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? (size_t)prop.maxSharedMemoryPerMultiProcessor : 65536;
-    }
-  }
-  d.rate = sample_rate;
-  d.B = (int)(sample_rate / 100.0);                    // speedy.c:335-338
-  d.W = (int)(1.5 * sample_rate / (float)100.0);       // speedy.c:213
-  d.N = 2 * d.W;
-  d.F = match_matlab ? 8 : 12;                         // speedy.h:136-146
-  d.Pp = match_matlab ? 12 : 8;
-  d.nstages = (d.W > 1) ? factor_radices(d.W, d.radix) : 0;
-  if (d.nstages > SPX_MAX_STAGES) {
-    delete p;
-    fail(-1, "spx_plan_create: too many DFT stages");
-    return nullptr;
-  }
-  // (a window too large even for that leaves the plan to linear jobs -- the TSM stage alone, spx_internal_analysis_fits --
-  // and a nonlinear job on it is refused; no rate below 128 kHz is)
-  d.minPeriod = sample_rate / 400;
-  d.maxPeriod = sample_rate / 65;
-  d.maxRequired = 2 * d.maxPeriod;
-  d.skip = sample_rate > 4000 ? sample_rate / 4000 : 1;
-  d.alpha = (float)exp(-1.0 / (float)100.0);          // speedy.c:67 with time constant kFrameRateHz
-  d.one_minus_alpha = 1 - d.alpha;                     // float, speedy.c:74
-
-  const int W = d.W;
-  // Rader applies to a prime W > 64 whose W - 1 has no prime factor above 13 (DESIGN.md "DFT spec")
-  const int M = W - 1;
-  bool rader = W > 64;
-  for (int q = 2; rader && (long)q * q <= W; q++) if (W % q == 0) rader = false;
-  if (rader) {
-    int m = M;
-    for (int q = 2; q <= 13; q++) while (m % q == 0) m /= q;
-    rader = (m == 1);
-  }
-  if (rader) {
-    d.rader = 1;
-    d.nstagesM = factor_radices(M, d.radixM);
-  }
-  // The analysis tile must fit one CU's LDS: 16 frames and four transforming waves up to about 49 kHz, 8 frames up to about
-  // 61 kHz; above that (round 3) fewer waves transform -- their fp64 work areas are what grows -- and the tile shrinks to 4
-  // frames (its rows of log terms grow too): 2 waves up to about 100 kHz, 1 wave up to the 128 kHz the walk kernel takes.
-  d.dft_waves = 4;
-  d.tile_frames = spx_analysis_tile_frames();
-  const int cand[5][2] = {{spx_analysis_tile_frames(), 4}, {spx_analysis_small_tile_frames(), 4}, {spx_analysis_small_tile_frames(), 2},
-                          {spx_analysis_tiny_tile_frames(), 2}, {spx_analysis_tiny_tile_frames(), 1}};
-  for (int c = 0; c < 5; c++) {
-    d.tile_frames = cand[c][0];
-    d.dft_waves = cand[c][1];
-    if (spx_analysis_lds_bytes(d) <= 160 * 1024) break;
-  }
-  if (spx_analysis_prefers_small_tile(d)) {  // 44.1 / 48 kHz: the compiled-in kernels, two 8-frame workgroups per CU
-    d.tile_frames = spx_analysis_small_tile_frames();
-    d.dft_waves = 4;
-  }
-  const size_t n_tw = 2 * (size_t)W, n_win = (size_t)W, n_tf = d.F + 1, n_tp = d.Pp + 1;
-  const size_t n_rd = rader ? 2 * (size_t)M : 0;  // doubles in each of twM and bfft
-  const size_t n_ri = rader ? (size_t)M : 0;      // ints in each of perm and iperm
-  const size_t n_ql = rader ? (size_t)W : 0;      // ints in qlog
-  const size_t bytes = sizeof(double) * (2 * n_tw + 2 * n_rd) + sizeof(float) * (n_win + n_tf + n_tp + 8) +
-                       sizeof(int) * (2 * n_ri + n_ql);
-  std::vector<unsigned char> host(bytes, 0);
-  double* tw = reinterpret_cast<double*>(host.data());
-  double* tw2 = tw + n_tw;
-  double* twM = tw2 + n_tw;
-  double* bfft = twM + n_rd;
-  float* win = reinterpret_cast<float*>(bfft + n_rd);
-  float* tf = win + n_win;
-  float* tp = tf + n_tf;
-  int* perm = reinterpret_cast<int*>(tp + n_tp + 8);
-  int* iperm = perm + n_ri;
-  int* qlog = iperm + n_ri;
-  // A twiddle factor (cos, -sin)(2 pi t / den) comes from spx_twiddle.h: IEEE double operations on the integers (t, den), no libm call --
-  // the same bits on every machine (round 6; rounds 1-5 took the box's libm, round 5 "one sincos call", so GPU == oracle held on any
-  // one box only).  The Hamming window's cosine likewise (speedy.c:256-258: a double expression stored as float).
-  for (int t = 0; t < W; t++) {
-    spx_tw::entry(t, W, &tw[2 * t]);
-    spx_tw::entry(t, 2L * W, &tw2[2 * t]);
-    double c = 1.0, sn = 0.0;
-    if (W > 1) spx_tw::sincos_2pi(t, W - 1, &c, &sn);
-    win[t] = 0.54 - 0.46 * c;  // speedy.c:256-258
-  }
-  if (rader) {
-    for (int t = 0; t < M; t++) spx_tw::entry(t, M, &twM[2 * t]);
-    int g = 2;  // smallest primitive root of W
-    for (; g < W; g++) {
-      long v = 1;
-      int k = 0;
-      do { v = (v * g) % W; k++; } while (v != 1);
-      if (k == M) break;
-    }
-    long v = 1;
-    for (int k = 0; k < M; k++) { perm[k] = (int)v; v = (v * g) % W; }
-    for (int q = 0; q < M; q++) iperm[q] = perm[(M - q) % M];  // g^-q = g^(M-q)
-    for (int q = 0; q < M; q++) qlog[iperm[q]] = q;
-    std::vector<double> b(2 * (size_t)M);
-    for (int q = 0; q < M; q++) { b[2 * q] = tw[2 * iperm[q]]; b[2 * q + 1] = tw[2 * iperm[q] + 1]; }
-    spx_host_dft(M, d.radixM, d.nstagesM, twM, b.data(), bfft);
-  }
-  // the tables of the compiled-in window sizes are pinned (spx_twiddle_hashes.h, generated by tools/twiddle_tables.py from a 60-digit
-  // evaluation): a build whose host arithmetic strays (fast-math, a contracted multiply-add) is refused here, loudly
-  {
-    const struct { long den, count; const double* t; } built[3] = {{W, W, tw}, {2L * W, W, tw2}, {rader ? M : 0, rader ? M : 0, twM}};
-    for (const auto& b : built)
-      for (const auto& pin : spx_twiddle_pins)
-        if (b.count > 0 && pin.den == b.den && pin.count == b.count && spx_tw::fnv1a(b.t, 16 * (size_t)b.count) != pin.hash) {
-          delete p;
-          fail(-1, "spx_plan_create: a twiddle table does not hash to its pinned value (spx_twiddle_hashes.h) -- host code built with fast-math or fp contraction?");
-          return nullptr;
-        }
-  }
-  for (int i = 0; i <= d.F; i++) tf[i] = (d.F - i) / (float)d.F;    // speedy.c:597
-  for (int i = 0; i <= d.Pp; i++) tp[i] = (d.Pp - i) / (float)d.Pp;  // speedy.c:604
-  {
-    // The library's own streams of this device -- the side stream, the two walk streams -- are created NOW, before anything the
-    // process creates later (a pipeline object's run and copy streams, the caller's own): HIP maps streams onto hardware queues
-    // and pipes in creation order, and with the pipeline's two streams created FIRST its resident loop read 1.15 instead of 1.03 ms
-    // per batch (profiles/r05/r5c_order_probe.txt).
-    hipStream_t w[SPX_MAX_WALK_STREAMS];
-    (void)dev_walk_streams(p->device, w, walk_stream_count());
-    (void)hipGetLastError();
-  }
-  if (hipMalloc(&p->tables, bytes) != hipSuccess ||
-      hipMemcpy(p->tables, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
-    fail(-2, "spx_plan_create: device allocation/copy failed (is a GPU visible?)");
-    if (p->tables) (void)hipFree(p->tables);
-    delete p;
-    return nullptr;
-  }
-  unsigned char* base = static_cast<unsigned char*>(p->tables);
-  d.tw = reinterpret_cast<const double*>(base);
-  d.tw2 = d.tw + n_tw;
-  d.twM = d.tw2 + n_tw;
-  d.bfft = d.twM + n_rd;
-  d.window = reinterpret_cast<const float*>(d.bfft + n_rd);
-  d.taperF = d.window + n_win;
-  d.taperP = d.taperF + n_tf;
-  d.perm = reinterpret_cast<const int*>(d.taperP + n_tp + 8);
-  d.iperm = d.perm + n_ri;
-  d.qlog = d.iperm + n_ri;
-  return p;
-}
-
-void spx_plan_destroy(spx_plan_t plan) {
-  if (!plan) return;
-  // (side / side2 belong to the device, not to the plan: dev_side_streams)
-  if (plan->side) (void)hipStreamSynchronize(plan->side);
-  if (plan->side2) (void)hipStreamSynchronize(plan->side2);
-  if (plan->mix) { (void)hipStreamSynchronize(plan->mix); (void)hipStreamDestroy(plan->mix); }
-  if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
-  if (plan->ev_an) (void)hipEventDestroy(plan->ev_an);
-  if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
-  if (plan->mix_stage.done) { (void)hipEventSynchronize(plan->mix_stage.done); (void)hipEventDestroy(plan->mix_stage.done); }
-  if (plan->mix_stage.p) (void)hipHostFree(plan->mix_stage.p);
-  if (plan->ev_tension) (void)hipEventDestroy(plan->ev_tension);
-  if (plan->ev_start) (void)hipEventDestroy(plan->ev_start);
-  for (auto& e : plan->ev_chunk) if (e) (void)hipEventDestroy(e);
-  for (auto& e : plan->trial.ev) if (e) (void)hipEventDestroy(e);
-  for (auto& e : plan->ev_walk) if (e) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); }
-  for (auto& e : plan->ev_call) if (e) (void)hipEventDestroy(e);
-  for (auto& e : plan->ev_split) if (e) (void)hipEventDestroy(e);
-  for (auto& g : plan->stage) {
-    if (g.done) { (void)hipEventSynchronize(g.done); (void)hipEventDestroy(g.done); }
-    if (g.p) (void)hipHostFree(g.p);
-  }
-  if (plan->tables) (void)hipFree(plan->tables);
-  delete plan;
-}
-int spx_plan_frame_step(spx_plan_t p) { return p->dev.B; }
-int spx_plan_window_size(spx_plan_t p) { return p->dev.W; }
-int spx_plan_fft_size(spx_plan_t p) { return p->dev.N; }
-int spx_plan_future(spx_plan_t p) { return p->dev.F; }
-int spx_plan_max_required(spx_plan_t p) { return p->dev.maxRequired; }
-
-static int64_t frames_for(const SpxPlanDev& d, int64_t n_in) {
-  // frame j is sent to the analysis once sample j*B + W has been written (soniclib.c:440-444)
-  if (n_in < d.W + 1) return 0;
-  return (n_in - d.W - 1) / d.B + 1;
-}
-int64_t spx_plan_frames(spx_plan_t p, int64_t n_in) { return frames_for(p->dev, n_in); }
-
-int64_t spx_plan_out_capacity_for(spx_plan_t p, int64_t n_in, float speed, float nonlinear) {
-  return spx_internal_out_bound(p->dev, n_in, speed, nonlinear != 0.0f);
-}
-int64_t spx_plan_out_capacity(spx_plan_t p, int64_t n_in, float speed) {
-  return spx_internal_out_bound(p->dev, n_in, speed, true);
-}
 
 }  // extern "C"
-bool spx_internal_analysis_fits(const SpxPlanDev& d) { return spx_analysis_lds_bytes(d) <= 160 * 1024; }
-
-static spx_plan* shared_plan_full(int sample_rate, int match_matlab) {
-  static std::mutex mu;
-  static std::map<std::pair<int, std::pair<int, int>>, spx_plan*> cache;  // (device, (rate, mode)): tables are per device
-  std::lock_guard<std::mutex> g(mu);
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  auto key = std::make_pair(dev, std::make_pair(sample_rate, match_matlab ? 1 : 0));
-  auto it = cache.find(key);
-  if (it != cache.end()) return it->second;
-  spx_plan* p = spx_plan_create(sample_rate, match_matlab);
-  if (!p) return nullptr;
-  cache[key] = p;
-  return p;
-}
-const SpxPlanDev* spx_internal_shared_plan(int sample_rate, int match_matlab) {
-  spx_plan* p = shared_plan_full(sample_rate, match_matlab);
-  return p ? &p->dev : nullptr;
-}
-int64_t spx_internal_frames_for(const SpxPlanDev& d, int64_t n_in) { return frames_for(d, n_in); }
-extern "C" {
-
-struct Layout {
-  size_t off_streams, off_states, off_rec, off_scratch, off_order, off_flags, off_ready, total;
-  int64_t max_tiles;
-  int64_t total_frames;
-};
-static Layout layout_for(const SpxPlanDev& d, const spx_stream_job* jobs, int n) {
+Layout layout_for(const SpxPlanDev& d, const spx_stream_job* jobs, int n) {
   Layout L;
   int64_t tf = 0;
   for (int i = 0; i < n; i++) tf += (jobs[i].nonlinear != 0.0f) ? frames_for(d, jobs[i].n_in) : 0;
@@ -574,7 +181,6 @@ static SpxTapsDev taps_of(const spx_taps* t) {
   return d;
 }
 
-}  // extern "C"
 // Idle-start gate (run_impl): holds the analysis stream back until every workgroup of the call's walk kernel has been
 // placed -- each announces itself in started[0] (= speed_ready[n_streams]) -- so the wait ends with the event it is
 // for, not after a tuned delay.  Bounded (about 0.3 ms): should the two streams share a hardware queue, the walk launch
@@ -586,6 +192,9 @@ __global__ void spx_gate_kernel(const int* started, int n_walk, unsigned max_spi
       __builtin_amdgcn_s_sleep(8);   // 8 * 64 clocks, about 0.25 us
     }
   }
+}
+void spx_launch_gate(const int* started, int n_walk, unsigned max_spins, hipStream_t st) {
+  hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, st, started, n_walk, max_spins);
 }
 // Job tables (and tile order) from the plan's pinned staging slot into the workspace, hand-off flags cleared.
 __global__ void __launch_bounds__(256)
@@ -623,7 +232,7 @@ static hipEvent_t take_event() {
 // behind its own tension kernel, and the call ran analysis and walk one after the other (3.5 instead of 2.4 ms per 256 x 10 s
 // at 22.05 kHz, profiles/r03/r03aj_lean_22k.txt).  Only one concurrent-mode call is in flight per device anyway (SpxDevGuard);
 // calls that pipeline time chunks from several host threads share the analysis stream.
-static int dev_side_streams(int dev, hipStream_t* side, hipStream_t* side2) {
+int dev_side_streams(int dev, hipStream_t* side, hipStream_t* side2) {
   static std::mutex mu;
   static hipStream_t s1[64], s2[64];
   const int d = (dev >= 0 && dev < 64) ? dev : 0;
@@ -640,7 +249,7 @@ static int dev_side_streams(int dev, hipStream_t* side, hipStream_t* side2) {
 // stream -- idle in that order: the tension kernel runs behind the analysis on the first -- and up to three more.  Round 4 ran two
 // (four streams per device in all, the caller's included: one per hardware queue of HIP's default four); since round 5 the library
 // asks for eight hardware queues, and round 6 lets the mode decide how many walk launches are in flight (walk_stream_count).
-static int walk_stream_count() {
+int walk_stream_count() {
   static const int n = [] {
     const char* e = spx_tuning_env("SPX_WALK_STREAMS");
     if (!e && spx_tuning_env("SPX_WALK_STREAMS3")) return 3;
@@ -649,7 +258,7 @@ static int walk_stream_count() {
   }();
   return n;
 }
-static int dev_walk_streams(int dev, hipStream_t* w, int n) {
+int dev_walk_streams(int dev, hipStream_t* w, int n) {
   static std::mutex mu;
   static hipStream_t s3[64][SPX_MAX_WALK_STREAMS];   // [.][0] unused: the first walk stream is the second side stream
   hipStream_t side = nullptr, side2 = nullptr;
@@ -678,7 +287,7 @@ static int dev_walk_streams(int dev, hipStream_t* w, int n) {
 // still running.  *waited_prev: the producers were made to wait for the call right before this one (nothing of it is in flight
 // by the time they run: no gate for its walk kernel, see run_impl).
 // ring_record: how a call leaves its end -- and its output buffers -- in the ring.
-static int ring_note(spx_plan* plan, hipStream_t st) {
+int ring_note(spx_plan* plan, hipStream_t st) {
   const int cur = plan->ahead_calls & 1;
   if (!plan->ev_call[cur]) HIPCHK(hipEventCreateWithFlags(&plan->ev_call[cur], hipEventDisableTiming));
   HIPCHK(hipEventRecord(plan->ev_call[cur], st));
@@ -686,7 +295,7 @@ static int ring_note(spx_plan* plan, hipStream_t st) {
   plan->ev_call_st[cur] = st;
   return 0;
 }
-static int ring_wait(spx_plan* plan, hipStream_t sa, const void* ws, hipStream_t st, bool* waited_prev) {
+int ring_wait(spx_plan* plan, hipStream_t sa, const void* ws, hipStream_t st, bool* waited_prev) {
   const int c = plan->ahead_calls % SPX_RING;
   if (waited_prev) *waited_prev = false;
   for (int back = SPX_RING; back >= 1; back--) {
@@ -699,13 +308,13 @@ static int ring_wait(spx_plan* plan, hipStream_t sa, const void* ws, hipStream_t
   }
   return 0;
 }
-static bool ring_previous_in_flight(spx_plan* plan) {
+bool ring_previous_in_flight(spx_plan* plan) {
   const int j = (plan->ahead_calls + SPX_RING - 1) % SPX_RING;
   const bool f = plan->ev_walk_valid[j] && hipEventQuery(plan->ev_walk[j]) == hipErrorNotReady;
   (void)hipGetLastError();
   return f;
 }
-static int ring_record(spx_plan* plan, hipStream_t on, void* ws, hipStream_t st, const void* out, const void* n_out, bool detached = false) {
+int ring_record(spx_plan* plan, hipStream_t on, void* ws, hipStream_t st, const void* out, const void* n_out, bool detached) {
   const int c = plan->ahead_calls % SPX_RING;
   if (!plan->ev_walk[c]) HIPCHK(hipEventCreateWithFlags(&plan->ev_walk[c], hipEventDisableTiming));
   HIPCHK(hipEventRecord(plan->ev_walk[c], on));
@@ -720,7 +329,7 @@ static int ring_record(spx_plan* plan, hipStream_t on, void* ws, hipStream_t st,
 }
 
 // ---- the inputs of spx_choose_mode (spx_mode.h) ----
-static SpxModeEnv mode_env() {
+SpxModeEnv mode_env() {
   // the developers' A/B switches exist in builds with -DSPX_TUNING only (spx_tuning_env); read once per process
   static const SpxModeEnv fixed = [] {
     SpxModeEnv e;
@@ -741,11 +350,10 @@ static SpxModeEnv mode_env() {
   e.chunks = g_chunks.load();
   return e;
 }
-static bool device_ours_cb(void* ctx) { return device_is_ours(*static_cast<int*>(ctx)); }
+bool device_ours_cb(void* ctx) { return device_is_ours(*static_cast<int*>(ctx)); }
 // What kind of speeds a batch's jobs bring: speedup_only -- every job speeds up (the walk kernel specialised for speeds >= 1
 // applies); any_speed -- not all do, but every speed is one the speed-up kernel's slow-down instantiations take (round 5).
-struct SpxSpeedClass { int maxC; bool speedup_only, any_speed; };
-static SpxSpeedClass speed_class(const spx_stream_job* jobs, int n) {
+SpxSpeedClass speed_class(const spx_stream_job* jobs, int n) {
   SpxSpeedClass c = {1, true, true};
   for (int i = 0; i < n; i++) {
     if (jobs[i].channels > c.maxC) c.maxC = jobs[i].channels;
@@ -756,7 +364,7 @@ static SpxSpeedClass speed_class(const spx_stream_job* jobs, int n) {
   if (c.speedup_only) c.any_speed = false;   // (the flag means: slow-down jobs are there)
   return c;
 }
-static SpxModeWalk mode_walk(const SpxPlanDev& d, int n, int maxC, bool speedup_only, bool lean, bool any_speed = false) {
+SpxModeWalk mode_walk(const SpxPlanDev& d, int n, int maxC, bool speedup_only, bool lean, bool any_speed) {
   const SpxWalkConfig c = spx_walk_config(d, n, maxC, speedup_only, false, lean, any_speed);
   SpxModeWalk w;
   w.lds = c.lds; w.waves = c.waves; w.fast_kernel = c.fast_kernel; w.nwc = c.nwc;
@@ -856,29 +464,6 @@ struct SpxTimed {
   }
 };
 
-// `force`: the call is one group of a mixed-rate batch (spx_batch_run_mixed): the launch mode was decided for all groups
-// together, and the device guard is held by the caller.
-//   ahead_sa: the group of a pipelined mixed call -- its producers go to this stream at once (spx_batch_run_mixed_ahead orders it);
-//   started_out: where the group's walk workgroups count themselves in (for the next call's gate)
-//   total_streams: of all groups of the mixed call; after_analysis: recorded behind the group's analysis launch (or null)
-struct SpxForce { int concurrent; bool idle_start; int total_streams; hipEvent_t after_analysis; hipStream_t ahead_sa; const int** started_out; };
-struct SpxCallOpts {
-  const SpxForce* force = nullptr;
-  bool ahead_req = false;      // spx_batch_run_ahead: pipelined with the plan's previous call where the shape allows
-  bool overlap_req = false;    // spx_batch_run_overlapped: ... and its walk kernel beside the previous call's
-  void* in_ready = nullptr;    // hipEvent_t: the producers wait for it (the caller's "input is there")
-  bool sub = false;            // a sub-batch of a plain call the engine has split (run_split): its `out` is the whole call's, never
-                               // "the previous call's output buffer handed over again"
-  // The pipeline object's calls (spx_pipeline.hip): done_event (a hipEvent_t) is recorded behind everything the call enqueued --
-  // and with `detached`, a call whose walk kernel goes to one of the library's walk streams does not touch hip_stream AT ALL
-  // (no note, no wait for the walk kernel: the event is recorded on the walk stream).  A caller stream that carries nothing but
-  // waits for walk kernels is a hardware queue whose head is a blocked barrier packet for 2 ms of every 2; depending on where
-  // that queue happens to land among the process's queues, the kernels of the side stream were dispatched 50 us late after each
-  // such packet (profiles/r05/r5e_trace_*.txt, r5f_queue_probe.txt: 1.14 against 1.03 ms per batch).
-  void* done_event = nullptr;
-  bool detached = false;
-};
-
 // One batch call: decide the launch mode (spx_choose_mode, a pure function of the inputs collected here), then execute it.
 // The three launch orders give the same results:
 //   in sequence  -- staging, analysis, tension, walk on the caller's stream (time chunks: the analysis of chunk c + 1 on a side
@@ -887,9 +472,9 @@ struct SpxCallOpts {
 //                   tiles of frames, then speeds, are handed over through flags the consumers poll;
 //   ahead        -- staging, analysis and tension kernels on the side stream AT ONCE, beside the previous call's walk kernel;
 //                   the walk kernel behind them on the caller's stream, or (walk2) on one of the library's two walk streams.
-static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
-                    int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs, bool do_a,
-                    bool do_w, const SpxCallOpts& opt = SpxCallOpts()) {
+int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out,
+             int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps, void* hs, bool do_a,
+             bool do_w, const SpxCallOpts& opt) {
   if (!plan || !jobs || n <= 0) return fail(-1, "spx_batch: bad arguments");
   SpxRange range_(do_a && do_w ? "spx_batch_run" : (do_a ? "spx_batch_analyze" : "spx_batch_walk"));
   const SpxForce* force = opt.force;
@@ -900,6 +485,9 @@ static int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const in
   const int maxC = SC.maxC;
   const bool speedup_only = SC.speedup_only, any_speed = SC.any_speed;
   std::lock_guard<std::mutex> plan_lock(plan->mu);
+  // a call that is not a sub-batch of run_split's leaves no split record for its workspace (spx_batch_analyze / _walk and mixed
+  // calls come here directly: a stale record made spx_batch_read_steps look for sub-batch slices -- ADVICE r5)
+  if (!opt.split_part) plan->split_of.erase(ws);
   const SpxModeResources& R = mode_resources(plan, n, maxC, speedup_only, any_speed);
   if (R.walk.lds > 160 * 1024)   // one CU's LDS; the window holds every channel of maxRequired + 64 frames at least
     return fail(-1, "spx_batch: too many channels for the walk kernel's LDS window");
@@ -1200,8 +788,8 @@ static int run_split(spx_plan_t plan, const spx_stream_job* jobs, int n, const i
     const SpxMode M = spx_choose_mode(S, R, mode_env(), T, none);
     if (!(M.ahead && M.walk2)) P.k = 1;
   }
-  { std::lock_guard<std::mutex> g(plan->mu); if (plan->split_of.size() > 64) plan->split_of.clear(); plan->split_of[ws] = P.k; }
   if (P.k <= 1) return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, true, true, opt);
+  { std::lock_guard<std::mutex> g(plan->mu); if (plan->split_of.size() > 64) plan->split_of.clear(); plan->split_of[ws] = P.k; }
   hipStream_t st = static_cast<hipStream_t>(hs);
   void* ready = opt.in_ready;
   if (plain) {
@@ -1229,6 +817,7 @@ static int run_split(spx_plan_t plan, const spx_stream_job* jobs, int n, const i
     }
     SpxCallOpts o;
     o.ahead_req = o.overlap_req = true;
+    o.split_part = true;
     o.sub = i > 0 || plain;      // (the first sub-batch of an overlapped call is ordered like the call itself: "the same out buffer again")
     o.in_ready = ready;
     if (i == P.k - 1) o.done_event = opt.done_event;   // (on hip_stream, which waits for every sub-batch's walk kernel: never detached)
@@ -1278,292 +867,10 @@ int spx_batch_walk(spx_plan_t plan, const spx_stream_job* jobs, int n, const int
   return run_impl(plan, jobs, n, in, out, n_out, ws, ws_bytes, taps, hs, false, true);
 }
 
-// ---- one call for a batch whose streams differ in sample rate (BASELINE configs[4]: 16 kHz and 22.05 kHz, mono and
-// stereo, two speeds in one shard).  The reference fixes the rate per handle (soniclib.c:93, speedy.c:213-214), so any mix
-// can be alive at once; here the tables and the kernel instantiations are per rate (a plan), so the batch is cut into one
-// group per plan and ALL groups are launched together: every group on a HIP stream of its own (its walk kernel there, its
-// analysis and tension kernels on the plan's side streams), forked from and joined to the caller's stream -- the walk
-// workgroups of all groups are resident at the same time, one stream per CU as in a homogeneous batch.  The launch mode
-// (concurrent: walk kernels polling for speeds beside the analysis kernels; or in sequence) is decided once for all
-// groups together: the co-residency bound of run_impl counts the polling workgroups of all of them. ----
-__global__ void spx_scatter_nout_kernel(const int64_t* __restrict__ src, const int* __restrict__ idx, int n, int64_t* __restrict__ dst) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[idx[i]] = src[i];
-}
-struct MixedLayout { std::vector<size_t> ws_off, ws_bytes; size_t off_nout, off_idx, total; };
-static MixedLayout mixed_layout(const spx_plan_t* plans, int n_plans, const std::vector<std::vector<spx_stream_job>>& gj, int n) {
-  MixedLayout M;
-  size_t o = 0;
-  for (int g = 0; g < n_plans; g++) {
-    const size_t b = gj[g].empty() ? 0 : layout_for(plans[g]->dev, gj[g].data(), (int)gj[g].size()).total;
-    M.ws_off.push_back(o); M.ws_bytes.push_back(b);
-    o += (b + 255) & ~(size_t)255;
-  }
-  M.off_nout = o; o += ((sizeof(int64_t) * (size_t)n + 255) & ~(size_t)255);
-  M.off_idx = o;  o += ((sizeof(int) * (size_t)n + 255) & ~(size_t)255);
-  M.total = o;
-  return M;
-}
-static int mixed_groups(int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
-                        std::vector<std::vector<spx_stream_job>>& gj, std::vector<std::vector<int>>& gi) {
-  gj.assign(n_plans, {}); gi.assign(n_plans, {});
-  for (int i = 0; i < n; i++) {
-    const int g = plan_index ? plan_index[i] : 0;
-    if (g < 0 || g >= n_plans) return fail(-1, "spx_batch_run_mixed: plan_index out of range");
-    gj[g].push_back(jobs[i]); gi[g].push_back(i);
-  }
-  return 0;
-}
-size_t spx_batch_workspace_bytes_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index,
-                                       int n_streams) {
-  std::vector<std::vector<spx_stream_job>> gj;
-  std::vector<std::vector<int>> gi;
-  if (!plans || n_plans < 1 || !jobs || n_streams < 1 || mixed_groups(n_plans, jobs, plan_index, n_streams, gj, gi)) return 0;
-  return mixed_layout(plans, n_plans, gj, n_streams).total;
-}
-static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
-                      const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps,
-                      void* hs, bool ahead_req, void* in_ready = nullptr);
 }  // extern "C"
-// (spx_pipeline.hip: a pipelined mixed call whose producers wait for an "input is there" event)
-int spx_internal_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n, const int16_t* in,
-                           int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, void* hs, bool ahead, void* in_ready) {
-  return mixed_impl(plans, n_plans, jobs, plan_index, n, in, out, n_out, ws, ws_bytes, nullptr, hs, ahead, in_ready);
-}
-extern "C" {
-int spx_batch_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
-                        const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, void* hs) {
-  return mixed_impl(plans, n_plans, jobs, plan_index, n, in, out, n_out, ws, ws_bytes, nullptr, hs, false);
-}
-int spx_batch_run_mixed_taps(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
-                             const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps,
-                             void* hs) {
-  return mixed_impl(plans, n_plans, jobs, plan_index, n, in, out, n_out, ws, ws_bytes, taps, hs, false);
-}
-// spx_batch_run_ahead for a mixed-rate batch: consecutive calls (two workspaces taking turns, one HIP stream, the same lead
-// plan) pipelined -- every group's staging, analysis and tension kernels on the device's first side stream at once, beside the
-// previous call's walk kernels; the groups' walk kernels on their streams as in a plain call, each behind its tension kernel.
-int spx_batch_run_mixed_ahead(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
-                              const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, void* hs) {
-  return mixed_impl(plans, n_plans, jobs, plan_index, n, in, out, n_out, ws, ws_bytes, nullptr, hs, true);
-}
-static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
-                      const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps,
-                      void* hs, bool ahead_req, void* in_ready) {
-  if (!plans || n_plans < 1 || n_plans > 8 || !jobs || n <= 0) return fail(-1, "spx_batch_run_mixed: bad arguments");
-  SpxRange range_("spx_batch_run_mixed");
-  std::vector<std::vector<spx_stream_job>> gj;
-  std::vector<std::vector<int>> gi;
-  int rc = mixed_groups(n_plans, jobs, plan_index, n, gj, gi);
-  if (rc) return rc;
-  const MixedLayout M = mixed_layout(plans, n_plans, gj, n);
-  if (!ws || ws_bytes < M.total) return fail(-1, "spx_batch_run_mixed: workspace too small");
-  hipStream_t st = static_cast<hipStream_t>(hs);
-  spx_plan* lead = plans[0];
-  for (int g = 0; g < n_plans; g++) if (plans[g]->device != lead->device) return fail(-1, "spx_batch_run_mixed: plans of different devices");
-  // ---- the launch mode, for all groups together (spx_choose_mixed_mode: the rules of run_impl, summed / maximised over the groups) ----
-  std::vector<SpxModeGroup> G;
-  for (int g = 0; g < n_plans; g++) {
-    if (gj[g].empty()) continue;
-    const SpxPlanDev& d = plans[g]->dev;
-    const SpxSpeedClass SC = speed_class(gj[g].data(), (int)gj[g].size());
-    const int maxC = SC.maxC;
-    bool any_nl = false;
-    for (const auto& j : gj[g]) any_nl = any_nl || j.nonlinear != 0.0f;
-    SpxModeGroup mg;
-    mg.n = (int)gj[g].size();
-    mg.walk = mode_walk(d, mg.n, maxC, SC.speedup_only, false, SC.any_speed);
-    if (mg.walk.lds > 160 * 1024) return fail(-1, "spx_batch_run_mixed: too many channels for the walk kernel's LDS window");
-    mg.any_nonlinear = any_nl;
-    mg.an_lds = spx_analysis_lds_bytes(d);
-    mg.an_vgprs = spx_analysis_vgprs(d);
-    G.push_back(mg);
-  }
-  const int groups = (int)G.size();
-  static const int env_mixed = spx_tuning_env("SPX_MIXED_MODE") ? atoi(spx_tuning_env("SPX_MIXED_MODE")) : -1;   // tuning: 0 sequence, 1 concurrent
-  static const bool no_sjf = spx_tuning_env("SPX_MIXED_NO_ORDER") != nullptr;   // A/B
-  SpxModeRuntime T;
-  memset(&T, 0, sizeof(T));
-  T.device_ours = device_ours_cb;
-  T.device_ctx = &lead->device;
-  const SpxModeEnv E = mode_env();
-  SpxMixedMode MM = spx_choose_mixed_mode(G.data(), groups, n, lead->cu_count, lead->lds_per_cu, spx_tension_lds_bytes(), spx_tension_vgprs(),
-                                          E, env_mixed, no_sjf, ahead_req, T);
-  // ---- the device guard, once for the whole call ----
-  SpxDevGuard& guard = g_guard[(lead->device >= 0 && lead->device < 64) ? lead->device : 0];
-  std::unique_lock<std::mutex> guard_lock(guard.mu, std::defer_lock);
-  SpxForce force = {0, false, n, nullptr, nullptr, nullptr};
-  if (MM.concurrent) {
-    guard_lock.lock();
-    const hipError_t q = guard.valid ? hipEventQuery(guard.last) : hipSuccess;
-    (void)hipGetLastError();
-    force.idle_start = (q == hipSuccess);
-    if (guard.valid && guard.last_stream != st && q == hipErrorNotReady) {
-      T.guard_busy = true;
-      MM = spx_choose_mixed_mode(G.data(), groups, n, lead->cu_count, lead->lds_per_cu, spx_tension_lds_bytes(), spx_tension_vgprs(), E,
-                                 env_mixed, no_sjf, ahead_req, T);
-      guard_lock.unlock();
-    }
-  }
-  const bool concurrent = MM.concurrent;
-  // pipelined with the previous call (spx_batch_run_mixed_ahead): kernels in sequence, one stream per CU at most
-  const bool ahead = MM.ahead;
-  force.concurrent = concurrent ? 1 : 0;
-  // ---- fork: every group on its plan's own stream ----
-  std::lock_guard<std::mutex> lead_lock(lead->mix_mu);
-  {
-    // every call that goes through the lead plan's ring notes where the caller's stream stands when it is made: the next
-    // spx_batch_run_overlapped on that plan orders its walk kernel behind THIS note (round 4 left it to plain calls only, and
-    // an overlapped call behind a mixed one was ordered behind a stale note)
-    std::lock_guard<std::mutex> ring_lock(lead->mu);
-    if (ring_note(lead, st)) return -2;
-  }
-  if (!lead->ev_fork) HIPCHK(hipEventCreateWithFlags(&lead->ev_fork, hipEventDisableTiming));
-  if (in_ready && !ahead) HIPCHK(hipStreamWaitEvent(st, static_cast<hipEvent_t>(in_ready), 0));   // (ahead: the producers' stream waits for it)
-  HIPCHK(hipEventRecord(lead->ev_fork, st));
-  unsigned char* w = static_cast<unsigned char*>(ws);
-  int64_t* d_nout = reinterpret_cast<int64_t*>(w + M.off_nout);
-  int* d_idx = reinterpret_cast<int*>(w + M.off_idx);
-  // job -> group-order index table: one small pinned staging slot of the lead plan, copied by the stream
-  std::vector<int> order;
-  order.reserve((size_t)n);
-  for (int g = 0; g < n_plans; g++) order.insert(order.end(), gi[g].begin(), gi[g].end());
-  // (copied by the caller's stream -- or, pipelined, by the producers' stream below: the copy and its dispatch then are not part of
-  // what the caller's stream runs between the previous call's walk kernel and this call's, 44 -> 25 us between the two)
-  auto upload_idx = [&](hipStream_t on) -> int {
-    SpxStage& G = lead->mix_stage;
-    if (G.done) HIPCHK(hipEventSynchronize(G.done));
-    else HIPCHK(hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
-    if (G.cap < sizeof(int) * (size_t)n) {
-      if (G.p) (void)hipHostFree(G.p);
-      G.p = nullptr; G.cap = 0;
-      HIPCHK(hipHostMalloc(&G.p, sizeof(int) * (size_t)n * 2 + 1024, hipHostMallocDefault));
-      G.cap = sizeof(int) * (size_t)n * 2 + 1024;
-    }
-    memcpy(G.p, order.data(), sizeof(int) * (size_t)n);
-    HIPCHK(hipMemcpyAsync(d_idx, G.p, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, on));
-    HIPCHK(hipEventRecord(G.done, on));
-    return 0;
-  };
-  if (!ahead && upload_idx(st)) return -2;
-  std::vector<size_t> gpos(n_plans, 0);
-  { size_t pos = 0; for (int g = 0; g < n_plans; g++) { gpos[g] = pos; pos += gj[g].size(); } }
-  // taps: the rows of group g follow those of groups 0 .. g-1 (plan order, whatever order the groups are launched in); the
-  // row widths of the two spectrum taps are the group's own N and W
-  std::vector<spx_taps> gtaps(n_plans);
-  if (taps) {
-    size_t rows = 0, o_spec = 0, o_norm = 0;
-    for (int g = 0; g < n_plans; g++) {
-      spx_taps& t = gtaps[g];
-      t.tension = taps->tension ? taps->tension + rows : nullptr;
-      t.speed = taps->speed ? taps->speed + rows : nullptr;
-      t.features = taps->features ? taps->features + rows * SPX_FEATURE_COUNT : nullptr;
-      t.spectrogram = taps->spectrogram ? taps->spectrogram + o_spec : nullptr;
-      t.normalized = taps->normalized ? taps->normalized + o_norm : nullptr;
-      const size_t fr = gj[g].empty() ? 0 : (size_t)layout_for(plans[g]->dev, gj[g].data(), (int)gj[g].size()).total_frames;
-      rows += fr; o_spec += fr * (size_t)plans[g]->dev.N; o_norm += fr * (size_t)plans[g]->dev.W;
-    }
-  }
-  // Kernels in sequence: the groups' analysis kernels one after the other, the cheapest first (lowest rate: fewest frames
-  // and the shortest transform), instead of all at once.  Shared, every analysis ends late and every walk kernel starts
-  // late; shortest first, the first group's walk starts early and the last analysis -- alone on what the running walk
-  // kernels leave -- ends no later than it did shared (configs[4] shard: 16 kHz analysis done at 0.31 instead of 0.50 ms,
-  // 22.05 kHz at 0.87 instead of 0.92; the call ends with the later group's walk kernel).
-  std::vector<int> ord;
-  for (int g = 0; g < n_plans; g++) if (!gj[g].empty()) ord.push_back(g);
-  const bool chain_analyses = MM.chain_analyses;
-  if (chain_analyses) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return plans[a]->dev.rate < plans[b]->dev.rate; });
-  // Which stream a group runs on.  Kernels in sequence (every mix measured so far): the first group on the CALLER's stream,
-  // the second on the device's second side stream (idle in this mode), further groups on their plans' own streams -- so the
-  // usual two-rate call keeps this library at its three streams per device whatever else the process has created.  HIP maps
-  // streams onto a few hardware queues, a queue runs its kernels in order, and two groups whose streams share a queue run one
-  // after the other: with a stream per plan, the configs[4] shard took 4.95 instead of 3.0 ms in every process that had run
-  // a concurrent-mode call before (its two side streams had taken queues; profiles/r04/r04c_c4_prefix.txt).
-  hipStream_t dev_s1 = nullptr, dev_s2 = nullptr;
-  if (!concurrent && (ord.size() > 1 || ahead) && dev_side_streams(lead->device, &dev_s1, &dev_s2)) return fail(-1, "spx_batch_run_mixed: no side streams");
-  std::vector<const int*> started(n_plans, nullptr);
-  if (ahead) {
-    // the producers' stream: behind the walk kernels of the lead plan's call before the previous one (the last user of this
-    // workspace when two take turns; the previous call too if it used this workspace or another stream), and -- while the
-    // previous call is still in flight -- behind gate kernels that wait until its walk workgroups have been placed
-    // (no gates when the producers wait for the previous call anyway -- the same workspace handed over again: its counters are
-    // the ones this call's staging kernels clear, and a gate would spin its full bound for counts nobody raises)
-    std::lock_guard<std::mutex> ring_lock(lead->mu);
-    bool waited_prev = false;
-    if (ring_wait(lead, dev_s1, ws, st, &waited_prev)) return -2;
-    const bool in_flight = !waited_prev && ring_previous_in_flight(lead);
-    if (in_ready) HIPCHK(hipStreamWaitEvent(dev_s1, static_cast<hipEvent_t>(in_ready), 0));   // the caller's "input is there"
-    // the job -> group-order table for the scatter kernel at the call's end: behind the ring's events (the scatter kernel of the
-    // call that last used this workspace is behind them), in front of the groups' producers -- every walk kernel, and with them
-    // the caller's stream, is ordered behind it through the tension events
-    if (upload_idx(dev_s1)) return -2;
-    if (in_flight)
-      for (const auto& sn : lead->mixed_started)
-        if (sn.first && sn.second > 0) hipLaunchKernelGGL(spx_gate_kernel, dim3(1), dim3(64), 0, dev_s1, sn.first, sn.second, 8000u);
-  }
-  hipEvent_t prev_an = nullptr;
-  int launch_idx = 0;
-  for (int g : ord) {
-    spx_plan* p = plans[g];
-    hipStream_t gs = nullptr;
-    if (!concurrent && launch_idx == 0) gs = st;
-    else if (!concurrent && launch_idx == 1) gs = dev_s2;
-    else {
-      if (!p->mix) HIPCHK(hipStreamCreateWithFlags(&p->mix, hipStreamNonBlocking));
-      gs = p->mix;
-    }
-    launch_idx++;
-    if (!p->ev_join) HIPCHK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-    if (!p->ev_an) HIPCHK(hipEventCreateWithFlags(&p->ev_an, hipEventDisableTiming));
-    if (gs != st) HIPCHK(hipStreamWaitEvent(gs, lead->ev_fork, 0));
-    SpxForce f = force;
-    if (ahead) {
-      f.ahead_sa = dev_s1;            // (the analyses follow one another on that stream by themselves, cheapest first)
-      f.started_out = &started[g];
-    } else if (chain_analyses) {
-      if (prev_an) HIPCHK(hipStreamWaitEvent(gs, prev_an, 0));
-      f.after_analysis = p->ev_an;
-      prev_an = p->ev_an;
-    }
-    SpxCallOpts go;
-    go.force = &f;
-    rc = run_impl(p, gj[g].data(), (int)gj[g].size(), in, out, d_nout + gpos[g], w + M.ws_off[g], M.ws_bytes[g], taps ? &gtaps[g] : nullptr, gs,
-                  true, true, go);
-    // (also when the group failed: whatever it -- and the groups before it -- enqueued on their streams still reads the
-    // caller's buffers, so the caller's stream waits for it before the error is returned)
-    const std::string err = rc ? g_err : std::string();
-    if (gs != st && (hipEventRecord(p->ev_join, gs) != hipSuccess || hipStreamWaitEvent(st, p->ev_join, 0) != hipSuccess)) {
-      (void)hipGetLastError();
-      (void)hipStreamSynchronize(gs);   // no event: make sure by waiting here
-      if (!rc) return fail(-2, "spx_batch_run_mixed: joining a group's stream failed");
-    }
-    if (rc) return fail(rc, err);
-  }
-  hipLaunchKernelGGL(spx_scatter_nout_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_nout, d_idx, n, n_out);
-  {
-    // every mixed call leaves its end in the lead plan's ring (a pipelined call orders its producers behind the two calls before it)
-    std::lock_guard<std::mutex> ring_lock(lead->mu);
-    if (ring_record(lead, st, ws, st, out, n_out)) return -2;
-    lead->ahead_started = nullptr;
-    lead->ahead_n = 0;
-    lead->mixed_started.clear();
-    if (ahead)
-      for (int g = 0; g < n_plans; g++)
-        if (started[g]) lead->mixed_started.emplace_back(started[g], (int)gj[g].size());
-  }
-  if (concurrent) {
-    if (!guard.last) HIPCHK(hipEventCreateWithFlags(&guard.last, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(guard.last, st));
-    guard.last_stream = st;
-    guard.valid = true;
-  }
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
 // Pitch searches per stream of the batch's last run (SpxWalkState::steps): the length of every stream's dependent chain.
 // Waits for hip_stream, then copies the state records out of the workspace.
-static int read_steps(const SpxPlanDev& d, const spx_stream_job* jobs, int n, const void* ws, int32_t* steps, hipStream_t st) {
+int spx_read_steps(const SpxPlanDev& d, const spx_stream_job* jobs, int n, const void* ws, int32_t* steps, hipStream_t st) {
   const Layout L = layout_for(d, jobs, n);
   std::vector<SpxStreamState> h((size_t)n);
   HIPCHK(hipStreamSynchronize(st));
@@ -1571,249 +878,20 @@ static int read_steps(const SpxPlanDev& d, const spx_stream_job* jobs, int n, co
   for (int i = 0; i < n; i++) steps[i] = h[i].w.steps;
   return 0;
 }
+extern "C" {
 int spx_batch_read_steps(spx_plan_t plan, const spx_stream_job* jobs, int n, const void* ws, int32_t* steps, void* hs) {
   if (!plan || !jobs || n <= 0 || !ws || !steps) return fail(-1, "spx_batch_read_steps: bad arguments");
   int k = 1;
   { std::lock_guard<std::mutex> g(plan->mu); auto it = plan->split_of.find(ws); if (it != plan->split_of.end()) k = it->second; }
-  if (k <= 1) return read_steps(plan->dev, jobs, n, ws, steps, static_cast<hipStream_t>(hs));
+  if (k <= 1) return spx_read_steps(plan->dev, jobs, n, ws, steps, static_cast<hipStream_t>(hs));
   // the call that last ran on this workspace was split into sub-batches (run_split): their state records sit in their slices
   const SplitPlan P = split_geometry(plan, jobs, n, SPX_SPLIT_LIMIT);
   if (P.k != k) return fail(-1, "spx_batch_read_steps: the jobs are not those of the call that last ran on this workspace");
   for (int i = 0; i < P.k; i++) {
     const int a = P.first[i], m = P.first[i + 1] - a;
-    const int rc = read_steps(plan->dev, jobs + a, m, static_cast<const unsigned char*>(ws) + P.ws_off[i], steps + a, static_cast<hipStream_t>(hs));
+    const int rc = spx_read_steps(plan->dev, jobs + a, m, static_cast<const unsigned char*>(ws) + P.ws_off[i], steps + a, static_cast<hipStream_t>(hs));
     if (rc) return rc;
   }
   return 0;
 }
-int spx_batch_read_steps_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
-                               const void* ws, int32_t* steps, void* hs) {
-  if (!plans || n_plans < 1 || n_plans > 8 || !jobs || n <= 0 || !ws || !steps) return fail(-1, "spx_batch_read_steps_mixed: bad arguments");
-  std::vector<std::vector<spx_stream_job>> gj;
-  std::vector<std::vector<int>> gi;
-  int rc = mixed_groups(n_plans, jobs, plan_index, n, gj, gi);
-  if (rc) return rc;
-  const MixedLayout M = mixed_layout(plans, n_plans, gj, n);
-  for (int g = 0; g < n_plans; g++) {
-    if (gj[g].empty()) continue;
-    std::vector<int32_t> sg(gj[g].size());
-    rc = read_steps(plans[g]->dev, gj[g].data(), (int)gj[g].size(), static_cast<const unsigned char*>(ws) + M.ws_off[g], sg.data(),
-                    static_cast<hipStream_t>(hs));
-    if (rc) return rc;
-    for (size_t k = 0; k < sg.size(); k++) steps[gi[g][k]] = sg[k];
-  }
-  return 0;
-}
-
-// Names of the kernels a batch of this shape is served by, as a profiler prints them (without "void" and the argument
-// list): "analysis;tension;walk".  bench.py keys its roofline object and profiles/pmc_traffic.json with them.
-static const char* kernel_names(spx_plan_t plan, int n_streams, int max_channels, int speedup_only, bool lean);
-const char* spx_batch_kernel_names(spx_plan_t plan, int n_streams, int max_channels, int speedup_only) {
-  return kernel_names(plan, n_streams, max_channels, speedup_only, false);
-}
-// ... with the walk kernel in its lean form (no output waves): what spx_batch_run_overlapped launches when three or more
-// workspaces take turns, and the concurrent mode at 22.05 kHz mono
-const char* spx_batch_kernel_names_lean(spx_plan_t plan, int n_streams, int max_channels, int speedup_only) {
-  return kernel_names(plan, n_streams, max_channels, speedup_only, true);
-}
-static const char* kernel_names(spx_plan_t plan, int n_streams, int max_channels, int speedup_only, bool lean) {
-  static thread_local char buf[256];
-  const SpxPlanDev& d = plan->dev;
-  const SpxWalkConfig c = spx_walk_config(d, n_streams, max_channels < 1 ? 1 : max_channels, speedup_only != 0, false, lean, speedup_only == 0);
-  char walk[96];
-  if (c.fast_kernel && c.slow)
-    snprintf(walk, sizeof(walk), "spx_walk_fast_kernel<%d, %d, 0, 0, %d>", c.nwm, c.nwc >= 4 ? 4 : 0, max_channels > 1 ? 3 : 2);
-  else if (c.fast_kernel)
-    {
-      const bool ct_rate = d.rate == 16000 || d.rate == 22050;
-      const bool lng = ct_rate && c.nwm == 4 && c.nwc >= 4 && c.wcap == 8192;   // spx_launch_walk_fast's long-window instantiations
-      snprintf(walk, sizeof(walk), "spx_walk_fast_kernel<%d, %d, %d, %d, %d>", c.nwm, c.nwc >= 4 ? 4 : (c.nwc >= 2 ? 2 : (c.nwc >= 1 ? 1 : 0)),
-               (ct_rate && (lng || c.wcap == ((c.nwc == 0 && c.nwm <= 2) ? 1536 : 4096))) ? d.rate : 0, lng ? 1 : 0, max_channels > 1 ? 1 : 0);
-    }
-  else
-    snprintf(walk, sizeof(walk), "spx_walk_kernel<%d, %d>", c.nw, c.mode);
-  snprintf(buf, sizeof(buf), "spx_analysis_kernel<%d, %d>;spx_tension_kernel;%s", d.tile_frames, spx_analysis_ct_window(d), walk);
-  return buf;
-}
-
-int spx_debug_last_call_concurrent(void) { return g_last_concurrent.load(std::memory_order_relaxed); }
-int spx_debug_kernel_vgprs(int which) {
-  if (which == 0) return spx_tension_vgprs();
-  const int rate = (which == 2 || which == 4) ? 22050 : 16000;
-  const SpxPlanDev* P = spx_internal_shared_plan(rate, 0);
-  if (!P) return -1;
-  switch (which) {
-    case 1: return spx_walk_vgprs(*P, 256, 1, true, false);
-    case 2: return spx_walk_vgprs(*P, 256, 1, true, true);
-    case 3: case 4: return spx_analysis_vgprs(*P);
-    case 5: return spx_walk_vgprs(*P, 256, 2, true, false);
-    default: return -1;
-  }
-}
-
-// Diagnostics: what spx_launch_walk would launch for a batch of this shape, and what that kernel costs -- out[0] allocated
-// VGPRs (rounded up to the granule of 8), out[1] scratch bytes per lane (spilled registers), out[2] LDS bytes per workgroup,
-// out[3] the form (16 * search waves + output waves; 0 = the general kernel), out[4] waves per workgroup.
-int spx_debug_walk_info(int sample_rate, int channels, int n_streams, int speedup_only, int short_jobs, int lean, int* out) {
-  const SpxPlanDev* P = spx_internal_shared_plan(sample_rate, 0);
-  if (!P || !out) return -1;
-  const SpxWalkConfig c = spx_walk_config(*P, n_streams, channels < 1 ? 1 : channels, speedup_only != 0, short_jobs != 0, lean != 0, speedup_only == 0);
-  int scratch = -1;
-  out[0] = spx_walk_kernel_regs(*P, n_streams, channels, speedup_only != 0, short_jobs != 0, lean != 0, &scratch, speedup_only == 0);
-  out[1] = scratch;
-  out[2] = (int)c.lds;
-  out[3] = c.fast_kernel ? 16 * c.nwm + c.nwc : 0;
-  out[4] = c.waves;
-  return 0;
-}
-// ... and the same for the analysis kernel of a rate (out[0] VGPRs, out[1] scratch bytes, out[2] LDS bytes) and the tension kernel
-int spx_debug_analysis_info(int sample_rate, int* out) {
-  const SpxPlanDev* P = spx_internal_shared_plan(sample_rate, 0);
-  if (!P || !out) return -1;
-  int scratch = -1;
-  out[0] = spx_analysis_vgprs(*P, &scratch);
-  out[1] = scratch;
-  out[2] = (int)spx_analysis_lds_bytes(*P);
-  return 0;
-}
-
-void spx_set_timing(int enabled) { g_timing = enabled != 0; }
-void spx_set_concurrent(int on) { g_concurrent = on != 0; }
-void spx_set_pipeline_chunks(int chunks) { g_chunks_set = true; g_chunks = chunks < 1 ? 1 : (chunks > SPX_MAX_CHUNKS ? SPX_MAX_CHUNKS : chunks); }
-static double g_last_tension_ms = 0.0;
-double spx_timing_last_tension_ms(void) { return g_last_tension_ms; }
-int spx_timing_collect(double* sum_ms_analyze, double* sum_ms_walk, int* n_calls) {
-  std::lock_guard<std::mutex> g(g_tmu);
-  double a = 0, w = 0, t = 0;
-  for (auto& ev : g_ev_pending) {
-    HIPCHK(hipEventSynchronize(ev.b));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, ev.a, ev.b));
-    if (ev.kind == 0) a += ms; else if (ev.kind == 1) w += ms; else t += ms;
-    g_ev_free.push_back(ev.a);
-    g_ev_free.push_back(ev.b);
-  }
-  g_ev_pending.clear();
-  g_last_tension_ms = t;
-  if (sum_ms_analyze) *sum_ms_analyze = a;
-  if (sum_ms_walk) *sum_ms_walk = w;
-  if (n_calls) *n_calls = g_calls_pending;
-  g_calls_pending = 0;
-  return 0;
-}
-
-void* spx_device_alloc(size_t bytes) {
-  void* p = nullptr;
-  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { fail(-2, "spx_device_alloc failed"); return nullptr; }
-  return p;
-}
-void spx_device_free(void* p) { if (p) (void)hipFree(p); }
-int spx_copy_to_device(void* dst, const void* src, size_t bytes, void* hs) {
-  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(hs)));
-  return 0;
-}
-}  // extern "C"
-
-// ---- output packing: offsets by one workgroup (serial prefix over <= a few thousand streams), then one workgroup per
-// stream copying its frames with coalesced loads/stores ----
-__global__ void __launch_bounds__(256)
-spx_pack_offsets_kernel(const int64_t* __restrict__ n_out, const int* __restrict__ channels,
-                        const int64_t* __restrict__ caps, int n, int64_t* __restrict__ offsets) {
-  // exclusive prefix sum of the streams' element counts: 256 streams per pass, Hillis-Steele scan in LDS, running carry
-  __shared__ int64_t sh[256];
-  __shared__ int64_t carry;
-  const int t = threadIdx.x;
-  if (t == 0) carry = 0;
-  __syncthreads();
-  for (int i0 = 0; i0 < n; i0 += 256) {
-    const int i = i0 + t;
-    int64_t v = 0;
-    if (i < n) {
-      const int64_t k = n_out[i];
-      // a negative count flags an overflowed stream: the frames that fitted its capacity are there, the count says how
-      // many there would have been; INT64_MIN a lost producer (nothing)
-      int64_t f = (k == INT64_MIN ? 0 : (k > 0 ? k : -k));
-      if (f > caps[i]) f = caps[i];
-      v = f * channels[i];
-    }
-    sh[t] = v;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-      const int64_t add = (t >= d) ? sh[t - d] : 0;
-      __syncthreads();
-      sh[t] += add;
-      __syncthreads();
-    }
-    const int64_t base = carry;
-    if (i < n) offsets[i] = base + sh[t] - v;
-    __syncthreads();
-    if (t == 255) carry = base + sh[255];
-    __syncthreads();
-  }
-  if (t == 0) offsets[n] = carry;
-}
-__global__ void __launch_bounds__(256)
-spx_pack_copy_kernel(const int16_t* __restrict__ out, const int64_t* __restrict__ out_offs,
-                     const int64_t* __restrict__ offsets, int16_t* __restrict__ packed) {
-  // 4 workgroups per stream (blockIdx.y), eight 2-byte loads in flight per thread: the copy is latency-bound otherwise
-  // (one load per thread at a time took 0.3 ms for the bench batch's 26.7 MB)
-  const int i = blockIdx.x;
-  const int16_t* src = out + out_offs[i];
-  int16_t* dst = packed + offsets[i];
-  const int64_t cnt = offsets[i + 1] - offsets[i];
-  const int64_t stride = (int64_t)gridDim.y * 256 * 8;
-  for (int64_t e0 = ((int64_t)blockIdx.y * 256 + threadIdx.x); e0 < cnt; e0 += stride) {
-    int16_t v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) { const int64_t e = e0 + (int64_t)u * gridDim.y * 256; v[u] = (e < cnt) ? src[e] : (int16_t)0; }
-#pragma unroll
-    for (int u = 0; u < 8; u++) { const int64_t e = e0 + (int64_t)u * gridDim.y * 256; if (e < cnt) dst[e] = v[u]; }
-  }
-}
-
-extern "C" {
-int spx_batch_pack_outputs(const spx_stream_job* jobs, int n, const int16_t* out, const int64_t* n_out, int16_t* packed,
-                           int64_t* offsets, void* hs) {
-  if (!jobs || n <= 0 || !out || !n_out || !packed || !offsets) return fail(-1, "spx_batch_pack_outputs: bad arguments");
-  hipStream_t st = static_cast<hipStream_t>(hs);
-  // small per-stream tables (channels, output offsets): a stream-ordered allocation, freed in stream order after the
-  // kernels that read it, so concurrent calls on other streams never share it
-  const size_t need = (size_t)n * (2 * sizeof(int64_t) + sizeof(int));
-  void* d_tab = nullptr;
-  if (hipMallocAsync(&d_tab, need, st) != hipSuccess) return fail(-2, "spx_batch_pack_outputs: allocation failed");
-  // host side of the table: a per-thread pinned slot, reused once the copy that last read it has retired
-  static thread_local SpxStage G;
-  if (G.done) HIPCHK(hipEventSynchronize(G.done));
-  else HIPCHK(hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
-  if (G.cap < need) {
-    if (G.p) (void)hipHostFree(G.p);
-    G.p = nullptr; G.cap = 0;
-    HIPCHK(hipHostMalloc(&G.p, need * 2 + 1024, hipHostMallocDefault));
-    G.cap = need * 2 + 1024;
-  }
-  unsigned char* h = static_cast<unsigned char*>(G.p);
-  int64_t* h_off = reinterpret_cast<int64_t*>(h);
-  int64_t* h_cap = h_off + n;
-  int* h_ch = reinterpret_cast<int*>(h + (size_t)n * 2 * sizeof(int64_t));
-  for (int i = 0; i < n; i++) { h_off[i] = jobs[i].out_off; h_cap[i] = jobs[i].out_cap; h_ch[i] = jobs[i].channels; }
-  HIPCHK(hipMemcpyAsync(d_tab, h, need, hipMemcpyHostToDevice, st));
-  HIPCHK(hipEventRecord(G.done, st));
-  const int64_t* d_off = reinterpret_cast<const int64_t*>(d_tab);
-  const int* d_ch = reinterpret_cast<const int*>(static_cast<unsigned char*>(d_tab) + (size_t)n * 2 * sizeof(int64_t));
-  hipLaunchKernelGGL(spx_pack_offsets_kernel, dim3(1), dim3(256), 0, st, n_out, d_ch, d_off + n, n, offsets);
-  hipLaunchKernelGGL(spx_pack_copy_kernel, dim3(n, 4), dim3(256), 0, st, out, d_off, offsets, packed);
-  (void)hipFreeAsync(d_tab, st);
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
-int spx_copy_to_host(void* dst, const void* src, size_t bytes, void* hs) {
-  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(hs)));
-  return 0;
-}
-int spx_stream_synchronize(void* hs) {
-  HIPCHK(hipStreamSynchronize(static_cast<hipStream_t>(hs)));
-  return 0;
-}
-
 }  // extern "C"

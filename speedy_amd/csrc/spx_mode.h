@@ -248,8 +248,8 @@ static inline SpxMixedMode spx_choose_mixed_mode(const SpxModeGroup* G, int grou
   if (!E.concurrent_enabled || E.serial || groups == 0) concurrent = false;
   if (env_mixed_mode >= 0 && max_an_lds > 0) concurrent = env_mixed_mode == 1;
   if (concurrent && !ours()) concurrent = false;
+  if (concurrent && T.guard_busy) concurrent = false;   // (before `ahead`: a call that hits the busy guard is still pipelined -- ADVICE r5)
   M.ahead = ahead_req && !concurrent && E.concurrent_enabled && !E.serial && groups > 0 && n_total <= cu_count && ours();
-  if (concurrent && T.guard_busy) concurrent = false;
   M.concurrent = concurrent;
   M.chain_analyses = !concurrent && !no_order && groups > 1;
   return M;

@@ -250,10 +250,10 @@ def test_input_may_be_overwritten_once_consumed(orc):
         if k >= 2:
             assert _crc(pipe.results(tickets[k - 2])) == want[seq[k - 2]], k
     # device memory: the same with a device buffer; consumed = the batch is done
-    dbuf = torch.empty(pipe.total_in, dtype=torch.int16, device="cuda")
+    dbuf = torch.zeros(pipe.total_in + 64, dtype=torch.int16, device="cuda")   # (+ 64: include/speedy_hip.h spx_pipeline_submit, device input)
     da, db = torch.from_numpy(ia).cuda(), torch.from_numpy(ib).cuda()
     for key in "abba":
-        dbuf.copy_(da if key == "a" else db)
+        dbuf[: pipe.total_in].copy_((da if key == "a" else db)[: pipe.total_in])
         torch.cuda.synchronize()
         t = pipe.submit(dbuf)
         pipe.input_consumed(t)

@@ -14,7 +14,7 @@ OD=../lib/obj
 if [ -n "$TUNING" ]; then OD=../lib/obj_tuning; EXTRA="$EXTRA -DSPX_TUNING"; fi
 /opt/rocm/bin/hipcc $FLAGS $HOT $EXTRA -c spx_hot.hip -o ../lib/obj/spx_hot_$NAME.o
 OBJ=""
-for o in spx_walk spx_engine spx_pipeline sonic2_api speedy_api spx_rate sonic2_pool wave_compat; do OBJ="$OBJ $OD/$o.o"; done
+for o in spx_walk spx_plan spx_engine spx_mixed spx_diag spx_pipeline sonic2_api speedy_api spx_rate sonic2_pool wave_compat; do OBJ="$OBJ $OD/$o.o"; done
 /opt/rocm/bin/hipcc $FLAGS -shared -o ../lib/ab/libspeedy_hip_$NAME.so ../lib/obj/spx_hot_$NAME.o $OBJ
 rm -f ../lib/obj/spx_hot_$NAME.o
 echo "built speedy_amd/lib/ab/libspeedy_hip_$NAME.so"
