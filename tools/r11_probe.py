@@ -164,7 +164,8 @@ def pipeline_audio_against_the_oracle(rate, batches, verbose=True, seconds=2):
 
         for k in range(batches):
             buf = np.random.default_rng([s, k, 11]).integers(-20000, 20000, size=NS * n * ch).astype(np.int16)
-            dev = torch.from_numpy(buf).cuda()
+            dev = torch.zeros(buf.size + 64, dtype=torch.int16, device="cuda")   # (+ 64: include/speedy_hip.h spx_pipeline_submit, device input)
+            dev[: buf.size].copy_(torch.from_numpy(buf))
             flight.append((k, pipe.submit(dev), buf, dev))
             if len(flight) > 3:
                 k0, t0, b0, _ = flight.pop(0)
