@@ -469,6 +469,35 @@ def test_sub_batches_of_an_overlapped_call_with_taps(orc):
     assert np.array_equal(bs[0].tap_arrays(151)["speed"], o["speed"]) and np.array_equal(bs[0].tap_arrays(151)["tension"], o["tension"])
 
 
+def test_step_counts_after_a_split_call_then_the_two_halves_on_the_same_workspace(orc):
+    """an overlapped call of 300 streams is cut into two sub-batches, and the plan remembers that for the workspace
+    (spx_batch_read_steps looks for the state records in the sub-batches' slices).  spx_batch_analyze + spx_batch_walk on the SAME
+    workspace afterwards run as one batch -- the record must go with them, or the step counts come from the wrong places."""
+    import torch
+    from speedy_amd.batch import Batch, Plan
+    from speedy_amd.synth import speech_like
+    rate, n_streams = 16000, 300
+    plan = Plan(rate, False)
+    L = plan.L
+    lens = [int(rate * (0.4 + 0.001 * i)) for i in range(n_streams)]
+    xs = [speech_like(lens[i], rate, seed=40 + i % 12) for i in range(n_streams)]
+    b = Batch(plan, lens, 1, 3.5, 1.0, 0.0)
+    b.upload(xs)
+    b.run()
+    torch.cuda.synchronize()
+    want_crc, want_steps = _crc(b.results()), list(b.step_counts())
+    for _ in range(2):
+        b.run_ahead(overlap=True)          # split in two: the record says k = 2
+    torch.cuda.synchronize()
+    assert list(b.step_counts()) == want_steps and _crc(b.results()) == want_crc
+    hs = torch.cuda.current_stream().cuda_stream
+    assert L.spx_batch_analyze(plan.h, b.jobs, b.n, b.d_in.data_ptr(), b.d_ws.data_ptr(), b.d_ws.numel(), None, hs) == 0
+    assert L.spx_batch_walk(plan.h, b.jobs, b.n, b.d_in.data_ptr(), b.d_out.data_ptr(), b.d_nout.data_ptr(), b.d_ws.data_ptr(),
+                            b.d_ws.numel(), None, hs) == 0
+    torch.cuda.synchronize()
+    assert list(b.step_counts()) == want_steps and _crc(b.results()) == want_crc
+
+
 def test_mixed_batches_against_the_oracle_at_scale():
     """BASELINE configs[4]'s shard shape (256 streams: two rates, mono and stereo, speeds 1.5 and 3.5 in one spx_batch_run_mixed call),
     eight batches of ragged two-second noise streams, plain and pipelined calls taking turns: every stream's CRC-32 against the CPU

@@ -161,11 +161,16 @@ def test_mixed_rate_call(table):
     g = (C.c_longlong * len(groups))(*groups)
     out = (C.c_longlong * 4)()
 
-    def mixed(n_total=256, enabled=1, serial=0, ahead=0, busy=0, ours=1):
+    def mixed(n_total=256, enabled=1, serial=0, ahead=0, busy=0, ours=1, env_mixed=-1):
         assert L.spx_mode_table_eval_mixed(g, 2, n_total, r16["cu_count"], r16["lds_per_cu"], r16["tension_lds"], r16["tension_vgprs"],
-                                           enabled, serial, -1, 0, ahead, busy, ours, out) == 0
+                                           enabled, serial, env_mixed, 0, ahead, busy, ours, out) == 0
         return dict(concurrent=out[0], ahead=out[1], chain=out[2], asked=out[3])
     assert mixed() == dict(concurrent=0, ahead=0, chain=1, asked=0)          # 2 x 128 + 48 + 2 x 168 > 512: kernels in sequence, analyses chained
     assert mixed(ahead=1) == dict(concurrent=0, ahead=1, chain=1, asked=1)   # spx_batch_run_mixed_ahead
     assert mixed(ahead=1, ours=0)["ahead"] == 0 and mixed(ahead=1, enabled=0)["ahead"] == 0
     assert mixed(n_total=2048, ahead=1)["ahead"] == 0
+    # a mix that WOULD run concurrently (here: said so by the tuning switch) and finds another concurrent call in flight runs in
+    # sequence -- and, asked to, still pipelined with its predecessor (round 5 computed `ahead` before the busy guard: ADVICE r5)
+    assert mixed(env_mixed=1)["concurrent"] == 1
+    assert mixed(env_mixed=1, busy=1) == dict(concurrent=0, ahead=0, chain=1, asked=1)
+    assert mixed(env_mixed=1, busy=1, ahead=1) == dict(concurrent=0, ahead=1, chain=1, asked=1)

@@ -10,24 +10,36 @@
 #   sq_counters.json                        SQ instruction / wait / LDS counters per kernel (tools/sq_counters.sh)
 #   perf_reference.json, kernel_resources.json, scale_streams.txt, scale_configs.txt
 TAG=${1:-r6z}
+PARTS=${2:-bench,stats,pmc,sq,refs,scale}     # second argument: only these parts (comma-separated)
+has() { case ",$PARTS," in *",$1,"*) return 0;; esac; return 1; }
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 OUT=$PWD/gpurun_out; D=$OUT/$TAG; mkdir -p "$D"
 Q="--no-cpu-baseline --no-pcie --no-api --no-config4 --no-large-batch --no-other-rates"
+if has bench; then
 python3 bench.py > "$D/bench.json" 2> "$D/bench.err"; echo "bench rc $?"; head -c 600 "$D/bench.json"; echo
 python3 bench.py --steps 20 --warmup 5 > "$D/bench_steps20.json" 2>> "$D/bench.err"; echo "bench steps20 rc $?"
+fi
+if has stats; then
 timeout 600 rocprofv3 --kernel-trace --stats -d "$D/stats" -o stats --output-format csv -- python3 bench.py $Q --no-unpipelined > "$D/stats.log" 2>&1
 cp $(find "$D/stats" -name "*kernel_stats.csv" | head -1) "$D/kernel_stats_pipelined_loop.csv" 2>/dev/null; head -6 "$D/kernel_stats_pipelined_loop.csv"
+fi
+if has pmc; then
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c -d "$D/pmc_$c" -o pmc --output-format csv -- python3 bench.py --serial --steps 3 --warmup 1 $Q > "$D/pmc_$c.log" 2>&1
-  timeout 600 rocprofv3 --kernel-trace --pmc $c -d "$D/pmcp_$c" -o pmc --output-format csv -- python3 bench.py --steps 3 --warmup 1 $Q --no-unpipelined > "$D/pmcp_$c.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c -d "$D/dir_pmc_$c" -o pmc --output-format csv -- python3 bench.py --serial --steps 3 --warmup 1 $Q > "$D/pmc_$c.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c -d "$D/dir_pmcp_$c" -o pmc --output-format csv -- python3 bench.py --steps 3 --warmup 1 $Q --no-unpipelined > "$D/pmcp_$c.log" 2>&1
 done
-bash tools/sq_counters.sh $TAG/sq > "$D/sq.log" 2>&1; cp "$OUT/$TAG/sq_sq_counters.json" "$D/sq_counters.json" 2>/dev/null
-python3 tools/perf_reference.py > "$D/perf_reference.log" 2>&1; cp profiles/perf_reference.json "$D/perf_reference.json"
+fi
+has sq && { bash tools/sq_counters.sh $TAG/sq > "$D/sq.log" 2>&1; cp "$OUT/$TAG/sq_sq_counters.json" "$D/sq_counters.json" 2>/dev/null; rm -f "$OUT/$TAG/sq_sq_counters.json"; }
+if has refs; then
+python3 tools/perf_reference.py > "$D/perf_reference.log" 2>&1; cp "$OUT/perf_reference.json" "$D/perf_reference.json"
 python3 tools/kernel_resources.py > "$D/kernel_resources.log" 2>&1; cp profiles/kernel_resources.json "$D/kernel_resources.json"
+fi
+if has scale; then
 timeout 600 python3 tools/scale_streams.py 256 512 1024 2048 > "$D/scale_streams.txt" 2>&1
 timeout 900 python3 tools/scale_configs.py > "$D/scale_configs.txt" 2>&1
-python3 - "$D" <<'PY'
+fi
+has pmc && python3 - "$D" <<'PY'
 import csv, glob, json, os, sys
 D = sys.argv[1]
 traffic = {}
@@ -42,7 +54,7 @@ def key_of(name):
 for sub, what in (("pmc", "kernels in sequence (bench.py --serial --steps 3 --warmup 1): one kernel in flight at a time"),
                   ("pmcp", "the pipelined loop through the pipeline object (--no-unpipelined: its walk kernel in the lean form; no polling kernels)")):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        for f in glob.glob(os.path.join(D, "%s_%s" % (sub, counter), "**", "*counter_collection.csv"), recursive=True):
+        for f in glob.glob(os.path.join(D, "dir_%s_%s" % (sub, counter), "**", "*counter_collection.csv"), recursive=True):
             acc = {}
             for row in csv.DictReader(open(f)):
                 k = key_of(row["Kernel_Name"])
@@ -61,5 +73,5 @@ traffic["_note"] = "HBM bytes per launch, tools/collect_round.sh (one build, one
 json.dump(traffic, open(os.path.join(D, "pmc_traffic.json"), "w"), indent=1)
 print({k: v.get("hbm_bytes_per_launch") for k, v in traffic.items() if k != "_note"})
 PY
-rm -rf "$D"/pmc_* "$D"/pmcp_* "$D/stats" "$OUT/$TAG"/sq_sq[0-9]*
+rm -rf "$D"/dir_pmc* "$D/stats" "$OUT/$TAG"/sq_sq[0-9]*
 ls -la "$D"
