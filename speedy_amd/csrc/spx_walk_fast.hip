@@ -74,7 +74,7 @@
 #endif
 #define SPX_CT_WCAP_OF(NWMV, NWCV) (((NWCV) == 0 && (NWMV) <= 2) ? SPX_CT_WCAP_TP : SPX_CT_WCAP)
 enum { FCMD_STEP = 1, FCMD_COPY = 2, FCMD_REFILL = 3, FCMD_POLL = 4, FCMD_EXIT = 5 };
-// Diagnostic builds only (-DSPX_PROBE_SITE=k, tools/slack_probe.sh): about 100 cycles of s_nop at ONE place of the step.  What
+// Diagnostic builds only (-DSPX_PROBE_SITE=k through tools/build_variant.sh + tools/variant_times.sh; rounds 4-5: tools/slack_probe.sh, in the history): about 100 cycles of s_nop at ONE place of the step.  What
 // the walk kernel's time grows by tells whether that place is on the chain (all of it shows) or in the shadow of a wait (none
 // does) -- in-kernel time stamps cannot tell since the waits went: reading s_memtime drains the LDS counter and serialises
 // exactly the overlap that is to be measured.  Never in the product.
@@ -760,7 +760,7 @@ spx_walk_fast_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, con
 #if SPX_WALK_PAD > 0
   // Code placement: the step loop's speed depends on where it lies relative to the 64-byte instruction fetch lines (round 3:
   // removing ONE 8-byte prologue instruction, the loop's ISA unchanged, cost 2 %).  SPX_WALK_PAD s_nop's here, executed once,
-  // shift everything behind them by four bytes each.  Swept 0 .. 64 bytes (tools/walk_pad_sweep.sh,
+  // shift everything behind them by four bytes each.  Swept 0 .. 64 bytes (variants -DSPX_WALK_PAD=n through tools/build_variant.sh + tools/variant_times.sh; rounds 3-5: tools/walk_pad_sweep.sh,
   // profiles/r03/r03x_walk_pad.txt): the walk kernel of the bench batch read 2.29 .. 2.36 ms, periodic in 64 bytes; 8 bytes
   // was the best.  With the step loop of the round's second half the sweep reads 2.032 .. 2.056 ms (r03af_walk_pad.txt): 8
   // bytes is within 0.2 % of the best and stays.  Re-run the sweep after any change to this kernel.

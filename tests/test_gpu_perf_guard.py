@@ -164,4 +164,4 @@ def test_shipped_code_placement_is_within_1_percent_of_its_neighbours():
         _record("code_placement", False, "noisy box: rounds disagree %r" % got)
         pytest.skip("noisy box: rounds disagree %r" % got)
     _record("code_placement", True, "%r" % best)
-    assert best["shipped"] <= 1.01 * min(best.values()), "SPX_WALK_PAD is no longer the best offset: %r -- re-run tools/walk_pad_sweep.sh" % best
+    assert best["shipped"] <= 1.01 * min(best.values()), "SPX_WALK_PAD is no longer the best offset: %r -- sweep -DSPX_WALK_PAD=n variants (tools/build_variant.sh, tools/variant_times.sh)" % best

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build container: a variant of the library with extra compiler flags for the hot code object only, as
-# speedy_amd/lib/ab/libspeedy_hip_<NAME>.so (A/B on the GPU box: SPEEDY_HIP_LIB=... python bench.py, tools/ab_variants.sh).
+# speedy_amd/lib/ab/libspeedy_hip_<NAME>.so (A/B on the GPU box: SPEEDY_HIP_LIB=... python bench.py, tools/variant_times.sh).
 #   bash tools/build_variant.sh NAME "-DSPX_WALK_PAD=3 -DFOO"      (several can run in parallel)
 set -e
 NAME=$1; EXTRA=$2
