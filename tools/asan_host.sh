@@ -15,6 +15,9 @@ for seed in $(seq 1 ${1:-6}); do
   timeout 600 speedy_amd/lib/asan/api_fuzz $seed $((16 + 8 * (seed % 5))) 3000 >> $LOG 2>&1 || echo "api_fuzz seed $seed FAILED (rc $?)" >> $LOG
 done
 timeout 300 speedy_amd/lib/asan/stream_bench 64 4 >> $LOG 2>&1 || echo "stream_bench FAILED" >> $LOG
+# (round 6) sixteen host threads in the reference's call order on the coalesced pool: flat combining, the lock released while the GPU works
+timeout 300 speedy_amd/lib/asan/stream_bench 64 4 1000 3.5 1 threads:16 >> $LOG 2>&1 || echo "stream_bench threads:16 FAILED" >> $LOG
+timeout 300 speedy_amd/lib/asan/stream_bench 48 2 700 1.5 1 threads:48 22050 >> $LOG 2>&1 || echo "stream_bench threads:48 FAILED" >> $LOG
 # ... and the two C99 programs over include/speedy_hip.h: the batch call and the owning pipeline object (round 5), each checking its
 # own outputs
 RAW=gpurun_out/asan_in.raw
