@@ -368,6 +368,36 @@ def test_life_cycle_fuzz_interleaved(orc, seed):
             lives.pop(j)
 
 
+@pytest.mark.parametrize("seed", list(range(81, 85)) + list(range(8000, 8000 + SOAK // 4)))
+def test_life_cycle_fuzz_threads(orc, seed):
+    """Round 6 (flat combining, sonic2_pool.hip): the same random lives on SIX HOST THREADS at once, three lives after one another
+    per thread -- every thread in the reference's call order on its own handles, while the other threads' staged writes travel in
+    whatever launch sequence comes next, handles leave the pool (callbacks, rate, sonicInt*, mode switches) beside runs in flight
+    and handles are destroyed while other threads wait for a run.  Every call of every life equals the oracle shim's."""
+    import threading
+    ops = "flush,speed,rate,nl,fb,mode,direct".split(",")
+    pick = np.random.default_rng(seed)
+    cbs = None
+    if pick.random() < 0.5:
+        ops, cbs = ["flush", "speed", "fb", "nl"], False   # half of the seeds: nothing that takes a handle out of the pool
+    errors = []
+
+    def worker(t):
+        try:
+            for i in range(3):
+                for _ in _life_cycle_case(orc, np.random.default_rng([seed, t, i]), seed, (t + i) % 5, ops, None, callbacks=cbs):
+                    pass
+        except BaseException as e:  # noqa: BLE001
+            errors.append((t, repr(e)[:800]))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors[:2]
+
+
 @pytest.mark.parametrize("seed", list(range(71, 74)) + list(range(7000, 7000 + SOAK // 10)))
 def test_throughput_batch_fuzz(orc, seed):
     """Batches of 577 .. 1 100 streams: the walk kernel's throughput form (two search waves, no output waves, 1536-frame
