@@ -143,7 +143,9 @@ void sonicDestroyStream(sonicStream s) {
 
 // sonicIntSetRate also restarts the two rate positions (the dependency does; a sample waiting in its pitch buffer stays)
 // A setting changes what the NEXT job does; work a pooled handle has only staged so far was written under the old one.
-static inline void settle(sonicStream s) { if (s->pooled && s->poolPending) (void)spx_pool_sync(s); }
+// (Round 6: through the pool's lock whatever the handle's own flags say -- with several host threads the handle's staged write may
+// be part of a run ANOTHER thread's read started a moment ago: no longer "pending", not yet done; spx_pool_sync waits for that run.)
+static inline void settle(sonicStream s) { if (s->pooled) (void)spx_pool_sync(s); }
 void sonicSetRate(sonicStream s, float rate) {
   settle(s);
   s->rate = rate;
