@@ -67,7 +67,11 @@ struct SpxRange {
 #define SPX_MAX_CHUNKS 16
 // The plan's ring of earlier calls (ring_wait below) and the library's walk streams per device (dev_walk_streams): the walk kernels
 // of consecutive pipelined calls take turns on up to SPX_MAX_WALK_STREAMS streams, and the ring remembers twice as many calls.
+#ifdef SPX_TUNING
+#define SPX_MAX_WALK_STREAMS 8   // (the developers' build: up to eight walk launches in flight, SPX_WALK_STREAMS)
+#else
 #define SPX_MAX_WALK_STREAMS 4
+#endif
 #define SPX_RING (2 * SPX_MAX_WALK_STREAMS)
 // Pinned staging slot for the small host tables of a call (job tables, tile order): the async copies read it after the
 // call has returned, so it is plan-owned and reused only once its copies have retired.

@@ -33,6 +33,11 @@ int spx_internal_run_mixed(const spx_plan_t* plans, int n_plans, const spx_strea
                            int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, void* hs, bool ahead, void* in_ready);
 void spx_internal_set_error(const char* msg);
 
+#ifdef SPX_TUNING
+#define SPX_PIPE_MAX_DEPTH 24   // (the developers' build: deeper pipelines for the walk-stream experiments)
+#else
+#define SPX_PIPE_MAX_DEPTH 8
+#endif
 #define PIPE_ALIGN 32   // int16 values: every stream's region starts at a 64-byte boundary, in device and in host memory
 
 // Offsets of the packed output: exclusive prefix sums of the streams' produced values, each rounded up to PIPE_ALIGN; written
@@ -223,7 +228,7 @@ extern "C" {
 
 spx_pipeline_t spx_pipeline_create_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index,
                                          int n_streams, int depth, unsigned flags) {
-  if (!plans || n_plans < 1 || n_plans > 8 || !jobs || n_streams < 1 || depth < 0 || depth == 1 || depth > 8) {
+  if (!plans || n_plans < 1 || n_plans > 8 || !jobs || n_streams < 1 || depth < 0 || depth == 1 || depth > SPX_PIPE_MAX_DEPTH) {
     pfail(-1, "spx_pipeline_create: bad arguments (depth 0 or 2 .. 8)");
     return nullptr;
   }
