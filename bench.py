@@ -699,6 +699,29 @@ def main():
                  "kernels": {"analysis": ka, "tension": kt, "walk": kw},
                  "note": "BASELINE configs[3]'s kind at eight times its batch: %d x %d s, 16 kHz mono, 3.5x nonlinear, ONE spx_batch_run "
                          "per step, %d distinct signals (seeds 1234 + 0 .. %d); the walk kernel in its throughput form" % (nl, SECONDS, nl, nl - 1)}
+        # ... and call after call through the owning pipeline object (round 6: a large pipelined call starts its producers at once --
+        # the next call's first analysis chunk runs beside this call's last walk chunk; three buffer sets, outputs left on the device)
+        try:
+            from speedy_amd.batch import Pipeline
+            pl = Pipeline(plan, [n] * nl, 1, SPEED, 1.0, 0.0, depth=3, device_out=True)
+            tl = [pl.submit(bl.d_in) for _ in range(4)]
+            torch.cuda.synchronize()
+            t0l = time.perf_counter()
+            tl += [pl.submit(bl.d_in) for _ in range(10)]
+            torch.cuda.synchronize()
+            dtp = (time.perf_counter() - t0l) / 10
+            _, _, c_ptr = pl.wait(tl[-1])
+            cnt_p = torch.empty(nl, dtype=torch.int64)
+            pl.L.spx_copy_to_host(cnt_p.data_ptr(), c_ptr, nl * 8, None)
+            pl.L.spx_stream_synchronize(None)
+            same = bool(np.array_equal(cnt_p.numpy(), np.asarray(nout_l)))
+            large["pipelined"] = {"ms_per_step": dtp * 1e3, "value": n * nl / dtp / 1e6, "unit": "Msamples/s", "buffer_sets": 3,
+                                  "hbm_frac": algo_l / dtp / 1e9 / HBM_PEAK_GBS, "produced_counts_equal_the_plain_calls": same,
+                                  "note": "spx_pipeline_submit x 10 after 4 warm-up submits, input resident, outputs on the device"}
+            pl.close()
+            del pl
+        except Exception as e:  # noqa: BLE001
+            large["pipelined"] = {"error": repr(e)[:200]}
         del bl
         torch.cuda.empty_cache()
 

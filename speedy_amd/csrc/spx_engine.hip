@@ -539,6 +539,7 @@ int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* 
   d.tile_frames = M.tile_frames;
   const int nch = M.nch;
   const bool concurrent = M.concurrent, ahead = M.ahead;
+  const bool chunk_ahead = M.chunk_ahead && !force;   // (producers on the side stream at once; walk chunks on the caller's as always)
   // ---- execute ----
   std::vector<SpxStreamDev> sv;
   std::vector<int> tiles;
@@ -559,7 +560,7 @@ int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* 
   if (dbg_mode)
     fprintf(stderr, "[spx mode] rate %d n %d maxC %d: co_resident %d doubtful %d lean %d want_concurrent %d chunks %d tiles %d -> %s%s\n",
             d.rate, n, maxC, (int)M.co_resident, (int)M.doubtful, (int)M.launch_lean, (int)M.want_concurrent, nch, tiles[0],
-            concurrent ? "concurrent" : (ahead ? (M.seq_ahead ? "ahead (kernels in sequence)" : "ahead") : "sequence"),
+            concurrent ? "concurrent" : (ahead ? (M.seq_ahead ? "ahead (kernels in sequence)" : "ahead") : (chunk_ahead ? "sequence, producers ahead" : "sequence")),
             M.walk2 ? ", walk kernels overlapping" : "");
   // the stream the walk kernel goes to: the caller's, or (walk2) one of the library's two, taking turns -- ordered behind whatever
   // the caller had queued by the PREVIOUS call (the consumer of the output this call overwrites, two buffers taking turns) and not
@@ -608,12 +609,12 @@ int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* 
         if (t < cnt[i]) order.push_back(sv[i].first_tile + t);
   }
   bool waited_prev = false;
-  if (ahead && !force) {
+  if ((ahead || chunk_ahead) && !force) {
     // this call's producers must not touch a workspace the walk kernel of an earlier call still reads (ring_wait)
     if (ring_wait(plan, sa, ws, st, &waited_prev)) return -2;
     if (opt.in_ready) HIPCHK(hipStreamWaitEvent(sa, static_cast<hipEvent_t>(opt.in_ready), 0));
   }
-  if (!ahead && opt.in_ready) HIPCHK(hipStreamWaitEvent(st, static_cast<hipEvent_t>(opt.in_ready), 0));
+  if (!ahead && !chunk_ahead && opt.in_ready) HIPCHK(hipStreamWaitEvent(st, static_cast<hipEvent_t>(opt.in_ready), 0));
   hipEvent_t staged_ev = nullptr;
   // (Round 5 tried staging a DETACHED call's tables on its own, otherwise empty, run stream -- beside the previous call's producers
   // instead of in front of this call's on the producers' stream: 1.045 against 0.94 ms per step.  A stream that holds nothing but
@@ -632,7 +633,7 @@ int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* 
   const bool ahead_gate = ahead && !force && plan->ahead_started != nullptr && plan->ahead_n > 0 && !no_gate && !waited_prev &&
                           ring_previous_in_flight(plan);
   rc = stage_tables(plan, sv, order, dstreams, d_order, d_flags, concurrent ? (unsigned)tiles[0] : 0u, d_ready,
-                    (concurrent || ahead) ? (unsigned)n + 1u : 0u, ahead ? sa : st, &staged_ev,
+                    (concurrent || ahead) ? (unsigned)n + 1u : 0u, (ahead || chunk_ahead) ? sa : st, &staged_ev,
                     (ahead_gate && !split_gate) ? plan->ahead_started : nullptr, plan->ahead_n, 8000u);
   if (rc) return rc;
   if (M.trial_slot >= 0) {  // bracket this call on the caller's stream (spx_plan::Trial)
@@ -640,7 +641,7 @@ int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* 
     if (!e0) HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventRecord(e0, st));
   }
-  if (sa != st && !ahead) {
+  if (sa != st && !ahead && !chunk_ahead) {
     // the side stream starts after everything already queued on the caller's stream (job tables, cleared flags, and the previous
     // call's walk, which still reads the frame records this call's analysis will overwrite): the staging slot's event marks
     // exactly that point of the caller's stream

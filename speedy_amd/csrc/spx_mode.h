@@ -74,6 +74,8 @@ struct SpxMode {
   bool concurrent;          // three kernels side by side, flags between them
   bool ahead, seq_ahead, ahead_forced;   // pipelined with the previous call (seq_ahead: its kernels otherwise in sequence)
   bool walk2;               // ... and its walk kernel on one of the library's two walk streams
+  bool chunk_ahead;         // a call of more than two streams per CU (time chunks, throughput-form walk kernels) whose PRODUCERS go to the
+                            // side stream at once: the next call's first analysis chunk beside this call's last walk chunk (round 6)
   int nch;                  // time chunks
   bool exclusive_cu;        // the walk workgroups ask for more than half a CU's LDS
   bool asked_device;        // device_ours was consulted
@@ -178,6 +180,13 @@ static inline SpxMode spx_mode_pass(const SpxModeShape& S, const SpxModeResource
   const int total = S.forced ? S.force_total_streams : S.n;
   M.exclusive_cu = !M.concurrent && (!M.ahead || M.ahead_forced || seq_ahead) && !E.no_excl && nch == 1 && total <= R.cu_count;
   M.launch_lean = lean_walk && (M.concurrent || M.ahead);
+  // Large calls asked to be pipelined (spx_batch_run_ahead / _overlapped, the pipeline object): kernels in sequence, two time chunks --
+  // the analysis chunks on the side stream, the tension and walk kernels on the caller's behind them.  With the producers started at
+  // once (behind the ring's events, not behind the caller's stream) the side stream runs analysis chunk after analysis chunk, call
+  // after call, beside the walk chunks on the caller's stream: the period of back-to-back calls is the larger of the two kernel sums
+  // instead of their overlap-less tail and head added up.
+  M.chunk_ahead = S.ahead_req && !S.forced && both && !M.ahead && !want_concurrent && nch >= 2 && S.n > 2 * R.cu_count &&
+                  E.concurrent_enabled && !E.serial && trial_slot < 0 && ours();
   return M;
 }
 

@@ -498,6 +498,42 @@ def test_step_counts_after_a_split_call_then_the_two_halves_on_the_same_workspac
     assert list(b.step_counts()) == want_steps and _crc(b.results()) == want_crc
 
 
+def test_large_calls_pipelined_producers_ahead(orc):
+    """Round 6: a pipelined call of more than two streams per CU (time chunks, throughput-form walk kernels) starts its producers at
+    once on the side stream -- the next call's first analysis chunk beside this call's last walk chunk.  600 ragged streams per call,
+    three batches of different content taking turns, plain calls in between and one workspace handed over twice in a row: every
+    call's outputs are the plain call's, and one stream per batch is the oracle's."""
+    import torch
+    from speedy_amd.batch import Batch, Plan
+    from speedy_amd.synth import speech_like
+    rate, n_streams = 16000, 600
+    plan = Plan(rate, False)
+    L = plan.L
+    rng = np.random.default_rng(17)
+    base = [speech_like(rate, rate, seed=300 + i) for i in range(12)]
+    bs, want = [], []
+    for k in range(3):
+        lens = [int(rate * rng.uniform(0.35, 1.0)) for _ in range(n_streams)]
+        xs = [np.roll(base[(i + 5 * k) % 12], 31 * i)[: lens[i]] for i in range(n_streams)]
+        b = Batch(plan, lens, 1, 3.5 if k != 1 else 1.5, 1.0, 0.0)
+        b.upload(xs)
+        b.run()
+        torch.cuda.synchronize()
+        want.append(_crc(b.results()))
+        ref = orc.compress_sound(xs[577], rate, 1, 3.5 if k != 1 else 1.5, 1.0, 0.0, False, chunk=1000, taps=False)["out"]
+        assert np.array_equal(b.results()[577], ref)
+        bs.append(b)
+    order = [0, 1, 2, 0, 1, 2, 2, 0, 1]          # (2, 2: the same workspace again -- the producers must wait for its own walk kernel)
+    for j, k in enumerate(order):
+        if j == 4:
+            bs[0].run()                            # a plain call in between (its own workspace is not in flight: batch 0 ran at j = 3)
+        bs[k].run_ahead(overlap=(j % 2 == 0))
+        assert L.spx_debug_last_call_concurrent() == 0   # kernels in sequence (the producers' early start is not a mode of its own here)
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert _crc(bs[k].results()) == want[k], k
+
+
 def test_mixed_batches_against_the_oracle_at_scale():
     """BASELINE configs[4]'s shard shape (256 streams: two rates, mono and stereo, speeds 1.5 and 3.5 in one spx_batch_run_mixed call),
     eight batches of ragged two-second noise streams, plain and pipelined calls taking turns: every stream's CRC-32 against the CPU
