@@ -487,8 +487,9 @@ def main():
     ap.add_argument("--no-api", action="store_true", help="skip the many-handle run of the drop-in API (tools/stream_bench.c)")
     ap.add_argument("--serial", action="store_true", help="spx_set_concurrent(0): the three kernels of a step back to back on one "
                     "stream (what the per-kernel PMC passes behind roofline.traffic need: one kernel in flight at a time)")
-    ap.add_argument("--chunks", type=int, default=int(os.environ.get("SPX_CHUNKS", "1")),
-                    help="time chunks per stream inside one spx_batch_run (analysis of chunk c+1 overlaps the walk of c)")
+    ap.add_argument("--chunks", type=int, default=None,
+                    help="force this many time chunks per stream inside every spx_batch_run (analysis of chunk c+1 overlaps the walk "
+                    "of c); default: the library's own choice -- one for the headline batch, two above two streams per CU")
     ap.add_argument("--crc-out", default=None, help="write this rank's per-stream output CRC-32s to CRC_OUT.rank<r>.json "
                     "(tests: N-rank runs must produce the same bytes per stream as solo runs); the configs[4] legs' CRCs "
                     "go to CRC_OUT.c4.rank<r>.json keyed by global stream index")
@@ -583,7 +584,11 @@ def main():
     b = Batch(plan, [n] * STREAMS_PER_GPU, 1, SPEED, 1.0, 0.0)
     b.upload(streams)
     L = plan.L
-    L.spx_set_pipeline_chunks(args.chunks)
+    # (until round 6 this line ran unconditionally with 1, and a chunk count SET by the caller is binding: the `large_batch` and
+    # `config4_full` calls then ran as ONE time chunk where every other caller of the library gets two)
+    if args.chunks is not None:
+        L.spx_set_pipeline_chunks(args.chunks)
+    args.chunks = args.chunks or 1    # what the headline batch (one stream per CU) runs with: the per-kernel accounting below
     if args.serial:
         L.spx_set_concurrent(0)
 
