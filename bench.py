@@ -156,7 +156,8 @@ def cpu_baseline(streams, gpu_outputs, budget_s=12.0, c4_checks=None, rate_check
         return dt, list(crcs)
 
     one, _ = run(streams[:1], 1)                       # single-thread rate, also sizes the sample
-    k = int(max(cores, min(4 * len(streams), budget_s * cores / max(one, 1e-4))))
+    # (at most eight cycles of the bench streams: 2 048 x 10 s = 17 s of CPU work at the port's 19 Msamples/s per thread)
+    k = int(max(cores, min(8 * len(streams), budget_s * cores / max(one, 1e-4))))
     sample = [streams[i % len(streams)] for i in range(k)]
     dt, crcs = run(sample, cores)
     mismatched = sum(1 for i, c in enumerate(crcs)
