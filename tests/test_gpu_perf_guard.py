@@ -160,6 +160,11 @@ def test_shipped_code_placement_is_within_1_percent_of_its_neighbours():
                 pytest.skip("noisy box: %s measured twice %.1f %% apart" % (name, 100 * spread))
             got[name].append(ms)
     best = {k: min(v) for k, v in got.items()}
+    # (a verdict that holds even with the shipped library's SLOWER round against every variant's faster one does not depend on the
+    # rounds agreeing: the last collection of round 6 skipped with shipped 1.4943 / 1.4949, padlo 1.4956 / 1.5115, padhi 1.5096 / 1.5066)
+    if max(got["shipped"]) <= 1.01 * min(best.values()):
+        _record("code_placement", True, "%r (both rounds of the shipped library within 1 %% of the best)" % got)
+        return
     if max(abs(a - b) / min(a, b) for a, b in got.values()) > 0.007:
         _record("code_placement", False, "noisy box: rounds disagree %r" % got)
         pytest.skip("noisy box: rounds disagree %r" % got)
