@@ -315,7 +315,29 @@ def config4_leg(ids, reps, warm=4, pipeline=True):
         assert b.crcs() == crcs and b2.crcs() == crcs, "the pipelined mixed calls changed the output"
         pipelined = True
         del b2
-    return {"dt": dt, "dt_plain": dt_plain, "pipelined": pipelined, "frames": C4.input_frames(ids), "streams": streams, "crcs": crcs,
+        dt_pair = dt
+        # ... and through the owning pipeline object (spx_pipeline_create_mixed, four buffer sets, outputs left on the device -- the
+        # headline's method; round 6: the groups' walk kernels of consecutive batches overlap on the library's walk streams)
+        from speedy_amd.batch import Pipeline
+        pipe = Pipeline(plans, [C4.SECONDS * C4.cfg(i)[0] for i in ids], [C4.cfg(i)[1] for i in ids], [C4.cfg(i)[2] for i in ids], 1.0, 0.0,
+                        depth=4, device_out=True, plan_index=[C4.RATES.index(C4.cfg(i)[0]) for i in ids])
+        ts = [pipe.submit(b.d_in) for _ in range(max(warm, 6))]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ts += [pipe.submit(b.d_in) for _ in range(reps_p)]
+        torch.cuda.synchronize()
+        dt_pipe = (time.perf_counter() - t0) / reps_p
+        for t in ts[-pipe.depth:]:   # every buffer set holds the plain call's bytes
+            assert [zlib.crc32(np.ascontiguousarray(o).tobytes()) for o in pipe.results(t)] == crcs, "the pipeline object's mixed batches differ"
+        pipe.close()
+        del pipe
+        dt = dt_pipe
+        through = "spx_pipeline (mixed), 4 buffer sets, outputs on the device"
+    else:
+        dt_pair = dt_pipe = None
+        through = "spx_batch_run_mixed, call after call"
+    return {"dt": dt, "dt_plain": dt_plain, "dt_pair": dt_pair, "dt_pipe": dt_pipe, "through": through,
+            "pipelined": pipelined, "frames": C4.input_frames(ids), "streams": streams, "crcs": crcs,
             "algo_bytes": C4.algorithmic_bytes(ids, counts), "steps": steps, "out_frames": int(counts.sum())}
 
 
@@ -785,14 +807,18 @@ def main():
         c4 = {"value": frames4 / dt4 / 1e6, "unit": "Msamples/s", "ms_per_step": dt4 * 1e3, "streams_per_gpu": 256,
               "hbm_frac": sum_over_ranks(leg["algo_bytes"]) / dt4 / 1e9 / (HBM_PEAK_GBS * world),
               "chain_steps_max": int(leg["steps"].max()),
-              "pipelined": leg["pipelined"],
+              "pipelined": leg["pipelined"], "timed_through": leg["through"],
               "unpipelined_ms_per_step": max_over_ranks(leg["dt_plain"]) * 1e3,
+              "two_batches_ahead_ms_per_step": max_over_ranks(leg["dt_pair"]) * 1e3 if leg["dt_pair"] is not None else None,
+              "pipeline_object_ms_per_step": max_over_ranks(leg["dt_pipe"]) * 1e3 if leg["dt_pipe"] is not None else None,
               "note": "BASELINE configs[4], WEAK: every rank its shard of 256 streams x 10 s (global stream i: 16 kHz if i even else "
                       "22.05 kHz; mono if (i/2) even else stereo; speed 1.5 if (i/4) even else 3.5; nonlinear 1; 2 048 distinct signals, "
-                      "seed 4000 + i), ONE spx_batch_run_mixed[_ahead] call per step, inputs resident in HBM, MAX over ranks; input sample "
-                      "frames of all ranks / that time.  Pipelined like `value`: two batches with the same input take turns, a step's "
-                      "analysis and tension kernels run beside the previous step's walk kernels, one window of 40 steps; "
-                      "`unpipelined_ms_per_step` is spx_batch_run_mixed on one batch, call after call (10 steps)"}
+                      "seed 4000 + i), ONE mixed-rate batch per step, inputs resident in HBM, MAX over ranks; input sample frames of all "
+                      "ranks / that time.  Pipelined like `value`, one window of 40 steps through the owning pipeline object created with "
+                      "spx_pipeline_create_mixed (four buffer sets, outputs left on the device; a step's producers beside the previous "
+                      "steps' walk kernels, the walk kernels of consecutive steps overlapping); `two_batches_ahead_ms_per_step`: two "
+                      "batches taking turns under spx_batch_run_mixed_ahead (rounds 4 - 5's figure); every buffer set's output CRCs equal "
+                      "the plain call's.  `unpipelined_ms_per_step` is spx_batch_run_mixed on one batch, call after call (10 steps)"}
         c4_checks["config4_shard"] = (leg["streams"], ids, leg["crcs"])
         c4_crc_dump.update({str(i): c for i, c in zip(ids, leg["crcs"])})
         if not args.no_config4_full:

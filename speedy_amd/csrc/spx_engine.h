@@ -184,7 +184,10 @@ void spx_launch_gate(const int* started, int n_walk, unsigned max_spins, hipStre
 //   ahead_sa: the group of a pipelined mixed call -- its producers go to this stream at once (spx_batch_run_mixed_ahead orders it);
 //   started_out: where the group's walk workgroups count themselves in (for the next call's gate)
 //   total_streams: of all groups of the mixed call; after_analysis: recorded behind the group's analysis launch (or null)
-struct SpxForce { int concurrent; bool idle_start; int total_streams; hipEvent_t after_analysis; hipStream_t ahead_sa; const int** started_out; };
+struct SpxForce { int concurrent; bool idle_start; int total_streams; hipEvent_t after_analysis; hipStream_t ahead_sa; const int** started_out;
+                  bool no_exclusive;   // the walk workgroups do NOT ask for a CU of their own and take the 4096-frame window (a mixed call whose walk
+                                       // kernels overlap the previous call's: two calls' walk workgroups and an analysis workgroup on a CU)
+};
 struct SpxCallOpts {
   const SpxForce* force = nullptr;
   bool ahead_req = false;      // spx_batch_run_ahead: pipelined with the plan's previous call where the shape allows

@@ -371,9 +371,14 @@ SpxModeWalk mode_walk(const SpxPlanDev& d, int n, int maxC, bool speedup_only, b
   w.vgprs = spx_walk_vgprs(d, n, maxC, speedup_only, lean, any_speed);
   return w;
 }
+static bool mixed_long_window_env() {   // A/B (tuning build): overlapped mixed calls keep the 8192-frame window
+  static const bool v = spx_tuning_env("SPX_MIXED_LONG_WINDOW") != nullptr;
+  return v;
+}
 // (cached per plan and shape: the register queries and spx_walk_config are not free, and the engine asks on every call)
-static const SpxModeResources& mode_resources(spx_plan* plan, int n, int maxC, bool speedup_only, bool any_speed = false) {
-  const long long key = ((long long)n << 16) ^ ((long long)maxC << 2) ^ (any_speed ? 2 : 0) ^ (speedup_only ? 1 : 0);
+// (short_window: the walk kernel as an overlapped mixed call launches it -- SpxForce::no_exclusive)
+static const SpxModeResources& mode_resources(spx_plan* plan, int n, int maxC, bool speedup_only, bool any_speed = false, bool short_window = false) {
+  const long long key = ((long long)n << 16) ^ ((long long)maxC << 3) ^ (short_window ? 4 : 0) ^ (any_speed ? 2 : 0) ^ (speedup_only ? 1 : 0);
   auto it = plan->res_cache.find(key);
   if (it != plan->res_cache.end()) return it->second;
   const SpxPlanDev& d = plan->dev;
@@ -382,6 +387,7 @@ static const SpxModeResources& mode_resources(spx_plan* plan, int n, int maxC, b
   R.cu_count = plan->cu_count;
   R.lds_per_cu = plan->lds_per_cu;
   R.walk = mode_walk(d, n, maxC, speedup_only, false, any_speed);
+  if (short_window) R.walk.lds = spx_walk_config(d, n, maxC, speedup_only, false, false, any_speed, true).lds;   // (same kernel family, same registers)
   R.walk_lean = R.walk;
   if (maxC == 1 && n <= plan->cu_count && R.walk.fast_kernel && R.walk.nwc > 0) {
     R.walk_lean = mode_walk(d, n, maxC, speedup_only, true, any_speed);
@@ -488,7 +494,7 @@ int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* 
   // a call that is not a sub-batch of run_split's leaves no split record for its workspace (spx_batch_analyze / _walk and mixed
   // calls come here directly: a stale record made spx_batch_read_steps look for sub-batch slices -- ADVICE r5)
   if (!opt.split_part) plan->split_of.erase(ws);
-  const SpxModeResources& R = mode_resources(plan, n, maxC, speedup_only, any_speed);
+  const SpxModeResources& R = mode_resources(plan, n, maxC, speedup_only, any_speed, opt.force && opt.force->no_exclusive && !mixed_long_window_env());
   if (R.walk.lds > 160 * 1024)   // one CU's LDS; the window holds every channel of maxRequired + 64 frames at least
     return fail(-1, "spx_batch: too many channels for the walk kernel's LDS window");
   hipStream_t st = static_cast<hipStream_t>(hs);
@@ -692,7 +698,8 @@ int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* 
         // count themselves in for the next call's gate.
         SpxTimed tm(timed, 1, stw);
         spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, ((concurrent && !diag_nowait) || ahead) ? d_ready : nullptr,
-                        speedup_only, stw, false, M.exclusive_cu ? R.lds_per_cu / 2 + 1024 : 0, M.launch_lean, any_speed);
+                        speedup_only, stw, false, (M.exclusive_cu && !(force && force->no_exclusive)) ? R.lds_per_cu / 2 + 1024 : 0, M.launch_lean, any_speed,
+                        force && force->no_exclusive && !mixed_long_window_env());
       }
       if (M.ahead_forced && force->started_out) *force->started_out = d_ready + n;
       if (c == nch - 1 && !force) {

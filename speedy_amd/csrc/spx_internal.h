@@ -176,7 +176,7 @@ void spx_launch_tension(const SpxPlanDev& P, const SpxStreamDev* streams, int n_
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int max_channels,
                      const int16_t* in, int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
                      const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs = false, size_t lds_min = 0,
-                     bool lean = false, bool any_speed = false);
+                     bool lean = false, bool any_speed = false, bool short_window = false);
 size_t spx_analysis_lds_bytes(const SpxPlanDev& P);
 int spx_analysis_ct_window(const SpxPlanDev& P);
 // The DFT of the spec run on the host (same operation order as the kernel): used to build the Rader tables.
@@ -195,8 +195,10 @@ struct SpxWalkConfig {
 // short_jobs: the streams bring a few pitch steps each (coalesced sonic2.h writes): latency form whatever their number
 // lean: no output waves (and the usual window) although the streams have a CU each -- the search waves do the output work:
 // one walk wave per SIMD instead of two, which is what lets two analysis waves of 168 registers sit beside it (22.05 kHz)
+// short_window: the 4 + 4 form with the usual 4096-frame window where it would take the long one (36.9 instead of 69.7 KB of LDS per
+// stream: two calls' walk workgroups AND an analysis workgroup on a CU -- a mixed call whose walk kernels overlap the previous call's)
 SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only, bool short_jobs = false,
-                              bool lean = false, bool any_speed = false);
+                              bool lean = false, bool any_speed = false, bool short_window = false);
 // spx_walk_fast.hip
 size_t spx_walk_fast_lds_bytes(const SpxPlanDev& P, int wcap);
 bool spx_walk_fast_supports(const SpxPlanDev& P, int nwm);

@@ -48,12 +48,15 @@ size_t spx_batch_workspace_bytes_mixed(const spx_plan_t* plans, int n_plans, con
 }
 static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
                       const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps,
-                      void* hs, bool ahead_req, void* in_ready = nullptr);
+                      void* hs, bool ahead_req, void* in_ready = nullptr, void* done_event = nullptr, bool detached = false);
 }  // extern "C"
-// (spx_pipeline.hip: a pipelined mixed call whose producers wait for an "input is there" event)
+// (spx_pipeline.hip: a pipelined mixed call whose producers wait for an "input is there" event; detached: the caller owns every buffer
+// of the call and orders their consumers itself behind done_event -- the call's walk kernels then run on the library's walk streams,
+// beside the previous call's, and nothing of it is enqueued on hs)
 int spx_internal_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n, const int16_t* in,
-                           int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, void* hs, bool ahead, void* in_ready) {
-  return mixed_impl(plans, n_plans, jobs, plan_index, n, in, out, n_out, ws, ws_bytes, nullptr, hs, ahead, in_ready);
+                           int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, void* hs, bool ahead, void* in_ready,
+                           void* done_event, bool detached) {
+  return mixed_impl(plans, n_plans, jobs, plan_index, n, in, out, n_out, ws, ws_bytes, nullptr, hs, ahead, in_ready, done_event, detached);
 }
 extern "C" {
 int spx_batch_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
@@ -74,7 +77,7 @@ int spx_batch_run_mixed_ahead(const spx_plan_t* plans, int n_plans, const spx_st
 }
 static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n,
                       const int16_t* in, int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, const spx_taps* taps,
-                      void* hs, bool ahead_req, void* in_ready) {
+                      void* hs, bool ahead_req, void* in_ready, void* done_event, bool detached_req) {
   if (!plans || n_plans < 1 || n_plans > 8 || !jobs || n <= 0) return fail(-1, "spx_batch_run_mixed: bad arguments");
   SpxRange range_("spx_batch_run_mixed");
   std::vector<std::vector<spx_stream_job>> gj;
@@ -117,7 +120,7 @@ static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job
   // ---- the device guard, once for the whole call ----
   SpxDevGuard& guard = g_guard[(lead->device >= 0 && lead->device < 64) ? lead->device : 0];
   std::unique_lock<std::mutex> guard_lock(guard.mu, std::defer_lock);
-  SpxForce force = {0, false, n, nullptr, nullptr, nullptr};
+  SpxForce force = {0, false, n, nullptr, nullptr, nullptr, false};
   if (MM.concurrent) {
     guard_lock.lock();
     const hipError_t q = guard.valid ? hipEventQuery(guard.last) : hipSuccess;
@@ -134,6 +137,16 @@ static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job
   // pipelined with the previous call (spx_batch_run_mixed_ahead): kernels in sequence, one stream per CU at most
   const bool ahead = MM.ahead;
   force.concurrent = concurrent ? 1 : 0;
+  // ... and (round 6, a DETACHED call: the pipeline object with its outputs left on the device) the walk kernels of consecutive calls
+  // overlapping as well, the way spx_batch_run_overlapped runs a one-plan batch: the first two groups' walk kernels on the library's
+  // walk streams -- two pairs taking turns, so at most two calls' walk kernels are in flight --, their workgroups without the LDS
+  // request that gives each a CU of its own (two calls' workgroups share the CUs), the scatter kernel and the call's events behind
+  // them on the first group's walk stream, nothing on the caller's.  configs[4] shard: 1.87 - 1.97 -> see profiles/r06.
+  static const bool no_mixed_walk2 = spx_tuning_env("SPX_MIXED_NO_WALK2") != nullptr;   // A/B
+  const bool walk2 = spx_mixed_walk2(MM, detached_req, taps != nullptr, E) && !no_mixed_walk2;
+  hipStream_t wst[SPX_MAX_WALK_STREAMS] = {nullptr};
+  if (walk2 && dev_walk_streams(lead->device, wst, 4)) return fail(-1, "spx_batch_run_mixed: no walk streams");
+  force.no_exclusive = walk2;
   // ---- fork: every group on its plan's own stream ----
   std::lock_guard<std::mutex> lead_lock(lead->mix_mu);
   {
@@ -229,10 +242,12 @@ static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job
   }
   hipEvent_t prev_an = nullptr;
   int launch_idx = 0;
+  hipStream_t end_stream = nullptr;   // walk2: the first group's walk stream, where the call ends
   for (int g : ord) {
     spx_plan* p = plans[g];
     hipStream_t gs = nullptr;
-    if (!concurrent && launch_idx == 0) gs = st;
+    if (walk2 && launch_idx < 2) gs = wst[2 * launch_idx + (int)(lead->ahead_calls & 1)];
+    else if (!concurrent && launch_idx == 0) gs = st;
     else if (!concurrent && launch_idx == 1) gs = dev_s2;
     else {
       if (!p->mix) HIPCHK(hipStreamCreateWithFlags(&p->mix, hipStreamNonBlocking));
@@ -241,7 +256,9 @@ static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job
     launch_idx++;
     if (!p->ev_join) HIPCHK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
     if (!p->ev_an) HIPCHK(hipEventCreateWithFlags(&p->ev_an, hipEventDisableTiming));
-    if (gs != st) HIPCHK(hipStreamWaitEvent(gs, lead->ev_fork, 0));
+    const bool on_walk_stream = walk2 && launch_idx <= 2;   // (launch_idx is already this group's + 1)
+    if (gs != st && !on_walk_stream) HIPCHK(hipStreamWaitEvent(gs, lead->ev_fork, 0));
+    if (!end_stream) end_stream = gs;
     SpxForce f = force;
     if (ahead) {
       f.ahead_sa = dev_s1;            // (the analyses follow one another on that stream by themselves, cheapest first)
@@ -258,18 +275,21 @@ static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job
     // (also when the group failed: whatever it -- and the groups before it -- enqueued on their streams still reads the
     // caller's buffers, so the caller's stream waits for it before the error is returned)
     const std::string err = rc ? g_spx_err : std::string();
-    if (gs != st && (hipEventRecord(p->ev_join, gs) != hipSuccess || hipStreamWaitEvent(st, p->ev_join, 0) != hipSuccess)) {
+    hipStream_t join_to = walk2 ? end_stream : st;
+    if (gs != join_to && (hipEventRecord(p->ev_join, gs) != hipSuccess || hipStreamWaitEvent(join_to, p->ev_join, 0) != hipSuccess)) {
       (void)hipGetLastError();
       (void)hipStreamSynchronize(gs);   // no event: make sure by waiting here
       if (!rc) return fail(-2, "spx_batch_run_mixed: joining a group's stream failed");
     }
     if (rc) return fail(rc, err);
   }
-  hipLaunchKernelGGL(spx_scatter_nout_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_nout, d_idx, n, n_out);
+  hipStream_t fin = (walk2 && end_stream) ? end_stream : st;
+  hipLaunchKernelGGL(spx_scatter_nout_kernel, dim3((n + 255) / 256), dim3(256), 0, fin, d_nout, d_idx, n, n_out);
+  if (done_event) HIPCHK(hipEventRecord(static_cast<hipEvent_t>(done_event), fin));
   {
     // every mixed call leaves its end in the lead plan's ring (a pipelined call orders its producers behind the two calls before it)
     std::lock_guard<std::mutex> ring_lock(lead->mu);
-    if (ring_record(lead, st, ws, st, out, n_out)) return -2;
+    if (ring_record(lead, fin, ws, st, out, n_out, walk2)) return -2;
     lead->ahead_started = nullptr;
     lead->ahead_n = 0;
     lead->mixed_started.clear();

@@ -264,4 +264,13 @@ static inline SpxMixedMode spx_choose_mixed_mode(const SpxModeGroup* G, int grou
   return M;
 }
 
+// ... and whether the walk kernels of consecutive mixed calls overlap (round 6): a pipelined call (`ahead` above) that is DETACHED -- its
+// caller owns every buffer and orders their consumers behind the call's event itself: the pipeline object with its outputs left on the
+// device -- and hands over no taps.  Its first two groups' walk kernels then go to the library's walk streams, two pairs taking turns,
+// in the 4 + 4 form with the 4096-frame window and without the LDS request for a CU of their own: two calls' walk workgroups and an
+// analysis workgroup share a CU (configs[4] shard through the pipeline object: 1.87 - 1.97 -> 1.56 ms per step).
+static inline bool spx_mixed_walk2(const SpxMixedMode& M, bool detached, bool taps, const SpxModeEnv& E) {
+  return M.ahead && !M.concurrent && detached && !taps && !E.walk1;
+}
+
 #endif  // SPX_MODE_H_

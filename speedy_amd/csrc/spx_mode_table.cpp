@@ -106,4 +106,12 @@ int spx_mode_table_eval_mixed(const long long* groups, int n_groups, int n_total
   out4[0] = M.concurrent; out4[1] = M.ahead; out4[2] = M.chain_analyses; out4[3] = M.asked_device;
   return 0;
 }
+// spx_mixed_walk2 for a decided mixed mode {concurrent, ahead}
+int spx_mode_table_mixed_walk2(int concurrent, int ahead, int detached, int taps, int walk1) {
+  SpxMixedMode M = {concurrent != 0, ahead != 0, false, false};
+  SpxModeEnv E;
+  memset(&E, 0, sizeof(E));
+  E.walk1 = walk1 != 0;
+  return spx_mixed_walk2(M, detached != 0, taps != 0, E) ? 1 : 0;
+}
 }

@@ -30,7 +30,8 @@
 int spx_internal_run(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* in, int16_t* out, int64_t* n_out, void* ws,
                      size_t ws_bytes, const spx_taps* taps, void* hs, bool ahead, bool overlap, void* in_ready, void* done_event, bool detached);
 int spx_internal_run_mixed(const spx_plan_t* plans, int n_plans, const spx_stream_job* jobs, const int* plan_index, int n, const int16_t* in,
-                           int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, void* hs, bool ahead, void* in_ready);
+                           int16_t* out, int64_t* n_out, void* ws, size_t ws_bytes, void* hs, bool ahead, void* in_ready,
+                           void* done_event, bool detached);
 void spx_internal_set_error(const char* msg);
 
 #ifdef SPX_TUNING
@@ -303,10 +304,12 @@ int64_t spx_pipeline_submit(spx_pipeline_t p, const int16_t* in, int in_is_devic
   // With the outputs left on the device nothing of a batch has to run behind its walk kernel: the call is DETACHED from the run
   // stream (spx_engine.hip SpxCallOpts) -- the batch's event is recorded on the walk stream itself and the run stream stays empty.
   bool event_recorded = false;
-  if (p->mixed)
+  if (p->mixed) {
+    // (round 6: detached like a one-plan batch -- the groups' walk kernels on the library's walk streams, two calls' worth in flight)
     rc = spx_internal_run_mixed(p->plans.data(), (int)p->plans.size(), p->jobs.data(), p->plan_index.data(), p->n, dev_in, S.d_out, S.d_nout,
-                                S.ws, p->ws_bytes, p->s_run, true, in_ready);
-  else {
+                                S.ws, p->ws_bytes, p->s_run, true, in_ready, host_out ? nullptr : S.ev_done, !host_out);
+    event_recorded = !host_out;
+  } else {
     rc = spx_internal_run(p->plans[0], p->jobs.data(), p->n, dev_in, S.d_out, S.d_nout, S.ws, p->ws_bytes, nullptr, p->s_run, true, true, in_ready,
                           host_out ? nullptr : S.ev_done, !host_out);
     event_recorded = !host_out;

@@ -923,7 +923,8 @@ static int walk_mode(const SpxPlanDev& P, int maxC, bool speedup_only) {
 
 // Kernel variant, waves per stream and LDS per stream for a batch: the one place the launcher and the engine's
 // co-residency arithmetic both ask.
-SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool short_jobs, bool lean, bool any_speed) {
+SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool short_jobs, bool lean, bool any_speed,
+                              bool short_window) {
   if (maxC < 1) maxC = 1;
   const WalkTuning& T = walk_tuning();
   SpxWalkConfig c;
@@ -973,6 +974,7 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
   // is refilled every ~2 700 frames at 44.1 kHz -- 160 times per 10 s stream; twice the window, a third of the refills
   if (!throughput && !short_jobs && c.fast_kernel && P.skip >= 6 && T.wcap <= 0) c.wcap = 8192;
   if (lean && !throughput) { c.nwc = 0; c.wcap = 4096; }
+  if (short_window && !throughput && P.skip < 6 && c.wcap > 4096) c.wcap = 4096;
   if (T.nwm > 0) c.nwm = T.nwm;
   if (T.nwc >= 0) c.nwc = T.nwc;
   if (T.wcap > 0) c.wcap = T.wcap;
@@ -1034,11 +1036,15 @@ extern "C" int spx_debug_last_walk_form(void) { return g_last_walk_form.load(std
 
 void spx_launch_walk(const SpxPlanDev& P, const SpxStreamDev* streams, int n_streams, int maxC, const int16_t* in,
                      int16_t* out, int64_t* n_out, SpxStreamState* states, const float* scratch,
-                     const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs, size_t lds_min, bool lean, bool any_speed) {
+                     const int* speed_ready, bool speedup_only, hipStream_t st, bool short_jobs, size_t lds_min, bool lean, bool any_speed,
+                     bool short_window) {
   if (n_streams <= 0) return;
   if (maxC < 1) maxC = 1;
-  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC, speedup_only, short_jobs, lean, any_speed);
+  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC, speedup_only, short_jobs, lean, any_speed, short_window);
   g_last_walk_form.store(cfg.fast_kernel ? 16 * cfg.nwm + cfg.nwc : 0, std::memory_order_relaxed);
+  static const bool dbg_mode = getenv("SPX_DEBUG_MODE") != nullptr;
+  if (dbg_mode) fprintf(stderr, "[spx walk] rate %d n %d maxC %d: %s %d + %d waves, window %d frames, %zu B LDS per stream (at least %zu asked)\n", P.rate, n_streams, maxC,
+                        cfg.fast_kernel ? "fast kernel" : "general kernel", cfg.fast_kernel ? cfg.nwm : cfg.nw, cfg.fast_kernel ? cfg.nwc : 0, cfg.wcap, cfg.lds, lds_min);
   if (cfg.fast_kernel) {
     spx_launch_walk_fast(P, streams, n_streams, in, out, n_out, states, scratch, speed_ready, cfg.nwm, cfg.nwc, cfg.wcap,
                          maxC, st, lds_min, cfg.slow);

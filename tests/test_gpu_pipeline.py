@@ -170,6 +170,47 @@ def test_mixed_rate_pipeline(orc):
     pipe.close()
 
 
+@pytest.mark.parametrize("rates,n,depth", [((16000, 22050), 256, 4), ((16000, 22050), 256, 2), ((16000, 22050), 90, 3),
+                                           ((16000, 22050, 11025), 150, 4), ((22050,), 64, 4)])
+def test_mixed_rate_pipeline_outputs_on_the_device_walk_kernels_overlapping(orc, rates, n, depth):
+    """Round 6: a mixed pipeline that leaves its outputs on the device is DETACHED -- the first two groups' walk kernels of consecutive
+    batches overlap on the library's walk streams (spx_mixed_walk2, spx_mode.h), a third group runs on its plan's own stream.  Batches
+    of different content through every buffer set, many more batches than sets: every batch equals the plain mixed call's bytes, samples
+    of it the oracle's."""
+    import torch
+    from speedy_amd.batch import MixedBatch, Pipeline, Plan
+    from speedy_amd.synth import speech_like
+    plans = [Plan(r, False) for r in rates]
+    pidx = [i % len(rates) for i in range(n)]
+    chs = [1 if (i // 2) % 2 == 0 else 2 for i in range(n)]
+    speeds = [1.5 if (i // 4) % 2 == 0 else 3.5 for i in range(n)]
+    lens = [int(rates[pidx[i]] * (1.0 + 0.006 * (i % 97))) for i in range(n)]
+    mb = MixedBatch(plans, pidx, lens, chs, speeds, 1.0, 0.0)
+    pipe = Pipeline(plans, lens, chs, speeds, 1.0, 0.0, depth=depth, device_out=True, plan_index=pidx)
+    want, dev_in = [], []
+    for seed in (51, 52, 53):
+        xs = [speech_like(lens[i], rates[pidx[i]], seed=seed * 100 + (i % 9), channels=chs[i]) for i in range(n)]
+        mb.upload(xs)
+        mb.run()
+        want.append(mb.crcs())
+        for i in (0, n // 2 + 1, n - 1):
+            ref = orc.compress_sound(xs[i], rates[pidx[i]], chs[i], speeds[i], 1.0, 0.0, False, chunk=1000)
+            assert want[-1][i] == zlib.crc32(np.ascontiguousarray(ref["out"]).tobytes()), (seed, i)
+        d = torch.zeros(pipe.total_in + 64, dtype=torch.int16, device="cuda")
+        d[: pipe.total_in].copy_(torch.from_numpy(pipe.pack(xs)))
+        dev_in.append(d)
+    torch.cuda.synchronize()
+    ts = []
+    for k in range(5 * depth + 3):
+        ts.append((pipe.submit(dev_in[k % 3]), k % 3))
+        if len(ts) > depth:          # the oldest batch still held by a buffer set
+            t, c = ts[-depth]
+            assert _crc(pipe.results(t)) == want[c], (k, t, c)
+    for t, c in ts[-depth:]:
+        assert _crc(pipe.results(t)) == want[c], (t, c)
+    pipe.close()
+
+
 def test_two_pipelines_and_plain_calls_side_by_side(orc):
     """Two pipelines of different plans alive at once, with plain spx_batch_run calls of a third shape in between."""
     from speedy_amd.batch import Batch, Pipeline, Plan

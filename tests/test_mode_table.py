@@ -174,3 +174,9 @@ def test_mixed_rate_call(table):
     assert mixed(env_mixed=1)["concurrent"] == 1
     assert mixed(env_mixed=1, busy=1) == dict(concurrent=0, ahead=0, chain=1, asked=1)
     assert mixed(env_mixed=1, busy=1, ahead=1) == dict(concurrent=0, ahead=1, chain=1, asked=1)
+    # round 6: the walk kernels of consecutive mixed calls overlap only for a pipelined, detached call without taps
+    # (spx_mixed_walk2: concurrent, ahead, detached, taps, the walk1 switch)
+    w2 = L.spx_mode_table_mixed_walk2
+    assert w2(0, 1, 1, 0, 0) == 1
+    assert w2(0, 1, 0, 0, 0) == 0 and w2(0, 0, 1, 0, 0) == 0 and w2(1, 0, 1, 0, 0) == 0
+    assert w2(0, 1, 1, 1, 0) == 0 and w2(0, 1, 1, 0, 1) == 0
