@@ -147,7 +147,9 @@ int spx_batch_run_ahead_when(spx_plan_t plan, const spx_stream_job* jobs, int n_
  *             spx_plan_out_capacity_for)
  *   plans / plan_index   as in spx_batch_run_mixed, for batches that mix sample rates (spx_pipeline_create: one plan)
  *   depth     buffer sets, 2 .. 8 (0 = the default, 4); 3 or more let the walk kernels of consecutive batches overlap fully
- *   flags     SPX_PIPELINE_DEVICE_OUT: the outputs stay in device memory (no gather, no copy out)
+ *   flags     SPX_PIPELINE_DEVICE_OUT: the outputs stay in device memory (no gather, no copy out).  Such a pipeline's calls are
+ *             detached from its run stream, and since round 6 that holds for mixed-rate batches too: the groups' walk kernels of
+ *             consecutive batches overlap on the library's walk streams (BASELINE configs[4] shard: 1.87 - 1.97 -> 1.56 ms per batch)
  * Not thread-safe: one host thread (or external locking) per pipeline; several pipelines may be alive at once. */
 typedef struct spx_pipeline* spx_pipeline_t;
 #define SPX_PIPELINE_DEVICE_OUT 1u
