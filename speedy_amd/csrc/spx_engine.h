@@ -177,7 +177,7 @@ SpxModeEnv mode_env();
 bool device_ours_cb(void* ctx);
 struct SpxSpeedClass { int maxC; bool speedup_only, any_speed; };
 SpxSpeedClass speed_class(const spx_stream_job* jobs, int n);
-SpxModeWalk mode_walk(const SpxPlanDev& d, int n, int maxC, bool speedup_only, bool lean, bool any_speed = false);
+SpxModeWalk mode_walk(const SpxPlanDev& d, int n, int maxC, bool speedup_only, bool lean, bool any_speed = false, bool short_window = false);
 void spx_launch_gate(const int* started, int n_walk, unsigned max_spins, hipStream_t st);   // the idle-start / previous-call gate kernel
 // `force`: the call is one group of a mixed-rate batch (spx_batch_run_mixed): the launch mode was decided for all groups
 // together, and the device guard is held by the caller.

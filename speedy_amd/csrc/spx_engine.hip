@@ -364,11 +364,11 @@ SpxSpeedClass speed_class(const spx_stream_job* jobs, int n) {
   if (c.speedup_only) c.any_speed = false;   // (the flag means: slow-down jobs are there)
   return c;
 }
-SpxModeWalk mode_walk(const SpxPlanDev& d, int n, int maxC, bool speedup_only, bool lean, bool any_speed) {
-  const SpxWalkConfig c = spx_walk_config(d, n, maxC, speedup_only, false, lean, any_speed);
+SpxModeWalk mode_walk(const SpxPlanDev& d, int n, int maxC, bool speedup_only, bool lean, bool any_speed, bool short_window) {
+  const SpxWalkConfig c = spx_walk_config(d, n, maxC, speedup_only, false, lean, any_speed, short_window);
   SpxModeWalk w;
   w.lds = c.lds; w.waves = c.waves; w.fast_kernel = c.fast_kernel; w.nwc = c.nwc;
-  w.vgprs = spx_walk_vgprs(d, n, maxC, speedup_only, lean, any_speed);
+  w.vgprs = spx_walk_vgprs(d, n, maxC, speedup_only, lean, any_speed, short_window);
   return w;
 }
 static bool mixed_long_window_env() {   // A/B (tuning build): overlapped mixed calls keep the 8192-frame window
@@ -386,8 +386,7 @@ static const SpxModeResources& mode_resources(spx_plan* plan, int n, int maxC, b
   memset(&R, 0, sizeof(R));
   R.cu_count = plan->cu_count;
   R.lds_per_cu = plan->lds_per_cu;
-  R.walk = mode_walk(d, n, maxC, speedup_only, false, any_speed);
-  if (short_window) R.walk.lds = spx_walk_config(d, n, maxC, speedup_only, false, false, any_speed, true).lds;   // (same kernel family, same registers)
+  R.walk = mode_walk(d, n, maxC, speedup_only, false, any_speed, short_window);
   R.walk_lean = R.walk;
   if (maxC == 1 && n <= plan->cu_count && R.walk.fast_kernel && R.walk.nwc > 0) {
     R.walk_lean = mode_walk(d, n, maxC, speedup_only, true, any_speed);
@@ -494,7 +493,16 @@ int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* 
   // a call that is not a sub-batch of run_split's leaves no split record for its workspace (spx_batch_analyze / _walk and mixed
   // calls come here directly: a stale record made spx_batch_read_steps look for sub-batch slices -- ADVICE r5)
   if (!opt.split_part) plan->split_of.erase(ws);
-  const SpxModeResources& R = mode_resources(plan, n, maxC, speedup_only, any_speed, opt.force && opt.force->no_exclusive && !mixed_long_window_env());
+  // The walk kernel's window: 4096 frames instead of the long one (36.9 instead of 69.7 KB of LDS per stream) for calls whose walk
+  // workgroups are to share CUs with another call's AND with analysis workgroups, and that have no lean form to take:
+  //   - the groups of an overlapped mixed call (SpxForce::no_exclusive): decided before the mode, the co-residency arithmetic (and
+  //     with it the tile: the 22.05 kHz group fell back to the 8-frame tile with the long window's 70.5 KB) is done with that form;
+  //   - multi-channel batches whose walk kernels overlap the previous call's (walk2 below; 16 kHz stereo x 256 through the pipeline
+  //     object: 1.33 -> 1.21 ms per batch): at the LAUNCH only -- the arithmetic stays with the long window's numbers, which errs on
+  //     the safe side (less LDS than counted) and leaves every decision where it was (done with the short window's, 22.05 kHz stereo
+  //     turns "doubtful", goes to the timed trial and ends in the concurrent mode: 1.69 -> 2.9 ms through the pipeline object).
+  const bool short_window_res = opt.force && opt.force->no_exclusive && !mixed_long_window_env();
+  const SpxModeResources& R = mode_resources(plan, n, maxC, speedup_only, any_speed, short_window_res);
   if (R.walk.lds > 160 * 1024)   // one CU's LDS; the window holds every channel of maxRequired + 64 frames at least
     return fail(-1, "spx_batch: too many channels for the walk kernel's LDS window");
   hipStream_t st = static_cast<hipStream_t>(hs);
@@ -699,7 +707,7 @@ int run_impl(spx_plan_t plan, const spx_stream_job* jobs, int n, const int16_t* 
         SpxTimed tm(timed, 1, stw);
         spx_launch_walk(d, dj, n, maxC, in, out, n_out, states, scratch, ((concurrent && !diag_nowait) || ahead) ? d_ready : nullptr,
                         speedup_only, stw, false, (M.exclusive_cu && !(force && force->no_exclusive)) ? R.lds_per_cu / 2 + 1024 : 0, M.launch_lean, any_speed,
-                        force && force->no_exclusive && !mixed_long_window_env());
+                        short_window_res || (!force && M.walk2 && !M.launch_lean && maxC > 1 && !mixed_long_window_env()));
       }
       if (M.ahead_forced && force->started_out) *force->started_out = d_ready + n;
       if (c == nch - 1 && !force) {

@@ -215,9 +215,10 @@ size_t spx_tension_lds_bytes();
 int spx_kernel_vgprs(const void* fn, int* scratch_bytes = nullptr);   // spx_engine.hip (one cache, behind a mutex)
 int spx_tension_vgprs();
 int spx_analysis_vgprs(const SpxPlanDev& P, int* scratch_bytes = nullptr);
-int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only, bool lean = false, bool any_speed = false);
+int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only, bool lean = false, bool any_speed = false,
+                   bool short_window = false);
 int spx_walk_kernel_regs(const SpxPlanDev& P, int n_streams, int max_channels, bool speedup_only, bool short_jobs, bool lean,
-                         int* scratch_bytes, bool any_speed = false);
+                         int* scratch_bytes, bool any_speed = false, bool short_window = false);
 // speedyComputeSpeedFromTension (speedy.c:768-788) on the stream's state record: *speed_out = requested speed, the
 // duration sums of the record advance.
 void spx_launch_speed_from_tension(SpxStreamState* state, float tension, float Rg, float feedback, float* speed_out,

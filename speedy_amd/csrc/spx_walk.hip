@@ -1007,8 +1007,8 @@ SpxWalkConfig spx_walk_config(const SpxPlanDev& P, int n_streams, int maxC, bool
 }
 int spx_walk_fast_vgprs(const SpxPlanDev& P, int nwm, int nwc, int wcap, int maxC, int* scratch_bytes = nullptr, bool slow = false);
 int spx_walk_kernel_regs(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool short_jobs, bool lean, int* scratch_bytes,
-                         bool any_speed) {
-  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC < 1 ? 1 : maxC, speedup_only, short_jobs, lean, any_speed);
+                         bool any_speed, bool short_window) {
+  const SpxWalkConfig cfg = spx_walk_config(P, n_streams, maxC < 1 ? 1 : maxC, speedup_only, short_jobs, lean, any_speed, short_window);
   if (cfg.fast_kernel) return spx_walk_fast_vgprs(P, cfg.nwm, cfg.nwc, cfg.wcap, maxC, scratch_bytes, cfg.slow);
   const void* fn;
 #define SPX_FN_W(NWV) (cfg.mode == 1 ? reinterpret_cast<const void*>(spx_walk_kernel<NWV, 1>)   \
@@ -1024,8 +1024,8 @@ int spx_walk_kernel_regs(const SpxPlanDev& P, int n_streams, int maxC, bool spee
 #undef SPX_FN_W
   return spx_kernel_vgprs(fn, scratch_bytes);
 }
-int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool lean, bool any_speed) {
-  return spx_walk_kernel_regs(P, n_streams, maxC, speedup_only, false, lean, nullptr, any_speed);
+int spx_walk_vgprs(const SpxPlanDev& P, int n_streams, int maxC, bool speedup_only, bool lean, bool any_speed, bool short_window) {
+  return spx_walk_kernel_regs(P, n_streams, maxC, speedup_only, false, lean, nullptr, any_speed, short_window);
 }
 size_t spx_walk_lds_bytes(const SpxPlanDev& P, int maxC, bool speedup_only) {
   return spx_walk_config(P, 256, maxC, speedup_only).lds;
