@@ -146,6 +146,7 @@ def test_shipped_code_placement_is_within_1_percent_of_its_neighbours():
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); from test_gpu_perf_guard import measure_walk_ms; "
             "(a, b), k = measure_walk_ms(); print('WALK', min(a, b), abs(a - b) / min(a, b))" % (ROOT, os.path.join(ROOT, "tests")))
     got = {k: [] for k in libs}
+    noisy = []
     for _ in range(2):
         for name, path in libs.items():
             env = dict(os.environ)
@@ -155,9 +156,8 @@ def test_shipped_code_placement_is_within_1_percent_of_its_neighbours():
             r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
             assert r.returncode == 0, r.stderr[-1500:]
             ms, spread = [float(v) for v in [ln for ln in r.stdout.splitlines() if ln.startswith("WALK")][-1].split()[1:]]
-            if spread > 0.01:
-                _record("code_placement", False, "noisy box: %s measured twice %.1f %% apart" % (name, 100 * spread))
-                pytest.skip("noisy box: %s measured twice %.1f %% apart" % (name, 100 * spread))
+            if spread > 0.01:   # (judged at the end: a verdict that does not depend on it stands)
+                noisy.append("%s measured twice %.1f %% apart" % (name, 100 * spread))
             got[name].append(ms)
     best = {k: min(v) for k, v in got.items()}
     # (a verdict that holds even with the shipped library's SLOWER round against every variant's faster one does not depend on the
@@ -165,6 +165,9 @@ def test_shipped_code_placement_is_within_1_percent_of_its_neighbours():
     if max(got["shipped"]) <= 1.01 * min(best.values()):
         _record("code_placement", True, "%r (both rounds of the shipped library within 1 %% of the best)" % got)
         return
+    if noisy:
+        _record("code_placement", False, "noisy box: " + "; ".join(noisy))
+        pytest.skip("noisy box: " + "; ".join(noisy))
     if max(abs(a - b) / min(a, b) for a, b in got.values()) > 0.007:
         _record("code_placement", False, "noisy box: rounds disagree %r" % got)
         pytest.skip("noisy box: rounds disagree %r" % got)
