@@ -501,5 +501,21 @@ def test_mixed_rate_batch_fuzz(orc, seed):
             taps = b.tap_arrays(i)
             for key in ("tension", "speed", "features"):
                 assert np.array_equal(taps[key], ref[key]), tag + (key,)
+    # ... and the same mix batch after batch through the owning pipeline object with its outputs left on the device (round 6: a
+    # detached mixed call -- the walk kernels of consecutive batches overlap on the library's walk streams, a third and fourth group
+    # on their plans' own): every batch of every buffer set equals the plain call's streams
+    if sum(lens) > 0:
+        import torch
+        from speedy_amd.batch import Pipeline
+        depth = int(rng.integers(2, 6))
+        pipe = Pipeline(plans, lens, chs, speeds, nls, fbs, depth=depth, device_out=True, plan_index=pidx)
+        d = torch.zeros(pipe.total_in + 64, dtype=torch.int16, device="cuda")
+        d[: pipe.total_in].copy_(torch.from_numpy(pipe.pack(xs)))
+        ts = [pipe.submit(d) for _ in range(2 * depth + 1)]
+        for t in ts[-depth:]:
+            got = pipe.results(t)
+            for i in range(k):
+                assert np.array_equal(got[i], outs[i]), (seed, "pipeline object", depth, t, i, rates, pidx[i], chs[i], lens[i], speeds[i], nls[i])
+        pipe.close()
     for p in plans:
         p.close()
