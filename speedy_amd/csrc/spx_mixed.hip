@@ -144,6 +144,7 @@ static int mixed_impl(const spx_plan_t* plans, int n_plans, const spx_stream_job
   // them on the first group's walk stream, nothing on the caller's.  configs[4] shard: 1.87 - 1.97 -> see profiles/r06.
   static const bool no_mixed_walk2 = spx_tuning_env("SPX_MIXED_NO_WALK2") != nullptr;   // A/B
   const bool walk2 = spx_mixed_walk2(MM, detached_req, taps != nullptr, E) && !no_mixed_walk2;
+  static_assert(SPX_MAX_WALK_STREAMS >= 4, "two pairs of walk streams taking turns");
   hipStream_t wst[SPX_MAX_WALK_STREAMS] = {nullptr};
   if (walk2 && dev_walk_streams(lead->device, wst, 4)) return fail(-1, "spx_batch_run_mixed: no walk streams");
   force.no_exclusive = walk2;
