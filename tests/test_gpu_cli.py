@@ -156,6 +156,38 @@ def test_c_pipeline_example(orc, tmp_path, name, speed, nl, copies, batches, dep
     assert np.array_equal(np.fromfile(out, dtype="<i2"), ref)
 
 
+@pytest.mark.parametrize("streams,batches,depth", [(96, 9, 4), (256, 7, 3), (300, 3, 2)])
+def test_c_mixed_pipeline_example(orc, tmp_path, streams, batches, depth):
+    """tools/mixed_pipeline_example.c (plain C99 over include/speedy_hip.h): one GPU's kind of BASELINE configs[4] shard through
+    spx_pipeline_create_mixed with SPX_PIPELINE_DEVICE_OUT -- input and outputs resident on the device, the walk kernels of
+    consecutive batches overlapping (round 6) -- every stream of every batch equal to ONE spx_batch_run_mixed call's (the program
+    checks that itself); here four of its streams, one per kind, against the oracle."""
+    exe = os.path.join(ROOT, "speedy_amd", "lib", "mixed_pipeline_example")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "speedy_amd", "csrc"), "pipeexample"])
+    x, rate, ch = read_wav("tapestry.wav")
+    x = x[: 2 * rate]
+    raw = str(tmp_path / "in.raw")
+    x.astype("<i2").tofile(raw)
+    r = subprocess.run([exe, raw, str(streams), str(batches), str(depth)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "every stream equals spx_batch_run_mixed's" in r.stdout
+    # the plain mixed call the program compares with is the oracle's: the same streams through the Python mirror
+    from speedy_amd.batch import MixedBatch, Plan
+    plans = [Plan(16000, False), Plan(22050, False)]
+    n = 8
+    pidx = [i % 2 for i in range(n)]
+    chs = [1 if (i // 2) % 2 == 0 else 2 for i in range(n)]
+    speeds = [1.5 if (i // 4) % 2 == 0 else 3.5 for i in range(n)]
+    mb = MixedBatch(plans, pidx, [x.size // c for c in chs], chs, speeds, 1.0, 0.0)
+    mb.upload([x] * n)
+    mb.run()
+    outs = mb.results()
+    for i in range(n):
+        ref = orc.compress_sound(x, [16000, 22050][pidx[i]], chs[i], speeds[i], 1.0, 0.0, False, chunk=1000, taps=False)["out"]
+        assert np.array_equal(outs[i], ref), i
+
+
 @pytest.mark.parametrize("seed,handles,env", [(1, 24, {}), (2, 40, {}), (3, 16, {}),
                                               # a frame arena that must grow several times, a staging area that forces runs
                                               (4, 48, {"SPX_POOL_FRAMES": "1024"}),

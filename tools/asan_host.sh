@@ -6,8 +6,10 @@
 #   gpurun -- bash tools/asan_host.sh [seeds]
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
-[ -f speedy_amd/lib/asan/pipeline_example ] || make -s -C speedy_amd/csrc asan-host || exit 1
-export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
+[ -f speedy_amd/lib/asan/mixed_pipeline_example ] || make -s -C speedy_amd/csrc asan-host || exit 1
+# (quarantine_size_mb: a program that frees tens of MB right before it exits makes the quarantine recycle chunks inside the ROCm
+# runtime's own exit handlers, where the sanitizer's device allocator has already gone -- an internal CHECK of the sanitizer, not a report)
+export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:halt_on_error=1:quarantine_size_mb=4096 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 mkdir -p gpurun_out
 LOG=gpurun_out/asan_host.log
 : > $LOG
@@ -29,6 +31,11 @@ if [ -f speedy_amd/lib/asan/pipeline_example ]; then
   timeout 600 speedy_amd/lib/asan/pipeline_example $RAW 16000 1 3.5 1 64 9 4 gpurun_out/asan_out2.raw >> $LOG 2>&1 || echo "pipeline_example FAILED (rc $?)" >> $LOG
   timeout 600 speedy_amd/lib/asan/pipeline_example $RAW 16000 1 1.5 0 300 5 3 gpurun_out/asan_out3.raw >> $LOG 2>&1 || echo "pipeline_example (300 streams: sub-batches) FAILED (rc $?)" >> $LOG
   cmp gpurun_out/asan_out1.raw gpurun_out/asan_out2.raw >> $LOG 2>&1 || echo "batch and pipeline outputs differ FAILED" >> $LOG
+fi
+# (round 6) mixed-rate batches through the pipeline object, outputs on the device: the groups' walk kernels of consecutive batches overlap
+if [ -f speedy_amd/lib/asan/mixed_pipeline_example ]; then
+  timeout 600 speedy_amd/lib/asan/mixed_pipeline_example $RAW 96 11 4 >> $LOG 2>&1 || echo "mixed_pipeline_example FAILED (rc $?)" >> $LOG
+  timeout 600 speedy_amd/lib/asan/mixed_pipeline_example $RAW 300 4 2 >> $LOG 2>&1 || echo "mixed_pipeline_example (300 streams) FAILED (rc $?)" >> $LOG
 fi
 cut -c1-220 $LOG | tail -12
 echo "sanitizer reports: $(grep -c 'ERROR: AddressSanitizer\|runtime error\|FAILED' $LOG)"
