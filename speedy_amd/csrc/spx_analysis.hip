@@ -518,11 +518,14 @@ __device__ __forceinline__ cplx packed_point(const short* fr, int n, int j, int 
 }
 
 // WCT != 0: the kernel is compiled for that window size (16 kHz: W = 240 = 4*4*3*5) -- see the phase-1 comment.
+#ifndef SPX_AN_W_330
+#define SPX_AN_W_330 3   // waves per SIMD the 22.05 kHz instantiation is compiled for (A/B: 4 = 128 registers)
+#endif
 #ifndef SPX_AN_W_BIG
 #define SPX_AN_W_BIG 2   // waves per SIMD the 44.1 / 48 kHz instantiations are compiled for (A/B: 3 = 168 registers)
 #endif
 template <int TF, int WCT>
-__global__ void __launch_bounds__(SPX_BLOCK, (WCT == 240 || WCT == 120 || WCT == 180) ? 4 : WCT == 330 ? 3 : (WCT == 661 || WCT == 720) ? SPX_AN_W_BIG : (WCT == 480 || WCT == 360) ? 2 : 1)  // (.., waves per SIMD the register count must allow: the concurrent mode's budgets)
+__global__ void __launch_bounds__(SPX_BLOCK, (WCT == 240 || WCT == 120 || WCT == 180) ? 4 : WCT == 330 ? SPX_AN_W_330 : (WCT == 661 || WCT == 720) ? SPX_AN_W_BIG : (WCT == 480 || WCT == 360) ? 2 : 1)  // (.., waves per SIMD the register count must allow: the concurrent mode's budgets)
 spx_analysis_kernel(SpxPlanDev P, const SpxStreamDev* __restrict__ streams, int n_streams,
                     const int16_t* __restrict__ in_base, SpxFrameRec* __restrict__ rec, SpxTapsDev taps,
                     const int* __restrict__ tile_order, int* tile_flags, const float* __restrict__ frames,
