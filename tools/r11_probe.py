@@ -246,12 +246,80 @@ def mixed_audio_against_the_oracle(batches, verbose=True, seconds=2):
     return bad, total
 
 
+def mixed_pipeline_audio_against_the_oracle(batches, verbose=True, seconds=2):
+    """The same shard shape through the OWNING PIPELINE OBJECT created with spx_pipeline_create_mixed, outputs left on the device (round 6:
+    the groups' walk kernels of consecutive batches overlap on the library's walk streams): one pipeline of four buffer sets per
+    length setting, noise streams, every batch different; every stream's CRC-32 against the CPU port's, kind by kind."""
+    import ctypes as C
+    import subprocess
+    import zlib
+    import torch
+    from speedy_amd import config4 as C4
+    from speedy_amd.batch import Pipeline, Plan
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liborc_bench.so"])
+    L = C.CDLL(os.path.join(ROOT, "oracle", "liborc_bench.so"))
+    L.orc_bench_run.restype = C.c_double
+    L.orc_bench_run.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    plans = [Plan(r, False) for r in C4.RATES]
+    threads = len(os.sched_getaffinity(0))
+    ids = list(range(NS))
+    bad = total = 0
+    pipes = {}
+    pending = []
+
+    def check(k, pipe, t, xs, lens):
+        nonlocal bad, total
+        outs = pipe.results(t)
+        for kind in range(8):
+            members = [i for i in ids if C4.kind(i) == kind]
+            rate, ch, speed = C4.cfg(kind)
+            buf = np.ascontiguousarray(np.concatenate([xs[i] for i in members]), np.int16)
+            frames = (C.c_long * len(members))()
+            crcs = (C.c_uint32 * len(members))()
+            L.orc_bench_run(buf.ctypes.data, lens[kind], len(members), rate, ch, speed, 1.0, 0.0, 0, 1000, threads, frames, crcs)
+            for j, i in enumerate(members):
+                if zlib.crc32(np.ascontiguousarray(outs[i]).tobytes()) != crcs[j] or outs[i].size != frames[j] * ch:
+                    bad += 1
+                    if verbose and bad <= 5:
+                        print("batch %d stream %d (rate %d ch %d speed %.1f): the output differs from the oracle's" % (k, i, rate, ch, speed))
+            total += len(members)
+
+    for k in range(batches):
+        lens = [seconds * C4.cfg(kind)[0] - 89 * ((k // 3 + kind) % 7) for kind in range(8)]   # three consecutive batches share a pipeline
+        xs = [np.random.default_rng([k, i, 17]).integers(-20000, 20000, size=lens[C4.kind(i)] * C4.cfg(i)[1]).astype(np.int16) for i in ids]
+        key = tuple(lens)
+        ent = pipes.get(key)
+        if ent is None:
+            pipe = Pipeline(plans, [lens[C4.kind(i)] for i in ids], [C4.cfg(i)[1] for i in ids], [C4.cfg(i)[2] for i in ids], 1.0, 0.0,
+                            depth=4, device_out=True, plan_index=[C4.RATES.index(C4.cfg(i)[0]) for i in ids])
+            ent = pipes[key] = (pipe, [torch.zeros(pipe.total_in + 64, dtype=torch.int16, device="cuda") for _ in range(4)])
+        pipe, bufs = ent
+        d = bufs[k % 4]
+        d[: pipe.total_in].copy_(torch.from_numpy(pipe.pack(xs)))
+        torch.cuda.synchronize()
+        t = pipe.submit(d)
+        pending.append((k, pipe, t, xs, lens))
+        if len(pending) > 2:          # two batches stay in flight while an earlier one is checked
+            check(*pending.pop(0))
+    for q in pending:
+        check(*q)
+    for pipe, _ in pipes.values():
+        pipe.close()
+    if verbose:
+        print("configs[4] shard shape through the mixed PIPELINE OBJECT (outputs on the device, walk kernels of consecutive batches overlapping): "
+              "the OUTPUT AUDIO of %d of %d streams differs from the ORACLE's (%d batches)" % (bad, total, batches))
+    return bad, total
+
+
 if __name__ != "__main__":
     pass
 elif sys.argv[1] == "audio":
     audio_against_the_oracle(RATE, int(sys.argv[2]))
 elif sys.argv[1] == "mixed":
     mixed_audio_against_the_oracle(int(sys.argv[2]))
+elif sys.argv[1] == "mixedpipe":
+    mixed_pipeline_audio_against_the_oracle(int(sys.argv[2]))
 elif sys.argv[1] == "pipeline":
     pipeline_audio_against_the_oracle(RATE, int(sys.argv[2]))
 elif sys.argv[1] == "oracle":   # [channels match_matlab feedback speed]

@@ -13,4 +13,5 @@ OUT=$PWD/gpurun_out; mkdir -p $OUT
   for r in 16000 22050 11025 44100; do SPX_PROBE_RATE=$r timeout 900 python3 tools/r11_probe.py audio 80 2>&1 | tail -1; done
   for r in 16000 22050; do SPX_PROBE_RATE=$r timeout 900 python3 tools/r11_probe.py pipeline 20 2>&1 | tail -1; done
   timeout 900 python3 tools/r11_probe.py mixed 40 2>&1 | tail -1
+  timeout 900 python3 tools/r11_probe.py mixedpipe 40 2>&1 | tail -1
 } | tee $OUT/${TAG}_final_build_probes.txt
